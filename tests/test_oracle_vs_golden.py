@@ -1,0 +1,175 @@
+"""Pin the CPU oracle (oracle/wc_oracle.py) against outputs of the real reference.
+
+The fixtures under tests/golden/ were produced by tools/make_goldens.py, which
+runs the upstream reference itself.  Indices, segment bounds and call
+coordinates must match exactly; float64 values bit-for-bit unless a BLAS
+reduction order is involved (PCA), where 1e-12 relative is required.
+"""
+import numpy as np
+import pytest
+
+from oracle import wc_oracle as wo
+
+KEYS = [str(c) for c in range(1, 23)] + ["X", "Y"]
+
+
+def same_bits(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if a.shape != b.shape:
+        return False
+    nan = np.isnan(a) & np.isnan(b)      # NaN payload / sign is not part of the contract
+    return bool(np.all(nan | (a.view(np.int64) == b.view(np.int64))))
+
+
+@pytest.mark.parametrize("name", ["plain", "ties", "fewcand", "special", "allsame", "deep"])
+@pytest.mark.parametrize("fast", [False, True])
+def test_get_reference(golden, name, fast):
+    g = golden("newref_kernel.npz")
+    data, bins, k = g[name + "_data"], g[name + "_bins"], int(g[name + "_k"])
+    sums = np.cumsum(bins)
+    for parts in g[name + "_parts"]:
+        for part in range(1, int(parts) + 1):
+            with np.errstate(all="ignore"):
+                idx, dst = wo.get_reference(data, bins, sums, k, part, int(parts), fast=fast)
+            idx = np.asarray(idx).reshape(-1, k)
+            dst = np.asarray(dst, dtype=np.float64).reshape(-1, k)
+            assert np.array_equal(idx, g["%s_idx_%d_%d" % (name, part, parts)])
+            assert same_bits(dst, g["%s_dst_%d_%d" % (name, part, parts)])
+
+
+def test_parts_concatenate_to_whole(golden):
+    g = golden("newref_kernel.npz")
+    for parts in (3, 7):
+        cat = np.concatenate([g["plain_idx_%d_%d" % (p, parts)] for p in range(1, parts + 1)])
+        assert np.array_equal(cat, g["plain_idx_1_1"])
+
+
+def test_pairwise_sum_is_numpy_order():
+    rng = np.random.RandomState(0)
+    for n in list(range(0, 140)) + [255, 256, 257, 600, 1000, 4986]:
+        a = rng.standard_normal(n) * 10.0 ** rng.uniform(-3, 3, n)
+        assert wo.pairwise_sum(a) == np.sum(a), n
+    # the 2-D row reduction used for distances (wisetools.py:302)
+    m = rng.standard_normal((5, 600))
+    assert all(wo.pairwise_sum(m[i]) == np.sum(m, 1)[i] for i in range(5))
+
+
+def test_fill_and_segment(golden):
+    g = golden("segments.npz")
+    for i in range(int(g["n_cases"])):
+        z = g["z_%d" % i]
+        tri = wo.fill_tri(z)
+        assert same_bits(tri, g["tri_%d" % i]), i
+        segs = wo.segment_tri(tri, z.shape[0], float(g["thresholds"][i]), 3)
+        got = np.array([[v, x, y] for v, (x, y) in segs], dtype=np.float64).reshape(-1, 3)
+        want = g["seg_%d" % i]
+        assert np.array_equal(got[:, 1:], want[:, 1:]), i
+        assert same_bits(got[:, 0], want[:, 0]), i
+    tri = wo.fill_tri_min(g["min_z"], g["min_r"], float(g["min_thr"]))
+    assert same_bits(tri, g["min_tri"])
+
+
+def test_scale_sample(golden):
+    g = golden("scale.npz")
+    offs = np.concatenate([[0], np.cumsum(g["lengths"])])
+    sample = {k: g["sample"][offs[i]:offs[i + 1]] for i, k in enumerate(KEYS)}
+    scaled = wo.scale_sample(sample, 50000., 250000)
+    assert [len(scaled[k]) for k in KEYS] == list(g["scaled_lengths"])
+    assert np.array_equal(np.concatenate([scaled[k] for k in KEYS]), g["scaled"])
+    with pytest.raises(ValueError):
+        wo.scale_sample(sample, 50000., 120000)
+
+
+def _split(flat, lengths):
+    offs = np.concatenate([[0], np.cumsum(lengths)])
+    return {k: flat[offs[i]:offs[i + 1]] for i, k in enumerate(KEYS)}
+
+
+def test_cfg1_prep(golden):
+    g = golden("cfg1_pipeline.npz")
+    samples = [_split(row, g["sample_chrom_lengths"]) for row in g["ref_samples"]]
+    masked, bins, mask = wo.to_numpy_array(samples)
+    assert list(bins) == list(g["prep_chromosomeBins"])
+    assert np.array_equal(mask, g["prep_mask"])
+    assert same_bits(masked, g["prep_maskedData"])
+    corrected, comps, mean = wo.train_pca(masked)
+    assert np.allclose(mean, g["prep_pca_mean"], rtol=1e-13, atol=0)
+    assert np.allclose(comps, g["prep_pca_components"], rtol=0, atol=1e-10)
+    assert np.allclose(corrected, g["prep_correctedData"], rtol=1e-11, atol=0)
+
+
+def test_cfg1_newref_from_prep_seam(golden):
+    g = golden("cfg1_pipeline.npz")
+    data = g["prep_correctedData"]
+    bins, sums = g["prep_maskedChromBins"], g["prep_maskedChromBinSums"]
+    # full reference on a slice of parts with the faithful insertion scan, all of it with argsort
+    idx, dst = wo.get_reference(data, bins, sums, 100, 1, 1, fast=True)
+    assert np.array_equal(idx, g["ref_indexes"])
+    assert same_bits(dst, g["ref_distances"])
+    idx, dst = wo.get_reference(data, bins, sums, 100, 5, 40, fast=False)
+    lo, hi = wo.get_part(4, 40, int(sums[-1]))
+    assert np.array_equal(idx, g["ref_indexes"][lo:hi])
+    assert same_bits(dst, g["ref_distances"][lo:hi])
+
+
+def _reference(g):
+    return dict(binsize=g["ref_binsize"], indexes=g["ref_indexes"], distances=g["ref_distances"],
+                chromosome_sizes=g["ref_chromosome_sizes"], mask=g["ref_mask"],
+                masked_sizes=g["ref_masked_sizes"], pca_mean=g["ref_pca_mean"],
+                pca_components=g["ref_pca_components"])
+
+
+def test_cfg1_cutoff(golden):
+    g = golden("cfg1_pipeline.npz")
+    cutoff, _ = wo.get_optimal_cutoff(g["ref_distances"], 3)
+    assert cutoff == float(g["cutoff"])
+
+
+@pytest.mark.parametrize("name", ["mild18", "gain5_gap", "gain5_past", "gain5_after", "loss2", "normal"])
+def test_cfg1_test_sample(golden, name):
+    g = golden("cfg1_pipeline.npz")
+    ref = _reference(g)
+    sample = _split(g["t_%s_sample" % name], g["sample_chrom_lengths"])
+    x = wo.to_numpy_ref_format(sample, ref["chromosome_sizes"], ref["mask"])
+    assert same_bits(x, g["t_%s_x" % name])
+    xp = wo.apply_pca(x, ref["pca_mean"], ref["pca_components"])
+    assert np.allclose(xp, g["t_%s_xpca" % name], rtol=1e-13, atol=0)
+    # z-score repeats from the golden PCA output: bit-exact
+    ms = [int(v) for v in ref["masked_sizes"]]
+    msum = list(np.cumsum(ms))
+    thr = float(g["t_%s_threshold_z" % name])
+    for reps in (1, 2, 5):
+        z, r, n, sd = wo.repeat_test(np.copy(g["t_%s_xpca" % name]), ref["indexes"], ref["distances"],
+                                     ms, msum, float(g["cutoff"]), thr, reps)
+        assert same_bits(z, g["t_%s_rep%d_z" % (name, reps)])
+        assert np.array_equal(n, g["t_%s_rep%d_n" % (name, reps)])
+    assert same_bits(r, g["t_%s_rep5_r" % name])
+    assert sd == float(g["t_%s_rep5_sd" % name])
+    # whole toolTest
+    out = wo.test_sample(sample, float(g["binsize"]), ref)
+    assert out["threshold_z"] == thr
+    want = g["t_%s_results_calls" % name]
+    got = out["results_calls"].reshape(-1, 5)
+    assert np.array_equal(got[:, :3], want[:, :3])
+    assert np.allclose(got[:, 3:], want[:, 3:], rtol=1e-10, atol=0)
+    assert np.allclose(np.concatenate(out["results_z"]), g["t_%s_results_z" % name], rtol=1e-10, atol=1e-12)
+    assert np.allclose(np.concatenate(out["results_r"]), g["t_%s_results_r" % name], rtol=1e-10, atol=1e-12)
+    assert np.allclose(out["results_cwz"], g["t_%s_results_cwz" % name], rtol=1e-10, atol=1e-10)
+    assert np.isclose(out["asdef"], float(g["t_%s_asdef" % name]), rtol=1e-12)
+    assert np.isclose(out["aasdef"], float(g["t_%s_aasdef" % name]), rtol=1e-12)
+
+
+def test_cfg1_test_options(golden):
+    g = golden("cfg1_pipeline.npz")
+    ref = _reference(g)
+    sample = _split(g["t_gain5_gap_sample"], g["sample_chrom_lengths"])
+    out = wo.test_sample(sample, float(g["binsize"]), ref, minzscore=4.0, chromosomes=[2, 5, 18],
+                         minrefbins=40, repeats=2)
+    want = g["opts_results_calls"]
+    got = out["results_calls"].reshape(-1, 5)
+    assert np.array_equal(got[:, :3], want[:, :3])
+    assert np.allclose(got[:, 3:], want[:, 3:], rtol=1e-10)
+    assert np.allclose(out["results_cwz"], g["opts_results_cwz"], rtol=1e-10)
+    assert np.allclose(np.concatenate(out["results_z"]), g["opts_results_z"], rtol=1e-10, atol=1e-12)
+    assert np.isclose(out["asdef"], float(g["opts_asdef"]), rtol=1e-12)

@@ -1,0 +1,304 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING the upstream reference (dev container only).
+
+The reference has no tests or fixtures of its own, so
+parity is pinned on its behaviour: this script imports the reference through
+tools/ref_loader.py (lib2to3 translation in a temp dir + the shims of
+SURVEY.md App. C, PCA forced to the deterministic full-SVD solver), feeds it
+seeded synthetic inputs and stores inputs + outputs as arrays.  Only data is
+written under tests/golden/; no reference source text is.
+
+Run:  python tools/make_goldens.py      (needs /root/reference; ~1 min)
+"""
+import argparse
+import contextlib
+import io
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_loader  # noqa: E402
+from wisecondor_amd import synth  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@contextlib.contextmanager
+def quiet():
+    with contextlib.redirect_stdout(io.StringIO()):
+        yield
+
+
+def obj_array(items):
+    out = np.empty(len(items), dtype=object)
+    for i, v in enumerate(items):
+        out[i] = v
+    return out
+
+
+# ---------------------------------------------------------------- newref ----
+def newref_cases(wt):
+    """Kernel-level getReference goldens (wisetools.py:364-398)."""
+    cases = {}
+    rng = np.random.RandomState(42)
+
+    def run(name, data, bins, k, parts_list):
+        bins = np.asarray(bins, dtype=np.int64)
+        sums = np.cumsum(bins)
+        cases[name + "_data"] = data
+        cases[name + "_bins"] = bins
+        cases[name + "_k"] = np.int64(k)
+        cases[name + "_parts"] = np.array(parts_list, dtype=np.int64)
+        for parts in parts_list:
+            for part in range(1, parts + 1):
+                with quiet(), np.errstate(all="ignore"):
+                    idx, dst = wt.getReference(data, list(bins), list(sums), k, part, parts)
+                idx = np.asarray(idx, dtype=np.int32).reshape(-1, k)
+                dst = np.asarray(dst, dtype=np.float64).reshape(-1, k)
+                cases["%s_idx_%d_%d" % (name, part, parts)] = idx
+                cases["%s_dst_%d_%d" % (name, part, parts)] = dst
+
+    # A: plain tiny genome, several part splits (incl. one that cuts inside chromosomes)
+    bins = rng.randint(10, 41, size=22)
+    data = 1.0 + 0.02 * rng.standard_normal((int(bins.sum()), 12))
+    run("plain", data, bins, 10, [1, 3, 7])
+
+    # B: exact ties -- duplicated rows spread over other chromosomes, 4-way ties
+    data_t = data.copy()
+    sums = np.cumsum(bins)
+    src = 3
+    for chrom in (2, 5, 9, 15):
+        data_t[sums[chrom] - 2] = data_t[src]
+        data_t[sums[chrom] - 5] = data_t[src]
+    data_t[sums[20] - 1] = data_t[sums[0] + 1]
+    run("ties", data_t, bins, 10, [1, 2])
+
+    # C: fewer candidates than k -> -1 / 1e10 padding
+    data_c = 1.0 + 0.05 * rng.standard_normal((12, 6))
+    run("fewcand", data_c, [5, 4, 3], 10, [1])
+
+    # D: NaN row, inf row and a far-away row whose distances exceed 1e10
+    data_d = data.copy()
+    data_d[7, 3] = np.nan
+    data_d[sums[4] + 2, 0] = np.inf
+    data_d[sums[10] + 1, :] = 2.0e5
+    run("special", data_d, bins, 10, [1])
+
+    # E: all rows identical (every distance is exactly 0: pure index order)
+    data_e = np.ones((int(bins.sum()), 5)) * 1.25
+    run("allsame", data_e, bins, 10, [1])
+
+    # F: S = 600-like summation depth (pairwise split > 128) on a small genome
+    bins_f = rng.randint(6, 15, size=22)
+    data_f = 1.0 + 0.02 * rng.standard_normal((int(bins_f.sum()), 300))
+    run("deep", data_f, bins_f, 20, [1])
+    return cases
+
+
+# ------------------------------------------------------------- segments ----
+def segment_cases(wt):
+    """fillTri + TriArr.segmentTri goldens (wisetools.py:466-472, triarray.py:59-84)."""
+    rng = np.random.RandomState(7)
+    vecs = []
+    thr = []
+
+    def add(z, t=3.0):
+        vecs.append(np.asarray(z, dtype=np.float64))
+        thr.append(t)
+
+    add([3, 0, 0, 0, 0, -3.0])                    # |min| == max -> positive wins
+    add([-3, 0, 0, 0, 0, 3.0])
+    add([0, 5, 0, 0, 0, 0, 5, 0.0])              # equal maxima -> lowest linear index
+    add([0, 0, 0, 6, 0, 0, 0, 0, 0, 0, 0, 0.0])  # x = 3: left side not searched
+    add([4, 0, 0, 0, 6, 0, 0, 0, 0, 0, 0, 0.0])  # x = 4: left side searched
+    add([0, 0, 0, 0, 0, 0, 0, 6, 0, 0, 0, 4.0])  # edge 12, y = 7: right searched
+    add([0, 0, 0, 0, 0, 0, 0, 0, 6, 0, 0, 4.0])  # edge 12, y = 8: right not searched
+    add([1.0])
+    add([5.0])
+    add([-7.0, 0.5])
+    add([0.0] * 9)
+    add([1, 2, np.nan, 4, 5, 6, 7, 8, 9, 10.0])  # NaN window is emitted as a call
+    add([0, 0, 0, 0, 0, 9, np.nan, 0, 0, 0, 0, 0, 0, 0.0])
+    add([np.inf, 0, 0, 0, 0, 1, 2, 3.0])
+    for n in (2, 3, 4, 5, 8, 17, 40, 130, 150):
+        z = rng.standard_normal(n)
+        add(z, 2.0)
+        z = rng.standard_normal(n)
+        lo = n // 3
+        z[lo:lo + max(1, n // 4)] += 3.0
+        if n > 20:
+            z[-6:-2] -= 4.0
+        add(z, 3.0)
+    out = {"n_cases": np.int64(len(vecs)), "thresholds": np.array(thr)}
+    for i, (z, t) in enumerate(zip(vecs, thr)):
+        with np.errstate(all="ignore"):
+            tri = wt.fillTri(z)
+            segs = tri.segmentTri(t, 3)
+        out["z_%d" % i] = z
+        out["tri_%d" % i] = np.array(tri.data_array)
+        out["seg_%d" % i] = np.array([[v, x, y] for v, (x, y) in segs], dtype=np.float64).reshape(-1, 3)
+    # fillTriMin with an effect-size threshold (non-default branch, wisetools.py:479-487)
+    z = rng.standard_normal(25)
+    r = 1.0 + 0.05 * rng.standard_normal(25)
+    z[5:12] += 3
+    r[5:12] += 0.08
+    with np.errstate(all="ignore"):
+        tri = wt.fillTriMin(z, r, 0.05)
+    out["min_z"], out["min_r"], out["min_thr"] = z, r, np.float64(0.05)
+    out["min_tri"] = np.array(tri.data_array)
+    return out
+
+
+# ---------------------------------------------------------------- cfg1 -----
+def write_sample(path, sample, binsize):
+    np.savez_compressed(path, arguments={"binsize": float(binsize)}, runtime={},
+                        sample=sample, quality={})
+
+
+def cfg1_cases(wt, wc, n_ref=16, binsize=1000000):
+    """End-to-end newref + test through the reference's own tool drivers."""
+    out = {}
+    profile = synth.bin_profile(binsize)
+    tmp = tempfile.mkdtemp(prefix="wc_gold_")
+    infiles = []
+    ref_samples = []
+    for i in range(n_ref):
+        s = synth.make_sample(profile, seed=i)
+        ref_samples.append(s)
+        p = os.path.join(tmp, "ref_%02d.npz" % i)
+        write_sample(p, s, binsize)
+        infiles.append(p)
+    keys = synth.CHROM_KEYS
+    out["ref_samples"] = np.stack([np.concatenate([s[k] for k in keys]) for s in ref_samples])
+    out["sample_chrom_lengths"] = np.array([len(ref_samples[0][k]) for k in keys], dtype=np.int64)
+    out["binsize"] = np.float64(binsize)
+
+    # prep -> part -> post, separately, so the prep arrays can be captured
+    prep = os.path.join(tmp, "ref_prep.npz")
+    with quiet(), np.errstate(all="ignore"):
+        wc.toolNewrefPrep(argparse.Namespace(infiles=infiles, prepfile=prep, binsize=None))
+        for part in (1, 2, 3):
+            wc.toolNewrefPart(argparse.Namespace(prepfile=prep, partfile=os.path.join(tmp, "ref_part"),
+                                                 part=[part, 3], refsize=100))
+        refpath = os.path.join(tmp, "reference.npz")
+        wc.toolNewrefPost(argparse.Namespace(prepfile=prep, partfile=os.path.join(tmp, "ref_part"),
+                                             parts=3, outfile=refpath))
+    pz = np.load(prep)
+    for k in ("chromosomeBins", "maskedData", "mask", "maskedChromBins", "maskedChromBinSums",
+              "correctedData", "pca_components", "pca_mean"):
+        out["prep_" + k] = np.asarray(pz[k])
+    rz = np.load(refpath)
+    for k in ("indexes", "distances", "chromosome_sizes", "mask", "masked_sizes",
+              "pca_components", "pca_mean"):
+        out["ref_" + k] = np.asarray(rz[k])
+    out["ref_binsize"] = np.float64(rz["binsize"].item())
+    with np.errstate(all="ignore"):
+        cutoff, _ = wt.getOptimalCutoff(rz["distances"], 3)
+    out["cutoff"] = np.float64(cutoff)
+
+    # test samples: see SURVEY.md App. A.5 for the chr5 gap cases
+    events = [
+        ("mild18", [("18", 20, 50, 1.05)]),
+        ("gain5_gap", [("5", 40, 68, 1.5)]),     # survivors end inside the masked gap
+        ("gain5_past", [("5", 40, 69, 1.5)]),
+        ("gain5_after", [("5", 67, 97, 1.5)]),
+        ("loss2", [("2", 100, 140, 0.5), ("11", 10, 14, 1.6)]),
+        ("normal", []),
+    ]
+    names = []
+    for j, (name, ev) in enumerate(events):
+        names.append(name)
+        s = synth.make_sample(profile, seed=999 + j, events=ev)
+        sp = os.path.join(tmp, "test_%s.npz" % name)
+        write_sample(sp, s, binsize)
+        op = os.path.join(tmp, "out_%s.npz" % name)
+        args = argparse.Namespace(infile=sp, outfile=op, reference=refpath, minzscore=None,
+                                  chromosomes=list(range(1, 23)), mineffectsize=0, multitest=1000,
+                                  minrefbins=25, repeats=5)
+        with quiet(), np.errstate(all="ignore"):
+            try:
+                wc.toolTest(args)
+            except SystemExit:
+                pass
+        tz = np.load(op)
+        out["t_%s_sample" % name] = np.concatenate([s[k] for k in keys])
+        out["t_%s_results_z" % name] = np.concatenate(list(tz["results_z"]))
+        out["t_%s_results_r" % name] = np.concatenate(list(tz["results_r"]))
+        out["t_%s_results_cwz" % name] = np.asarray(tz["results_cwz"], dtype=np.float64)
+        out["t_%s_results_calls" % name] = np.asarray(tz["results_calls"], dtype=np.float64).reshape(-1, 5)
+        for k in ("threshold_z", "asdef", "aasdef"):
+            out["t_%s_%s" % (name, k)] = np.float64(tz[k])
+        # function-level intermediates, from the reference's own functions
+        with quiet(), np.errstate(all="ignore"):
+            x = wt.toNumpyRefFormat(s, rz["chromosome_sizes"], rz["mask"])
+            xp = wt.applyPCA(x, rz["pca_mean"], rz["pca_components"])
+            ms = [int(v) for v in rz["masked_sizes"]]
+            msum = [sum(ms[:i + 1]) for i in range(len(ms))]
+            for reps in (1, 2, 5):
+                z, r, n, sd = wt.repeatTest(np.copy(xp), rz["indexes"], rz["distances"], ms, msum,
+                                            cutoff, float(tz["threshold_z"]), reps)
+                out["t_%s_rep%d_z" % (name, reps)] = z
+                out["t_%s_rep%d_n" % (name, reps)] = n
+                if reps == 5:
+                    out["t_%s_rep5_r" % name] = r
+                    out["t_%s_rep5_sd" % name] = np.float64(sd)
+        out["t_%s_x" % name] = x
+        out["t_%s_xpca" % name] = xp
+    out["test_names"] = np.array(names)
+    # -minzscore / -chromosomes / -minrefbins / -repeats variants on one sample
+    s = synth.make_sample(profile, seed=999 + 1, events=events[1][1])
+    sp = os.path.join(tmp, "test_opts.npz")
+    write_sample(sp, s, binsize)
+    op = os.path.join(tmp, "out_opts.npz")
+    args = argparse.Namespace(infile=sp, outfile=op, reference=refpath, minzscore=4.0,
+                              chromosomes=[2, 5, 18], mineffectsize=0, multitest=1000,
+                              minrefbins=40, repeats=2)
+    with quiet(), np.errstate(all="ignore"):
+        try:
+            wc.toolTest(args)
+        except SystemExit:
+            pass
+    tz = np.load(op)
+    out["opts_results_z"] = np.concatenate(list(tz["results_z"]))
+    out["opts_results_cwz"] = np.asarray(tz["results_cwz"], dtype=np.float64)
+    out["opts_results_calls"] = np.asarray(tz["results_calls"], dtype=np.float64).reshape(-1, 5)
+    out["opts_asdef"] = np.float64(tz["asdef"])
+    return out
+
+
+# ------------------------------------------------------------- binsize -----
+def scale_cases(wt):
+    """scaleSample + a 2-sample newrefprep at a merged bin size (wisetools.py:220-264)."""
+    rng = np.random.RandomState(3)
+    sample = {k: rng.poisson(30, size=n).astype(np.int32)
+              for k, n in zip(synth.CHROM_KEYS, rng.randint(7, 30, size=24))}
+    with quiet():
+        scaled = wt.scaleSample(sample, 50000., 250000)
+    out = {"lengths": np.array([len(sample[k]) for k in synth.CHROM_KEYS]),
+           "sample": np.concatenate([sample[k] for k in synth.CHROM_KEYS]),
+           "scaled_lengths": np.array([len(scaled[k]) for k in synth.CHROM_KEYS]),
+           "scaled": np.concatenate([scaled[k] for k in synth.CHROM_KEYS])}
+    return out
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    wt, wc, _tri = ref_loader.load(full_svd=True)
+    save = ref_loader.np.savez_compressed
+    save(os.path.join(GOLD, "newref_kernel.npz"), **newref_cases(wt))
+    save(os.path.join(GOLD, "segments.npz"), **segment_cases(wt))
+    save(os.path.join(GOLD, "scale.npz"), **scale_cases(wt))
+    save(os.path.join(GOLD, "cfg1_pipeline.npz"), **cfg1_cases(wt, wc))
+    for f in sorted(os.listdir(GOLD)):
+        print(f, os.path.getsize(os.path.join(GOLD, f)))
+
+
+if __name__ == "__main__":
+    main()
