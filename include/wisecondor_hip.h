@@ -1,0 +1,185 @@
+/*
+ * wisecondor_hip.h -- C ABI of the MI355X (gfx950) implementation of WISECONDOR's
+ * numeric hot path: `newref` reference-bin selection and the `test` path
+ * (PCA-apply, masked z-score repeats, Stouffer window segmentation).
+ *
+ * The reference (VUmcCGP/wisecondor) is pure Python/numpy and has no FFI of its
+ * own; each entry point below replaces one numpy function of the reference and
+ * cites it as file:line under the upstream tree.  INTEGRATION.md shows the
+ * ctypes stub a maintainer would add to wisetools.py to bind them.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every array is a dense row-major buffer.
+ *   - functions ending in `_dev` take DEVICE pointers and enqueue work on the
+ *     given hipStream_t (passed as void*; NULL = default stream) without
+ *     synchronising; the others take HOST pointers, copy, run and synchronise.
+ *   - return value 0 = success, negative = WC_E_* below; wc_last_error() gives
+ *     a message.  Nothing here falls back to a CPU implementation.
+ *   - IEEE specials propagate as in the reference (np.seterr('ignore'),
+ *     wisetools.py:34): NaN/inf inputs yield NaN/inf outputs, never a trap.
+ */
+#ifndef WISECONDOR_HIP_H
+#define WISECONDOR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WC_OK 0
+#define WC_E_ARG (-1)      /* invalid argument (shape, range, NULL)            */
+#define WC_E_HIP (-2)      /* a HIP runtime call failed                        */
+#define WC_E_LIMIT (-3)    /* size beyond a documented implementation limit    */
+#define WC_E_INTERNAL (-4) /* internal consistency check failed                */
+
+typedef struct wc_ctx wc_ctx; /* per-device context: workspaces, scratch, counters */
+
+/* ---- context -------------------------------------------------------------- */
+wc_ctx *wc_create(int device);
+void wc_destroy(wc_ctx *ctx);
+const char *wc_last_error(void);
+const char *wc_version(void);
+/* counters of the last newref call: [0] rows finished by the fast path,
+ * [1] rows that took the exact fallback path, [2] symmetric tiles launched,
+ * [3] sample columns M, [4] candidates re-scored in float64 (sum over rows)   */
+int wc_newref_stats(wc_ctx *ctx, int64_t out[8]);
+
+/* ---- newref: reference-bin selection -------------------------------------- */
+/* getPart, wisetools.py:358-361: rows [start,end) of zero-based part p of n.  */
+void wc_get_part(int64_t partnum, int64_t outof, int64_t bincount, int64_t *start, int64_t *end);
+
+/*
+ * getReference + getRefForBins, wisetools.py:298-325 and :364-398.
+ * corrected      [n_bins, n_samples] float64 (the prep file's correctedData)
+ * chrom_bins     [n_chrom] bins per chromosome (maskedChromBins); sum == n_bins
+ * k              selectRefAmount (reference default 100)
+ * row_begin/end  target rows to produce (getPart of part, splitParts)
+ * idx_out        [row_end-row_begin, k] int32: positions in the
+ *                "all bins not on the target's chromosome" concatenation
+ *                (wisetools.py:386-387), -1 padded
+ * dist_out       [row_end-row_begin, k] float64 ascending, 1e10 padded
+ * Results equal the reference bit for bit (stable (distance, position) order,
+ * numpy pairwise-summed float64 distances).
+ */
+int wc_get_reference(wc_ctx *ctx, const double *corrected, int64_t n_bins, int64_t n_samples,
+                     const int64_t *chrom_bins, int n_chrom, int k,
+                     int64_t row_begin, int64_t row_end, int32_t *idx_out, double *dist_out);
+int wc_get_reference_dev(wc_ctx *ctx, void *stream, const double *corrected, int64_t n_bins,
+                         int64_t n_samples, const int64_t *chrom_bins_host, int n_chrom, int k,
+                         int64_t row_begin, int64_t row_end, int32_t *idx_out, double *dist_out);
+
+/*
+ * Multi-GPU building blocks of the same computation (one process per GPU; the
+ * host exchanges `thr` / candidate lists with RCCL between the calls).
+ *   stage A  wc_newref_prepare_dev    centre + f32 convert + norms (all rows)
+ *   stage B  wc_newref_thresholds_dev per-row admission thresholds for rows
+ *            [row_begin,row_end) from a fixed pseudo-random column sample
+ *   stage C  wc_newref_collect_dev    symmetric MFMA distance tiles
+ *            `tile_rank` of `tile_ranks` (round-robin), appending candidates
+ *            whose lower-bound distance passes the row threshold
+ *   stage D  wc_newref_finish_dev     float64 re-score in numpy order, stable
+ *            sort, certificate, exact fallback -> idx/dist for the row range
+ * wc_get_reference_dev == A, B(all), C(0 of 1), D(range).
+ */
+int wc_newref_prepare_dev(wc_ctx *ctx, void *stream, const double *corrected, int64_t n_bins,
+                          int64_t n_samples, const int64_t *chrom_bins_host, int n_chrom, int k);
+int wc_newref_thresholds_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end);
+float *wc_newref_threshold_buffer(wc_ctx *ctx);              /* device float[n_bins_padded]       */
+int wc_newref_collect_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end,
+                          int tile_rank, int tile_ranks);
+int32_t *wc_newref_count_buffer(wc_ctx *ctx);                /* device int32[n_bins_padded]       */
+uint64_t *wc_newref_list_buffer(wc_ctx *ctx, int64_t *cap);  /* device u64[n_bins_padded, cap]    */
+int wc_newref_finish_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end,
+                         int32_t *idx_out, double *dist_out);
+
+/* ---- test: per-reference state -------------------------------------------- */
+typedef struct wc_reference wc_reference;
+
+/*
+ * Everything toolTest derives from the reference file alone
+ * (wisecondor.py:177-201): uploads indexes/distances/PCA, computes
+ * getOptimalCutoff(distances, cutoff_repeats) (wisetools.py:328-336) on the
+ * GPU and the per-bin reference lists `index[i][distances[i] < cutoff]`
+ * (wisetools.py:424) once, since they are sample independent.
+ *   indexes [n_bins,k] int32, distances [n_bins,k] float64,
+ *   chromosome_sizes/masked_sizes [n_chrom] int64, mask [sum(chromosome_sizes)] uint8,
+ *   pca_mean [n_bins], pca_components [n_comp, n_bins] float64.
+ */
+wc_reference *wc_reference_create(wc_ctx *ctx, const int32_t *indexes, const double *distances,
+                                  int64_t n_bins, int k, const int64_t *chromosome_sizes,
+                                  const int64_t *masked_sizes, int n_chrom, const uint8_t *mask,
+                                  const double *pca_mean, const double *pca_components, int n_comp,
+                                  int cutoff_repeats);
+void wc_reference_destroy(wc_reference *ref);
+double wc_reference_cutoff(const wc_reference *ref);
+
+/* getOptimalCutoff alone, wisetools.py:328-336 (host pointers). */
+int wc_optimal_cutoff(wc_ctx *ctx, const double *distances, int64_t count, int repeats, double *cutoff);
+
+/*
+ * toNumpyRefFormat + applyPCA, wisetools.py:267-278 and :104-113, for a batch.
+ * counts [n_samples, sum(chromosome_sizes)] int32: per chromosome already
+ * padded/truncated to the reference length (host marshalling of the dict).
+ * out    [n_samples, n_bins] float64 (PCA-corrected, masked, unit-sum).
+ * raw    optional [n_samples, n_bins] float64: the vector before PCA.
+ */
+int wc_prepare_samples(wc_ctx *ctx, const wc_reference *ref, const int32_t *counts,
+                       int64_t n_samples, double *out, double *raw);
+
+/*
+ * repeatTest/trySample, wisetools.py:407-448, for a batch of samples.
+ * data [n_samples, n_bins] float64 -> z, r, ref_sizes [n_samples, n_bins]
+ * float64 and sd_avg [n_samples] (stdDevAvg).  Means and standard deviations
+ * are summed in numpy's pairwise order.
+ */
+int wc_repeat_test(wc_ctx *ctx, const wc_reference *ref, const double *data, int64_t n_samples,
+                   double threshold, int repeats, double *z, double *r, double *ref_sizes,
+                   double *sd_avg);
+
+/*
+ * fillTri (wisetools.py:466-472) + TriArr.segmentTri (triarray.py:59-84) on a
+ * batch of independent regions without materialising the triangle.
+ * z [total] float64: concatenated regions; region_offsets [n_regions+1].
+ * Outputs per region: whole-region Stouffer z (getValue(0,n-1),
+ * wisecondor.py:237) and up to max_calls segments (value, x, y inclusive) in
+ * ascending position order; n_calls[region] holds the number found (if it
+ * exceeds max_calls the call fails with WC_E_LIMIT).
+ */
+int wc_stouffer_segments(wc_ctx *ctx, const double *z, const int64_t *region_offsets,
+                         int64_t n_regions, double threshold, int min_search, int max_calls,
+                         double *region_z, int32_t *n_calls, double *call_value, int32_t *call_x,
+                         int32_t *call_y);
+
+/*
+ * The numeric content of toolTest (wisecondor.py:199-268) for a batch:
+ * prepare -> repeatTest -> minrefbins cleaning -> Stouffer segmentation ->
+ * call coordinate mapping and median effect -> inflated per-bin outputs.
+ *   counts        [n_samples, n_total_bins] int32 (see wc_prepare_samples)
+ *   chromosomes   [n_sel] 1-based chromosome numbers to segment (-chromosomes)
+ *   results_z/r   [n_samples, n_total_bins] float64 (r is ratio-1), zeros at
+ *                 masked / removed bins
+ *   results_cwz   [n_samples, n_sel]
+ *   calls         [n_samples, max_calls, 5] rows [chrom, start, end, z, effect]
+ *   n_calls       [n_samples]
+ *   asdef         [n_samples]
+ * mineffectsize must be 0 (the reference default); the median-filtered
+ * triangle of wisetools.py:479-487 is not implemented on the GPU yet.
+ */
+int wc_test_batch(wc_ctx *ctx, const wc_reference *ref, const int32_t *counts, int64_t n_samples,
+                  double threshold, int min_ref_bins, int repeats, const int32_t *chromosomes,
+                  int n_sel, int max_calls, double *results_z, double *results_r,
+                  double *results_cwz, double *calls, int32_t *n_calls, double *asdef);
+
+/* Device-resident variant used by bench.py: counts already on the GPU, outputs
+ * stay on the GPU (any output pointer may be NULL to skip it).                */
+int wc_test_batch_dev(wc_ctx *ctx, void *stream, const wc_reference *ref, const int32_t *counts,
+                      int64_t n_samples, double threshold, int min_ref_bins, int repeats,
+                      const int32_t *chromosomes_host, int n_sel, int max_calls,
+                      double *results_z, double *results_r, double *results_cwz, double *calls,
+                      int32_t *n_calls, double *asdef);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WISECONDOR_HIP_H */

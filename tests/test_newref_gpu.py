@@ -1,0 +1,95 @@
+"""GPU parity of the HIP newref path (through the C ABI) against the golden
+fixtures and the CPU oracle.  Indices must be identical, distances bit-equal."""
+import numpy as np
+import pytest
+
+from oracle import wc_oracle as wo
+
+pytestmark = pytest.mark.gpu
+
+
+def same_bits(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if a.shape != b.shape:
+        return False
+    nan = np.isnan(a) & np.isnan(b)
+    return bool(np.all(nan | (a.view(np.int64) == b.view(np.int64))))
+
+
+@pytest.fixture(scope="module")
+def wt():
+    from wisecondor_amd import wisetools
+    return wisetools
+
+
+@pytest.mark.parametrize("name", ["plain", "ties", "fewcand", "special", "allsame", "deep"])
+def test_golden_kernel_cases(golden, wt, name):
+    g = golden("newref_kernel.npz")
+    data, bins, k = g[name + "_data"], g[name + "_bins"], int(g[name + "_k"])
+    sums = np.cumsum(bins)
+    for parts in g[name + "_parts"]:
+        for part in range(1, int(parts) + 1):
+            idx, dst = wt.getReference(data, bins, sums, k, part, int(parts))
+            assert np.array_equal(idx, g["%s_idx_%d_%d" % (name, part, parts)]), (name, part, parts)
+            assert same_bits(dst, g["%s_dst_%d_%d" % (name, part, parts)]), (name, part, parts)
+
+
+def test_golden_cfg1_prep_seam(golden, wt):
+    g = golden("cfg1_pipeline.npz")
+    data = g["prep_correctedData"]
+    bins, sums = g["prep_maskedChromBins"], g["prep_maskedChromBinSums"]
+    idx, dst = wt.getReference(data, bins, sums, 100, 1, 1)
+    assert np.array_equal(idx, g["ref_indexes"])
+    assert same_bits(dst, g["ref_distances"])
+    st = wt.newref_stats()
+    assert st["fast_rows"] + st["fallback_rows"] == data.shape[0]
+    assert st["fallback_rows"] < data.shape[0] // 10, st
+    cat_i, cat_d = [], []
+    for part in range(1, 6):
+        i, d = wt.getReference(data, bins, sums, 100, part, 5)
+        cat_i.append(i)
+        cat_d.append(d)
+    assert np.array_equal(np.concatenate(cat_i), g["ref_indexes"])
+    assert same_bits(np.concatenate(cat_d), g["ref_distances"])
+
+
+@pytest.mark.parametrize("n_samples,binsize,k", [(16, 1000000, 100), (100, 1000000, 50), (257, 2000000, 100)])
+def test_oracle_synthetic(wt, n_samples, binsize, k):
+    from wisecondor_amd import synth
+    data, bins, sums = synth.corrected_matrix(binsize, n_samples, seed=3)
+    idx, dst = wt.getReference(data, bins, sums, k, 1, 1)
+    st = wt.newref_stats()
+    want_i, want_d = wo.get_reference(data, bins, sums, k, 1, 1, fast=True)
+    assert np.array_equal(idx, want_i)
+    assert same_bits(dst, want_d)
+    assert st["fallback_rows"] <= data.shape[0] // 20, st
+
+
+def test_oracle_hard_ties_and_outliers(wt):
+    """Duplicated rows (exact ties across chromosomes), an outlier bin and a NaN bin."""
+    from wisecondor_amd import synth
+    data, bins, sums = synth.corrected_matrix(2000000, 24, seed=5)
+    rng = np.random.RandomState(1)
+    src = rng.randint(0, data.shape[0], size=40)
+    dstrows = rng.randint(0, data.shape[0], size=40)
+    data[dstrows] = data[src]
+    data[17] *= 40.0
+    data[333, 2] = np.nan
+    idx, dst = wt.getReference(data, bins, sums, 30, 1, 1)
+    with np.errstate(all="ignore"):
+        want_i, want_d = wo.get_reference(data, bins, sums, 30, 1, 1, fast=True)
+    assert np.array_equal(idx, want_i)
+    assert same_bits(dst, want_d)
+
+
+def test_large_slice_against_oracle(wt):
+    """cfg2 shape (100 samples x 250 kb): a row slice checked against the oracle."""
+    from wisecondor_amd import synth
+    data, bins, sums = synth.corrected_matrix(250000, 100, seed=0)
+    parts = 64
+    part = 23
+    idx, dst = wt.getReference(data, bins, sums, 100, part, parts)
+    want_i, want_d = wo.get_reference(data, bins, sums, 100, part, parts, fast=True)
+    assert np.array_equal(idx, want_i)
+    assert same_bits(dst, want_d)

@@ -1,0 +1,99 @@
+"""ctypes binding of libwisecondor_hip.so (the C ABI in include/wisecondor_hip.h).
+
+There is deliberately no CPU fallback: if the HIP library is missing or no GPU
+is visible, every numeric entry point of this package raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libwisecondor_hip.so")
+
+_c = ctypes
+_i64 = _c.c_int64
+_i32 = _c.c_int
+_dbl = _c.c_double
+_vp = _c.c_void_p
+
+#: every symbol include/wisecondor_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "wc_create": (_vp, [_i32]),
+    "wc_destroy": (None, [_vp]),
+    "wc_last_error": (_c.c_char_p, []),
+    "wc_version": (_c.c_char_p, []),
+    "wc_newref_stats": (_i32, [_vp, _vp]),
+    "wc_get_part": (None, [_i64, _i64, _i64, _vp, _vp]),
+    "wc_get_reference": (_i32, [_vp, _vp, _i64, _i64, _vp, _i32, _i32, _i64, _i64, _vp, _vp]),
+    "wc_get_reference_dev": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i32, _i32, _i64, _i64, _vp, _vp]),
+    "wc_newref_prepare_dev": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i32, _i32]),
+    "wc_newref_thresholds_dev": (_i32, [_vp, _vp, _i64, _i64]),
+    "wc_newref_threshold_buffer": (_vp, [_vp]),
+    "wc_newref_collect_dev": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32]),
+    "wc_newref_count_buffer": (_vp, [_vp]),
+    "wc_newref_list_buffer": (_vp, [_vp, _vp]),
+    "wc_newref_finish_dev": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "wc_reference_create": (_vp, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32]),
+    "wc_reference_destroy": (None, [_vp]),
+    "wc_reference_cutoff": (_dbl, [_vp]),
+    "wc_optimal_cutoff": (_i32, [_vp, _vp, _i64, _i32, _vp]),
+    "wc_prepare_samples": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "wc_repeat_test": (_i32, [_vp, _vp, _vp, _i64, _dbl, _i32, _vp, _vp, _vp, _vp]),
+    "wc_stouffer_segments": (_i32, [_vp, _vp, _vp, _i64, _dbl, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "wc_test_batch": (_i32, [_vp, _vp, _vp, _i64, _dbl, _i32, _i32, _vp, _i32, _i32,
+                             _vp, _vp, _vp, _vp, _vp, _vp]),
+    "wc_test_batch_dev": (_i32, [_vp, _vp, _vp, _vp, _i64, _dbl, _i32, _i32, _vp, _i32, _i32,
+                                 _vp, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class WisecondorHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library and attach prototypes; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise WisecondorHipError(
+            "%s is missing: build it with `python -m wisecondor_amd.build` "
+            "(this package has no CPU fallback)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise WisecondorHipError("wisecondor_hip error %d: %s" % (rc, load().wc_last_error().decode()))
+
+
+def ptr(arr):
+    """Host pointer of a C-contiguous numpy array (or None)."""
+    if arr is None:
+        return None
+    assert isinstance(arr, np.ndarray) and arr.flags["C_CONTIGUOUS"]
+    return arr.ctypes.data_as(_vp)
+
+
+_contexts = {}
+
+
+def context(device=0):
+    """One wc_ctx per device, created lazily; fails loudly without a GPU."""
+    if device not in _contexts:
+        lib = load()
+        h = lib.wc_create(device)
+        if not h:
+            raise WisecondorHipError("wc_create(%d) failed: %s" % (device, lib.wc_last_error().decode()))
+        _contexts[device] = h
+    return _contexts[device]

@@ -1,0 +1,180 @@
+// Shared helpers for the gfx950 WISECONDOR kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <float.h>
+#include <string>
+#include <vector>
+
+#include "../../include/wisecondor_hip.h"
+
+namespace wc {
+
+void set_error(const char *fmt, ...);
+
+#define WC_HIP(call)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            wc::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                          __LINE__);                                                       \
+            return WC_E_HIP;                                                               \
+        }                                                                                  \
+    } while (0)
+
+#define WC_CHECK(cond, code, ...)      \
+    do {                               \
+        if (!(cond)) {                 \
+            wc::set_error(__VA_ARGS__); \
+            return code;               \
+        }                              \
+    } while (0)
+
+// A grow-only device buffer; contexts keep these so repeated calls do not
+// hipMalloc/hipFree (sized for 288 GB HBM: never shrinks, never spills).
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t want) {
+        if (want <= bytes) return WC_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        size_t ask = want + (want >> 3) + 256;
+        hipError_t e = hipMalloc(&p, ask);
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%zu) failed: %s", ask, hipGetErrorString(e));
+            return WC_E_HIP;
+        }
+        bytes = ask;
+        return WC_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// ---- order-preserving integer images of floats ---------------------------------
+// NaN maps to the largest image so that it never wins a "smallest" selection.
+__host__ __device__ inline uint32_t f32_ordered(float f) {
+    if (f != f) return 0xFFFFFFFFu;
+    uint32_t b;
+    memcpy(&b, &f, 4);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__host__ __device__ inline float f32_from_ordered(uint32_t u) {
+    uint32_t b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+}
+__host__ __device__ inline uint64_t f64_ordered(double d) {
+    if (d != d) return ~0ull;
+    uint64_t b;
+    memcpy(&b, &d, 8);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+__host__ __device__ inline double f64_from_ordered(uint64_t u) {
+    uint64_t b = (u & 0x8000000000000000ull) ? (u & 0x7FFFFFFFFFFFFFFFull) : ~u;
+    double d;
+    memcpy(&d, &b, 8);
+    return d;
+}
+
+// ---- numpy pairwise summation ---------------------------------------------------
+// numpy's add.reduce over a contiguous float64 run of n elements
+// (loops_utils.h.src pairwise_sum): n < 8 sequential from 0; n <= 128 eight strided
+// accumulators combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) then the n%8 tail
+// sequentially; larger n split at (n/2 - (n/2)%8) recursively.  The device code
+// walks that tree with an explicit stack (no recursion) and evaluates each leaf
+// either in one thread or across an aligned group of 8 lanes (lane j owns the
+// elements congruent to j mod 8, which is exactly numpy's accumulator r[j]).
+#define WC_PW_BLOCK 128
+#define WC_PW_DEPTH 24
+
+// Leaf evaluated by ONE thread; f(i) returns element i.
+template <class F> __device__ inline double pw_leaf_serial(F f, int64_t off, int n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res = res + f(off + i);
+        return res;
+    }
+    double r0 = f(off + 0), r1 = f(off + 1), r2 = f(off + 2), r3 = f(off + 3);
+    double r4 = f(off + 4), r5 = f(off + 5), r6 = f(off + 6), r7 = f(off + 7);
+    int body = n - (n % 8);
+    for (int i = 8; i < body; i += 8) {
+        r0 = r0 + f(off + i + 0);
+        r1 = r1 + f(off + i + 1);
+        r2 = r2 + f(off + i + 2);
+        r3 = r3 + f(off + i + 3);
+        r4 = r4 + f(off + i + 4);
+        r5 = r5 + f(off + i + 5);
+        r6 = r6 + f(off + i + 6);
+        r7 = r7 + f(off + i + 7);
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (int i = body; i < n; ++i) res = res + f(off + i);
+    return res;
+}
+
+// Leaf evaluated by an aligned group of 8 lanes (sub = lane & 7); every lane of the
+// group returns the same value.  All 64 lanes of the wave must call this together.
+template <class F> __device__ inline double pw_leaf_group8(F f, int64_t off, int n, int sub) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res = res + f(off + i);
+        return res;
+    }
+    int body = n - (n % 8);
+    double r = f(off + sub);
+    for (int i = 8; i < body; i += 8) r = r + f(off + i + sub);
+    // (r0+r1), (r2+r3), ... : fp addition is commutative, so the xor butterfly
+    // yields numpy's tree in every lane.
+    r = r + __shfl_xor(r, 1);
+    r = r + __shfl_xor(r, 2);
+    r = r + __shfl_xor(r, 4);
+    for (int i = body; i < n; ++i) r = r + f(off + i);
+    return r;
+}
+
+template <bool GROUP8, class F> __device__ inline double pairwise_sum(F f, int64_t n, int sub) {
+    if (n <= WC_PW_BLOCK)
+        return GROUP8 ? pw_leaf_group8(f, 0, (int)n, sub) : pw_leaf_serial(f, 0, (int)n);
+    int64_t s_off[WC_PW_DEPTH], s_n[WC_PW_DEPTH];
+    double s_left[WC_PW_DEPTH];
+    int s_phase[WC_PW_DEPTH];
+    int sp = 0;
+    s_off[0] = 0; s_n[0] = n; s_phase[0] = 0; s_left[0] = 0.0; sp = 1;
+    double result = 0.0;
+    while (sp > 0) {
+        int t = sp - 1;
+        int64_t nn = s_n[t], off = s_off[t];
+        if (nn <= WC_PW_BLOCK) {
+            result = GROUP8 ? pw_leaf_group8(f, off, (int)nn, sub) : pw_leaf_serial(f, off, (int)nn);
+            sp--;
+        } else {
+            int64_t n2 = nn / 2;
+            n2 -= n2 % 8;
+            if (s_phase[t] == 0) {
+                s_phase[t] = 1;
+                s_off[sp] = off; s_n[sp] = n2; s_phase[sp] = 0; sp++;
+            } else if (s_phase[t] == 1) {
+                s_left[t] = result;
+                s_phase[t] = 2;
+                s_off[sp] = off + n2; s_n[sp] = nn - n2; s_phase[sp] = 0; sp++;
+            } else {
+                result = s_left[t] + result;
+                sp--;
+            }
+        }
+    }
+    return result;
+}
+
+}  // namespace wc

@@ -1,0 +1,42 @@
+// Per-device context: cached workspaces for the newref and test paths.
+#pragma once
+#include "common.h"
+
+#define WC_MAX_CHROM 64
+
+struct NewrefState {
+    // problem
+    int64_t n_bins = 0, n_samples = 0;
+    int64_t bins_pad = 0;   // rows padded to the 128-row tile
+    int64_t k_pad = 0;      // samples padded to the 32-wide k-slab
+    int n_chrom = 0, k = 0;
+    int64_t chrom_off[WC_MAX_CHROM + 1] = {0};
+    const double *corrected = nullptr;  // device, caller owned
+    // tuning
+    int64_t n_sample_cols = 0;      // M, multiple of 128
+    int64_t cap = 0;                // candidate-list capacity per row
+    int64_t expect = 0;             // expected candidates per row under the sampled threshold
+    float beta = 0.f;               // relative half-width of the key error interval
+    bool prepared = false;
+    // device buffers
+    wc::DevBuf col_partial, col_mean, a32, norm_lo, norm_hi, chrom_of_row, chrom_off_dev;
+    wc::DevBuf sample_rows, s32, s_norm_lo, s_chrom;
+    wc::DevBuf keys1, thr, cnt, list, tiles;
+    wc::DevBuf fb_rows, fb_count, fb_scratch, stats;
+};
+
+struct wc_ctx {
+    int device = 0;
+    NewrefState nr;
+    wc::DevBuf tmp_a, tmp_b, tmp_c, tmp_d;  // host-pointer API staging
+    void *pinned = nullptr;
+    size_t pinned_bytes = 0;
+    int64_t last_stats[8] = {0};
+
+    std::vector<wc::DevBuf *> all_buffers() {
+        return {&nr.col_partial, &nr.col_mean, &nr.a32, &nr.norm_lo, &nr.norm_hi, &nr.chrom_of_row,
+                &nr.chrom_off_dev, &nr.sample_rows, &nr.s32, &nr.s_norm_lo, &nr.s_chrom, &nr.keys1,
+                &nr.thr, &nr.cnt, &nr.list, &nr.tiles, &nr.fb_rows, &nr.fb_count, &nr.fb_scratch,
+                &nr.stats, &tmp_a, &tmp_b, &tmp_c, &tmp_d};
+    }
+};

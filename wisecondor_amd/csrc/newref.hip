@@ -1,0 +1,957 @@
+// newref: reference-bin selection on gfx950.
+//
+// Replaces getReference/getRefForBins (wisetools.py:298-325, 364-398): for every
+// target bin, squared-L2 distance across the sample axis to every bin on another
+// chromosome, keep the k nearest in stable (distance, position) order.
+//
+// Pipeline (DESIGN.md section "newref"):
+//   prepare     robust per-sample centre, float64 -> float32, row norms with a
+//               rigorous error interval
+//   thresholds  fp32-MFMA Gram tiles of all rows x M pseudo-random sample rows ->
+//               per-row admission threshold from an order statistic
+//   collect     symmetric fp32-MFMA Gram tiles over the cross-chromosome triangle;
+//               epilogue turns dot products into LOWER BOUNDS of the true
+//               distance and appends the few that pass the row threshold
+//   finish      per row: sort candidates, keep those whose lower bound does not
+//               exceed the k-th upper bound, re-score them in float64 in numpy's
+//               pairwise order, stable sort, emit; rows whose certificate fails
+//               take an exact brute-force path on the GPU
+#include "ctx.h"
+
+#include <algorithm>
+
+namespace {
+
+constexpr int TB = 128;        // tile edge (rows and cols)
+constexpr int BK = 32;         // k-slab depth
+constexpr int LDA = 36;        // LDS row stride of a staged slab, floats (144 B keeps b128 reads conflict free)
+constexpr int LDD = 129;       // LDS row stride of the dot-product tile
+constexpr int ROLE_ROWS = 1;   // targets are the tile's rows (P side)
+constexpr int ROLE_COLS = 2;   // targets are the tile's columns (Q side)
+constexpr int MAX_SAMPLE_COLS = 4096;
+constexpr int LIST_CAP = 1024;
+constexpr int FB_BLOCKS = 512;
+#define WC_ADMIT_ALL FLT_MAX
+constexpr double SENTINEL_DISTANCE = 1e10;  // wisetools.py:306
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------ prepare ----
+// Column statistics over finite values; optional window |v - centre| <= radius.
+// mode 0: sum(v), count   mode 1: sum(|v - centre|), count
+__global__ void k_col_partial(const double *__restrict__ X, int64_t B, int64_t S, int R, int mode,
+                              const double *__restrict__ centre, const double *__restrict__ radius,
+                              double *__restrict__ psum, double *__restrict__ pcnt) {
+    __shared__ double sh_s[4][64];
+    __shared__ double sh_c[4][64];
+    int64_t s = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    int64_t per = (B + R - 1) / R;
+    int64_t r0 = (int64_t)blockIdx.y * per;
+    int64_t r1 = r0 + per < B ? r0 + per : B;
+    double sum = 0.0, cnt = 0.0;
+    if (s < S) {
+        double c = centre ? centre[s] : 0.0;
+        double rad = radius ? radius[s] : 0.0;
+        for (int64_t r = r0 + threadIdx.y; r < r1; r += 4) {
+            double v = X[r * S + s];
+            if (!isfinite(v)) continue;
+            if (radius && !(fabs(v - c) <= rad)) continue;
+            sum += (mode == 1) ? fabs(v - c) : v;
+            cnt += 1.0;
+        }
+    }
+    sh_s[threadIdx.y][threadIdx.x] = sum;
+    sh_c[threadIdx.y][threadIdx.x] = cnt;
+    __syncthreads();
+    if (threadIdx.y == 0 && s < S) {
+        double a = (sh_s[0][threadIdx.x] + sh_s[1][threadIdx.x]) + (sh_s[2][threadIdx.x] + sh_s[3][threadIdx.x]);
+        double b = (sh_c[0][threadIdx.x] + sh_c[1][threadIdx.x]) + (sh_c[2][threadIdx.x] + sh_c[3][threadIdx.x]);
+        psum[(int64_t)blockIdx.y * S + s] = a;
+        pcnt[(int64_t)blockIdx.y * S + s] = b;
+    }
+}
+
+// out[s] = scale * sum/count (0 when nothing was counted)
+__global__ void k_col_finish(const double *__restrict__ psum, const double *__restrict__ pcnt, int R,
+                             int64_t S, double scale, double *__restrict__ out) {
+    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    double a = 0.0, b = 0.0;
+    for (int r = 0; r < R; ++r) {
+        a += psum[(int64_t)r * S + s];
+        b += pcnt[(int64_t)r * S + s];
+    }
+    out[s] = b > 0.0 ? scale * (a / b) : 0.0;
+}
+
+// One wave per row: centred float32 image, norm interval, chromosome id.
+__global__ __launch_bounds__(256) void k_convert(const double *__restrict__ X, int64_t B, int64_t S,
+                                                 int64_t Bpad, int64_t Kpad,
+                                                 const double *__restrict__ mean, double beta,
+                                                 const int64_t *__restrict__ chrom_off, int n_chrom,
+                                                 float *__restrict__ A, float *__restrict__ norm_lo,
+                                                 float *__restrict__ norm_hi, int *__restrict__ chrom_of_row) {
+    int lane = threadIdx.x & 63;
+    int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= Bpad) return;
+    double acc = 0.0;
+    for (int64_t s = lane; s < Kpad; s += 64) {
+        float a = 0.f;
+        if (row < B && s < S) a = (float)(X[row * S + s] - mean[s]);
+        A[row * Kpad + s] = a;
+        acc += (double)a * (double)a;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) {
+        float lo = INFINITY, hi = INFINITY;
+        int ch = -1;
+        if (row < B) {
+            if (isfinite(acc) && acc < 1e37) {
+                // key = lo_i + lo_j - 2 dot must never exceed the true distance
+                lo = __double2float_rd(acc * (1.0 - beta) - 1e-37);
+                hi = __double2float_ru(acc * (1.0 + 1e-9));
+            }
+            int c = 0;
+            while (c + 1 < n_chrom && row >= chrom_off[c + 1]) ++c;
+            ch = c;
+        }
+        norm_lo[row] = lo;
+        norm_hi[row] = hi;
+        chrom_of_row[row] = ch;
+    }
+}
+
+__global__ void k_gather_samples(const float *__restrict__ A, int64_t Kpad, const float *__restrict__ norm_lo,
+                                 const int *__restrict__ chrom_of_row, const int *__restrict__ sample_rows,
+                                 int64_t M, int64_t Mpad, float *__restrict__ S32, float *__restrict__ s_norm_lo,
+                                 int *__restrict__ s_chrom) {
+    int64_t m = blockIdx.x;
+    bool real = m < M;
+    int64_t src = real ? sample_rows[m] : 0;
+    for (int64_t s = threadIdx.x; s < Kpad; s += blockDim.x) S32[m * Kpad + s] = real ? A[src * Kpad + s] : 0.f;
+    if (threadIdx.x == 0) {
+        s_norm_lo[m] = real ? norm_lo[src] : INFINITY;
+        s_chrom[m] = real ? chrom_of_row[src] : -2;
+    }
+}
+
+__global__ void k_fill_f32(float *p, int64_t n, float v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// --------------------------------------------------------------- Gram tiles ----
+struct GramArgs {
+    const float *P, *Q;          // [rows, ld] float32, rows padded to 128
+    int64_t ld;                  // padded sample count
+    int nslab;                   // ld / 32
+    const float *nbP, *nbQ;      // lower norm bounds
+    const int *chP, *chQ;        // chromosome ids
+    const int4 *tiles;           // {I, J, roles, 0}
+    int ntiles;
+    float *keys;                 // MODE 0: [rowsP, ldo]
+    int64_t ldo;
+    const float *thr;            // MODE 1: per target row
+    int *cnt;
+    unsigned long long *list;
+    int cap;
+};
+
+__device__ inline unsigned long long pack_entry(float key, int j) {
+    return ((unsigned long long)wc::f32_ordered(key) << 32) | (unsigned int)j;
+}
+
+// 128x128 output tile per 256-thread workgroup; each wave owns 64x64 as 2x2
+// v_mfma_f32_32x32x2_f32 accumulators.  A/B slabs are staged global->regs->LDS
+// with the next slab's loads in flight during the MFMA phase.  Within a slab
+// lane (i, h) feeds k = 16h + t at MFMA step t, so each lane fetches its 16
+// operands with four conflict-free ds_read_b128.
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_gram(GramArgs g) {
+    __shared__ __attribute__((aligned(16))) float sm[TB * LDD + 6 * TB];
+    float *As = sm;
+    float *Bs = sm + TB * LDA;
+    float *D = sm;
+    float *nbPs = sm + TB * LDD;
+    float *nbQs = nbPs + TB;
+    float *thPs = nbQs + TB;
+    float *thQs = thPs + TB;
+    int *chPs = (int *)(thQs + TB);
+    int *chQs = chPs + TB;
+
+    // XCD-aware order: workgroup b runs on XCD b%8; give each XCD a contiguous run
+    // of the (I-major) tile list so co-resident tiles share operand panels in its L2.
+    const int chunk = (g.ntiles + 7) >> 3;
+    const int t_id = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (t_id >= g.ntiles) return;
+    const int4 tile = g.tiles[t_id];
+    const int I = tile.x, J = tile.y, roles = tile.z;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    if (tid < TB) {
+        int64_t gp = (int64_t)I * TB + tid;
+        nbPs[tid] = g.nbP[gp];
+        chPs[tid] = g.chP[gp];
+        thPs[tid] = (MODE == 1) ? g.thr[gp] : 0.f;
+    } else {
+        int c = tid - TB;
+        int64_t gq = (int64_t)J * TB + c;
+        nbQs[c] = g.nbQ[gq];
+        chQs[c] = g.chQ[gq];
+        thQs[c] = (MODE == 1) ? g.thr[gq] : 0.f;
+    }
+
+    const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+    const float *Pg = g.P + ((int64_t)I * TB + lrow) * g.ld + lcol;
+    const float *Qg = g.Q + ((int64_t)J * TB + lrow) * g.ld + lcol;
+    f32x4 pa[4], qb[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        pa[p] = *(const f32x4 *)(Pg + (int64_t)p * 32 * g.ld);
+        qb[p] = *(const f32x4 *)(Qg + (int64_t)p * 32 * g.ld);
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    for (int slab = 0; slab < g.nslab; ++slab) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            *(f32x4 *)&As[(lrow + 32 * p) * LDA + lcol] = pa[p];
+            *(f32x4 *)&Bs[(lrow + 32 * p) * LDA + lcol] = qb[p];
+        }
+        __syncthreads();
+        {   // next slab's loads fly during the MFMA phase (last iteration re-reads its own slab)
+            const int64_t ko = (int64_t)(slab + 1 < g.nslab ? slab + 1 : slab) * BK;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                pa[p] = *(const f32x4 *)(Pg + ko + (int64_t)p * 32 * g.ld);
+                qb[p] = *(const f32x4 *)(Qg + ko + (int64_t)p * 32 * g.ld);
+            }
+        }
+        float af[2][16], bf[2][16];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 va = *(const f32x4 *)&As[(wr * 64 + m * 32 + li) * LDA + lh * 16 + q * 4];
+                f32x4 vb = *(const f32x4 *)&Bs[(wc * 64 + m * 32 + li) * LDA + lh * 16 + q * 4];
+                af[m][q * 4 + 0] = va.x; af[m][q * 4 + 1] = va.y; af[m][q * 4 + 2] = va.z; af[m][q * 4 + 3] = va.w;
+                bf[m][q * 4 + 0] = vb.x; bf[m][q * 4 + 1] = vb.y; bf[m][q * 4 + 2] = vb.z; bf[m][q * 4 + 3] = vb.w;
+            }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][t], bf[0][t], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][t], bf[1][t], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][t], bf[0][t], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][t], bf[1][t], acc[1][1], 0, 0, 0);
+        }
+    }
+
+    // dot products -> LDS tile (aliases the staging buffers)
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                int col = wc * 64 + n * 32 + li;
+                D[row * LDD + col] = acc[m][n][r];
+            }
+    __syncthreads();
+
+    const int x = tid & 127, half = tid >> 7;
+    if (MODE == 0) {
+        // dense lower-bound keys, same-chromosome pairs masked to +inf
+        const float nbc = nbQs[x];
+        const int chc = chQs[x];
+        float *out = g.keys + ((int64_t)I * TB + half * 64) * g.ldo + (int64_t)J * TB + x;
+        for (int rr = 0; rr < 64; ++rr) {
+            int r = half * 64 + rr;
+            float key = fmaf(-2.f, D[r * LDD + x], nbPs[r] + nbc);
+            if (chPs[r] == chc) key = INFINITY;
+            out[(int64_t)rr * g.ldo] = key;
+        }
+        return;
+    }
+    if (roles & ROLE_COLS) {  // target = column x, candidates = rows of this half
+        const float nbc = nbQs[x], th = thQs[x];
+        const int chc = chQs[x];
+        unsigned long long mask = 0ull;
+        for (int rr = 0; rr < 64; ++rr) {
+            int r = half * 64 + rr;
+            float key = fmaf(-2.f, D[r * LDD + x], nbPs[r] + nbc);
+            bool pass = (key <= th) && (chPs[r] != chc);
+            mask |= (unsigned long long)pass << rr;
+        }
+        if (mask) {
+            int64_t gq = (int64_t)J * TB + x;
+            int base = atomicAdd(&g.cnt[gq], __popcll(mask));
+            unsigned long long *dst = g.list + gq * g.cap;
+            while (mask) {
+                int rr = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                int r = half * 64 + rr;
+                float key = fmaf(-2.f, D[r * LDD + x], nbPs[r] + nbc);
+                if (base < g.cap) dst[base] = pack_entry(key, I * TB + r);
+                ++base;
+            }
+        }
+    }
+    if (roles & ROLE_ROWS) {  // target = row x, candidates = columns of this half
+        const float nbr = nbPs[x], th = thPs[x];
+        const int chr = chPs[x];
+        unsigned long long mask = 0ull;
+        for (int cc = 0; cc < 64; ++cc) {
+            int c = half * 64 + cc;
+            float key = fmaf(-2.f, D[x * LDD + c], nbr + nbQs[c]);
+            bool pass = (key <= th) && (chQs[c] != chr);
+            mask |= (unsigned long long)pass << cc;
+        }
+        if (mask) {
+            int64_t gp = (int64_t)I * TB + x;
+            int base = atomicAdd(&g.cnt[gp], __popcll(mask));
+            unsigned long long *dst = g.list + gp * g.cap;
+            while (mask) {
+                int cc = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                int c = half * 64 + cc;
+                float key = fmaf(-2.f, D[x * LDD + c], nbr + nbQs[c]);
+                if (base < g.cap) dst[base] = pack_entry(key, J * TB + c);
+                ++base;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------- threshold selection ----
+// One wave per row: q-th smallest sampled key, q scaled so that about `expect`
+// candidates of the full row pass `key <= thr` (distribution free: the sample is a
+// fixed pseudo-random subset of the rows).
+__global__ __launch_bounds__(256) void k_select_thr(const float *__restrict__ keys, int64_t ldo, int M,
+                                                    const int *__restrict__ chrom_of_row,
+                                                    const int64_t *__restrict__ chrom_off, int64_t B,
+                                                    int64_t row_begin, int64_t row_end, int expect, int cap,
+                                                    float *__restrict__ thr) {
+    const int lane = threadIdx.x & 63;
+    int64_t row = row_begin + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= row_end) return;
+    const int per_lane = M / 64;
+    uint32_t u[MAX_SAMPLE_COLS / 64];
+    const uint32_t FIN = wc::f32_ordered(FLT_MAX);
+    int mvalid = 0;
+#pragma unroll
+    for (int e = 0; e < MAX_SAMPLE_COLS / 64; ++e) {
+        u[e] = 0xFFFFFFFFu;
+        if (e < per_lane) u[e] = wc::f32_ordered(keys[row * ldo + (int64_t)e * 64 + lane]);
+        mvalid += (u[e] <= FIN);
+    }
+    for (int o = 32; o > 0; o >>= 1) mvalid += __shfl_xor(mvalid, o);
+    int ch = chrom_of_row[row];
+    int64_t nvalid = B - (chrom_off[ch + 1] - chrom_off[ch]);
+    float result;
+    if (nvalid <= cap / 2) {
+        result = WC_ADMIT_ALL;
+    } else if (mvalid == 0) {
+        result = -INFINITY;
+    } else {
+        int64_t q = ((int64_t)expect * mvalid + nvalid - 1) / nvalid;
+        if (q < 1) q = 1;
+        if (q > mvalid) q = mvalid;
+        uint32_t res = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            uint32_t trial = res | (1u << bit);
+            int c = 0;
+#pragma unroll
+            for (int e = 0; e < MAX_SAMPLE_COLS / 64; ++e) c += (u[e] < trial);
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+            if (c < q) res = trial;
+        }
+        result = wc::f32_from_ordered(res);
+    }
+    if (lane == 0) thr[row] = result;
+}
+
+// ------------------------------------------------------------------- finish ----
+template <class T> __device__ inline void cswap(T &a, T &b) { T t = a; a = b; b = t; }
+
+__device__ inline void bitonic_u64(unsigned long long *v, int n, int tid, int nthreads) {
+    for (int k2 = 2; k2 <= n; k2 <<= 1)
+        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+            for (int t = tid; t < n; t += nthreads) {
+                int p = t ^ j2;
+                if (p > t) {
+                    bool asc = (t & k2) == 0;
+                    unsigned long long a = v[t], b = v[p];
+                    if ((a > b) == asc) { v[t] = b; v[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+__device__ inline void bitonic_pair(unsigned long long *d, int *j, int n, int tid, int nthreads) {
+    for (int k2 = 2; k2 <= n; k2 <<= 1)
+        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+            for (int t = tid; t < n; t += nthreads) {
+                int p = t ^ j2;
+                if (p > t) {
+                    bool asc = (t & k2) == 0;
+                    unsigned long long a = d[t], b = d[p];
+                    int ja = j[t], jb = j[p];
+                    bool gt = (a > b) || (a == b && ja > jb);
+                    if (gt == asc) { d[t] = b; d[p] = a; j[t] = jb; j[p] = ja; }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+struct FinishArgs {
+    const double *X;
+    int64_t B, S;
+    const float *norm_hi, *thr;
+    const int *cnt;
+    const unsigned long long *list;
+    int cap, k;
+    double beta;
+    const int *chrom_of_row;
+    const int64_t *chrom_off;
+    int64_t row_begin, row_end;
+    int32_t *idx_out;
+    double *dist_out;
+    int *fb_rows, *fb_count;
+    unsigned long long *stats;
+};
+
+// Exact distance of rows j and i in numpy's order: subtract, square (rounded),
+// pairwise sum (wisetools.py:302).  Eight lanes cooperate per candidate.
+__device__ inline double exact_distance(const double *__restrict__ xj, const double *xi, int64_t S, int sub) {
+    return wc::pairwise_sum<true>(
+        [&](int64_t s) {
+            double df = xj[s] - xi[s];
+            double sq = df * df;
+            return sq;
+        },
+        S, sub);
+}
+
+__global__ __launch_bounds__(256) void k_finish(FinishArgs a) {
+    __shared__ unsigned long long ent[LIST_CAP];
+    __shared__ unsigned long long dk[LIST_CAP];
+    __shared__ int jv[LIST_CAP];
+    __shared__ double xs[2048];
+    __shared__ double red[256];
+    __shared__ int red_i[4];
+    const int tid = threadIdx.x;
+    const int64_t row = a.row_begin + blockIdx.x;
+    if (row >= a.row_end) return;
+    const int c = a.cnt[row];
+    const float thr_f = a.thr[row];
+    const bool admit_all = (thr_f == WC_ADMIT_ALL);
+    bool fallback = c > a.cap;
+    const int n = fallback ? 0 : c;
+    int p2 = 2;
+    while (p2 < n) p2 <<= 1;
+    for (int t = tid; t < p2; t += 256) ent[t] = t < n ? a.list[row * a.cap + t] : ~0ull;
+    const double *xi = a.X + row * a.S;
+    if (a.S <= 2048) {
+        for (int64_t s = tid; s < a.S; s += 256) xs[s] = xi[s];
+        xi = xs;
+    }
+    __syncthreads();
+    bitonic_u64(ent, p2, tid, 256);
+
+    int R = 0;
+    if (!fallback) {
+        if (n < a.k) {
+            if (!admit_all) fallback = true;
+            R = n;
+        } else {
+            // upper bound of the k-th true distance from the k smallest lower bounds
+            const double nhi = (double)a.norm_hi[row];
+            double my = -INFINITY;
+            for (int t = tid; t < a.k; t += 256) {
+                float key = wc::f32_from_ordered((uint32_t)(ent[t] >> 32));
+                int j = (int)(uint32_t)ent[t];
+                double ub = (double)key + 3.0 * a.beta * (nhi + (double)a.norm_hi[j]) + 1e-36;
+                my = fmax(my, ub);
+            }
+            red[tid] = my;
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) {
+                if (tid < o) red[tid] = fmax(red[tid], red[tid + o]);
+                __syncthreads();
+            }
+            const double U = red[0];
+            __syncthreads();
+            // every candidate not listed has lower bound > thr; need thr >= U
+            if (!admit_all && !(U <= (double)thr_f)) fallback = true;
+            int mine = 0;
+            for (int t = tid; t < n; t += 256) {
+                float key = wc::f32_from_ordered((uint32_t)(ent[t] >> 32));
+                mine += ((double)key <= U);
+            }
+            for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+            if ((tid & 63) == 0) red_i[tid >> 6] = mine;
+            __syncthreads();
+            R = red_i[0] + red_i[1] + red_i[2] + red_i[3];
+            if (!(U == U)) fallback = true;
+        }
+    }
+    if (fallback) {
+        if (tid == 0) {
+            int at = atomicAdd(a.fb_count, 1);
+            a.fb_rows[at] = (int)row;
+        }
+        return;
+    }
+
+    // float64 re-score, 32 candidates per pass
+    const int grp = tid >> 3, sub = tid & 7;
+    for (int base = 0; base < R; base += 32) {
+        int t = base + grp;
+        bool active = t < R;
+        int j = active ? (int)(uint32_t)ent[t] : (int)row;
+        double d = exact_distance(a.X + (int64_t)j * a.S, xi, a.S, sub);
+        if (active && sub == 0) {
+            bool ok = d < SENTINEL_DISTANCE;  // NaN and >= 1e10 are never admitted (wisetools.py:314)
+            dk[t] = ok ? wc::f64_ordered(d) : ~0ull;
+            jv[t] = ok ? j : 0x7FFFFFFF;
+        }
+    }
+    int q2 = 2;
+    while (q2 < R) q2 <<= 1;
+    for (int t = R + tid; t < q2; t += 256) { dk[t] = ~0ull; jv[t] = 0x7FFFFFFF; }
+    __syncthreads();
+    bitonic_pair(dk, jv, q2, tid, 256);
+
+    const int ch = a.chrom_of_row[row];
+    const int64_t cs = a.chrom_off[ch], ce = a.chrom_off[ch + 1];
+    const int64_t orow = row - a.row_begin;
+    for (int t = tid; t < a.k; t += 256) {
+        int32_t oi = -1;
+        double od = SENTINEL_DISTANCE;
+        if (t < R && dk[t] != ~0ull) {
+            int64_t j = jv[t];
+            oi = (int32_t)(j < cs ? j : j - (ce - cs));
+            od = wc::f64_from_ordered(dk[t]);
+        }
+        a.idx_out[orow * a.k + t] = oi;
+        a.dist_out[orow * a.k + t] = od;
+    }
+    if (tid == 0) {
+        atomicAdd(&a.stats[0], 1ull);
+        atomicAdd(&a.stats[4], (unsigned long long)R);
+    }
+}
+
+// Exact path for rows whose certificate failed (ties at the boundary, outlier
+// rows, list overflow): every distance in float64, then k rounds of
+// lexicographic (distance, position) minimum selection.
+__global__ __launch_bounds__(256) void k_fallback(FinishArgs a, unsigned long long *scratch, int64_t Bpad) {
+    __shared__ unsigned long long rk[256];
+    __shared__ int rj[256];
+    __shared__ double xs[2048];
+    const int tid = threadIdx.x;
+    const int nfb = *a.fb_count;
+    unsigned long long *sc = scratch + (int64_t)blockIdx.x * Bpad;
+    for (int f = blockIdx.x; f < nfb; f += gridDim.x) {
+        const int64_t row = a.fb_rows[f];
+        const int ch = a.chrom_of_row[row];
+        const int64_t cs = a.chrom_off[ch], ce = a.chrom_off[ch + 1];
+        const double *xi = a.X + row * a.S;
+        __syncthreads();
+        if (a.S <= 2048) {
+            for (int64_t s = tid; s < a.S; s += 256) xs[s] = xi[s];
+            xi = xs;
+        }
+        __syncthreads();
+        const int grp = tid >> 3, sub = tid & 7;
+        for (int64_t base = 0; base < a.B; base += 32) {
+            int64_t j = base + grp;
+            bool in = j < a.B;
+            double d = exact_distance(a.X + (in ? j : row) * a.S, xi, a.S, sub);
+            if (in && sub == 0) {
+                bool ok = !(j >= cs && j < ce) && d < SENTINEL_DISTANCE;
+                sc[j] = ok ? wc::f64_ordered(d) : ~0ull;
+            }
+        }
+        __syncthreads();
+        unsigned long long last_d = 0ull;
+        int last_j = -1;
+        const int64_t orow = row - a.row_begin;
+        bool exhausted = false;
+        for (int t = 0; t < a.k; ++t) {
+            unsigned long long bd = ~0ull;
+            int bj = 0x7FFFFFFF;
+            if (!exhausted) {
+                for (int64_t j = tid; j < a.B; j += 256) {
+                    unsigned long long v = sc[j];
+                    bool after = (v > last_d) || (v == last_d && (int)j > last_j);
+                    bool better = (v < bd) || (v == bd && (int)j < bj);
+                    if (after && better) { bd = v; bj = (int)j; }
+                }
+            }
+            rk[tid] = bd;
+            rj[tid] = bj;
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) {
+                if (tid < o) {
+                    unsigned long long v = rk[tid + o];
+                    int jj = rj[tid + o];
+                    if (v < rk[tid] || (v == rk[tid] && jj < rj[tid])) { rk[tid] = v; rj[tid] = jj; }
+                }
+                __syncthreads();
+            }
+            bd = rk[0];
+            bj = rj[0];
+            __syncthreads();
+            if (bd == ~0ull) exhausted = true;
+            if (tid == 0) {
+                int32_t oi = -1;
+                double od = SENTINEL_DISTANCE;
+                if (!exhausted) {
+                    oi = (int32_t)(bj < cs ? bj : bj - (ce - cs));
+                    od = wc::f64_from_ordered(bd);
+                }
+                a.idx_out[orow * a.k + t] = oi;
+                a.dist_out[orow * a.k + t] = od;
+            }
+            last_d = bd;
+            last_j = bj;
+        }
+        if (tid == 0) atomicAdd(&a.stats[1], 1ull);
+    }
+}
+
+// ----------------------------------------------------------------- host side ----
+inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+int build_tiles(NewrefState &st, int64_t row_begin, int64_t row_end, int rank, int ranks,
+                std::vector<int4> &tiles) {
+    const int nb = (int)(st.bins_pad / TB);
+    const int ib = (int)(row_begin / TB), ie = (int)((row_end + TB - 1) / TB);
+    auto chrom_at = [&](int64_t row) {
+        if (row >= st.n_bins) row = st.n_bins - 1;
+        int c = 0;
+        while (c + 1 < st.n_chrom && row >= st.chrom_off[c + 1]) ++c;
+        return c;
+    };
+    std::vector<int> clo(nb), chi(nb);
+    for (int b = 0; b < nb; ++b) {
+        clo[b] = chrom_at((int64_t)b * TB);
+        chi[b] = chrom_at((int64_t)b * TB + TB - 1);
+    }
+    int64_t serial = 0;
+    for (int I = ib; I < ie; ++I)
+        for (int J = 0; J < nb; ++J) {
+            int roles;
+            bool in = J >= ib && J < ie;
+            if (in) {
+                if (J < I) continue;
+                roles = (J == I) ? ROLE_COLS : (ROLE_ROWS | ROLE_COLS);
+            } else {
+                roles = ROLE_ROWS;
+            }
+            // a tile whose rows and columns all sit on one chromosome has no candidates
+            if (clo[I] == chi[I] && clo[J] == chi[J] && clo[I] == clo[J]) continue;
+            if ((serial++ % ranks) != rank) continue;
+            tiles.push_back(make_int4(I, J, roles, 0));
+        }
+    return WC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, int64_t n_bins,
+                          int64_t n_samples, const int64_t *chrom_bins_host, int n_chrom, int k) {
+    WC_CHECK(ctx && corrected && chrom_bins_host, WC_E_ARG, "newref: NULL argument");
+    WC_CHECK(n_bins > 0 && n_samples > 0 && k > 0, WC_E_ARG, "newref: empty problem");
+    WC_CHECK(n_chrom > 0 && n_chrom <= WC_MAX_CHROM, WC_E_ARG, "newref: n_chrom out of range");
+    WC_CHECK(n_samples <= 8192, WC_E_LIMIT, "newref: more than 8192 samples not supported");
+    WC_CHECK(k <= LIST_CAP / 4, WC_E_LIMIT, "newref: refsize above %d not supported", LIST_CAP / 4);
+    WC_CHECK(n_bins < (1ll << 31) - 256, WC_E_LIMIT, "newref: too many bins");
+    hipStream_t stream = (hipStream_t)stream_;
+    WC_HIP(hipSetDevice(ctx->device));
+    NewrefState &st = ctx->nr;
+    st.prepared = false;
+    st.n_bins = n_bins;
+    st.n_samples = n_samples;
+    st.n_chrom = n_chrom;
+    st.k = k;
+    st.corrected = corrected;
+    st.chrom_off[0] = 0;
+    for (int c = 0; c < n_chrom; ++c) {
+        WC_CHECK(chrom_bins_host[c] >= 0, WC_E_ARG, "newref: negative chromosome size");
+        st.chrom_off[c + 1] = st.chrom_off[c] + chrom_bins_host[c];
+    }
+    WC_CHECK(st.chrom_off[n_chrom] == n_bins, WC_E_ARG, "newref: chromosome sizes sum to %lld, expected %lld",
+             (long long)st.chrom_off[n_chrom], (long long)n_bins);
+    st.bins_pad = round_up(n_bins, TB);
+    st.k_pad = round_up(n_samples, BK);
+    st.cap = LIST_CAP;
+    st.expect = LIST_CAP / 2;
+    st.beta = (float)((double)(n_samples + 16) * 5.9604644775390625e-08 * 1.001);
+    int64_t M = round_up((n_bins + 13) / 14, TB);
+    if (M < 512) M = 512;
+    if (M > MAX_SAMPLE_COLS) M = MAX_SAMPLE_COLS;
+    if (M > st.bins_pad) M = st.bins_pad;
+    st.n_sample_cols = M;  // padded count; real sample rows = min(M, n_bins)
+
+    const int R = 64;
+    int rc;
+    if ((rc = st.col_partial.reserve(sizeof(double) * 2 * R * n_samples))) return rc;
+    if ((rc = st.col_mean.reserve(sizeof(double) * 3 * n_samples))) return rc;
+    if ((rc = st.a32.reserve(sizeof(float) * st.bins_pad * st.k_pad))) return rc;
+    if ((rc = st.norm_lo.reserve(sizeof(float) * st.bins_pad))) return rc;
+    if ((rc = st.norm_hi.reserve(sizeof(float) * st.bins_pad))) return rc;
+    if ((rc = st.chrom_of_row.reserve(sizeof(int) * st.bins_pad))) return rc;
+    if ((rc = st.chrom_off_dev.reserve(sizeof(int64_t) * (WC_MAX_CHROM + 1)))) return rc;
+    if ((rc = st.sample_rows.reserve(sizeof(int) * M))) return rc;
+    if ((rc = st.s32.reserve(sizeof(float) * M * st.k_pad))) return rc;
+    if ((rc = st.s_norm_lo.reserve(sizeof(float) * M))) return rc;
+    if ((rc = st.s_chrom.reserve(sizeof(int) * M))) return rc;
+    if ((rc = st.keys1.reserve(sizeof(float) * st.bins_pad * M))) return rc;
+    if ((rc = st.thr.reserve(sizeof(float) * st.bins_pad))) return rc;
+    if ((rc = st.cnt.reserve(sizeof(int) * st.bins_pad))) return rc;
+    if ((rc = st.list.reserve(sizeof(uint64_t) * st.bins_pad * st.cap))) return rc;
+    if ((rc = st.fb_rows.reserve(sizeof(int) * st.bins_pad))) return rc;
+    if ((rc = st.fb_count.reserve(sizeof(int) * 4))) return rc;
+    if ((rc = st.stats.reserve(sizeof(uint64_t) * 8))) return rc;
+
+    WC_HIP(hipMemcpyAsync(st.chrom_off_dev.p, st.chrom_off, sizeof(int64_t) * (n_chrom + 1),
+                          hipMemcpyHostToDevice, stream));
+    // fixed pseudo-random sample of rows (partial Fisher-Yates on a 64-bit LCG), ascending
+    {
+        int64_t real = std::min<int64_t>(M, n_bins);
+        std::vector<int> perm(n_bins);
+        for (int64_t i = 0; i < n_bins; ++i) perm[i] = (int)i;
+        uint64_t s = 0x9E3779B97F4A7C15ull;
+        for (int64_t i = 0; i < real; ++i) {
+            s = s * 6364136223846793005ull + 1442695040888963407ull;
+            int64_t pick = i + (int64_t)((s >> 33) % (uint64_t)(n_bins - i));
+            std::swap(perm[i], perm[pick]);
+        }
+        std::sort(perm.begin(), perm.begin() + real);
+        WC_HIP(hipMemcpyAsync(st.sample_rows.p, perm.data(), sizeof(int) * real, hipMemcpyHostToDevice, stream));
+        WC_HIP(hipStreamSynchronize(stream));  // perm goes out of scope
+    }
+
+    double *psum = st.col_partial.as<double>();
+    double *pcnt = psum + (int64_t)R * n_samples;
+    double *mean1 = st.col_mean.as<double>();
+    double *rad = mean1 + n_samples;
+    double *mean2 = rad + n_samples;
+    dim3 pg((unsigned)((n_samples + 63) / 64), R), pb(64, 4);
+    unsigned fg = (unsigned)((n_samples + 255) / 256);
+    // mean -> 8 x mean absolute deviation window -> trimmed mean (robust to outlier bins)
+    hipLaunchKernelGGL(k_col_partial, pg, pb, 0, stream, corrected, n_bins, n_samples, R, 0,
+                       (const double *)nullptr, (const double *)nullptr, psum, pcnt);
+    hipLaunchKernelGGL(k_col_finish, dim3(fg), dim3(256), 0, stream, psum, pcnt, R, n_samples, 1.0, mean1);
+    hipLaunchKernelGGL(k_col_partial, pg, pb, 0, stream, corrected, n_bins, n_samples, R, 1,
+                       (const double *)mean1, (const double *)nullptr, psum, pcnt);
+    hipLaunchKernelGGL(k_col_finish, dim3(fg), dim3(256), 0, stream, psum, pcnt, R, n_samples, 8.0, rad);
+    hipLaunchKernelGGL(k_col_partial, pg, pb, 0, stream, corrected, n_bins, n_samples, R, 0,
+                       (const double *)mean1, (const double *)rad, psum, pcnt);
+    hipLaunchKernelGGL(k_col_finish, dim3(fg), dim3(256), 0, stream, psum, pcnt, R, n_samples, 1.0, mean2);
+
+    hipLaunchKernelGGL(k_convert, dim3((unsigned)(st.bins_pad / 4)), dim3(256), 0, stream, corrected, n_bins,
+                       n_samples, st.bins_pad, st.k_pad, (const double *)mean2, (double)st.beta,
+                       st.chrom_off_dev.as<int64_t>(), n_chrom, st.a32.as<float>(), st.norm_lo.as<float>(),
+                       st.norm_hi.as<float>(), st.chrom_of_row.as<int>());
+    hipLaunchKernelGGL(k_gather_samples, dim3((unsigned)M), dim3(256), 0, stream, st.a32.as<float>(), st.k_pad,
+                       st.norm_lo.as<float>(), st.chrom_of_row.as<int>(), st.sample_rows.as<int>(),
+                       std::min<int64_t>(M, n_bins), M, st.s32.as<float>(), st.s_norm_lo.as<float>(),
+                       st.s_chrom.as<int>());
+    hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)((st.bins_pad + 255) / 256)), dim3(256), 0, stream,
+                       st.thr.as<float>(), st.bins_pad, -INFINITY);
+    WC_HIP(hipMemsetAsync(st.cnt.p, 0, sizeof(int) * st.bins_pad, stream));
+    WC_HIP(hipMemsetAsync(st.stats.p, 0, sizeof(uint64_t) * 8, stream));
+    WC_HIP(hipGetLastError());
+    st.prepared = true;
+    return WC_OK;
+}
+
+int wc_newref_thresholds_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t row_end) {
+    WC_CHECK(ctx && ctx->nr.prepared, WC_E_ARG, "newref: prepare has not run");
+    NewrefState &st = ctx->nr;
+    WC_CHECK(row_begin >= 0 && row_begin <= row_end && row_end <= st.n_bins, WC_E_ARG, "newref: bad row range");
+    if (row_begin == row_end) return WC_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int ib = (int)(row_begin / TB), ie = (int)((row_end + TB - 1) / TB);
+    const int mb = (int)(st.n_sample_cols / TB);
+    std::vector<int4> tiles;
+    tiles.reserve((size_t)(ie - ib) * mb);
+    for (int I = ib; I < ie; ++I)
+        for (int J = 0; J < mb; ++J) tiles.push_back(make_int4(I, J, 0, 0));
+    int rc;
+    if ((rc = st.tiles.reserve(sizeof(int4) * tiles.size()))) return rc;
+    WC_HIP(hipMemcpyAsync(st.tiles.p, tiles.data(), sizeof(int4) * tiles.size(), hipMemcpyHostToDevice, stream));
+    WC_HIP(hipStreamSynchronize(stream));
+    GramArgs g{};
+    g.P = st.a32.as<float>();
+    g.Q = st.s32.as<float>();
+    g.ld = st.k_pad;
+    g.nslab = (int)(st.k_pad / BK);
+    g.nbP = st.norm_lo.as<float>();
+    g.nbQ = st.s_norm_lo.as<float>();
+    g.chP = st.chrom_of_row.as<int>();
+    g.chQ = st.s_chrom.as<int>();
+    g.tiles = st.tiles.as<int4>();
+    g.ntiles = (int)tiles.size();
+    g.keys = st.keys1.as<float>();
+    g.ldo = st.n_sample_cols;
+    unsigned grid = (unsigned)(((g.ntiles + 7) / 8) * 8);
+    hipLaunchKernelGGL(k_gram<0>, dim3(grid), dim3(256), 0, stream, g);
+    unsigned sg = (unsigned)((row_end - row_begin + 3) / 4);
+    hipLaunchKernelGGL(k_select_thr, dim3(sg), dim3(256), 0, stream, (const float *)st.keys1.as<float>(),
+                       st.n_sample_cols, (int)st.n_sample_cols, (const int *)st.chrom_of_row.as<int>(),
+                       (const int64_t *)st.chrom_off_dev.as<int64_t>(), st.n_bins, row_begin, row_end,
+                       (int)st.expect, (int)st.cap, st.thr.as<float>());
+    WC_HIP(hipGetLastError());
+    return WC_OK;
+}
+
+float *wc_newref_threshold_buffer(wc_ctx *ctx) { return ctx ? ctx->nr.thr.as<float>() : nullptr; }
+int32_t *wc_newref_count_buffer(wc_ctx *ctx) { return ctx ? ctx->nr.cnt.as<int32_t>() : nullptr; }
+uint64_t *wc_newref_list_buffer(wc_ctx *ctx, int64_t *cap) {
+    if (!ctx) return nullptr;
+    if (cap) *cap = ctx->nr.cap;
+    return ctx->nr.list.as<uint64_t>();
+}
+
+int wc_newref_collect_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t row_end, int tile_rank,
+                          int tile_ranks) {
+    WC_CHECK(ctx && ctx->nr.prepared, WC_E_ARG, "newref: prepare has not run");
+    NewrefState &st = ctx->nr;
+    WC_CHECK(row_begin >= 0 && row_begin <= row_end && row_end <= st.n_bins, WC_E_ARG, "newref: bad row range");
+    WC_CHECK(tile_ranks >= 1 && tile_rank >= 0 && tile_rank < tile_ranks, WC_E_ARG, "newref: bad tile rank");
+    if (row_begin == row_end) return WC_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    std::vector<int4> tiles;
+    build_tiles(st, row_begin, row_end, tile_rank, tile_ranks, tiles);
+    ctx->last_stats[2] = (int64_t)tiles.size();
+    ctx->last_stats[3] = st.n_sample_cols;
+    if (tiles.empty()) return WC_OK;
+    int rc;
+    if ((rc = st.tiles.reserve(sizeof(int4) * tiles.size()))) return rc;
+    WC_HIP(hipMemcpyAsync(st.tiles.p, tiles.data(), sizeof(int4) * tiles.size(), hipMemcpyHostToDevice, stream));
+    WC_HIP(hipStreamSynchronize(stream));
+    GramArgs g{};
+    g.P = g.Q = st.a32.as<float>();
+    g.ld = st.k_pad;
+    g.nslab = (int)(st.k_pad / BK);
+    g.nbP = g.nbQ = st.norm_lo.as<float>();
+    g.chP = g.chQ = st.chrom_of_row.as<int>();
+    g.tiles = st.tiles.as<int4>();
+    g.ntiles = (int)tiles.size();
+    g.thr = st.thr.as<float>();
+    g.cnt = st.cnt.as<int>();
+    g.list = st.list.as<unsigned long long>();
+    g.cap = (int)st.cap;
+    unsigned grid = (unsigned)(((g.ntiles + 7) / 8) * 8);
+    hipLaunchKernelGGL(k_gram<1>, dim3(grid), dim3(256), 0, stream, g);
+    WC_HIP(hipGetLastError());
+    return WC_OK;
+}
+
+int wc_newref_finish_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t row_end, int32_t *idx_out,
+                         double *dist_out) {
+    WC_CHECK(ctx && ctx->nr.prepared, WC_E_ARG, "newref: prepare has not run");
+    NewrefState &st = ctx->nr;
+    WC_CHECK(row_begin >= 0 && row_begin <= row_end && row_end <= st.n_bins, WC_E_ARG, "newref: bad row range");
+    WC_CHECK(idx_out && dist_out, WC_E_ARG, "newref: NULL output");
+    if (row_begin == row_end) return WC_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc;
+    if ((rc = st.fb_scratch.reserve(sizeof(uint64_t) * FB_BLOCKS * st.bins_pad))) return rc;
+    WC_HIP(hipMemsetAsync(st.fb_count.p, 0, sizeof(int) * 4, stream));
+    FinishArgs a{};
+    a.X = st.corrected;
+    a.B = st.n_bins;
+    a.S = st.n_samples;
+    a.norm_hi = st.norm_hi.as<float>();
+    a.thr = st.thr.as<float>();
+    a.cnt = st.cnt.as<int>();
+    a.list = st.list.as<unsigned long long>();
+    a.cap = (int)st.cap;
+    a.k = st.k;
+    a.beta = (double)st.beta;
+    a.chrom_of_row = st.chrom_of_row.as<int>();
+    a.chrom_off = st.chrom_off_dev.as<int64_t>();
+    a.row_begin = row_begin;
+    a.row_end = row_end;
+    a.idx_out = idx_out;
+    a.dist_out = dist_out;
+    a.fb_rows = st.fb_rows.as<int>();
+    a.fb_count = st.fb_count.as<int>();
+    a.stats = st.stats.as<unsigned long long>();
+    hipLaunchKernelGGL(k_finish, dim3((unsigned)(row_end - row_begin)), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(k_fallback, dim3(FB_BLOCKS), dim3(256), 0, stream, a,
+                       st.fb_scratch.as<unsigned long long>(), st.bins_pad);
+    WC_HIP(hipGetLastError());
+    return WC_OK;
+}
+
+int wc_get_reference_dev(wc_ctx *ctx, void *stream, const double *corrected, int64_t n_bins, int64_t n_samples,
+                         const int64_t *chrom_bins_host, int n_chrom, int k, int64_t row_begin,
+                         int64_t row_end, int32_t *idx_out, double *dist_out) {
+    int rc = wc_newref_prepare_dev(ctx, stream, corrected, n_bins, n_samples, chrom_bins_host, n_chrom, k);
+    if (rc) return rc;
+    if ((rc = wc_newref_thresholds_dev(ctx, stream, row_begin, row_end))) return rc;
+    if ((rc = wc_newref_collect_dev(ctx, stream, row_begin, row_end, 0, 1))) return rc;
+    return wc_newref_finish_dev(ctx, stream, row_begin, row_end, idx_out, dist_out);
+}
+
+int wc_get_reference(wc_ctx *ctx, const double *corrected, int64_t n_bins, int64_t n_samples,
+                     const int64_t *chrom_bins, int n_chrom, int k, int64_t row_begin, int64_t row_end,
+                     int32_t *idx_out, double *dist_out) {
+    WC_CHECK(ctx && corrected && idx_out && dist_out, WC_E_ARG, "getReference: NULL argument");
+    WC_CHECK(row_begin >= 0 && row_begin <= row_end && row_end <= n_bins, WC_E_ARG, "getReference: bad row range");
+    WC_HIP(hipSetDevice(ctx->device));
+    int64_t rows = row_end - row_begin;
+    int rc;
+    if ((rc = ctx->tmp_a.reserve(sizeof(double) * n_bins * n_samples))) return rc;
+    if ((rc = ctx->tmp_b.reserve(sizeof(int32_t) * std::max<int64_t>(rows, 1) * k))) return rc;
+    if ((rc = ctx->tmp_c.reserve(sizeof(double) * std::max<int64_t>(rows, 1) * k))) return rc;
+    WC_HIP(hipMemcpy(ctx->tmp_a.p, corrected, sizeof(double) * n_bins * n_samples, hipMemcpyHostToDevice));
+    rc = wc_get_reference_dev(ctx, nullptr, ctx->tmp_a.as<double>(), n_bins, n_samples, chrom_bins, n_chrom, k,
+                              row_begin, row_end, ctx->tmp_b.as<int32_t>(), ctx->tmp_c.as<double>());
+    if (rc) return rc;
+    WC_HIP(hipDeviceSynchronize());
+    if (rows > 0) {
+        WC_HIP(hipMemcpy(idx_out, ctx->tmp_b.p, sizeof(int32_t) * rows * k, hipMemcpyDeviceToHost));
+        WC_HIP(hipMemcpy(dist_out, ctx->tmp_c.p, sizeof(double) * rows * k, hipMemcpyDeviceToHost));
+    }
+    return WC_OK;
+}
+
+int wc_newref_stats(wc_ctx *ctx, int64_t out[8]) {
+    WC_CHECK(ctx && out, WC_E_ARG, "stats: NULL argument");
+    uint64_t dev[8] = {0};
+    if (ctx->nr.stats.p) {
+        WC_HIP(hipSetDevice(ctx->device));
+        WC_HIP(hipDeviceSynchronize());
+        WC_HIP(hipMemcpy(dev, ctx->nr.stats.p, sizeof(dev), hipMemcpyDeviceToHost));
+    }
+    for (int i = 0; i < 8; ++i) out[i] = (int64_t)dev[i];
+    out[2] = ctx->last_stats[2];
+    out[3] = ctx->last_stats[3];
+    return WC_OK;
+}
+
+}  // extern "C"
