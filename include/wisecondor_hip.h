@@ -33,6 +33,16 @@ extern "C" {
 #define WC_E_LIMIT (-3)    /* size beyond a documented implementation limit    */
 #define WC_E_INTERNAL (-4) /* internal consistency check failed                */
 
+/* Summation order of the float64 distance, which numpy derives from the memory
+ * layout of correctedData (wisetools.py:302): a C-contiguous [bins, samples]
+ * array is reduced row by row with numpy's pairwise summation; the
+ * Fortran-contiguous array that np.load returns for a prep file (trainPCA
+ * returns corrected.T, wisetools.py:101) is reduced sample by sample, i.e. a
+ * plain left-to-right sum.  The buffers handed to this library are always
+ * row-major [bins, samples]; the flag only selects the rounding order.        */
+#define WC_SUM_PAIRWISE 0
+#define WC_SUM_SEQUENTIAL 1
+
 typedef struct wc_ctx wc_ctx; /* per-device context: workspaces, scratch, counters */
 
 /* ---- context -------------------------------------------------------------- */
@@ -54,6 +64,7 @@ void wc_get_part(int64_t partnum, int64_t outof, int64_t bincount, int64_t *star
  * corrected      [n_bins, n_samples] float64 (the prep file's correctedData)
  * chrom_bins     [n_chrom] bins per chromosome (maskedChromBins); sum == n_bins
  * k              selectRefAmount (reference default 100)
+ * sum_order      WC_SUM_PAIRWISE / WC_SUM_SEQUENTIAL (see above)
  * row_begin/end  target rows to produce (getPart of part, splitParts)
  * idx_out        [row_end-row_begin, k] int32: positions in the
  *                "all bins not on the target's chromosome" concatenation
@@ -63,11 +74,12 @@ void wc_get_part(int64_t partnum, int64_t outof, int64_t bincount, int64_t *star
  * numpy pairwise-summed float64 distances).
  */
 int wc_get_reference(wc_ctx *ctx, const double *corrected, int64_t n_bins, int64_t n_samples,
-                     const int64_t *chrom_bins, int n_chrom, int k,
+                     const int64_t *chrom_bins, int n_chrom, int k, int sum_order,
                      int64_t row_begin, int64_t row_end, int32_t *idx_out, double *dist_out);
 int wc_get_reference_dev(wc_ctx *ctx, void *stream, const double *corrected, int64_t n_bins,
                          int64_t n_samples, const int64_t *chrom_bins_host, int n_chrom, int k,
-                         int64_t row_begin, int64_t row_end, int32_t *idx_out, double *dist_out);
+                         int sum_order, int64_t row_begin, int64_t row_end, int32_t *idx_out,
+                         double *dist_out);
 
 /*
  * Multi-GPU building blocks of the same computation (one process per GPU; the
@@ -83,7 +95,8 @@ int wc_get_reference_dev(wc_ctx *ctx, void *stream, const double *corrected, int
  * wc_get_reference_dev == A, B(all), C(0 of 1), D(range).
  */
 int wc_newref_prepare_dev(wc_ctx *ctx, void *stream, const double *corrected, int64_t n_bins,
-                          int64_t n_samples, const int64_t *chrom_bins_host, int n_chrom, int k);
+                          int64_t n_samples, const int64_t *chrom_bins_host, int n_chrom, int k,
+                          int sum_order);
 int wc_newref_thresholds_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end);
 float *wc_newref_threshold_buffer(wc_ctx *ctx);              /* device float[n_bins_padded]       */
 int wc_newref_collect_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end,

@@ -54,10 +54,14 @@ def test_golden_cfg1_prep_seam(golden, wt):
     assert same_bits(np.concatenate(cat_d), g["ref_distances"])
 
 
+@pytest.mark.parametrize("order", ["C", "F"])
 @pytest.mark.parametrize("n_samples,binsize,k", [(16, 1000000, 100), (100, 1000000, 50), (257, 2000000, 100)])
-def test_oracle_synthetic(wt, n_samples, binsize, k):
+def test_oracle_synthetic(wt, n_samples, binsize, k, order):
+    """C-ordered input -> numpy pairwise bits; F-ordered (prep-file layout) -> sequential bits."""
     from wisecondor_amd import synth
     data, bins, sums = synth.corrected_matrix(binsize, n_samples, seed=3)
+    if order == "F":
+        data = np.asfortranarray(data)
     idx, dst = wt.getReference(data, bins, sums, k, 1, 1)
     st = wt.newref_stats()
     want_i, want_d = wo.get_reference(data, bins, sums, k, 1, 1, fast=True)

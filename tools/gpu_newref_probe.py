@@ -20,7 +20,7 @@ for binsize, S in [(1000000, 16), (250000, 100), (50000, 600)]:
     for it in range(3):
         torch.cuda.synchronize()
         t0 = time.time()
-        _lib.check(lib.wc_get_reference_dev(ctx, None, X.data_ptr(), B, S, _lib.ptr(bins_c), 22, 100, 0, B,
+        _lib.check(lib.wc_get_reference_dev(ctx, None, X.data_ptr(), B, S, _lib.ptr(bins_c), 22, 100, 0, 0, B,
                                             idx.data_ptr(), dst.data_ptr()))
         torch.cuda.synchronize()
         dt = time.time() - t0

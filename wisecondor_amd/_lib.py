@@ -25,9 +25,9 @@ SIGNATURES = {
     "wc_version": (_c.c_char_p, []),
     "wc_newref_stats": (_i32, [_vp, _vp]),
     "wc_get_part": (None, [_i64, _i64, _i64, _vp, _vp]),
-    "wc_get_reference": (_i32, [_vp, _vp, _i64, _i64, _vp, _i32, _i32, _i64, _i64, _vp, _vp]),
-    "wc_get_reference_dev": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i32, _i32, _i64, _i64, _vp, _vp]),
-    "wc_newref_prepare_dev": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i32, _i32]),
+    "wc_get_reference": (_i32, [_vp, _vp, _i64, _i64, _vp, _i32, _i32, _i32, _i64, _i64, _vp, _vp]),
+    "wc_get_reference_dev": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i32, _i32, _i32, _i64, _i64, _vp, _vp]),
+    "wc_newref_prepare_dev": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i32, _i32, _i32]),
     "wc_newref_thresholds_dev": (_i32, [_vp, _vp, _i64, _i64]),
     "wc_newref_threshold_buffer": (_vp, [_vp]),
     "wc_newref_collect_dev": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32]),
@@ -46,6 +46,9 @@ SIGNATURES = {
     "wc_test_batch_dev": (_i32, [_vp, _vp, _vp, _vp, _i64, _dbl, _i32, _i32, _vp, _i32, _i32,
                                  _vp, _vp, _vp, _vp, _vp, _vp]),
 }
+
+SUM_PAIRWISE = 0
+SUM_SEQUENTIAL = 1
 
 _lib = None
 

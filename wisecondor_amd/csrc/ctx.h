@@ -9,7 +9,7 @@ struct NewrefState {
     int64_t n_bins = 0, n_samples = 0;
     int64_t bins_pad = 0;   // rows padded to the 128-row tile
     int64_t k_pad = 0;      // samples padded to the 32-wide k-slab
-    int n_chrom = 0, k = 0;
+    int n_chrom = 0, k = 0, sum_order = 0;
     int64_t chrom_off[WC_MAX_CHROM + 1] = {0};
     const double *corrected = nullptr;  // device, caller owned
     // tuning

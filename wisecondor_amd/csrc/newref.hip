@@ -433,18 +433,41 @@ struct FinishArgs {
     double *dist_out;
     int *fb_rows, *fb_count;
     unsigned long long *stats;
+    int sum_order;
 };
 
-// Exact distance of rows j and i in numpy's order: subtract, square (rounded),
-// pairwise sum (wisetools.py:302).  Eight lanes cooperate per candidate.
-__device__ inline double exact_distance(const double *__restrict__ xj, const double *xi, int64_t S, int sub) {
-    return wc::pairwise_sum<true>(
-        [&](int64_t s) {
+// Exact distance of rows j and i with numpy's bits: subtract, square (rounded), sum
+// (wisetools.py:302).  Eight lanes cooperate per candidate.  The summation order
+// numpy uses depends on the memory layout of correctedData:
+//   WC_SUM_PAIRWISE    C-contiguous [bins, samples]: each row is reduced by
+//                      numpy's pairwise_sum;
+//   WC_SUM_SEQUENTIAL  Fortran-contiguous (what np.load returns for the prep
+//                      file, because trainPCA hands back corrected.T,
+//                      wisetools.py:101): the reduction runs sample by sample,
+//                      i.e. a plain left-to-right sum.
+__device__ inline double exact_distance(const double *__restrict__ xj, const double *xi, int64_t S, int sub,
+                                        int sum_order) {
+    if (sum_order == WC_SUM_PAIRWISE) {
+        return wc::pairwise_sum<true>(
+            [&](int64_t s) {
+                double df = xj[s] - xi[s];
+                double sq = df * df;
+                return sq;
+            },
+            S, sub);
+    }
+    double acc = 0.0;
+    for (int64_t s0 = 0; s0 < S; s0 += 8) {
+        int64_t s = s0 + sub;
+        double sq = 0.0;
+        if (s < S) {
             double df = xj[s] - xi[s];
-            double sq = df * df;
-            return sq;
-        },
-        S, sub);
+            sq = df * df;
+        }
+        int lim = (S - s0) < 8 ? (int)(S - s0) : 8;
+        for (int i = 0; i < lim; ++i) acc = acc + __shfl(sq, i, 8);
+    }
+    return acc;
 }
 
 __global__ __launch_bounds__(256) void k_finish(FinishArgs a) {
@@ -524,7 +547,7 @@ __global__ __launch_bounds__(256) void k_finish(FinishArgs a) {
         int t = base + grp;
         bool active = t < R;
         int j = active ? (int)(uint32_t)ent[t] : (int)row;
-        double d = exact_distance(a.X + (int64_t)j * a.S, xi, a.S, sub);
+        double d = exact_distance(a.X + (int64_t)j * a.S, xi, a.S, sub, a.sum_order);
         if (active && sub == 0) {
             bool ok = d < SENTINEL_DISTANCE;  // NaN and >= 1e10 are never admitted (wisetools.py:314)
             dk[t] = ok ? wc::f64_ordered(d) : ~0ull;
@@ -582,7 +605,7 @@ __global__ __launch_bounds__(256) void k_fallback(FinishArgs a, unsigned long lo
         for (int64_t base = 0; base < a.B; base += 32) {
             int64_t j = base + grp;
             bool in = j < a.B;
-            double d = exact_distance(a.X + (in ? j : row) * a.S, xi, a.S, sub);
+            double d = exact_distance(a.X + (in ? j : row) * a.S, xi, a.S, sub, a.sum_order);
             if (in && sub == 0) {
                 bool ok = !(j >= cs && j < ce) && d < SENTINEL_DISTANCE;
                 sc[j] = ok ? wc::f64_ordered(d) : ~0ull;
@@ -678,13 +701,15 @@ int build_tiles(NewrefState &st, int64_t row_begin, int64_t row_end, int rank, i
 extern "C" {
 
 int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, int64_t n_bins,
-                          int64_t n_samples, const int64_t *chrom_bins_host, int n_chrom, int k) {
+                          int64_t n_samples, const int64_t *chrom_bins_host, int n_chrom, int k,
+                          int sum_order) {
     WC_CHECK(ctx && corrected && chrom_bins_host, WC_E_ARG, "newref: NULL argument");
     WC_CHECK(n_bins > 0 && n_samples > 0 && k > 0, WC_E_ARG, "newref: empty problem");
     WC_CHECK(n_chrom > 0 && n_chrom <= WC_MAX_CHROM, WC_E_ARG, "newref: n_chrom out of range");
     WC_CHECK(n_samples <= 8192, WC_E_LIMIT, "newref: more than 8192 samples not supported");
     WC_CHECK(k <= LIST_CAP / 4, WC_E_LIMIT, "newref: refsize above %d not supported", LIST_CAP / 4);
     WC_CHECK(n_bins < (1ll << 31) - 256, WC_E_LIMIT, "newref: too many bins");
+    WC_CHECK(sum_order == WC_SUM_PAIRWISE || sum_order == WC_SUM_SEQUENTIAL, WC_E_ARG, "newref: bad sum_order");
     hipStream_t stream = (hipStream_t)stream_;
     WC_HIP(hipSetDevice(ctx->device));
     NewrefState &st = ctx->nr;
@@ -694,6 +719,7 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
     st.n_chrom = n_chrom;
     st.k = k;
     st.corrected = corrected;
+    st.sum_order = sum_order;
     st.chrom_off[0] = 0;
     for (int c = 0; c < n_chrom; ++c) {
         WC_CHECK(chrom_bins_host[c] >= 0, WC_E_ARG, "newref: negative chromosome size");
@@ -900,6 +926,7 @@ int wc_newref_finish_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t 
     a.fb_rows = st.fb_rows.as<int>();
     a.fb_count = st.fb_count.as<int>();
     a.stats = st.stats.as<unsigned long long>();
+    a.sum_order = st.sum_order;
     hipLaunchKernelGGL(k_finish, dim3((unsigned)(row_end - row_begin)), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(k_fallback, dim3(FB_BLOCKS), dim3(256), 0, stream, a,
                        st.fb_scratch.as<unsigned long long>(), st.bins_pad);
@@ -908,9 +935,10 @@ int wc_newref_finish_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t 
 }
 
 int wc_get_reference_dev(wc_ctx *ctx, void *stream, const double *corrected, int64_t n_bins, int64_t n_samples,
-                         const int64_t *chrom_bins_host, int n_chrom, int k, int64_t row_begin,
-                         int64_t row_end, int32_t *idx_out, double *dist_out) {
-    int rc = wc_newref_prepare_dev(ctx, stream, corrected, n_bins, n_samples, chrom_bins_host, n_chrom, k);
+                         const int64_t *chrom_bins_host, int n_chrom, int k, int sum_order,
+                         int64_t row_begin, int64_t row_end, int32_t *idx_out, double *dist_out) {
+    int rc = wc_newref_prepare_dev(ctx, stream, corrected, n_bins, n_samples, chrom_bins_host, n_chrom, k,
+                                   sum_order);
     if (rc) return rc;
     if ((rc = wc_newref_thresholds_dev(ctx, stream, row_begin, row_end))) return rc;
     if ((rc = wc_newref_collect_dev(ctx, stream, row_begin, row_end, 0, 1))) return rc;
@@ -918,8 +946,8 @@ int wc_get_reference_dev(wc_ctx *ctx, void *stream, const double *corrected, int
 }
 
 int wc_get_reference(wc_ctx *ctx, const double *corrected, int64_t n_bins, int64_t n_samples,
-                     const int64_t *chrom_bins, int n_chrom, int k, int64_t row_begin, int64_t row_end,
-                     int32_t *idx_out, double *dist_out) {
+                     const int64_t *chrom_bins, int n_chrom, int k, int sum_order, int64_t row_begin,
+                     int64_t row_end, int32_t *idx_out, double *dist_out) {
     WC_CHECK(ctx && corrected && idx_out && dist_out, WC_E_ARG, "getReference: NULL argument");
     WC_CHECK(row_begin >= 0 && row_begin <= row_end && row_end <= n_bins, WC_E_ARG, "getReference: bad row range");
     WC_HIP(hipSetDevice(ctx->device));
@@ -930,7 +958,7 @@ int wc_get_reference(wc_ctx *ctx, const double *corrected, int64_t n_bins, int64
     if ((rc = ctx->tmp_c.reserve(sizeof(double) * std::max<int64_t>(rows, 1) * k))) return rc;
     WC_HIP(hipMemcpy(ctx->tmp_a.p, corrected, sizeof(double) * n_bins * n_samples, hipMemcpyHostToDevice));
     rc = wc_get_reference_dev(ctx, nullptr, ctx->tmp_a.as<double>(), n_bins, n_samples, chrom_bins, n_chrom, k,
-                              row_begin, row_end, ctx->tmp_b.as<int32_t>(), ctx->tmp_c.as<double>());
+                              sum_order, row_begin, row_end, ctx->tmp_b.as<int32_t>(), ctx->tmp_c.as<double>());
     if (rc) return rc;
     WC_HIP(hipDeviceSynchronize());
     if (rows > 0) {

@@ -22,6 +22,20 @@ def getPart(partnum, outof, bincount):
     return a.value, b.value
 
 
+def sum_order_of(correctedData):
+    """Rounding order numpy would use for np.sum(..., 1) on this array (wisetools.py:302).
+
+    numpy reduces along the smaller-stride axis in its inner loop: a C-ordered
+    [bins, samples] array gets a pairwise sum per row, the Fortran-ordered array
+    np.load returns for a prep file (trainPCA's corrected.T, wisetools.py:101) a
+    plain sample-by-sample sum.  The HIP library reproduces either.
+    """
+    a = np.asarray(correctedData)
+    if a.ndim != 2 or a.shape[1] <= 1 or a.flags["C_CONTIGUOUS"]:
+        return _lib.SUM_PAIRWISE
+    return _lib.SUM_PAIRWISE if abs(a.strides[1]) <= abs(a.strides[0]) else _lib.SUM_SEQUENTIAL
+
+
 def getReference(correctedData, chromosomeBins, chromosomeBinSums, selectRefAmount=100, part=1,
                  splitParts=1, device=0):
     """Reference bins for the rows of part `part` of `splitParts` (wisetools.py:364-398).
@@ -31,6 +45,7 @@ def getReference(correctedData, chromosomeBins, chromosomeBinSums, selectRefAmou
     """
     lib = _lib.load()
     ctx = _lib.context(device)
+    order = sum_order_of(correctedData)
     data = np.ascontiguousarray(correctedData, dtype=np.float64)
     bins = np.ascontiguousarray(chromosomeBins, dtype=np.int64)
     n_bins = int(np.asarray(chromosomeBinSums)[-1])
@@ -43,7 +58,7 @@ def getReference(correctedData, chromosomeBins, chromosomeBinSums, selectRefAmou
     idx = np.empty((rows, k), dtype=np.int32)
     dst = np.empty((rows, k), dtype=np.float64)
     _lib.check(lib.wc_get_reference(ctx, _lib.ptr(data), n_bins, data.shape[1], _lib.ptr(bins),
-                                    bins.shape[0], k, start, end, _lib.ptr(idx), _lib.ptr(dst)))
+                                    bins.shape[0], k, order, start, end, _lib.ptr(idx), _lib.ptr(dst)))
     return idx, dst
 
 
