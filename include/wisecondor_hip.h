@@ -118,17 +118,25 @@ typedef struct wc_reference wc_reference;
  *   indexes [n_bins,k] int32, distances [n_bins,k] float64,
  *   chromosome_sizes/masked_sizes [n_chrom] int64, mask [sum(chromosome_sizes)] uint8,
  *   pca_mean [n_bins], pca_components [n_comp, n_bins] float64.
+ * cutoff_override: NULL to compute the cutoff, else the value to use (the
+ * reference passes it explicitly to repeatTest, wisetools.py:438).
+ * Limits: k <= 128 (one numpy pairwise block), n_comp <= 8.
  */
 wc_reference *wc_reference_create(wc_ctx *ctx, const int32_t *indexes, const double *distances,
                                   int64_t n_bins, int k, const int64_t *chromosome_sizes,
                                   const int64_t *masked_sizes, int n_chrom, const uint8_t *mask,
                                   const double *pca_mean, const double *pca_components, int n_comp,
-                                  int cutoff_repeats);
+                                  int cutoff_repeats, const double *cutoff_override);
 void wc_reference_destroy(wc_reference *ref);
 double wc_reference_cutoff(const wc_reference *ref);
 
 /* getOptimalCutoff alone, wisetools.py:328-336 (host pointers). */
 int wc_optimal_cutoff(wc_ctx *ctx, const double *distances, int64_t count, int repeats, double *cutoff);
+
+/* applyPCA alone, wisetools.py:104-113, for a batch of already normalised and
+ * masked vectors: samples/out [n_samples, n_bins] float64 (host pointers).    */
+int wc_apply_pca(wc_ctx *ctx, const double *samples, int64_t n_samples, int64_t n_bins,
+                 const double *pca_mean, const double *pca_components, int n_comp, double *out);
 
 /*
  * toNumpyRefFormat + applyPCA, wisetools.py:267-278 and :104-113, for a batch.

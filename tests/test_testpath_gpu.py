@@ -1,0 +1,180 @@
+"""GPU parity of the HIP `test` path (through the C ABI) against golden fixtures
+produced by the reference and against the CPU oracle.
+
+Contract: call coordinates, segment bounds and reference counts exact; z-scores,
+ratios and effect sizes within 1e-9 relative (float64 everywhere; the only
+non-bit-exact step is the PCA projection, whose BLAS summation order is not
+reproducible), stated next to each assertion.
+"""
+import numpy as np
+import pytest
+
+from oracle import wc_oracle as wo
+
+pytestmark = pytest.mark.gpu
+KEYS = [str(c) for c in range(1, 23)] + ["X", "Y"]
+NAMES = ["mild18", "gain5_gap", "gain5_past", "gain5_after", "loss2", "normal"]
+
+
+def same_bits(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if a.shape != b.shape:
+        return False
+    nan = np.isnan(a) & np.isnan(b)
+    return bool(np.all(nan | (a.view(np.int64) == b.view(np.int64))))
+
+
+def _split(flat, lengths):
+    offs = np.concatenate([[0], np.cumsum(lengths)])
+    return {k: flat[offs[i]:offs[i + 1]] for i, k in enumerate(KEYS)}
+
+
+@pytest.fixture(scope="module")
+def wt():
+    from wisecondor_amd import wisetools
+    return wisetools
+
+
+@pytest.fixture(scope="module")
+def cfg1(golden):
+    return golden("cfg1_pipeline.npz")
+
+
+@pytest.fixture(scope="module")
+def reference(wt, cfg1):
+    g = cfg1
+    ref = wt.Reference(g["ref_indexes"], g["ref_distances"], g["ref_chromosome_sizes"], g["ref_masked_sizes"],
+                       g["ref_mask"], g["ref_pca_mean"], g["ref_pca_components"], binsize=float(g["ref_binsize"]))
+    yield ref
+    ref.close()
+
+
+def test_cutoff(wt, cfg1, reference):
+    # float64 reduction in a different (deterministic) order than numpy's pairwise sum: 1e-12 relative
+    assert np.isclose(reference.cutoff, float(cfg1["cutoff"]), rtol=1e-12, atol=0)
+    cut, _ = wt.getOptimalCutoff(cfg1["ref_distances"], 3)
+    assert np.isclose(cut, float(cfg1["cutoff"]), rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_prepare_and_pca(wt, cfg1, name):
+    g = cfg1
+    sample = _split(g["t_%s_sample" % name], g["sample_chrom_lengths"])
+    x = wt.toNumpyRefFormat(sample, g["ref_chromosome_sizes"], g["ref_mask"])
+    assert same_bits(x, g["t_%s_x" % name])          # integer sums and one division: bit-exact
+    xp = wt.applyPCA(g["t_%s_x" % name], g["ref_pca_mean"], g["ref_pca_components"])
+    assert np.allclose(xp, g["t_%s_xpca" % name], rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("reps", [1, 2, 5])
+def test_repeat_test_bits(wt, cfg1, reps):
+    """From the golden PCA output the z-score repeats must reproduce numpy's bits."""
+    g = cfg1
+    data = np.stack([g["t_%s_xpca" % n] for n in NAMES])
+    thr = float(g["t_mild18_threshold_z"])
+    ms = g["ref_masked_sizes"]
+    z, r, n, sd = wt.repeatTest(data, g["ref_indexes"], g["ref_distances"], ms, np.cumsum(ms),
+                                float(g["cutoff"]), thr, reps)
+    for row, name in enumerate(NAMES):
+        assert np.array_equal(n[row], g["t_%s_rep%d_n" % (name, reps)]), name
+        assert same_bits(z[row], g["t_%s_rep%d_z" % (name, reps)]), name
+        if reps == 5:
+            assert same_bits(r[row], g["t_%s_rep5_r" % name]), name
+            assert sd[row] == float(g["t_%s_rep5_sd" % name]), name
+
+
+def test_segments_golden(wt, golden):
+    g = golden("segments.npz")
+    for i in range(int(g["n_cases"])):
+        z = g["z_%d" % i]
+        thr = float(g["thresholds"][i])
+        whole, segs = wt.stouffer_segments([z], thr, 3)
+        want = g["seg_%d" % i]
+        got = np.array([[v, x, y] for v, (x, y) in segs[0]], dtype=np.float64).reshape(-1, 3)
+        assert np.array_equal(got[:, 1:], want[:, 1:]), (i, got, want)
+        assert same_bits(got[:, 0], want[:, 0]), (i, got, want)
+        tri = g["tri_%d" % i]
+        assert same_bits([whole[0]], [tri[len(z) - 1]]), i      # getValue(0, n-1)
+    # several regions in one call
+    zs = [g["z_%d" % i] for i in range(14, int(g["n_cases"]))]
+    _, segs = wt.stouffer_segments(zs, 3.0, 3)
+    for z, s in zip(zs, segs):
+        tri = wo.fill_tri(z)
+        want = wo.segment_tri(tri, z.shape[0], 3.0, 3)
+        assert [(x, y) for _, (x, y) in s] == [(x, y) for _, (x, y) in want]
+        assert same_bits([v for v, _ in s], [v for v, _ in want])
+
+
+def test_triarr_mirror(wt, golden):
+    from wisecondor_amd.triarray import TriArr
+    g = golden("segments.npz")
+    z = g["z_27"]
+    tri = wt.fillTriMin(z, np.ones_like(z), 0)
+    assert isinstance(tri, TriArr)
+    want = g["tri_27"]
+    n = len(z)
+    assert tri.getValue(0, n - 1) == want[n - 1]
+    assert tri.getValue(3, 9) == want[wo.tri_offset(n, 3, 9)]
+    assert tri.linTo2D(wo.tri_offset(n, 13, 22)) == (13, 22)
+    segs = tri.segmentTri(float(g["thresholds"][27]), 3)
+    assert [(x, y) for _, (x, y) in segs] == [tuple(int(v) for v in row[1:]) for row in g["seg_27"]]
+    with pytest.raises(NotImplementedError):
+        wt.fillTriMin(z, np.ones_like(z), 0.05)
+
+
+def test_segments_random_vs_oracle(wt):
+    rng = np.random.RandomState(11)
+    regions = []
+    for n in [1, 2, 3, 4, 5, 7, 33, 64, 65, 129, 200, 257, 300]:
+        z = rng.standard_normal(n)
+        if n > 20:
+            a = rng.randint(0, n - 10)
+            z[a:a + rng.randint(3, 10)] += rng.choice([-1, 1]) * 3.0
+        regions.append(z)
+    regions.append(np.zeros(40))                       # everything ties at zero
+    regions.append(np.round(rng.standard_normal(60)))  # many exact ties between windows
+    regions.append(np.array([2.0] * 50))               # monotone growth, single call
+    thr = 3.5
+    whole, segs = wt.stouffer_segments(regions, thr, 3)
+    for z, w, s in zip(regions, whole, segs):
+        tri = wo.fill_tri(z)
+        want = wo.segment_tri(tri, z.shape[0], thr, 3)
+        assert [(x, y) for _, (x, y) in s] == [(x, y) for _, (x, y) in want], z.shape
+        assert same_bits([v for v, _ in s], [v for v, _ in want])
+        assert same_bits([w], [tri[z.shape[0] - 1]])
+
+
+@pytest.mark.parametrize("batch", [False, True])
+def test_cfg1_whole_test(wt, cfg1, reference, batch):
+    g = cfg1
+    thr = float(g["t_mild18_threshold_z"])
+    samples = [_split(g["t_%s_sample" % n], g["sample_chrom_lengths"]) for n in NAMES]
+    if batch:
+        outs = wt.test_batch(reference, samples, thr)
+    else:
+        outs = [wt.test_batch(reference, [s], thr)[0] for s in samples]
+    for name, out in zip(NAMES, outs):
+        want = g["t_%s_results_calls" % name]
+        got = out["results_calls"].reshape(-1, 5)
+        assert np.array_equal(got[:, :3], want[:, :3]), (name, got, want)   # chromosome, start, end: exact
+        assert np.allclose(got[:, 3:], want[:, 3:], rtol=1e-9, atol=0), name
+        assert np.allclose(np.concatenate(out["results_z"]), g["t_%s_results_z" % name], rtol=1e-9, atol=1e-11)
+        assert np.allclose(np.concatenate(out["results_r"]), g["t_%s_results_r" % name], rtol=1e-9, atol=1e-12)
+        assert np.allclose(out["results_cwz"], g["t_%s_results_cwz" % name], rtol=1e-9, atol=1e-9)
+        assert np.isclose(out["asdef"], float(g["t_%s_asdef" % name]), rtol=1e-11)
+        zero = np.concatenate(out["results_z"]) == 0
+        assert np.array_equal(zero, g["t_%s_results_z" % name] == 0)        # same removed-bin pattern
+
+
+def test_cfg1_options(wt, cfg1, reference):
+    g = cfg1
+    sample = _split(g["t_gain5_gap_sample"], g["sample_chrom_lengths"])
+    out = wt.test_batch(reference, [sample], 4.0, minrefbins=40, repeats=2, chromosomes=[2, 5, 18])[0]
+    want = g["opts_results_calls"]
+    got = out["results_calls"].reshape(-1, 5)
+    assert np.array_equal(got[:, :3], want[:, :3])
+    assert np.allclose(got[:, 3:], want[:, 3:], rtol=1e-9)
+    assert np.allclose(out["results_cwz"], g["opts_results_cwz"], rtol=1e-9)
+    assert np.allclose(np.concatenate(out["results_z"]), g["opts_results_z"], rtol=1e-9, atol=1e-11)
+    assert np.isclose(out["asdef"], float(g["opts_asdef"]), rtol=1e-11)

@@ -34,7 +34,8 @@ SIGNATURES = {
     "wc_newref_count_buffer": (_vp, [_vp]),
     "wc_newref_list_buffer": (_vp, [_vp, _vp]),
     "wc_newref_finish_dev": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
-    "wc_reference_create": (_vp, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32]),
+    "wc_reference_create": (_vp, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "wc_apply_pca": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _i32, _vp]),
     "wc_reference_destroy": (None, [_vp]),
     "wc_reference_cutoff": (_dbl, [_vp]),
     "wc_optimal_cutoff": (_i32, [_vp, _vp, _i64, _i32, _vp]),

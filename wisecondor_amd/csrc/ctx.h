@@ -25,9 +25,21 @@ struct NewrefState {
     wc::DevBuf fb_rows, fb_count, fb_scratch, stats;
 };
 
+// Workspaces of the batched test path (grow-only, reused across calls).
+struct TestState {
+    wc::DevBuf counts, totals, raw, proj, data, xt, xc, zt, rt, nt, sdt, z, r, n, sd_avg;
+    wc::DevBuf zc, rc, gpos, clean_n, regions, sel;
+    wc::DevBuf res_z, res_r, cwz, calls, n_calls;
+    // Stouffer search
+    wc::DevBuf prefix, reg_abs, reg_flag, rs, jobs_a, jobs_b, job_cnt, partial, job_res, hot, cand, cand_cnt;
+    wc::DevBuf seg, seg_cnt, out_val, out_x, out_y, out_n, whole, effect, misc, reduce_tmp;
+    int64_t rs_len = 0;
+};
+
 struct wc_ctx {
     int device = 0;
     NewrefState nr;
+    TestState ts;
     wc::DevBuf tmp_a, tmp_b, tmp_c, tmp_d;  // host-pointer API staging
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
@@ -37,6 +49,12 @@ struct wc_ctx {
         return {&nr.col_partial, &nr.col_mean, &nr.a32, &nr.norm_lo, &nr.norm_hi, &nr.chrom_of_row,
                 &nr.chrom_off_dev, &nr.sample_rows, &nr.s32, &nr.s_norm_lo, &nr.s_chrom, &nr.keys1,
                 &nr.thr, &nr.cnt, &nr.list, &nr.tiles, &nr.fb_rows, &nr.fb_count, &nr.fb_scratch,
-                &nr.stats, &tmp_a, &tmp_b, &tmp_c, &tmp_d};
+                &nr.stats, &tmp_a, &tmp_b, &tmp_c, &tmp_d,
+                &ts.counts, &ts.totals, &ts.raw, &ts.proj, &ts.data, &ts.xt, &ts.xc, &ts.zt, &ts.rt, &ts.nt,
+                &ts.sdt, &ts.z, &ts.r, &ts.n, &ts.sd_avg, &ts.zc, &ts.rc, &ts.gpos, &ts.clean_n, &ts.regions,
+                &ts.sel, &ts.res_z, &ts.res_r, &ts.cwz, &ts.calls, &ts.n_calls, &ts.prefix, &ts.reg_abs,
+                &ts.reg_flag, &ts.rs, &ts.jobs_a, &ts.jobs_b, &ts.job_cnt, &ts.partial, &ts.job_res, &ts.hot,
+                &ts.cand, &ts.cand_cnt, &ts.seg, &ts.seg_cnt, &ts.out_val, &ts.out_x, &ts.out_y, &ts.out_n,
+                &ts.whole, &ts.effect, &ts.misc, &ts.reduce_tmp};
     }
 };

@@ -1,23 +1,1263 @@
-// placeholder until the test-path kernels land (replaced in the next commit)
+// test path on gfx950: sample preparation + PCA-apply, masked z-score repeats,
+// minrefbins cleaning, Stouffer window segmentation, call mapping, inflation.
+//
+// Replaces (per batch of samples) toNumpyRefFormat / applyPCA / getOptimalCutoff /
+// trySample / repeatTest / fillTri / TriArr.segmentTri and the numeric part of
+// toolTest (wisetools.py:104-113, 267-278, 328-336, 407-448, 466-472;
+// triarray.py:59-84; wisecondor.py:199-268).  Everything is float64: these stages
+// are gather/HBM or fp64-ALU bound, and the reference's flags and segment bounds
+// hinge on exact comparisons.
 #include "ctx.h"
-struct wc_reference { int unused; };
-#define NOTYET wc::set_error("test path not built yet"); return WC_E_INTERNAL
+
+#include <algorithm>
+
+struct wc_reference {
+    wc_ctx *ctx = nullptr;
+    int64_t B = 0, Btot = 0;
+    int k = 0, n_chrom = 0, n_comp = 0;
+    int64_t moff[WC_MAX_CHROM + 1] = {0};  // masked-bin offsets per chromosome
+    int64_t goff[WC_MAX_CHROM + 1] = {0};  // genomic-bin offsets per chromosome
+    double cutoff = 0.0;
+    wc::DevBuf gidx, nref, pca_mean, pca_comp, m2g, g2m, moff_dev, goff_dev;
+};
+
+namespace {
+
+constexpr int MAX_COMP = 8;
+constexpr int ROWS_HALF = 32;  // window rows per side handled by one search workgroup
+constexpr int CAND_CAP = 64;
+
+struct Region { long long off; int n; int pad; };
+struct Job { int region, lo, hi, pad; };
+struct Extreme { double maxv, minv; int max_x, max_y, min_x, min_y; };
+struct Seg { double val; int region, x, y, pad; };
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ------------------------------------------------------------- reductions ----
+// mode 0: sum and count of d < cutoff; mode 1: sum of (d-centre)^2 over d < cutoff
+__global__ __launch_bounds__(256) void k_moments1(const double *__restrict__ d, int64_t n, double cutoff,
+                                                  double centre, int mode, double *__restrict__ part) {
+    __shared__ double ss[256], sc[256];
+    double s = 0.0, c = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        double v = d[i];
+        if (v < cutoff) {
+            if (mode == 0) s += v; else { double t = v - centre; s += t * t; }
+            c += 1.0;
+        }
+    }
+    ss[threadIdx.x] = s; sc[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { ss[threadIdx.x] += ss[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = ss[0]; part[2 * blockIdx.x + 1] = sc[0]; }
+}
+
+__global__ __launch_bounds__(256) void k_moments2(const double *__restrict__ part, int nparts,
+                                                  double *__restrict__ out) {
+    __shared__ double ss[256], sc[256];
+    double s = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) { s += part[2 * i]; c += part[2 * i + 1]; }
+    ss[threadIdx.x] = s; sc[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { ss[threadIdx.x] += ss[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = ss[0]; out[1] = sc[0]; }
+}
+
+// getOptimalCutoff (wisetools.py:328-336) with the reductions on the device.
+int device_cutoff(wc_ctx *ctx, const double *d_dev, int64_t count, int repeats, hipStream_t stream, double *out) {
+    int rc;
+    const int G = 1024;
+    if ((rc = ctx->ts.reduce_tmp.reserve(sizeof(double) * (2 * G + 2)))) return rc;
+    double *part = ctx->ts.reduce_tmp.as<double>();
+    double *res = part + 2 * G;
+    double cutoff = INFINITY;
+    for (int it = 0; it < repeats; ++it) {
+        double h[2];
+        hipLaunchKernelGGL(k_moments1, dim3(G), dim3(256), 0, stream, d_dev, count, cutoff, 0.0, 0, part);
+        hipLaunchKernelGGL(k_moments2, dim3(1), dim3(256), 0, stream, (const double *)part, G, res);
+        WC_HIP(hipMemcpyAsync(h, res, sizeof(h), hipMemcpyDeviceToHost, stream));
+        WC_HIP(hipStreamSynchronize(stream));
+        double mean = h[0] / h[1];
+        hipLaunchKernelGGL(k_moments1, dim3(G), dim3(256), 0, stream, d_dev, count, cutoff, mean, 1, part);
+        hipLaunchKernelGGL(k_moments2, dim3(1), dim3(256), 0, stream, (const double *)part, G, res);
+        WC_HIP(hipMemcpyAsync(h, res, sizeof(h), hipMemcpyDeviceToHost, stream));
+        WC_HIP(hipStreamSynchronize(stream));
+        double sd = sqrt(h[0] / h[1]);
+        cutoff = mean + 3 * sd;
+    }
+    *out = cutoff;
+    return WC_OK;
+}
+
+// Per-bin reference lists: index[i][distances[i] < cutoff] (wisetools.py:424) mapped
+// from "other chromosomes" positions (wisetools.py:420-421) to masked-bin numbers.
+__global__ void k_ref_lists(const int *__restrict__ idx, const double *__restrict__ dist, int64_t B, int k,
+                            const int64_t *__restrict__ moff, int n_chrom, double cutoff,
+                            int *__restrict__ gidx, int *__restrict__ nref) {
+    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int c = 0;
+    while (c + 1 < n_chrom && b >= moff[c + 1]) ++c;
+    const int64_t cs = moff[c], ce = moff[c + 1], len = B - (ce - cs);
+    int n = 0;
+    for (int r = 0; r < k; ++r) {
+        if (!(dist[b * k + r] < cutoff)) continue;
+        int64_t p = idx[b * k + r];
+        if (p < 0) p += len;  // numpy negative indexing (the -1 padding picks the last element)
+        int64_t g = p < cs ? p : p + (ce - cs);
+        if (p < 0 || g >= B) g = -1;  // numpy would raise IndexError; dropped here
+        gidx[b * k + n] = (int)g;
+        ++n;
+    }
+    nref[b] = n;
+    for (int r = n; r < k; ++r) gidx[b * k + r] = -1;
+}
+
+// -------------------------------------------------------- sample preparation ----
+__global__ __launch_bounds__(256) void k_sample_totals(const int *__restrict__ counts, int64_t Btot,
+                                                       double *__restrict__ totals) {
+    __shared__ long long sh[256];
+    const int *row = counts + (int64_t)blockIdx.x * Btot;
+    long long s = 0;
+    for (int64_t g = threadIdx.x; g < Btot; g += 256) s += row[g];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = (double)sh[0];  // integer sums are exact in any order
+}
+
+// toNumpyRefFormat (wisetools.py:275-276): x = counts / total, masked bins only
+__global__ void k_normalize(const int *__restrict__ counts, int64_t Btot, const int *__restrict__ m2g, int64_t B,
+                            const double *__restrict__ totals, double *__restrict__ raw) {
+    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t i = blockIdx.y;
+    if (b >= B) return;
+    raw[i * B + b] = (double)counts[i * Btot + m2g[b]] / totals[i];
+}
+
+// applyPCA step 1 (wisetools.py:109): t = (x - mean) . components^T
+__global__ __launch_bounds__(256) void k_pca_project(const double *__restrict__ raw, int64_t B,
+                                                     const double *__restrict__ mean, const double *__restrict__ comp,
+                                                     int n_comp, double *__restrict__ proj) {
+    __shared__ double sh[MAX_COMP][256];
+    const double *x = raw + (int64_t)blockIdx.x * B;
+    double acc[MAX_COMP];
+#pragma unroll
+    for (int c = 0; c < MAX_COMP; ++c) acc[c] = 0.0;
+    for (int64_t b = threadIdx.x; b < B; b += 256) {
+        double d = x[b] - mean[b];
+#pragma unroll
+        for (int c = 0; c < MAX_COMP; ++c)
+            if (c < n_comp) acc[c] += d * comp[(int64_t)c * B + b];
+    }
+#pragma unroll
+    for (int c = 0; c < MAX_COMP; ++c) sh[c][threadIdx.x] = acc[c];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+#pragma unroll
+            for (int c = 0; c < MAX_COMP; ++c) sh[c][threadIdx.x] += sh[c][threadIdx.x + o];
+        __syncthreads();
+    }
+    if ((int)threadIdx.x < n_comp) proj[(int64_t)blockIdx.x * MAX_COMP + threadIdx.x] = sh[threadIdx.x][0];
+}
+
+// applyPCA step 2 (wisetools.py:111-113): x / (t . components + mean)
+__global__ void k_pca_apply(const double *__restrict__ raw, int64_t B, const double *__restrict__ mean,
+                            const double *__restrict__ comp, int n_comp, const double *__restrict__ proj,
+                            double *__restrict__ out) {
+    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t i = blockIdx.y;
+    if (b >= B) return;
+    double rec = 0.0;
+    for (int c = 0; c < n_comp; ++c) rec += proj[i * MAX_COMP + c] * comp[(int64_t)c * B + b];
+    rec += mean[b];
+    out[i * B + b] = raw[i * B + b] / rec;
+}
+
+// [R, C] -> [C, R]
+__global__ void k_transpose(const double *__restrict__ in, int64_t R, int64_t C, double *__restrict__ out) {
+    __shared__ double tile[32][33];
+    int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        int64_t r = r0 + j, c = c0 + threadIdx.x;
+        if (r < R && c < C) tile[j][threadIdx.x] = in[r * C + c];
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        int64_t c = c0 + j, r = r0 + threadIdx.x;
+        if (r < R && c < C) out[c * R + r] = tile[threadIdx.x][j];
+    }
+}
+
+// ------------------------------------------------------------------ z-score ----
+__device__ inline double combine8(const double *r) {
+    return ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+}
+
+// numpy's pairwise sum over the kept values v_0..v_{m-1} (m <= 128) streamed in
+// order: the first m - m%8 values go round-robin into eight accumulators, which
+// are combined before the tail is added sequentially; m < 8 is a plain sum.
+struct StreamSum {
+    double r[8];
+    double res;
+    int pos, body;
+    __device__ inline void init(int m) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = 0.0;
+        res = 0.0;
+        pos = 0;
+        body = m < 8 ? 0 : m - (m & 7);
+    }
+    __device__ inline void push(double v) {
+        if (pos < body) {
+            int slot = pos & 7;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = r[j] + (slot == j ? v : 0.0);
+        } else {
+            if (pos == body) res = combine8(r);
+            res = res + v;
+        }
+        ++pos;
+    }
+    __device__ inline double finish(int m) { return (m == body) ? combine8(r) : res; }
+};
+
+// trySample (wisetools.py:407-435) for every (bin, sample) pair; sample is the
+// fastest index so a wave reads 64 consecutive samples of one reference bin.
+__global__ __launch_bounds__(256) void k_zscore(const double *__restrict__ XT, const double *__restrict__ XC,
+                                                const int *__restrict__ gidx, const int *__restrict__ nref, int k,
+                                                int64_t B, int64_t Ns, double *__restrict__ zT,
+                                                double *__restrict__ rT, double *__restrict__ nT,
+                                                double *__restrict__ sdT) {
+    int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= B * Ns) return;
+    int64_t b = gid / Ns, i = gid - b * Ns;
+    const int *lst = gidx + b * k;
+    const int n = nref[b];
+    int m = 0;
+    for (int r = 0; r < n; ++r) {
+        int g = lst[r];
+        double v = g >= 0 ? XC[(int64_t)g * Ns + i] : -1.0;
+        m += (v >= 0.0);  // flagged (-1), negative and NaN values are dropped (wisetools.py:425)
+    }
+    StreamSum acc;
+    acc.init(m);
+    for (int r = 0; r < n; ++r) {
+        int g = lst[r];
+        double v = g >= 0 ? XC[(int64_t)g * Ns + i] : -1.0;
+        if (v >= 0.0) acc.push(v);
+    }
+    const double mean = acc.finish(m) / (double)m;
+    acc.init(m);
+    for (int r = 0; r < n; ++r) {
+        int g = lst[r];
+        double v = g >= 0 ? XC[(int64_t)g * Ns + i] : -1.0;
+        if (v >= 0.0) {
+            double dv = v - mean;
+            double sq = dv * dv;
+            acc.push(sq);
+        }
+    }
+    const double var = acc.finish(m) / (double)m;
+    const double sd = sqrt(var);
+    const double x = XT[gid];
+    zT[gid] = (x - mean) / sd;
+    rT[gid] = x / mean;
+    nT[gid] = (double)m;
+    sdT[gid] = sd;
+}
+
+// testCopy[abs(z) >= threshold] = -1 (wisetools.py:446)
+__global__ void k_flag(const double *__restrict__ zT, double thr, int64_t n, double *__restrict__ XC) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && fabs(zT[i]) >= thr) XC[i] = -1.0;
+}
+
+// stdDevAvg (wisetools.py:428-435): sequential sum over bins of the non-NaN sds
+__global__ void k_sd_avg(const double *__restrict__ sdT, int64_t B, int64_t Ns, double *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Ns) return;
+    double s = 0.0;
+    long long c = 0;
+    for (int64_t b = 0; b < B; ++b) {
+        double v = sdT[b * Ns + i];
+        if (v == v) { s += v; ++c; }
+    }
+    out[i] = s / (double)c;
+}
+
+// --------------------------------------------------------------- cleaning ----
+// Keep bins with refSizes >= minrefbins (wisecondor.py:215-222); one wave per
+// (sample, selected chromosome) compacts z, r and the genomic position in order.
+__global__ __launch_bounds__(64) void k_clean(const double *__restrict__ zT, const double *__restrict__ rT,
+                                              const double *__restrict__ nT, int64_t B, int64_t Ns,
+                                              const int64_t *__restrict__ moff, const int64_t *__restrict__ goff,
+                                              const int *__restrict__ m2g, const int *__restrict__ sel, int n_sel,
+                                              double minref, double *__restrict__ zc, double *__restrict__ rc,
+                                              int *__restrict__ gpos, Region *__restrict__ regions) {
+    const int lane = threadIdx.x;
+    const int64_t i = blockIdx.y;
+    const int si = blockIdx.x;
+    const int c = sel[si];
+    const int64_t cs = moff[c], ce = moff[c + 1];
+    int count = 0;
+    for (int64_t base = cs; base < ce; base += 64) {
+        int64_t b = base + lane;
+        bool keep = false;
+        if (b < ce) keep = nT[b * Ns + i] >= minref;
+        unsigned long long mask = __ballot(keep);
+        if (keep) {
+            int at = count + __popcll(mask & ((1ull << lane) - 1ull));
+            zc[i * B + cs + at] = zT[b * Ns + i];
+            rc[i * B + cs + at] = rT[b * Ns + i];
+            gpos[i * B + cs + at] = (int)(m2g[b] - goff[c]);
+        }
+        count += __popcll(mask);
+    }
+    if (lane == 0) {
+        Region rg;
+        rg.off = i * B + cs;
+        rg.n = count;
+        rg.pad = c;
+        regions[i * n_sel + si] = rg;
+    }
+}
+
+// inflateArrayMulti + per-chromosome split (wisetools.py:281-295, wisecondor.py:260-268)
+__global__ void k_inflate(const double *__restrict__ zT, const double *__restrict__ rT, const double *__restrict__ nT,
+                          int64_t Ns, int64_t Btot, const int *__restrict__ g2m, double minref,
+                          double *__restrict__ res_z, double *__restrict__ res_r) {
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t i = blockIdx.y;
+    if (g >= Btot) return;
+    int m = g2m[g];
+    double z = 0.0, r = 0.0;
+    if (m >= 0 && nT[(int64_t)m * Ns + i] >= minref) {
+        z = zT[(int64_t)m * Ns + i];
+        r = rT[(int64_t)m * Ns + i] - 1.0;
+    }
+    if (res_z) res_z[i * Btot + g] = z;
+    if (res_r) res_r[i * Btot + g] = r;
+}
+
+// ------------------------------------------------------- Stouffer windows ----
+__global__ void k_fill_rs(double *rs, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rs[i] = i > 0 ? 1.0 / sqrt((double)i) : 0.0;
+}
+
+// Sequential prefix sums, sum |z| and a finiteness flag per region.
+__global__ void k_region_prefix(const double *__restrict__ z, const Region *__restrict__ regions, int64_t n_regions,
+                                double *__restrict__ prefix, double *__restrict__ reg_abs, int *__restrict__ reg_flag) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_regions) return;
+    const Region rg = regions[r];
+    const double *zz = z + rg.off;
+    double *P = prefix + rg.off + r;
+    double s = 0.0, a = 0.0;
+    int finite = 1;
+    P[0] = 0.0;
+    for (int t = 0; t < rg.n; ++t) {
+        double v = zz[t];
+        if (!isfinite(v)) finite = 0;
+        s += v;
+        a += fabs(v);
+        P[t + 1] = s;
+    }
+    reg_abs[r] = a;
+    reg_flag[r] = finite;
+}
+
+// Exact value of window [x, y]: np_sum(z[x:y+1]) / np_sqrt(y-x+1) (wisetools.py:471)
+template <bool GROUP8> __device__ inline double window_exact(const double *__restrict__ zz, int x, int y, int sub) {
+    const double *p = zz + x;
+    double s = wc::pairwise_sum<GROUP8>([&](int64_t t) { return p[t]; }, (int64_t)(y - x + 1), sub);
+    return s / sqrt((double)(y - x + 1));
+}
+
+__global__ __launch_bounds__(256) void k_region_whole(const double *__restrict__ z, const Region *__restrict__ regions,
+                                                      int64_t n_regions, double *__restrict__ whole) {
+    int64_t r = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+    int sub = threadIdx.x & 7;
+    bool in = r < n_regions;
+    Region rg = regions[in ? r : 0];
+    double v = rg.n > 0 ? window_exact<true>(z + rg.off, 0, rg.n - 1, sub) : NAN;
+    if (in && sub == 0) whole[r] = v;
+}
+
+__global__ void k_init_jobs(const Region *__restrict__ regions, int64_t n_regions, Job *__restrict__ jobs) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_regions) return;
+    Job j;
+    j.region = (int)r;
+    j.lo = 0;
+    j.hi = regions[r].n;
+    j.pad = 0;
+    jobs[r] = j;
+}
+
+struct ScanCtx {
+    const double *P;   // prefix of the region
+    int lo, hi, L, half, chunk;
+};
+
+// Rows handled by (job, chunk): ROWS_HALF rows from the top of the triangle and the
+// ROWS_HALF mirrored rows from the bottom, so every workgroup sees ~ the same work.
+template <class F> __device__ inline void scan_chunk(const ScanCtx &c, const double *__restrict__ rs, int tid, F f) {
+    for (int s = 0; s < 2 * ROWS_HALF; ++s) {
+        int xr;
+        if (s < ROWS_HALF) {
+            xr = c.chunk * ROWS_HALF + s;
+            if (xr >= c.half) continue;
+        } else {
+            xr = c.L - 1 - (c.chunk * ROWS_HALF + (s - ROWS_HALF));
+            if (xr < c.half) continue;
+        }
+        const int x = c.lo + xr;
+        const double px = c.P[x];
+        for (int y = x + tid; y < c.hi; y += 256) {
+            double v = (c.P[y + 1] - px) * rs[y - x + 1];
+            f(v, x, y);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_seg_search(const Job *__restrict__ jobs, int n_jobs,
+                                                    const Region *__restrict__ regions,
+                                                    const double *__restrict__ prefix, const double *__restrict__ rs,
+                                                    const int *__restrict__ reg_flag, int max_chunks,
+                                                    Extreme *__restrict__ partial) {
+    __shared__ double smax[256], smin[256];
+    __shared__ int sx[256], sy[256], tx[256], ty[256];
+    const int j = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    if (j >= n_jobs) return;
+    const Job job = jobs[j];
+    ScanCtx c;
+    c.lo = job.lo; c.hi = job.hi; c.L = job.hi - job.lo; c.half = (c.L + 1) / 2; c.chunk = chunk;
+    if (c.L <= 0 || chunk * ROWS_HALF >= c.half) return;
+    if (!reg_flag[job.region]) return;  // non-finite region: exact brute-force path
+    c.P = prefix + regions[job.region].off + job.region;
+    double bmax = -INFINITY, bmin = INFINITY;
+    int mx = -1, my = -1, nx = -1, ny = -1;
+    scan_chunk(c, rs, tid, [&](double v, int x, int y) {
+        if (v > bmax) { bmax = v; mx = x; my = y; }
+        if (v < bmin) { bmin = v; nx = x; ny = y; }
+    });
+    smax[tid] = bmax; smin[tid] = bmin; sx[tid] = mx; sy[tid] = my; tx[tid] = nx; ty[tid] = ny;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            if (smax[tid + o] > smax[tid]) { smax[tid] = smax[tid + o]; sx[tid] = sx[tid + o]; sy[tid] = sy[tid + o]; }
+            if (smin[tid + o] < smin[tid]) { smin[tid] = smin[tid + o]; tx[tid] = tx[tid + o]; ty[tid] = ty[tid + o]; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        Extreme e;
+        e.maxv = smax[0]; e.minv = smin[0]; e.max_x = sx[0]; e.max_y = sy[0]; e.min_x = tx[0]; e.min_y = ty[0];
+        partial[(int64_t)j * max_chunks + chunk] = e;
+    }
+}
+
+// error bound of the prefix-sum window value against numpy's exact value
+__device__ inline double window_eps(int n, double abs_sum) {
+    return (2.0 * n + 64.0) * 1.1102230246251565e-16 * abs_sum;
+}
+
+// One wave per job: merge chunk results, then classify: quiet (no call possible),
+// hot (exact evaluation of the near-extreme windows) or brute (non-finite region).
+__global__ __launch_bounds__(64) void k_seg_classify(const Job *__restrict__ jobs, int n_jobs,
+                                                     const Region *__restrict__ regions,
+                                                     const double *__restrict__ reg_abs, const int *__restrict__ reg_flag,
+                                                     const Extreme *__restrict__ partial, int max_chunks, double thr,
+                                                     Extreme *__restrict__ job_res, int *__restrict__ hot,
+                                                     int *__restrict__ brute, int *__restrict__ counters) {
+    const int j = blockIdx.x, lane = threadIdx.x;
+    if (j >= n_jobs) return;
+    const Job job = jobs[j];
+    const int L = job.hi - job.lo;
+    if (L <= 0) return;
+    if (!reg_flag[job.region]) {
+        if (lane == 0) brute[atomicAdd(&counters[3], 1)] = j;
+        return;
+    }
+    const int nch = (int)(((L + 1) / 2 + ROWS_HALF - 1) / ROWS_HALF);
+    Extreme e;
+    e.maxv = -INFINITY; e.minv = INFINITY; e.max_x = e.max_y = e.min_x = e.min_y = -1;
+    for (int ch = lane; ch < nch; ch += 64) {
+        Extreme p = partial[(int64_t)j * max_chunks + ch];
+        if (p.maxv > e.maxv) { e.maxv = p.maxv; e.max_x = p.max_x; e.max_y = p.max_y; }
+        if (p.minv < e.minv) { e.minv = p.minv; e.min_x = p.min_x; e.min_y = p.min_y; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        double ov = __shfl_xor(e.maxv, o);
+        int ox = __shfl_xor(e.max_x, o), oy = __shfl_xor(e.max_y, o);
+        if (ov > e.maxv) { e.maxv = ov; e.max_x = ox; e.max_y = oy; }
+        double uv = __shfl_xor(e.minv, o);
+        int ux = __shfl_xor(e.min_x, o), uy = __shfl_xor(e.min_y, o);
+        if (uv < e.minv) { e.minv = uv; e.min_x = ux; e.min_y = uy; }
+    }
+    if (lane == 0) {
+        job_res[j] = e;
+        double eps = window_eps(regions[job.region].n, reg_abs[job.region]);
+        double big = fmax(fabs(e.maxv), fabs(e.minv));
+        if (!(big + eps < thr)) hot[atomicAdd(&counters[2], 1)] = j;
+    }
+}
+
+// Second scan of the hot jobs: every window within 2 eps of the approximate
+// maximum (minimum) could be numpy's argmax (argmin); list them for exact scoring.
+__global__ __launch_bounds__(256) void k_seg_collect(const Job *__restrict__ jobs, const int *__restrict__ hot,
+                                                     const int *__restrict__ counters,
+                                                     const Region *__restrict__ regions,
+                                                     const double *__restrict__ prefix, const double *__restrict__ rs,
+                                                     const double *__restrict__ reg_abs,
+                                                     const Extreme *__restrict__ job_res, int2 *__restrict__ cand,
+                                                     int *__restrict__ cand_cnt) {
+    const int h = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    if (h >= counters[2]) return;
+    const int j = hot[h];
+    const Job job = jobs[j];
+    ScanCtx c;
+    c.lo = job.lo; c.hi = job.hi; c.L = job.hi - job.lo; c.half = (c.L + 1) / 2; c.chunk = chunk;
+    if (chunk * ROWS_HALF >= c.half) return;
+    c.P = prefix + regions[job.region].off + job.region;
+    const double eps2 = 2.0 * window_eps(regions[job.region].n, reg_abs[job.region]);
+    const Extreme e = job_res[j];
+    const double hi_cut = e.maxv - eps2, lo_cut = e.minv + eps2;
+    scan_chunk(c, rs, tid, [&](double v, int x, int y) {
+        if (v >= hi_cut) {
+            int at = atomicAdd(&cand_cnt[2 * h], 1);
+            if (at < CAND_CAP) cand[((int64_t)2 * h) * CAND_CAP + at] = make_int2(x, y);
+        }
+        if (v <= lo_cut) {
+            int at = atomicAdd(&cand_cnt[2 * h + 1], 1);
+            if (at < CAND_CAP) cand[((int64_t)2 * h + 1) * CAND_CAP + at] = make_int2(x, y);
+        }
+    });
+}
+
+// The decision of TriArr.segmentTri (triarray.py:59-84) given the exact extremes.
+__device__ inline void decide_emit(const Job &job, double maxv, int mx, int my, double minv, int nx, int ny,
+                                   double thr, int min_search, Seg *segs, int seg_cap, Job *next, int job_cap,
+                                   int *counters) {
+    double champ = maxv;
+    int cx = mx, cy = my;
+    if (fabs(minv) > champ) { champ = minv; cx = nx; cy = ny; }
+    if (fabs(champ) < thr) return;
+    int at = atomicAdd(&counters[4], 1);
+    if (at < seg_cap) {
+        Seg s;
+        s.val = champ; s.region = job.region; s.x = cx; s.y = cy; s.pad = 0;
+        segs[at] = s;
+    }
+    const int xr = cx - job.lo, yr = cy - job.lo, edge = job.hi - job.lo;
+    if (xr > min_search) {
+        int p = atomicAdd(&counters[1], 1);
+        if (p < job_cap) { Job n; n.region = job.region; n.lo = job.lo; n.hi = cx; n.pad = 0; next[p] = n; }
+    }
+    if (yr + 1 < edge - min_search) {
+        int p = atomicAdd(&counters[1], 1);
+        if (p < job_cap) { Job n; n.region = job.region; n.lo = cy + 1; n.hi = job.hi; n.pad = 0; next[p] = n; }
+    }
+}
+
+// numpy argmax/argmin order: the first NaN wins, otherwise the extreme value with
+// the lowest linear (row-major by x, then y) position.
+__device__ inline bool better_max(double v, int x, int y, double bv, int bx, int by) {
+    if (bx < 0) return true;
+    bool vn = v != v, bn = bv != bv;
+    if (bn) return vn && (x < bx || (x == bx && y < by));
+    if (vn) return true;
+    if (v > bv) return true;
+    return v == bv && (x < bx || (x == bx && y < by));
+}
+__device__ inline bool better_min(double v, int x, int y, double bv, int bx, int by) {
+    if (bx < 0) return true;
+    bool vn = v != v, bn = bv != bv;
+    if (bn) return vn && (x < bx || (x == bx && y < by));
+    if (vn) return true;
+    if (v < bv) return true;
+    return v == bv && (x < bx || (x == bx && y < by));
+}
+
+struct BestPair {
+    double maxv, minv;
+    int mx, my, nx, ny;
+};
+
+__device__ inline void block_best(BestPair &b, int tid) {
+    __shared__ double smax[256], smin[256];
+    __shared__ int sx[256], sy[256], tx[256], ty[256];
+    smax[tid] = b.maxv; smin[tid] = b.minv; sx[tid] = b.mx; sy[tid] = b.my; tx[tid] = b.nx; ty[tid] = b.ny;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            if (sx[tid + o] >= 0 && better_max(smax[tid + o], sx[tid + o], sy[tid + o], smax[tid], sx[tid], sy[tid])) {
+                smax[tid] = smax[tid + o]; sx[tid] = sx[tid + o]; sy[tid] = sy[tid + o];
+            }
+            if (tx[tid + o] >= 0 && better_min(smin[tid + o], tx[tid + o], ty[tid + o], smin[tid], tx[tid], ty[tid])) {
+                smin[tid] = smin[tid + o]; tx[tid] = tx[tid + o]; ty[tid] = ty[tid + o];
+            }
+        }
+        __syncthreads();
+    }
+    b.maxv = smax[0]; b.minv = smin[0]; b.mx = sx[0]; b.my = sy[0]; b.nx = tx[0]; b.ny = ty[0];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_seg_decide(const Job *__restrict__ jobs, const int *__restrict__ hot,
+                                                    int *__restrict__ counters, const Region *__restrict__ regions,
+                                                    const double *__restrict__ z, const int2 *__restrict__ cand,
+                                                    const int *__restrict__ cand_cnt, double thr, int min_search,
+                                                    Seg *__restrict__ segs, int seg_cap, Job *__restrict__ next,
+                                                    int job_cap, int *__restrict__ brute) {
+    const int h = blockIdx.x, tid = threadIdx.x;
+    if (h >= counters[2]) return;
+    const int j = hot[h];
+    const Job job = jobs[j];
+    const int n_hi = cand_cnt[2 * h], n_lo = cand_cnt[2 * h + 1];
+    if (n_hi > CAND_CAP || n_lo > CAND_CAP) {  // massive ties: evaluate everything exactly
+        if (tid == 0) brute[atomicAdd(&counters[3], 1)] = j;
+        return;
+    }
+    const double *zz = z + regions[job.region].off;
+    const int grp = tid >> 3, sub = tid & 7;
+    BestPair b;
+    b.maxv = 0.0; b.minv = 0.0; b.mx = b.my = b.nx = b.ny = -1;
+    for (int base = 0; base < CAND_CAP; base += 32) {
+        int t = base + grp;
+        {
+            bool act = t < n_hi;
+            int2 w = cand[((int64_t)2 * h) * CAND_CAP + (act ? t : 0)];
+            double v = n_hi > 0 ? window_exact<true>(zz, w.x, w.y, sub) : 0.0;
+            if (act && sub == 0 && better_max(v, w.x, w.y, b.maxv, b.mx, b.my)) { b.maxv = v; b.mx = w.x; b.my = w.y; }
+        }
+        {
+            bool act = t < n_lo;
+            int2 w = cand[((int64_t)2 * h + 1) * CAND_CAP + (act ? t : 0)];
+            double v = n_lo > 0 ? window_exact<true>(zz, w.x, w.y, sub) : 0.0;
+            if (act && sub == 0 && better_min(v, w.x, w.y, b.minv, b.nx, b.ny)) { b.minv = v; b.nx = w.x; b.ny = w.y; }
+        }
+    }
+    block_best(b, tid);
+    if (tid == 0)
+        decide_emit(job, b.maxv, b.mx, b.my, b.minv, b.nx, b.ny, thr, min_search, segs, seg_cap, next, job_cap, counters);
+}
+
+// Exact evaluation of every window of a job (non-finite input or tie overflow).
+__global__ __launch_bounds__(256) void k_seg_brute(const Job *__restrict__ jobs, const int *__restrict__ brute,
+                                                   int *__restrict__ counters, const Region *__restrict__ regions,
+                                                   const double *__restrict__ z, double thr, int min_search,
+                                                   Seg *__restrict__ segs, int seg_cap, Job *__restrict__ next,
+                                                   int job_cap) {
+    const int q = blockIdx.x, tid = threadIdx.x;
+    if (q >= counters[3]) return;
+    const Job job = jobs[brute[q]];
+    const double *zz = z + regions[job.region].off;
+    BestPair b;
+    b.maxv = 0.0; b.minv = 0.0; b.mx = b.my = b.nx = b.ny = -1;
+    for (int x = job.lo; x < job.hi; ++x)
+        for (int y = x + tid; y < job.hi; y += 256) {
+            double v = window_exact<false>(zz, x, y, 0);
+            if (better_max(v, x, y, b.maxv, b.mx, b.my)) { b.maxv = v; b.mx = x; b.my = y; }
+            if (better_min(v, x, y, b.minv, b.nx, b.ny)) { b.minv = v; b.nx = x; b.ny = y; }
+        }
+    block_best(b, tid);
+    if (tid == 0 && b.mx >= 0)
+        decide_emit(job, b.maxv, b.mx, b.my, b.minv, b.nx, b.ny, thr, min_search, segs, seg_cap, next, job_cap, counters);
+}
+
+// Order each region's segments by position (the reference's in-order recursion).
+__global__ void k_seg_gather(const Seg *__restrict__ segs, int n_segs, int max_calls, double *__restrict__ out_val,
+                             int *__restrict__ out_x, int *__restrict__ out_y, int *__restrict__ out_n) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_segs) return;
+    const Seg me = segs[s];
+    int rank = 0;
+    for (int t = 0; t < n_segs; ++t) {
+        const Seg o = segs[t];
+        if (o.region == me.region && o.x < me.x) ++rank;
+    }
+    atomicAdd(&out_n[me.region], 1);
+    if (rank < max_calls) {
+        int64_t at = (int64_t)me.region * max_calls + rank;
+        out_val[at] = me.val;
+        out_x[at] = me.x;
+        out_y[at] = me.y;
+    }
+}
+
+// Call coordinates and effect size (wisecondor.py:239-257): one workgroup per call.
+__global__ __launch_bounds__(256) void k_call_post(const Region *__restrict__ regions, const double *__restrict__ rc,
+                                                   const int *__restrict__ gpos, const double *__restrict__ out_val,
+                                                   const int *__restrict__ out_x, const int *__restrict__ out_y,
+                                                   const int *__restrict__ out_n, int max_calls,
+                                                   double *__restrict__ reg_calls) {
+    __shared__ double pick[2];
+    __shared__ int has_nan;
+    const int r = blockIdx.y, cidx = blockIdx.x, tid = threadIdx.x;
+    int n = out_n[r];
+    if (n > max_calls) n = max_calls;
+    if (cidx >= n) return;
+    const Region rg = regions[r];
+    const int64_t at = (int64_t)r * max_calls + cidx;
+    const int x = out_x[at], y = out_y[at];
+    const double *v = rc + rg.off + x;
+    const int L = y - x + 1;
+    if (tid == 0) { has_nan = 0; pick[0] = pick[1] = 0.0; }
+    __syncthreads();
+    const int klo = (L - 1) / 2, khi = L / 2;
+    for (int e = tid; e < L; e += 256) {
+        double ve = v[e];
+        if (ve != ve) { has_nan = 1; continue; }
+        int rank = 0;
+        for (int f = 0; f < L; ++f) {
+            double vf = v[f];
+            rank += (vf < ve) || (vf == ve && f < e);
+        }
+        if (rank == klo) pick[0] = ve;
+        if (rank == khi) pick[1] = ve;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double med = (L & 1) ? pick[0] : (pick[0] + pick[1]) / 2.0;  // np.median: mean of the middle pair
+        if (has_nan) med = NAN;
+        // the end walk of the reference restarts at `start` and re-counts it:
+        // end = position(survivor y-1) + 1, or start itself when y == x
+        int start = gpos[rg.off + x];
+        int end = (y > x) ? gpos[rg.off + y - 1] + 1 : start;
+        double *o = reg_calls + at * 5;
+        o[0] = (double)(rg.pad + 1);
+        o[1] = (double)start;
+        o[2] = (double)end;
+        o[3] = out_val[at];
+        o[4] = med - 1.0;
+    }
+}
+
+__global__ void k_assemble_calls(const double *__restrict__ reg_calls, const int *__restrict__ out_n, int n_sel,
+                                 int max_calls, int64_t Ns, double *__restrict__ calls, int *__restrict__ n_calls,
+                                 int *__restrict__ overflow) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Ns) return;
+    int total = 0;
+    for (int s = 0; s < n_sel; ++s) {
+        int64_t r = i * n_sel + s;
+        int n = out_n[r];
+        if (n > max_calls) { *overflow = 1; n = max_calls; }
+        for (int c = 0; c < n; ++c) {
+            if (total < max_calls) {
+                for (int f = 0; f < 5; ++f)
+                    calls[(i * max_calls + total) * 5 + f] = reg_calls[(r * max_calls + c) * 5 + f];
+            } else {
+                *overflow = 1;
+            }
+            ++total;
+        }
+    }
+    n_calls[i] = total < max_calls ? total : max_calls;
+}
+
+// ------------------------------------------------------------ host drivers ----
+int run_prepare(wc_ctx *ctx, const wc_reference *ref, const int *counts_dev, int64_t Ns, hipStream_t stream) {
+    TestState &ts = ctx->ts;
+    int rc;
+    if ((rc = ts.totals.reserve(sizeof(double) * Ns))) return rc;
+    if ((rc = ts.raw.reserve(sizeof(double) * Ns * ref->B))) return rc;
+    if ((rc = ts.proj.reserve(sizeof(double) * Ns * MAX_COMP))) return rc;
+    if ((rc = ts.data.reserve(sizeof(double) * Ns * ref->B))) return rc;
+    hipLaunchKernelGGL(k_sample_totals, dim3((unsigned)Ns), dim3(256), 0, stream, counts_dev, ref->Btot,
+                       ts.totals.as<double>());
+    dim3 g((unsigned)cdiv(ref->B, 256), (unsigned)Ns);
+    hipLaunchKernelGGL(k_normalize, g, dim3(256), 0, stream, counts_dev, ref->Btot, (const int *)ref->m2g.as<int>(),
+                       ref->B, (const double *)ts.totals.as<double>(), ts.raw.as<double>());
+    hipLaunchKernelGGL(k_pca_project, dim3((unsigned)Ns), dim3(256), 0, stream, (const double *)ts.raw.as<double>(),
+                       ref->B, (const double *)ref->pca_mean.as<double>(), (const double *)ref->pca_comp.as<double>(),
+                       ref->n_comp, ts.proj.as<double>());
+    hipLaunchKernelGGL(k_pca_apply, g, dim3(256), 0, stream, (const double *)ts.raw.as<double>(), ref->B,
+                       (const double *)ref->pca_mean.as<double>(), (const double *)ref->pca_comp.as<double>(),
+                       ref->n_comp, (const double *)ts.proj.as<double>(), ts.data.as<double>());
+    WC_HIP(hipGetLastError());
+    return WC_OK;
+}
+
+void launch_transpose(const double *in, int64_t R, int64_t C, double *out, hipStream_t stream) {
+    dim3 g((unsigned)cdiv(C, 32), (unsigned)cdiv(R, 32));
+    hipLaunchKernelGGL(k_transpose, g, dim3(32, 8), 0, stream, in, R, C, out);
+}
+
+// repeatTest on device data [Ns, B]; leaves zt/rt/nt/sdt as [B, Ns] and sd_avg[Ns]
+int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int64_t Ns, double thr, int repeats,
+               hipStream_t stream) {
+    TestState &ts = ctx->ts;
+    const int64_t n = ref->B * Ns;
+    int rc;
+    for (wc::DevBuf *b : {&ts.xt, &ts.xc, &ts.zt, &ts.rt, &ts.nt, &ts.sdt})
+        if ((rc = b->reserve(sizeof(double) * n))) return rc;
+    if ((rc = ts.sd_avg.reserve(sizeof(double) * Ns))) return rc;
+    launch_transpose(data_dev, Ns, ref->B, ts.xt.as<double>(), stream);
+    WC_HIP(hipMemcpyAsync(ts.xc.p, ts.xt.p, sizeof(double) * n, hipMemcpyDeviceToDevice, stream));
+    const unsigned g = (unsigned)cdiv(n, 256);
+    if (repeats < 1) {  // the reference would return None; give NaNs
+        WC_HIP(hipMemsetAsync(ts.zt.p, 0xFF, sizeof(double) * n, stream));
+        WC_HIP(hipMemsetAsync(ts.rt.p, 0xFF, sizeof(double) * n, stream));
+        WC_HIP(hipMemsetAsync(ts.nt.p, 0, sizeof(double) * n, stream));
+        WC_HIP(hipMemsetAsync(ts.sdt.p, 0xFF, sizeof(double) * n, stream));
+    }
+    for (int it = 0; it < repeats; ++it) {
+        hipLaunchKernelGGL(k_zscore, dim3(g), dim3(256), 0, stream, (const double *)ts.xt.as<double>(),
+                           (const double *)ts.xc.as<double>(), (const int *)ref->gidx.as<int>(),
+                           (const int *)ref->nref.as<int>(), ref->k, ref->B, Ns, ts.zt.as<double>(),
+                           ts.rt.as<double>(), ts.nt.as<double>(), ts.sdt.as<double>());
+        hipLaunchKernelGGL(k_flag, dim3(g), dim3(256), 0, stream, (const double *)ts.zt.as<double>(), thr, n,
+                           ts.xc.as<double>());
+    }
+    hipLaunchKernelGGL(k_sd_avg, dim3((unsigned)cdiv(Ns, 64)), dim3(64), 0, stream,
+                       (const double *)ts.sdt.as<double>(), ref->B, Ns, ts.sd_avg.as<double>());
+    WC_HIP(hipGetLastError());
+    return WC_OK;
+}
+
+// Segment search over device regions.  Results: ts.out_val/out_x/out_y [n_regions, max_calls],
+// ts.out_n [n_regions], ts.whole [n_regions].
+int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, int64_t n_regions, int64_t total_len,
+                 int64_t max_n, double thr, int min_search, int max_calls, hipStream_t stream) {
+    TestState &ts = ctx->ts;
+    int rc;
+    if (n_regions == 0) return WC_OK;
+    const int64_t job_cap = n_regions + total_len / 4 + 64;
+    const int64_t seg_cap = n_regions * (int64_t)max_calls + 64;
+    const int max_chunks = (int)std::max<int64_t>(1, cdiv((max_n + 1) / 2, ROWS_HALF));
+    if ((rc = ts.prefix.reserve(sizeof(double) * (total_len + n_regions + 8)))) return rc;
+    if ((rc = ts.reg_abs.reserve(sizeof(double) * n_regions))) return rc;
+    if ((rc = ts.reg_flag.reserve(sizeof(int) * n_regions))) return rc;
+    if (ts.rs_len < max_n + 2) {
+        if ((rc = ts.rs.reserve(sizeof(double) * (max_n + 2)))) return rc;
+        ts.rs_len = max_n + 2;
+        hipLaunchKernelGGL(k_fill_rs, dim3((unsigned)cdiv(ts.rs_len, 256)), dim3(256), 0, stream, ts.rs.as<double>(),
+                           ts.rs_len);
+    }
+    if ((rc = ts.jobs_a.reserve(sizeof(Job) * job_cap))) return rc;
+    if ((rc = ts.jobs_b.reserve(sizeof(Job) * job_cap))) return rc;
+    if ((rc = ts.job_cnt.reserve(sizeof(int) * 8))) return rc;
+    if ((rc = ts.partial.reserve(sizeof(Extreme) * job_cap * max_chunks))) return rc;
+    if ((rc = ts.job_res.reserve(sizeof(Extreme) * job_cap))) return rc;
+    if ((rc = ts.hot.reserve(sizeof(int) * 2 * job_cap))) return rc;
+    if ((rc = ts.cand.reserve(sizeof(int2) * 2 * CAND_CAP * job_cap))) return rc;
+    if ((rc = ts.cand_cnt.reserve(sizeof(int) * 2 * job_cap))) return rc;
+    if ((rc = ts.seg.reserve(sizeof(Seg) * seg_cap))) return rc;
+    if ((rc = ts.out_val.reserve(sizeof(double) * n_regions * max_calls))) return rc;
+    if ((rc = ts.out_x.reserve(sizeof(int) * n_regions * max_calls))) return rc;
+    if ((rc = ts.out_y.reserve(sizeof(int) * n_regions * max_calls))) return rc;
+    if ((rc = ts.out_n.reserve(sizeof(int) * n_regions))) return rc;
+    if ((rc = ts.whole.reserve(sizeof(double) * n_regions))) return rc;
+
+    int *counters = ts.job_cnt.as<int>();  // [1] next jobs [2] hot [3] brute [4] segments
+    int *hot = ts.hot.as<int>();
+    int *brute = hot + job_cap;
+    WC_HIP(hipMemsetAsync(counters, 0, sizeof(int) * 8, stream));
+    WC_HIP(hipMemsetAsync(ts.out_n.p, 0, sizeof(int) * n_regions, stream));
+    hipLaunchKernelGGL(k_region_prefix, dim3((unsigned)cdiv(n_regions, 64)), dim3(64), 0, stream, z_dev, regions_dev,
+                       n_regions, ts.prefix.as<double>(), ts.reg_abs.as<double>(), ts.reg_flag.as<int>());
+    hipLaunchKernelGGL(k_region_whole, dim3((unsigned)cdiv(n_regions, 32)), dim3(256), 0, stream, z_dev, regions_dev,
+                       n_regions, ts.whole.as<double>());
+    hipLaunchKernelGGL(k_init_jobs, dim3((unsigned)cdiv(n_regions, 256)), dim3(256), 0, stream, regions_dev, n_regions,
+                       ts.jobs_a.as<Job>());
+    Job *cur = ts.jobs_a.as<Job>(), *next = ts.jobs_b.as<Job>();
+    int64_t n_jobs = n_regions;
+    int guard = 0;
+    while (n_jobs > 0) {
+        WC_CHECK(++guard < 100000, WC_E_INTERNAL, "stouffer: recursion did not terminate");
+        WC_HIP(hipMemsetAsync(counters + 1, 0, sizeof(int) * 3, stream));
+        WC_HIP(hipMemsetAsync(ts.cand_cnt.p, 0, sizeof(int) * 2 * n_jobs, stream));
+        dim3 sg((unsigned)max_chunks, (unsigned)n_jobs);
+        hipLaunchKernelGGL(k_seg_search, sg, dim3(256), 0, stream, (const Job *)cur, (int)n_jobs, regions_dev,
+                           (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
+                           (const int *)ts.reg_flag.as<int>(), max_chunks, ts.partial.as<Extreme>());
+        hipLaunchKernelGGL(k_seg_classify, dim3((unsigned)n_jobs), dim3(64), 0, stream, (const Job *)cur, (int)n_jobs,
+                           regions_dev, (const double *)ts.reg_abs.as<double>(), (const int *)ts.reg_flag.as<int>(),
+                           (const Extreme *)ts.partial.as<Extreme>(), max_chunks, thr, ts.job_res.as<Extreme>(), hot,
+                           brute, counters);
+        int h[8];
+        WC_HIP(hipMemcpyAsync(h, counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
+        WC_HIP(hipStreamSynchronize(stream));
+        const int n_hot = h[2];
+        if (n_hot > 0) {
+            hipLaunchKernelGGL(k_seg_collect, dim3((unsigned)max_chunks, (unsigned)n_hot), dim3(256), 0, stream,
+                               (const Job *)cur, (const int *)hot, (const int *)counters, regions_dev,
+                               (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
+                               (const double *)ts.reg_abs.as<double>(), (const Extreme *)ts.job_res.as<Extreme>(),
+                               ts.cand.as<int2>(), ts.cand_cnt.as<int>());
+            hipLaunchKernelGGL(k_seg_decide, dim3((unsigned)n_hot), dim3(256), 0, stream, (const Job *)cur,
+                               (const int *)hot, counters, regions_dev, z_dev, (const int2 *)ts.cand.as<int2>(),
+                               (const int *)ts.cand_cnt.as<int>(), thr, min_search, ts.seg.as<Seg>(), (int)seg_cap,
+                               next, (int)job_cap, brute);
+        }
+        // brute list may have grown in decide; its length is only known on the device
+        hipLaunchKernelGGL(k_seg_brute, dim3((unsigned)n_jobs), dim3(256), 0, stream, (const Job *)cur,
+                           (const int *)brute, counters, regions_dev, z_dev, thr, min_search, ts.seg.as<Seg>(),
+                           (int)seg_cap, next, (int)job_cap);
+        WC_HIP(hipMemcpyAsync(h, counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
+        WC_HIP(hipStreamSynchronize(stream));
+        WC_CHECK(h[1] <= job_cap, WC_E_INTERNAL, "stouffer: job list overflow");
+        WC_CHECK(h[4] <= seg_cap, WC_E_LIMIT, "stouffer: more than max_calls=%d segments per region", max_calls);
+        n_jobs = h[1];
+        std::swap(cur, next);
+    }
+    int h[8];
+    WC_HIP(hipMemcpyAsync(h, counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
+    WC_HIP(hipStreamSynchronize(stream));
+    if (h[4] > 0)
+        hipLaunchKernelGGL(k_seg_gather, dim3((unsigned)cdiv(h[4], 256)), dim3(256), 0, stream,
+                           (const Seg *)ts.seg.as<Seg>(), h[4], max_calls, ts.out_val.as<double>(), ts.out_x.as<int>(),
+                           ts.out_y.as<int>(), ts.out_n.as<int>());
+    WC_HIP(hipGetLastError());
+    return WC_OK;
+}
+
+}  // namespace
+
 extern "C" {
-wc_reference *wc_reference_create(wc_ctx *, const int32_t *, const double *, int64_t, int, const int64_t *,
-                                  const int64_t *, int, const uint8_t *, const double *, const double *, int, int) {
-    wc::set_error("test path not built yet");
-    return nullptr;
+
+int wc_optimal_cutoff(wc_ctx *ctx, const double *distances, int64_t count, int repeats, double *cutoff) {
+    WC_CHECK(ctx && distances && cutoff && count > 0, WC_E_ARG, "getOptimalCutoff: bad argument");
+    WC_HIP(hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ctx->tmp_a.reserve(sizeof(double) * count))) return rc;
+    WC_HIP(hipMemcpy(ctx->tmp_a.p, distances, sizeof(double) * count, hipMemcpyHostToDevice));
+    return device_cutoff(ctx, ctx->tmp_a.as<double>(), count, repeats, nullptr, cutoff);
 }
-void wc_reference_destroy(wc_reference *) {}
-double wc_reference_cutoff(const wc_reference *) { return NAN; }
-int wc_optimal_cutoff(wc_ctx *, const double *, int64_t, int, double *) { NOTYET; }
-int wc_prepare_samples(wc_ctx *, const wc_reference *, const int32_t *, int64_t, double *, double *) { NOTYET; }
-int wc_repeat_test(wc_ctx *, const wc_reference *, const double *, int64_t, double, int, double *, double *,
-                   double *, double *) { NOTYET; }
-int wc_stouffer_segments(wc_ctx *, const double *, const int64_t *, int64_t, double, int, int, double *,
-                         int32_t *, double *, int32_t *, int32_t *) { NOTYET; }
-int wc_test_batch(wc_ctx *, const wc_reference *, const int32_t *, int64_t, double, int, int, const int32_t *,
-                  int, int, double *, double *, double *, double *, int32_t *, double *) { NOTYET; }
-int wc_test_batch_dev(wc_ctx *, void *, const wc_reference *, const int32_t *, int64_t, double, int, int,
-                      const int32_t *, int, int, double *, double *, double *, double *, int32_t *, double *) { NOTYET; }
+
+wc_reference *wc_reference_create(wc_ctx *ctx, const int32_t *indexes, const double *distances, int64_t n_bins,
+                                  int k, const int64_t *chromosome_sizes, const int64_t *masked_sizes, int n_chrom,
+                                  const uint8_t *mask, const double *pca_mean, const double *pca_components,
+                                  int n_comp, int cutoff_repeats, const double *cutoff_override) {
+    auto fail = [&](wc_reference *r) -> wc_reference * {
+        if (r) wc_reference_destroy(r);
+        return nullptr;
+    };
+    if (!ctx || !indexes || !distances || !chromosome_sizes || !masked_sizes || !mask || !pca_mean ||
+        !pca_components) {
+        wc::set_error("reference: NULL argument");
+        return nullptr;
+    }
+    if (n_bins <= 0 || k <= 0 || k > 128 || n_chrom <= 0 || n_chrom > WC_MAX_CHROM || n_comp < 0 ||
+        n_comp > MAX_COMP) {
+        wc::set_error("reference: unsupported shape (bins %lld, refsize %d (max 128), chromosomes %d, components %d)",
+                      (long long)n_bins, k, n_chrom, n_comp);
+        return nullptr;
+    }
+    if (hipSetDevice(ctx->device) != hipSuccess) {
+        wc::set_error("reference: hipSetDevice failed");
+        return nullptr;
+    }
+    wc_reference *ref = new wc_reference();
+    ref->ctx = ctx;
+    ref->B = n_bins;
+    ref->k = k;
+    ref->n_chrom = n_chrom;
+    ref->n_comp = n_comp;
+    for (int c = 0; c < n_chrom; ++c) {
+        ref->moff[c + 1] = ref->moff[c] + masked_sizes[c];
+        ref->goff[c + 1] = ref->goff[c] + chromosome_sizes[c];
+    }
+    ref->Btot = ref->goff[n_chrom];
+    if (ref->moff[n_chrom] != n_bins) {
+        wc::set_error("reference: masked_sizes sum to %lld, indexes have %lld rows", (long long)ref->moff[n_chrom],
+                      (long long)n_bins);
+        return fail(ref);
+    }
+    std::vector<int> m2g(n_bins), g2m(ref->Btot, -1);
+    int64_t at = 0;
+    for (int c = 0; c < n_chrom; ++c) {
+        int64_t in_chrom = 0;
+        for (int64_t g = ref->goff[c]; g < ref->goff[c + 1]; ++g)
+            if (mask[g]) {
+                if (at < n_bins) { m2g[at] = (int)g; g2m[g] = (int)at; }
+                ++at;
+                ++in_chrom;
+            }
+        if (in_chrom != masked_sizes[c]) {
+            wc::set_error("reference: mask has %lld bins on chromosome %d, masked_sizes says %lld", (long long)in_chrom,
+                          c + 1, (long long)masked_sizes[c]);
+            return fail(ref);
+        }
+    }
+    const int64_t nk = n_bins * k;
+    bool ok = ref->gidx.reserve(sizeof(int) * nk) == 0 && ref->nref.reserve(sizeof(int) * n_bins) == 0 &&
+              ref->pca_mean.reserve(sizeof(double) * n_bins) == 0 &&
+              ref->pca_comp.reserve(sizeof(double) * std::max<int64_t>(1, (int64_t)n_comp * n_bins)) == 0 &&
+              ref->m2g.reserve(sizeof(int) * n_bins) == 0 && ref->g2m.reserve(sizeof(int) * ref->Btot) == 0 &&
+              ref->moff_dev.reserve(sizeof(int64_t) * (WC_MAX_CHROM + 1)) == 0 &&
+              ref->goff_dev.reserve(sizeof(int64_t) * (WC_MAX_CHROM + 1)) == 0 &&
+              ctx->tmp_a.reserve(sizeof(double) * nk) == 0 && ctx->tmp_b.reserve(sizeof(int) * nk) == 0;
+    if (!ok) return fail(ref);
+    bool cp = hipMemcpy(ctx->tmp_a.p, distances, sizeof(double) * nk, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(ctx->tmp_b.p, indexes, sizeof(int) * nk, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(ref->pca_mean.p, pca_mean, sizeof(double) * n_bins, hipMemcpyHostToDevice) == hipSuccess &&
+              (n_comp == 0 || hipMemcpy(ref->pca_comp.p, pca_components, sizeof(double) * n_comp * n_bins,
+                                        hipMemcpyHostToDevice) == hipSuccess) &&
+              hipMemcpy(ref->m2g.p, m2g.data(), sizeof(int) * n_bins, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(ref->g2m.p, g2m.data(), sizeof(int) * ref->Btot, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(ref->moff_dev.p, ref->moff, sizeof(int64_t) * (n_chrom + 1), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(ref->goff_dev.p, ref->goff, sizeof(int64_t) * (n_chrom + 1), hipMemcpyHostToDevice) == hipSuccess;
+    if (!cp) {
+        wc::set_error("reference: upload failed: %s", hipGetErrorString(hipGetLastError()));
+        return fail(ref);
+    }
+    if (cutoff_override) {
+        ref->cutoff = *cutoff_override;
+    } else if (device_cutoff(ctx, ctx->tmp_a.as<double>(), nk, cutoff_repeats, nullptr, &ref->cutoff) != WC_OK) {
+        return fail(ref);
+    }
+    hipLaunchKernelGGL(k_ref_lists, dim3((unsigned)cdiv(n_bins, 128)), dim3(128), 0, nullptr,
+                       (const int *)ctx->tmp_b.as<int>(), (const double *)ctx->tmp_a.as<double>(), n_bins, k,
+                       (const int64_t *)ref->moff_dev.as<int64_t>(), n_chrom, ref->cutoff, ref->gidx.as<int>(),
+                       ref->nref.as<int>());
+    if (hipDeviceSynchronize() != hipSuccess) {
+        wc::set_error("reference: list kernel failed: %s", hipGetErrorString(hipGetLastError()));
+        return fail(ref);
+    }
+    return ref;
 }
+
+void wc_reference_destroy(wc_reference *ref) {
+    if (!ref) return;
+    if (ref->ctx) (void)hipSetDevice(ref->ctx->device);
+    (void)hipDeviceSynchronize();
+    for (wc::DevBuf *b : {&ref->gidx, &ref->nref, &ref->pca_mean, &ref->pca_comp, &ref->m2g, &ref->g2m,
+                          &ref->moff_dev, &ref->goff_dev})
+        b->release();
+    delete ref;
+}
+
+double wc_reference_cutoff(const wc_reference *ref) { return ref ? ref->cutoff : NAN; }
+
+int wc_prepare_samples(wc_ctx *ctx, const wc_reference *ref, const int32_t *counts, int64_t n_samples, double *out,
+                       double *raw) {
+    WC_CHECK(ctx && ref && counts && out && n_samples > 0, WC_E_ARG, "prepare: bad argument");
+    WC_HIP(hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ctx->ts.counts.reserve(sizeof(int) * n_samples * ref->Btot))) return rc;
+    WC_HIP(hipMemcpy(ctx->ts.counts.p, counts, sizeof(int) * n_samples * ref->Btot, hipMemcpyHostToDevice));
+    if ((rc = run_prepare(ctx, ref, ctx->ts.counts.as<int>(), n_samples, nullptr))) return rc;
+    WC_HIP(hipDeviceSynchronize());
+    WC_HIP(hipMemcpy(out, ctx->ts.data.p, sizeof(double) * n_samples * ref->B, hipMemcpyDeviceToHost));
+    if (raw) WC_HIP(hipMemcpy(raw, ctx->ts.raw.p, sizeof(double) * n_samples * ref->B, hipMemcpyDeviceToHost));
+    return WC_OK;
+}
+
+int wc_apply_pca(wc_ctx *ctx, const double *samples, int64_t n_samples, int64_t n_bins, const double *pca_mean,
+                 const double *pca_components, int n_comp, double *out) {
+    WC_CHECK(ctx && samples && pca_mean && out && n_samples > 0 && n_bins > 0, WC_E_ARG, "applyPCA: bad argument");
+    WC_CHECK(n_samples <= 60000, WC_E_LIMIT, "applyPCA: more than 60000 samples per call");
+    WC_CHECK(n_comp >= 0 && n_comp <= MAX_COMP && (n_comp == 0 || pca_components), WC_E_ARG,
+             "applyPCA: 0..%d components supported", MAX_COMP);
+    WC_HIP(hipSetDevice(ctx->device));
+    TestState &ts = ctx->ts;
+    int rc;
+    if ((rc = ts.raw.reserve(sizeof(double) * n_samples * n_bins))) return rc;
+    if ((rc = ts.data.reserve(sizeof(double) * n_samples * n_bins))) return rc;
+    if ((rc = ts.proj.reserve(sizeof(double) * n_samples * MAX_COMP))) return rc;
+    if ((rc = ctx->tmp_a.reserve(sizeof(double) * n_bins))) return rc;
+    if ((rc = ctx->tmp_c.reserve(sizeof(double) * std::max<int64_t>(1, (int64_t)n_comp * n_bins)))) return rc;
+    WC_HIP(hipMemcpy(ts.raw.p, samples, sizeof(double) * n_samples * n_bins, hipMemcpyHostToDevice));
+    WC_HIP(hipMemcpy(ctx->tmp_a.p, pca_mean, sizeof(double) * n_bins, hipMemcpyHostToDevice));
+    if (n_comp) WC_HIP(hipMemcpy(ctx->tmp_c.p, pca_components, sizeof(double) * n_comp * n_bins, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_pca_project, dim3((unsigned)n_samples), dim3(256), 0, nullptr,
+                       (const double *)ts.raw.as<double>(), n_bins, (const double *)ctx->tmp_a.as<double>(),
+                       (const double *)ctx->tmp_c.as<double>(), n_comp, ts.proj.as<double>());
+    dim3 g((unsigned)cdiv(n_bins, 256), (unsigned)n_samples);
+    hipLaunchKernelGGL(k_pca_apply, g, dim3(256), 0, nullptr, (const double *)ts.raw.as<double>(), n_bins,
+                       (const double *)ctx->tmp_a.as<double>(), (const double *)ctx->tmp_c.as<double>(), n_comp,
+                       (const double *)ts.proj.as<double>(), ts.data.as<double>());
+    WC_HIP(hipDeviceSynchronize());
+    WC_HIP(hipMemcpy(out, ts.data.p, sizeof(double) * n_samples * n_bins, hipMemcpyDeviceToHost));
+    return WC_OK;
+}
+
+int wc_repeat_test(wc_ctx *ctx, const wc_reference *ref, const double *data, int64_t n_samples, double threshold,
+                   int repeats, double *z, double *r, double *ref_sizes, double *sd_avg) {
+    WC_CHECK(ctx && ref && data && n_samples > 0, WC_E_ARG, "repeatTest: bad argument");
+    WC_HIP(hipSetDevice(ctx->device));
+    TestState &ts = ctx->ts;
+    const int64_t n = n_samples * ref->B;
+    int rc;
+    if ((rc = ts.data.reserve(sizeof(double) * n))) return rc;
+    if ((rc = ts.z.reserve(sizeof(double) * n))) return rc;
+    WC_HIP(hipMemcpy(ts.data.p, data, sizeof(double) * n, hipMemcpyHostToDevice));
+    if ((rc = run_repeat(ctx, ref, ts.data.as<double>(), n_samples, threshold, repeats, nullptr))) return rc;
+    struct { wc::DevBuf *src; double *dst; } outs[] = {{&ts.zt, z}, {&ts.rt, r}, {&ts.nt, ref_sizes}};
+    for (auto &o : outs) {
+        if (!o.dst) continue;
+        launch_transpose(o.src->as<double>(), ref->B, n_samples, ts.z.as<double>(), nullptr);
+        WC_HIP(hipDeviceSynchronize());
+        WC_HIP(hipMemcpy(o.dst, ts.z.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+    }
+    WC_HIP(hipDeviceSynchronize());
+    if (sd_avg) WC_HIP(hipMemcpy(sd_avg, ts.sd_avg.p, sizeof(double) * n_samples, hipMemcpyDeviceToHost));
+    return WC_OK;
+}
+
+int wc_stouffer_segments(wc_ctx *ctx, const double *z, const int64_t *region_offsets, int64_t n_regions,
+                         double threshold, int min_search, int max_calls, double *region_z, int32_t *n_calls,
+                         double *call_value, int32_t *call_x, int32_t *call_y) {
+    WC_CHECK(ctx && z && region_offsets && n_regions >= 0 && max_calls > 0, WC_E_ARG, "segments: bad argument");
+    if (n_regions == 0) return WC_OK;
+    WC_CHECK(n_regions <= 60000, WC_E_LIMIT, "segments: more than 60000 regions per call");
+    WC_HIP(hipSetDevice(ctx->device));
+    TestState &ts = ctx->ts;
+    const int64_t total = region_offsets[n_regions];
+    std::vector<Region> regs(n_regions);
+    int64_t max_n = 0;
+    for (int64_t r = 0; r < n_regions; ++r) {
+        int64_t n = region_offsets[r + 1] - region_offsets[r];
+        WC_CHECK(n >= 0 && n < (1ll << 30), WC_E_ARG, "segments: bad region offsets");
+        regs[r].off = region_offsets[r];
+        regs[r].n = (int)n;
+        regs[r].pad = 0;
+        max_n = std::max(max_n, n);
+    }
+    int rc;
+    if ((rc = ts.zc.reserve(sizeof(double) * std::max<int64_t>(total, 1)))) return rc;
+    if ((rc = ts.regions.reserve(sizeof(Region) * n_regions))) return rc;
+    WC_HIP(hipMemcpy(ts.zc.p, z, sizeof(double) * total, hipMemcpyHostToDevice));
+    WC_HIP(hipMemcpy(ts.regions.p, regs.data(), sizeof(Region) * n_regions, hipMemcpyHostToDevice));
+    if ((rc = run_stouffer(ctx, ts.zc.as<double>(), ts.regions.as<Region>(), n_regions, total, max_n, threshold,
+                           min_search, max_calls, nullptr)))
+        return rc;
+    WC_HIP(hipDeviceSynchronize());
+    if (region_z) WC_HIP(hipMemcpy(region_z, ts.whole.p, sizeof(double) * n_regions, hipMemcpyDeviceToHost));
+    std::vector<int> hn(n_regions);
+    WC_HIP(hipMemcpy(hn.data(), ts.out_n.p, sizeof(int) * n_regions, hipMemcpyDeviceToHost));
+    for (int64_t r = 0; r < n_regions; ++r) {
+        WC_CHECK(hn[r] <= max_calls, WC_E_LIMIT, "segments: region %lld has %d calls, max_calls is %d", (long long)r,
+                 hn[r], max_calls);
+        if (n_calls) n_calls[r] = hn[r];
+    }
+    const int64_t m = n_regions * max_calls;
+    if (call_value) WC_HIP(hipMemcpy(call_value, ts.out_val.p, sizeof(double) * m, hipMemcpyDeviceToHost));
+    if (call_x) WC_HIP(hipMemcpy(call_x, ts.out_x.p, sizeof(int) * m, hipMemcpyDeviceToHost));
+    if (call_y) WC_HIP(hipMemcpy(call_y, ts.out_y.p, sizeof(int) * m, hipMemcpyDeviceToHost));
+    return WC_OK;
+}
+
+int wc_test_batch_dev(wc_ctx *ctx, void *stream_, const wc_reference *ref, const int32_t *counts, int64_t n_samples,
+                      double threshold, int min_ref_bins, int repeats, const int32_t *chromosomes_host, int n_sel,
+                      int max_calls, double *results_z, double *results_r, double *results_cwz, double *calls,
+                      int32_t *n_calls, double *asdef) {
+    WC_CHECK(ctx && ref && counts && n_samples > 0, WC_E_ARG, "test: bad argument");
+    WC_CHECK(n_samples <= 60000, WC_E_LIMIT, "test: more than 60000 samples per call; split the batch");
+    WC_CHECK(n_sel >= 0 && n_sel <= WC_MAX_CHROM && max_calls > 0, WC_E_ARG, "test: bad chromosome selection");
+    WC_CHECK(n_sel == 0 || chromosomes_host, WC_E_ARG, "test: NULL chromosome list");
+    hipStream_t stream = (hipStream_t)stream_;
+    WC_HIP(hipSetDevice(ctx->device));
+    TestState &ts = ctx->ts;
+    const int64_t Ns = n_samples, B = ref->B;
+    int rc;
+    if ((rc = run_prepare(ctx, ref, counts, Ns, stream))) return rc;
+    if ((rc = run_repeat(ctx, ref, ts.data.as<double>(), Ns, threshold, repeats, stream))) return rc;
+    if (asdef) WC_HIP(hipMemcpyAsync(asdef, ts.sd_avg.p, sizeof(double) * Ns, hipMemcpyDeviceToDevice, stream));
+    if (results_z || results_r) {
+        dim3 g((unsigned)cdiv(ref->Btot, 256), (unsigned)Ns);
+        hipLaunchKernelGGL(k_inflate, g, dim3(256), 0, stream, (const double *)ts.zt.as<double>(),
+                           (const double *)ts.rt.as<double>(), (const double *)ts.nt.as<double>(), Ns, ref->Btot,
+                           (const int *)ref->g2m.as<int>(), (double)min_ref_bins, results_z, results_r);
+    }
+    if (n_calls) WC_HIP(hipMemsetAsync(n_calls, 0, sizeof(int) * Ns, stream));
+    if (n_sel == 0) return WC_OK;
+    std::vector<int> sel(n_sel);
+    int64_t max_n = 0;
+    for (int s = 0; s < n_sel; ++s) {
+        int c = chromosomes_host[s] - 1;
+        WC_CHECK(c >= 0 && c < ref->n_chrom, WC_E_ARG, "test: chromosome %d out of range", chromosomes_host[s]);
+        sel[s] = c;
+        max_n = std::max(max_n, ref->moff[c + 1] - ref->moff[c]);
+    }
+    const int64_t n_regions = Ns * n_sel;
+    WC_CHECK(n_regions <= 60000, WC_E_LIMIT, "test: samples x chromosomes = %lld exceeds 60000 per call; split the batch",
+             (long long)n_regions);
+    if ((rc = ts.sel.reserve(sizeof(int) * n_sel))) return rc;
+    if ((rc = ts.zc.reserve(sizeof(double) * Ns * B))) return rc;
+    if ((rc = ts.rc.reserve(sizeof(double) * Ns * B))) return rc;
+    if ((rc = ts.gpos.reserve(sizeof(int) * Ns * B))) return rc;
+    if ((rc = ts.regions.reserve(sizeof(Region) * n_regions))) return rc;
+    if ((rc = ts.effect.reserve(sizeof(double) * n_regions * max_calls * 5))) return rc;
+    if ((rc = ts.misc.reserve(sizeof(int) * 4))) return rc;
+    WC_HIP(hipMemcpyAsync(ts.sel.p, sel.data(), sizeof(int) * n_sel, hipMemcpyHostToDevice, stream));
+    WC_HIP(hipStreamSynchronize(stream));
+    hipLaunchKernelGGL(k_clean, dim3((unsigned)n_sel, (unsigned)Ns), dim3(64), 0, stream,
+                       (const double *)ts.zt.as<double>(), (const double *)ts.rt.as<double>(),
+                       (const double *)ts.nt.as<double>(), B, Ns, (const int64_t *)ref->moff_dev.as<int64_t>(),
+                       (const int64_t *)ref->goff_dev.as<int64_t>(), (const int *)ref->m2g.as<int>(),
+                       (const int *)ts.sel.as<int>(), n_sel, (double)min_ref_bins, ts.zc.as<double>(),
+                       ts.rc.as<double>(), ts.gpos.as<int>(), ts.regions.as<Region>());
+    if ((rc = run_stouffer(ctx, ts.zc.as<double>(), ts.regions.as<Region>(), n_regions, Ns * B, max_n, threshold, 3,
+                           max_calls, stream)))
+        return rc;
+    if (results_cwz)
+        WC_HIP(hipMemcpyAsync(results_cwz, ts.whole.p, sizeof(double) * n_regions, hipMemcpyDeviceToDevice, stream));
+    if (calls && n_calls) {
+        WC_HIP(hipMemsetAsync(ts.misc.p, 0, sizeof(int) * 4, stream));
+        hipLaunchKernelGGL(k_call_post, dim3((unsigned)max_calls, (unsigned)n_regions), dim3(256), 0, stream,
+                           (const Region *)ts.regions.as<Region>(), (const double *)ts.rc.as<double>(),
+                           (const int *)ts.gpos.as<int>(), (const double *)ts.out_val.as<double>(),
+                           (const int *)ts.out_x.as<int>(), (const int *)ts.out_y.as<int>(),
+                           (const int *)ts.out_n.as<int>(), max_calls, ts.effect.as<double>());
+        hipLaunchKernelGGL(k_assemble_calls, dim3((unsigned)cdiv(Ns, 64)), dim3(64), 0, stream,
+                           (const double *)ts.effect.as<double>(), (const int *)ts.out_n.as<int>(), n_sel, max_calls, Ns,
+                           calls, n_calls, ts.misc.as<int>());
+        int overflow = 0;
+        WC_HIP(hipMemcpyAsync(&overflow, ts.misc.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+        WC_HIP(hipStreamSynchronize(stream));
+        WC_CHECK(!overflow, WC_E_LIMIT, "test: a sample has more than max_calls=%d calls", max_calls);
+    }
+    WC_HIP(hipGetLastError());
+    return WC_OK;
+}
+
+int wc_test_batch(wc_ctx *ctx, const wc_reference *ref, const int32_t *counts, int64_t n_samples, double threshold,
+                  int min_ref_bins, int repeats, const int32_t *chromosomes, int n_sel, int max_calls,
+                  double *results_z, double *results_r, double *results_cwz, double *calls, int32_t *n_calls,
+                  double *asdef) {
+    WC_CHECK(ctx && ref && counts && n_samples > 0, WC_E_ARG, "test: bad argument");
+    WC_HIP(hipSetDevice(ctx->device));
+    TestState &ts = ctx->ts;
+    const int64_t Ns = n_samples;
+    int rc;
+    if ((rc = ts.counts.reserve(sizeof(int) * Ns * ref->Btot))) return rc;
+    if ((rc = ts.res_z.reserve(sizeof(double) * Ns * ref->Btot))) return rc;
+    if ((rc = ts.res_r.reserve(sizeof(double) * Ns * ref->Btot))) return rc;
+    if ((rc = ts.cwz.reserve(sizeof(double) * Ns * std::max(n_sel, 1)))) return rc;
+    if ((rc = ts.calls.reserve(sizeof(double) * Ns * max_calls * 5))) return rc;
+    if ((rc = ts.n_calls.reserve(sizeof(int) * Ns))) return rc;
+    if ((rc = ts.n.reserve(sizeof(double) * Ns))) return rc;
+    WC_HIP(hipMemcpy(ts.counts.p, counts, sizeof(int) * Ns * ref->Btot, hipMemcpyHostToDevice));
+    rc = wc_test_batch_dev(ctx, nullptr, ref, ts.counts.as<int>(), Ns, threshold, min_ref_bins, repeats, chromosomes,
+                           n_sel, max_calls, ts.res_z.as<double>(), ts.res_r.as<double>(), ts.cwz.as<double>(),
+                           ts.calls.as<double>(), ts.n_calls.as<int>(), ts.n.as<double>());
+    if (rc) return rc;
+    WC_HIP(hipDeviceSynchronize());
+    if (results_z) WC_HIP(hipMemcpy(results_z, ts.res_z.p, sizeof(double) * Ns * ref->Btot, hipMemcpyDeviceToHost));
+    if (results_r) WC_HIP(hipMemcpy(results_r, ts.res_r.p, sizeof(double) * Ns * ref->Btot, hipMemcpyDeviceToHost));
+    if (results_cwz && n_sel > 0)
+        WC_HIP(hipMemcpy(results_cwz, ts.cwz.p, sizeof(double) * Ns * n_sel, hipMemcpyDeviceToHost));
+    if (calls) WC_HIP(hipMemcpy(calls, ts.calls.p, sizeof(double) * Ns * max_calls * 5, hipMemcpyDeviceToHost));
+    if (n_calls) WC_HIP(hipMemcpy(n_calls, ts.n_calls.p, sizeof(int) * Ns, hipMemcpyDeviceToHost));
+    if (asdef) WC_HIP(hipMemcpy(asdef, ts.n.p, sizeof(double) * Ns, hipMemcpyDeviceToHost));
+    return WC_OK;
+}
+
+}  // extern "C"

@@ -68,3 +68,261 @@ def newref_stats(device=0):
     _lib.check(_lib.load().wc_newref_stats(_lib.context(device), _lib.ptr(out)))
     return dict(fast_rows=int(out[0]), fallback_rows=int(out[1]), tiles=int(out[2]),
                 sample_cols=int(out[3]), rescored=int(out[4]))
+
+
+# ---------------------------------------------------------------------------
+# test path
+# ---------------------------------------------------------------------------
+MAX_CALLS = 256  # per sample (and per region) capacity handed to the C ABI
+
+
+def scaleSample(sample, fromSize, toSize):
+    """Merge bins to a coarser size (wisetools.py:220-237); host data marshalling."""
+    if fromSize == toSize or toSize is None:
+        return sample
+    if toSize == 0 or fromSize == 0 or toSize < fromSize or toSize % fromSize > 0:
+        print('ERROR: Impossible binsize scaling requested:', fromSize, 'to', toSize)
+        raise SystemExit(1)
+    scale = int(toSize / fromSize)
+    out = dict()
+    for chrom in sample:
+        data = np.asarray(sample[chrom])
+        new_len = int(np.ceil(len(data) / float(scale)))
+        padded = np.zeros(new_len * scale, dtype=np.int64)
+        padded[:len(data)] = data
+        out[chrom] = padded.reshape(new_len, scale).sum(axis=1).astype(np.int32)
+    return out
+
+
+def samples_to_counts(samples, chromosome_sizes):
+    """Dense int32 [n_samples, sum(chromosome_sizes)] image of sample dicts.
+
+    The pad/truncate-to-reference-length part of toNumpyRefFormat
+    (wisetools.py:268-274); the arithmetic happens on the GPU.
+    """
+    sizes = [int(v) for v in chromosome_sizes]
+    out = np.zeros((len(samples), int(sum(sizes))), dtype=np.int32)
+    for row, sample in enumerate(samples):
+        at = 0
+        for chrom, want in enumerate(sizes, start=1):
+            data = np.asarray(sample[str(chrom)])
+            have = min(want, len(data))
+            out[row, at:at + have] = data[:have]
+            at += want
+    return out
+
+
+class Reference(object):
+    """Device-resident reference (`newref` output) shared by every sample of a batch.
+
+    Holds what toolTest derives from the reference file alone
+    (wisecondor.py:177-201): the arrays themselves, getOptimalCutoff and the
+    per-bin reference lists.
+    """
+
+    def __init__(self, indexes, distances, chromosome_sizes, masked_sizes, mask, pca_mean,
+                 pca_components, binsize=None, cutoff=None, device=0):
+        lib = _lib.load()
+        self.device = device
+        self.ctx = _lib.context(device)
+        self.binsize = binsize
+        self.indexes = np.ascontiguousarray(indexes, dtype=np.int32)
+        self.distances = np.ascontiguousarray(distances, dtype=np.float64)
+        self.chromosome_sizes = np.ascontiguousarray(chromosome_sizes, dtype=np.int64)
+        self.masked_sizes = np.ascontiguousarray(masked_sizes, dtype=np.int64)
+        self.mask = np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
+        self.pca_mean = np.ascontiguousarray(pca_mean, dtype=np.float64)
+        comps = np.ascontiguousarray(pca_components, dtype=np.float64)
+        self.pca_components = comps.reshape(-1, self.pca_mean.shape[0]) if comps.size else comps.reshape(0, self.pca_mean.shape[0])
+        self.n_bins, self.k = self.indexes.shape
+        self.n_total = int(self.chromosome_sizes.sum())
+        override = None
+        if cutoff is not None:
+            override = ctypes.byref(ctypes.c_double(float(cutoff)))
+        self.handle = lib.wc_reference_create(
+            self.ctx, _lib.ptr(self.indexes), _lib.ptr(self.distances), self.n_bins, self.k,
+            _lib.ptr(self.chromosome_sizes), _lib.ptr(self.masked_sizes), len(self.chromosome_sizes),
+            _lib.ptr(self.mask), _lib.ptr(self.pca_mean), _lib.ptr(self.pca_components),
+            self.pca_components.shape[0], 3, override)
+        if not self.handle:
+            raise _lib.WisecondorHipError("wc_reference_create: " + lib.wc_last_error().decode())
+        self.cutoff = lib.wc_reference_cutoff(self.handle)
+
+    @classmethod
+    def from_npz(cls, npz, device=0):
+        binsize = npz['binsize'].item() if hasattr(npz['binsize'], 'item') else npz['binsize']
+        return cls(npz['indexes'], npz['distances'], npz['chromosome_sizes'], npz['masked_sizes'],
+                   npz['mask'], npz['pca_mean'], npz['pca_components'], binsize=binsize, device=device)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.load().wc_reference_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def toNumpyRefFormat(sample, chromBins, mask, device=0):
+    """Pad/truncate, normalise to unit sum, apply the mask (wisetools.py:267-278)."""
+    counts = samples_to_counts([sample], chromBins)
+    mask = np.asarray(mask).astype(bool)
+    n_bins = int(mask.sum())
+    # a reference with only the layout (no neighbours, no PCA components) drives the kernels
+    sizes = np.asarray(chromBins, dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    msz = np.array([int(mask[offs[i]:offs[i + 1]].sum()) for i in range(len(sizes))], dtype=np.int64)
+    ref = Reference(np.zeros((n_bins, 1), np.int32), np.full((n_bins, 1), 1e10), sizes, msz, mask,
+                    np.ones(n_bins), np.zeros((0, n_bins)), cutoff=0.0, device=device)
+    out = np.empty((1, n_bins))
+    raw = np.empty((1, n_bins))
+    _lib.check(_lib.load().wc_prepare_samples(ref.ctx, ref.handle, _lib.ptr(counts), 1, _lib.ptr(out), _lib.ptr(raw)))
+    ref.close()
+    return raw[0]
+
+
+def applyPCA(sampleData, mean, components, device=0):
+    """x / reconstruction from the stored components (wisetools.py:104-113)."""
+    x = np.ascontiguousarray(np.atleast_2d(sampleData), dtype=np.float64)
+    mean = np.ascontiguousarray(mean, dtype=np.float64)
+    comps = np.ascontiguousarray(components, dtype=np.float64).reshape(-1, mean.shape[0])
+    out = np.empty_like(x)
+    _lib.check(_lib.load().wc_apply_pca(_lib.context(device), _lib.ptr(x), x.shape[0], x.shape[1],
+                                        _lib.ptr(mean), _lib.ptr(comps), comps.shape[0], _lib.ptr(out)))
+    return out[0] if np.ndim(sampleData) == 1 else out
+
+
+def getOptimalCutoff(reference, repeats, device=0):
+    """Iterated mean + 3 sd clip of the reference distances (wisetools.py:328-336)."""
+    d = np.ascontiguousarray(reference, dtype=np.float64)
+    cutoff = ctypes.c_double()
+    _lib.check(_lib.load().wc_optimal_cutoff(_lib.context(device), _lib.ptr(d), d.size, int(repeats),
+                                             ctypes.byref(cutoff)))
+    # the mask the reference returns is the one of the LAST iteration, i.e. against the
+    # previous cutoff; toolTest never uses it (wisecondor.py:201), so it is not rebuilt here
+    return cutoff.value, None
+
+
+def repeatTest(testData, indexes, distances, chromosomeBins, chromosomeBinSums, cutoff, threshold,
+               repeats, device=0, reference=None):
+    """`repeats` z-score passes with flagging (wisetools.py:438-448).
+
+    testData may be one vector [bins] or a batch [samples, bins]; returns
+    (Z, R, refSizes, stdDevAvg) shaped like the input.
+    """
+    data = np.ascontiguousarray(np.atleast_2d(testData), dtype=np.float64)
+    own = reference is None
+    if own:
+        sizes = np.asarray(chromosomeBins, dtype=np.int64)
+        n_bins = int(sizes.sum())
+        reference = Reference(indexes, distances, sizes, sizes, np.ones(n_bins, np.uint8), np.zeros(n_bins),
+                              np.zeros((0, n_bins)), cutoff=cutoff, device=device)
+    z = np.empty_like(data)
+    r = np.empty_like(data)
+    n = np.empty_like(data)
+    sd = np.empty(data.shape[0])
+    _lib.check(_lib.load().wc_repeat_test(reference.ctx, reference.handle, _lib.ptr(data), data.shape[0],
+                                          float(threshold), int(repeats), _lib.ptr(z), _lib.ptr(r),
+                                          _lib.ptr(n), _lib.ptr(sd)))
+    if own:
+        reference.close()
+    if np.ndim(testData) == 1:
+        return z[0], r[0], n[0], sd[0]
+    return z, r, n, sd
+
+
+def stouffer_segments(regions, threshold, min_search=3, device=0):
+    """fillTri + segmentTri for a list of 1-D z arrays (wisetools.py:466-472, triarray.py:59-84).
+
+    Returns (whole_region_z [n], [[(value, (x, y)), ...] per region]).
+    """
+    lib = _lib.load()
+    regions = [np.ascontiguousarray(r, dtype=np.float64) for r in regions]
+    offs = np.zeros(len(regions) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([r.shape[0] for r in regions])
+    z = np.ascontiguousarray(np.concatenate(regions) if regions else np.zeros(0))
+    if z.size == 0:
+        z = np.zeros(1)
+    nreg = len(regions)
+    whole = np.empty(nreg)
+    ncalls = np.zeros(nreg, dtype=np.int32)
+    val = np.zeros((nreg, MAX_CALLS))
+    cx = np.zeros((nreg, MAX_CALLS), dtype=np.int32)
+    cy = np.zeros((nreg, MAX_CALLS), dtype=np.int32)
+    _lib.check(lib.wc_stouffer_segments(_lib.context(device), _lib.ptr(z), _lib.ptr(offs), nreg,
+                                        float(threshold), int(min_search), MAX_CALLS, _lib.ptr(whole),
+                                        _lib.ptr(ncalls), _lib.ptr(val), _lib.ptr(cx), _lib.ptr(cy)))
+    segs = [[(val[r, c], (int(cx[r, c]), int(cy[r, c]))) for c in range(ncalls[r])] for r in range(nreg)]
+    return whole, segs
+
+
+def fillTri(region, device=0):
+    """Window triangle of a region (wisetools.py:466-472), never materialised on the GPU."""
+    from .triarray import TriArr
+    return TriArr.from_region(region, device=device)
+
+
+def fillTriMin(regionZ, regionR, threshold, device=0):
+    """fillTri, optionally median-effect filtered (wisetools.py:475-487)."""
+    if threshold == 0:
+        return fillTri(regionZ, device=device)
+    raise NotImplementedError("-mineffectsize > 0 (median-filtered triangle, wisetools.py:479-487) "
+                              "is not implemented on the GPU yet")
+
+
+def inflateArray(array, mask):
+    """Scatter into the True positions of mask (wisetools.py:281-288); host shaping helper."""
+    mask = np.asarray(mask)
+    temp = np.zeros(mask.shape[0])
+    temp[np.flatnonzero(mask)] = array
+    return temp
+
+
+def inflateArrayMulti(array, mask_list):
+    """wisetools.py:291-295."""
+    temp = array
+    for mask in reversed(mask_list):
+        temp = inflateArray(temp, mask)
+    return temp
+
+
+def test_batch(reference, samples, threshold, minrefbins=25, repeats=5, chromosomes=None):
+    """Numeric content of toolTest (wisecondor.py:199-268) for a list of sample dicts.
+
+    Returns a list of dicts with results_z / results_r (per-chromosome lists),
+    results_cwz, results_calls, asdef.  Samples must already be at the
+    reference's bin size (see scaleSample).
+    """
+    lib = _lib.load()
+    if chromosomes is None:
+        chromosomes = list(range(1, 23))
+    sel = np.ascontiguousarray(chromosomes, dtype=np.int32)
+    out = []
+    max_batch = max(1, 60000 // max(1, len(sel)))
+    sizes = [int(v) for v in reference.chromosome_sizes]
+    for lo in range(0, len(samples), max_batch):
+        chunk = samples[lo:lo + max_batch]
+        counts = samples_to_counts(chunk, sizes)
+        ns = counts.shape[0]
+        rz = np.empty((ns, reference.n_total))
+        rr = np.empty((ns, reference.n_total))
+        cwz = np.empty((ns, max(len(sel), 1)))
+        calls = np.zeros((ns, MAX_CALLS, 5))
+        ncalls = np.zeros(ns, dtype=np.int32)
+        asdef = np.empty(ns)
+        _lib.check(lib.wc_test_batch(reference.ctx, reference.handle, _lib.ptr(counts), ns, float(threshold),
+                                     int(minrefbins), int(repeats), _lib.ptr(sel), len(sel), MAX_CALLS,
+                                     _lib.ptr(rz), _lib.ptr(rr), _lib.ptr(cwz), _lib.ptr(calls),
+                                     _lib.ptr(ncalls), _lib.ptr(asdef)))
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        for i in range(ns):
+            out.append(dict(
+                results_z=[rz[i, offs[c]:offs[c + 1]].copy() for c in range(len(sizes))],
+                results_r=[rr[i, offs[c]:offs[c + 1]].copy() for c in range(len(sizes))],
+                results_cwz=cwz[i, :len(sel)].copy(),
+                results_calls=calls[i, :ncalls[i]].copy(),
+                asdef=float(asdef[i])))
+    return out
