@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Benchmark of the WISECONDOR hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the `newref` reference-bin selection over the whole
+workload (BASELINE.json config 2 by default: 100 samples x 250 kb bins) with
+the corrected matrix already resident in HBM, followed (timed separately) by
+one batched `test` pass (PCA-apply -> 5 masked z-score repeats -> Stouffer
+segmentation) over --test-samples samples per GPU at the same bin size.
+
+Rank 0 prints ONE JSON line: `value` is the newref metric of BASELINE.json
+(ordered cross-chromosome bin-pair distances per second, whole job), the `test`
+object carries samples/s, `roofline` describes the dominant kernel (the
+symmetric fp32-MFMA distance kernel) and `cpu_baseline` the CPU oracle timed on
+this box (rank 0, N=1 only).  Inputs are synthetic (seeded), see
+wisecondor_amd/synth.py.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (binsize, reference samples)
+    "cfg1": (1000000, 16),
+    "cfg2": (250000, 100),
+    "cfg4": (50000, 600),
+}
+PEAK_FP32_MFMA = 157.3e12  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def build_inputs(binsize, n_ref, n_test, seed0=0):
+    """Pipeline-level synthetic inputs: reference samples -> prep (host, untimed) and test samples."""
+    from wisecondor_amd import synth
+    from wisecondor_amd import wisetools as wt
+    import contextlib
+    import io
+    profile = synth.bin_profile(binsize)
+    samples = [synth.make_sample(profile, seed=seed0 + i) for i in range(n_ref)]
+    with contextlib.redirect_stdout(io.StringIO()):
+        masked, chrom_bins, mask = wt.toNumpyArray(samples)
+        corrected, pca = wt.trainPCA(masked)
+    offs = np.concatenate([[0], np.cumsum(chrom_bins)])
+    masked_bins = np.array([int(mask[offs[i]:offs[i + 1]].sum()) for i in range(22)], dtype=np.int64)
+    rng = np.random.RandomState(4242)
+    tests = []
+    for i in range(n_test):
+        events = []
+        if rng.rand() < 0.05:  # 5 % of the test samples carry a 1-5 % gain/loss
+            c = int(rng.randint(1, 23))
+            n = len(profile[c - 1])
+            a = int(rng.randint(0, max(1, n - n // 4)))
+            f = 1.0 + rng.choice([-1, 1]) * rng.uniform(0.01, 0.05)
+            events.append((str(c), a, a + n // 4, f))
+        tests.append(synth.make_sample(profile, seed=1000 + i, events=events))
+    return dict(corrected=corrected, chrom_bins=np.asarray(chrom_bins, dtype=np.int64), mask=mask,
+                masked_bins=masked_bins, pca_mean=pca.mean_, pca_components=pca.components_,
+                tests=tests)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--test-samples", type=int, default=64, help="test samples per GPU in the batched test pass")
+    ap.add_argument("--refsize", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from wisecondor_amd import _lib, distributed
+    from wisecondor_amd import wisetools as wt
+    from wisecondor_amd.wisecondor import zThreshold
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    lib = _lib.load()
+    ctx = _lib.context(local_rank)
+
+    binsize, n_ref = WORKLOADS[args.workload]
+    k = args.refsize
+    inp = build_inputs(binsize, n_ref, args.test_samples, seed0=0)
+    corrected = inp["corrected"]                       # Fortran-ordered, like the reference's prep file
+    order = wt.sum_order_of(corrected)
+    B, S = corrected.shape
+    bins = np.ascontiguousarray(inp["masked_bins"])
+    pairs = float(B) * B - float((bins.astype(np.float64) ** 2).sum())   # ordered cross-chromosome pairs
+    X = torch.from_numpy(np.ascontiguousarray(corrected)).to(dev)
+
+    job = distributed.NewrefJob(ctx, X, bins, k, order, rank=rank, world=world)
+    stream = torch.cuda.current_stream()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # ------------------------------------------------------------ newref ----
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * args.steps)]
+    for _ in range(args.warmup):
+        idx, dst = job.run()
+    sync_all()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        idx, dst = job.run(collect_events=(ev[2 * s], ev[2 * s + 1]))
+    sync_all()
+    t_newref = time.perf_counter() - t0
+    kernel_ms = float(np.mean([ev[2 * s].elapsed_time(ev[2 * s + 1]) for s in range(args.steps)]))
+    stats = wt.newref_stats(local_rank)
+    tmax = torch.tensor([t_newref], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    t_newref = float(tmax.item())
+    ms_per_step = 1e3 * t_newref / args.steps
+    value = pairs * args.steps / t_newref
+
+    # -------------------------------------------------------------- test ----
+    reference = wt.Reference(idx.cpu().numpy(), dst.cpu().numpy(), inp["chrom_bins"], inp["masked_bins"],
+                             inp["mask"], inp["pca_mean"], inp["pca_components"], binsize=binsize,
+                             device=local_rank)
+    thr = float(zThreshold([int(v) for v in inp["masked_bins"]], 1000, None))
+    counts_h = wt.samples_to_counts(inp["tests"], inp["chrom_bins"])
+    tb = distributed.TestBatch(reference, torch.from_numpy(counts_h).to(dev), thr)
+    for _ in range(max(1, args.warmup // 2)):
+        tb.run()
+    sync_all()
+    t0 = time.perf_counter()
+    test_steps = max(1, args.steps // 4)
+    for _ in range(test_steps):
+        tb.run()
+    sync_all()
+    t_test = time.perf_counter() - t0
+    tmax = torch.tensor([t_test], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    t_test = float(tmax.item())
+    samples_per_s = world * args.test_samples * test_steps / t_test
+    n_calls = int(tb.n_calls.sum().item())
+
+    # ------------------------------------------------------- cpu baseline ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import wc_oracle as wo
+        import contextlib
+        import io
+        sums = np.cumsum(bins)
+        parts = max(1, int(round(B * float(B) * S / 4.0e9)))       # ~10-20 s of numpy work per slice
+        lo, hi = wo.get_part(0, parts, B)
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()), np.errstate(all="ignore"):
+            ci, cd = wo.get_reference(corrected, bins, sums, k, 1, parts)
+        t_cpu = time.perf_counter() - t0
+        ok = bool(np.array_equal(ci, idx[lo:hi].cpu().numpy()))
+        slice_pairs = float(sum(B - bins[np.searchsorted(sums, r, side="right")] for r in range(lo, hi)))
+        cpu = {"value": slice_pairs / t_cpu, "unit": "bin-pair distances/s", "cores": 1, "kind": "port",
+               "sample": "oracle get_reference (numpy distance + Python insertion top-k, the reference's own "
+                         "structure) on target rows [%d,%d) of %d x all candidates, %.1f s" % (lo, hi, B, t_cpu),
+               "matches_gpu_indices": ok}
+
+    if rank == 0:
+        # algorithmic work of the dominant kernel: one multiply-add per sample per unordered pair
+        flops = (pairs / 2.0) * 2.0 * S / world
+        achieved = flops / (kernel_ms * 1e-3)
+        out = {
+            "metric": "newref bin-pair distances/sec",
+            "value": value,
+            "unit": "bin-pair distances/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32 MFMA distance + f64 exact re-score",
+            "data": "synthetic",
+            "config": {"workload": "%s: newref %d samples x %d kb bins (%d masked bins, refsize %d), "
+                                   "then batched test of %d samples/GPU at the same bin size"
+                                   % (args.workload, S, binsize // 1000, B, k, args.test_samples),
+                       "parallelism": "tile-sharded newref + sample-sharded test, %d rank(s)" % world},
+            "test": {"metric": "test samples/sec", "value": samples_per_s, "unit": "samples/s",
+                     "ms_per_batch": 1e3 * t_test / test_steps, "samples_per_gpu": args.test_samples,
+                     "calls_found": n_calls},
+            "roofline": {"kernel": "k_gram<1> (symmetric fp32 MFMA distance tiles + candidate filter)",
+                         "bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_FP32_MFMA / 1e12,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA, "traffic": None,
+                         "kernel_ms": kernel_ms, "algorithmic_flop_per_launch": flops},
+            "newref_stats": stats,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -98,11 +98,20 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream, const double *corrected, in
                           int64_t n_samples, const int64_t *chrom_bins_host, int n_chrom, int k,
                           int sum_order);
 int wc_newref_thresholds_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end);
-float *wc_newref_threshold_buffer(wc_ctx *ctx);              /* device float[n_bins_padded]       */
+/* copy thresholds of rows [row_begin,row_end) out of / into the context (device float[rows]) */
+int wc_newref_get_thresholds_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end, float *out);
+int wc_newref_set_thresholds_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end, const float *in);
 int wc_newref_collect_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end,
                           int tile_rank, int tile_ranks);
-int32_t *wc_newref_count_buffer(wc_ctx *ctx);                /* device int32[n_bins_padded]       */
-uint64_t *wc_newref_list_buffer(wc_ctx *ctx, int64_t *cap);  /* device u64[n_bins_padded, cap]    */
+/* candidate-list exchange: pack the lists of rows [row_begin,row_end) into
+ * dst_cnt int32[rows] / dst_list u64[rows, dst_cap] (device), and merge lists
+ * received from another rank into this context's lists for those rows.  A source
+ * row with more than `cap` entries marks the row for the exact fallback path.  */
+int64_t wc_newref_list_capacity(wc_ctx *ctx);
+int wc_newref_export_lists_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end,
+                               int64_t dst_cap, int32_t *dst_cnt, uint64_t *dst_list);
+int wc_newref_import_lists_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end,
+                               int64_t src_cap, const int32_t *src_cnt, const uint64_t *src_list);
 int wc_newref_finish_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end,
                          int32_t *idx_out, double *dist_out);
 

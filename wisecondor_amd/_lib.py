@@ -29,10 +29,12 @@ SIGNATURES = {
     "wc_get_reference_dev": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i32, _i32, _i32, _i64, _i64, _vp, _vp]),
     "wc_newref_prepare_dev": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _i32, _i32, _i32]),
     "wc_newref_thresholds_dev": (_i32, [_vp, _vp, _i64, _i64]),
-    "wc_newref_threshold_buffer": (_vp, [_vp]),
+    "wc_newref_get_thresholds_dev": (_i32, [_vp, _vp, _i64, _i64, _vp]),
+    "wc_newref_set_thresholds_dev": (_i32, [_vp, _vp, _i64, _i64, _vp]),
     "wc_newref_collect_dev": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32]),
-    "wc_newref_count_buffer": (_vp, [_vp]),
-    "wc_newref_list_buffer": (_vp, [_vp, _vp]),
+    "wc_newref_list_capacity": (_i64, [_vp]),
+    "wc_newref_export_lists_dev": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "wc_newref_import_lists_dev": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "wc_newref_finish_dev": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "wc_reference_create": (_vp, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp]),
     "wc_apply_pca": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _i32, _vp]),

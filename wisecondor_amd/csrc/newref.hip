@@ -659,6 +659,36 @@ __global__ __launch_bounds__(256) void k_fallback(FinishArgs a, unsigned long lo
     }
 }
 
+// Multi-GPU exchange helpers: pack / merge per-row candidate lists.
+__global__ __launch_bounds__(64) void k_export_lists(const int *__restrict__ cnt,
+                                                     const unsigned long long *__restrict__ list, int cap,
+                                                     int64_t row_begin, int dst_cap, int *__restrict__ dst_cnt,
+                                                     unsigned long long *__restrict__ dst_list) {
+    const int64_t r = blockIdx.x, row = row_begin + r;
+    const int c = cnt[row];
+    const int n = c < dst_cap ? c : dst_cap;
+    for (int t = threadIdx.x; t < n; t += 64) dst_list[r * dst_cap + t] = list[row * cap + t];
+    if (threadIdx.x == 0) dst_cnt[r] = c;  // the true count: > dst_cap tells the owner entries were lost
+}
+
+__global__ __launch_bounds__(64) void k_import_lists(int *__restrict__ cnt, unsigned long long *__restrict__ list,
+                                                     int cap, int64_t row_begin, int src_cap,
+                                                     const int *__restrict__ src_cnt,
+                                                     const unsigned long long *__restrict__ src_list) {
+    const int64_t r = blockIdx.x, row = row_begin + r;
+    const int c = src_cnt[r];
+    const int base = cnt[row];
+    if (c > src_cap || base > cap) {
+        __syncthreads();
+        if (threadIdx.x == 0) cnt[row] = cap + 1;  // lost entries: the row takes the exact path
+        return;
+    }
+    for (int t = threadIdx.x; t < c; t += 64)
+        if (base + t < cap) list[row * cap + base + t] = src_list[r * src_cap + t];
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[row] = base + c;
+}
+
 // ----------------------------------------------------------------- host side ----
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
@@ -761,8 +791,10 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
 
     WC_HIP(hipMemcpyAsync(st.chrom_off_dev.p, st.chrom_off, sizeof(int64_t) * (n_chrom + 1),
                           hipMemcpyHostToDevice, stream));
-    // fixed pseudo-random sample of rows (partial Fisher-Yates on a 64-bit LCG), ascending
-    {
+    // fixed pseudo-random sample of rows (partial Fisher-Yates on a 64-bit LCG), ascending;
+    // depends on (n_bins, M) only, so it is uploaded once per layout
+    std::vector<int64_t> skey = {n_bins, M};
+    if (skey != st.sample_key) {
         int64_t real = std::min<int64_t>(M, n_bins);
         std::vector<int> perm(n_bins);
         for (int64_t i = 0; i < n_bins; ++i) perm[i] = (int)i;
@@ -775,6 +807,9 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
         std::sort(perm.begin(), perm.begin() + real);
         WC_HIP(hipMemcpyAsync(st.sample_rows.p, perm.data(), sizeof(int) * real, hipMemcpyHostToDevice, stream));
         WC_HIP(hipStreamSynchronize(stream));  // perm goes out of scope
+        st.sample_key = skey;
+        st.tiles0_key.clear();
+        st.tiles1_key.clear();
     }
 
     double *psum = st.col_partial.as<double>();
@@ -820,14 +855,19 @@ int wc_newref_thresholds_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int6
     hipStream_t stream = (hipStream_t)stream_;
     const int ib = (int)(row_begin / TB), ie = (int)((row_end + TB - 1) / TB);
     const int mb = (int)(st.n_sample_cols / TB);
-    std::vector<int4> tiles;
-    tiles.reserve((size_t)(ie - ib) * mb);
-    for (int I = ib; I < ie; ++I)
-        for (int J = 0; J < mb; ++J) tiles.push_back(make_int4(I, J, 0, 0));
-    int rc;
-    if ((rc = st.tiles.reserve(sizeof(int4) * tiles.size()))) return rc;
-    WC_HIP(hipMemcpyAsync(st.tiles.p, tiles.data(), sizeof(int4) * tiles.size(), hipMemcpyHostToDevice, stream));
-    WC_HIP(hipStreamSynchronize(stream));
+    std::vector<int64_t> key = {st.bins_pad, st.n_sample_cols, ib, ie};
+    if (key != st.tiles0_key) {
+        std::vector<int4> tiles;
+        tiles.reserve((size_t)(ie - ib) * mb);
+        for (int I = ib; I < ie; ++I)
+            for (int J = 0; J < mb; ++J) tiles.push_back(make_int4(I, J, 0, 0));
+        int rc;
+        if ((rc = st.tiles0.reserve(sizeof(int4) * tiles.size()))) return rc;
+        WC_HIP(hipMemcpyAsync(st.tiles0.p, tiles.data(), sizeof(int4) * tiles.size(), hipMemcpyHostToDevice, stream));
+        WC_HIP(hipStreamSynchronize(stream));
+        st.tiles0_key = key;
+        st.tiles0_n = (int64_t)tiles.size();
+    }
     GramArgs g{};
     g.P = st.a32.as<float>();
     g.Q = st.s32.as<float>();
@@ -837,8 +877,8 @@ int wc_newref_thresholds_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int6
     g.nbQ = st.s_norm_lo.as<float>();
     g.chP = st.chrom_of_row.as<int>();
     g.chQ = st.s_chrom.as<int>();
-    g.tiles = st.tiles.as<int4>();
-    g.ntiles = (int)tiles.size();
+    g.tiles = st.tiles0.as<int4>();
+    g.ntiles = (int)st.tiles0_n;
     g.keys = st.keys1.as<float>();
     g.ldo = st.n_sample_cols;
     unsigned grid = (unsigned)(((g.ntiles + 7) / 8) * 8);
@@ -852,12 +892,50 @@ int wc_newref_thresholds_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int6
     return WC_OK;
 }
 
-float *wc_newref_threshold_buffer(wc_ctx *ctx) { return ctx ? ctx->nr.thr.as<float>() : nullptr; }
-int32_t *wc_newref_count_buffer(wc_ctx *ctx) { return ctx ? ctx->nr.cnt.as<int32_t>() : nullptr; }
-uint64_t *wc_newref_list_buffer(wc_ctx *ctx, int64_t *cap) {
-    if (!ctx) return nullptr;
-    if (cap) *cap = ctx->nr.cap;
-    return ctx->nr.list.as<uint64_t>();
+int64_t wc_newref_list_capacity(wc_ctx *ctx) { return ctx ? ctx->nr.cap : 0; }
+
+int wc_newref_get_thresholds_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end, float *out) {
+    WC_CHECK(ctx && ctx->nr.prepared && out, WC_E_ARG, "newref: bad argument");
+    WC_CHECK(row_begin >= 0 && row_begin <= row_end && row_end <= ctx->nr.n_bins, WC_E_ARG, "newref: bad row range");
+    if (row_end > row_begin)
+        WC_HIP(hipMemcpyAsync(out, ctx->nr.thr.as<float>() + row_begin, sizeof(float) * (row_end - row_begin),
+                              hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return WC_OK;
+}
+
+int wc_newref_set_thresholds_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end, const float *in) {
+    WC_CHECK(ctx && ctx->nr.prepared && in, WC_E_ARG, "newref: bad argument");
+    WC_CHECK(row_begin >= 0 && row_begin <= row_end && row_end <= ctx->nr.n_bins, WC_E_ARG, "newref: bad row range");
+    if (row_end > row_begin)
+        WC_HIP(hipMemcpyAsync(ctx->nr.thr.as<float>() + row_begin, in, sizeof(float) * (row_end - row_begin),
+                              hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return WC_OK;
+}
+
+int wc_newref_export_lists_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end, int64_t dst_cap,
+                               int32_t *dst_cnt, uint64_t *dst_list) {
+    WC_CHECK(ctx && ctx->nr.prepared && dst_cnt && dst_list && dst_cap > 0, WC_E_ARG, "newref: bad argument");
+    WC_CHECK(row_begin >= 0 && row_begin <= row_end && row_end <= ctx->nr.n_bins, WC_E_ARG, "newref: bad row range");
+    if (row_end == row_begin) return WC_OK;
+    NewrefState &st = ctx->nr;
+    hipLaunchKernelGGL(k_export_lists, dim3((unsigned)(row_end - row_begin)), dim3(64), 0, (hipStream_t)stream,
+                       (const int *)st.cnt.as<int>(), (const unsigned long long *)st.list.as<unsigned long long>(),
+                       (int)st.cap, row_begin, (int)dst_cap, dst_cnt, (unsigned long long *)dst_list);
+    WC_HIP(hipGetLastError());
+    return WC_OK;
+}
+
+int wc_newref_import_lists_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end, int64_t src_cap,
+                               const int32_t *src_cnt, const uint64_t *src_list) {
+    WC_CHECK(ctx && ctx->nr.prepared && src_cnt && src_list && src_cap > 0, WC_E_ARG, "newref: bad argument");
+    WC_CHECK(row_begin >= 0 && row_begin <= row_end && row_end <= ctx->nr.n_bins, WC_E_ARG, "newref: bad row range");
+    if (row_end == row_begin) return WC_OK;
+    NewrefState &st = ctx->nr;
+    hipLaunchKernelGGL(k_import_lists, dim3((unsigned)(row_end - row_begin)), dim3(64), 0, (hipStream_t)stream,
+                       st.cnt.as<int>(), st.list.as<unsigned long long>(), (int)st.cap, row_begin, (int)src_cap,
+                       src_cnt, (const unsigned long long *)src_list);
+    WC_HIP(hipGetLastError());
+    return WC_OK;
 }
 
 int wc_newref_collect_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t row_end, int tile_rank,
@@ -868,15 +946,23 @@ int wc_newref_collect_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t
     WC_CHECK(tile_ranks >= 1 && tile_rank >= 0 && tile_rank < tile_ranks, WC_E_ARG, "newref: bad tile rank");
     if (row_begin == row_end) return WC_OK;
     hipStream_t stream = (hipStream_t)stream_;
-    std::vector<int4> tiles;
-    build_tiles(st, row_begin, row_end, tile_rank, tile_ranks, tiles);
-    ctx->last_stats[2] = (int64_t)tiles.size();
+    std::vector<int64_t> key = {st.n_bins, row_begin, row_end, tile_rank, tile_ranks};
+    for (int c = 0; c <= st.n_chrom; ++c) key.push_back(st.chrom_off[c]);
+    if (key != st.tiles1_key) {
+        std::vector<int4> tiles;
+        build_tiles(st, row_begin, row_end, tile_rank, tile_ranks, tiles);
+        int rc;
+        if ((rc = st.tiles.reserve(sizeof(int4) * std::max<size_t>(tiles.size(), 1)))) return rc;
+        if (!tiles.empty()) {
+            WC_HIP(hipMemcpyAsync(st.tiles.p, tiles.data(), sizeof(int4) * tiles.size(), hipMemcpyHostToDevice, stream));
+            WC_HIP(hipStreamSynchronize(stream));
+        }
+        st.tiles1_key = key;
+        st.tiles1_n = (int64_t)tiles.size();
+    }
+    ctx->last_stats[2] = st.tiles1_n;
     ctx->last_stats[3] = st.n_sample_cols;
-    if (tiles.empty()) return WC_OK;
-    int rc;
-    if ((rc = st.tiles.reserve(sizeof(int4) * tiles.size()))) return rc;
-    WC_HIP(hipMemcpyAsync(st.tiles.p, tiles.data(), sizeof(int4) * tiles.size(), hipMemcpyHostToDevice, stream));
-    WC_HIP(hipStreamSynchronize(stream));
+    if (st.tiles1_n == 0) return WC_OK;
     GramArgs g{};
     g.P = g.Q = st.a32.as<float>();
     g.ld = st.k_pad;
@@ -884,7 +970,7 @@ int wc_newref_collect_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t
     g.nbP = g.nbQ = st.norm_lo.as<float>();
     g.chP = g.chQ = st.chrom_of_row.as<int>();
     g.tiles = st.tiles.as<int4>();
-    g.ntiles = (int)tiles.size();
+    g.ntiles = (int)st.tiles1_n;
     g.thr = st.thr.as<float>();
     g.cnt = st.cnt.as<int>();
     g.list = st.list.as<unsigned long long>();

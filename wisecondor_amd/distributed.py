@@ -1,0 +1,206 @@
+"""One-process-per-GPU drivers of the hot path (torch.distributed over RCCL/xGMI).
+
+newref  The reference parallelises `newref` by splitting the target rows into
+        parts and gathering part files (wisecondor.py:47-61, 135-158).  Here the
+        symmetric distance-tile space is dealt round-robin to the ranks, which
+        halves the MFMA work compared with row parts; the price is one exchange
+        step: every rank holds partial candidate lists for ALL rows, so the
+        lists of each row range travel to the rank that owns it (all-to-all),
+        the owner finishes its rows (float64 re-score, stable top-k) and the
+        [rows, k] results are all-gathered.  Thresholds are computed per owner
+        and all-gathered first.  Row ownership is the reference's getPart.
+test    Samples are independent (one per invocation in the reference,
+        wisecondor.py:193-199): the batch is sharded by sample, no collective.
+
+torch is used for device memory, streams and the collectives only; all
+arithmetic happens behind the C ABI (include/wisecondor_hip.h).
+"""
+import numpy as np
+
+from . import _lib
+
+
+def row_range(rank, world, n_bins):
+    """Rows owned by `rank`: getPart(rank, world, bins) (wisetools.py:358-361)."""
+    per = n_bins / float(world)
+    return int(per * rank), int(per * (rank + 1))
+
+
+class HipStages(object):
+    """The four newref stages of the C ABI on torch CUDA tensors / the current stream."""
+
+    def __init__(self, ctx, X, chrom_bins, k, sum_order):
+        import torch
+        self.torch = torch
+        self.lib = _lib.load()
+        self.ctx = ctx
+        self.X = X
+        self.bins = np.ascontiguousarray(chrom_bins, dtype=np.int64)
+        self.k = int(k)
+        self.order = int(sum_order)
+        self.n_bins, self.n_samples = int(X.shape[0]), int(X.shape[1])
+        self.device = X.device
+
+    def _stream(self):
+        return self.torch.cuda.current_stream().cuda_stream
+
+    def prepare(self):
+        _lib.check(self.lib.wc_newref_prepare_dev(self.ctx, self._stream(), self.X.data_ptr(), self.n_bins,
+                                                  self.n_samples, _lib.ptr(self.bins), len(self.bins), self.k,
+                                                  self.order))
+        self.cap = int(self.lib.wc_newref_list_capacity(self.ctx))
+
+    def thresholds(self, rb, re):
+        _lib.check(self.lib.wc_newref_thresholds_dev(self.ctx, self._stream(), rb, re))
+
+    def get_thr(self, rb, re, out):
+        _lib.check(self.lib.wc_newref_get_thresholds_dev(self.ctx, self._stream(), rb, re, out.data_ptr()))
+
+    def set_thr(self, rb, re, src):
+        _lib.check(self.lib.wc_newref_set_thresholds_dev(self.ctx, self._stream(), rb, re, src.data_ptr()))
+
+    def collect(self, rb, re, tile_rank, tile_ranks):
+        _lib.check(self.lib.wc_newref_collect_dev(self.ctx, self._stream(), rb, re, tile_rank, tile_ranks))
+
+    def export(self, rb, re, cap, cnt, lst):
+        _lib.check(self.lib.wc_newref_export_lists_dev(self.ctx, self._stream(), rb, re, cap, cnt.data_ptr(),
+                                                       lst.data_ptr()))
+
+    def import_(self, rb, re, cap, cnt, lst):
+        _lib.check(self.lib.wc_newref_import_lists_dev(self.ctx, self._stream(), rb, re, cap, cnt.data_ptr(),
+                                                       lst.data_ptr()))
+
+    def finish(self, rb, re, idx, dst):
+        _lib.check(self.lib.wc_newref_finish_dev(self.ctx, self._stream(), rb, re, idx.data_ptr(), dst.data_ptr()))
+
+    def empty(self, shape, dtype):
+        return self.torch.empty(shape, dtype=dtype, device=self.device)
+
+
+class NewrefJob(object):
+    """getReference for all rows, on `world` ranks; every rank ends with the full result."""
+
+    def __init__(self, ctx, X, chrom_bins, k, sum_order, rank=0, world=1, stages=None, dist=None):
+        import torch
+        self.torch = torch
+        self.rank, self.world = int(rank), int(world)
+        self.st = stages if stages is not None else HipStages(ctx, X, chrom_bins, k, sum_order)
+        self.k = int(k)
+        self.n_bins = int(self.st.n_bins)
+        if dist is None and self.world > 1:
+            import torch.distributed as dist
+        self.dist = dist
+        self.ranges = [row_range(r, self.world, self.n_bins) for r in range(self.world)]
+        self.max_rows = max(e - b for b, e in self.ranges)
+        t = torch
+        e = self.st.empty
+        if self.world == 1:
+            self.idx = e((self.n_bins, self.k), t.int32)
+            self.dst = e((self.n_bins, self.k), t.float64)
+        else:
+            self.idx_own = e((self.max_rows, self.k), t.int32)
+            self.dst_own = e((self.max_rows, self.k), t.float64)
+            self.idx_all = e((self.world, self.max_rows, self.k), t.int32)
+            self.dst_all = e((self.world, self.max_rows, self.k), t.float64)
+            self.thr_own = e((self.max_rows,), t.float32)
+            self.thr_all = e((self.world, self.max_rows), t.float32)
+            self.buffers_ready = False
+
+    def _alloc_exchange(self):
+        t = self.torch
+        e = self.st.empty
+        cap = self.st.cap
+        self.cap_x = int(min(cap, max(64, (2 * cap) // self.world)))
+        self.send_cnt = e((self.world, self.max_rows), t.int32)
+        self.recv_cnt = e((self.world, self.max_rows), t.int32)
+        self.send_lst = e((self.world, self.max_rows, self.cap_x), t.int64)
+        self.recv_lst = e((self.world, self.max_rows, self.cap_x), t.int64)
+        self.buffers_ready = True
+
+    def run(self, collect_events=None):
+        st = self.st
+        st.prepare()
+        if self.world == 1:
+            st.thresholds(0, self.n_bins)
+            if collect_events:
+                collect_events[0].record()
+            st.collect(0, self.n_bins, 0, 1)
+            if collect_events:
+                collect_events[1].record()
+            st.finish(0, self.n_bins, self.idx, self.dst)
+            return self.idx, self.dst
+
+        dist = self.dist
+        rb, re = self.ranges[self.rank]
+        if not self.buffers_ready:
+            self._alloc_exchange()
+        # thresholds: owner computes, everyone needs them for the tiles it was dealt
+        st.thresholds(rb, re)
+        self.thr_own.zero_()
+        st.get_thr(rb, re, self.thr_own)
+        dist.all_gather_into_tensor(self.thr_all.view(-1), self.thr_own)
+        for r, (b, e) in enumerate(self.ranges):
+            if r != self.rank:
+                st.set_thr(b, e, self.thr_all[r])
+        # this rank's share of the symmetric tile space, candidates for all rows
+        if collect_events:
+            collect_events[0].record()
+        st.collect(0, self.n_bins, self.rank, self.world)
+        if collect_events:
+            collect_events[1].record()
+        # candidate lists travel to the rows' owners
+        self.send_cnt.zero_()
+        for r, (b, e) in enumerate(self.ranges):
+            if r != self.rank:
+                st.export(b, e, self.cap_x, self.send_cnt[r], self.send_lst[r])
+        dist.all_to_all_single(self.recv_cnt.view(-1), self.send_cnt.view(-1))
+        dist.all_to_all_single(self.recv_lst.view(-1), self.send_lst.view(-1))
+        for r in range(self.world):
+            if r != self.rank:
+                st.import_(rb, re, self.cap_x, self.recv_cnt[r], self.recv_lst[r])
+        # owners finish their rows; results to everyone
+        st.finish(rb, re, self.idx_own, self.dst_own)
+        dist.all_gather_into_tensor(self.idx_all.view(-1), self.idx_own.view(-1))
+        dist.all_gather_into_tensor(self.dst_all.view(-1), self.dst_own.view(-1))
+        idx = self.torch.cat([self.idx_all[r, :e - b] for r, (b, e) in enumerate(self.ranges)])
+        dst = self.torch.cat([self.dst_all[r, :e - b] for r, (b, e) in enumerate(self.ranges)])
+        return idx, dst
+
+
+class TestBatch(object):
+    """Device-resident batched `test` of this rank's sample shard (no collective)."""
+
+    def __init__(self, reference, counts, threshold, minrefbins=25, repeats=5, chromosomes=None,
+                 max_calls=64):
+        import torch
+        self.torch = torch
+        self.lib = _lib.load()
+        self.ref = reference
+        self.counts = counts
+        self.ns = int(counts.shape[0])
+        self.thr = float(threshold)
+        self.minrefbins, self.repeats, self.max_calls = int(minrefbins), int(repeats), int(max_calls)
+        self.sel = np.ascontiguousarray(chromosomes if chromosomes is not None else range(1, 23), dtype=np.int32)
+        dev = counts.device
+        f64 = torch.float64
+        self.results_z = torch.empty((self.ns, reference.n_total), dtype=f64, device=dev)
+        self.results_r = torch.empty((self.ns, reference.n_total), dtype=f64, device=dev)
+        self.cwz = torch.empty((self.ns, len(self.sel)), dtype=f64, device=dev)
+        self.calls = torch.zeros((self.ns, self.max_calls, 5), dtype=f64, device=dev)
+        self.n_calls = torch.zeros((self.ns,), dtype=torch.int32, device=dev)
+        self.asdef = torch.empty((self.ns,), dtype=f64, device=dev)
+
+    def run(self):
+        stream = self.torch.cuda.current_stream().cuda_stream
+        _lib.check(self.lib.wc_test_batch_dev(
+            self.ref.ctx, stream, self.ref.handle, self.counts.data_ptr(), self.ns, self.thr, self.minrefbins,
+            self.repeats, _lib.ptr(self.sel), len(self.sel), self.max_calls, self.results_z.data_ptr(),
+            self.results_r.data_ptr(), self.cwz.data_ptr(), self.calls.data_ptr(), self.n_calls.data_ptr(),
+            self.asdef.data_ptr()))
+
+
+def shard_samples(n_samples, rank, world):
+    """Contiguous sample shard of `rank` (sizes differ by at most one)."""
+    per, extra = divmod(n_samples, world)
+    lo = rank * per + min(rank, extra)
+    return lo, lo + per + (1 if rank < extra else 0)
