@@ -163,7 +163,7 @@ def main():
         import contextlib
         import io
         sums = np.cumsum(bins)
-        parts = max(1, int(round(B * float(B) * S / 4.0e9)))       # ~10-20 s of numpy work per slice
+        parts = max(1, int(round(B * float(B) * S / 1.2e10)))      # ~10-20 s of numpy work per slice
         lo, hi = wo.get_part(0, parts, B)
         t0 = time.perf_counter()
         with contextlib.redirect_stdout(io.StringIO()), np.errstate(all="ignore"):
@@ -175,6 +175,21 @@ def main():
                "sample": "oracle get_reference (numpy distance + Python insertion top-k, the reference's own "
                          "structure) on target rows [%d,%d) of %d x all candidates, %.1f s" % (lo, hi, B, t_cpu),
                "matches_gpu_indices": ok}
+        # the reference's `test` on ONE of the batch's samples (fillTri dominates: one np.sum per window)
+        ref_dict = dict(binsize=np.float64(binsize), indexes=reference.indexes, distances=reference.distances,
+                        chromosome_sizes=inp["chrom_bins"], mask=inp["mask"], masked_sizes=inp["masked_bins"],
+                        pca_mean=inp["pca_mean"], pca_components=inp["pca_components"])
+        t0 = time.perf_counter()
+        with np.errstate(all="ignore"):
+            o = wo.test_sample(inp["tests"][0], binsize, ref_dict)
+        t_cpu_test = time.perf_counter() - t0
+        nc = int(tb.n_calls[0].item())
+        gpu_calls = tb.calls[0, :nc].cpu().numpy()
+        cpu_calls = np.asarray(o["results_calls"], dtype=np.float64).reshape(-1, 5)
+        cpu["test"] = {"value": 1.0 / t_cpu_test, "unit": "samples/s", "cores": 1, "kind": "port",
+                       "sample": "oracle test_sample on 1 of the batch's samples, %.1f s" % t_cpu_test,
+                       "matches_gpu_calls": bool(cpu_calls.shape == gpu_calls.shape and
+                                                 np.array_equal(cpu_calls[:, :3], gpu_calls[:, :3]))}
 
     if rank == 0:
         # algorithmic work of the dominant kernel: one multiply-add per sample per unordered pair

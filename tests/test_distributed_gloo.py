@@ -1,0 +1,140 @@
+"""world_size-2 (and 3) gloo runs of the multi-GPU newref choreography on CPU.
+
+The HIP stages cannot run here, so the driver (wisecondor_amd.distributed.NewrefJob:
+threshold all-gather, round-robin tile deal, candidate-list all-to-all, owner-side
+finish, result all-gather) is exercised with a numpy stand-in for the four stages
+that follows the same contract (test infrastructure only).  The multi-rank result
+must equal the single-rank result and the oracle, bit for bit.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import wc_oracle as wo
+from wisecondor_amd.distributed import NewrefJob
+
+TILE = 8
+
+
+class NumpyStages(object):
+    """Same contract as HipStages, exact float64 distances as keys."""
+
+    def __init__(self, X, bins, k):
+        self.X = np.asarray(X)
+        self.bins = np.asarray(bins, dtype=np.int64)
+        self.k = k
+        self.n_bins, self.n_samples = self.X.shape
+        self.off = np.concatenate([[0], np.cumsum(self.bins)])
+        self.chrom = np.repeat(np.arange(len(bins)), self.bins)
+
+    def prepare(self):
+        self.cap = 64
+        self.thr = np.full(self.n_bins, -np.inf, dtype=np.float32)
+        self.lists = [[] for _ in range(self.n_bins)]
+
+    def empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype)
+
+    def thresholds(self, rb, re):
+        # owner-side rule that depends on the row only: the distance to the 30th nearest candidate
+        for i in range(rb, re):
+            d = self._dist_row(i)
+            self.thr[i] = np.float32(np.sort(d[np.isfinite(d)])[min(29, np.isfinite(d).sum() - 1)] * 1.0001)
+
+    def _dist_row(self, i):
+        d = np.sum(np.power(self.X - self.X[i], 2), 1)
+        d[self.chrom == self.chrom[i]] = np.inf
+        return d
+
+    def get_thr(self, rb, re, out):
+        out[:re - rb] = torch.from_numpy(self.thr[rb:re].copy())
+
+    def set_thr(self, rb, re, src):
+        self.thr[rb:re] = src[:re - rb].numpy()
+
+    def collect(self, rb, re, rank, ranks):
+        nb = (self.n_bins + TILE - 1) // TILE
+        serial = 0
+        for I in range(nb):
+            for J in range(I, nb):
+                mine = serial % ranks == rank
+                serial += 1
+                if not mine:
+                    continue
+                for i in range(I * TILE, min((I + 1) * TILE, self.n_bins)):
+                    for j in range(J * TILE, min((J + 1) * TILE, self.n_bins)):
+                        if self.chrom[i] == self.chrom[j] or (I == J and j <= i):
+                            continue
+                        d = float(np.sum(np.power(self.X[j] - self.X[i], 2)))
+                        if d <= self.thr[i]:
+                            self.lists[i].append(j)
+                        if d <= self.thr[j]:
+                            self.lists[j].append(i)
+
+    def export(self, rb, re, cap, cnt, lst):
+        for r in range(rb, re):
+            n = len(self.lists[r])
+            cnt[r - rb] = n
+            lst[r - rb, :min(n, cap)] = torch.tensor(self.lists[r][:cap], dtype=torch.int64)
+
+    def import_(self, rb, re, cap, cnt, lst):
+        for r in range(rb, re):
+            n = int(cnt[r - rb])
+            assert n <= cap
+            self.lists[r].extend(int(v) for v in lst[r - rb, :n])
+
+    def finish(self, rb, re, idx, dst):
+        for r in range(rb, re):
+            cand = np.array(sorted(set(self.lists[r])), dtype=np.int64)
+            assert len(cand) == len(self.lists[r]), "duplicate candidate: a tile was processed twice"
+            d = np.sum(np.power(self.X[cand] - self.X[r], 2), 1)
+            order = np.argsort(d, kind="stable")[:self.k]
+            c = self.chrom[r]
+            lo, hi = self.off[c], self.off[c + 1]
+            loc = np.where(cand[order] < lo, cand[order], cand[order] - (hi - lo))
+            idx[r - rb] = torch.from_numpy(loc.astype(np.int32))
+            dst[r - rb] = torch.from_numpy(d[order])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, X, bins, k, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        st = NumpyStages(X, bins, k)
+        job = NewrefJob(None, None, bins, k, 0, rank=rank, world=world, stages=st, dist=dist)
+        for _ in range(2):          # second run reuses the exchange buffers
+            idx, dst = job.run()
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), idx=idx.numpy(), dst=dst.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_rank_equals_single_rank_and_oracle(tmp_path, world):
+    rng = np.random.RandomState(5)
+    bins = np.array([9, 14, 7, 12, 11], dtype=np.int64)
+    X = 1.0 + 0.05 * rng.standard_normal((int(bins.sum()), 6))
+    k = 10
+    mp.spawn(_worker, args=(world, _free_port(), X, bins, k, str(tmp_path)), nprocs=world, join=True)
+    st = NumpyStages(X, bins, k)
+    one_i, one_d = NewrefJob(None, None, bins, k, 0, rank=0, world=1, stages=st).run()
+    want_i, want_d = wo.get_reference(X, bins, np.cumsum(bins), k, 1, 1, fast=True)
+    assert np.array_equal(one_i.numpy(), want_i) and np.array_equal(one_d.numpy(), want_d)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        assert np.array_equal(got["idx"], want_i), r
+        assert np.array_equal(got["dst"], want_d), r

@@ -96,7 +96,7 @@ __host__ __device__ inline double f64_from_ordered(uint64_t u) {
 // either in one thread or across an aligned group of 8 lanes (lane j owns the
 // elements congruent to j mod 8, which is exactly numpy's accumulator r[j]).
 #define WC_PW_BLOCK 128
-#define WC_PW_DEPTH 24
+#define WC_PW_DEPTH 12
 
 // Leaf evaluated by ONE thread; f(i) returns element i.
 template <class F> __device__ inline double pw_leaf_serial(F f, int64_t off, int n) {
@@ -133,7 +133,17 @@ template <class F> __device__ inline double pw_leaf_group8(F f, int64_t off, int
     }
     int body = n - (n % 8);
     double r = f(off + sub);
-    for (int i = 8; i < body; i += 8) r = r + f(off + i + sub);
+    int i = 8;
+    // four loads in flight per lane; the adds stay in numpy's order
+    for (; i + 24 < body; i += 32) {
+        double v0 = f(off + i + sub), v1 = f(off + i + 8 + sub);
+        double v2 = f(off + i + 16 + sub), v3 = f(off + i + 24 + sub);
+        r = r + v0;
+        r = r + v1;
+        r = r + v2;
+        r = r + v3;
+    }
+    for (; i < body; i += 8) r = r + f(off + i + sub);
     // (r0+r1), (r2+r3), ... : fp addition is commutative, so the xor butterfly
     // yields numpy's tree in every lane.
     r = r + __shfl_xor(r, 1);

@@ -37,6 +37,7 @@ struct TestState {
     wc::DevBuf prefix, reg_abs, reg_flag, rs, jobs_a, jobs_b, job_cnt, partial, job_res, hot, cand, cand_cnt;
     wc::DevBuf seg, seg_cnt, out_val, out_x, out_y, out_n, whole, effect, misc, reduce_tmp;
     int64_t rs_len = 0;
+    int64_t last_segs = 0;
 };
 
 struct wc_ctx {

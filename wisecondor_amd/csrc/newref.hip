@@ -38,51 +38,45 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------ prepare ----
-// Column statistics over finite values; optional window |v - centre| <= radius.
-// mode 0: sum(v), count   mode 1: sum(|v - centre|), count
-__global__ void k_col_partial(const double *__restrict__ X, int64_t B, int64_t S, int R, int mode,
-                              const double *__restrict__ centre, const double *__restrict__ radius,
-                              double *__restrict__ psum, double *__restrict__ pcnt) {
+// Robust per-sample centre from a strided subset of rows: mean -> 8 x mean absolute
+// deviation window -> trimmed mean (all over finite values).  Any centre is valid
+// (distances are translation invariant per sample); a good one keeps the float32
+// norms, and with them the error interval of the MFMA distances, small even when
+// a few bins are wild outliers.  One block owns 64 samples end to end.
+__global__ __launch_bounds__(256) void k_col_centre(const double *__restrict__ X, int64_t B, int64_t S,
+                                                    int64_t n_rows, int64_t row_step,
+                                                    double *__restrict__ centre) {
     __shared__ double sh_s[4][64];
     __shared__ double sh_c[4][64];
-    int64_t s = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    int64_t per = (B + R - 1) / R;
-    int64_t r0 = (int64_t)blockIdx.y * per;
-    int64_t r1 = r0 + per < B ? r0 + per : B;
-    double sum = 0.0, cnt = 0.0;
-    if (s < S) {
-        double c = centre ? centre[s] : 0.0;
-        double rad = radius ? radius[s] : 0.0;
-        for (int64_t r = r0 + threadIdx.y; r < r1; r += 4) {
-            double v = X[r * S + s];
-            if (!isfinite(v)) continue;
-            if (radius && !(fabs(v - c) <= rad)) continue;
-            sum += (mode == 1) ? fabs(v - c) : v;
-            cnt += 1.0;
+    __shared__ double sh_v[64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t s = (int64_t)blockIdx.x * 64 + tx;
+    double c = 0.0, rad = 0.0;
+    for (int pass = 0; pass < 3; ++pass) {
+        double sum = 0.0, cnt = 0.0;
+        if (s < S) {
+            for (int64_t q = ty; q < n_rows; q += 4) {
+                double v = X[(q * row_step) * S + s];
+                if (!isfinite(v)) continue;
+                if (pass == 2 && !(fabs(v - c) <= rad)) continue;
+                sum += (pass == 1) ? fabs(v - c) : v;
+                cnt += 1.0;
+            }
         }
+        sh_s[ty][tx] = sum;
+        sh_c[ty][tx] = cnt;
+        __syncthreads();
+        if (ty == 0) {
+            double a = (sh_s[0][tx] + sh_s[1][tx]) + (sh_s[2][tx] + sh_s[3][tx]);
+            double b = (sh_c[0][tx] + sh_c[1][tx]) + (sh_c[2][tx] + sh_c[3][tx]);
+            sh_v[tx] = b > 0.0 ? a / b : 0.0;
+        }
+        __syncthreads();
+        if (pass == 0) c = sh_v[tx];
+        else if (pass == 1) rad = 8.0 * sh_v[tx];
+        else if (ty == 0 && s < S) centre[s] = sh_v[tx];
+        __syncthreads();
     }
-    sh_s[threadIdx.y][threadIdx.x] = sum;
-    sh_c[threadIdx.y][threadIdx.x] = cnt;
-    __syncthreads();
-    if (threadIdx.y == 0 && s < S) {
-        double a = (sh_s[0][threadIdx.x] + sh_s[1][threadIdx.x]) + (sh_s[2][threadIdx.x] + sh_s[3][threadIdx.x]);
-        double b = (sh_c[0][threadIdx.x] + sh_c[1][threadIdx.x]) + (sh_c[2][threadIdx.x] + sh_c[3][threadIdx.x]);
-        psum[(int64_t)blockIdx.y * S + s] = a;
-        pcnt[(int64_t)blockIdx.y * S + s] = b;
-    }
-}
-
-// out[s] = scale * sum/count (0 when nothing was counted)
-__global__ void k_col_finish(const double *__restrict__ psum, const double *__restrict__ pcnt, int R,
-                             int64_t S, double scale, double *__restrict__ out) {
-    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
-    double a = 0.0, b = 0.0;
-    for (int r = 0; r < R; ++r) {
-        a += psum[(int64_t)r * S + s];
-        b += pcnt[(int64_t)r * S + s];
-    }
-    out[s] = b > 0.0 ? scale * (a / b) : 0.0;
 }
 
 // One wave per row: centred float32 image, norm interval, chromosome id.
@@ -432,7 +426,7 @@ struct FinishArgs {
     int32_t *idx_out;
     double *dist_out;
     int *fb_rows, *fb_count;
-    unsigned long long *stats;
+    int *row_stat;
     int sum_order;
 };
 
@@ -456,16 +450,31 @@ __device__ inline double exact_distance(const double *__restrict__ xj, const dou
             },
             S, sub);
     }
+    // left-to-right sum: the chain is serial per candidate, so keep eight coalesced
+    // loads per lane in flight and feed the chain by 8-lane broadcasts.  Padding
+    // with +0.0 is exact because every partial sum is >= +0 (or NaN).
     double acc = 0.0;
-    for (int64_t s0 = 0; s0 < S; s0 += 8) {
-        int64_t s = s0 + sub;
-        double sq = 0.0;
-        if (s < S) {
-            double df = xj[s] - xi[s];
-            sq = df * df;
+    double cur[8], nxt[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        int64_t s = 8 * u + sub;
+        double df = (s < S) ? xj[s] - xi[s] : 0.0;
+        cur[u] = df * df;
+    }
+    for (int64_t s0 = 0; s0 < S; s0 += 64) {
+        // next 64 samples are requested before the serial chain consumes the current ones
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            int64_t s = s0 + 64 + 8 * u + sub;
+            double df = (s < S) ? xj[s] - xi[s] : 0.0;
+            nxt[u] = df * df;
         }
-        int lim = (S - s0) < 8 ? (int)(S - s0) : 8;
-        for (int i = 0; i < lim; ++i) acc = acc + __shfl(sq, i, 8);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc = acc + __shfl(cur[u], i, 8);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
     }
     return acc;
 }
@@ -537,6 +546,7 @@ __global__ __launch_bounds__(256) void k_finish(FinishArgs a) {
         if (tid == 0) {
             int at = atomicAdd(a.fb_count, 1);
             a.fb_rows[at] = (int)row;
+            a.row_stat[row] = -1;  // exact fallback path
         }
         return;
     }
@@ -574,10 +584,7 @@ __global__ __launch_bounds__(256) void k_finish(FinishArgs a) {
         a.idx_out[orow * a.k + t] = oi;
         a.dist_out[orow * a.k + t] = od;
     }
-    if (tid == 0) {
-        atomicAdd(&a.stats[0], 1ull);
-        atomicAdd(&a.stats[4], (unsigned long long)R);
-    }
+    if (tid == 0) a.row_stat[row] = R;  // >= 0: fast path, number of float64 re-scores
 }
 
 // Exact path for rows whose certificate failed (ties at the boundary, outlier
@@ -655,7 +662,6 @@ __global__ __launch_bounds__(256) void k_fallback(FinishArgs a, unsigned long lo
             last_d = bd;
             last_j = bj;
         }
-        if (tid == 0) atomicAdd(&a.stats[1], 1ull);
     }
 }
 
@@ -768,9 +774,7 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
     if (M > st.bins_pad) M = st.bins_pad;
     st.n_sample_cols = M;  // padded count; real sample rows = min(M, n_bins)
 
-    const int R = 64;
     int rc;
-    if ((rc = st.col_partial.reserve(sizeof(double) * 2 * R * n_samples))) return rc;
     if ((rc = st.col_mean.reserve(sizeof(double) * 3 * n_samples))) return rc;
     if ((rc = st.a32.reserve(sizeof(float) * st.bins_pad * st.k_pad))) return rc;
     if ((rc = st.norm_lo.reserve(sizeof(float) * st.bins_pad))) return rc;
@@ -787,7 +791,7 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
     if ((rc = st.list.reserve(sizeof(uint64_t) * st.bins_pad * st.cap))) return rc;
     if ((rc = st.fb_rows.reserve(sizeof(int) * st.bins_pad))) return rc;
     if ((rc = st.fb_count.reserve(sizeof(int) * 4))) return rc;
-    if ((rc = st.stats.reserve(sizeof(uint64_t) * 8))) return rc;
+    if ((rc = st.stats.reserve(sizeof(int) * st.bins_pad))) return rc;
 
     WC_HIP(hipMemcpyAsync(st.chrom_off_dev.p, st.chrom_off, sizeof(int64_t) * (n_chrom + 1),
                           hipMemcpyHostToDevice, stream));
@@ -812,23 +816,13 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
         st.tiles1_key.clear();
     }
 
-    double *psum = st.col_partial.as<double>();
-    double *pcnt = psum + (int64_t)R * n_samples;
-    double *mean1 = st.col_mean.as<double>();
-    double *rad = mean1 + n_samples;
-    double *mean2 = rad + n_samples;
-    dim3 pg((unsigned)((n_samples + 63) / 64), R), pb(64, 4);
-    unsigned fg = (unsigned)((n_samples + 255) / 256);
-    // mean -> 8 x mean absolute deviation window -> trimmed mean (robust to outlier bins)
-    hipLaunchKernelGGL(k_col_partial, pg, pb, 0, stream, corrected, n_bins, n_samples, R, 0,
-                       (const double *)nullptr, (const double *)nullptr, psum, pcnt);
-    hipLaunchKernelGGL(k_col_finish, dim3(fg), dim3(256), 0, stream, psum, pcnt, R, n_samples, 1.0, mean1);
-    hipLaunchKernelGGL(k_col_partial, pg, pb, 0, stream, corrected, n_bins, n_samples, R, 1,
-                       (const double *)mean1, (const double *)nullptr, psum, pcnt);
-    hipLaunchKernelGGL(k_col_finish, dim3(fg), dim3(256), 0, stream, psum, pcnt, R, n_samples, 8.0, rad);
-    hipLaunchKernelGGL(k_col_partial, pg, pb, 0, stream, corrected, n_bins, n_samples, R, 0,
-                       (const double *)mean1, (const double *)rad, psum, pcnt);
-    hipLaunchKernelGGL(k_col_finish, dim3(fg), dim3(256), 0, stream, psum, pcnt, R, n_samples, 1.0, mean2);
+    double *mean2 = st.col_mean.as<double>();
+    {
+        int64_t n_rows = std::min<int64_t>(n_bins, 1024);
+        int64_t row_step = n_bins / n_rows;
+        hipLaunchKernelGGL(k_col_centre, dim3((unsigned)((n_samples + 63) / 64)), dim3(256), 0, stream, corrected,
+                           n_bins, n_samples, n_rows, row_step, mean2);
+    }
 
     hipLaunchKernelGGL(k_convert, dim3((unsigned)(st.bins_pad / 4)), dim3(256), 0, stream, corrected, n_bins,
                        n_samples, st.bins_pad, st.k_pad, (const double *)mean2, (double)st.beta,
@@ -841,7 +835,7 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
     hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)((st.bins_pad + 255) / 256)), dim3(256), 0, stream,
                        st.thr.as<float>(), st.bins_pad, -INFINITY);
     WC_HIP(hipMemsetAsync(st.cnt.p, 0, sizeof(int) * st.bins_pad, stream));
-    WC_HIP(hipMemsetAsync(st.stats.p, 0, sizeof(uint64_t) * 8, stream));
+    WC_HIP(hipMemsetAsync(st.stats.p, 0xFE, sizeof(int) * st.bins_pad, stream));  // "row not finished"
     WC_HIP(hipGetLastError());
     st.prepared = true;
     return WC_OK;
@@ -1011,7 +1005,7 @@ int wc_newref_finish_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t 
     a.dist_out = dist_out;
     a.fb_rows = st.fb_rows.as<int>();
     a.fb_count = st.fb_count.as<int>();
-    a.stats = st.stats.as<unsigned long long>();
+    a.row_stat = st.stats.as<int>();
     a.sum_order = st.sum_order;
     hipLaunchKernelGGL(k_finish, dim3((unsigned)(row_end - row_begin)), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(k_fallback, dim3(FB_BLOCKS), dim3(256), 0, stream, a,
@@ -1056,13 +1050,18 @@ int wc_get_reference(wc_ctx *ctx, const double *corrected, int64_t n_bins, int64
 
 int wc_newref_stats(wc_ctx *ctx, int64_t out[8]) {
     WC_CHECK(ctx && out, WC_E_ARG, "stats: NULL argument");
-    uint64_t dev[8] = {0};
-    if (ctx->nr.stats.p) {
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    NewrefState &st = ctx->nr;
+    if (st.stats.p && st.prepared) {
         WC_HIP(hipSetDevice(ctx->device));
         WC_HIP(hipDeviceSynchronize());
-        WC_HIP(hipMemcpy(dev, ctx->nr.stats.p, sizeof(dev), hipMemcpyDeviceToHost));
+        std::vector<int> rows(st.n_bins);
+        WC_HIP(hipMemcpy(rows.data(), st.stats.p, sizeof(int) * st.n_bins, hipMemcpyDeviceToHost));
+        for (int64_t r = 0; r < st.n_bins; ++r) {
+            if (rows[r] >= 0) { out[0] += 1; out[4] += rows[r]; }
+            else if (rows[r] == -1) out[1] += 1;
+        }
     }
-    for (int i = 0; i < 8; ++i) out[i] = (int64_t)dev[i];
     out[2] = ctx->last_stats[2];
     out[3] = ctx->last_stats[3];
     return WC_OK;

@@ -290,7 +290,21 @@ __global__ void k_sd_avg(const double *__restrict__ sdT, int64_t B, int64_t Ns, 
     if (i >= Ns) return;
     double s = 0.0;
     long long c = 0;
-    for (int64_t b = 0; b < B; ++b) {
+    int64_t b = 0;
+    // the sum is serial by definition (a Python loop in the reference); keep 16 loads
+    // in flight.  Skipped (NaN) terms add +0.0, which is exact for a sum of sds >= 0.
+    for (; b + 16 <= B; b += 16) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = sdT[(b + u) * Ns + i];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            bool ok = v[u] == v[u];
+            s = s + (ok ? v[u] : 0.0);
+            c += ok;
+        }
+    }
+    for (; b < B; ++b) {
         double v = sdT[b * Ns + i];
         if (v == v) { s += v; ++c; }
     }
@@ -699,50 +713,81 @@ __global__ void k_seg_gather(const Seg *__restrict__ segs, int n_segs, int max_c
     }
 }
 
-// Call coordinates and effect size (wisecondor.py:239-257): one workgroup per call.
-__global__ __launch_bounds__(256) void k_call_post(const Region *__restrict__ regions, const double *__restrict__ rc,
-                                                   const int *__restrict__ gpos, const double *__restrict__ out_val,
-                                                   const int *__restrict__ out_x, const int *__restrict__ out_y,
-                                                   const int *__restrict__ out_n, int max_calls,
-                                                   double *__restrict__ reg_calls) {
-    __shared__ double pick[2];
-    __shared__ int has_nan;
-    const int r = blockIdx.y, cidx = blockIdx.x, tid = threadIdx.x;
-    int n = out_n[r];
-    if (n > max_calls) n = max_calls;
-    if (cidx >= n) return;
-    const Region rg = regions[r];
-    const int64_t at = (int64_t)r * max_calls + cidx;
-    const int x = out_x[at], y = out_y[at];
-    const double *v = rc + rg.off + x;
-    const int L = y - x + 1;
-    if (tid == 0) { has_nan = 0; pick[0] = pick[1] = 0.0; }
-    __syncthreads();
-    const int klo = (L - 1) / 2, khi = L / 2;
-    for (int e = tid; e < L; e += 256) {
-        double ve = v[e];
-        if (ve != ve) { has_nan = 1; continue; }
-        int rank = 0;
-        for (int f = 0; f < L; ++f) {
-            double vf = v[f];
-            rank += (vf < ve) || (vf == ve && f < e);
+// k-th smallest (0-based) of v[0..L) by radix selection on the ordered 64-bit image;
+// all 256 threads of the workgroup take part.
+__device__ inline double block_select(const double *__restrict__ v, int L, int k, int tid) {
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned long long s_prefix;
+    __shared__ int s_k;
+    unsigned long long prefix = 0ull, mask = 0ull;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        hist[tid] = 0;
+        __syncthreads();
+        for (int e = tid; e < L; e += 256) {
+            unsigned long long key = wc::f64_ordered(v[e]);
+            if ((key & mask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
         }
-        if (rank == klo) pick[0] = ve;
-        if (rank == khi) pick[1] = ve;
+        __syncthreads();
+        if (tid == 0) {
+            int kk = k, d = 0;
+            for (; d < 255; ++d) {
+                if (kk < (int)hist[d]) break;
+                kk -= (int)hist[d];
+            }
+            s_k = kk;
+            s_prefix = prefix | ((unsigned long long)d << shift);
+        }
+        __syncthreads();
+        k = s_k;
+        prefix = s_prefix;
+        mask |= 0xFFull << shift;
+        __syncthreads();
     }
+    return wc::f64_from_ordered(prefix);
+}
+
+// Call coordinates and effect size (wisecondor.py:239-257): one workgroup per segment.
+__global__ __launch_bounds__(256) void k_call_post(const Seg *__restrict__ segs, int n_segs,
+                                                   const Region *__restrict__ regions, const double *__restrict__ rc,
+                                                   const int *__restrict__ gpos, int max_calls,
+                                                   double *__restrict__ reg_calls) {
+    __shared__ int s_flag[2];
+    const int tid = threadIdx.x;
+    const Seg me = segs[blockIdx.x];
+    if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
     __syncthreads();
+    int rank = 0;
+    for (int t = tid; t < n_segs; t += 256) {
+        const Seg o = segs[t];
+        rank += (o.region == me.region && o.x < me.x);
+    }
+    if (rank) atomicAdd(&s_flag[0], rank);
+    const Region rg = regions[me.region];
+    const int x = me.x, y = me.y, L = y - x + 1;
+    const double *v = rc + rg.off + x;
+    for (int e = tid; e < L; e += 256)
+        if (v[e] != v[e]) s_flag[1] = 1;
+    __syncthreads();
+    rank = s_flag[0];
+    const bool has_nan = s_flag[1] != 0;
+    if (rank >= max_calls) return;
+    double lo = 0.0, hi = 0.0;
+    if (!has_nan) {
+        lo = block_select(v, L, (L - 1) / 2, tid);
+        hi = (L & 1) ? lo : block_select(v, L, L / 2, tid);
+    }
     if (tid == 0) {
-        double med = (L & 1) ? pick[0] : (pick[0] + pick[1]) / 2.0;  // np.median: mean of the middle pair
+        double med = (L & 1) ? lo : (lo + hi) / 2.0;  // np.median: mean of the middle pair
         if (has_nan) med = NAN;
         // the end walk of the reference restarts at `start` and re-counts it:
         // end = position(survivor y-1) + 1, or start itself when y == x
         int start = gpos[rg.off + x];
         int end = (y > x) ? gpos[rg.off + y - 1] + 1 : start;
-        double *o = reg_calls + at * 5;
+        double *o = reg_calls + ((int64_t)me.region * max_calls + rank) * 5;
         o[0] = (double)(rg.pad + 1);
         o[1] = (double)start;
         o[2] = (double)end;
-        o[3] = out_val[at];
+        o[3] = me.val;
         o[4] = med - 1.0;
     }
 }
@@ -836,6 +881,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
                  int64_t max_n, double thr, int min_search, int max_calls, hipStream_t stream) {
     TestState &ts = ctx->ts;
     int rc;
+    ts.last_segs = 0;
     if (n_regions == 0) return WC_OK;
     const int64_t job_cap = n_regions + total_len / 4 + 64;
     const int64_t seg_cap = n_regions * (int64_t)max_calls + 64;
@@ -919,6 +965,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     int h[8];
     WC_HIP(hipMemcpyAsync(h, counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
     WC_HIP(hipStreamSynchronize(stream));
+    ts.last_segs = h[4];
     if (h[4] > 0)
         hipLaunchKernelGGL(k_seg_gather, dim3((unsigned)cdiv(h[4], 256)), dim3(256), 0, stream,
                            (const Seg *)ts.seg.as<Seg>(), h[4], max_calls, ts.out_val.as<double>(), ts.out_x.as<int>(),
@@ -1211,11 +1258,11 @@ int wc_test_batch_dev(wc_ctx *ctx, void *stream_, const wc_reference *ref, const
         WC_HIP(hipMemcpyAsync(results_cwz, ts.whole.p, sizeof(double) * n_regions, hipMemcpyDeviceToDevice, stream));
     if (calls && n_calls) {
         WC_HIP(hipMemsetAsync(ts.misc.p, 0, sizeof(int) * 4, stream));
-        hipLaunchKernelGGL(k_call_post, dim3((unsigned)max_calls, (unsigned)n_regions), dim3(256), 0, stream,
-                           (const Region *)ts.regions.as<Region>(), (const double *)ts.rc.as<double>(),
-                           (const int *)ts.gpos.as<int>(), (const double *)ts.out_val.as<double>(),
-                           (const int *)ts.out_x.as<int>(), (const int *)ts.out_y.as<int>(),
-                           (const int *)ts.out_n.as<int>(), max_calls, ts.effect.as<double>());
+        if (ts.last_segs > 0)
+            hipLaunchKernelGGL(k_call_post, dim3((unsigned)ts.last_segs), dim3(256), 0, stream,
+                               (const Seg *)ts.seg.as<Seg>(), (int)ts.last_segs,
+                               (const Region *)ts.regions.as<Region>(), (const double *)ts.rc.as<double>(),
+                               (const int *)ts.gpos.as<int>(), max_calls, ts.effect.as<double>());
         hipLaunchKernelGGL(k_assemble_calls, dim3((unsigned)cdiv(Ns, 64)), dim3(64), 0, stream,
                            (const double *)ts.effect.as<double>(), (const int *)ts.out_n.as<int>(), n_sel, max_calls, Ns,
                            calls, n_calls, ts.misc.as<int>());
