@@ -187,4 +187,20 @@ template <bool GROUP8, class F> __device__ inline double pairwise_sum(F f, int64
     return result;
 }
 
+// Small per-lane value stack addressed by a wave-uniform index; the switch keeps the
+// array in registers (a runtime subscript would send it to scratch memory).
+__device__ inline void stack_set(double (&v)[10], int i, double x) {
+    switch (i) {
+        case 0: v[0] = x; break; case 1: v[1] = x; break; case 2: v[2] = x; break; case 3: v[3] = x; break;
+        case 4: v[4] = x; break; case 5: v[5] = x; break; case 6: v[6] = x; break; case 7: v[7] = x; break;
+        case 8: v[8] = x; break; default: v[9] = x; break;
+    }
+}
+__device__ inline double stack_get(const double (&v)[10], int i) {
+    switch (i) {
+        case 0: return v[0]; case 1: return v[1]; case 2: return v[2]; case 3: return v[3]; case 4: return v[4];
+        case 5: return v[5]; case 6: return v[6]; case 7: return v[7]; case 8: return v[8]; default: return v[9];
+    }
+}
+
 }  // namespace wc

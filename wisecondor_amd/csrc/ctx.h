@@ -22,7 +22,9 @@ struct NewrefState {
     wc::DevBuf col_partial, col_mean, a32, norm_lo, norm_hi, chrom_of_row, chrom_off_dev;
     wc::DevBuf sample_rows, s32, s_norm_lo, s_chrom;
     wc::DevBuf keys1, thr, cnt, list, tiles;
-    wc::DevBuf fb_rows, fb_count, fb_scratch, stats, tiles0;
+    wc::DevBuf fb_rows, fb_count, fb_scratch, stats, tiles0, pw_prog;
+    int pw_leaves = 0;
+    int64_t pw_for = -1;
     // host-side caches so that repeated calls on the same layout enqueue kernels only
     std::vector<int64_t> sample_key, tiles0_key, tiles1_key;
     int64_t tiles0_n = 0, tiles1_n = 0;
@@ -53,7 +55,7 @@ struct wc_ctx {
         return {&nr.col_partial, &nr.col_mean, &nr.a32, &nr.norm_lo, &nr.norm_hi, &nr.chrom_of_row,
                 &nr.chrom_off_dev, &nr.sample_rows, &nr.s32, &nr.s_norm_lo, &nr.s_chrom, &nr.keys1,
                 &nr.thr, &nr.cnt, &nr.list, &nr.tiles, &nr.fb_rows, &nr.fb_count, &nr.fb_scratch,
-                &nr.stats, &nr.tiles0, &tmp_a, &tmp_b, &tmp_c, &tmp_d,
+                &nr.stats, &nr.tiles0, &nr.pw_prog, &tmp_a, &tmp_b, &tmp_c, &tmp_d,
                 &ts.counts, &ts.totals, &ts.raw, &ts.proj, &ts.data, &ts.xt, &ts.xc, &ts.zt, &ts.rt, &ts.nt,
                 &ts.sdt, &ts.z, &ts.r, &ts.n, &ts.sd_avg, &ts.zc, &ts.rc, &ts.gpos, &ts.clean_n, &ts.regions,
                 &ts.sel, &ts.res_z, &ts.res_r, &ts.cwz, &ts.calls, &ts.n_calls, &ts.prefix, &ts.reg_abs,

@@ -19,6 +19,7 @@
 #include "ctx.h"
 
 #include <algorithm>
+#include <stdlib.h>
 
 namespace {
 
@@ -43,11 +44,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // (distances are translation invariant per sample); a good one keeps the float32
 // norms, and with them the error interval of the MFMA distances, small even when
 // a few bins are wild outliers.  One block owns 64 samples end to end.
-__global__ __launch_bounds__(256) void k_col_centre(const double *__restrict__ X, int64_t B, int64_t S,
-                                                    int64_t n_rows, int64_t row_step,
-                                                    double *__restrict__ centre) {
-    __shared__ double sh_s[4][64];
-    __shared__ double sh_c[4][64];
+__global__ __launch_bounds__(1024) void k_col_centre(const double *__restrict__ X, int64_t B, int64_t S,
+                                                     int64_t n_rows, int64_t row_step,
+                                                     double *__restrict__ centre) {
+    __shared__ double sh_s[16][64];
+    __shared__ double sh_c[16][64];
     __shared__ double sh_v[64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int64_t s = (int64_t)blockIdx.x * 64 + tx;
@@ -55,20 +56,20 @@ __global__ __launch_bounds__(256) void k_col_centre(const double *__restrict__ X
     for (int pass = 0; pass < 3; ++pass) {
         double sum = 0.0, cnt = 0.0;
         if (s < S) {
-            for (int64_t q = ty; q < n_rows; q += 4) {
+#pragma unroll 8
+            for (int64_t q = ty; q < n_rows; q += 16) {
                 double v = X[(q * row_step) * S + s];
-                if (!isfinite(v)) continue;
-                if (pass == 2 && !(fabs(v - c) <= rad)) continue;
-                sum += (pass == 1) ? fabs(v - c) : v;
-                cnt += 1.0;
+                bool ok = isfinite(v) && (pass != 2 || fabs(v - c) <= rad);
+                sum += ok ? ((pass == 1) ? fabs(v - c) : v) : 0.0;
+                cnt += ok ? 1.0 : 0.0;
             }
         }
         sh_s[ty][tx] = sum;
         sh_c[ty][tx] = cnt;
         __syncthreads();
         if (ty == 0) {
-            double a = (sh_s[0][tx] + sh_s[1][tx]) + (sh_s[2][tx] + sh_s[3][tx]);
-            double b = (sh_c[0][tx] + sh_c[1][tx]) + (sh_c[2][tx] + sh_c[3][tx]);
+            double a = 0.0, b = 0.0;
+            for (int r = 0; r < 16; ++r) { a += sh_s[r][tx]; b += sh_c[r][tx]; }
             sh_v[tx] = b > 0.0 ? a / b : 0.0;
         }
         __syncthreads();
@@ -428,6 +429,9 @@ struct FinishArgs {
     int *fb_rows, *fb_count;
     int *row_stat;
     int sum_order;
+    int xs_in_lds;
+    const int2 *pw_prog;   // pairwise leaf table: {leaf end, adds after it}
+    int pw_leaves;
 };
 
 // Exact distance of rows j and i with numpy's bits: subtract, square (rounded), sum
@@ -479,14 +483,63 @@ __device__ inline double exact_distance(const double *__restrict__ xj, const dou
     return acc;
 }
 
-__global__ __launch_bounds__(256) void k_finish(FinishArgs a) {
-    __shared__ unsigned long long ent[LIST_CAP];
-    __shared__ unsigned long long dk[LIST_CAP];
-    __shared__ int jv[LIST_CAP];
-    __shared__ double xs[2048];
+constexpr int RMAX = 512;       // most candidates re-scored on the fast path (more -> exact fallback)
+constexpr int ST_CH = 16;       // samples per staged chunk of the sequential re-score
+constexpr int ST_LD = 17;       // LDS row stride of the staged chunk, doubles
+
+// k-th smallest (0-based rank kk) 32-bit ordered key among ent[0..n): 4 radix passes.
+__device__ inline uint32_t select_key(const unsigned long long *ent, int n, int kk, unsigned int *hist,
+                                      int *s_tmp, int tid) {
+    uint32_t prefix = 0, mask = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        hist[tid] = 0;
+        __syncthreads();
+        for (int t = tid; t < n; t += 256) {
+            uint32_t key = (uint32_t)(ent[t] >> 32);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            int c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+            int sum = c0 + c1 + c2 + c3, incl = sum;
+            for (int o = 1; o < 64; o <<= 1) {
+                int v = __shfl_up(incl, o);
+                if (tid >= o) incl += v;
+            }
+            int excl = incl - sum;
+            if (excl <= kk && kk < incl) {
+                int r = kk - excl, d;
+                if (r < c0) d = 0;
+                else if (r < c0 + c1) { d = 1; r -= c0; }
+                else if (r < c0 + c1 + c2) { d = 2; r -= c0 + c1; }
+                else { d = 3; r -= c0 + c1 + c2; }
+                s_tmp[0] = 4 * tid + d;
+                s_tmp[1] = r;
+            }
+        }
+        __syncthreads();
+        prefix |= (uint32_t)s_tmp[0] << shift;
+        kk = s_tmp[1];
+        mask |= 0xFFu << shift;
+        __syncthreads();
+    }
+    return prefix;
+}
+
+// One workgroup per target row: pick the candidates that can still be among the k
+// nearest, re-score them exactly, order them, write the reference's output row.
+template <bool SEQ>
+__global__ __launch_bounds__(256, 4) void k_finish(FinishArgs a) {
+    extern __shared__ double xs_dyn[];                     // the target row (S doubles) when it fits
+    __shared__ __attribute__((aligned(16))) unsigned long long ent[LIST_CAP > 128 * ST_LD ? LIST_CAP : 128 * ST_LD];
+    __shared__ unsigned long long dk[RMAX];
+    __shared__ int jv[RMAX];
+    __shared__ int cj[RMAX];
+    __shared__ unsigned int hist[256];
     __shared__ double red[256];
-    __shared__ int red_i[4];
-    const int tid = threadIdx.x;
+    __shared__ int s_tmp[4];
+    double *stage = reinterpret_cast<double *>(ent);       // aliases ent once the candidates are compacted
+    const int tid = threadIdx.x, lane = tid & 63;
     const int64_t row = a.row_begin + blockIdx.x;
     if (row >= a.row_end) return;
     const int c = a.cnt[row];
@@ -494,31 +547,33 @@ __global__ __launch_bounds__(256) void k_finish(FinishArgs a) {
     const bool admit_all = (thr_f == WC_ADMIT_ALL);
     bool fallback = c > a.cap;
     const int n = fallback ? 0 : c;
-    int p2 = 2;
-    while (p2 < n) p2 <<= 1;
-    for (int t = tid; t < p2; t += 256) ent[t] = t < n ? a.list[row * a.cap + t] : ~0ull;
+    for (int t = tid; t < n; t += 256) ent[t] = a.list[row * a.cap + t];
     const double *xi = a.X + row * a.S;
-    if (a.S <= 2048) {
-        for (int64_t s = tid; s < a.S; s += 256) xs[s] = xi[s];
-        xi = xs;
+    if (a.xs_in_lds) {
+        for (int64_t s = tid; s < a.S; s += 256) xs_dyn[s] = xi[s];
+        xi = xs_dyn;
     }
+    if (tid == 0) s_tmp[2] = 0;
     __syncthreads();
-    bitonic_u64(ent, p2, tid, 256);
 
     int R = 0;
     if (!fallback) {
+        double U = INFINITY;  // admit-all rows with fewer than k candidates re-score everything
         if (n < a.k) {
             if (!admit_all) fallback = true;
-            R = n;
         } else {
-            // upper bound of the k-th true distance from the k smallest lower bounds
+            // upper bound of the k-th true distance: the largest upper bound among the
+            // entries whose lower bound is within the k smallest
+            const uint32_t kth = select_key(ent, n, a.k - 1, hist, s_tmp, tid);
             const double nhi = (double)a.norm_hi[row];
             double my = -INFINITY;
-            for (int t = tid; t < a.k; t += 256) {
-                float key = wc::f32_from_ordered((uint32_t)(ent[t] >> 32));
-                int j = (int)(uint32_t)ent[t];
-                double ub = (double)key + 3.0 * a.beta * (nhi + (double)a.norm_hi[j]) + 1e-36;
-                my = fmax(my, ub);
+            for (int t = tid; t < n; t += 256) {
+                uint32_t ku = (uint32_t)(ent[t] >> 32);
+                if (ku <= kth) {
+                    int j = (int)(uint32_t)ent[t];
+                    double ub = (double)wc::f32_from_ordered(ku) + 3.0 * a.beta * (nhi + (double)a.norm_hi[j]) + 1e-36;
+                    my = fmax(my, ub);
+                }
             }
             red[tid] = my;
             __syncthreads();
@@ -526,20 +581,30 @@ __global__ __launch_bounds__(256) void k_finish(FinishArgs a) {
                 if (tid < o) red[tid] = fmax(red[tid], red[tid + o]);
                 __syncthreads();
             }
-            const double U = red[0];
-            __syncthreads();
-            // every candidate not listed has lower bound > thr; need thr >= U
-            if (!admit_all && !(U <= (double)thr_f)) fallback = true;
-            int mine = 0;
-            for (int t = tid; t < n; t += 256) {
-                float key = wc::f32_from_ordered((uint32_t)(ent[t] >> 32));
-                mine += ((double)key <= U);
+            U = red[0];
+            // every candidate that was never listed has a lower bound > thr: need thr >= U
+            if (!(U == U) || (!admit_all && !(U <= (double)thr_f))) fallback = true;
+        }
+        if (!fallback) {
+            // compact the survivors (order is irrelevant: they are sorted exactly below)
+            for (int t0 = 0; t0 < n; t0 += 256) {
+                int t = t0 + tid;
+                bool keep = false;
+                int j = 0;
+                if (t < n) {
+                    j = (int)(uint32_t)ent[t];
+                    keep = (double)wc::f32_from_ordered((uint32_t)(ent[t] >> 32)) <= U;
+                }
+                unsigned long long m = __ballot(keep);
+                int base = 0;
+                if (lane == 0 && m) base = atomicAdd(&s_tmp[2], __popcll(m));
+                base = __shfl(base, 0);
+                int at = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (keep && at < RMAX) cj[at] = j;
             }
-            for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
-            if ((tid & 63) == 0) red_i[tid >> 6] = mine;
             __syncthreads();
-            R = red_i[0] + red_i[1] + red_i[2] + red_i[3];
-            if (!(U == U)) fallback = true;
+            R = s_tmp[2];
+            if (R > RMAX) fallback = true;
         }
     }
     if (fallback) {
@@ -551,21 +616,98 @@ __global__ __launch_bounds__(256) void k_finish(FinishArgs a) {
         return;
     }
 
-    // float64 re-score, 32 candidates per pass
-    const int grp = tid >> 3, sub = tid & 7;
-    for (int base = 0; base < R; base += 32) {
-        int t = base + grp;
-        bool active = t < R;
-        int j = active ? (int)(uint32_t)ent[t] : (int)row;
-        double d = exact_distance(a.X + (int64_t)j * a.S, xi, a.S, sub, a.sum_order);
-        if (active && sub == 0) {
-            bool ok = d < SENTINEL_DISTANCE;  // NaN and >= 1e10 are never admitted (wisetools.py:314)
-            dk[t] = ok ? wc::f64_ordered(d) : ~0ull;
-            jv[t] = ok ? j : 0x7FFFFFFF;
+    {
+        // Exact float64 distances (wisetools.py:302) with numpy's rounding order.  One
+        // lane per candidate; 16-sample chunks of the candidate rows are staged through
+        // LDS with coalesced 128-byte loads, the next chunk in flight during the sums.
+        //   sequential order: one running sum per lane;
+        //   pairwise order:   numpy's eight strided accumulators per leaf (<= 128
+        //                     samples, boundaries from the host-built leaf table),
+        //                     leaf sums folded with a small value stack.
+        constexpr bool seq = SEQ;  // sequential order, or fewer than 8 samples (numpy sums those left to right too)
+        const int l16 = tid & 15, r0 = tid >> 4;
+        for (int b0 = 0; b0 < R; b0 += 128) {
+            const int nb = (R - b0) < 128 ? (R - b0) : 128;
+            const double *src[8];
+            double pre[8];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                int rr = r0 + 16 * p;
+                src[p] = a.X + (int64_t)cj[b0 + (rr < nb ? rr : 0)] * a.S;
+                pre[p] = (rr < nb && l16 < a.S) ? src[p][l16] : 0.0;
+            }
+            double acc = 0.0;                     // sequential sum / tail sum of the last leaf
+            double r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            double vs[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            int sp = 0, leaf = 0;
+            bool in_tail = false;
+            int2 lf = seq ? make_int2(0, 0) : a.pw_prog[0];   // {leaf end, adds after the leaf}
+            for (int64_t c0 = 0; c0 < a.S; c0 += ST_CH) {
+                __syncthreads();
+#pragma unroll
+                for (int p = 0; p < 8; ++p) stage[(r0 + 16 * p) * ST_LD + l16] = pre[p];
+                __syncthreads();
+                const int64_t sn = c0 + ST_CH + l16;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) pre[p] = (r0 + 16 * p < nb && sn < a.S) ? src[p][sn] : 0.0;
+                if (tid < 128) {
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const int64_t base = c0 + 8 * g;
+                        if (base >= a.S) break;
+                        const int cntg = (a.S - base) < 8 ? (int)(a.S - base) : 8;
+                        double sq[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            double df = (e < cntg) ? stage[tid * ST_LD + 8 * g + e] - xi[base + e] : 0.0;
+                            sq[e] = df * df;
+                        }
+                        if (seq || in_tail || cntg < 8) {
+                            for (int e = 0; e < cntg; ++e) acc = acc + sq[e];
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) r[e] = r[e] + sq[e];
+                            if (base + 8 == (int64_t)(lf.x - (lf.x & 7))) {   // body of the current leaf complete
+                                double val = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) r[e] = 0.0;
+                                if (lf.x & 7) {          // last leaf with a tail: added after the combine
+                                    acc = val;
+                                    in_tail = true;
+                                } else {
+                                    wc::stack_set(vs, sp++, val);
+                                    for (int q = 0; q < lf.y; ++q) {
+                                        double right = wc::stack_get(vs, --sp), left = wc::stack_get(vs, sp - 1);
+                                        wc::stack_set(vs, sp - 1, left + right);
+                                    }
+                                    ++leaf;
+                                    if (leaf < a.pw_leaves) lf = a.pw_prog[leaf];
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (!seq) {
+                if (in_tail) {
+                    wc::stack_set(vs, sp++, acc);
+                    for (int q = 0; q < lf.y; ++q) {
+                        double right = wc::stack_get(vs, --sp), left = wc::stack_get(vs, sp - 1);
+                        wc::stack_set(vs, sp - 1, left + right);
+                    }
+                }
+                acc = vs[0];
+            }
+            if (tid < nb) {
+                bool ok = acc < SENTINEL_DISTANCE;  // NaN and >= 1e10 are never admitted (wisetools.py:314)
+                dk[b0 + tid] = ok ? wc::f64_ordered(acc) : ~0ull;
+                jv[b0 + tid] = ok ? cj[b0 + tid] : 0x7FFFFFFF;
+            }
         }
     }
     int q2 = 2;
     while (q2 < R) q2 <<= 1;
+    __syncthreads();
     for (int t = R + tid; t < q2; t += 256) { dk[t] = ~0ull; jv[t] = 0x7FFFFFFF; }
     __syncthreads();
     bitonic_pair(dk, jv, q2, tid, 256);
@@ -698,6 +840,18 @@ __global__ __launch_bounds__(64) void k_import_lists(int *__restrict__ cnt, unsi
 // ----------------------------------------------------------------- host side ----
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
+void build_pairwise_leaves(int n, int off, std::vector<int2> &prog) {
+    if (n <= 128) {
+        prog.push_back(make_int2(off + n, 0));
+        return;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    build_pairwise_leaves(n2, off, prog);
+    build_pairwise_leaves(n - n2, off + n2, prog);
+    prog.back().y += 1;
+}
+
 int build_tiles(NewrefState &st, int64_t row_begin, int64_t row_end, int rank, int ranks,
                 std::vector<int4> &tiles) {
     const int nb = (int)(st.bins_pad / TB);
@@ -795,6 +949,17 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
 
     WC_HIP(hipMemcpyAsync(st.chrom_off_dev.p, st.chrom_off, sizeof(int64_t) * (n_chrom + 1),
                           hipMemcpyHostToDevice, stream));
+    if (st.pw_for != n_samples) {
+        // numpy's pairwise split tree over n_samples, flattened: leaves in order with the
+        // number of pending "add the two top partial sums" steps after each
+        std::vector<int2> prog;
+        build_pairwise_leaves((int)n_samples, 0, prog);
+        if ((rc = st.pw_prog.reserve(sizeof(int2) * prog.size()))) return rc;
+        WC_HIP(hipMemcpyAsync(st.pw_prog.p, prog.data(), sizeof(int2) * prog.size(), hipMemcpyHostToDevice, stream));
+        WC_HIP(hipStreamSynchronize(stream));
+        st.pw_leaves = (int)prog.size();
+        st.pw_for = n_samples;
+    }
     // fixed pseudo-random sample of rows (partial Fisher-Yates on a 64-bit LCG), ascending;
     // depends on (n_bins, M) only, so it is uploaded once per layout
     std::vector<int64_t> skey = {n_bins, M};
@@ -818,9 +983,9 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
 
     double *mean2 = st.col_mean.as<double>();
     {
-        int64_t n_rows = std::min<int64_t>(n_bins, 1024);
+        int64_t n_rows = std::min<int64_t>(n_bins, 512);
         int64_t row_step = n_bins / n_rows;
-        hipLaunchKernelGGL(k_col_centre, dim3((unsigned)((n_samples + 63) / 64)), dim3(256), 0, stream, corrected,
+        hipLaunchKernelGGL(k_col_centre, dim3((unsigned)((n_samples + 63) / 64)), dim3(1024), 0, stream, corrected,
                            n_bins, n_samples, n_rows, row_step, mean2);
     }
 
@@ -1007,7 +1172,15 @@ int wc_newref_finish_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t 
     a.fb_count = st.fb_count.as<int>();
     a.row_stat = st.stats.as<int>();
     a.sum_order = st.sum_order;
-    hipLaunchKernelGGL(k_finish, dim3((unsigned)(row_end - row_begin)), dim3(256), 0, stream, a);
+    a.xs_in_lds = st.n_samples <= 2048;
+    a.pw_prog = st.pw_prog.as<int2>();
+    a.pw_leaves = st.pw_leaves;
+    if (st.sum_order == WC_SUM_SEQUENTIAL || st.n_samples < 8)
+        hipLaunchKernelGGL(k_finish<true>, dim3((unsigned)(row_end - row_begin)), dim3(256),
+                           a.xs_in_lds ? sizeof(double) * st.n_samples : 0, stream, a);
+    else
+        hipLaunchKernelGGL(k_finish<false>, dim3((unsigned)(row_end - row_begin)), dim3(256),
+                           a.xs_in_lds ? sizeof(double) * st.n_samples : 0, stream, a);
     hipLaunchKernelGGL(k_fallback, dim3(FB_BLOCKS), dim3(256), 0, stream, a,
                        st.fb_scratch.as<unsigned long long>(), st.bins_pad);
     WC_HIP(hipGetLastError());
