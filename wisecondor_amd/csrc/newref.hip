@@ -163,12 +163,12 @@ __device__ inline unsigned long long pack_entry(float key, int j) {
 // lane (i, h) feeds k = 16h + t at MFMA step t, so each lane fetches its 16
 // operands with four conflict-free ds_read_b128.
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void k_gram(GramArgs g) {
-    __shared__ __attribute__((aligned(16))) float sm[TB * LDD + 6 * TB];
+__global__ __launch_bounds__(256, 4) void k_gram(GramArgs g) {
+    __shared__ __attribute__((aligned(16))) float sm[2 * TB * LDA + 6 * TB];   // 64 * LDD <= 2 * TB * LDA
     float *As = sm;
     float *Bs = sm + TB * LDA;
     float *D = sm;
-    float *nbPs = sm + TB * LDD;
+    float *nbPs = sm + 2 * TB * LDA;
     float *nbQs = nbPs + TB;
     float *thPs = nbQs + TB;
     float *thQs = thPs + TB;
@@ -252,79 +252,87 @@ __global__ __launch_bounds__(256, 2) void k_gram(GramArgs g) {
         }
     }
 
-    // dot products -> LDS tile (aliases the staging buffers)
-    __syncthreads();
+    // Epilogue in two halves (rows 0-63 from the waves with wr == 0, then rows 64-127):
+    // the 64 x 128 dot-product tile aliases the staging buffers, which keeps the
+    // workgroup at 39 KB of LDS -> four workgroups per CU cover each other's
+    // load / barrier / epilogue phases with MFMA work.
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+        if (wr == h) {
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+                for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int row = wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                int col = wc * 64 + n * 32 + li;
-                D[row * LDD + col] = acc[m][n][r];
-            }
-    __syncthreads();
+                    for (int r = 0; r < 16; ++r) {
+                        int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        int col = wc * 64 + n * 32 + li;
+                        D[row * LDD + col] = acc[m][n][r];
+                    }
+        }
+        __syncthreads();
 
-    const int x = tid & 127, half = tid >> 7;
-    if (MODE == 0) {
-        // dense lower-bound keys, same-chromosome pairs masked to +inf
-        const float nbc = nbQs[x];
-        const int chc = chQs[x];
-        float *out = g.keys + ((int64_t)I * TB + half * 64) * g.ldo + (int64_t)J * TB + x;
-        for (int rr = 0; rr < 64; ++rr) {
-            int r = half * 64 + rr;
-            float key = fmaf(-2.f, D[r * LDD + x], nbPs[r] + nbc);
-            if (chPs[r] == chc) key = INFINITY;
-            out[(int64_t)rr * g.ldo] = key;
+        const int x = tid & 127, q = tid >> 7;      // column x, 32-row half q of this 64-row slab
+        if (MODE == 0) {
+            // dense lower-bound keys, same-chromosome pairs masked to +inf
+            const float nbc = nbQs[x];
+            const int chc = chQs[x];
+            float *out = g.keys + ((int64_t)I * TB + h * 64 + q * 32) * g.ldo + (int64_t)J * TB + x;
+            for (int rr = 0; rr < 32; ++rr) {
+                int lr = q * 32 + rr, r = h * 64 + lr;
+                float key = fmaf(-2.f, D[lr * LDD + x], nbPs[r] + nbc);
+                if (chPs[r] == chc) key = INFINITY;
+                out[(int64_t)rr * g.ldo] = key;
+            }
+            continue;
         }
-        return;
-    }
-    if (roles & ROLE_COLS) {  // target = column x, candidates = rows of this half
-        const float nbc = nbQs[x], th = thQs[x];
-        const int chc = chQs[x];
-        unsigned long long mask = 0ull;
-        for (int rr = 0; rr < 64; ++rr) {
-            int r = half * 64 + rr;
-            float key = fmaf(-2.f, D[r * LDD + x], nbPs[r] + nbc);
-            bool pass = (key <= th) && (chPs[r] != chc);
-            mask |= (unsigned long long)pass << rr;
-        }
-        if (mask) {
-            int64_t gq = (int64_t)J * TB + x;
-            int base = atomicAdd(&g.cnt[gq], __popcll(mask));
-            unsigned long long *dst = g.list + gq * g.cap;
-            while (mask) {
-                int rr = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                int r = half * 64 + rr;
-                float key = fmaf(-2.f, D[r * LDD + x], nbPs[r] + nbc);
-                if (base < g.cap) dst[base] = pack_entry(key, I * TB + r);
-                ++base;
+        if (roles & ROLE_COLS) {  // target = column x, candidates = 32 rows of this slab
+            const float nbc = nbQs[x], th = thQs[x];
+            const int chc = chQs[x];
+            unsigned int mask = 0u;
+            for (int rr = 0; rr < 32; ++rr) {
+                int lr = q * 32 + rr, r = h * 64 + lr;
+                float key = fmaf(-2.f, D[lr * LDD + x], nbPs[r] + nbc);
+                bool pass = (key <= th) && (chPs[r] != chc);
+                mask |= (unsigned int)pass << rr;
+            }
+            if (mask) {
+                int64_t gq = (int64_t)J * TB + x;
+                int base = atomicAdd(&g.cnt[gq], __popc(mask));
+                unsigned long long *dst = g.list + gq * g.cap;
+                while (mask) {
+                    int rr = __ffs((int)mask) - 1;
+                    mask &= mask - 1;
+                    int lr = q * 32 + rr, r = h * 64 + lr;
+                    float key = fmaf(-2.f, D[lr * LDD + x], nbPs[r] + nbc);
+                    if (base < g.cap) dst[base] = pack_entry(key, I * TB + r);
+                    ++base;
+                }
             }
         }
-    }
-    if (roles & ROLE_ROWS) {  // target = row x, candidates = columns of this half
-        const float nbr = nbPs[x], th = thPs[x];
-        const int chr = chPs[x];
-        unsigned long long mask = 0ull;
-        for (int cc = 0; cc < 64; ++cc) {
-            int c = half * 64 + cc;
-            float key = fmaf(-2.f, D[x * LDD + c], nbr + nbQs[c]);
-            bool pass = (key <= th) && (chQs[c] != chr);
-            mask |= (unsigned long long)pass << cc;
-        }
-        if (mask) {
-            int64_t gp = (int64_t)I * TB + x;
-            int base = atomicAdd(&g.cnt[gp], __popcll(mask));
-            unsigned long long *dst = g.list + gp * g.cap;
-            while (mask) {
-                int cc = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                int c = half * 64 + cc;
-                float key = fmaf(-2.f, D[x * LDD + c], nbr + nbQs[c]);
-                if (base < g.cap) dst[base] = pack_entry(key, J * TB + c);
-                ++base;
+        if (roles & ROLE_ROWS) {  // target = row lr of this slab, candidates = 32 columns
+            const int lr = tid & 63, cq = tid >> 6, r = h * 64 + lr;
+            const float nbr = nbPs[r], th = thPs[r];
+            const int chr = chPs[r];
+            unsigned int mask = 0u;
+            for (int cc = 0; cc < 32; ++cc) {
+                int c = cq * 32 + cc;
+                float key = fmaf(-2.f, D[lr * LDD + c], nbr + nbQs[c]);
+                bool pass = (key <= th) && (chQs[c] != chr);
+                mask |= (unsigned int)pass << cc;
+            }
+            if (mask) {
+                int64_t gp = (int64_t)I * TB + r;
+                int base = atomicAdd(&g.cnt[gp], __popc(mask));
+                unsigned long long *dst = g.list + gp * g.cap;
+                while (mask) {
+                    int cc = __ffs((int)mask) - 1;
+                    mask &= mask - 1;
+                    int c = cq * 32 + cc;
+                    float key = fmaf(-2.f, D[lr * LDD + c], nbr + nbQs[c]);
+                    if (base < g.cap) dst[base] = pack_entry(key, J * TB + c);
+                    ++base;
+                }
             }
         }
     }
@@ -867,21 +875,32 @@ int build_tiles(NewrefState &st, int64_t row_begin, int64_t row_end, int rank, i
         clo[b] = chrom_at((int64_t)b * TB);
         chi[b] = chrom_at((int64_t)b * TB + TB - 1);
     }
-    int64_t serial = 0;
-    for (int I = ib; I < ie; ++I)
-        for (int J = 0; J < nb; ++J) {
-            int roles;
-            bool in = J >= ib && J < ie;
-            if (in) {
-                if (J < I) continue;
-                roles = (J == I) ? ROLE_COLS : (ROLE_ROWS | ROLE_COLS);
-            } else {
-                roles = ROLE_ROWS;
-            }
-            // a tile whose rows and columns all sit on one chromosome has no candidates
-            if (clo[I] == chi[I] && clo[J] == chi[J] && clo[I] == clo[J]) continue;
-            if ((serial++ % ranks) != rank) continue;
-            tiles.push_back(make_int4(I, J, roles, 0));
+    // Order: 8x8 super-tiles (8 row panels x 8 column panels).  An XCD runs 64 workgroups
+    // at a time over a contiguous stretch of this list, i.e. one super-tile: its 64 tiles
+    // share 16 operand panels in that XCD's L2 instead of streaming 64 different ones.
+    // Ranks are dealt whole super-tiles when there are plenty, single tiles otherwise.
+    constexpr int ST = 8;
+    const int64_t n_super = (int64_t)((ie - ib + ST - 1) / ST) * ((nb + ST - 1) / ST);
+    const bool deal_super = n_super >= 32ll * ranks;
+    int64_t serial = 0, super_serial = -1;
+    for (int I0 = ib; I0 < ie; I0 += ST)
+        for (int J0 = 0; J0 < nb; J0 += ST) {
+            ++super_serial;
+            for (int I = I0; I < std::min(I0 + ST, ie); ++I)
+                for (int J = J0; J < std::min(J0 + ST, nb); ++J) {
+                    int roles;
+                    bool in = J >= ib && J < ie;
+                    if (in) {
+                        if (J < I) continue;
+                        roles = (J == I) ? ROLE_COLS : (ROLE_ROWS | ROLE_COLS);
+                    } else {
+                        roles = ROLE_ROWS;
+                    }
+                    // a tile whose rows and columns all sit on one chromosome has no candidates
+                    if (clo[I] == chi[I] && clo[J] == chi[J] && clo[I] == clo[J]) continue;
+                    if (((deal_super ? super_serial : serial++) % ranks) != rank) continue;
+                    tiles.push_back(make_int4(I, J, roles, 0));
+                }
         }
     return WC_OK;
 }
