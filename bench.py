@@ -192,6 +192,12 @@ def main():
                                                  np.array_equal(cpu_calls[:, :3], gpu_calls[:, :3]))}
 
     if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if world == 1 and os.path.exists(tpath):
+            t = json.load(open(tpath)).get(args.workload)
+            if t:   # HBM-side bytes per launch from the committed PMC passes of this same workload
+                traffic = 1024.0 * (2.0 * t["fetch_kb_per_launch"] + t["write_kb_per_launch"])
         # algorithmic work of the dominant kernel: one multiply-add per sample per unordered pair
         flops = (pairs / 2.0) * 2.0 * S / world
         achieved = flops / (kernel_ms * 1e-3)
@@ -217,7 +223,8 @@ def main():
                      "calls_found": n_calls},
             "roofline": {"kernel": "k_gram<1> (symmetric fp32 MFMA distance tiles + candidate filter)",
                          "bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_FP32_MFMA / 1e12,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA, "traffic": traffic,
+                         "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_traffic.json)",
                          "kernel_ms": kernel_ms, "algorithmic_flop_per_launch": flops},
             "newref_stats": stats,
             "cpu_baseline": cpu,
