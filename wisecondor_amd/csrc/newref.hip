@@ -342,6 +342,7 @@ __global__ __launch_bounds__(256, 4) void k_gram(GramArgs g) {
 // One wave per row: q-th smallest sampled key, q scaled so that about `expect`
 // candidates of the full row pass `key <= thr` (distribution free: the sample is a
 // fixed pseudo-random subset of the rows).
+template <int NV>   // keys per lane (M / 64 rounded up to 16 / 32 / 64)
 __global__ __launch_bounds__(256) void k_select_thr(const float *__restrict__ keys, int64_t ldo, int M,
                                                     const int *__restrict__ chrom_of_row,
                                                     const int64_t *__restrict__ chrom_off, int64_t B,
@@ -351,11 +352,11 @@ __global__ __launch_bounds__(256) void k_select_thr(const float *__restrict__ ke
     int64_t row = row_begin + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= row_end) return;
     const int per_lane = M / 64;
-    uint32_t u[MAX_SAMPLE_COLS / 64];
+    uint32_t u[NV];
     const uint32_t FIN = wc::f32_ordered(FLT_MAX);
     int mvalid = 0;
 #pragma unroll
-    for (int e = 0; e < MAX_SAMPLE_COLS / 64; ++e) {
+    for (int e = 0; e < NV; ++e) {
         u[e] = 0xFFFFFFFFu;
         if (e < per_lane) u[e] = wc::f32_ordered(keys[row * ldo + (int64_t)e * 64 + lane]);
         mvalid += (u[e] <= FIN);
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(256) void k_select_thr(const float *__restrict__ ke
             uint32_t trial = res | (1u << bit);
             int c = 0;
 #pragma unroll
-            for (int e = 0; e < MAX_SAMPLE_COLS / 64; ++e) c += (u[e] < trial);
+            for (int e = 0; e < NV; ++e) c += (u[e] < trial);
             for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
             if (c < q) res = trial;
         }
@@ -1062,10 +1063,20 @@ int wc_newref_thresholds_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int6
     unsigned grid = (unsigned)(((g.ntiles + 7) / 8) * 8);
     hipLaunchKernelGGL(k_gram<0>, dim3(grid), dim3(256), 0, stream, g);
     unsigned sg = (unsigned)((row_end - row_begin + 3) / 4);
-    hipLaunchKernelGGL(k_select_thr, dim3(sg), dim3(256), 0, stream, (const float *)st.keys1.as<float>(),
-                       st.n_sample_cols, (int)st.n_sample_cols, (const int *)st.chrom_of_row.as<int>(),
-                       (const int64_t *)st.chrom_off_dev.as<int64_t>(), st.n_bins, row_begin, row_end,
-                       (int)st.expect, (int)st.cap, st.thr.as<float>());
+    {
+        const float *kp = st.keys1.as<float>();
+        const int *cr = st.chrom_of_row.as<int>();
+        const int64_t *co = st.chrom_off_dev.as<int64_t>();
+        const int per_lane = (int)(st.n_sample_cols / 64);
+#define WC_SELECT(NV)                                                                                          \
+    hipLaunchKernelGGL(k_select_thr<NV>, dim3(sg), dim3(256), 0, stream, kp, st.n_sample_cols,                \
+                       (int)st.n_sample_cols, cr, co, st.n_bins, row_begin, row_end, (int)st.expect, (int)st.cap, \
+                       st.thr.as<float>())
+        if (per_lane <= 16) WC_SELECT(16);
+        else if (per_lane <= 32) WC_SELECT(32);
+        else WC_SELECT(64);
+#undef WC_SELECT
+    }
     WC_HIP(hipGetLastError());
     return WC_OK;
 }

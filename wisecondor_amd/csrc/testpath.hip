@@ -205,61 +205,64 @@ __device__ inline double combine8(const double *r) {
     return ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
 }
 
-// numpy's pairwise sum over the kept values v_0..v_{m-1} (m <= 128) streamed in
-// order: the first m - m%8 values go round-robin into eight accumulators, which
-// are combined before the tail is added sequentially; m < 8 is a plain sum.
+// numpy's pairwise sum over kept values v_0..v_{m-1} (m <= 128) streamed in order,
+// WITHOUT knowing m in advance: values fill a pending group of eight; a complete
+// group is committed to the eight strided accumulators; whatever is pending at the
+// end is numpy's tail (added sequentially after the accumulators are combined).
+// m < 8 degenerates to the plain left-to-right sum numpy uses there.
 struct StreamSum {
-    double r[8];
-    double res;
-    int pos, body;
-    __device__ inline void init(int m) {
+    double r[8], p[8];
+    int pos;
+    __device__ inline void init() {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = 0.0;
-        res = 0.0;
+        for (int j = 0; j < 8; ++j) { r[j] = 0.0; p[j] = 0.0; }
         pos = 0;
-        body = m < 8 ? 0 : m - (m & 7);
     }
     __device__ inline void push(double v) {
-        if (pos < body) {
-            int slot = pos & 7;
+        const int slot = pos & 7;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) r[j] = r[j] + (slot == j ? v : 0.0);
-        } else {
-            if (pos == body) res = combine8(r);
-            res = res + v;
+        for (int j = 0; j < 8; ++j) p[j] = (slot == j) ? v : p[j];
+        if (slot == 7) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = r[j] + p[j];   // first group: 0 + v == v exactly (v >= 0)
         }
         ++pos;
     }
-    __device__ inline double finish(int m) { return (m == body) ? combine8(r) : res; }
+    __device__ inline double finish() const {
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        const int tail = pos & 7;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < tail) res = res + p[j];
+        return res;
+    }
 };
 
 // trySample (wisetools.py:407-435) for every (bin, sample) pair; sample is the
 // fastest index so a wave reads 64 consecutive samples of one reference bin.
+// `active` (per sample) is cleared when a repeat set no new flag for that sample:
+// the next pass would reproduce the same numbers bit for bit, so it is skipped.
 __global__ __launch_bounds__(256) void k_zscore(const double *__restrict__ XT, const double *__restrict__ XC,
                                                 const int *__restrict__ gidx, const int *__restrict__ nref, int k,
-                                                int64_t B, int64_t Ns, double *__restrict__ zT,
-                                                double *__restrict__ rT, double *__restrict__ nT,
-                                                double *__restrict__ sdT) {
+                                                int64_t B, int64_t Ns, const int *__restrict__ active,
+                                                double *__restrict__ zT, double *__restrict__ rT,
+                                                double *__restrict__ nT, double *__restrict__ sdT) {
     int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= B * Ns) return;
     int64_t b = gid / Ns, i = gid - b * Ns;
+    if (active && !active[i]) return;
     const int *lst = gidx + b * k;
     const int n = nref[b];
-    int m = 0;
-    for (int r = 0; r < n; ++r) {
-        int g = lst[r];
-        double v = g >= 0 ? XC[(int64_t)g * Ns + i] : -1.0;
-        m += (v >= 0.0);  // flagged (-1), negative and NaN values are dropped (wisetools.py:425)
-    }
     StreamSum acc;
-    acc.init(m);
+    acc.init();
     for (int r = 0; r < n; ++r) {
         int g = lst[r];
         double v = g >= 0 ? XC[(int64_t)g * Ns + i] : -1.0;
-        if (v >= 0.0) acc.push(v);
+        if (v >= 0.0) acc.push(v);  // flagged (-1), negative and NaN values are dropped (wisetools.py:425)
     }
-    const double mean = acc.finish(m) / (double)m;
-    acc.init(m);
+    const int m = acc.pos;
+    const double mean = acc.finish() / (double)m;
+    acc.init();
     for (int r = 0; r < n; ++r) {
         int g = lst[r];
         double v = g >= 0 ? XC[(int64_t)g * Ns + i] : -1.0;
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(256) void k_zscore(const double *__restrict__ XT, c
             acc.push(sq);
         }
     }
-    const double var = acc.finish(m) / (double)m;
+    const double var = acc.finish() / (double)m;
     const double sd = sqrt(var);
     const double x = XT[gid];
     zT[gid] = (x - mean) / sd;
@@ -279,9 +282,18 @@ __global__ __launch_bounds__(256) void k_zscore(const double *__restrict__ XT, c
 }
 
 // testCopy[abs(z) >= threshold] = -1 (wisetools.py:446)
-__global__ void k_flag(const double *__restrict__ zT, double thr, int64_t n, double *__restrict__ XC) {
+// `cur` says which samples were recomputed in this repeat; `next` receives 1 for the
+// samples that got a NEW flag (only those can change in the following repeat).
+__global__ void k_flag(const double *__restrict__ zT, double thr, int64_t n, int64_t Ns,
+                       const int *__restrict__ cur, int *__restrict__ next, double *__restrict__ XC) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && fabs(zT[i]) >= thr) XC[i] = -1.0;
+    if (i >= n) return;
+    int64_t smp = i % Ns;
+    if (cur && !cur[smp]) return;
+    if (fabs(zT[i]) >= thr && XC[i] != -1.0) {
+        XC[i] = -1.0;
+        next[smp] = 1;
+    }
 }
 
 // stdDevAvg (wisetools.py:428-435): sequential sum over bins of the non-NaN sds
@@ -293,16 +305,23 @@ __global__ void k_sd_avg(const double *__restrict__ sdT, int64_t B, int64_t Ns, 
     int64_t b = 0;
     // the sum is serial by definition (a Python loop in the reference); keep 16 loads
     // in flight.  Skipped (NaN) terms add +0.0, which is exact for a sum of sds >= 0.
-    for (; b + 16 <= B; b += 16) {
-        double v[16];
+    double v[32], w[32];
+    if (B >= 32) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = sdT[(b + u) * Ns + i];
+        for (int u = 0; u < 32; ++u) v[u] = sdT[(int64_t)u * Ns + i];
+    }
+    for (; b + 32 <= B; b += 32) {
+        const bool more = b + 64 <= B;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < 32; ++u) w[u] = more ? sdT[(b + 32 + u) * Ns + i] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
             bool ok = v[u] == v[u];
             s = s + (ok ? v[u] : 0.0);
             c += ok;
         }
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = w[u];
     }
     for (; b < B; ++b) {
         double v = sdT[b * Ns + i];
@@ -371,26 +390,47 @@ __global__ void k_fill_rs(double *rs, int64_t n) {
     if (i < n) rs[i] = i > 0 ? 1.0 / sqrt((double)i) : 0.0;
 }
 
-// Sequential prefix sums, sum |z| and a finiteness flag per region.
-__global__ void k_region_prefix(const double *__restrict__ z, const Region *__restrict__ regions, int64_t n_regions,
-                                double *__restrict__ prefix, double *__restrict__ reg_abs, int *__restrict__ reg_flag) {
-    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// Prefix sums, sum |z| and a finiteness flag per region; one wave per region, each
+// lane scans a contiguous chunk (any summation order satisfies window_eps' bound).
+__global__ __launch_bounds__(256) void k_region_prefix(const double *__restrict__ z,
+                                                       const Region *__restrict__ regions, int64_t n_regions,
+                                                       double *__restrict__ prefix, double *__restrict__ reg_abs,
+                                                       int *__restrict__ reg_flag) {
+    const int lane = threadIdx.x & 63;
+    int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_regions) return;
     const Region rg = regions[r];
     const double *zz = z + rg.off;
     double *P = prefix + rg.off + r;
+    const int per = (rg.n + 63) / 64;
+    const int lo = lane * per, hi = (lo + per < rg.n) ? lo + per : rg.n;
     double s = 0.0, a = 0.0;
     int finite = 1;
-    P[0] = 0.0;
-    for (int t = 0; t < rg.n; ++t) {
+    for (int t = lo; t < hi; ++t) {
         double v = zz[t];
         if (!isfinite(v)) finite = 0;
         s += v;
         a += fabs(v);
-        P[t + 1] = s;
     }
-    reg_abs[r] = a;
-    reg_flag[r] = finite;
+    double incl = s;
+    for (int o = 1; o < 64; o <<= 1) {
+        double up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    double run = incl - s;   // sum of the chunks before this lane
+    if (lane == 0) P[0] = 0.0;
+    for (int t = lo; t < hi; ++t) {
+        run += zz[t];
+        P[t + 1] = run;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o);
+        finite &= __shfl_xor(finite, o);
+    }
+    if (lane == 0) {
+        reg_abs[r] = a;
+        reg_flag[r] = finite;
+    }
 }
 
 // Exact value of window [x, y]: np_sum(z[x:y+1]) / np_sqrt(y-x+1) (wisetools.py:471)
@@ -861,13 +901,19 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
         WC_HIP(hipMemsetAsync(ts.nt.p, 0, sizeof(double) * n, stream));
         WC_HIP(hipMemsetAsync(ts.sdt.p, 0xFF, sizeof(double) * n, stream));
     }
+    // active[it & 1][sample]: did repeat it-1 add a flag for this sample?
+    if ((rc = ts.misc2.reserve(sizeof(int) * 2 * Ns))) return rc;
+    int *act = ts.misc2.as<int>();
     for (int it = 0; it < repeats; ++it) {
+        const int *cur = it == 0 ? nullptr : act + (it & 1) * Ns;
+        int *next = act + ((it + 1) & 1) * Ns;
+        WC_HIP(hipMemsetAsync(next, 0, sizeof(int) * Ns, stream));
         hipLaunchKernelGGL(k_zscore, dim3(g), dim3(256), 0, stream, (const double *)ts.xt.as<double>(),
                            (const double *)ts.xc.as<double>(), (const int *)ref->gidx.as<int>(),
-                           (const int *)ref->nref.as<int>(), ref->k, ref->B, Ns, ts.zt.as<double>(),
+                           (const int *)ref->nref.as<int>(), ref->k, ref->B, Ns, cur, ts.zt.as<double>(),
                            ts.rt.as<double>(), ts.nt.as<double>(), ts.sdt.as<double>());
-        hipLaunchKernelGGL(k_flag, dim3(g), dim3(256), 0, stream, (const double *)ts.zt.as<double>(), thr, n,
-                           ts.xc.as<double>());
+        hipLaunchKernelGGL(k_flag, dim3(g), dim3(256), 0, stream, (const double *)ts.zt.as<double>(), thr, n, Ns,
+                           cur, next, ts.xc.as<double>());
     }
     hipLaunchKernelGGL(k_sd_avg, dim3((unsigned)cdiv(Ns, 64)), dim3(64), 0, stream,
                        (const double *)ts.sdt.as<double>(), ref->B, Ns, ts.sd_avg.as<double>());
@@ -915,7 +961,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     int *brute = hot + job_cap;
     WC_HIP(hipMemsetAsync(counters, 0, sizeof(int) * 8, stream));
     WC_HIP(hipMemsetAsync(ts.out_n.p, 0, sizeof(int) * n_regions, stream));
-    hipLaunchKernelGGL(k_region_prefix, dim3((unsigned)cdiv(n_regions, 64)), dim3(64), 0, stream, z_dev, regions_dev,
+    hipLaunchKernelGGL(k_region_prefix, dim3((unsigned)cdiv(n_regions, 4)), dim3(256), 0, stream, z_dev, regions_dev,
                        n_regions, ts.prefix.as<double>(), ts.reg_abs.as<double>(), ts.reg_flag.as<int>());
     hipLaunchKernelGGL(k_region_whole, dim3((unsigned)cdiv(n_regions, 32)), dim3(256), 0, stream, z_dev, regions_dev,
                        n_regions, ts.whole.as<double>());
