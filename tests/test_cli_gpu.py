@@ -1,0 +1,104 @@
+"""End-to-end run of the drop-in CLI (newref with parts, test) on the GPU, checked
+against the oracle and the reference's .npz schema."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import wc_oracle as wo
+
+pytestmark = pytest.mark.gpu
+KEYS = [str(c) for c in range(1, 23)] + ["X", "Y"]
+
+
+def _write_sample(path, flat, lengths, binsize):
+    offs = np.concatenate([[0], np.cumsum(lengths)])
+    sample = {k: np.asarray(flat[offs[i]:offs[i + 1]], dtype=np.int32) for i, k in enumerate(KEYS)}
+    np.savez_compressed(path, arguments={"binsize": float(binsize)}, runtime={}, sample=sample, quality={})
+    return sample
+
+
+def test_newref_and_test_cli(tmp_path, golden):
+    from wisecondor_amd import wisecondor as cli
+    g = golden("cfg1_pipeline.npz")
+    lengths = g["sample_chrom_lengths"]
+    binsize = float(g["binsize"])
+    infiles = []
+    for i, row in enumerate(g["ref_samples"]):
+        p = str(tmp_path / ("ref_%02d.npz" % i))
+        _write_sample(p, row, lengths, binsize)
+        infiles.append(p)
+    refpath = str(tmp_path / "reference.npz")
+    cli.main(["newref"] + infiles + [refpath, "-parts", "3", "-refsize", "100"])
+    assert not os.path.exists(str(tmp_path / "reference_prep.npz"))       # temp files removed like the reference does
+    assert not os.path.exists(str(tmp_path / "reference_part_1.npz"))
+    ref = np.load(refpath, allow_pickle=True)
+    assert set(ref.files) == {"arguments", "runtime", "binsize", "indexes", "distances", "chromosome_sizes",
+                              "mask", "masked_sizes", "pca_components", "pca_mean"}
+    assert ref["indexes"].dtype == np.int32 and ref["distances"].dtype == np.float64
+    assert ref["indexes"].shape == g["ref_indexes"].shape
+    assert np.array_equal(ref["mask"], g["ref_mask"])
+    assert np.array_equal(ref["masked_sizes"], g["ref_masked_sizes"])
+    assert set(ref["runtime"].item()) == {"version", "datetime", "hostname", "username"}
+    assert ref["arguments"].item()["refsize"] == 100
+
+    # the prep seam: rebuild this run's correctedData and check the GPU selection against the oracle
+    samples = [_write_sample(str(tmp_path / "tmp.npz"), row, lengths, binsize) for row in g["ref_samples"]]
+    masked, bins, mask = wo.to_numpy_array(samples)
+    corrected, comps, mean = wo.train_pca(masked)
+    mbins = np.asarray(ref["masked_sizes"])
+    want_i, want_d = wo.get_reference(corrected, mbins, np.cumsum(mbins), 100, 1, 1, fast=True)
+    assert np.array_equal(ref["indexes"], want_i)
+    assert np.array_equal(ref["distances"], want_d)
+    # and it is the golden reference up to the PCA solver's rounding
+    assert np.mean(ref["indexes"] == g["ref_indexes"]) > 0.99
+
+    # test sub-command on two samples
+    for name in ("gain5_gap", "loss2"):
+        sp = str(tmp_path / ("test_%s.npz" % name))
+        sample = _write_sample(sp, g["t_%s_sample" % name], lengths, binsize)
+        op = str(tmp_path / ("out_%s.npz" % name))
+        with pytest.raises(SystemExit) as e:
+            cli.main(["test", sp, op, refpath])
+        assert e.value.code == 0
+        out = np.load(op, allow_pickle=True)
+        assert set(out.files) == {"arguments", "runtime", "binsize", "results_r", "results_z", "results_cwz",
+                                  "results_calls", "threshold_z", "asdef", "aasdef"}
+        assert out["results_z"].dtype == object and len(out["results_z"]) == 22
+        assert [len(a) for a in out["results_z"]] == [int(v) for v in ref["chromosome_sizes"]]
+        want = wo.test_sample(sample, binsize, {k: ref[k] for k in ref.files})
+        wc_ = np.asarray(want["results_calls"]).reshape(-1, 5)
+        gc_ = np.asarray(out["results_calls"]).reshape(-1, 5)
+        assert np.array_equal(gc_[:, :3], wc_[:, :3])
+        assert np.allclose(gc_[:, 3:], wc_[:, 3:], rtol=1e-9)
+        assert np.allclose(np.concatenate(list(out["results_z"])), np.concatenate(want["results_z"]), rtol=1e-9, atol=1e-11)
+        assert np.isclose(float(out["threshold_z"]), want["threshold_z"], rtol=1e-14)
+        assert np.isclose(float(out["asdef"]), want["asdef"], rtol=1e-11)
+        # the golden (reference-produced) calls, coordinates included, come out of this reference too
+        assert np.array_equal(gc_[:, :3], g["t_%s_results_calls" % name][:, :3])
+
+
+def test_newrefpart_cluster_style(tmp_path, golden):
+    """newrefprep / newrefpart m n / newrefpost as separate commands (README.md:135-142)."""
+    from wisecondor_amd import wisecondor as cli
+    g = golden("cfg1_pipeline.npz")
+    lengths = g["sample_chrom_lengths"]
+    infiles = []
+    for i, row in enumerate(g["ref_samples"][:8]):
+        p = str(tmp_path / ("ref_%02d.npz" % i))
+        _write_sample(p, row, lengths, 1e6)
+        infiles.append(p)
+    prep = str(tmp_path / "r_prep.npz")
+    cli.main(["newrefprep"] + infiles + [prep, "-binsize", "2000000"])
+    for m in (1, 2):
+        cli.main(["newrefpart", prep, str(tmp_path / "r_part"), str(m), "2", "-refsize", "60"])
+    cli.main(["newrefpost", prep, str(tmp_path / "r_part"), "2", str(tmp_path / "r.npz")])
+    ref = np.load(str(tmp_path / "r.npz"), allow_pickle=True)
+    pz = np.load(prep, allow_pickle=True)
+    assert float(ref["binsize"]) == 2000000
+    assert pz["correctedData"].flags["F_CONTIGUOUS"]
+    want_i, want_d = wo.get_reference(pz["correctedData"], pz["maskedChromBins"], pz["maskedChromBinSums"], 60, 1, 1,
+                                      fast=True)
+    assert np.array_equal(ref["indexes"], want_i) and np.array_equal(ref["distances"], want_d)
+    part1 = np.load(str(tmp_path / "r_part_1.npz"), allow_pickle=True)
+    assert set(part1.files) == {"arguments", "runtime", "indexes", "distances"}

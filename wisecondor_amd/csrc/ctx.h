@@ -50,6 +50,17 @@ struct wc_ctx {
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
     int64_t last_stats[8] = {0};
+    // side stream for work that only feeds an output (overlaps with the main stream)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool side_pending = false;
+    int ensure_side_stream() {
+        if (side) return WC_OK;
+        WC_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        WC_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        WC_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        return WC_OK;
+    }
 
     std::vector<wc::DevBuf *> all_buffers() {
         return {&nr.col_partial, &nr.col_mean, &nr.a32, &nr.norm_lo, &nr.norm_hi, &nr.chrom_of_row,

@@ -49,6 +49,9 @@ void wc_destroy(wc_ctx *ctx) {
     (void)hipDeviceSynchronize();
     for (wc::DevBuf *b : ctx->all_buffers()) b->release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->side) (void)hipStreamDestroy(ctx->side);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     delete ctx;
 }
 

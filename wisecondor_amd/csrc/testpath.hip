@@ -305,23 +305,16 @@ __global__ void k_sd_avg(const double *__restrict__ sdT, int64_t B, int64_t Ns, 
     int64_t b = 0;
     // the sum is serial by definition (a Python loop in the reference); keep 16 loads
     // in flight.  Skipped (NaN) terms add +0.0, which is exact for a sum of sds >= 0.
-    double v[32], w[32];
-    if (B >= 32) {
+    for (; b + 16 <= B; b += 16) {
+        double v[16];
 #pragma unroll
-        for (int u = 0; u < 32; ++u) v[u] = sdT[(int64_t)u * Ns + i];
-    }
-    for (; b + 32 <= B; b += 32) {
-        const bool more = b + 64 <= B;
+        for (int u = 0; u < 16; ++u) v[u] = sdT[(b + u) * Ns + i];
 #pragma unroll
-        for (int u = 0; u < 32; ++u) w[u] = more ? sdT[(b + 32 + u) * Ns + i] : 0.0;
-#pragma unroll
-        for (int u = 0; u < 32; ++u) {
+        for (int u = 0; u < 16; ++u) {
             bool ok = v[u] == v[u];
             s = s + (ok ? v[u] : 0.0);
             c += ok;
         }
-#pragma unroll
-        for (int u = 0; u < 32; ++u) v[u] = w[u];
     }
     for (; b < B; ++b) {
         double v = sdT[b * Ns + i];
@@ -915,9 +908,25 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
         hipLaunchKernelGGL(k_flag, dim3(g), dim3(256), 0, stream, (const double *)ts.zt.as<double>(), thr, n, Ns,
                            cur, next, ts.xc.as<double>());
     }
-    hipLaunchKernelGGL(k_sd_avg, dim3((unsigned)cdiv(Ns, 64)), dim3(64), 0, stream,
+    // stdDevAvg is a serial sum by definition (one lane per sample); it only feeds the
+    // asdef output, so it runs on the context's side stream under the segmentation work.
+    if ((rc = ctx->ensure_side_stream())) return rc;
+    WC_HIP(hipEventRecord(ctx->ev_fork, stream));
+    WC_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+    hipLaunchKernelGGL(k_sd_avg, dim3((unsigned)cdiv(Ns, 64)), dim3(64), 0, ctx->side,
                        (const double *)ts.sdt.as<double>(), ref->B, Ns, ts.sd_avg.as<double>());
+    WC_HIP(hipEventRecord(ctx->ev_join, ctx->side));
+    ctx->side_pending = true;
     WC_HIP(hipGetLastError());
+    return WC_OK;
+}
+
+// Make `stream` wait for the side-stream work of run_repeat (before sd_avg is consumed).
+int join_side(wc_ctx *ctx, hipStream_t stream) {
+    if (ctx->side_pending) {
+        WC_HIP(hipStreamWaitEvent(stream, ctx->ev_join, 0));
+        ctx->side_pending = false;
+    }
     return WC_OK;
 }
 
@@ -1192,6 +1201,7 @@ int wc_repeat_test(wc_ctx *ctx, const wc_reference *ref, const double *data, int
     if ((rc = ts.z.reserve(sizeof(double) * n))) return rc;
     WC_HIP(hipMemcpy(ts.data.p, data, sizeof(double) * n, hipMemcpyHostToDevice));
     if ((rc = run_repeat(ctx, ref, ts.data.as<double>(), n_samples, threshold, repeats, nullptr))) return rc;
+    if ((rc = join_side(ctx, nullptr))) return rc;
     struct { wc::DevBuf *src; double *dst; } outs[] = {{&ts.zt, z}, {&ts.rt, r}, {&ts.nt, ref_sizes}};
     for (auto &o : outs) {
         if (!o.dst) continue;
@@ -1262,7 +1272,13 @@ int wc_test_batch_dev(wc_ctx *ctx, void *stream_, const wc_reference *ref, const
     int rc;
     if ((rc = run_prepare(ctx, ref, counts, Ns, stream))) return rc;
     if ((rc = run_repeat(ctx, ref, ts.data.as<double>(), Ns, threshold, repeats, stream))) return rc;
-    if (asdef) WC_HIP(hipMemcpyAsync(asdef, ts.sd_avg.p, sizeof(double) * Ns, hipMemcpyDeviceToDevice, stream));
+    struct Joiner {   // asdef is copied out once the side stream's sum is done, on every exit path
+        wc_ctx *c; hipStream_t s; double *dst; int64_t n;
+        ~Joiner() {
+            if (join_side(c, s) == WC_OK && dst)
+                (void)hipMemcpyAsync(dst, c->ts.sd_avg.p, sizeof(double) * n, hipMemcpyDeviceToDevice, s);
+        }
+    } joiner{ctx, stream, asdef, Ns};
     if (results_z || results_r) {
         dim3 g((unsigned)cdiv(ref->Btot, 256), (unsigned)Ns);
         hipLaunchKernelGGL(k_inflate, g, dim3(256), 0, stream, (const double *)ts.zt.as<double>(),
