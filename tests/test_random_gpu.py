@@ -1,0 +1,116 @@
+"""Randomised GPU-vs-oracle parity over shapes that do not line up with any tile size:
+ragged chromosome layouts (including empty and 1-bin chromosomes), k above and below the
+candidate count, duplicated rows, outlier rows, both numpy summation orders; and the
+whole `test` path on references produced by the GPU newref."""
+import numpy as np
+import pytest
+
+from oracle import wc_oracle as wo
+
+pytestmark = pytest.mark.gpu
+
+
+def same_bits(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if a.shape != b.shape:
+        return False
+    nan = np.isnan(a) & np.isnan(b)
+    return bool(np.all(nan | (a.view(np.int64) == b.view(np.int64))))
+
+
+@pytest.fixture(scope="module")
+def wt():
+    from wisecondor_amd import wisetools
+    return wisetools
+
+
+def random_layout(rng, n_chrom, lo, hi):
+    bins = rng.randint(lo, hi, size=n_chrom)
+    if n_chrom > 3 and rng.rand() < 0.5:
+        bins[rng.randint(0, n_chrom)] = 0          # a chromosome that lost every bin to the mask
+    if n_chrom > 3 and rng.rand() < 0.5:
+        bins[rng.randint(0, n_chrom)] = 1
+    return bins.astype(np.int64)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_newref_random(wt, seed):
+    rng = np.random.RandomState(1000 + seed)
+    n_chrom = int(rng.choice([2, 3, 5, 22, 22, 24]))
+    bins = random_layout(rng, n_chrom, 1, int(rng.choice([6, 30, 90, 140])))
+    B = int(bins.sum())
+    if B < 3:
+        bins[0] += 3
+        B = int(bins.sum())
+    S = int(rng.choice([1, 2, 7, 8, 9, 31, 33, 64, 100, 129, 200, 513]))
+    k = int(rng.choice([1, 5, 17, 100, 128]))
+    data = 1.0 + 0.03 * rng.standard_normal((B, S))
+    if rng.rand() < 0.5:      # exact duplicates across the genome
+        for _ in range(max(1, B // 10)):
+            data[rng.randint(0, B)] = data[rng.randint(0, B)]
+    if rng.rand() < 0.3:
+        data[rng.randint(0, B)] *= rng.choice([0.0, 30.0, 1e4])
+    if rng.rand() < 0.2:
+        data[rng.randint(0, B), rng.randint(0, S)] = rng.choice([np.nan, np.inf])
+    if rng.rand() < 0.5:
+        data = np.asfortranarray(data)
+    sums = np.cumsum(bins)
+    parts = int(rng.choice([1, 1, 2, 5]))
+    for part in range(1, parts + 1):
+        idx, dst = wt.getReference(data, bins, sums, k, part, parts)
+        with np.errstate(all="ignore"):
+            want_i, want_d = wo.get_reference(data, bins, sums, k, part, parts, fast=True)
+        want_i = np.asarray(want_i).reshape(-1, k)
+        want_d = np.asarray(want_d, dtype=np.float64).reshape(-1, k)
+        assert np.array_equal(idx, want_i), (seed, B, S, k, part, parts)
+        assert same_bits(dst, want_d), (seed, B, S, k, part, parts)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_whole_test_path_random(wt, seed):
+    """Reference from the GPU newref on random data, samples with planted events, oracle toolTest."""
+    rng = np.random.RandomState(77 + seed)
+    sizes = rng.randint(25, 70, size=22).astype(np.int64)          # genomic bins per chromosome
+    total = int(sizes.sum())
+    mask = rng.rand(total) > 0.06
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    msizes = np.array([int(mask[offs[i]:offs[i + 1]].sum()) for i in range(22)], dtype=np.int64)
+    B = int(msizes.sum())
+    S = 20
+    corrected = 1.0 + 0.02 * rng.standard_normal((B, S))
+    k = int(rng.choice([30, 60]))
+    idx, dst = wt.getReference(np.asfortranarray(corrected), msizes, np.cumsum(msizes), k, 1, 1)
+    comps = np.linalg.qr(rng.standard_normal((B, 3)))[0].T
+    mean = np.full(B, 1.0 / B) * (1 + 0.01 * rng.standard_normal(B))
+    ref = dict(binsize=np.float64(1e6), indexes=idx, distances=dst, chromosome_sizes=sizes, mask=mask,
+               masked_sizes=msizes, pca_mean=mean, pca_components=comps)
+    reference = wt.Reference(idx, dst, sizes, msizes, mask, mean, comps, binsize=1e6)
+    samples = []
+    for _ in range(5):
+        lam = np.full(total, 3000.0) * (1 + 0.02 * rng.standard_normal(total)).clip(0.5)
+        c = rng.randint(0, 22)
+        a = offs[c] + rng.randint(0, max(1, sizes[c] - 12))
+        lam[a:a + rng.randint(4, 12)] *= rng.choice([0.6, 1.4, 1.08])
+        counts = rng.poisson(lam).astype(np.int32)
+        if rng.rand() < 0.5:
+            counts[offs[3]:offs[3] + 2] = 0
+        sample = {str(c + 1): counts[offs[c]:offs[c + 1]] for c in range(22)}
+        # ragged inputs: one chromosome longer, one shorter than the reference layout
+        sample["7"] = np.concatenate([sample["7"], np.array([5, 6, 7], dtype=np.int32)])
+        sample["9"] = sample["9"][:-2]
+        samples.append(sample)
+    minref = int(rng.choice([5, 25]))
+    thr = 4.2
+    outs = wt.test_batch(reference, samples, thr, minrefbins=minref, repeats=4)
+    for sample, out in zip(samples, outs):
+        with np.errstate(all="ignore"):
+            want = wo.test_sample(sample, 1e6, ref, minzscore=thr, minrefbins=minref, repeats=4)
+        wc_ = np.asarray(want["results_calls"], dtype=np.float64).reshape(-1, 5)
+        gc_ = out["results_calls"].reshape(-1, 5)
+        assert np.array_equal(gc_[:, :3], wc_[:, :3]), (seed, gc_, wc_)
+        assert np.allclose(gc_[:, 3:], wc_[:, 3:], rtol=1e-8, equal_nan=True)
+        assert np.allclose(np.concatenate(out["results_z"]), np.concatenate(want["results_z"]),
+                           rtol=1e-8, atol=1e-10, equal_nan=True)
+        assert np.allclose(out["results_cwz"], want["results_cwz"], rtol=1e-8, atol=1e-9, equal_nan=True)
+    reference.close()
