@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--test-samples", type=int, default=64, help="test samples per GPU in the batched test pass")
     ap.add_argument("--refsize", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
+                    "functional tests of the multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
     import torch
@@ -85,11 +87,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.backend == "gloo":
+        local_rank = local_rank % max(1, torch.cuda.device_count())   # ranks may share a GPU in tests
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     lib = _lib.load()
@@ -126,7 +133,8 @@ def main():
     t_newref = time.perf_counter() - t0
     kernel_ms = float(np.mean([ev[2 * s].elapsed_time(ev[2 * s + 1]) for s in range(args.steps)]))
     stats = wt.newref_stats(local_rank)
-    tmax = torch.tensor([t_newref], device=dev, dtype=torch.float64)
+    tdev = dev if args.backend == "nccl" else torch.device("cpu")
+    tmax = torch.tensor([t_newref], device=tdev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     t_newref = float(tmax.item())
@@ -149,7 +157,7 @@ def main():
         tb.run()
     sync_all()
     t_test = time.perf_counter() - t0
-    tmax = torch.tensor([t_test], device=dev, dtype=torch.float64)
+    tmax = torch.tensor([t_test], device=tdev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     t_test = float(tmax.item())

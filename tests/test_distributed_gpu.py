@@ -1,0 +1,62 @@
+"""Two and three ranks sharing the one GPU of the test box (gloo for the collectives,
+staged through host memory): the real HIP stages with the real exchange kernels
+(export / import of candidate lists, threshold hand-over) must reproduce the single-rank
+result bit for bit.  RCCL itself needs one GPU per rank and is exercised by bench.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle import wc_oracle as wo
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, path_in, out_dir):
+    import torch
+    import torch.distributed as dist
+    from wisecondor_amd import _lib
+    from wisecondor_amd.distributed import NewrefJob
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        z = np.load(path_in)
+        X = torch.from_numpy(np.ascontiguousarray(z["data"])).cuda()
+        job = NewrefJob(_lib.context(0), X, z["bins"], int(z["k"]), int(z["order"]), rank=rank, world=world, dist=dist)
+        for _ in range(2):
+            idx, dst = job.run()
+        torch.cuda.synchronize()
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), idx=idx.cpu().numpy(), dst=dst.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,order", [(2, 1), (3, 0)])
+def test_hip_multi_rank_on_one_gpu(tmp_path, world, order):
+    import torch.multiprocessing as mp
+    from wisecondor_amd import synth
+    data, bins, sums = synth.corrected_matrix(1000000, 40, seed=9)
+    data[5] = data[900]                       # a tie across ranks' row ranges
+    data[2000] *= 25.0                        # an outlier row that needs the exact fallback
+    k = 100
+    path_in = str(tmp_path / "in.npz")
+    np.savez(path_in, data=data, bins=bins, k=k, order=order)
+    mp.get_context("spawn")
+    mp.spawn(_worker, args=(world, _free_port(), path_in, str(tmp_path)), nprocs=world, join=True)
+    src = data if order == 0 else np.asfortranarray(data)
+    with np.errstate(all="ignore"):
+        want_i, want_d = wo.get_reference(src, bins, sums, k, 1, 1, fast=True)
+    for r in range(world):
+        got = np.load(str(tmp_path / ("rank%d.npz" % r)))
+        assert np.array_equal(got["idx"], want_i), r
+        assert np.array_equal(got["dst"], want_d), r

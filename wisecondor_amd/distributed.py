@@ -106,6 +106,27 @@ class NewrefJob(object):
             self.thr_all = e((self.world, self.max_rows), t.float32)
             self.buffers_ready = False
 
+    # Collectives: RCCL moves device tensors directly; under gloo (CPU tests, or two ranks
+    # sharing one GPU in tests) device tensors are staged through host memory.
+    def _needs_staging(self, t):
+        return self.dist.get_backend() == "gloo" and t.device.type != "cpu"
+
+    def _all_gather(self, out, inp):
+        if self._needs_staging(inp):
+            o = out.cpu()
+            self.dist.all_gather_into_tensor(o, inp.cpu())
+            out.copy_(o)
+        else:
+            self.dist.all_gather_into_tensor(out, inp)
+
+    def _all_to_all(self, out, inp):
+        if self._needs_staging(inp):
+            o = out.cpu()
+            self.dist.all_to_all_single(o, inp.cpu())
+            out.copy_(o)
+        else:
+            self.dist.all_to_all_single(out, inp)
+
     def _alloc_exchange(self):
         t = self.torch
         e = self.st.empty
@@ -138,7 +159,7 @@ class NewrefJob(object):
         st.thresholds(rb, re)
         self.thr_own.zero_()
         st.get_thr(rb, re, self.thr_own)
-        dist.all_gather_into_tensor(self.thr_all.view(-1), self.thr_own)
+        self._all_gather(self.thr_all.view(-1), self.thr_own)
         for r, (b, e) in enumerate(self.ranges):
             if r != self.rank:
                 st.set_thr(b, e, self.thr_all[r])
@@ -153,15 +174,15 @@ class NewrefJob(object):
         for r, (b, e) in enumerate(self.ranges):
             if r != self.rank:
                 st.export(b, e, self.cap_x, self.send_cnt[r], self.send_lst[r])
-        dist.all_to_all_single(self.recv_cnt.view(-1), self.send_cnt.view(-1))
-        dist.all_to_all_single(self.recv_lst.view(-1), self.send_lst.view(-1))
+        self._all_to_all(self.recv_cnt.view(-1), self.send_cnt.view(-1))
+        self._all_to_all(self.recv_lst.view(-1), self.send_lst.view(-1))
         for r in range(self.world):
             if r != self.rank:
                 st.import_(rb, re, self.cap_x, self.recv_cnt[r], self.recv_lst[r])
         # owners finish their rows; results to everyone
         st.finish(rb, re, self.idx_own, self.dst_own)
-        dist.all_gather_into_tensor(self.idx_all.view(-1), self.idx_own.view(-1))
-        dist.all_gather_into_tensor(self.dst_all.view(-1), self.dst_own.view(-1))
+        self._all_gather(self.idx_all.view(-1), self.idx_own.view(-1))
+        self._all_gather(self.dst_all.view(-1), self.dst_own.view(-1))
         idx = self.torch.cat([self.idx_all[r, :e - b] for r, (b, e) in enumerate(self.ranges)])
         dst = self.torch.cat([self.dst_all[r, :e - b] for r, (b, e) in enumerate(self.ranges)])
         return idx, dst
