@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--test-samples", type=int, default=64, help="test samples per GPU in the batched test pass")
     ap.add_argument("--refsize", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra 600 x 50 kb newref measurement")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
                     "functional tests of the multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -164,6 +165,42 @@ def main():
     samples_per_s = world * args.test_samples * test_steps / t_test
     n_calls = int(tb.n_calls.sum().item())
 
+    # ------------------------------------------- extra: newref at 600 x 50 kb ----
+    # BASELINE.json config 4 (the at-scale shape), kernel-level synthetic matrix; reported
+    # beside the headline so that the MFMA kernel is also seen where it is not launch bound.
+    extra = None
+    if not args.no_extra and args.workload != "cfg4":
+        from wisecondor_amd import synth
+        xb, xs = WORKLOADS["cfg4"]
+        xdata, xbins, _ = synth.corrected_matrix(xb, xs, seed=0)
+        XB = int(xdata.shape[0])
+        xpairs = float(XB) * XB - float((xbins.astype(np.float64) ** 2).sum())
+        XX = torch.from_numpy(xdata).to(dev)
+        del xdata
+        xjob = distributed.NewrefJob(ctx, XX, xbins, k, _lib.SUM_SEQUENTIAL, rank=rank, world=world)
+        xsteps = 3
+        xev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * xsteps)]
+        xjob.run()
+        sync_all()
+        t0 = time.perf_counter()
+        for q in range(xsteps):
+            xjob.run(collect_events=(xev[2 * q], xev[2 * q + 1]))
+        sync_all()
+        xt = time.perf_counter() - t0
+        tmax = torch.tensor([xt], device=tdev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        xt = float(tmax.item())
+        xk_ms = float(np.mean([xev[2 * q].elapsed_time(xev[2 * q + 1]) for q in range(xsteps)]))
+        xflops = (xpairs / 2.0) * 2.0 * xs / world
+        extra = {"workload": "cfg4: newref %d samples x %d kb bins (%d bins), kernel-level synthetic matrix"
+                             % (xs, xb // 1000, XB),
+                 "value": xpairs * xsteps / xt, "unit": "bin-pair distances/s", "ms_per_step": 1e3 * xt / xsteps,
+                 "steps": xsteps, "k_gram_ms": xk_ms, "k_gram_tflops": xflops / (xk_ms * 1e-3) / 1e12,
+                 "k_gram_frac_of_fp32_mfma_peak": xflops / (xk_ms * 1e-3) / PEAK_FP32_MFMA}
+        del xjob, XX
+        # the main job's context state was replaced by the extra run; nothing below needs it
+
     # ------------------------------------------------------- cpu baseline ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -235,6 +272,7 @@ def main():
                          "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_traffic.json)",
                          "kernel_ms": kernel_ms, "algorithmic_flop_per_launch": flops},
             "newref_stats": stats,
+            "extra": extra,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -192,6 +192,25 @@ def zThreshold(masked_sizes, multitest, minzscore):
     return z_threshold
 
 
+def writeTestOutput(outfile, args, binsize, out, z_threshold):
+    """The test .npz exactly as the reference lays it out (wisecondor.py:270-280): ragged
+    per-chromosome lists become object arrays (modern numpy refuses to infer them), an empty
+    call list stays shape (0,) like np.array([])."""
+    calls = np.asarray(out['results_calls'])
+    stdDevAvg = out['asdef']
+    np.savez_compressed(outfile,
+                        arguments=vars(args),
+                        runtime=getRuntime(),
+                        binsize=binsize,
+                        results_r=_object_array(out['results_r']),
+                        results_z=_object_array(out['results_z']),
+                        results_cwz=out['results_cwz'],
+                        results_calls=calls if len(calls) else np.array([]),
+                        threshold_z=z_threshold,
+                        asdef=stdDevAvg,
+                        aasdef=stdDevAvg * z_threshold)
+
+
 def toolTest(args):
     """wisecondor.py:174-281: one sample against a reference, on the GPU."""
     referenceFile = _load(args.reference)
@@ -219,18 +238,7 @@ def toolTest(args):
     print('ASDES:', stdDevAvg, '\nAASDEF:', stdDevAvg * z_threshold)
     print('Time spent on z-scores and stouffers z-scores:', int(time.time() - start), 'seconds')
 
-    calls = out['results_calls']
-    np.savez_compressed(args.outfile,
-                        arguments=vars(args),
-                        runtime=getRuntime(),
-                        binsize=binsize,
-                        results_r=_object_array(out['results_r']),
-                        results_z=_object_array(out['results_z']),
-                        results_cwz=out['results_cwz'],
-                        results_calls=calls if len(calls) else np.array([]),
-                        threshold_z=z_threshold,
-                        asdef=stdDevAvg,
-                        aasdef=stdDevAvg * z_threshold)
+    writeTestOutput(args.outfile, args, binsize, out, z_threshold)
     reference.close()
     sys.exit(0)
 
