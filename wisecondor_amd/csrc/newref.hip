@@ -233,22 +233,22 @@ __global__ __launch_bounds__(256, 4) void k_gram(GramArgs g) {
                 qb[p] = *(const f32x4 *)(Qg + ko + (int64_t)p * 32 * g.ld);
             }
         }
-        float af[2][16], bf[2][16];
+        // keep the prefetch above the MFMA phase: the staging registers stay live, and the
+        // fragments are fetched in four groups of four steps (16 live floats) instead
+        __builtin_amdgcn_sched_barrier(0);
+        const float *a0 = &As[(wr * 64 + li) * LDA + lh * 16], *a1 = a0 + 32 * LDA;
+        const float *b0 = &Bs[(wc * 64 + li) * LDA + lh * 16], *b1 = b0 + 32 * LDA;
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int tg = 0; tg < 4; ++tg) {
+            const f32x4 ca0 = *(const f32x4 *)(a0 + 4 * tg), ca1 = *(const f32x4 *)(a1 + 4 * tg);
+            const f32x4 cb0 = *(const f32x4 *)(b0 + 4 * tg), cb1 = *(const f32x4 *)(b1 + 4 * tg);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 va = *(const f32x4 *)&As[(wr * 64 + m * 32 + li) * LDA + lh * 16 + q * 4];
-                f32x4 vb = *(const f32x4 *)&Bs[(wc * 64 + m * 32 + li) * LDA + lh * 16 + q * 4];
-                af[m][q * 4 + 0] = va.x; af[m][q * 4 + 1] = va.y; af[m][q * 4 + 2] = va.z; af[m][q * 4 + 3] = va.w;
-                bf[m][q * 4 + 0] = vb.x; bf[m][q * 4 + 1] = vb.y; bf[m][q * 4 + 2] = vb.z; bf[m][q * 4 + 3] = vb.w;
+            for (int e = 0; e < 4; ++e) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca0[e], cb0[e], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca0[e], cb1[e], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca1[e], cb0[e], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca1[e], cb1[e], acc[1][1], 0, 0, 0);
             }
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][t], bf[0][t], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][t], bf[1][t], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][t], bf[0][t], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][t], bf[1][t], acc[1][1], 0, 0, 0);
         }
     }
 
