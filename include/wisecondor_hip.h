@@ -168,18 +168,21 @@ int wc_repeat_test(wc_ctx *ctx, const wc_reference *ref, const double *data, int
                    double *sd_avg);
 
 /*
- * fillTri (wisetools.py:466-472) + TriArr.segmentTri (triarray.py:59-84) on a
- * batch of independent regions without materialising the triangle.
+ * fillTri / fillTriMin (wisetools.py:466-487) + TriArr.segmentTri (triarray.py:59-84)
+ * on a batch of independent regions without materialising the triangle.
  * z [total] float64: concatenated regions; region_offsets [n_regions+1].
+ * min_effect != 0 enables fillTriMin's filter: a window keeps its value only if
+ * abs(median(ratio[x..y]) - 1) >= min_effect (ratio laid out like z; may be NULL
+ * when min_effect == 0).
  * Outputs per region: whole-region Stouffer z (getValue(0,n-1),
  * wisecondor.py:237) and up to max_calls segments (value, x, y inclusive) in
  * ascending position order; n_calls[region] holds the number found (if it
  * exceeds max_calls the call fails with WC_E_LIMIT).
  */
-int wc_stouffer_segments(wc_ctx *ctx, const double *z, const int64_t *region_offsets,
-                         int64_t n_regions, double threshold, int min_search, int max_calls,
-                         double *region_z, int32_t *n_calls, double *call_value, int32_t *call_x,
-                         int32_t *call_y);
+int wc_stouffer_segments(wc_ctx *ctx, const double *z, const double *ratio, double min_effect,
+                         const int64_t *region_offsets, int64_t n_regions, double threshold,
+                         int min_search, int max_calls, double *region_z, int32_t *n_calls,
+                         double *call_value, int32_t *call_x, int32_t *call_y);
 
 /*
  * The numeric content of toolTest (wisecondor.py:199-268) for a batch:
@@ -193,19 +196,19 @@ int wc_stouffer_segments(wc_ctx *ctx, const double *z, const int64_t *region_off
  *   calls         [n_samples, max_calls, 5] rows [chrom, start, end, z, effect]
  *   n_calls       [n_samples]
  *   asdef         [n_samples]
- * mineffectsize must be 0 (the reference default); the median-filtered
- * triangle of wisetools.py:479-487 is not implemented on the GPU yet.
+ * min_effect is -mineffectsize (0 = the reference default, no filter).
  */
 int wc_test_batch(wc_ctx *ctx, const wc_reference *ref, const int32_t *counts, int64_t n_samples,
-                  double threshold, int min_ref_bins, int repeats, const int32_t *chromosomes,
-                  int n_sel, int max_calls, double *results_z, double *results_r,
-                  double *results_cwz, double *calls, int32_t *n_calls, double *asdef);
+                  double threshold, int min_ref_bins, int repeats, double min_effect,
+                  const int32_t *chromosomes, int n_sel, int max_calls, double *results_z,
+                  double *results_r, double *results_cwz, double *calls, int32_t *n_calls,
+                  double *asdef);
 
 /* Device-resident variant used by bench.py: counts already on the GPU, outputs
  * stay on the GPU (any output pointer may be NULL to skip it).                */
 int wc_test_batch_dev(wc_ctx *ctx, void *stream, const wc_reference *ref, const int32_t *counts,
                       int64_t n_samples, double threshold, int min_ref_bins, int repeats,
-                      const int32_t *chromosomes_host, int n_sel, int max_calls,
+                      double min_effect, const int32_t *chromosomes_host, int n_sel, int max_calls,
                       double *results_z, double *results_r, double *results_cwz, double *calls,
                       int32_t *n_calls, double *asdef);
 

@@ -173,3 +173,28 @@ def test_cfg1_test_options(golden):
     assert np.allclose(out["results_cwz"], g["opts_results_cwz"], rtol=1e-10)
     assert np.allclose(np.concatenate(out["results_z"]), g["opts_results_z"], rtol=1e-10, atol=1e-12)
     assert np.isclose(out["asdef"], float(g["opts_asdef"]), rtol=1e-12)
+
+
+def test_fill_tri_min_segments(golden):
+    g = golden("segments.npz")
+    for i in range(int(g["mincase_n"])):
+        z, r, eff = g["mincase_z_%d" % i], g["mincase_r_%d" % i], float(g["mincase_eff_%d" % i])
+        with np.errstate(all="ignore"):
+            tri = wo.fill_tri_min(z, r, eff)
+        assert same_bits(tri, g["mincase_tri_%d" % i]), i
+        segs = wo.segment_tri(tri, z.shape[0], 3.0, 3)
+        got = np.array([[v, x, y] for v, (x, y) in segs], dtype=np.float64).reshape(-1, 3)
+        assert np.array_equal(got[:, 1:], g["mincase_seg_%d" % i][:, 1:]), i
+        assert same_bits(got[:, 0], g["mincase_seg_%d" % i][:, 0]), i
+
+
+@pytest.mark.parametrize("name", ["loss2", "gain5_gap"])
+def test_cfg1_mineffectsize(golden, name):
+    g = golden("cfg1_pipeline.npz")
+    sample = _split(g["t_%s_sample" % name], g["sample_chrom_lengths"])
+    out = wo.test_sample(sample, float(g["binsize"]), _reference(g), mineffectsize=float(g["eff_mineffectsize"]))
+    want = g["eff_%s_results_calls" % name]
+    got = out["results_calls"].reshape(-1, 5)
+    assert np.array_equal(got[:, :3], want[:, :3])
+    assert np.allclose(got[:, 3:], want[:, 3:], rtol=1e-10)
+    assert np.allclose(out["results_cwz"], g["eff_%s_results_cwz" % name], rtol=1e-10, atol=1e-10)

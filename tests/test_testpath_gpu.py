@@ -119,8 +119,58 @@ def test_triarr_mirror(wt, golden):
     assert tri.linTo2D(wo.tri_offset(n, 13, 22)) == (13, 22)
     segs = tri.segmentTri(float(g["thresholds"][27]), 3)
     assert [(x, y) for _, (x, y) in segs] == [tuple(int(v) for v in row[1:]) for row in g["seg_27"]]
-    with pytest.raises(NotImplementedError):
-        wt.fillTriMin(z, np.ones_like(z), 0.05)
+
+
+def test_fill_tri_min_golden(wt, golden):
+    """-mineffectsize branch (wisetools.py:479-487): window values and segments of the filtered triangle."""
+    g = golden("segments.npz")
+    for i in range(int(g["mincase_n"])):
+        z, r, eff = g["mincase_z_%d" % i], g["mincase_r_%d" % i], float(g["mincase_eff_%d" % i])
+        tri = wt.fillTriMin(z, r, eff)
+        want_tri = g["mincase_tri_%d" % i]
+        n = len(z)
+        rng = np.random.RandomState(i)
+        for _ in range(min(12, n * (n + 1) // 2)):
+            x = int(rng.randint(0, n))
+            y = int(rng.randint(x, n))
+            assert same_bits([tri.getValue(x, y)], [want_tri[wo.tri_offset(n, x, y)]]), (i, x, y)
+        segs = tri.segmentTri(3.0, 3)
+        want = g["mincase_seg_%d" % i]
+        got = np.array([[v, x, y] for v, (x, y) in segs], dtype=np.float64).reshape(-1, 3)
+        assert np.array_equal(got[:, 1:], want[:, 1:]), (i, got, want)
+        assert same_bits(got[:, 0], want[:, 0]), i
+    # batched, against the oracle, with ties and NaN ratios
+    rng = np.random.RandomState(3)
+    zs, rs = [], []
+    for n in (5, 31, 77, 130):
+        z = rng.standard_normal(n)
+        r = np.round(1.0 + 0.05 * rng.standard_normal(n), 2)      # many equal ratios: median ties
+        z[n // 2:n // 2 + 4] += 4
+        r[n // 2:n // 2 + 4] += 0.1
+        zs.append(z)
+        rs.append(r)
+    rs[2][5] = np.nan
+    whole, segs = wt.stouffer_segments(zs, 3.0, 3, ratios=rs, mineffectsize=0.05)
+    for z, r, w, s in zip(zs, rs, whole, segs):
+        with np.errstate(all="ignore"):
+            tri = wo.fill_tri_min(z, r, 0.05)
+        want = wo.segment_tri(tri, len(z), 3.0, 3)
+        assert [(x, y) for _, (x, y) in s] == [(x, y) for _, (x, y) in want]
+        assert same_bits([v for v, _ in s], [v for v, _ in want])
+        assert same_bits([w], [tri[len(z) - 1]])
+
+
+@pytest.mark.parametrize("name", ["loss2", "gain5_gap"])
+def test_cfg1_mineffectsize(wt, cfg1, reference, name):
+    g = cfg1
+    thr = float(g["t_mild18_threshold_z"])
+    sample = _split(g["t_%s_sample" % name], g["sample_chrom_lengths"])
+    out = wt.test_batch(reference, [sample], thr, mineffectsize=float(g["eff_mineffectsize"]))[0]
+    want = g["eff_%s_results_calls" % name]
+    got = out["results_calls"].reshape(-1, 5)
+    assert np.array_equal(got[:, :3], want[:, :3]), (got, want)
+    assert np.allclose(got[:, 3:], want[:, 3:], rtol=1e-9)
+    assert np.allclose(out["results_cwz"], g["eff_%s_results_cwz" % name], rtol=1e-9, atol=1e-9)
 
 
 def test_segments_random_vs_oracle(wt):

@@ -153,6 +153,28 @@ def segment_cases(wt):
         tri = wt.fillTriMin(z, r, 0.05)
     out["min_z"], out["min_r"], out["min_thr"] = z, r, np.float64(0.05)
     out["min_tri"] = np.array(tri.data_array)
+    # fillTriMin + segmentTri (the -mineffectsize branch), several shapes incl. NaN ratios
+    cases = []
+    for n, eff in ((1, 0.05), (2, 0.05), (9, 0.02), (33, 0.04), (64, 0.03), (90, 0.05), (140, 0.02)):
+        z = rng.standard_normal(n)
+        r = 1.0 + 0.03 * rng.standard_normal(n)
+        if n > 8:
+            a = n // 3
+            z[a:a + n // 5] += 3.5
+            r[a:a + n // 5] += 0.07
+            z[-5:-1] -= 4.0
+            r[-5:-1] -= 0.01      # significant z, but too small an effect: must be filtered out
+        if n == 64:
+            r[10] = np.nan
+        cases.append((z, r, eff))
+    out["mincase_n"] = np.int64(len(cases))
+    for i, (z, r, eff) in enumerate(cases):
+        with np.errstate(all="ignore"):
+            tri = wt.fillTriMin(z, r, eff)
+            segs = tri.segmentTri(3.0, 3)
+        out["mincase_z_%d" % i], out["mincase_r_%d" % i], out["mincase_eff_%d" % i] = z, r, np.float64(eff)
+        out["mincase_tri_%d" % i] = np.array(tri.data_array)
+        out["mincase_seg_%d" % i] = np.array([[v, x, y] for v, (x, y) in segs], dtype=np.float64).reshape(-1, 3)
     return out
 
 
@@ -270,6 +292,22 @@ def cfg1_cases(wt, wc, n_ref=16, binsize=1000000):
     out["opts_results_cwz"] = np.asarray(tz["results_cwz"], dtype=np.float64)
     out["opts_results_calls"] = np.asarray(tz["results_calls"], dtype=np.float64).reshape(-1, 5)
     out["opts_asdef"] = np.float64(tz["asdef"])
+    # -mineffectsize (fillTriMin's median filter) on two samples
+    for name in ("loss2", "gain5_gap"):
+        sp = os.path.join(tmp, "test_%s.npz" % name)
+        op = os.path.join(tmp, "outeff_%s.npz" % name)
+        args = argparse.Namespace(infile=sp, outfile=op, reference=refpath, minzscore=None,
+                                  chromosomes=list(range(1, 23)), mineffectsize=0.07, multitest=1000,
+                                  minrefbins=25, repeats=5)
+        with quiet(), np.errstate(all="ignore"):
+            try:
+                wc.toolTest(args)
+            except SystemExit:
+                pass
+        tz = np.load(op)
+        out["eff_%s_results_cwz" % name] = np.asarray(tz["results_cwz"], dtype=np.float64)
+        out["eff_%s_results_calls" % name] = np.asarray(tz["results_calls"], dtype=np.float64).reshape(-1, 5)
+    out["eff_mineffectsize"] = np.float64(0.07)
     return out
 
 

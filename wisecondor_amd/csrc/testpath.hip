@@ -426,20 +426,104 @@ __global__ __launch_bounds__(256) void k_region_prefix(const double *__restrict_
     }
 }
 
+// fillTriMin's filter (wisetools.py:479-487): a window keeps its value only if
+// abs(median(ratio[x..y]) - 1) >= mineffectsize, otherwise it is exactly 0.  One bit per
+// window, packed region by region in triangle order; a NULL bitmap means "no filter".
+struct WindowMask {
+    const unsigned int *bits;   // NULL -> every window valid
+    long long base;             // bit offset of this region's triangle
+    int n;                      // region length
+    __device__ inline bool valid(int x, int y) const {
+        if (!bits) return true;
+        long long lin = base + (long long)x * n - ((long long)x * (x - 1)) / 2 + (y - x);
+        return (bits[lin >> 5] >> (lin & 31)) & 1u;
+    }
+};
+
+// One wave per (region, first bin x): the windows [x, y], y = x..n-1, by inserting
+// ratio[y] into a sorted LDS array (count-smaller + shift) and reading the median off
+// the middle.  np.median averages the two middle values for even lengths; a NaN in the
+// window makes the median NaN, which fails the comparison (window zeroed).
+__global__ __launch_bounds__(64) void k_window_valid(const double *__restrict__ ratio,
+                                                     const Region *__restrict__ regions,
+                                                     const long long *__restrict__ bit_off, double min_effect,
+                                                     unsigned int *__restrict__ bits) {
+    extern __shared__ double sorted[];
+    const int lane = threadIdx.x;
+    const int x = blockIdx.x;
+    const Region rg = regions[blockIdx.y];
+    if (x >= rg.n) return;
+    const double *rr = ratio + rg.off;
+    const long long row_base = bit_off[blockIdx.y] + (long long)x * rg.n - ((long long)x * (x - 1)) / 2;
+    int len = 0, nans = 0;
+    unsigned int word = 0;
+    long long word_idx = row_base >> 5;
+    for (int y = x; y < rg.n; ++y) {
+        const double v = rr[y];
+        if (v != v) {
+            ++nans;
+        } else {
+            int cnt = 0;
+            for (int t = lane; t < len; t += 64) cnt += (sorted[t] < v);
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+            const int pos = cnt;
+            for (int hi = len; hi > pos; hi -= 64) {
+                const int lo = (hi - 64 > pos) ? hi - 64 : pos;
+                const int t = lo + lane;
+                double val = 0.0;
+                if (t < hi) val = sorted[t];
+                __syncthreads();
+                if (t < hi) sorted[t + 1] = val;
+                __syncthreads();
+            }
+            if (lane == 0) sorted[pos] = v;
+            ++len;
+            __syncthreads();
+        }
+        double med = NAN;
+        if (nans == 0) med = (len & 1) ? sorted[len / 2] : (sorted[len / 2 - 1] + sorted[len / 2]) / 2.0;
+        const bool ok = fabs(med - 1.0) >= min_effect;
+        const long long lin = row_base + (y - x);
+        if ((lin >> 5) != word_idx) {
+            if (lane == 0 && word) atomicOr(&bits[word_idx], word);
+            word = 0;
+            word_idx = lin >> 5;
+        }
+        if (ok) word |= 1u << (lin & 31);
+    }
+    if (lane == 0 && word) atomicOr(&bits[word_idx], word);
+}
+
+// bit offset of every region's triangle in the window bitmap (exclusive scan of n(n+1)/2)
+__global__ void k_bit_offsets(const Region *__restrict__ regions, int64_t n_regions, long long *__restrict__ bit_off) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    long long at = 0;
+    for (int64_t r = 0; r < n_regions; ++r) {
+        bit_off[r] = at;
+        long long n = regions[r].n;
+        at += n * (n + 1) / 2;
+    }
+}
+
 // Exact value of window [x, y]: np_sum(z[x:y+1]) / np_sqrt(y-x+1) (wisetools.py:471)
-template <bool GROUP8> __device__ inline double window_exact(const double *__restrict__ zz, int x, int y, int sub) {
+template <bool GROUP8>
+__device__ inline double window_exact(const double *__restrict__ zz, int x, int y, int sub, const WindowMask &wm) {
+    if (!wm.valid(x, y)) return 0.0;   // uniform per 8-lane group: all its lanes evaluate the same window
     const double *p = zz + x;
     double s = wc::pairwise_sum<GROUP8>([&](int64_t t) { return p[t]; }, (int64_t)(y - x + 1), sub);
     return s / sqrt((double)(y - x + 1));
 }
 
 __global__ __launch_bounds__(256) void k_region_whole(const double *__restrict__ z, const Region *__restrict__ regions,
-                                                      int64_t n_regions, double *__restrict__ whole) {
+                                                      int64_t n_regions, const unsigned int *__restrict__ bits,
+                                                      const long long *__restrict__ bit_off,
+                                                      double *__restrict__ whole) {
     int64_t r = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
     int sub = threadIdx.x & 7;
     bool in = r < n_regions;
     Region rg = regions[in ? r : 0];
-    double v = rg.n > 0 ? window_exact<true>(z + rg.off, 0, rg.n - 1, sub) : NAN;
+    WindowMask wm{bits, bits ? bit_off[in ? r : 0] : 0, rg.n};
+    double v = rg.n > 0 ? window_exact<true>(z + rg.off, 0, rg.n - 1, sub, wm) : NAN;
     if (in && sub == 0) whole[r] = v;
 }
 
@@ -457,6 +541,7 @@ __global__ void k_init_jobs(const Region *__restrict__ regions, int64_t n_region
 struct ScanCtx {
     const double *P;   // prefix of the region
     int lo, hi, L, half, chunk;
+    WindowMask wm;
 };
 
 // Rows handled by (job, chunk): ROWS_HALF rows from the top of the triangle and the
@@ -475,6 +560,7 @@ template <class F> __device__ inline void scan_chunk(const ScanCtx &c, const dou
         const double px = c.P[x];
         for (int y = x + tid; y < c.hi; y += 256) {
             double v = (c.P[y + 1] - px) * rs[y - x + 1];
+            if (!c.wm.valid(x, y)) v = 0.0;
             f(v, x, y);
         }
     }
@@ -484,6 +570,8 @@ __global__ __launch_bounds__(256) void k_seg_search(const Job *__restrict__ jobs
                                                     const Region *__restrict__ regions,
                                                     const double *__restrict__ prefix, const double *__restrict__ rs,
                                                     const int *__restrict__ reg_flag, int max_chunks,
+                                                    const unsigned int *__restrict__ bits,
+                                                    const long long *__restrict__ bit_off,
                                                     Extreme *__restrict__ partial) {
     __shared__ double smax[256], smin[256];
     __shared__ int sx[256], sy[256], tx[256], ty[256];
@@ -495,6 +583,7 @@ __global__ __launch_bounds__(256) void k_seg_search(const Job *__restrict__ jobs
     if (c.L <= 0 || chunk * ROWS_HALF >= c.half) return;
     if (!reg_flag[job.region]) return;  // non-finite region: exact brute-force path
     c.P = prefix + regions[job.region].off + job.region;
+    c.wm = WindowMask{bits, bits ? bit_off[job.region] : 0, regions[job.region].n};
     double bmax = -INFINITY, bmin = INFINITY;
     int mx = -1, my = -1, nx = -1, ny = -1;
     scan_chunk(c, rs, tid, [&](double v, int x, int y) {
@@ -570,7 +659,9 @@ __global__ __launch_bounds__(256) void k_seg_collect(const Job *__restrict__ job
                                                      const Region *__restrict__ regions,
                                                      const double *__restrict__ prefix, const double *__restrict__ rs,
                                                      const double *__restrict__ reg_abs,
-                                                     const Extreme *__restrict__ job_res, int2 *__restrict__ cand,
+                                                     const Extreme *__restrict__ job_res,
+                                                     const unsigned int *__restrict__ bits,
+                                                     const long long *__restrict__ bit_off, int2 *__restrict__ cand,
                                                      int *__restrict__ cand_cnt) {
     const int h = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
     if (h >= counters[2]) return;
@@ -580,6 +671,7 @@ __global__ __launch_bounds__(256) void k_seg_collect(const Job *__restrict__ job
     c.lo = job.lo; c.hi = job.hi; c.L = job.hi - job.lo; c.half = (c.L + 1) / 2; c.chunk = chunk;
     if (chunk * ROWS_HALF >= c.half) return;
     c.P = prefix + regions[job.region].off + job.region;
+    c.wm = WindowMask{bits, bits ? bit_off[job.region] : 0, regions[job.region].n};
     const double eps2 = 2.0 * window_eps(regions[job.region].n, reg_abs[job.region]);
     const Extreme e = job_res[j];
     const double hi_cut = e.maxv - eps2, lo_cut = e.minv + eps2;
@@ -668,8 +760,10 @@ __global__ __launch_bounds__(256) void k_seg_decide(const Job *__restrict__ jobs
                                                     int *__restrict__ counters, const Region *__restrict__ regions,
                                                     const double *__restrict__ z, const int2 *__restrict__ cand,
                                                     const int *__restrict__ cand_cnt, double thr, int min_search,
-                                                    Seg *__restrict__ segs, int seg_cap, Job *__restrict__ next,
-                                                    int job_cap, int *__restrict__ brute) {
+                                                    const unsigned int *__restrict__ bits,
+                                                    const long long *__restrict__ bit_off, Seg *__restrict__ segs,
+                                                    int seg_cap, Job *__restrict__ next, int job_cap,
+                                                    int *__restrict__ brute) {
     const int h = blockIdx.x, tid = threadIdx.x;
     if (h >= counters[2]) return;
     const int j = hot[h];
@@ -680,6 +774,7 @@ __global__ __launch_bounds__(256) void k_seg_decide(const Job *__restrict__ jobs
         return;
     }
     const double *zz = z + regions[job.region].off;
+    const WindowMask wm{bits, bits ? bit_off[job.region] : 0, regions[job.region].n};
     const int grp = tid >> 3, sub = tid & 7;
     BestPair b;
     b.maxv = 0.0; b.minv = 0.0; b.mx = b.my = b.nx = b.ny = -1;
@@ -688,13 +783,13 @@ __global__ __launch_bounds__(256) void k_seg_decide(const Job *__restrict__ jobs
         {
             bool act = t < n_hi;
             int2 w = cand[((int64_t)2 * h) * CAND_CAP + (act ? t : 0)];
-            double v = n_hi > 0 ? window_exact<true>(zz, w.x, w.y, sub) : 0.0;
+            double v = n_hi > 0 ? window_exact<true>(zz, w.x, w.y, sub, wm) : 0.0;
             if (act && sub == 0 && better_max(v, w.x, w.y, b.maxv, b.mx, b.my)) { b.maxv = v; b.mx = w.x; b.my = w.y; }
         }
         {
             bool act = t < n_lo;
             int2 w = cand[((int64_t)2 * h + 1) * CAND_CAP + (act ? t : 0)];
-            double v = n_lo > 0 ? window_exact<true>(zz, w.x, w.y, sub) : 0.0;
+            double v = n_lo > 0 ? window_exact<true>(zz, w.x, w.y, sub, wm) : 0.0;
             if (act && sub == 0 && better_min(v, w.x, w.y, b.minv, b.nx, b.ny)) { b.minv = v; b.nx = w.x; b.ny = w.y; }
         }
     }
@@ -707,17 +802,19 @@ __global__ __launch_bounds__(256) void k_seg_decide(const Job *__restrict__ jobs
 __global__ __launch_bounds__(256) void k_seg_brute(const Job *__restrict__ jobs, const int *__restrict__ brute,
                                                    int *__restrict__ counters, const Region *__restrict__ regions,
                                                    const double *__restrict__ z, double thr, int min_search,
-                                                   Seg *__restrict__ segs, int seg_cap, Job *__restrict__ next,
-                                                   int job_cap) {
+                                                   const unsigned int *__restrict__ bits,
+                                                   const long long *__restrict__ bit_off, Seg *__restrict__ segs,
+                                                   int seg_cap, Job *__restrict__ next, int job_cap) {
     const int q = blockIdx.x, tid = threadIdx.x;
     if (q >= counters[3]) return;
     const Job job = jobs[brute[q]];
     const double *zz = z + regions[job.region].off;
+    const WindowMask wm{bits, bits ? bit_off[job.region] : 0, regions[job.region].n};
     BestPair b;
     b.maxv = 0.0; b.minv = 0.0; b.mx = b.my = b.nx = b.ny = -1;
     for (int x = job.lo; x < job.hi; ++x)
         for (int y = x + tid; y < job.hi; y += 256) {
-            double v = window_exact<false>(zz, x, y, 0);
+            double v = window_exact<false>(zz, x, y, 0, wm);
             if (better_max(v, x, y, b.maxv, b.mx, b.my)) { b.maxv = v; b.mx = x; b.my = y; }
             if (better_min(v, x, y, b.minv, b.nx, b.ny)) { b.minv = v; b.nx = x; b.ny = y; }
         }
@@ -933,7 +1030,8 @@ int join_side(wc_ctx *ctx, hipStream_t stream) {
 // Segment search over device regions.  Results: ts.out_val/out_x/out_y [n_regions, max_calls],
 // ts.out_n [n_regions], ts.whole [n_regions].
 int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, int64_t n_regions, int64_t total_len,
-                 int64_t max_n, double thr, int min_search, int max_calls, hipStream_t stream) {
+                 int64_t max_n, double thr, int min_search, int max_calls, hipStream_t stream,
+                 const double *ratio_dev = nullptr, double min_effect = 0.0, int64_t bits_upper = 0) {
     TestState &ts = ctx->ts;
     int rc;
     ts.last_segs = 0;
@@ -965,6 +1063,23 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     if ((rc = ts.out_n.reserve(sizeof(int) * n_regions))) return rc;
     if ((rc = ts.whole.reserve(sizeof(double) * n_regions))) return rc;
 
+    // -mineffectsize: one validity bit per window (wisetools.py:479-487)
+    const unsigned int *bits = nullptr;
+    const long long *bit_off = nullptr;
+    if (min_effect != 0.0) {
+        WC_CHECK(ratio_dev, WC_E_ARG, "segments: mineffectsize needs the ratio vector");
+        WC_CHECK(max_n * 8 <= 160 * 1024 - 1024, WC_E_LIMIT, "segments: region too long for the median filter");
+        const int64_t words = bits_upper / 32 + 2;
+        if ((rc = ts.win_bits.reserve(sizeof(unsigned int) * words))) return rc;
+        if ((rc = ts.bit_off.reserve(sizeof(long long) * n_regions))) return rc;
+        WC_HIP(hipMemsetAsync(ts.win_bits.p, 0, sizeof(unsigned int) * words, stream));
+        hipLaunchKernelGGL(k_bit_offsets, dim3(1), dim3(1), 0, stream, regions_dev, n_regions, ts.bit_off.as<long long>());
+        hipLaunchKernelGGL(k_window_valid, dim3((unsigned)max_n, (unsigned)n_regions), dim3(64),
+                           sizeof(double) * (max_n + 1), stream, ratio_dev, regions_dev,
+                           (const long long *)ts.bit_off.as<long long>(), min_effect, ts.win_bits.as<unsigned int>());
+        bits = ts.win_bits.as<unsigned int>();
+        bit_off = ts.bit_off.as<long long>();
+    }
     int *counters = ts.job_cnt.as<int>();  // [1] next jobs [2] hot [3] brute [4] segments
     int *hot = ts.hot.as<int>();
     int *brute = hot + job_cap;
@@ -973,7 +1088,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     hipLaunchKernelGGL(k_region_prefix, dim3((unsigned)cdiv(n_regions, 4)), dim3(256), 0, stream, z_dev, regions_dev,
                        n_regions, ts.prefix.as<double>(), ts.reg_abs.as<double>(), ts.reg_flag.as<int>());
     hipLaunchKernelGGL(k_region_whole, dim3((unsigned)cdiv(n_regions, 32)), dim3(256), 0, stream, z_dev, regions_dev,
-                       n_regions, ts.whole.as<double>());
+                       n_regions, bits, bit_off, ts.whole.as<double>());
     hipLaunchKernelGGL(k_init_jobs, dim3((unsigned)cdiv(n_regions, 256)), dim3(256), 0, stream, regions_dev, n_regions,
                        ts.jobs_a.as<Job>());
     Job *cur = ts.jobs_a.as<Job>(), *next = ts.jobs_b.as<Job>();
@@ -986,7 +1101,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
         dim3 sg((unsigned)max_chunks, (unsigned)n_jobs);
         hipLaunchKernelGGL(k_seg_search, sg, dim3(256), 0, stream, (const Job *)cur, (int)n_jobs, regions_dev,
                            (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
-                           (const int *)ts.reg_flag.as<int>(), max_chunks, ts.partial.as<Extreme>());
+                           (const int *)ts.reg_flag.as<int>(), max_chunks, bits, bit_off, ts.partial.as<Extreme>());
         hipLaunchKernelGGL(k_seg_classify, dim3((unsigned)n_jobs), dim3(64), 0, stream, (const Job *)cur, (int)n_jobs,
                            regions_dev, (const double *)ts.reg_abs.as<double>(), (const int *)ts.reg_flag.as<int>(),
                            (const Extreme *)ts.partial.as<Extreme>(), max_chunks, thr, ts.job_res.as<Extreme>(), hot,
@@ -1000,16 +1115,16 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
                                (const Job *)cur, (const int *)hot, (const int *)counters, regions_dev,
                                (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
                                (const double *)ts.reg_abs.as<double>(), (const Extreme *)ts.job_res.as<Extreme>(),
-                               ts.cand.as<int2>(), ts.cand_cnt.as<int>());
+                               bits, bit_off, ts.cand.as<int2>(), ts.cand_cnt.as<int>());
             hipLaunchKernelGGL(k_seg_decide, dim3((unsigned)n_hot), dim3(256), 0, stream, (const Job *)cur,
                                (const int *)hot, counters, regions_dev, z_dev, (const int2 *)ts.cand.as<int2>(),
-                               (const int *)ts.cand_cnt.as<int>(), thr, min_search, ts.seg.as<Seg>(), (int)seg_cap,
-                               next, (int)job_cap, brute);
+                               (const int *)ts.cand_cnt.as<int>(), thr, min_search, bits, bit_off, ts.seg.as<Seg>(),
+                               (int)seg_cap, next, (int)job_cap, brute);
         }
         // brute list may have grown in decide; its length is only known on the device
         hipLaunchKernelGGL(k_seg_brute, dim3((unsigned)n_jobs), dim3(256), 0, stream, (const Job *)cur,
-                           (const int *)brute, counters, regions_dev, z_dev, thr, min_search, ts.seg.as<Seg>(),
-                           (int)seg_cap, next, (int)job_cap);
+                           (const int *)brute, counters, regions_dev, z_dev, thr, min_search, bits, bit_off,
+                           ts.seg.as<Seg>(), (int)seg_cap, next, (int)job_cap);
         WC_HIP(hipMemcpyAsync(h, counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
         WC_HIP(hipStreamSynchronize(stream));
         WC_CHECK(h[1] <= job_cap, WC_E_INTERNAL, "stouffer: job list overflow");
@@ -1214,9 +1329,10 @@ int wc_repeat_test(wc_ctx *ctx, const wc_reference *ref, const double *data, int
     return WC_OK;
 }
 
-int wc_stouffer_segments(wc_ctx *ctx, const double *z, const int64_t *region_offsets, int64_t n_regions,
-                         double threshold, int min_search, int max_calls, double *region_z, int32_t *n_calls,
-                         double *call_value, int32_t *call_x, int32_t *call_y) {
+int wc_stouffer_segments(wc_ctx *ctx, const double *z, const double *ratio, double min_effect,
+                         const int64_t *region_offsets, int64_t n_regions, double threshold, int min_search,
+                         int max_calls, double *region_z, int32_t *n_calls, double *call_value, int32_t *call_x,
+                         int32_t *call_y) {
     WC_CHECK(ctx && z && region_offsets && n_regions >= 0 && max_calls > 0, WC_E_ARG, "segments: bad argument");
     if (n_regions == 0) return WC_OK;
     WC_CHECK(n_regions <= 60000, WC_E_LIMIT, "segments: more than 60000 regions per call");
@@ -1238,8 +1354,15 @@ int wc_stouffer_segments(wc_ctx *ctx, const double *z, const int64_t *region_off
     if ((rc = ts.regions.reserve(sizeof(Region) * n_regions))) return rc;
     WC_HIP(hipMemcpy(ts.zc.p, z, sizeof(double) * total, hipMemcpyHostToDevice));
     WC_HIP(hipMemcpy(ts.regions.p, regs.data(), sizeof(Region) * n_regions, hipMemcpyHostToDevice));
+    int64_t bits_upper = 0;
+    if (min_effect != 0.0) {
+        WC_CHECK(ratio, WC_E_ARG, "segments: mineffectsize needs the ratio vector");
+        if ((rc = ts.rc.reserve(sizeof(double) * std::max<int64_t>(total, 1)))) return rc;
+        WC_HIP(hipMemcpy(ts.rc.p, ratio, sizeof(double) * total, hipMemcpyHostToDevice));
+        for (int64_t r = 0; r < n_regions; ++r) bits_upper += (int64_t)regs[r].n * (regs[r].n + 1) / 2;
+    }
     if ((rc = run_stouffer(ctx, ts.zc.as<double>(), ts.regions.as<Region>(), n_regions, total, max_n, threshold,
-                           min_search, max_calls, nullptr)))
+                           min_search, max_calls, nullptr, ts.rc.as<double>(), min_effect, bits_upper)))
         return rc;
     WC_HIP(hipDeviceSynchronize());
     if (region_z) WC_HIP(hipMemcpy(region_z, ts.whole.p, sizeof(double) * n_regions, hipMemcpyDeviceToHost));
@@ -1258,9 +1381,9 @@ int wc_stouffer_segments(wc_ctx *ctx, const double *z, const int64_t *region_off
 }
 
 int wc_test_batch_dev(wc_ctx *ctx, void *stream_, const wc_reference *ref, const int32_t *counts, int64_t n_samples,
-                      double threshold, int min_ref_bins, int repeats, const int32_t *chromosomes_host, int n_sel,
-                      int max_calls, double *results_z, double *results_r, double *results_cwz, double *calls,
-                      int32_t *n_calls, double *asdef) {
+                      double threshold, int min_ref_bins, int repeats, double min_effect,
+                      const int32_t *chromosomes_host, int n_sel, int max_calls, double *results_z,
+                      double *results_r, double *results_cwz, double *calls, int32_t *n_calls, double *asdef) {
     WC_CHECK(ctx && ref && counts && n_samples > 0, WC_E_ARG, "test: bad argument");
     WC_CHECK(n_samples <= 60000, WC_E_LIMIT, "test: more than 60000 samples per call; split the batch");
     WC_CHECK(n_sel >= 0 && n_sel <= WC_MAX_CHROM && max_calls > 0, WC_E_ARG, "test: bad chromosome selection");
@@ -1313,8 +1436,14 @@ int wc_test_batch_dev(wc_ctx *ctx, void *stream_, const wc_reference *ref, const
                        (const int64_t *)ref->goff_dev.as<int64_t>(), (const int *)ref->m2g.as<int>(),
                        (const int *)ts.sel.as<int>(), n_sel, (double)min_ref_bins, ts.zc.as<double>(),
                        ts.rc.as<double>(), ts.gpos.as<int>(), ts.regions.as<Region>());
+    int64_t bits_upper = 0;
+    if (min_effect != 0.0)
+        for (int s = 0; s < n_sel; ++s) {
+            int64_t n = ref->moff[sel[s] + 1] - ref->moff[sel[s]];
+            bits_upper += Ns * (n * (n + 1) / 2);
+        }
     if ((rc = run_stouffer(ctx, ts.zc.as<double>(), ts.regions.as<Region>(), n_regions, Ns * B, max_n, threshold, 3,
-                           max_calls, stream)))
+                           max_calls, stream, ts.rc.as<double>(), min_effect, bits_upper)))
         return rc;
     if (results_cwz)
         WC_HIP(hipMemcpyAsync(results_cwz, ts.whole.p, sizeof(double) * n_regions, hipMemcpyDeviceToDevice, stream));
@@ -1338,9 +1467,9 @@ int wc_test_batch_dev(wc_ctx *ctx, void *stream_, const wc_reference *ref, const
 }
 
 int wc_test_batch(wc_ctx *ctx, const wc_reference *ref, const int32_t *counts, int64_t n_samples, double threshold,
-                  int min_ref_bins, int repeats, const int32_t *chromosomes, int n_sel, int max_calls,
-                  double *results_z, double *results_r, double *results_cwz, double *calls, int32_t *n_calls,
-                  double *asdef) {
+                  int min_ref_bins, int repeats, double min_effect, const int32_t *chromosomes, int n_sel,
+                  int max_calls, double *results_z, double *results_r, double *results_cwz, double *calls,
+                  int32_t *n_calls, double *asdef) {
     WC_CHECK(ctx && ref && counts && n_samples > 0, WC_E_ARG, "test: bad argument");
     WC_HIP(hipSetDevice(ctx->device));
     TestState &ts = ctx->ts;
@@ -1354,8 +1483,8 @@ int wc_test_batch(wc_ctx *ctx, const wc_reference *ref, const int32_t *counts, i
     if ((rc = ts.n_calls.reserve(sizeof(int) * Ns))) return rc;
     if ((rc = ts.n.reserve(sizeof(double) * Ns))) return rc;
     WC_HIP(hipMemcpy(ts.counts.p, counts, sizeof(int) * Ns * ref->Btot, hipMemcpyHostToDevice));
-    rc = wc_test_batch_dev(ctx, nullptr, ref, ts.counts.as<int>(), Ns, threshold, min_ref_bins, repeats, chromosomes,
-                           n_sel, max_calls, ts.res_z.as<double>(), ts.res_r.as<double>(), ts.cwz.as<double>(),
+    rc = wc_test_batch_dev(ctx, nullptr, ref, ts.counts.as<int>(), Ns, threshold, min_ref_bins, repeats, min_effect,
+                           chromosomes, n_sel, max_calls, ts.res_z.as<double>(), ts.res_r.as<double>(), ts.cwz.as<double>(),
                            ts.calls.as<double>(), ts.n_calls.as<int>(), ts.n.as<double>());
     if (rc) return rc;
     WC_HIP(hipDeviceSynchronize());

@@ -192,7 +192,7 @@ class TestBatch(object):
     """Device-resident batched `test` of this rank's sample shard (no collective)."""
 
     def __init__(self, reference, counts, threshold, minrefbins=25, repeats=5, chromosomes=None,
-                 max_calls=64):
+                 max_calls=64, mineffectsize=0.0):
         import torch
         self.torch = torch
         self.lib = _lib.load()
@@ -201,6 +201,7 @@ class TestBatch(object):
         self.ns = int(counts.shape[0])
         self.thr = float(threshold)
         self.minrefbins, self.repeats, self.max_calls = int(minrefbins), int(repeats), int(max_calls)
+        self.mineffectsize = float(mineffectsize)
         self.sel = np.ascontiguousarray(chromosomes if chromosomes is not None else range(1, 23), dtype=np.int32)
         dev = counts.device
         f64 = torch.float64
@@ -215,7 +216,8 @@ class TestBatch(object):
         stream = self.torch.cuda.current_stream().cuda_stream
         _lib.check(self.lib.wc_test_batch_dev(
             self.ref.ctx, stream, self.ref.handle, self.counts.data_ptr(), self.ns, self.thr, self.minrefbins,
-            self.repeats, _lib.ptr(self.sel), len(self.sel), self.max_calls, self.results_z.data_ptr(),
+            self.repeats, self.mineffectsize, _lib.ptr(self.sel), len(self.sel), self.max_calls,
+            self.results_z.data_ptr(),
             self.results_r.data_ptr(), self.cwz.data_ptr(), self.calls.data_ptr(), self.n_calls.data_ptr(),
             self.asdef.data_ptr()))
 

@@ -224,16 +224,13 @@ def toolTest(args):
     sampleBinSize = sampleFile['arguments'].item()['binsize']
     sample = wt.scaleSample(sample, sampleBinSize, binsize)
 
-    if args.mineffectsize != 0:
-        print('ERROR: -mineffectsize other than 0 is not supported by the GPU build yet')
-        sys.exit(1)
-
     z_threshold = zThreshold(masked_sizes, args.multitest, args.minzscore)
     print('Per bin z-score threshold for first testing cycles:', z_threshold)
 
     start = time.time()
     out = wt.test_batch(reference, [sample], z_threshold, minrefbins=args.minrefbins,
-                        repeats=args.repeats, chromosomes=list(args.chromosomes))[0]
+                        repeats=args.repeats, chromosomes=list(args.chromosomes),
+                        mineffectsize=args.mineffectsize)[0]
     stdDevAvg = out['asdef']
     print('ASDES:', stdDevAvg, '\nAASDEF:', stdDevAvg * z_threshold)
     print('Time spent on z-scores and stouffers z-scores:', int(time.time() - start), 'seconds')

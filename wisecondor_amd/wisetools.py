@@ -234,10 +234,12 @@ def repeatTest(testData, indexes, distances, chromosomeBins, chromosomeBinSums, 
     return z, r, n, sd
 
 
-def stouffer_segments(regions, threshold, min_search=3, device=0):
-    """fillTri + segmentTri for a list of 1-D z arrays (wisetools.py:466-472, triarray.py:59-84).
+def stouffer_segments(regions, threshold, min_search=3, device=0, ratios=None, mineffectsize=0):
+    """fillTri / fillTriMin + segmentTri for a list of 1-D z arrays
+    (wisetools.py:466-487, triarray.py:59-84).
 
-    Returns (whole_region_z [n], [[(value, (x, y)), ...] per region]).
+    With mineffectsize != 0, `ratios` (same shapes as `regions`) drive fillTriMin's
+    median filter.  Returns (whole_region_z [n], [[(value, (x, y)), ...] per region]).
     """
     lib = _lib.load()
     regions = [np.ascontiguousarray(r, dtype=np.float64) for r in regions]
@@ -246,15 +248,24 @@ def stouffer_segments(regions, threshold, min_search=3, device=0):
     z = np.ascontiguousarray(np.concatenate(regions) if regions else np.zeros(0))
     if z.size == 0:
         z = np.zeros(1)
+    rat = None
+    if mineffectsize != 0:
+        if ratios is None or [len(r) for r in ratios] != [len(r) for r in regions]:
+            raise ValueError("mineffectsize needs one ratio array per region")
+        rat = np.ascontiguousarray(np.concatenate([np.asarray(r, dtype=np.float64) for r in ratios])
+                                   if regions else np.zeros(1))
+        if rat.size == 0:
+            rat = np.zeros(1)
     nreg = len(regions)
     whole = np.empty(nreg)
     ncalls = np.zeros(nreg, dtype=np.int32)
     val = np.zeros((nreg, MAX_CALLS))
     cx = np.zeros((nreg, MAX_CALLS), dtype=np.int32)
     cy = np.zeros((nreg, MAX_CALLS), dtype=np.int32)
-    _lib.check(lib.wc_stouffer_segments(_lib.context(device), _lib.ptr(z), _lib.ptr(offs), nreg,
-                                        float(threshold), int(min_search), MAX_CALLS, _lib.ptr(whole),
-                                        _lib.ptr(ncalls), _lib.ptr(val), _lib.ptr(cx), _lib.ptr(cy)))
+    _lib.check(lib.wc_stouffer_segments(_lib.context(device), _lib.ptr(z), _lib.ptr(rat), float(mineffectsize),
+                                        _lib.ptr(offs), nreg, float(threshold), int(min_search), MAX_CALLS,
+                                        _lib.ptr(whole), _lib.ptr(ncalls), _lib.ptr(val), _lib.ptr(cx),
+                                        _lib.ptr(cy)))
     segs = [[(val[r, c], (int(cx[r, c]), int(cy[r, c]))) for c in range(ncalls[r])] for r in range(nreg)]
     return whole, segs
 
@@ -266,11 +277,11 @@ def fillTri(region, device=0):
 
 
 def fillTriMin(regionZ, regionR, threshold, device=0):
-    """fillTri, optionally median-effect filtered (wisetools.py:475-487)."""
+    """fillTri, or its median-effect filtered variant when threshold != 0 (wisetools.py:475-487)."""
+    from .triarray import TriArr
     if threshold == 0:
         return fillTri(regionZ, device=device)
-    raise NotImplementedError("-mineffectsize > 0 (median-filtered triangle, wisetools.py:479-487) "
-                              "is not implemented on the GPU yet")
+    return TriArr.from_region(regionZ, device=device, ratio=regionR, mineffectsize=threshold)
 
 
 def inflateArray(array, mask):
@@ -289,7 +300,7 @@ def inflateArrayMulti(array, mask_list):
     return temp
 
 
-def test_batch(reference, samples, threshold, minrefbins=25, repeats=5, chromosomes=None):
+def test_batch(reference, samples, threshold, minrefbins=25, repeats=5, chromosomes=None, mineffectsize=0):
     """Numeric content of toolTest (wisecondor.py:199-268) for a list of sample dicts.
 
     Returns a list of dicts with results_z / results_r (per-chromosome lists),
@@ -314,7 +325,8 @@ def test_batch(reference, samples, threshold, minrefbins=25, repeats=5, chromoso
         ncalls = np.zeros(ns, dtype=np.int32)
         asdef = np.empty(ns)
         _lib.check(lib.wc_test_batch(reference.ctx, reference.handle, _lib.ptr(counts), ns, float(threshold),
-                                     int(minrefbins), int(repeats), _lib.ptr(sel), len(sel), MAX_CALLS,
+                                     int(minrefbins), int(repeats), float(mineffectsize), _lib.ptr(sel), len(sel),
+                                     MAX_CALLS,
                                      _lib.ptr(rz), _lib.ptr(rr), _lib.ptr(cwz), _lib.ptr(calls),
                                      _lib.ptr(ncalls), _lib.ptr(asdef)))
         offs = np.concatenate([[0], np.cumsum(sizes)])
