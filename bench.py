@@ -164,6 +164,15 @@ def main():
     t_test = float(tmax.item())
     samples_per_s = world * args.test_samples * test_steps / t_test
     n_calls = int(tb.n_calls.sum().item())
+    # BASELINE config 3: one sample per call (latency mode, nothing amortised over a batch)
+    tb1 = distributed.TestBatch(reference, torch.from_numpy(counts_h[:1].copy()).to(dev), thr)
+    tb1.run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        tb1.run()
+    torch.cuda.synchronize()
+    single_ms = 1e3 * (time.perf_counter() - t0) / 10
 
     # ------------------------------------------- extra: newref at 600 x 50 kb ----
     # BASELINE.json config 4 (the at-scale shape), kernel-level synthetic matrix; reported
@@ -265,6 +274,7 @@ def main():
                        "parallelism": "tile-sharded newref + sample-sharded test, %d rank(s)" % world},
             "test": {"metric": "test samples/sec", "value": samples_per_s, "unit": "samples/s",
                      "ms_per_batch": 1e3 * t_test / test_steps, "samples_per_gpu": args.test_samples,
+                     "single_sample_latency_ms": single_ms,
                      "calls_found": n_calls},
             "roofline": {"kernel": "k_gram<1> (symmetric fp32 MFMA distance tiles + candidate filter)",
                          "bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_FP32_MFMA / 1e12,

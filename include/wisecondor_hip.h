@@ -115,6 +115,34 @@ int wc_newref_import_lists_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int
 int wc_newref_finish_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end,
                          int32_t *idx_out, double *dist_out);
 
+/*
+ * newref prep (upstream of the hot path): toNumpyArray's
+ * normalisation + all-zero-bin mask (wisetools.py:240-264) and trainPCA
+ * (wisetools.py:89-101) as a deterministic exact PCA (float64 Gram matrix on the GPU,
+ * its [samples, samples] eigenproblem on the host, everything bins-sized on the GPU).
+ *   counts [n_samples, n_total_bins] int32: per chromosome padded with zeros to
+ *          chromosome_bins[c] (the longest sample, wisetools.py:245-250)
+ *   mask_out [n_total_bins], masked_chrom_bins_out [n_chrom], *n_masked_out = B
+ *   masked_data_out [B, n_samples]; corrected_t_out [n_samples, B] (the reference's
+ *   correctedData is its transpose VIEW, i.e. Fortran-ordered [B, n_samples]);
+ *   pca_components_out [n_comp, B]; pca_mean_out [B].
+ * Call once with the four data outputs NULL to learn B, then again with buffers.
+ * wc_newref_prep solves the small eigenproblem with a host Jacobi; callers that own a
+ * LAPACK use the two-step form: _gram returns the Gram matrix G [n_samples, n_samples]
+ * of the centred data, _finish takes the n_comp leading eigenvectors (rows, unit norm)
+ * and eigenvalues of G in descending order.
+ */
+int wc_newref_prep_gram(wc_ctx *ctx, const int32_t *counts, int64_t n_samples, int64_t n_total_bins,
+                        const int64_t *chromosome_bins, int n_chrom, uint8_t *mask_out,
+                        int64_t *masked_chrom_bins_out, int64_t *n_masked_out, double *gram_out);
+int wc_newref_prep_finish(wc_ctx *ctx, int n_comp, const double *eigvecs, const double *eigvals,
+                          double *masked_data_out, double *corrected_t_out, double *pca_components_out,
+                          double *pca_mean_out);
+int wc_newref_prep(wc_ctx *ctx, const int32_t *counts, int64_t n_samples, int64_t n_total_bins,
+                   const int64_t *chromosome_bins, int n_chrom, int n_comp, uint8_t *mask_out,
+                   int64_t *masked_chrom_bins_out, int64_t *n_masked_out, double *masked_data_out,
+                   double *corrected_t_out, double *pca_components_out, double *pca_mean_out);
+
 /* ---- test: per-reference state -------------------------------------------- */
 typedef struct wc_reference wc_reference;
 

@@ -29,6 +29,11 @@ def test_newref_and_test_cli(tmp_path, golden):
         _write_sample(p, row, lengths, binsize)
         infiles.append(p)
     refpath = str(tmp_path / "reference.npz")
+    # run the prep step first and keep a copy: `newref` must pick the existing prep file up
+    # (resume by file existence, wisecondor.py:43) and delete it at the end
+    import shutil
+    cli.main(["newrefprep"] + infiles + [str(tmp_path / "reference_prep.npz")])
+    shutil.copy(str(tmp_path / "reference_prep.npz"), str(tmp_path / "kept_prep.npz"))
     cli.main(["newref"] + infiles + [refpath, "-parts", "3", "-refsize", "100"])
     assert not os.path.exists(str(tmp_path / "reference_prep.npz"))       # temp files removed like the reference does
     assert not os.path.exists(str(tmp_path / "reference_part_1.npz"))
@@ -42,10 +47,13 @@ def test_newref_and_test_cli(tmp_path, golden):
     assert set(ref["runtime"].item()) == {"version", "datetime", "hostname", "username"}
     assert ref["arguments"].item()["refsize"] == 100
 
-    # the prep seam: rebuild this run's correctedData and check the GPU selection against the oracle
-    samples = [_write_sample(str(tmp_path / "tmp.npz"), row, lengths, binsize) for row in g["ref_samples"]]
-    masked, bins, mask = wo.to_numpy_array(samples)
-    corrected, comps, mean = wo.train_pca(masked)
+    # the prep seam: this run's correctedData -> the GPU selection must equal the oracle's
+    pz = np.load(str(tmp_path / "kept_prep.npz"), allow_pickle=True)
+    assert set(pz.files) == {"arguments", "runtime", "binsize", "chromosomeBins", "maskedData", "mask",
+                             "maskedChromBins", "maskedChromBinSums", "correctedData", "pca_components", "pca_mean"}
+    corrected = pz["correctedData"]
+    assert corrected.flags["F_CONTIGUOUS"]                 # same layout as the reference's prep file
+    assert np.allclose(corrected, g["prep_correctedData"], rtol=1e-10, atol=0)
     mbins = np.asarray(ref["masked_sizes"])
     want_i, want_d = wo.get_reference(corrected, mbins, np.cumsum(mbins), 100, 1, 1, fast=True)
     assert np.array_equal(ref["indexes"], want_i)

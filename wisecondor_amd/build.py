@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwisecondor_hip.so")
-SOURCES = ["ctx.hip", "newref.hip", "testpath.hip"]
+SOURCES = ["ctx.hip", "newref.hip", "testpath.hip", "prep.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
 

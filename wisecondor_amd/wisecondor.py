@@ -80,7 +80,7 @@ def toolNewref(args):
 
 
 def toolNewrefPrep(args):
-    """wisecondor.py:72-108 (host numpy: upstream of the GPU hot path)."""
+    """wisecondor.py:72-108; normalisation, mask and PCA run through wt.prepReference (GPU)."""
     samples = []
     binsizes = set()
     for infile in args.infiles:
@@ -100,12 +100,12 @@ def toolNewrefPrep(args):
     if args.binsize is None:
         binsize = binsizes.pop()
 
-    maskedData, chromosomeBins, mask = wt.toNumpyArray(samples)
+    print('Applying nonzero mask on the data and fitting the PCA on the GPU:', end=' ')
+    maskedData, chromosomeBins, mask, correctedData, comps, mean, maskedChromBins = wt.prepReference(samples)
+    print((len(mask), len(samples)), 'becomes', maskedData.shape)
     del samples
-    offs = np.concatenate([[0], np.cumsum(chromosomeBins)])
-    maskedChromBins = [int(np.sum(mask[offs[i]:offs[i + 1]])) for i in range(len(chromosomeBins))]
     maskedChromBinSums = [int(v) for v in np.cumsum(maskedChromBins)]
-    correctedData, pca = wt.trainPCA(maskedData)
+    pca = wt._PCAResult(comps, mean)
     np.savez_compressed(args.prepfile,
                         arguments=vars(args),
                         runtime=getRuntime(),

@@ -392,3 +392,38 @@ def trainPCA(refData, pcacomp=3):
     with np.errstate(all='ignore'):
         corrected = tData / inversed
     return corrected.T, _PCAResult(comps, mean)
+
+
+def prepReference(samples, pcacomp=3, device=0):
+    """toNumpyArray + trainPCA (wisetools.py:240-264, 89-101) with the bins-sized work on the GPU.
+
+    The Gram matrix of the centred [samples, bins] data comes from the GPU, numpy's
+    LAPACK solves its small [samples, samples] eigenproblem, and the GPU finishes
+    (components, projection, reconstruction, division).  Returns
+    (maskedData [B,S], chromosomeBins, mask, correctedData [B,S] Fortran-ordered like the
+    reference's, pca_components [n,B], pca_mean [B], maskedChromBins).
+    """
+    lib = _lib.load()
+    ctx = _lib.context(device)
+    chromBins = [max(len(s[str(c)]) for s in samples) for c in range(1, 23)]
+    counts = samples_to_counts(samples, chromBins)
+    n_s, n_total = counts.shape
+    sizes = np.ascontiguousarray(chromBins, dtype=np.int64)
+    mask = np.empty(n_total, dtype=np.uint8)
+    mbins = np.empty(len(sizes), dtype=np.int64)
+    n_b = ctypes.c_int64()
+    gram = np.empty((n_s, n_s))
+    _lib.check(lib.wc_newref_prep_gram(ctx, _lib.ptr(counts), n_s, n_total, _lib.ptr(sizes), len(sizes),
+                                       _lib.ptr(mask), _lib.ptr(mbins), ctypes.byref(n_b), _lib.ptr(gram)))
+    vals, vecs = np.linalg.eigh(gram)
+    order = np.argsort(vals)[::-1][:pcacomp]
+    evals = np.ascontiguousarray(vals[order])
+    evecs = np.ascontiguousarray(vecs[:, order].T)
+    B = n_b.value
+    masked = np.empty((B, n_s))
+    corrected_t = np.empty((n_s, B))
+    comps = np.empty((pcacomp, B))
+    mean = np.empty(B)
+    _lib.check(lib.wc_newref_prep_finish(ctx, int(pcacomp), _lib.ptr(evecs), _lib.ptr(evals), _lib.ptr(masked),
+                                         _lib.ptr(corrected_t), _lib.ptr(comps), _lib.ptr(mean)))
+    return masked, chromBins, mask.astype(bool), corrected_t.T, comps, mean, [int(v) for v in mbins]
