@@ -584,13 +584,10 @@ __global__ __launch_bounds__(256, 4) void k_finish(FinishArgs a) {
                     my = fmax(my, ub);
                 }
             }
-            red[tid] = my;
+            for (int o = 32; o > 0; o >>= 1) my = fmax(my, __shfl_xor(my, o));
+            if (lane == 0) red[tid >> 6] = my;
             __syncthreads();
-            for (int o = 128; o > 0; o >>= 1) {
-                if (tid < o) red[tid] = fmax(red[tid], red[tid + o]);
-                __syncthreads();
-            }
-            U = red[0];
+            U = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
             // every candidate that was never listed has a lower bound > thr: need thr >= U
             if (!(U == U) || (!admit_all && !(U <= (double)thr_f))) fallback = true;
         }
