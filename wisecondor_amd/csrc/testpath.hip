@@ -1051,11 +1051,8 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     if ((rc = ts.jobs_a.reserve(sizeof(Job) * job_cap))) return rc;
     if ((rc = ts.jobs_b.reserve(sizeof(Job) * job_cap))) return rc;
     if ((rc = ts.job_cnt.reserve(sizeof(int) * 8))) return rc;
-    if ((rc = ts.partial.reserve(sizeof(Extreme) * job_cap * max_chunks))) return rc;
     if ((rc = ts.job_res.reserve(sizeof(Extreme) * job_cap))) return rc;
     if ((rc = ts.hot.reserve(sizeof(int) * 2 * job_cap))) return rc;
-    if ((rc = ts.cand.reserve(sizeof(int2) * 2 * CAND_CAP * job_cap))) return rc;
-    if ((rc = ts.cand_cnt.reserve(sizeof(int) * 2 * job_cap))) return rc;
     if ((rc = ts.seg.reserve(sizeof(Seg) * seg_cap))) return rc;
     if ((rc = ts.out_val.reserve(sizeof(double) * n_regions * max_calls))) return rc;
     if ((rc = ts.out_x.reserve(sizeof(int) * n_regions * max_calls))) return rc;
@@ -1096,6 +1093,10 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     int guard = 0;
     while (n_jobs > 0) {
         WC_CHECK(++guard < 100000, WC_E_INTERNAL, "stouffer: recursion did not terminate");
+        // per-round scratch is sized by the jobs of this round, not by the worst case
+        if ((rc = ts.partial.reserve(sizeof(Extreme) * n_jobs * max_chunks))) return rc;
+        if ((rc = ts.cand.reserve(sizeof(int2) * 2 * CAND_CAP * n_jobs))) return rc;
+        if ((rc = ts.cand_cnt.reserve(sizeof(int) * 2 * n_jobs))) return rc;
         WC_HIP(hipMemsetAsync(counters + 1, 0, sizeof(int) * 3, stream));
         WC_HIP(hipMemsetAsync(ts.cand_cnt.p, 0, sizeof(int) * 2 * n_jobs, stream));
         dim3 sg((unsigned)max_chunks, (unsigned)n_jobs);

@@ -131,7 +131,11 @@ class NewrefJob(object):
         t = self.torch
         e = self.st.empty
         cap = self.st.cap
-        self.cap_x = int(min(cap, max(64, (2 * cap) // self.world)))
+        # per (source rank, row) capacity of the exchange: a rank holds ~1/world of a row's ~cap/2
+        # candidates; mean + 8 sigma (Poisson) + slack, in steps of 32.  A row that still
+        # overflows is marked by the importer and takes the exact fallback path.
+        mean = cap / 2.0 / self.world
+        self.cap_x = int(min(cap, 32 * int(np.ceil((mean + 8.0 * np.sqrt(mean) + 16.0) / 32.0))))
         self.send_cnt = e((self.world, self.max_rows), t.int32)
         self.recv_cnt = e((self.world, self.max_rows), t.int32)
         self.send_lst = e((self.world, self.max_rows, self.cap_x), t.int64)
