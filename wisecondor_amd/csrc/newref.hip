@@ -373,8 +373,11 @@ __global__ __launch_bounds__(256) void k_select_thr(const float *__restrict__ ke
         int64_t q = ((int64_t)expect * mvalid + nvalid - 1) / nvalid;
         if (q < 1) q = 1;
         if (q > mvalid) q = mvalid;
+        // bitwise search for the q-th smallest key; the threshold is only an admission cut,
+        // so 20 leading bits (sign, exponent, 11 mantissa bits) suffice: the rest is rounded
+        // UP, which can only admit more candidates
         uint32_t res = 0;
-        for (int bit = 31; bit >= 0; --bit) {
+        for (int bit = 31; bit >= 12; --bit) {
             uint32_t trial = res | (1u << bit);
             int c = 0;
 #pragma unroll
@@ -382,6 +385,8 @@ __global__ __launch_bounds__(256) void k_select_thr(const float *__restrict__ ke
             for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
             if (c < q) res = trial;
         }
+        res |= 0xFFFu;
+        if (res > FIN) res = FIN;   // never beyond the largest finite key
         result = wc::f32_from_ordered(res);
     }
     if (lane == 0) thr[row] = result;
