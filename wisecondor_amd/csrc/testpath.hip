@@ -296,31 +296,46 @@ __global__ void k_flag(const double *__restrict__ zT, double thr, int64_t n, int
     }
 }
 
-// stdDevAvg (wisetools.py:428-435): sequential sum over bins of the non-NaN sds
-__global__ void k_sd_avg(const double *__restrict__ sdT, int64_t B, int64_t Ns, double *__restrict__ out) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Ns) return;
+// stdDevAvg (wisetools.py:428-435): the reference adds the non-NaN sds bin by bin in a
+// Python loop, i.e. a strictly sequential sum per sample.  One lane per sample does the
+// adds; all 256 threads of the workgroup stream 128-bin chunks of sds through LDS (the
+// next chunk's loads in flight during the adds), so the chain is add-latency bound, not
+// load-latency bound.  Skipped (NaN) terms add +0.0, exact for a sum of sds >= 0.
+__global__ __launch_bounds__(256) void k_sd_avg(const double *__restrict__ sdT, int64_t B, int64_t Ns,
+                                                double *__restrict__ out) {
+    __shared__ double buf[128][64];
+    const int ss = threadIdx.x & 63, bq = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + ss;
+    const bool live = i < Ns;
+    double pre[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+        int64_t b = bq + 4 * u;
+        pre[u] = (live && b < B) ? sdT[b * Ns + i] : NAN;
+    }
     double s = 0.0;
     long long c = 0;
-    int64_t b = 0;
-    // the sum is serial by definition (a Python loop in the reference); keep 16 loads
-    // in flight.  Skipped (NaN) terms add +0.0, which is exact for a sum of sds >= 0.
-    for (; b + 16 <= B; b += 16) {
-        double v[16];
+    for (int64_t b0 = 0; b0 < B; b0 += 128) {
+        __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = sdT[(b + u) * Ns + i];
+        for (int u = 0; u < 32; ++u) buf[bq + 4 * u][ss] = pre[u];
+        __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            bool ok = v[u] == v[u];
-            s = s + (ok ? v[u] : 0.0);
-            c += ok;
+        for (int u = 0; u < 32; ++u) {
+            int64_t b = b0 + 128 + bq + 4 * u;
+            pre[u] = (live && b < B) ? sdT[b * Ns + i] : NAN;
+        }
+        if (threadIdx.x < 64) {
+            const int lim = (B - b0) < 128 ? (int)(B - b0) : 128;
+            for (int bb = 0; bb < lim; ++bb) {
+                double v = buf[bb][ss];
+                bool ok = v == v;
+                s = s + (ok ? v : 0.0);
+                c += ok;
+            }
         }
     }
-    for (; b < B; ++b) {
-        double v = sdT[b * Ns + i];
-        if (v == v) { s += v; ++c; }
-    }
-    out[i] = s / (double)c;
+    if (threadIdx.x < 64 && live) out[i] = s / (double)c;
 }
 
 // --------------------------------------------------------------- cleaning ----
@@ -1010,7 +1025,7 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
     if ((rc = ctx->ensure_side_stream())) return rc;
     WC_HIP(hipEventRecord(ctx->ev_fork, stream));
     WC_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
-    hipLaunchKernelGGL(k_sd_avg, dim3((unsigned)cdiv(Ns, 64)), dim3(64), 0, ctx->side,
+    hipLaunchKernelGGL(k_sd_avg, dim3((unsigned)cdiv(Ns, 64)), dim3(256), 0, ctx->side,
                        (const double *)ts.sdt.as<double>(), ref->B, Ns, ts.sd_avg.as<double>());
     WC_HIP(hipEventRecord(ctx->ev_join, ctx->side));
     ctx->side_pending = true;
@@ -1107,10 +1122,16 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
                            regions_dev, (const double *)ts.reg_abs.as<double>(), (const int *)ts.reg_flag.as<int>(),
                            (const Extreme *)ts.partial.as<Extreme>(), max_chunks, thr, ts.job_res.as<Extreme>(), hot,
                            brute, counters);
+        // The number of hot jobs lives on the device.  Small rounds (latency mode, child
+        // ranges) launch the follow-up kernels for the upper bound n_jobs and let surplus
+        // workgroups exit, which saves a host round trip; big rounds read the count back.
         int h[8];
-        WC_HIP(hipMemcpyAsync(h, counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
-        WC_HIP(hipStreamSynchronize(stream));
-        const int n_hot = h[2];
+        int n_hot = (int)n_jobs;
+        if (n_jobs > 512) {
+            WC_HIP(hipMemcpyAsync(h, counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
+            WC_HIP(hipStreamSynchronize(stream));
+            n_hot = h[2];
+        }
         if (n_hot > 0) {
             hipLaunchKernelGGL(k_seg_collect, dim3((unsigned)max_chunks, (unsigned)n_hot), dim3(256), 0, stream,
                                (const Job *)cur, (const int *)hot, (const int *)counters, regions_dev,
