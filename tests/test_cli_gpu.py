@@ -110,3 +110,35 @@ def test_newrefpart_cluster_style(tmp_path, golden):
     assert np.array_equal(ref["indexes"], want_i) and np.array_equal(ref["distances"], want_d)
     part1 = np.load(str(tmp_path / "r_part_1.npz"), allow_pickle=True)
     assert set(part1.files) == {"arguments", "runtime", "indexes", "distances"}
+
+
+def test_testbatch_equals_single_tests(tmp_path, golden):
+    """The build-only `testbatch` sub-command writes what `test` writes, sample by sample."""
+    from wisecondor_amd import wisecondor as cli
+    g = golden("cfg1_pipeline.npz")
+    lengths = g["sample_chrom_lengths"]
+    refpath = str(tmp_path / "reference.npz")
+    np.savez_compressed(refpath, arguments={}, runtime={}, binsize=float(g["ref_binsize"]),
+                        indexes=g["ref_indexes"], distances=g["ref_distances"],
+                        chromosome_sizes=g["ref_chromosome_sizes"], mask=g["ref_mask"],
+                        masked_sizes=g["ref_masked_sizes"], pca_components=g["ref_pca_components"],
+                        pca_mean=g["ref_pca_mean"])
+    names = ["mild18", "gain5_gap", "loss2", "normal"]
+    paths = []
+    for n in names:
+        p = str(tmp_path / ("s_%s.npz" % n))
+        _write_sample(p, g["t_%s_sample" % n], lengths, float(g["binsize"]))
+        paths.append(p)
+    cli.main(["testbatch"] + paths + [str(tmp_path / "out"), refpath, "-batch", "3"])
+    for n, p in zip(names, paths):
+        single = str(tmp_path / ("single_%s.npz" % n))
+        with pytest.raises(SystemExit):
+            cli.main(["test", p, single, refpath])
+        a = np.load(single, allow_pickle=True)
+        b = np.load(str(tmp_path / "out" / ("s_%s_test.npz" % n)), allow_pickle=True)
+        assert np.array_equal(a["results_calls"], b["results_calls"])
+        assert np.array_equal(np.concatenate(list(a["results_z"])), np.concatenate(list(b["results_z"])))
+        assert np.array_equal(a["results_cwz"], b["results_cwz"])
+        assert float(a["asdef"]) == float(b["asdef"])
+        want = g["t_%s_results_calls" % n]
+        assert np.array_equal(np.asarray(b["results_calls"]).reshape(-1, 5)[:, :3], want[:, :3])

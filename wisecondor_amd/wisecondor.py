@@ -240,6 +240,47 @@ def toolTest(args):
     sys.exit(0)
 
 
+def toolTestBatch(args):
+    """Build-only addition: `test` for many samples in one GPU batch (same numbers and the
+    same per-sample output files as running `test` once per sample).  Under torchrun the
+    samples are sharded over the ranks (one process per GPU, no collective needed)."""
+    from .distributed import shard_samples
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    device = int(os.environ.get('LOCAL_RANK', '0'))
+    referenceFile = _load(args.reference)
+    reference = wt.Reference.from_npz(referenceFile, device=device)
+    binsize = reference.binsize
+    masked_sizes = [int(v) for v in referenceFile['masked_sizes']]
+    del referenceFile
+    z_threshold = zThreshold(masked_sizes, args.multitest, args.minzscore)
+    print('Per bin z-score threshold for first testing cycles:', z_threshold)
+    lo, hi = shard_samples(len(args.infiles), rank, world)
+    infiles = args.infiles[lo:hi]
+    if not os.path.isdir(args.outdir):
+        os.makedirs(args.outdir, exist_ok=True)
+    start = time.time()
+    for at in range(0, len(infiles), args.batch):
+        names = infiles[at:at + args.batch]
+        samples = []
+        for name in names:
+            sampleFile = _load(name)
+            samples.append(wt.scaleSample(sampleFile['sample'].item(),
+                                          sampleFile['arguments'].item()['binsize'], binsize))
+        outs = wt.test_batch(reference, samples, z_threshold, minrefbins=args.minrefbins, repeats=args.repeats,
+                             chromosomes=list(args.chromosomes), mineffectsize=args.mineffectsize)
+        for name, out in zip(names, outs):
+            base = os.path.basename(name)
+            base = base[:-4] if base.endswith('.npz') else base
+            one = argparse.Namespace(**vars(args))
+            one.infile = name
+            one.outfile = os.path.join(args.outdir, base + '_test.npz')
+            writeTestOutput(one.outfile, one, binsize, out, z_threshold)
+            print(name, '->', one.outfile, 'calls:', len(out['results_calls']))
+    print('Time spent on', len(infiles), 'samples:', int(time.time() - start), 'seconds')
+    reference.close()
+
+
 def _out_of_scope(args):
     print('ERROR: this sub-command is not part of the MI355X build (newref*, test only); '
           'use the upstream wisecondor.py for it')
@@ -325,6 +366,24 @@ def buildParser():
         help='Minimum amount of sensible ref bins per target bin')
     parser_test.add_argument('-repeats', type=int, default=5, help='Repeats when calling')
     parser_test.set_defaults(func=toolTest)
+
+    # build-only addition: the same test for many samples per GPU batch
+    parser_tb = subparsers.add_parser('testbatch', description='Test many samples in GPU batches')
+    parser_tb.add_argument('infiles', type=str, nargs='+', help='Samples to test')
+    parser_tb.add_argument('outdir', type=str, help='Directory for the <sample>_test.npz outputs')
+    parser_tb.add_argument('reference', type=str, help='Reference as previously created')
+    parser_tb.add_argument('-batch', type=int, default=256, help='Samples per GPU batch')
+    parser_tb.add_argument('-minzscore', type=float, default=None, help='Minimum absolute z-score')
+    parser_tb.add_argument('-chromosomes', type=_int_list, default=list(range(1, 23)),
+                           help='Chromosomes to test, comma delimited')
+    parser_tb.add_argument('-mineffectsize', type=float, default=0,
+                           help='Minimum absolute relative change in read depth')
+    parser_tb.add_argument('-multitest', type=float, default=1000,
+                           help='Increase z-score to compensate for multiple sample testing')
+    parser_tb.add_argument('-minrefbins', type=int, default=25,
+                           help='Minimum amount of sensible ref bins per target bin')
+    parser_tb.add_argument('-repeats', type=int, default=5, help='Repeats when calling')
+    parser_tb.set_defaults(func=toolTestBatch)
     return parser
 
 
