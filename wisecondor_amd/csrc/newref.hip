@@ -37,6 +37,7 @@ constexpr double SENTINEL_DISTANCE = 1e10;  // wisetools.py:306
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------ prepare ----
 // Robust per-sample centre from a strided subset of rows: mean -> 8 x mean absolute
@@ -410,6 +411,26 @@ __device__ inline void bitonic_u64(unsigned long long *v, int n, int tid, int nt
         }
 }
 
+// n <= 128 pairs: one wave does every round (64 compare-exchanges), ordering its own LDS
+// traffic with a workgroup fence instead of workgroup barriers; the caller barriers after.
+__device__ inline void bitonic_pair_wave(unsigned long long *d, int *j, int n, int lane) {
+    for (int k2 = 2; k2 <= n; k2 <<= 1)
+        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+            for (int t = lane; t < n; t += 64) {
+                int p = t ^ j2;
+                if (p > t) {
+                    bool asc = (t & k2) == 0;
+                    unsigned long long a = d[t], b = d[p];
+                    int ja = j[t], jb = j[p];
+                    bool gt = (a > b) || (a == b && ja > jb);
+                    if (gt == asc) { d[t] = b; d[p] = a; j[t] = jb; j[p] = ja; }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+}
+
 __device__ inline void bitonic_pair(unsigned long long *d, int *j, int n, int tid, int nthreads) {
     for (int k2 = 2; k2 <= n; k2 <<= 1)
         for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
@@ -499,58 +520,71 @@ __device__ inline double exact_distance(const double *__restrict__ xj, const dou
 
 constexpr int RMAX = 512;       // most candidates re-scored on the fast path (more -> exact fallback)
 constexpr int ST_CH = 16;       // samples per staged chunk of the sequential re-score
-constexpr int ST_LD = 17;       // LDS row stride of the staged chunk, doubles
+constexpr int ST_LD = 18;       // LDS row stride of the staged chunk, doubles (even: 16-byte reads; 36 dwords: conflict free)
 
-// k-th smallest (0-based rank kk) 32-bit ordered key among ent[0..n): 4 radix passes.
-__device__ inline uint32_t select_key(const unsigned long long *ent, int n, int kk, unsigned int *hist,
-                                      int *s_tmp, int tid) {
-    uint32_t prefix = 0, mask = 0;
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        hist[tid] = 0;
-        __syncthreads();
-        for (int t = tid; t < n; t += 256) {
-            uint32_t key = (uint32_t)(ent[t] >> 32);
-            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        if (tid < 64) {
-            int c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
-            int sum = c0 + c1 + c2 + c3, incl = sum;
-            for (int o = 1; o < 64; o <<= 1) {
-                int v = __shfl_up(incl, o);
-                if (tid >= o) incl += v;
+// k-th smallest (0-based rank kk) 32-bit ordered key among ent[0..n), n <= LIST_CAP.
+// Wave 0 holds up to 16 keys per lane and runs a bitwise binary search with wave-wide
+// counts (no LDS atomics: the keys of one row share their leading bits, so a histogram
+// would serialise on a few addresses).  The result reaches every thread through s_tmp.
+template <int NT>
+__device__ inline uint32_t select_key(const unsigned long long *ent, int n, int kk, int *s_tmp, int tid) {
+    if (tid < 64) {
+        // the k-th key only gates a SUPERSET of the k smallest entries, so its 20 leading bits
+        // (rounded up) are enough; most rows list <= 512 entries = 8 keys per lane
+        uint32_t res = 0;
+        if (n <= 512) {
+            uint32_t key[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                int t = e * 64 + tid;
+                key[e] = t < n ? (uint32_t)(ent[t] >> 32) : 0xFFFFFFFFu;
             }
-            int excl = incl - sum;
-            if (excl <= kk && kk < incl) {
-                int r = kk - excl, d;
-                if (r < c0) d = 0;
-                else if (r < c0 + c1) { d = 1; r -= c0; }
-                else if (r < c0 + c1 + c2) { d = 2; r -= c0 + c1; }
-                else { d = 3; r -= c0 + c1 + c2; }
-                s_tmp[0] = 4 * tid + d;
-                s_tmp[1] = r;
+            for (int bit = 31; bit >= 12; --bit) {
+                const uint32_t trial = res | (1u << bit);
+                int c = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) c += __popcll(__ballot(key[e] < trial));
+                if (c <= kk) res = trial;
+            }
+        } else {
+            uint32_t key[LIST_CAP / 64];
+#pragma unroll
+            for (int e = 0; e < LIST_CAP / 64; ++e) {
+                int t = e * 64 + tid;
+                key[e] = t < n ? (uint32_t)(ent[t] >> 32) : 0xFFFFFFFFu;
+            }
+            for (int bit = 31; bit >= 12; --bit) {
+                const uint32_t trial = res | (1u << bit);
+                int c = 0;
+#pragma unroll
+                for (int e = 0; e < LIST_CAP / 64; ++e) c += __popcll(__ballot(key[e] < trial));
+                if (c <= kk) res = trial;     // fewer than kk+1 keys below trial: the answer is >= trial
             }
         }
-        __syncthreads();
-        prefix |= (uint32_t)s_tmp[0] << shift;
-        kk = s_tmp[1];
-        mask |= 0xFFu << shift;
-        __syncthreads();
+        res |= 0xFFFu;
+        if (tid == 0) s_tmp[0] = (int)res;
     }
-    return prefix;
+    __syncthreads();
+    const uint32_t out = (uint32_t)s_tmp[0];
+    __syncthreads();
+    return out;
 }
 
 // One workgroup per target row: pick the candidates that can still be among the k
 // nearest, re-score them exactly, order them, write the reference's output row.
-template <bool SEQ>
-__global__ __launch_bounds__(256, 4) void k_finish(FinishArgs a) {
+// NT threads per row: 256 (candidate batches of 128) or 128 (batches of 64, half the LDS,
+// twice the rows in flight per CU -- better when the per-row latency dominates, S small).
+template <bool SEQ, int NT>
+__global__ __launch_bounds__(NT, (NT == 256 ? 4 : 8) * NT / 256) void k_finish(FinishArgs a) {
+    constexpr int CB = NT / 2;        // candidates re-scored per batch (one lane each)
+    constexpr int RP = NT / 16;       // candidate rows staged per pass
+    constexpr int NP = CB / RP;       // passes per chunk
     extern __shared__ double xs_dyn[];                     // the target row (S doubles) when it fits
-    __shared__ __attribute__((aligned(16))) unsigned long long ent[LIST_CAP > 128 * ST_LD ? LIST_CAP : 128 * ST_LD];
+    __shared__ __attribute__((aligned(16))) unsigned long long ent[LIST_CAP > CB * ST_LD ? LIST_CAP : CB * ST_LD];
     __shared__ unsigned long long dk[RMAX];
     __shared__ int jv[RMAX];
     __shared__ int cj[RMAX];
-    __shared__ unsigned int hist[256];
-    __shared__ double red[256];
+    __shared__ double red[4];
     __shared__ int s_tmp[4];
     double *stage = reinterpret_cast<double *>(ent);       // aliases ent once the candidates are compacted
     const int tid = threadIdx.x, lane = tid & 63;
@@ -561,10 +595,10 @@ __global__ __launch_bounds__(256, 4) void k_finish(FinishArgs a) {
     const bool admit_all = (thr_f == WC_ADMIT_ALL);
     bool fallback = c > a.cap;
     const int n = fallback ? 0 : c;
-    for (int t = tid; t < n; t += 256) ent[t] = a.list[row * a.cap + t];
+    for (int t = tid; t < n; t += NT) ent[t] = a.list[row * a.cap + t];
     const double *xi = a.X + row * a.S;
     if (a.xs_in_lds) {
-        for (int64_t s = tid; s < a.S; s += 256) xs_dyn[s] = xi[s];
+        for (int64_t s = tid; s < a.S; s += NT) xs_dyn[s] = xi[s];
         xi = xs_dyn;
     }
     if (tid == 0) s_tmp[2] = 0;
@@ -578,10 +612,10 @@ __global__ __launch_bounds__(256, 4) void k_finish(FinishArgs a) {
         } else {
             // upper bound of the k-th true distance: the largest upper bound among the
             // entries whose lower bound is within the k smallest
-            const uint32_t kth = select_key(ent, n, a.k - 1, hist, s_tmp, tid);
+            const uint32_t kth = select_key<NT>(ent, n, a.k - 1, s_tmp, tid);
             const double nhi = (double)a.norm_hi[row];
             double my = -INFINITY;
-            for (int t = tid; t < n; t += 256) {
+            for (int t = tid; t < n; t += NT) {
                 uint32_t ku = (uint32_t)(ent[t] >> 32);
                 if (ku <= kth) {
                     int j = (int)(uint32_t)ent[t];
@@ -592,13 +626,14 @@ __global__ __launch_bounds__(256, 4) void k_finish(FinishArgs a) {
             for (int o = 32; o > 0; o >>= 1) my = fmax(my, __shfl_xor(my, o));
             if (lane == 0) red[tid >> 6] = my;
             __syncthreads();
-            U = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+            U = red[0];
+            for (int q = 1; q < NT / 64; ++q) U = fmax(U, red[q]);
             // every candidate that was never listed has a lower bound > thr: need thr >= U
             if (!(U == U) || (!admit_all && !(U <= (double)thr_f))) fallback = true;
         }
         if (!fallback) {
             // compact the survivors (order is irrelevant: they are sorted exactly below)
-            for (int t0 = 0; t0 < n; t0 += 256) {
+            for (int t0 = 0; t0 < n; t0 += NT) {
                 int t = t0 + tid;
                 bool keep = false;
                 int j = 0;
@@ -637,15 +672,16 @@ __global__ __launch_bounds__(256, 4) void k_finish(FinishArgs a) {
         //                     leaf sums folded with a small value stack.
         constexpr bool seq = SEQ;  // sequential order, or fewer than 8 samples (numpy sums those left to right too)
         const int l16 = tid & 15, r0 = tid >> 4;
-        for (int b0 = 0; b0 < R; b0 += 128) {
-            const int nb = (R - b0) < 128 ? (R - b0) : 128;
-            const double *src[8];
-            double pre[8];
+        for (int b0 = 0; b0 < R; b0 += CB) {
+            const int nb = (R - b0) < CB ? (R - b0) : CB;
+            // element offsets fit 32 bits whenever the matrix is below 32 GB (checked by the host)
+            unsigned int src[NP];
+            double pre[NP];
 #pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                int rr = r0 + 16 * p;
-                src[p] = a.X + (int64_t)cj[b0 + (rr < nb ? rr : 0)] * a.S;
-                pre[p] = (rr < nb && l16 < a.S) ? src[p][l16] : 0.0;
+            for (int p = 0; p < NP; ++p) {
+                int rr = r0 + RP * p;
+                src[p] = (unsigned int)cj[b0 + (rr < nb ? rr : 0)] * (unsigned int)a.S + (unsigned int)l16;
+                pre[p] = (rr < nb && l16 < a.S) ? a.X[src[p]] : 0.0;
             }
             double acc = 0.0;                     // sequential sum / tail sum of the last leaf
             double r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -656,22 +692,52 @@ __global__ __launch_bounds__(256, 4) void k_finish(FinishArgs a) {
             for (int64_t c0 = 0; c0 < a.S; c0 += ST_CH) {
                 __syncthreads();
 #pragma unroll
-                for (int p = 0; p < 8; ++p) stage[(r0 + 16 * p) * ST_LD + l16] = pre[p];
+                for (int p = 0; p < NP; ++p) stage[(r0 + RP * p) * ST_LD + l16] = pre[p];
                 __syncthreads();
                 const int64_t sn = c0 + ST_CH + l16;
+                const unsigned int so = (unsigned int)(c0 + ST_CH);
 #pragma unroll
-                for (int p = 0; p < 8; ++p) pre[p] = (r0 + 16 * p < nb && sn < a.S) ? src[p][sn] : 0.0;
-                if (tid < 128) {
+                for (int p = 0; p < NP; ++p) pre[p] = (r0 + RP * p < nb && sn < a.S) ? a.X[src[p] + so] : 0.0;
+                if (SEQ && tid < CB && c0 + ST_CH <= a.S && a.xs_in_lds) {
+                    // full chunk, left-to-right sum: 16-byte LDS reads, no per-element control flow
+                    const double *sp_ = &stage[tid * ST_LD];
+                    const double *xp_ = &xi[c0];
+#pragma unroll
+                    for (int e = 0; e < ST_CH; e += 2) {
+                        const f64x2 v = *(const f64x2 *)(sp_ + e);
+                        const f64x2 x2 = *(const f64x2 *)(xp_ + e);
+                        double d0 = v.x - x2.x;
+                        double s0 = d0 * d0;
+                        acc = acc + s0;
+                        double d1 = v.y - x2.y;
+                        double s1 = d1 * d1;
+                        acc = acc + s1;
+                    }
+                } else if (tid < CB) {
+                    const bool full = c0 + ST_CH <= a.S && a.xs_in_lds;
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
                         const int64_t base = c0 + 8 * g;
                         if (base >= a.S) break;
                         const int cntg = (a.S - base) < 8 ? (int)(a.S - base) : 8;
                         double sq[8];
+                        if (full) {   // 16-byte LDS reads, no per-element guards
+                            const double *sp_ = &stage[tid * ST_LD + 8 * g];
+                            const double *xp_ = &xi[base];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            double df = (e < cntg) ? stage[tid * ST_LD + 8 * g + e] - xi[base + e] : 0.0;
-                            sq[e] = df * df;
+                            for (int e = 0; e < 8; e += 2) {
+                                const f64x2 v = *(const f64x2 *)(sp_ + e);
+                                const f64x2 x2 = *(const f64x2 *)(xp_ + e);
+                                double d0 = v.x - x2.x, d1 = v.y - x2.y;
+                                sq[e] = d0 * d0;
+                                sq[e + 1] = d1 * d1;
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                double df = (e < cntg) ? stage[tid * ST_LD + 8 * g + e] - xi[base + e] : 0.0;
+                                sq[e] = df * df;
+                            }
                         }
                         if (seq || in_tail || cntg < 8) {
                             for (int e = 0; e < cntg; ++e) acc = acc + sq[e];
@@ -719,14 +785,19 @@ __global__ __launch_bounds__(256, 4) void k_finish(FinishArgs a) {
     int q2 = 2;
     while (q2 < R) q2 <<= 1;
     __syncthreads();
-    for (int t = R + tid; t < q2; t += 256) { dk[t] = ~0ull; jv[t] = 0x7FFFFFFF; }
+    for (int t = R + tid; t < q2; t += NT) { dk[t] = ~0ull; jv[t] = 0x7FFFFFFF; }
     __syncthreads();
-    bitonic_pair(dk, jv, q2, tid, 256);
+    if (q2 <= 128) {
+        if (tid < 64) bitonic_pair_wave(dk, jv, q2, tid);
+        __syncthreads();
+    } else {
+        bitonic_pair(dk, jv, q2, tid, NT);
+    }
 
     const int ch = a.chrom_of_row[row];
     const int64_t cs = a.chrom_off[ch], ce = a.chrom_off[ch + 1];
     const int64_t orow = row - a.row_begin;
-    for (int t = tid; t < a.k; t += 256) {
+    for (int t = tid; t < a.k; t += NT) {
         int32_t oi = -1;
         double od = SENTINEL_DISTANCE;
         if (t < R && dk[t] != ~0ull) {
@@ -921,6 +992,7 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
     WC_CHECK(n_samples <= 8192, WC_E_LIMIT, "newref: more than 8192 samples not supported");
     WC_CHECK(k <= LIST_CAP / 4, WC_E_LIMIT, "newref: refsize above %d not supported", LIST_CAP / 4);
     WC_CHECK(n_bins < (1ll << 31) - 256, WC_E_LIMIT, "newref: too many bins");
+    WC_CHECK(n_bins * n_samples < (1ll << 32), WC_E_LIMIT, "newref: more than 2^32 matrix elements not supported");
     WC_CHECK(sum_order == WC_SUM_PAIRWISE || sum_order == WC_SUM_SEQUENTIAL, WC_E_ARG, "newref: bad sum_order");
     hipStream_t stream = (hipStream_t)stream_;
     WC_HIP(hipSetDevice(ctx->device));
@@ -1207,12 +1279,20 @@ int wc_newref_finish_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t 
     a.xs_in_lds = st.n_samples <= 2048;
     a.pw_prog = st.pw_prog.as<int2>();
     a.pw_leaves = st.pw_leaves;
-    if (st.sum_order == WC_SUM_SEQUENTIAL || st.n_samples < 8)
-        hipLaunchKernelGGL(k_finish<true>, dim3((unsigned)(row_end - row_begin)), dim3(256),
-                           a.xs_in_lds ? sizeof(double) * st.n_samples : 0, stream, a);
-    else
-        hipLaunchKernelGGL(k_finish<false>, dim3((unsigned)(row_end - row_begin)), dim3(256),
-                           a.xs_in_lds ? sizeof(double) * st.n_samples : 0, stream, a);
+    {
+        const bool seq = st.sum_order == WC_SUM_SEQUENTIAL || st.n_samples < 8;
+        const char *e = getenv("WC_FINISH_THREADS");
+        const int nt = e ? atoi(e) : 128;   // 128 threads per row measured faster at every size tried
+        const dim3 grid((unsigned)(row_end - row_begin));
+        const size_t dyn = a.xs_in_lds ? sizeof(double) * st.n_samples : 0;
+        if (nt == 128) {
+            if (seq) hipLaunchKernelGGL((k_finish<true, 128>), grid, dim3(128), dyn, stream, a);
+            else hipLaunchKernelGGL((k_finish<false, 128>), grid, dim3(128), dyn, stream, a);
+        } else {
+            if (seq) hipLaunchKernelGGL((k_finish<true, 256>), grid, dim3(256), dyn, stream, a);
+            else hipLaunchKernelGGL((k_finish<false, 256>), grid, dim3(256), dyn, stream, a);
+        }
+    }
     hipLaunchKernelGGL(k_fallback, dim3(FB_BLOCKS), dim3(256), 0, stream, a,
                        st.fb_scratch.as<unsigned long long>(), st.bins_pad);
     WC_HIP(hipGetLastError());
