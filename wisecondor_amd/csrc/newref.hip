@@ -355,14 +355,13 @@ __global__ __launch_bounds__(256) void k_select_thr(const float *__restrict__ ke
     const int per_lane = M / 64;
     uint32_t u[NV];
     const uint32_t FIN = wc::f32_ordered(FLT_MAX);
-    int mvalid = 0;
+    int mvalid = 0;   // wave-wide counts through ballots (scalar popcounts, no cross-lane traffic)
 #pragma unroll
     for (int e = 0; e < NV; ++e) {
         u[e] = 0xFFFFFFFFu;
         if (e < per_lane) u[e] = wc::f32_ordered(keys[row * ldo + (int64_t)e * 64 + lane]);
-        mvalid += (u[e] <= FIN);
+        mvalid += __popcll(__ballot(u[e] <= FIN));
     }
-    for (int o = 32; o > 0; o >>= 1) mvalid += __shfl_xor(mvalid, o);
     int ch = chrom_of_row[row];
     int64_t nvalid = B - (chrom_off[ch + 1] - chrom_off[ch]);
     float result;
@@ -382,8 +381,7 @@ __global__ __launch_bounds__(256) void k_select_thr(const float *__restrict__ ke
             uint32_t trial = res | (1u << bit);
             int c = 0;
 #pragma unroll
-            for (int e = 0; e < NV; ++e) c += (u[e] < trial);
-            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+            for (int e = 0; e < NV; ++e) c += __popcll(__ballot(u[e] < trial));
             if (c < q) res = trial;
         }
         res |= 0xFFFu;
@@ -1077,7 +1075,7 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
 
     double *mean2 = st.col_mean.as<double>();
     {
-        int64_t n_rows = std::min<int64_t>(n_bins, 512);
+        int64_t n_rows = std::min<int64_t>(n_bins, 128);
         int64_t row_step = n_bins / n_rows;
         hipLaunchKernelGGL(k_col_centre, dim3((unsigned)((n_samples + 63) / 64)), dim3(1024), 0, stream, corrected,
                            n_bins, n_samples, n_rows, row_step, mean2);
