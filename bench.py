@@ -276,7 +276,7 @@ def main():
                      "ms_per_batch": 1e3 * t_test / test_steps, "samples_per_gpu": args.test_samples,
                      "single_sample_latency_ms": single_ms,
                      "calls_found": n_calls},
-            "roofline": {"kernel": "k_gram<1> (symmetric fp32 MFMA distance tiles + candidate filter)",
+            "roofline": {"kernel": "k_gram (symmetric fp32 MFMA distance tiles + candidate filter)",
                          "bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_FP32_MFMA / 1e12,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA, "traffic": traffic,
                          "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_traffic.json)",

@@ -9,6 +9,7 @@ struct NewrefState {
     int64_t n_bins = 0, n_samples = 0;
     int64_t bins_pad = 0;   // rows padded to the 128-row tile
     int64_t k_pad = 0;      // samples padded to the 32-wide k-slab
+    int64_t k_pad16 = 0;    // samples padded to the 64-wide bf16 k-slab
     int n_chrom = 0, k = 0, sum_order = 0;
     int64_t chrom_off[WC_MAX_CHROM + 1] = {0};
     const double *corrected = nullptr;  // device, caller owned
@@ -20,7 +21,7 @@ struct NewrefState {
     bool prepared = false;
     // device buffers
     wc::DevBuf col_partial, col_mean, a32, norm_lo, norm_hi, chrom_of_row, chrom_off_dev;
-    wc::DevBuf sample_rows, s32, s_norm_lo, s_chrom;
+    wc::DevBuf sample_rows, s32, s_norm_lo, s_chrom, a16, s16;
     wc::DevBuf keys1, thr, cnt, list, tiles;
     wc::DevBuf fb_rows, fb_count, fb_scratch, stats, tiles0, pw_prog;
     int pw_leaves = 0;
@@ -66,7 +67,7 @@ struct wc_ctx {
         return {&nr.col_partial, &nr.col_mean, &nr.a32, &nr.norm_lo, &nr.norm_hi, &nr.chrom_of_row,
                 &nr.chrom_off_dev, &nr.sample_rows, &nr.s32, &nr.s_norm_lo, &nr.s_chrom, &nr.keys1,
                 &nr.thr, &nr.cnt, &nr.list, &nr.tiles, &nr.fb_rows, &nr.fb_count, &nr.fb_scratch,
-                &nr.stats, &nr.tiles0, &nr.pw_prog, &tmp_a, &tmp_b, &tmp_c, &tmp_d,
+                &nr.stats, &nr.tiles0, &nr.pw_prog, &nr.a16, &nr.s16, &tmp_a, &tmp_b, &tmp_c, &tmp_d,
                 &ts.counts, &ts.totals, &ts.raw, &ts.proj, &ts.data, &ts.xt, &ts.xc, &ts.zt, &ts.rt, &ts.nt,
                 &ts.sdt, &ts.z, &ts.r, &ts.n, &ts.sd_avg, &ts.zc, &ts.rc, &ts.gpos, &ts.clean_n, &ts.regions,
                 &ts.sel, &ts.res_z, &ts.res_r, &ts.cwz, &ts.calls, &ts.n_calls, &ts.prefix, &ts.reg_abs,

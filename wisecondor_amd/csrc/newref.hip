@@ -81,21 +81,32 @@ __global__ __launch_bounds__(1024) void k_col_centre(const double *__restrict__ 
     }
 }
 
-// One wave per row: centred float32 image, norm interval, chromosome id.
+// round-to-nearest-even float -> bfloat16 bits (NaN stays NaN, overflow becomes inf)
+__device__ inline unsigned short f32_to_bf16(float f) {
+    unsigned int b = __float_as_uint(f);
+    if ((b & 0x7FFFFFFFu) > 0x7F800000u) return (unsigned short)((b >> 16) | 0x40u);
+    b += 0x7FFFu + ((b >> 16) & 1u);
+    return (unsigned short)(b >> 16);
+}
+
+// One wave per row: centred float32 image (+ a bfloat16 image used only for the
+// admission-threshold estimate), norm interval, chromosome id.
 __global__ __launch_bounds__(256) void k_convert(const double *__restrict__ X, int64_t B, int64_t S,
                                                  int64_t Bpad, int64_t Kpad,
                                                  const double *__restrict__ mean, double beta,
                                                  const int64_t *__restrict__ chrom_off, int n_chrom,
-                                                 float *__restrict__ A, float *__restrict__ norm_lo,
+                                                 float *__restrict__ A, unsigned short *__restrict__ A16,
+                                                 int64_t Kpad16, float *__restrict__ norm_lo,
                                                  float *__restrict__ norm_hi, int *__restrict__ chrom_of_row) {
     int lane = threadIdx.x & 63;
     int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= Bpad) return;
     double acc = 0.0;
-    for (int64_t s = lane; s < Kpad; s += 64) {
+    for (int64_t s = lane; s < Kpad16; s += 64) {
         float a = 0.f;
         if (row < B && s < S) a = (float)(X[row * S + s] - mean[s]);
-        A[row * Kpad + s] = a;
+        if (s < Kpad) A[row * Kpad + s] = a;
+        A16[row * Kpad16 + s] = f32_to_bf16(a);
         acc += (double)a * (double)a;
     }
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
@@ -118,14 +129,16 @@ __global__ __launch_bounds__(256) void k_convert(const double *__restrict__ X, i
     }
 }
 
-__global__ void k_gather_samples(const float *__restrict__ A, int64_t Kpad, const float *__restrict__ norm_lo,
-                                 const int *__restrict__ chrom_of_row, const int *__restrict__ sample_rows,
-                                 int64_t M, int64_t Mpad, float *__restrict__ S32, float *__restrict__ s_norm_lo,
+__global__ void k_gather_samples(const unsigned short *__restrict__ A16, int64_t Kpad16,
+                                 const float *__restrict__ norm_lo, const int *__restrict__ chrom_of_row,
+                                 const int *__restrict__ sample_rows, int64_t M, int64_t Mpad,
+                                 unsigned short *__restrict__ S16, float *__restrict__ s_norm_lo,
                                  int *__restrict__ s_chrom) {
     int64_t m = blockIdx.x;
     bool real = m < M;
     int64_t src = real ? sample_rows[m] : 0;
-    for (int64_t s = threadIdx.x; s < Kpad; s += blockDim.x) S32[m * Kpad + s] = real ? A[src * Kpad + s] : 0.f;
+    for (int64_t s = threadIdx.x; s < Kpad16; s += blockDim.x)
+        S16[m * Kpad16 + s] = real ? A16[src * Kpad16 + s] : (unsigned short)0;
     if (threadIdx.x == 0) {
         s_norm_lo[m] = real ? norm_lo[src] : INFINITY;
         s_chrom[m] = real ? chrom_of_row[src] : -2;
@@ -146,9 +159,7 @@ struct GramArgs {
     const int *chP, *chQ;        // chromosome ids
     const int4 *tiles;           // {I, J, roles, 0}
     int ntiles;
-    float *keys;                 // MODE 0: [rowsP, ldo]
-    int64_t ldo;
-    const float *thr;            // MODE 1: per target row
+    const float *thr;            // admission threshold per target row
     int *cnt;
     unsigned long long *list;
     int cap;
@@ -163,7 +174,6 @@ __device__ inline unsigned long long pack_entry(float key, int j) {
 // with the next slab's loads in flight during the MFMA phase.  Within a slab
 // lane (i, h) feeds k = 16h + t at MFMA step t, so each lane fetches its 16
 // operands with four conflict-free ds_read_b128.
-template <int MODE>
 __global__ __launch_bounds__(256, 4) void k_gram(GramArgs g) {
     __shared__ __attribute__((aligned(16))) float sm[2 * TB * LDA + 6 * TB];   // 64 * LDD <= 2 * TB * LDA
     float *As = sm;
@@ -192,13 +202,13 @@ __global__ __launch_bounds__(256, 4) void k_gram(GramArgs g) {
         int64_t gp = (int64_t)I * TB + tid;
         nbPs[tid] = g.nbP[gp];
         chPs[tid] = g.chP[gp];
-        thPs[tid] = (MODE == 1) ? g.thr[gp] : 0.f;
+        thPs[tid] = g.thr[gp];
     } else {
         int c = tid - TB;
         int64_t gq = (int64_t)J * TB + c;
         nbQs[c] = g.nbQ[gq];
         chQs[c] = g.chQ[gq];
-        thQs[c] = (MODE == 1) ? g.thr[gq] : 0.f;
+        thQs[c] = g.thr[gq];
     }
 
     const int lrow = tid >> 3, lcol = (tid & 7) * 4;
@@ -274,19 +284,6 @@ __global__ __launch_bounds__(256, 4) void k_gram(GramArgs g) {
         __syncthreads();
 
         const int x = tid & 127, q = tid >> 7;      // column x, 32-row half q of this 64-row slab
-        if (MODE == 0) {
-            // dense lower-bound keys, same-chromosome pairs masked to +inf
-            const float nbc = nbQs[x];
-            const int chc = chQs[x];
-            float *out = g.keys + ((int64_t)I * TB + h * 64 + q * 32) * g.ldo + (int64_t)J * TB + x;
-            for (int rr = 0; rr < 32; ++rr) {
-                int lr = q * 32 + rr, r = h * 64 + lr;
-                float key = fmaf(-2.f, D[lr * LDD + x], nbPs[r] + nbc);
-                if (chPs[r] == chc) key = INFINITY;
-                out[(int64_t)rr * g.ldo] = key;
-            }
-            continue;
-        }
         if (roles & ROLE_COLS) {  // target = column x, candidates = 32 rows of this slab
             const float nbc = nbQs[x], th = thQs[x];
             const int chc = chQs[x];
@@ -335,6 +332,121 @@ __global__ __launch_bounds__(256, 4) void k_gram(GramArgs g) {
                     ++base;
                 }
             }
+        }
+    }
+}
+
+
+// ---------------------------------------------- threshold-estimate Gram (bf16) ----
+// The admission thresholds only have to put a few hundred candidates per row on the
+// lists; they decide nothing (every stored index and distance is re-derived exactly).
+// So the distances to the M sampled rows use the bf16 matrix cores: 16x the fp32 MFMA
+// rate, ~0.4 % error on the dot products, i.e. a ~10 % wobble of the candidate count.
+// Same 128x128 tile / 4 waves / LDS byte layout as k_gram; a slab is 64 bf16 (128 B) deep.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256, 4) void k_gram_thr16(const unsigned short *__restrict__ P16,
+                                                       const unsigned short *__restrict__ Q16, int64_t ld16,
+                                                       int nslab, const float *__restrict__ nbP,
+                                                       const float *__restrict__ nbQ, const int *__restrict__ chP,
+                                                       const int *__restrict__ chQ, const int4 *__restrict__ tiles,
+                                                       int ntiles, float *__restrict__ keys, int64_t ldo) {
+    __shared__ __attribute__((aligned(16))) float sm[2 * TB * LDA + 4 * TB];
+    float *As = sm;
+    float *Bs = sm + TB * LDA;
+    float *D = sm;
+    float *nbPs = sm + 2 * TB * LDA;
+    float *nbQs = nbPs + TB;
+    int *chPs = (int *)(nbQs + TB);
+    int *chQs = chPs + TB;
+
+    const int chunk = (ntiles + 7) >> 3;
+    const int t_id = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (t_id >= ntiles) return;
+    const int4 tile = tiles[t_id];
+    const int I = tile.x, J = tile.y;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    if (tid < TB) {
+        nbPs[tid] = nbP[(int64_t)I * TB + tid];
+        chPs[tid] = chP[(int64_t)I * TB + tid];
+    } else {
+        nbQs[tid - TB] = nbQ[(int64_t)J * TB + tid - TB];
+        chQs[tid - TB] = chQ[(int64_t)J * TB + tid - TB];
+    }
+    const int lrow = tid >> 3, lcol = (tid & 7) * 8;   // 8 bf16 = 16 bytes per thread and row
+    const unsigned short *Pg = P16 + ((int64_t)I * TB + lrow) * ld16 + lcol;
+    const unsigned short *Qg = Q16 + ((int64_t)J * TB + lrow) * ld16 + lcol;
+    f32x4 pa[4], qb[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        pa[p] = *(const f32x4 *)(Pg + (int64_t)p * 32 * ld16);
+        qb[p] = *(const f32x4 *)(Qg + (int64_t)p * 32 * ld16);
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int lcolf = (tid & 7) * 4;   // the same 16 bytes, in float units of the LDS row
+    for (int slab = 0; slab < nslab; ++slab) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            *(f32x4 *)&As[(lrow + 32 * p) * LDA + lcolf] = pa[p];
+            *(f32x4 *)&Bs[(lrow + 32 * p) * LDA + lcolf] = qb[p];
+        }
+        __syncthreads();
+        {
+            const int64_t ko = (int64_t)(slab + 1 < nslab ? slab + 1 : slab) * 64;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                pa[p] = *(const f32x4 *)(Pg + ko + (int64_t)p * 32 * ld16);
+                qb[p] = *(const f32x4 *)(Qg + ko + (int64_t)p * 32 * ld16);
+            }
+        }
+        // MFMA step t covers k = 16 t .. 16 t + 15; lane half h supplies 8 consecutive k.
+        // A and B use the same slots, so the pairing of k is right whatever the hardware order.
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int off = t * 8 + lh * 4;   // float units: (16 t + 8 h) bf16 = 32 t + 16 h bytes
+            const bf16x8 a0 = *(const bf16x8 *)&As[(wr * 64 + li) * LDA + off];
+            const bf16x8 a1 = *(const bf16x8 *)&As[(wr * 64 + 32 + li) * LDA + off];
+            const bf16x8 b0 = *(const bf16x8 *)&Bs[(wc * 64 + li) * LDA + off];
+            const bf16x8 b1 = *(const bf16x8 *)&Bs[(wc * 64 + 32 + li) * LDA + off];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+        if (wr == h) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        int col = wc * 64 + n * 32 + li;
+                        D[row * LDD + col] = acc[m][n][r];
+                    }
+        }
+        __syncthreads();
+        const int x = tid & 127, q = tid >> 7;
+        const float nbc = nbQs[x];
+        const int chc = chQs[x];
+        float *out = keys + ((int64_t)I * TB + h * 64 + q * 32) * ldo + (int64_t)J * TB + x;
+        for (int rr = 0; rr < 32; ++rr) {
+            int lr = q * 32 + rr, r = h * 64 + lr;
+            float key = fmaf(-2.f, D[lr * LDD + x], nbPs[r] + nbc);
+            if (chPs[r] == chc) key = INFINITY;
+            out[(int64_t)rr * ldo] = key;
         }
     }
 }
@@ -1011,6 +1123,7 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
              (long long)st.chrom_off[n_chrom], (long long)n_bins);
     st.bins_pad = round_up(n_bins, TB);
     st.k_pad = round_up(n_samples, BK);
+    st.k_pad16 = round_up(n_samples, 64);
     st.cap = LIST_CAP;
     st.expect = LIST_CAP / 2;
     st.beta = (float)((double)(n_samples + 16) * 5.9604644775390625e-08 * 1.001);
@@ -1028,7 +1141,8 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
     if ((rc = st.chrom_of_row.reserve(sizeof(int) * st.bins_pad))) return rc;
     if ((rc = st.chrom_off_dev.reserve(sizeof(int64_t) * (WC_MAX_CHROM + 1)))) return rc;
     if ((rc = st.sample_rows.reserve(sizeof(int) * M))) return rc;
-    if ((rc = st.s32.reserve(sizeof(float) * M * st.k_pad))) return rc;
+    if ((rc = st.a16.reserve(sizeof(unsigned short) * st.bins_pad * st.k_pad16))) return rc;
+    if ((rc = st.s16.reserve(sizeof(unsigned short) * M * st.k_pad16))) return rc;
     if ((rc = st.s_norm_lo.reserve(sizeof(float) * M))) return rc;
     if ((rc = st.s_chrom.reserve(sizeof(int) * M))) return rc;
     if ((rc = st.keys1.reserve(sizeof(float) * st.bins_pad * M))) return rc;
@@ -1083,12 +1197,12 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
 
     hipLaunchKernelGGL(k_convert, dim3((unsigned)(st.bins_pad / 4)), dim3(256), 0, stream, corrected, n_bins,
                        n_samples, st.bins_pad, st.k_pad, (const double *)mean2, (double)st.beta,
-                       st.chrom_off_dev.as<int64_t>(), n_chrom, st.a32.as<float>(), st.norm_lo.as<float>(),
-                       st.norm_hi.as<float>(), st.chrom_of_row.as<int>());
-    hipLaunchKernelGGL(k_gather_samples, dim3((unsigned)M), dim3(256), 0, stream, st.a32.as<float>(), st.k_pad,
-                       st.norm_lo.as<float>(), st.chrom_of_row.as<int>(), st.sample_rows.as<int>(),
-                       std::min<int64_t>(M, n_bins), M, st.s32.as<float>(), st.s_norm_lo.as<float>(),
-                       st.s_chrom.as<int>());
+                       st.chrom_off_dev.as<int64_t>(), n_chrom, st.a32.as<float>(), st.a16.as<unsigned short>(),
+                       st.k_pad16, st.norm_lo.as<float>(), st.norm_hi.as<float>(), st.chrom_of_row.as<int>());
+    hipLaunchKernelGGL(k_gather_samples, dim3((unsigned)M), dim3(256), 0, stream,
+                       (const unsigned short *)st.a16.as<unsigned short>(), st.k_pad16, st.norm_lo.as<float>(),
+                       st.chrom_of_row.as<int>(), st.sample_rows.as<int>(), std::min<int64_t>(M, n_bins), M,
+                       st.s16.as<unsigned short>(), st.s_norm_lo.as<float>(), st.s_chrom.as<int>());
     hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)((st.bins_pad + 255) / 256)), dim3(256), 0, stream,
                        st.thr.as<float>(), st.bins_pad, -INFINITY);
     WC_HIP(hipMemsetAsync(st.cnt.p, 0, sizeof(int) * st.bins_pad, stream));
@@ -1119,21 +1233,16 @@ int wc_newref_thresholds_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int6
         st.tiles0_key = key;
         st.tiles0_n = (int64_t)tiles.size();
     }
-    GramArgs g{};
-    g.P = st.a32.as<float>();
-    g.Q = st.s32.as<float>();
-    g.ld = st.k_pad;
-    g.nslab = (int)(st.k_pad / BK);
-    g.nbP = st.norm_lo.as<float>();
-    g.nbQ = st.s_norm_lo.as<float>();
-    g.chP = st.chrom_of_row.as<int>();
-    g.chQ = st.s_chrom.as<int>();
-    g.tiles = st.tiles0.as<int4>();
-    g.ntiles = (int)st.tiles0_n;
-    g.keys = st.keys1.as<float>();
-    g.ldo = st.n_sample_cols;
-    unsigned grid = (unsigned)(((g.ntiles + 7) / 8) * 8);
-    hipLaunchKernelGGL(k_gram<0>, dim3(grid), dim3(256), 0, stream, g);
+    {
+        const int ntiles = (int)st.tiles0_n;
+        unsigned grid = (unsigned)(((ntiles + 7) / 8) * 8);
+        hipLaunchKernelGGL(k_gram_thr16, dim3(grid), dim3(256), 0, stream,
+                           (const unsigned short *)st.a16.as<unsigned short>(),
+                           (const unsigned short *)st.s16.as<unsigned short>(), st.k_pad16, (int)(st.k_pad16 / 64),
+                           (const float *)st.norm_lo.as<float>(), (const float *)st.s_norm_lo.as<float>(),
+                           (const int *)st.chrom_of_row.as<int>(), (const int *)st.s_chrom.as<int>(),
+                           (const int4 *)st.tiles0.as<int4>(), ntiles, st.keys1.as<float>(), st.n_sample_cols);
+    }
     unsigned sg = (unsigned)((row_end - row_begin + 3) / 4);
     {
         const float *kp = st.keys1.as<float>();
@@ -1237,7 +1346,7 @@ int wc_newref_collect_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t
     g.list = st.list.as<unsigned long long>();
     g.cap = (int)st.cap;
     unsigned grid = (unsigned)(((g.ntiles + 7) / 8) * 8);
-    hipLaunchKernelGGL(k_gram<1>, dim3(grid), dim3(256), 0, stream, g);
+    hipLaunchKernelGGL(k_gram, dim3(grid), dim3(256), 0, stream, g);
     WC_HIP(hipGetLastError());
     return WC_OK;
 }
