@@ -164,6 +164,13 @@ def main():
     t_test = float(tmax.item())
     samples_per_s = world * args.test_samples * test_steps / t_test
     n_calls = int(tb.n_calls.sum().item())
+    # SURVEY.md 8(d) traffic model of the test path, per sample: the z-score gathers
+    # (repeats x sum_i n_i x (4 B index + 8 B value)) plus one float64 per Stouffer window (the
+    # materialised-triangle model; the kernels never write the triangle, so this can exceed
+    # what actually moves -- windows/s is reported beside it)
+    n_refs = float((reference.distances < reference.cutoff).sum())
+    windows = float(sum(int(n) * (int(n) + 1) // 2 for n in inp["masked_bins"]))
+    test_bytes = 5.0 * n_refs * 12.0 + windows * 8.0
     # BASELINE config 3: one sample per call (latency mode, nothing amortised over a batch)
     tb1 = distributed.TestBatch(reference, torch.from_numpy(counts_h[:1].copy()).to(dev), thr)
     tb1.run()
@@ -275,6 +282,12 @@ def main():
             "test": {"metric": "test samples/sec", "value": samples_per_s, "unit": "samples/s",
                      "ms_per_batch": 1e3 * t_test / test_steps, "samples_per_gpu": args.test_samples,
                      "single_sample_latency_ms": single_ms,
+                     "roofline": {"bound": "hbm", "model": "5 repeats x gathered refs x 12 B + 8 B per Stouffer window "
+                                  "(SURVEY.md 8d); triangle never materialised",
+                                  "bytes_per_sample": test_bytes, "achieved": samples_per_s / world * test_bytes / 1e9,
+                                  "peak": 8000.0, "unit": "GB/s",
+                                  "frac": samples_per_s / world * test_bytes / 8.0e12,
+                                  "windows_per_s": samples_per_s * windows},
                      "calls_found": n_calls},
             "roofline": {"kernel": "k_gram (symmetric fp32 MFMA distance tiles + candidate filter)",
                          "bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_FP32_MFMA / 1e12,
