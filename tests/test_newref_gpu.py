@@ -97,3 +97,24 @@ def test_large_slice_against_oracle(wt):
     want_i, want_d = wo.get_reference(data, bins, sums, 100, part, parts, fast=True)
     assert np.array_equal(idx, want_i)
     assert same_bits(dst, want_d)
+
+
+def test_error_reporting_through_the_c_abi(wt):
+    """Bad arguments come back as error codes + messages; nothing exits or falls back."""
+    from wisecondor_amd import _lib
+    data = np.ones((10, 4))
+    with pytest.raises(_lib.WisecondorHipError, match="chromosome sizes sum"):
+        wt.getReference(data, [3, 3], [3, 10], 2)            # sizes do not add up to the row count
+    with pytest.raises(_lib.WisecondorHipError, match="refsize above"):
+        wt.getReference(data, [5, 5], [5, 10], 100000)
+    with pytest.raises(ValueError):
+        wt.getReference(np.ones((9, 4)), [5, 5], [5, 10], 2)  # matrix / layout mismatch caught on the host
+    with pytest.raises(_lib.WisecondorHipError, match="mask has"):
+        wt.Reference(np.zeros((4, 2), np.int32), np.ones((4, 2)), [3, 3], [2, 2], np.array([1, 1, 1, 0, 1, 0], np.uint8),
+                     np.ones(4), np.zeros((0, 4)))
+    with pytest.raises(_lib.WisecondorHipError, match="unsupported shape"):
+        wt.Reference(np.zeros((4, 200), np.int32), np.ones((4, 200)), [2, 2], [2, 2], np.ones(4, np.uint8),
+                     np.ones(4), np.zeros((0, 4)))           # refsize 200 > 128 in the test path
+    # and the context is still usable afterwards
+    idx, dst = wt.getReference(np.arange(40.0).reshape(10, 4), [5, 5], [5, 10], 2)
+    assert idx.shape == (10, 2) and np.all(idx >= 0)

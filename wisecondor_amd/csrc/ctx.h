@@ -43,8 +43,15 @@ struct TestState {
     int64_t last_segs = 0;
 };
 
+// state carried from wc_newref_prep_gram to wc_newref_prep_finish
+struct PrepState {
+    int64_t S = 0, Btot = 0, B = 0;
+    bool ready = false;
+};
+
 struct wc_ctx {
     int device = 0;
+    PrepState prep;
     NewrefState nr;
     TestState ts;
     wc::DevBuf tmp_a, tmp_b, tmp_c, tmp_d;  // host-pointer API staging

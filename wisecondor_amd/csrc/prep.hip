@@ -190,13 +190,6 @@ void jacobi_eigh(std::vector<double> a, int n, std::vector<double> &val, std::ve
     }
 }
 
-// state carried from wc_newref_prep_gram to wc_newref_prep_finish
-struct PrepState {
-    int64_t S = 0, Btot = 0, B = 0;
-    bool ready = false;
-};
-PrepState g_prep;   // one prep at a time per process (the CLI runs one)
-
 }  // namespace
 
 extern "C" {
@@ -209,6 +202,7 @@ int wc_newref_prep_gram(wc_ctx *ctx, const int32_t *counts, int64_t n_samples, i
     WC_CHECK(n_samples > 0 && n_total_bins > 0 && n_chrom > 0 && n_chrom <= WC_MAX_CHROM, WC_E_ARG, "prep: bad shape");
     WC_CHECK(n_samples <= 4096, WC_E_LIMIT, "prep: more than 4096 samples not supported");
     WC_HIP(hipSetDevice(ctx->device));
+    PrepState &g_prep = ctx->prep;
     g_prep.ready = false;
     const int64_t S = n_samples, Btot = n_total_bins;
     TestState &ts = ctx->ts;
@@ -267,6 +261,7 @@ int wc_newref_prep_finish(wc_ctx *ctx, int n_comp, const double *eigvecs, const 
                           double *pca_mean_out) {
     WC_CHECK(ctx && eigvecs && eigvals && masked_data_out && corrected_t_out && pca_components_out && pca_mean_out,
              WC_E_ARG, "prep: NULL argument");
+    PrepState &g_prep = ctx->prep;
     WC_CHECK(g_prep.ready, WC_E_ARG, "prep: wc_newref_prep_gram has not run");
     const int64_t S = g_prep.S, B = g_prep.B;
     WC_CHECK(n_comp >= 1 && n_comp <= 8 && n_comp <= S, WC_E_ARG, "prep: 1..8 components supported");
