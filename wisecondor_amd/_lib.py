@@ -69,9 +69,14 @@ def load():
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise WisecondorHipError(
-            "%s is missing: build it with `python -m wisecondor_amd.build` "
-            "(this package has no CPU fallback)" % LIB_PATH)
+        # a fresh checkout: compile the HIP sources (still the GPU product, not a fallback)
+        try:
+            from . import build
+            build.build_library(verbose=False)
+        except Exception as exc:
+            raise WisecondorHipError(
+                "%s is missing and could not be built (%s): run `python -m wisecondor_amd.build` "
+                "(this package has no CPU fallback)" % (LIB_PATH, exc))
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
