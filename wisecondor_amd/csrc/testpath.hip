@@ -326,12 +326,18 @@ __global__ __launch_bounds__(256) void k_sd_avg(const double *__restrict__ sdT, 
             pre[u] = (live && b < B) ? sdT[b * Ns + i] : NAN;
         }
         if (threadIdx.x < 64) {
-            const int lim = (B - b0) < 128 ? (int)(B - b0) : 128;
-            for (int bb = 0; bb < lim; ++bb) {
-                double v = buf[bb][ss];
-                bool ok = v == v;
-                s = s + (ok ? v : 0.0);
-                c += ok;
+            // bins past the end were staged as NaN and are skipped like any other NaN, so the
+            // trip count is fixed: 16 LDS reads in flight per group, then the serial adds
+            for (int bb = 0; bb < 128; bb += 16) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = buf[bb + u][ss];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    bool ok = v[u] == v[u];
+                    s = s + (ok ? v[u] : 0.0);
+                    c += ok;
+                }
             }
         }
     }
