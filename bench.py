@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--test-samples", type=int, default=64, help="test samples per GPU in the batched test pass")
+    ap.add_argument("--test-samples", type=int, default=128, help="test samples per GPU in the batched test pass")
     ap.add_argument("--refsize", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra 600 x 50 kb newref measurement")

@@ -48,6 +48,9 @@ def test_hip_multi_rank_on_one_gpu(tmp_path, world, order):
     data, bins, sums = synth.corrected_matrix(1000000, 40, seed=9)
     data[5] = data[900]                       # a tie across ranks' row ranges
     data[2000] *= 25.0                        # an outlier row that needs the exact fallback
+    rng = np.random.RandomState(4)
+    members = rng.permutation(data.shape[0])[:900]
+    data[members] = data[members[0]]          # 900 identical rows: per-source exchange slots overflow -> fallback
     k = 100
     path_in = str(tmp_path / "in.npz")
     np.savez(path_in, data=data, bins=bins, k=k, order=order)

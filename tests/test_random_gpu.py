@@ -114,3 +114,34 @@ def test_whole_test_path_random(wt, seed):
                            rtol=1e-8, atol=1e-10, equal_nan=True)
         assert np.allclose(out["results_cwz"], want["results_cwz"], rtol=1e-8, atol=1e-9, equal_nan=True)
     reference.close()
+
+
+@pytest.mark.parametrize("order", ["C", "F"])
+def test_newref_rare_paths(wt, order):
+    """Clusters of exact duplicates large enough to hit the rarely taken paths: more than 64
+    re-score candidates per row (several batches), more than RMAX tied candidates and
+    candidate-list overflow (both -> exact fallback), k at its maximum."""
+    rng = np.random.RandomState(99)
+    bins = np.array([310, 150, 290, 40, 260, 333, 128, 257, 600, 90, 275, 267], dtype=np.int64)
+    B = int(bins.sum())
+    S = 24
+    data = 1.0 + 0.02 * rng.standard_normal((B, S))
+    perm = rng.permutation(B)
+    at = 0
+    for size in (70, 300, 700, 1500):               # rows of one cluster are bit-identical
+        members = perm[at:at + size]
+        data[members] = data[members[0]]
+        at += size
+    near = perm[at:at + 200]                        # near-duplicates: distances ~1e-14 apart
+    data[near] = data[near[0]] + 1e-9 * rng.standard_normal((200, S))
+    if order == "F":
+        data = np.asfortranarray(data)
+    sums = np.cumsum(bins)
+    for k in (100, 256):
+        idx, dst = wt.getReference(data, bins, sums, k, 1, 1)
+        st = wt.newref_stats()
+        with np.errstate(all="ignore"):
+            want_i, want_d = wo.get_reference(data, bins, sums, k, 1, 1, fast=True)
+        assert np.array_equal(idx, want_i), (order, k)
+        assert same_bits(dst, want_d), (order, k)
+        assert st["fallback_rows"] > 0 and st["fast_rows"] > 0, st     # both paths were exercised
