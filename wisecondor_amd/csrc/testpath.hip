@@ -253,6 +253,17 @@ __global__ __launch_bounds__(256) void k_zscore(const double *__restrict__ XT, c
     if (active && !active[i]) return;
     const int *lst = gidx + b * k;
     const int n = nref[b];
+    if (active) {
+        // Later repeats: flags only accumulate, so a bin whose number of kept references
+        // did not change has exactly the same reference set and the same results.
+        int kept = 0;
+        for (int r = 0; r < n; ++r) {
+            int g = lst[r];
+            double v = g >= 0 ? XC[(int64_t)g * Ns + i] : -1.0;
+            kept += (v >= 0.0);
+        }
+        if ((double)kept == nT[gid]) return;
+    }
     StreamSum acc;
     acc.init();
     for (int r = 0; r < n; ++r) {
