@@ -24,7 +24,7 @@ struct wc_reference {
 namespace {
 
 constexpr int MAX_COMP = 8;
-constexpr int ROWS_HALF = 32;  // window rows per side handled by one search workgroup
+constexpr int ROWS_HALF = 64;  // window rows per side handled by one search workgroup (one lane each)
 constexpr int CAND_CAP = 64;
 
 struct Region { long long off; int n; int pad; };
@@ -578,22 +578,35 @@ struct ScanCtx {
 
 // Rows handled by (job, chunk): ROWS_HALF rows from the top of the triangle and the
 // ROWS_HALF mirrored rows from the bottom, so every workgroup sees ~ the same work.
+// A lane owns one start bin x (its prefix value stays in a register); the four waves of
+// the workgroup take the window lengths len = 1 + w, 5 + w, ...: within a wave the length
+// is uniform, so rs[len] is one scalar load and P[x + len] one coalesced vector load.
 template <class F> __device__ inline void scan_chunk(const ScanCtx &c, const double *__restrict__ rs, int tid, F f) {
-    for (int s = 0; s < 2 * ROWS_HALF; ++s) {
-        int xr;
-        if (s < ROWS_HALF) {
-            xr = c.chunk * ROWS_HALF + s;
-            if (xr >= c.half) continue;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int side = 0; side < 2; ++side) {
+        int xr = c.chunk * ROWS_HALF + lane;
+        bool live;
+        if (side == 0) {
+            live = xr < c.half;
         } else {
-            xr = c.L - 1 - (c.chunk * ROWS_HALF + (s - ROWS_HALF));
-            if (xr < c.half) continue;
+            xr = c.L - 1 - xr;
+            live = xr >= c.half;
         }
-        const int x = c.lo + xr;
+        // longest window among the rows of this block (lane 0 has the smallest / largest start)
+        const int xr_min = side == 0 ? c.chunk * ROWS_HALF : c.L - 1 - (c.chunk * ROWS_HALF + 63);
+        const int max_len = c.L - (xr_min < 0 ? 0 : xr_min);
+        const int x = c.lo + (live ? xr : 0);
         const double px = c.P[x];
-        for (int y = x + tid; y < c.hi; y += 256) {
-            double v = (c.P[y + 1] - px) * rs[y - x + 1];
-            if (!c.wm.valid(x, y)) v = 0.0;
-            f(v, x, y);
+        const int room = live ? c.hi - x : 0;            // windows [x, x + len - 1] with len <= room
+        for (int len = 1 + w; len <= max_len; len += 4) {
+            const double r = rs[len];
+            if (len <= room) {
+                const int y = x + len - 1;
+                double v = (c.P[y + 1] - px) * r;
+                if (!c.wm.valid(x, y)) v = 0.0;
+                f(v, x, y);
+            }
         }
     }
 }
