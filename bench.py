@@ -212,7 +212,7 @@ def main():
         extra = {"workload": "cfg4: newref %d samples x %d kb bins (%d bins), kernel-level synthetic matrix"
                              % (xs, xb // 1000, XB),
                  "value": xpairs * xsteps / xt, "unit": "bin-pair distances/s", "ms_per_step": 1e3 * xt / xsteps,
-                 "steps": xsteps, "k_gram_ms": xk_ms, "k_gram_tflops": xflops / (xk_ms * 1e-3) / 1e12,
+                 "steps": xsteps, "shard_mode": xjob.mode or "tiles", "k_gram_ms": xk_ms, "k_gram_tflops": xflops / (xk_ms * 1e-3) / 1e12,
                  "k_gram_frac_of_fp32_mfma_peak": xflops / (xk_ms * 1e-3) / PEAK_FP32_MFMA}
         del xjob, XX
         # the main job's context state was replaced by the extra run; nothing below needs it
@@ -278,7 +278,10 @@ def main():
             "config": {"workload": "%s: newref %d samples x %d kb bins (%d masked bins, refsize %d), "
                                    "then batched test of %d samples/GPU at the same bin size"
                                    % (args.workload, S, binsize // 1000, B, k, args.test_samples),
-                       "parallelism": "tile-sharded newref + sample-sharded test, %d rank(s)" % world},
+                       "parallelism": "newref sharded by %s + sample-sharded test, %d rank(s)"
+                                      % ({"rows": "row bands (all-gather only)", "tiles": "symmetric tiles "
+                                          "(threshold all-gather, list all-to-all, result all-gather)"}
+                                         .get(job.mode or "tiles"), world)},
             "test": {"metric": "test samples/sec", "value": samples_per_s, "unit": "samples/s",
                      "ms_per_batch": 1e3 * t_test / test_steps, "samples_per_gpu": args.test_samples,
                      "single_sample_latency_ms": single_ms,

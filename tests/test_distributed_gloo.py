@@ -2,7 +2,7 @@
 
 The HIP stages cannot run here, so the driver (wisecondor_amd.distributed.NewrefJob:
 threshold all-gather, round-robin tile deal, candidate-list all-to-all, owner-side
-finish, result all-gather) is exercised with a numpy stand-in for the four stages
+finish, result all-gather; and the row-band mode with the all-gather only) is exercised with a numpy stand-in for the four stages
 that follows the same contract (test infrastructure only).  The multi-rank result
 must equal the single-rank result and the oracle, bit for bit.
 """
@@ -71,9 +71,9 @@ class NumpyStages(object):
                         if self.chrom[i] == self.chrom[j] or (I == J and j <= i):
                             continue
                         d = float(np.sum(np.power(self.X[j] - self.X[i], 2)))
-                        if d <= self.thr[i]:
+                        if d <= self.thr[i] and rb <= i < re:
                             self.lists[i].append(j)
-                        if d <= self.thr[j]:
+                        if d <= self.thr[j] and rb <= j < re:
                             self.lists[j].append(i)
 
     def export(self, rb, re, cap, cnt, lst):
@@ -109,13 +109,13 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, X, bins, k, out_dir):
+def _worker(rank, world, port, X, bins, k, out_dir, mode):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         st = NumpyStages(X, bins, k)
-        job = NewrefJob(None, None, bins, k, 0, rank=rank, world=world, stages=st, dist=dist)
+        job = NewrefJob(None, None, bins, k, 0, rank=rank, world=world, stages=st, dist=dist, mode=mode)
         for _ in range(2):          # second run reuses the exchange buffers
             idx, dst = job.run()
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), idx=idx.numpy(), dst=dst.numpy())
@@ -123,13 +123,13 @@ def _worker(rank, world, port, X, bins, k, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_multi_rank_equals_single_rank_and_oracle(tmp_path, world):
+@pytest.mark.parametrize("world,mode", [(2, "tiles"), (3, "tiles"), (2, "rows"), (3, None)])
+def test_multi_rank_equals_single_rank_and_oracle(tmp_path, world, mode):
     rng = np.random.RandomState(5)
     bins = np.array([9, 14, 7, 12, 11], dtype=np.int64)
     X = 1.0 + 0.05 * rng.standard_normal((int(bins.sum()), 6))
     k = 10
-    mp.spawn(_worker, args=(world, _free_port(), X, bins, k, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), X, bins, k, str(tmp_path), mode), nprocs=world, join=True)
     st = NumpyStages(X, bins, k)
     one_i, one_d = NewrefJob(None, None, bins, k, 0, rank=0, world=1, stages=st).run()
     want_i, want_d = wo.get_reference(X, bins, np.cumsum(bins), k, 1, 1, fast=True)

@@ -21,7 +21,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, path_in, out_dir):
+def _worker(rank, world, port, path_in, out_dir, mode):
     import torch
     import torch.distributed as dist
     from wisecondor_amd import _lib
@@ -32,7 +32,8 @@ def _worker(rank, world, port, path_in, out_dir):
     try:
         z = np.load(path_in)
         X = torch.from_numpy(np.ascontiguousarray(z["data"])).cuda()
-        job = NewrefJob(_lib.context(0), X, z["bins"], int(z["k"]), int(z["order"]), rank=rank, world=world, dist=dist)
+        job = NewrefJob(_lib.context(0), X, z["bins"], int(z["k"]), int(z["order"]), rank=rank, world=world, dist=dist,
+                        mode=mode)
         for _ in range(2):
             idx, dst = job.run()
         torch.cuda.synchronize()
@@ -41,8 +42,8 @@ def _worker(rank, world, port, path_in, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,order", [(2, 1), (3, 0)])
-def test_hip_multi_rank_on_one_gpu(tmp_path, world, order):
+@pytest.mark.parametrize("world,order,mode", [(2, 1, "tiles"), (3, 0, "tiles"), (2, 0, "rows"), (3, 1, "rows")])
+def test_hip_multi_rank_on_one_gpu(tmp_path, world, order, mode):
     import torch.multiprocessing as mp
     from wisecondor_amd import synth
     data, bins, sums = synth.corrected_matrix(1000000, 40, seed=9)
@@ -55,7 +56,7 @@ def test_hip_multi_rank_on_one_gpu(tmp_path, world, order):
     path_in = str(tmp_path / "in.npz")
     np.savez(path_in, data=data, bins=bins, k=k, order=order)
     mp.get_context("spawn")
-    mp.spawn(_worker, args=(world, _free_port(), path_in, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), path_in, str(tmp_path), mode), nprocs=world, join=True)
     src = data if order == 0 else np.asfortranarray(data)
     with np.errstate(all="ignore"):
         want_i, want_d = wo.get_reference(src, bins, sums, k, 1, 1, fast=True)

@@ -143,3 +143,16 @@ def test_shard_helpers():
     assert all(got[i][1] == got[i + 1][0] for i in range(7))
     got = [shard_samples(10, r, 4) for r in range(4)]
     assert [b - a for a, b in got] == [3, 3, 2, 2]
+
+
+def test_shard_mode_choice():
+    """Small jobs shard by row bands (no exchange), the 600 x 50 kb job by symmetric tiles."""
+    from wisecondor_amd import distributed as d
+    from wisecondor_amd import synth
+    bins250 = synth.chrom_bins(250000)
+    bins50 = synth.chrom_bins(50000)
+    assert d.choose_shard_mode(int(sum(bins250)), 100, bins250, 8, 1024) == "rows"
+    assert d.choose_shard_mode(int(sum(bins50)), 600, bins50, 8, 1024) == "tiles"
+    assert d.choose_shard_mode(int(sum(bins50)), 600, bins50, 2, 1024) == "tiles"
+    assert d.choose_shard_mode(int(sum(bins50)), 600, bins50, 1, 1024) == "tiles"
+    assert d.exchange_capacity(1024, 8) % 32 == 0 and d.exchange_capacity(1024, 1) == 1024

@@ -15,6 +15,8 @@ test    Samples are independent (one per invocation in the reference,
 torch is used for device memory, streams and the collectives only; all
 arithmetic happens behind the C ABI (include/wisecondor_hip.h).
 """
+import os
+
 import numpy as np
 
 from . import _lib
@@ -77,10 +79,61 @@ class HipStages(object):
         return self.torch.empty(shape, dtype=dtype, device=self.device)
 
 
-class NewrefJob(object):
-    """getReference for all rows, on `world` ranks; every rank ends with the full result."""
+# Cost model of the shard-mode choice (seconds; one MI355X per rank, xGMI between them).
+# Measured on one GPU: the symmetric distance kernel sustains ~60 % of the fp32 MFMA peak at
+# 100 samples and ~80 % at 600.  The exchange figures are planning numbers for RCCL on a
+# fully connected 8-GPU node (not measured here: the test box has one GPU).
+_MFMA_RATE = 0.6 * 157.3e12          # sustained flop/s of the distance kernel
+_COLL_LATENCY = 30e-6                # fixed cost of one small RCCL collective
+_XGMI_RATE = 100e9                   # bytes/s a rank moves in an all-to-all (several links busy)
 
-    def __init__(self, ctx, X, chrom_bins, k, sum_order, rank=0, world=1, stages=None, dist=None):
+
+def choose_shard_mode(n_bins, n_samples, chrom_bins, world, cap):
+    """'tiles' (symmetric tile deal + candidate exchange) or 'rows' (row bands, no exchange).
+
+    tiles: every unordered pair is evaluated once on the node; costs the threshold all-gather,
+           the list all-to-all (world * rows/rank * cap_x * 8 B per rank) and export/import.
+    rows:  rank r evaluates its rows against all columns, i.e. every unordered pair twice on
+           the node; nothing but the final all-gather.
+    Rows mode wins when one rank's share of the symmetric work is shorter than the exchange."""
+    if world <= 1:
+        return "tiles"
+    env = os.environ.get("WC_NEWREF_SHARD", "auto")
+    if env in ("tiles", "rows"):
+        return env
+    b = np.asarray(chrom_bins, dtype=np.float64)
+    unordered = (float(n_bins) ** 2 - float((b * b).sum())) / 2.0
+    t_sym = unordered * 2.0 * n_samples / _MFMA_RATE / world
+    rows = n_bins / float(world)
+    t_exchange = 2 * _COLL_LATENCY + world * rows * exchange_capacity(cap, world) * 8.0 / _XGMI_RATE
+    return "rows" if t_sym < t_exchange else "tiles"
+
+
+def exchange_capacity(cap, world):
+    """Per (source rank, row) slot count of the candidate exchange.
+
+    A rank holds ~1/world of a row's candidates, whose total is ~cap/2 with a row-to-row
+    spread of ~20 % (it comes from a sampled order statistic): 1.75 x mean + 8 sigma
+    (Poisson) + slack, in steps of 32.  A row that still overflows is marked by the
+    importer and takes the exact fallback."""
+    mean = cap / 2.0 / world
+    return int(min(cap, 32 * int(np.ceil((1.75 * mean + 8.0 * np.sqrt(mean) + 16.0) / 32.0))))
+
+
+def _align(n, a):
+    return (n + a - 1) // a * a
+
+
+class NewrefJob(object):
+    """getReference for all rows, on `world` ranks; every rank ends with the full result.
+
+    Collectives per run: tiles mode 3 (thresholds all-gather, one all-to-all carrying counts
+    and lists, one all-gather carrying indexes and distances), rows mode 1 (the all-gather).
+    Counts+lists and indexes+distances share one byte buffer each so that they travel in
+    one collective; the result all-gather is in place (the rank's own slot is its finish
+    output)."""
+
+    def __init__(self, ctx, X, chrom_bins, k, sum_order, rank=0, world=1, stages=None, dist=None, mode=None):
         import torch
         self.torch = torch
         self.rank, self.world = int(rank), int(world)
@@ -90,6 +143,8 @@ class NewrefJob(object):
         if dist is None and self.world > 1:
             import torch.distributed as dist
         self.dist = dist
+        self.mode = mode            # None: decided after prepare(), when the list capacity is known
+        self.chrom_bins = np.asarray(chrom_bins, dtype=np.int64)
         self.ranges = [row_range(r, self.world, self.n_bins) for r in range(self.world)]
         self.max_rows = max(e - b for b, e in self.ranges)
         t = torch
@@ -98,11 +153,14 @@ class NewrefJob(object):
             self.idx = e((self.n_bins, self.k), t.int32)
             self.dst = e((self.n_bins, self.k), t.float64)
         else:
-            self.idx_own = e((self.max_rows, self.k), t.int32)
-            self.dst_own = e((self.max_rows, self.k), t.float64)
-            self.idx_all = e((self.world, self.max_rows, self.k), t.int32)
-            self.dst_all = e((self.world, self.max_rows, self.k), t.float64)
-            self.thr_own = e((self.max_rows,), t.float32)
+            # result slots [world, dst f64 | idx i32], one all-gather for both
+            n = self.max_rows * self.k
+            self.res_bytes = _align(n * 12, 16)
+            self.res_all = e((self.world, self.res_bytes), t.uint8)
+            self.dst_all = [self.res_all[r, :n * 8].view(t.float64).view(self.max_rows, self.k)
+                            for r in range(self.world)]
+            self.idx_all = [self.res_all[r, n * 8:n * 12].view(t.int32).view(self.max_rows, self.k)
+                            for r in range(self.world)]
             self.thr_all = e((self.world, self.max_rows), t.float32)
             self.buffers_ready = False
 
@@ -111,13 +169,16 @@ class NewrefJob(object):
     def _needs_staging(self, t):
         return self.dist.get_backend() == "gloo" and t.device.type != "cpu"
 
-    def _all_gather(self, out, inp):
-        if self._needs_staging(inp):
+    def _all_gather(self, out, own):
+        """In-place all-gather: `own` is this rank's slot of `out`."""
+        if self._needs_staging(out):
             o = out.cpu()
-            self.dist.all_gather_into_tensor(o, inp.cpu())
+            self.dist.all_gather_into_tensor(o, own.cpu())
             out.copy_(o)
+        elif self.dist.get_backend() == "gloo":
+            self.dist.all_gather_into_tensor(out, own.clone())
         else:
-            self.dist.all_gather_into_tensor(out, inp)
+            self.dist.all_gather_into_tensor(out, own)
 
     def _all_to_all(self, out, inp):
         if self._needs_staging(inp):
@@ -130,18 +191,27 @@ class NewrefJob(object):
     def _alloc_exchange(self):
         t = self.torch
         e = self.st.empty
-        cap = self.st.cap
-        # per (source rank, row) capacity of the exchange: a rank holds ~1/world of a row's
-        # candidates, whose total is ~cap/2 with a row-to-row spread of ~20 % (it comes from a
-        # sampled order statistic); 1.75 x mean + 8 sigma (Poisson) + slack, in steps of 32.
-        # A row that still overflows is marked by the importer and takes the exact fallback.
-        mean = cap / 2.0 / self.world
-        self.cap_x = int(min(cap, 32 * int(np.ceil((1.75 * mean + 8.0 * np.sqrt(mean) + 16.0) / 32.0))))
-        self.send_cnt = e((self.world, self.max_rows), t.int32)
-        self.recv_cnt = e((self.world, self.max_rows), t.int32)
-        self.send_lst = e((self.world, self.max_rows, self.cap_x), t.int64)
-        self.recv_lst = e((self.world, self.max_rows, self.cap_x), t.int64)
+        self.cap_x = exchange_capacity(self.st.cap, self.world)
+        # per destination rank: [counts i32 x max_rows | lists i64 x max_rows x cap_x]
+        off = _align(self.max_rows * 4, 16)
+        self.x_bytes = off + self.max_rows * self.cap_x * 8
+        self.send = e((self.world, self.x_bytes), t.uint8)
+        self.recv = e((self.world, self.x_bytes), t.uint8)
+
+        def views(buf):
+            cnt = [buf[r, :self.max_rows * 4].view(t.int32) for r in range(self.world)]
+            lst = [buf[r, off:].view(t.int64).view(self.max_rows, self.cap_x) for r in range(self.world)]
+            return cnt, lst
+        self.send_cnt, self.send_lst = views(self.send)
+        self.recv_cnt, self.recv_lst = views(self.recv)
+        self.send_cnt_all = self.send[:, :off]
         self.buffers_ready = True
+
+    def _gather_results(self):
+        self._all_gather(self.res_all.view(-1), self.res_all[self.rank])
+        idx = self.torch.cat([self.idx_all[r][:e - b] for r, (b, e) in enumerate(self.ranges)])
+        dst = self.torch.cat([self.dst_all[r][:e - b] for r, (b, e) in enumerate(self.ranges)])
+        return idx, dst
 
     def run(self, collect_events=None):
         st = self.st
@@ -156,15 +226,27 @@ class NewrefJob(object):
             st.finish(0, self.n_bins, self.idx, self.dst)
             return self.idx, self.dst
 
-        dist = self.dist
         rb, re = self.ranges[self.rank]
+        if self.mode is None:
+            self.mode = choose_shard_mode(self.n_bins, st.n_samples, self.chrom_bins, self.world, st.cap)
+        if self.mode == "rows":
+            # row band of this rank against all columns: no exchange, one collective
+            st.thresholds(rb, re)
+            if collect_events:
+                collect_events[0].record()
+            st.collect(rb, re, 0, 1)
+            if collect_events:
+                collect_events[1].record()
+            st.finish(rb, re, self.idx_all[self.rank], self.dst_all[self.rank])
+            return self._gather_results()
+
         if not self.buffers_ready:
             self._alloc_exchange()
         # thresholds: owner computes, everyone needs them for the tiles it was dealt
         st.thresholds(rb, re)
-        self.thr_own.zero_()
-        st.get_thr(rb, re, self.thr_own)
-        self._all_gather(self.thr_all.view(-1), self.thr_own)
+        self.thr_all[self.rank].zero_()
+        st.get_thr(rb, re, self.thr_all[self.rank])
+        self._all_gather(self.thr_all.view(-1), self.thr_all[self.rank])
         for r, (b, e) in enumerate(self.ranges):
             if r != self.rank:
                 st.set_thr(b, e, self.thr_all[r])
@@ -175,22 +257,17 @@ class NewrefJob(object):
         if collect_events:
             collect_events[1].record()
         # candidate lists travel to the rows' owners
-        self.send_cnt.zero_()
+        self.send_cnt_all.zero_()
         for r, (b, e) in enumerate(self.ranges):
             if r != self.rank:
                 st.export(b, e, self.cap_x, self.send_cnt[r], self.send_lst[r])
-        self._all_to_all(self.recv_cnt.view(-1), self.send_cnt.view(-1))
-        self._all_to_all(self.recv_lst.view(-1), self.send_lst.view(-1))
+        self._all_to_all(self.recv.view(-1), self.send.view(-1))
         for r in range(self.world):
             if r != self.rank:
                 st.import_(rb, re, self.cap_x, self.recv_cnt[r], self.recv_lst[r])
         # owners finish their rows; results to everyone
-        st.finish(rb, re, self.idx_own, self.dst_own)
-        self._all_gather(self.idx_all.view(-1), self.idx_own.view(-1))
-        self._all_gather(self.dst_all.view(-1), self.dst_own.view(-1))
-        idx = self.torch.cat([self.idx_all[r, :e - b] for r, (b, e) in enumerate(self.ranges)])
-        dst = self.torch.cat([self.dst_all[r, :e - b] for r, (b, e) in enumerate(self.ranges)])
-        return idx, dst
+        st.finish(rb, re, self.idx_all[self.rank], self.dst_all[self.rank])
+        return self._gather_results()
 
 
 class TestBatch(object):
