@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256) void k_convert(const double *__restrict__ X, i
                                                  const int64_t *__restrict__ chrom_off, int n_chrom,
                                                  float *__restrict__ A, unsigned short *__restrict__ A16,
                                                  int64_t Kpad16, float *__restrict__ norm_lo,
-                                                 float *__restrict__ norm_hi, int *__restrict__ chrom_of_row) {
+                                                 float *__restrict__ norm_hi, int *__restrict__ chrom_of_row,
+                                                 int2 *__restrict__ chrom_range) {
     int lane = threadIdx.x & 63;
     int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= Bpad) return;
@@ -113,6 +114,7 @@ __global__ __launch_bounds__(256) void k_convert(const double *__restrict__ X, i
     if (lane == 0) {
         float lo = INFINITY, hi = INFINITY;
         int ch = -1;
+        int2 range = make_int2(0, 0);   // rows of this row's chromosome (padding rows: none)
         if (row < B) {
             if (isfinite(acc) && acc < 1e37) {
                 // key = lo_i + lo_j - 2 dot must never exceed the true distance
@@ -122,7 +124,9 @@ __global__ __launch_bounds__(256) void k_convert(const double *__restrict__ X, i
             int c = 0;
             while (c + 1 < n_chrom && row >= chrom_off[c + 1]) ++c;
             ch = c;
+            range = make_int2((int)chrom_off[c], (int)chrom_off[c + 1]);
         }
+        chrom_range[row] = range;
         norm_lo[row] = lo;
         norm_hi[row] = hi;
         chrom_of_row[row] = ch;
@@ -155,8 +159,9 @@ struct GramArgs {
     const float *P, *Q;          // [rows, ld] float32, rows padded to 128
     int64_t ld;                  // padded sample count
     int nslab;                   // ld / 32
+    int last_groups;             // groups of four MFMA steps of the last slab that hold samples (1..4)
     const float *nbP, *nbQ;      // lower norm bounds
-    const int *chP, *chQ;        // chromosome ids
+    const int2 *range;           // per row: [first, last+1) row of its chromosome (never candidates)
     const int4 *tiles;           // {I, J, roles, 0}
     int ntiles;
     const float *thr;            // admission threshold per target row
@@ -164,6 +169,15 @@ struct GramArgs {
     unsigned long long *list;
     int cap;
 };
+
+// bits [a, b) of a 32-bit mask, a and b clipped to [0, 32]
+__device__ inline unsigned int run_mask(int a, int b) {
+    a = a < 0 ? 0 : a;
+    b = b > 32 ? 32 : b;
+    if (a >= b) return 0u;
+    const unsigned int upto_b = b == 32 ? ~0u : ((1u << b) - 1u);
+    return upto_b & ~((1u << a) - 1u);
+}
 
 __device__ inline unsigned long long pack_entry(float key, int j) {
     return ((unsigned long long)wc::f32_ordered(key) << 32) | (unsigned int)j;
@@ -175,7 +189,7 @@ __device__ inline unsigned long long pack_entry(float key, int j) {
 // lane (i, h) feeds k = 16h + t at MFMA step t, so each lane fetches its 16
 // operands with four conflict-free ds_read_b128.
 __global__ __launch_bounds__(256, 4) void k_gram(GramArgs g) {
-    __shared__ __attribute__((aligned(16))) float sm[2 * TB * LDA + 6 * TB];   // 64 * LDD <= 2 * TB * LDA
+    __shared__ __attribute__((aligned(16))) float sm[2 * TB * LDA + 4 * TB];   // 64 * LDD <= 2 * TB * LDA
     float *As = sm;
     float *Bs = sm + TB * LDA;
     float *D = sm;
@@ -183,8 +197,6 @@ __global__ __launch_bounds__(256, 4) void k_gram(GramArgs g) {
     float *nbQs = nbPs + TB;
     float *thPs = nbQs + TB;
     float *thQs = thPs + TB;
-    int *chPs = (int *)(thQs + TB);
-    int *chQs = chPs + TB;
 
     // XCD-aware order: workgroup b runs on XCD b%8; give each XCD a contiguous run
     // of the (I-major) tile list so co-resident tiles share operand panels in its L2.
@@ -201,13 +213,11 @@ __global__ __launch_bounds__(256, 4) void k_gram(GramArgs g) {
     if (tid < TB) {
         int64_t gp = (int64_t)I * TB + tid;
         nbPs[tid] = g.nbP[gp];
-        chPs[tid] = g.chP[gp];
         thPs[tid] = g.thr[gp];
     } else {
         int c = tid - TB;
         int64_t gq = (int64_t)J * TB + c;
         nbQs[c] = g.nbQ[gq];
-        chQs[c] = g.chQ[gq];
         thQs[c] = g.thr[gq];
     }
 
@@ -228,6 +238,7 @@ __global__ __launch_bounds__(256, 4) void k_gram(GramArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    __builtin_amdgcn_s_setprio(2);   // waves feeding the matrix cores go ahead of waves in their epilogue
     for (int slab = 0; slab < g.nslab; ++slab) {
         __syncthreads();
 #pragma unroll
@@ -249,8 +260,12 @@ __global__ __launch_bounds__(256, 4) void k_gram(GramArgs g) {
         __builtin_amdgcn_sched_barrier(0);
         const float *a0 = &As[(wr * 64 + li) * LDA + lh * 16], *a1 = a0 + 32 * LDA;
         const float *b0 = &Bs[(wc * 64 + li) * LDA + lh * 16], *b1 = b0 + 32 * LDA;
+        // the last slab runs only the step groups that hold samples (lane half h feeds
+        // k = 16h + t; the padding beyond the sample count is zero)
+        const int ntg = slab + 1 < g.nslab ? 4 : g.last_groups;
 #pragma unroll
         for (int tg = 0; tg < 4; ++tg) {
+            if (tg >= ntg) break;
             const f32x4 ca0 = *(const f32x4 *)(a0 + 4 * tg), ca1 = *(const f32x4 *)(a1 + 4 * tg);
             const f32x4 cb0 = *(const f32x4 *)(b0 + 4 * tg), cb1 = *(const f32x4 *)(b1 + 4 * tg);
 #pragma unroll
@@ -267,6 +282,15 @@ __global__ __launch_bounds__(256, 4) void k_gram(GramArgs g) {
     // the 64 x 128 dot-product tile aliases the staging buffers, which keeps the
     // workgroup at 39 KB of LDS -> four workgroups per CU cover each other's
     // load / barrier / epilogue phases with MFMA work.
+    // Each thread scans 32 candidates for a column target and 32 for a row target: all 32
+    // dot products are fetched first (independent LDS reads), the candidates' norm bounds
+    // come as wave-uniform 16-byte broadcasts, and same-chromosome candidates -- a
+    // contiguous run of the tile's rows / columns -- are cleared from the pass mask at once.
+    __builtin_amdgcn_s_setprio(0);
+    const int x = tid & 127, q = __builtin_amdgcn_readfirstlane(tid >> 7);   // column x, 32-row half q
+    const int lr = tid & 63, cq = __builtin_amdgcn_readfirstlane(tid >> 6);  // row lr, 32-column quarter cq
+    const int2 rgq = g.range[(int64_t)J * TB + x];
+    const int2 rgp0 = g.range[(int64_t)I * TB + lr], rgp1 = g.range[(int64_t)I * TB + 64 + lr];
     for (int h = 0; h < 2; ++h) {
         __syncthreads();
         if (wr == h) {
@@ -283,54 +307,69 @@ __global__ __launch_bounds__(256, 4) void k_gram(GramArgs g) {
         }
         __syncthreads();
 
-        const int x = tid & 127, q = tid >> 7;      // column x, 32-row half q of this 64-row slab
-        if (roles & ROLE_COLS) {  // target = column x, candidates = 32 rows of this slab
+        unsigned int mask_c = 0u, mask_r = 0u;
+        float dv[32];
+        if (roles & ROLE_COLS) {  // target = column x, candidates = rows [h*64 + q*32, +32) of tile I
             const float nbc = nbQs[x], th = thQs[x];
-            const int chc = chQs[x];
-            unsigned int mask = 0u;
-            for (int rr = 0; rr < 32; ++rr) {
-                int lr = q * 32 + rr, r = h * 64 + lr;
-                float key = fmaf(-2.f, D[lr * LDD + x], nbPs[r] + nbc);
-                bool pass = (key <= th) && (chPs[r] != chc);
-                mask |= (unsigned int)pass << rr;
-            }
-            if (mask) {
-                int64_t gq = (int64_t)J * TB + x;
-                int base = atomicAdd(&g.cnt[gq], __popc(mask));
-                unsigned long long *dst = g.list + gq * g.cap;
-                while (mask) {
-                    int rr = __ffs((int)mask) - 1;
-                    mask &= mask - 1;
-                    int lr = q * 32 + rr, r = h * 64 + lr;
-                    float key = fmaf(-2.f, D[lr * LDD + x], nbPs[r] + nbc);
-                    if (base < g.cap) dst[base] = pack_entry(key, I * TB + r);
-                    ++base;
+#pragma unroll
+            for (int rr = 0; rr < 32; ++rr) dv[rr] = D[(q * 32 + rr) * LDD + x];
+            const f32x4 *nbv = (const f32x4 *)&nbPs[h * 64 + q * 32];
+#pragma unroll
+            for (int g4 = 0; g4 < 8; ++g4) {
+                const f32x4 nb4 = nbv[g4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float key = fmaf(-2.f, dv[4 * g4 + e], nb4[e] + nbc);
+                    mask_c |= (key <= th) ? (1u << (4 * g4 + e)) : 0u;
                 }
+            }
+            mask_c &= ~run_mask(rgq.x - (I * TB + h * 64 + q * 32), rgq.y - (I * TB + h * 64 + q * 32));
+        }
+        if (roles & ROLE_ROWS) {  // target = row h*64 + lr, candidates = columns [cq*32, +32) of tile J
+            const int r = h * 64 + lr;
+            const float nbr = nbPs[r], th = thPs[r];
+#pragma unroll
+            for (int cc = 0; cc < 32; ++cc) dv[cc] = D[lr * LDD + cq * 32 + cc];
+            const f32x4 *nbv = (const f32x4 *)&nbQs[cq * 32];
+#pragma unroll
+            for (int g4 = 0; g4 < 8; ++g4) {
+                const f32x4 nb4 = nbv[g4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float key = fmaf(-2.f, dv[4 * g4 + e], nbr + nb4[e]);
+                    mask_r |= (key <= th) ? (1u << (4 * g4 + e)) : 0u;
+                }
+            }
+            const int2 rg = h ? rgp1 : rgp0;
+            mask_r &= ~run_mask(rg.x - (J * TB + cq * 32), rg.y - (J * TB + cq * 32));
+        }
+        // both list reservations are in flight together
+        int base_c = 0, base_r = 0;
+        const int64_t gq = (int64_t)J * TB + x, gp = (int64_t)I * TB + h * 64 + lr;
+        if (mask_c) base_c = atomicAdd(&g.cnt[gq], __popc(mask_c));
+        if (mask_r) base_r = atomicAdd(&g.cnt[gp], __popc(mask_r));
+        if (mask_c) {
+            const float nbc = nbQs[x];
+            unsigned long long *dst = g.list + gq * g.cap;
+            while (mask_c) {
+                int rr = __ffs((int)mask_c) - 1;
+                mask_c &= mask_c - 1;
+                int l = q * 32 + rr, r = h * 64 + l;
+                float key = fmaf(-2.f, D[l * LDD + x], nbPs[r] + nbc);
+                if (base_c < g.cap) dst[base_c] = pack_entry(key, I * TB + r);
+                ++base_c;
             }
         }
-        if (roles & ROLE_ROWS) {  // target = row lr of this slab, candidates = 32 columns
-            const int lr = tid & 63, cq = tid >> 6, r = h * 64 + lr;
-            const float nbr = nbPs[r], th = thPs[r];
-            const int chr = chPs[r];
-            unsigned int mask = 0u;
-            for (int cc = 0; cc < 32; ++cc) {
+        if (mask_r) {
+            const float nbr = nbPs[h * 64 + lr];
+            unsigned long long *dst = g.list + gp * g.cap;
+            while (mask_r) {
+                int cc = __ffs((int)mask_r) - 1;
+                mask_r &= mask_r - 1;
                 int c = cq * 32 + cc;
                 float key = fmaf(-2.f, D[lr * LDD + c], nbr + nbQs[c]);
-                bool pass = (key <= th) && (chQs[c] != chr);
-                mask |= (unsigned int)pass << cc;
-            }
-            if (mask) {
-                int64_t gp = (int64_t)I * TB + r;
-                int base = atomicAdd(&g.cnt[gp], __popc(mask));
-                unsigned long long *dst = g.list + gp * g.cap;
-                while (mask) {
-                    int cc = __ffs((int)mask) - 1;
-                    mask &= mask - 1;
-                    int c = cq * 32 + cc;
-                    float key = fmaf(-2.f, D[lr * LDD + c], nbr + nbQs[c]);
-                    if (base < g.cap) dst[base] = pack_entry(key, J * TB + c);
-                    ++base;
-                }
+                if (base_r < g.cap) dst[base_r] = pack_entry(key, J * TB + c);
+                ++base_r;
             }
         }
     }
@@ -1139,6 +1178,7 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
     if ((rc = st.norm_lo.reserve(sizeof(float) * st.bins_pad))) return rc;
     if ((rc = st.norm_hi.reserve(sizeof(float) * st.bins_pad))) return rc;
     if ((rc = st.chrom_of_row.reserve(sizeof(int) * st.bins_pad))) return rc;
+    if ((rc = st.chrom_range.reserve(sizeof(int2) * st.bins_pad))) return rc;
     if ((rc = st.chrom_off_dev.reserve(sizeof(int64_t) * (WC_MAX_CHROM + 1)))) return rc;
     if ((rc = st.sample_rows.reserve(sizeof(int) * M))) return rc;
     if ((rc = st.a16.reserve(sizeof(unsigned short) * st.bins_pad * st.k_pad16))) return rc;
@@ -1198,7 +1238,8 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
     hipLaunchKernelGGL(k_convert, dim3((unsigned)(st.bins_pad / 4)), dim3(256), 0, stream, corrected, n_bins,
                        n_samples, st.bins_pad, st.k_pad, (const double *)mean2, (double)st.beta,
                        st.chrom_off_dev.as<int64_t>(), n_chrom, st.a32.as<float>(), st.a16.as<unsigned short>(),
-                       st.k_pad16, st.norm_lo.as<float>(), st.norm_hi.as<float>(), st.chrom_of_row.as<int>());
+                       st.k_pad16, st.norm_lo.as<float>(), st.norm_hi.as<float>(), st.chrom_of_row.as<int>(),
+                       st.chrom_range.as<int2>());
     hipLaunchKernelGGL(k_gather_samples, dim3((unsigned)M), dim3(256), 0, stream,
                        (const unsigned short *)st.a16.as<unsigned short>(), st.k_pad16, st.norm_lo.as<float>(),
                        st.chrom_of_row.as<int>(), st.sample_rows.as<int>(), std::min<int64_t>(M, n_bins), M,
@@ -1337,8 +1378,12 @@ int wc_newref_collect_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t
     g.P = g.Q = st.a32.as<float>();
     g.ld = st.k_pad;
     g.nslab = (int)(st.k_pad / BK);
+    {
+        const int64_t rem = st.n_samples - (int64_t)(g.nslab - 1) * BK;     // samples in the last slab, 1..32
+        g.last_groups = (int)((std::min<int64_t>(rem, 16) + 3) / 4);
+    }
     g.nbP = g.nbQ = st.norm_lo.as<float>();
-    g.chP = g.chQ = st.chrom_of_row.as<int>();
+    g.range = st.chrom_range.as<int2>();
     g.tiles = st.tiles.as<int4>();
     g.ntiles = (int)st.tiles1_n;
     g.thr = st.thr.as<float>();
