@@ -38,6 +38,7 @@ constexpr double SENTINEL_DISTANCE = 1e10;  // wisetools.py:306
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------ prepare ----
 // Robust per-sample centre from a strided subset of rows: mean -> 8 x mean absolute
@@ -730,8 +731,8 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : 8) * NT / 256) void k_finish(F
     constexpr int NP = CB / RP;       // passes per chunk
     extern __shared__ double xs_dyn[];                     // the target row (S doubles) when it fits
     __shared__ __attribute__((aligned(16))) unsigned long long ent[LIST_CAP > CB * ST_LD ? LIST_CAP : CB * ST_LD];
-    __shared__ unsigned long long dk[RMAX];
-    __shared__ int jv[RMAX];
+    __shared__ __attribute__((aligned(16))) unsigned long long dk[RMAX + 2];
+    __shared__ __attribute__((aligned(16))) int jv[RMAX + 2];
     __shared__ int cj[RMAX];
     __shared__ double red[4];
     __shared__ int s_tmp[4];
@@ -927,35 +928,62 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : 8) * NT / 256) void k_finish(F
             if (tid < nb) {
                 bool ok = acc < SENTINEL_DISTANCE;  // NaN and >= 1e10 are never admitted (wisetools.py:314)
                 dk[b0 + tid] = ok ? wc::f64_ordered(acc) : ~0ull;
-                jv[b0 + tid] = ok ? cj[b0 + tid] : 0x7FFFFFFF;
+                jv[b0 + tid] = ok ? cj[b0 + tid] : 0x40000000 + b0 + tid;   // unique, after every real index
             }
         }
     }
-    int q2 = 2;
-    while (q2 < R) q2 <<= 1;
-    __syncthreads();
-    for (int t = R + tid; t < q2; t += NT) { dk[t] = ~0ull; jv[t] = 0x7FFFFFFF; }
-    __syncthreads();
-    if (q2 <= 128) {
-        if (tid < 64) bitonic_pair_wave(dk, jv, q2, tid);
-        __syncthreads();
-    } else {
-        bitonic_pair(dk, jv, q2, tid, NT);
-    }
-
     const int ch = a.chrom_of_row[row];
     const int64_t cs = a.chrom_off[ch], ce = a.chrom_off[ch + 1];
     const int64_t orow = row - a.row_begin;
-    for (int t = tid; t < a.k; t += NT) {
-        int32_t oi = -1;
-        double od = SENTINEL_DISTANCE;
-        if (t < R && dk[t] != ~0ull) {
-            int64_t j = jv[t];
-            oi = (int32_t)(j < cs ? j : j - (ce - cs));
-            od = wc::f64_from_ordered(dk[t]);
+    __syncthreads();
+    if (R <= 2 * NT) {
+        // Order by counting: element t goes to slot #{u : (d_u, j_u) < (d_t, j_t)}.  Every thread
+        // streams the same (broadcast) LDS pairs, no round-to-round dependencies; the few
+        // hundred comparisons per element beat the 28 dependent rounds of a bitonic network.
+        if (tid == 0 && (R & 1)) { dk[R] = ~0ull; jv[R] = 0x7FFFFFFF; }
+        __syncthreads();
+        for (int t = tid; t < R; t += NT) {
+            const unsigned long long mine = dk[t];
+            const int myj = jv[t];
+            int rank = 0;
+            for (int u = 0; u < R; u += 2) {
+                const u64x2 kk = *(const u64x2 *)&dk[u];
+                const int2 jj = *(const int2 *)&jv[u];
+                rank += (kk.x < mine) | ((kk.x == mine) & (jj.x < myj));
+                rank += (kk.y < mine) | ((kk.y == mine) & (jj.y < myj));
+            }
+            if (rank < a.k) {
+                int32_t oi = -1;
+                double od = SENTINEL_DISTANCE;
+                if (mine != ~0ull) {
+                    oi = (int32_t)(myj < cs ? myj : myj - (ce - cs));
+                    od = wc::f64_from_ordered(mine);
+                }
+                a.idx_out[orow * a.k + rank] = oi;
+                a.dist_out[orow * a.k + rank] = od;
+            }
         }
-        a.idx_out[orow * a.k + t] = oi;
-        a.dist_out[orow * a.k + t] = od;
+        for (int t = R + tid; t < a.k; t += NT) {     // fewer candidates than k: sentinels (wisetools.py:305-306)
+            a.idx_out[orow * a.k + t] = -1;
+            a.dist_out[orow * a.k + t] = SENTINEL_DISTANCE;
+        }
+    } else {
+        int q2 = 2;
+        while (q2 < R) q2 <<= 1;
+        for (int t = R + tid; t < q2; t += NT) { dk[t] = ~0ull; jv[t] = 0x7FFFFFFF; }
+        __syncthreads();
+        bitonic_pair(dk, jv, q2, tid, NT);
+        for (int t = tid; t < a.k; t += NT) {
+            int32_t oi = -1;
+            double od = SENTINEL_DISTANCE;
+            if (t < R && dk[t] != ~0ull) {
+                int64_t j = jv[t];
+                oi = (int32_t)(j < cs ? j : j - (ce - cs));
+                od = wc::f64_from_ordered(dk[t]);
+            }
+            a.idx_out[orow * a.k + t] = oi;
+            a.dist_out[orow * a.k + t] = od;
+        }
     }
     if (tid == 0) a.row_stat[row] = R;  // >= 0: fast path, number of float64 re-scores
 }
