@@ -38,6 +38,7 @@ constexpr double SENTINEL_DISTANCE = 1e10;  // wisetools.py:306
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef double f64x2_u __attribute__((ext_vector_type(2), aligned(8)));   // rows of an odd sample count start 8-byte aligned
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------ prepare ----
@@ -544,60 +545,6 @@ __global__ __launch_bounds__(256) void k_select_thr(const float *__restrict__ ke
 }
 
 // ------------------------------------------------------------------- finish ----
-template <class T> __device__ inline void cswap(T &a, T &b) { T t = a; a = b; b = t; }
-
-__device__ inline void bitonic_u64(unsigned long long *v, int n, int tid, int nthreads) {
-    for (int k2 = 2; k2 <= n; k2 <<= 1)
-        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-            for (int t = tid; t < n; t += nthreads) {
-                int p = t ^ j2;
-                if (p > t) {
-                    bool asc = (t & k2) == 0;
-                    unsigned long long a = v[t], b = v[p];
-                    if ((a > b) == asc) { v[t] = b; v[p] = a; }
-                }
-            }
-            __syncthreads();
-        }
-}
-
-// n <= 128 pairs: one wave does every round (64 compare-exchanges), ordering its own LDS
-// traffic with a workgroup fence instead of workgroup barriers; the caller barriers after.
-__device__ inline void bitonic_pair_wave(unsigned long long *d, int *j, int n, int lane) {
-    for (int k2 = 2; k2 <= n; k2 <<= 1)
-        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-            for (int t = lane; t < n; t += 64) {
-                int p = t ^ j2;
-                if (p > t) {
-                    bool asc = (t & k2) == 0;
-                    unsigned long long a = d[t], b = d[p];
-                    int ja = j[t], jb = j[p];
-                    bool gt = (a > b) || (a == b && ja > jb);
-                    if (gt == asc) { d[t] = b; d[p] = a; j[t] = jb; j[p] = ja; }
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-        }
-}
-
-__device__ inline void bitonic_pair(unsigned long long *d, int *j, int n, int tid, int nthreads) {
-    for (int k2 = 2; k2 <= n; k2 <<= 1)
-        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-            for (int t = tid; t < n; t += nthreads) {
-                int p = t ^ j2;
-                if (p > t) {
-                    bool asc = (t & k2) == 0;
-                    unsigned long long a = d[t], b = d[p];
-                    int ja = j[t], jb = j[p];
-                    bool gt = (a > b) || (a == b && ja > jb);
-                    if (gt == asc) { d[t] = b; d[p] = a; j[t] = jb; j[p] = ja; }
-                }
-            }
-            __syncthreads();
-        }
-}
-
 struct FinishArgs {
     const double *X;
     int64_t B, S;
@@ -725,9 +672,9 @@ __device__ inline uint32_t select_key(const unsigned long long *ent, int n, int 
 // NT threads per row: 256 (candidate batches of 128) or 128 (batches of 64, half the LDS,
 // twice the rows in flight per CU -- better when the per-row latency dominates, S small).
 template <bool SEQ, int NT>
-__global__ __launch_bounds__(NT, (NT == 256 ? 4 : 8) * NT / 256) void k_finish(FinishArgs a) {
+__global__ __launch_bounds__(NT, 4) void k_finish(FinishArgs a) {
     constexpr int CB = NT / 2;        // candidates re-scored per batch (one lane each)
-    constexpr int RP = NT / 16;       // candidate rows staged per pass
+    constexpr int RP = NT / 8;        // candidate rows staged per pass (8 lanes x 16 bytes = one 16-sample chunk row)
     constexpr int NP = CB / RP;       // passes per chunk
     extern __shared__ double xs_dyn[];                     // the target row (S doubles) when it fits
     __shared__ __attribute__((aligned(16))) unsigned long long ent[LIST_CAP > CB * ST_LD ? LIST_CAP : CB * ST_LD];
@@ -821,18 +768,32 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : 8) * NT / 256) void k_finish(F
         //                     samples, boundaries from the host-built leaf table),
         //                     leaf sums folded with a small value stack.
         constexpr bool seq = SEQ;  // sequential order, or fewer than 8 samples (numpy sums those left to right too)
-        const int l16 = tid & 15, r0 = tid >> 4;
+        const int l8 = tid & 7, r0 = tid >> 3;
         for (int b0 = 0; b0 < R; b0 += CB) {
             const int nb = (R - b0) < CB ? (R - b0) : CB;
-            // element offsets fit 32 bits whenever the matrix is below 32 GB (checked by the host)
+            // element offsets fit 32 bits whenever the matrix is below 32 GB (checked by the host).
+            // Staging rows beyond nb re-read the batch's first candidate; their lanes' sums are dropped.
             unsigned int src[NP];
-            double pre[NP];
+            f64x2 pre[NP];
+            auto fetch = [&](unsigned int so) {     // 16 samples from `so` of every staged row, two per lane
+                if ((int64_t)so + ST_CH <= a.S) {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) pre[p] = *(const f64x2_u *)&a.X[src[p] + so];
+                } else {
+                    const int64_t s0 = (int64_t)so + 2 * l8;
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        pre[p].x = s0 < a.S ? a.X[src[p] + so] : 0.0;
+                        pre[p].y = s0 + 1 < a.S ? a.X[src[p] + so + 1] : 0.0;
+                    }
+                }
+            };
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 int rr = r0 + RP * p;
-                src[p] = (unsigned int)cj[b0 + (rr < nb ? rr : 0)] * (unsigned int)a.S + (unsigned int)l16;
-                pre[p] = (rr < nb && l16 < a.S) ? a.X[src[p]] : 0.0;
+                src[p] = (unsigned int)cj[b0 + (rr < nb ? rr : 0)] * (unsigned int)a.S + 2u * (unsigned int)l8;
             }
+            fetch(0u);
             double acc = 0.0;                     // sequential sum / tail sum of the last leaf
             double r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             double vs[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -842,12 +803,9 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : 8) * NT / 256) void k_finish(F
             for (int64_t c0 = 0; c0 < a.S; c0 += ST_CH) {
                 __syncthreads();
 #pragma unroll
-                for (int p = 0; p < NP; ++p) stage[(r0 + RP * p) * ST_LD + l16] = pre[p];
+                for (int p = 0; p < NP; ++p) *(f64x2 *)&stage[(r0 + RP * p) * ST_LD + 2 * l8] = pre[p];
                 __syncthreads();
-                const int64_t sn = c0 + ST_CH + l16;
-                const unsigned int so = (unsigned int)(c0 + ST_CH);
-#pragma unroll
-                for (int p = 0; p < NP; ++p) pre[p] = (r0 + RP * p < nb && sn < a.S) ? a.X[src[p] + so] : 0.0;
+                if (c0 + ST_CH < a.S) fetch((unsigned int)(c0 + ST_CH));
                 if (SEQ && tid < CB && c0 + ST_CH <= a.S && a.xs_in_lds) {
                     // full chunk, left-to-right sum: 16-byte LDS reads, no per-element control flow
                     const double *sp_ = &stage[tid * ST_LD];
@@ -936,7 +894,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : 8) * NT / 256) void k_finish(F
     const int64_t cs = a.chrom_off[ch], ce = a.chrom_off[ch + 1];
     const int64_t orow = row - a.row_begin;
     __syncthreads();
-    if (R <= 2 * NT) {
+    {
         // Order by counting: element t goes to slot #{u : (d_u, j_u) < (d_t, j_t)}.  Every thread
         // streams the same (broadcast) LDS pairs, no round-to-round dependencies; the few
         // hundred comparisons per element beat the 28 dependent rounds of a bitonic network.
@@ -966,23 +924,6 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 4 : 8) * NT / 256) void k_finish(F
         for (int t = R + tid; t < a.k; t += NT) {     // fewer candidates than k: sentinels (wisetools.py:305-306)
             a.idx_out[orow * a.k + t] = -1;
             a.dist_out[orow * a.k + t] = SENTINEL_DISTANCE;
-        }
-    } else {
-        int q2 = 2;
-        while (q2 < R) q2 <<= 1;
-        for (int t = R + tid; t < q2; t += NT) { dk[t] = ~0ull; jv[t] = 0x7FFFFFFF; }
-        __syncthreads();
-        bitonic_pair(dk, jv, q2, tid, NT);
-        for (int t = tid; t < a.k; t += NT) {
-            int32_t oi = -1;
-            double od = SENTINEL_DISTANCE;
-            if (t < R && dk[t] != ~0ull) {
-                int64_t j = jv[t];
-                oi = (int32_t)(j < cs ? j : j - (ce - cs));
-                od = wc::f64_from_ordered(dk[t]);
-            }
-            a.idx_out[orow * a.k + t] = oi;
-            a.dist_out[orow * a.k + t] = od;
         }
     }
     if (tid == 0) a.row_stat[row] = R;  // >= 0: fast path, number of float64 re-scores
