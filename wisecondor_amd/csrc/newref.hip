@@ -496,6 +496,12 @@ __global__ __launch_bounds__(256, 4) void k_gram_thr16(const unsigned short *__r
 // One wave per row: q-th smallest sampled key, q scaled so that about `expect`
 // candidates of the full row pass `key <= thr` (distribution free: the sample is a
 // fixed pseudo-random subset of the rows).
+__device__ inline uint32_t umed3(uint32_t x, uint32_t y, uint32_t z) {   // v_med3_u32
+    const uint32_t lo = x < y ? x : y, hi = x < y ? y : x;
+    const uint32_t m = hi < z ? hi : z;
+    return lo > m ? lo : m;
+}
+
 template <int NV>   // keys per lane (M / 64 rounded up to 16 / 32 / 64)
 __global__ __launch_bounds__(256) void k_select_thr(const float *__restrict__ keys, int64_t ldo, int M,
                                                     const int *__restrict__ chrom_of_row,
@@ -508,13 +514,21 @@ __global__ __launch_bounds__(256) void k_select_thr(const float *__restrict__ ke
     const int per_lane = M / 64;
     uint32_t u[NV];
     const uint32_t FIN = wc::f32_ordered(FLT_MAX);
-    int mvalid = 0;   // wave-wide counts through ballots (scalar popcounts, no cross-lane traffic)
+    // per lane: how many keys are finite, and its four smallest keys (sorted a <= b <= c <= d)
+    int myvalid = 0;
+    uint32_t a4 = 0xFFFFFFFFu, b4 = 0xFFFFFFFFu, c4 = 0xFFFFFFFFu, d4 = 0xFFFFFFFFu;
 #pragma unroll
     for (int e = 0; e < NV; ++e) {
         u[e] = 0xFFFFFFFFu;
         if (e < per_lane) u[e] = wc::f32_ordered(keys[row * ldo + (int64_t)e * 64 + lane]);
-        mvalid += __popcll(__ballot(u[e] <= FIN));
+        myvalid += u[e] <= FIN;
+        d4 = umed3(c4, d4, u[e]);
+        c4 = umed3(b4, c4, u[e]);
+        b4 = umed3(a4, b4, u[e]);
+        a4 = a4 < u[e] ? a4 : u[e];
     }
+    int mvalid = myvalid;
+    for (int o = 32; o > 0; o >>= 1) mvalid += __shfl_xor(mvalid, o);
     int ch = chrom_of_row[row];
     int64_t nvalid = B - (chrom_off[ch + 1] - chrom_off[ch]);
     float result;
@@ -530,12 +544,24 @@ __global__ __launch_bounds__(256) void k_select_thr(const float *__restrict__ ke
         // so 20 leading bits (sign, exponent, 11 mantissa bits) suffice: the rest is rounded
         // UP, which can only admit more candidates
         uint32_t res = 0;
-        for (int bit = 31; bit >= 12; --bit) {
-            uint32_t trial = res | (1u << bit);
-            int c = 0;
+        if (q <= 48) {
+            // The q smallest of the row are spread over 64 lanes (mean q/64 <= 0.75 per lane): the
+            // lanes' four smallest hold them all but for a ~3e-4 chance per lane, and then the
+            // cut only moves up by one order statistic -- a few more candidates, nothing else.
+            for (int bit = 31; bit >= 12; --bit) {
+                const uint32_t trial = res | (1u << bit);
+                const int c = __popcll(__ballot(a4 < trial)) + __popcll(__ballot(b4 < trial)) +
+                              __popcll(__ballot(c4 < trial)) + __popcll(__ballot(d4 < trial));
+                if (c < q) res = trial;
+            }
+        } else {
+            for (int bit = 31; bit >= 12; --bit) {
+                uint32_t trial = res | (1u << bit);
+                int c = 0;
 #pragma unroll
-            for (int e = 0; e < NV; ++e) c += __popcll(__ballot(u[e] < trial));
-            if (c < q) res = trial;
+                for (int e = 0; e < NV; ++e) c += __popcll(__ballot(u[e] < trial));
+                if (c < q) res = trial;
+            }
         }
         res |= 0xFFFu;
         if (res > FIN) res = FIN;   // never beyond the largest finite key
