@@ -118,3 +118,27 @@ def test_error_reporting_through_the_c_abi(wt):
     # and the context is still usable afterwards
     idx, dst = wt.getReference(np.arange(40.0).reshape(10, 4), [5, 5], [5, 10], 2)
     assert idx.shape == (10, 2) and np.all(idx >= 0)
+
+
+def test_thresholds_are_reproducible():
+    """The admission thresholds (bf16 MFMA estimate -> 16-bit key codes -> order statistic) must
+    come out identical on every call: a run-to-run difference once exposed a packed-float32
+    hazard in the key-code epilogue (see the note on -fno-slp-vectorize in build.py)."""
+    import torch
+    from wisecondor_amd import _lib, distributed, synth
+    data, bins, _ = synth.corrected_matrix(250000, 100, seed=3)
+    X = torch.from_numpy(data).cuda()
+    job = distributed.NewrefJob(_lib.context(0), X, bins, 100, _lib.SUM_SEQUENTIAL)
+    st = job.st
+    seen = []
+    for it in range(3):
+        st.prepare()
+        st.thresholds(0, st.n_bins)
+        t = torch.empty(st.n_bins, dtype=torch.float32, device="cuda")
+        st.get_thr(0, st.n_bins, t)
+        torch.cuda.synchronize()
+        seen.append(t.cpu().numpy())
+        if it == 0:
+            job.run()          # dirty every workspace in between
+    assert np.array_equal(seen[0], seen[1]) and np.array_equal(seen[0], seen[2])
+    assert np.isfinite(seen[0]).all() and (seen[0] > 0).all()

@@ -13,8 +13,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwisecondor_hip.so")
 SOURCES = ["ctx.hip", "newref.hip", "testpath.hip", "prep.hip"]
+# -fno-slp-vectorize: the SLP vectoriser pairs float32 operations into v_pk_add_f32 /
+# v_pk_fma_f32; an in-place pair whose low half reads the destination's high half
+# (v_pk_add_f32 v[74:75], v[84:85], v[74:75] op_sel:[0,1]) returned run-to-run different
+# results on gfx950 in the threshold kernel.  Nothing here gains from packed float32 math.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+         "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
 
 
 def _hipcc():

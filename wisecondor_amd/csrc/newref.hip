@@ -139,7 +139,8 @@ __global__ void k_gather_samples(const unsigned short *__restrict__ A16, int64_t
                                  const float *__restrict__ norm_lo, const int *__restrict__ chrom_of_row,
                                  const int *__restrict__ sample_rows, int64_t M, int64_t Mpad,
                                  unsigned short *__restrict__ S16, float *__restrict__ s_norm_lo,
-                                 int *__restrict__ s_chrom) {
+                                 int *__restrict__ s_chrom, const int2 *__restrict__ chrom_range,
+                                 int2 *__restrict__ s_range) {
     int64_t m = blockIdx.x;
     bool real = m < M;
     int64_t src = real ? sample_rows[m] : 0;
@@ -148,6 +149,7 @@ __global__ void k_gather_samples(const unsigned short *__restrict__ A16, int64_t
     if (threadIdx.x == 0) {
         s_norm_lo[m] = real ? norm_lo[src] : INFINITY;
         s_chrom[m] = real ? chrom_of_row[src] : -2;
+        s_range[m] = real ? chrom_range[src] : make_int2(0, 0);
     }
 }
 
@@ -171,6 +173,17 @@ struct GramArgs {
     unsigned long long *list;
     int cap;
 };
+
+// 16-bit image of a non-negative float32 key for the threshold estimate: exponent and 8
+// mantissa bits, truncated (the estimate adds the bucket width back); 0xFFFF = not a candidate
+// (infinite / NaN lower bound).  Negative keys (near-identical rows) count as 0.
+__device__ inline unsigned int key_code16(float key) {
+    const unsigned int code = __float_as_uint(fmaxf(key, 0.f)) >> 15;
+    return key < INFINITY ? code : 0xFFFFu;
+}
+__device__ inline float key_from_code16(unsigned int code) {   // upper edge of the bucket
+    return __uint_as_float((code << 15) | 0x7FFFu);
+}
 
 // bits [a, b) of a 32-bit mask, a and b clipped to [0, 32]
 __device__ inline unsigned int run_mask(int a, int b) {
@@ -389,17 +402,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(256, 4) void k_gram_thr16(const unsigned short *__restrict__ P16,
                                                        const unsigned short *__restrict__ Q16, int64_t ld16,
                                                        int nslab, const float *__restrict__ nbP,
-                                                       const float *__restrict__ nbQ, const int *__restrict__ chP,
-                                                       const int *__restrict__ chQ, const int4 *__restrict__ tiles,
-                                                       int ntiles, float *__restrict__ keys, int64_t ldo) {
-    __shared__ __attribute__((aligned(16))) float sm[2 * TB * LDA + 4 * TB];
+                                                       const float *__restrict__ nbQ,
+                                                       const int2 *__restrict__ rangeQ,
+                                                       const int4 *__restrict__ tiles, int ntiles,
+                                                       unsigned int *__restrict__ keys, int64_t ldo) {
+    __shared__ __attribute__((aligned(16))) float sm[2 * TB * LDA + 2 * TB];
     float *As = sm;
     float *Bs = sm + TB * LDA;
     float *D = sm;
     float *nbPs = sm + 2 * TB * LDA;
     float *nbQs = nbPs + TB;
-    int *chPs = (int *)(nbQs + TB);
-    int *chQs = chPs + TB;
 
     const int chunk = (ntiles + 7) >> 3;
     const int t_id = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
@@ -409,13 +421,8 @@ __global__ __launch_bounds__(256, 4) void k_gram_thr16(const unsigned short *__r
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
     const int li = lane & 31, lh = lane >> 5;
-    if (tid < TB) {
-        nbPs[tid] = nbP[(int64_t)I * TB + tid];
-        chPs[tid] = chP[(int64_t)I * TB + tid];
-    } else {
-        nbQs[tid - TB] = nbQ[(int64_t)J * TB + tid - TB];
-        chQs[tid - TB] = chQ[(int64_t)J * TB + tid - TB];
-    }
+    if (tid < TB) nbPs[tid] = nbP[(int64_t)I * TB + tid];
+    else nbQs[tid - TB] = nbQ[(int64_t)J * TB + tid - TB];
     const int lrow = tid >> 3, lcol = (tid & 7) * 8;   // 8 bf16 = 16 bytes per thread and row
     const unsigned short *Pg = P16 + ((int64_t)I * TB + lrow) * ld16 + lcol;
     const unsigned short *Qg = Q16 + ((int64_t)J * TB + lrow) * ld16 + lcol;
@@ -464,6 +471,9 @@ __global__ __launch_bounds__(256, 4) void k_gram_thr16(const unsigned short *__r
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
         }
     }
+    const int cp = tid & 63, rq = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float nbc0 = nbQs[2 * cp], nbc1 = nbQs[2 * cp + 1];
+    const int2 rg0 = rangeQ[(int64_t)J * TB + 2 * cp], rg1 = rangeQ[(int64_t)J * TB + 2 * cp + 1];
     for (int h = 0; h < 2; ++h) {
         __syncthreads();
         if (wr == h) {
@@ -479,31 +489,43 @@ __global__ __launch_bounds__(256, 4) void k_gram_thr16(const unsigned short *__r
                     }
         }
         __syncthreads();
-        const int x = tid & 127, q = tid >> 7;
-        const float nbc = nbQs[x];
-        const int chc = chQs[x];
-        float *out = keys + ((int64_t)I * TB + h * 64 + q * 32) * ldo + (int64_t)J * TB + x;
-        for (int rr = 0; rr < 32; ++rr) {
-            int lr = q * 32 + rr, r = h * 64 + lr;
-            float key = fmaf(-2.f, D[lr * LDD + x], nbPs[r] + nbc);
-            if (chPs[r] == chc) key = INFINITY;
-            out[(int64_t)rr * ldo] = key;
+        // thread = column pair (2cp, 2cp+1) x 16 rows: one 32-bit store carries two 16-bit keys, a
+        // wave writes 256 contiguous bytes per row
+        const int base_row = I * TB + h * 64 + rq * 16;
+        float d0[16], d1[16];
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            d0[rr] = D[(rq * 16 + rr) * LDD + 2 * cp];
+            d1[rr] = D[(rq * 16 + rr) * LDD + 2 * cp + 1];
+        }
+        const f32x4 *nbv = (const f32x4 *)&nbPs[h * 64 + rq * 16];
+        const unsigned int ex0 = run_mask(rg0.x - base_row, rg0.y - base_row);
+        const unsigned int ex1 = run_mask(rg1.x - base_row, rg1.y - base_row);
+        unsigned int *out = keys + (((int64_t)base_row * ldo + (int64_t)J * TB) >> 1) + cp;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 nb4 = nbv[g4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int rr = 4 * g4 + e;
+                unsigned int c0 = key_code16(fmaf(-2.f, d0[rr], nb4[e] + nbc0));
+                unsigned int c1 = key_code16(fmaf(-2.f, d1[rr], nb4[e] + nbc1));
+                if ((ex0 >> rr) & 1u) c0 = 0xFFFFu;     // same chromosome: never a candidate
+                if ((ex1 >> rr) & 1u) c1 = 0xFFFFu;
+                out[(int64_t)rr * (ldo >> 1)] = c0 | (c1 << 16);
+            }
         }
     }
 }
 
-// ------------------------------------------------------- threshold selection ----
-// One wave per row: q-th smallest sampled key, q scaled so that about `expect`
-// candidates of the full row pass `key <= thr` (distribution free: the sample is a
-// fixed pseudo-random subset of the rows).
 __device__ inline uint32_t umed3(uint32_t x, uint32_t y, uint32_t z) {   // v_med3_u32
     const uint32_t lo = x < y ? x : y, hi = x < y ? y : x;
     const uint32_t m = hi < z ? hi : z;
     return lo > m ? lo : m;
 }
 
-template <int NV>   // keys per lane (M / 64 rounded up to 16 / 32 / 64)
-__global__ __launch_bounds__(256) void k_select_thr(const float *__restrict__ keys, int64_t ldo, int M,
+template <int NV>   // keys per lane (M / 64 rounded up to 16 / 32 / 64), two per 32-bit word
+__global__ __launch_bounds__(256) void k_select_thr(const unsigned int *__restrict__ keys, int64_t ldo, int M,
                                                     const int *__restrict__ chrom_of_row,
                                                     const int64_t *__restrict__ chrom_off, int64_t B,
                                                     int64_t row_begin, int64_t row_end, int expect, int cap,
@@ -511,21 +533,27 @@ __global__ __launch_bounds__(256) void k_select_thr(const float *__restrict__ ke
     const int lane = threadIdx.x & 63;
     int64_t row = row_begin + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= row_end) return;
-    const int per_lane = M / 64;
+    const int words = M / 128;            // 32-bit words per lane
     uint32_t u[NV];
-    const uint32_t FIN = wc::f32_ordered(FLT_MAX);
+    const uint32_t FIN = 0xFEFFu;         // largest code of a finite key
     // per lane: how many keys are finite, and its four smallest keys (sorted a <= b <= c <= d)
     int myvalid = 0;
-    uint32_t a4 = 0xFFFFFFFFu, b4 = 0xFFFFFFFFu, c4 = 0xFFFFFFFFu, d4 = 0xFFFFFFFFu;
+    uint32_t a4 = 0xFFFFu, b4 = 0xFFFFu, c4 = 0xFFFFu, d4 = 0xFFFFu;
+    const unsigned int *kr = keys + row * (ldo >> 1) + lane;
 #pragma unroll
-    for (int e = 0; e < NV; ++e) {
-        u[e] = 0xFFFFFFFFu;
-        if (e < per_lane) u[e] = wc::f32_ordered(keys[row * ldo + (int64_t)e * 64 + lane]);
-        myvalid += u[e] <= FIN;
-        d4 = umed3(c4, d4, u[e]);
-        c4 = umed3(b4, c4, u[e]);
-        b4 = umed3(a4, b4, u[e]);
-        a4 = a4 < u[e] ? a4 : u[e];
+    for (int e = 0; e < NV / 2; ++e) {
+        const uint32_t w = e < words ? kr[(int64_t)e * 64] : 0xFFFFFFFFu;
+        u[2 * e] = w & 0xFFFFu;
+        u[2 * e + 1] = w >> 16;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint32_t x = u[2 * e + t];
+            myvalid += x <= FIN;
+            d4 = umed3(c4, d4, x);
+            c4 = umed3(b4, c4, x);
+            b4 = umed3(a4, b4, x);
+            a4 = a4 < x ? a4 : x;
+        }
     }
     int mvalid = myvalid;
     for (int o = 32; o > 0; o >>= 1) mvalid += __shfl_xor(mvalid, o);
@@ -540,22 +568,21 @@ __global__ __launch_bounds__(256) void k_select_thr(const float *__restrict__ ke
         int64_t q = ((int64_t)expect * mvalid + nvalid - 1) / nvalid;
         if (q < 1) q = 1;
         if (q > mvalid) q = mvalid;
-        // bitwise search for the q-th smallest key; the threshold is only an admission cut,
-        // so 20 leading bits (sign, exponent, 11 mantissa bits) suffice: the rest is rounded
-        // UP, which can only admit more candidates
+        // bitwise search for the q-th smallest 16-bit key code; the threshold is only an
+        // admission cut, so the code's bucket is rounded UP, which can only admit more candidates
         uint32_t res = 0;
         if (q <= 48) {
             // The q smallest of the row are spread over 64 lanes (mean q/64 <= 0.75 per lane): the
             // lanes' four smallest hold them all but for a ~3e-4 chance per lane, and then the
             // cut only moves up by one order statistic -- a few more candidates, nothing else.
-            for (int bit = 31; bit >= 12; --bit) {
+            for (int bit = 15; bit >= 0; --bit) {
                 const uint32_t trial = res | (1u << bit);
                 const int c = __popcll(__ballot(a4 < trial)) + __popcll(__ballot(b4 < trial)) +
                               __popcll(__ballot(c4 < trial)) + __popcll(__ballot(d4 < trial));
                 if (c < q) res = trial;
             }
         } else {
-            for (int bit = 31; bit >= 12; --bit) {
+            for (int bit = 15; bit >= 0; --bit) {
                 uint32_t trial = res | (1u << bit);
                 int c = 0;
 #pragma unroll
@@ -563,9 +590,7 @@ __global__ __launch_bounds__(256) void k_select_thr(const float *__restrict__ ke
                 if (c < q) res = trial;
             }
         }
-        res |= 0xFFFu;
-        if (res > FIN) res = FIN;   // never beyond the largest finite key
-        result = wc::f32_from_ordered(res);
+        result = res > FIN ? FLT_MAX : key_from_code16(res);   // never beyond the largest finite key
     }
     if (lane == 0) thr[row] = result;
 }
@@ -1180,7 +1205,8 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
     if ((rc = st.s16.reserve(sizeof(unsigned short) * M * st.k_pad16))) return rc;
     if ((rc = st.s_norm_lo.reserve(sizeof(float) * M))) return rc;
     if ((rc = st.s_chrom.reserve(sizeof(int) * M))) return rc;
-    if ((rc = st.keys1.reserve(sizeof(float) * st.bins_pad * M))) return rc;
+    if ((rc = st.s_range.reserve(sizeof(int2) * M))) return rc;
+    if ((rc = st.keys1.reserve(sizeof(unsigned short) * st.bins_pad * M))) return rc;
     if ((rc = st.thr.reserve(sizeof(float) * st.bins_pad))) return rc;
     if ((rc = st.cnt.reserve(sizeof(int) * st.bins_pad))) return rc;
     if ((rc = st.list.reserve(sizeof(uint64_t) * st.bins_pad * st.cap))) return rc;
@@ -1238,7 +1264,8 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
     hipLaunchKernelGGL(k_gather_samples, dim3((unsigned)M), dim3(256), 0, stream,
                        (const unsigned short *)st.a16.as<unsigned short>(), st.k_pad16, st.norm_lo.as<float>(),
                        st.chrom_of_row.as<int>(), st.sample_rows.as<int>(), std::min<int64_t>(M, n_bins), M,
-                       st.s16.as<unsigned short>(), st.s_norm_lo.as<float>(), st.s_chrom.as<int>());
+                       st.s16.as<unsigned short>(), st.s_norm_lo.as<float>(), st.s_chrom.as<int>(),
+                       (const int2 *)st.chrom_range.as<int2>(), st.s_range.as<int2>());
     hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)((st.bins_pad + 255) / 256)), dim3(256), 0, stream,
                        st.thr.as<float>(), st.bins_pad, -INFINITY);
     WC_HIP(hipMemsetAsync(st.cnt.p, 0, sizeof(int) * st.bins_pad, stream));
@@ -1276,12 +1303,12 @@ int wc_newref_thresholds_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int6
                            (const unsigned short *)st.a16.as<unsigned short>(),
                            (const unsigned short *)st.s16.as<unsigned short>(), st.k_pad16, (int)(st.k_pad16 / 64),
                            (const float *)st.norm_lo.as<float>(), (const float *)st.s_norm_lo.as<float>(),
-                           (const int *)st.chrom_of_row.as<int>(), (const int *)st.s_chrom.as<int>(),
-                           (const int4 *)st.tiles0.as<int4>(), ntiles, st.keys1.as<float>(), st.n_sample_cols);
+                           (const int2 *)st.s_range.as<int2>(), (const int4 *)st.tiles0.as<int4>(), ntiles,
+                           st.keys1.as<unsigned int>(), st.n_sample_cols);
     }
     unsigned sg = (unsigned)((row_end - row_begin + 3) / 4);
     {
-        const float *kp = st.keys1.as<float>();
+        const unsigned int *kp = st.keys1.as<unsigned int>();
         const int *cr = st.chrom_of_row.as<int>();
         const int64_t *co = st.chrom_off_dev.as<int64_t>();
         const int per_lane = (int)(st.n_sample_cols / 64);
