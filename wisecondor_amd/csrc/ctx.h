@@ -21,13 +21,13 @@ struct NewrefState {
     bool prepared = false;
     // device buffers
     wc::DevBuf col_partial, col_mean, a32, norm_lo, norm_hi, chrom_of_row, chrom_range, chrom_off_dev;
-    wc::DevBuf sample_rows, s32, s_norm_lo, s_chrom, s_range, a16, s16;
+    wc::DevBuf sample_rows, sample_slot, s32, s_norm_lo, s_chrom, s_range, a16, s16;
     wc::DevBuf keys1, thr, cnt, list, tiles;
     wc::DevBuf fb_rows, fb_count, fb_scratch, stats, tiles0, pw_prog;
     int pw_leaves = 0;
     int64_t pw_for = -1;
     // host-side caches so that repeated calls on the same layout enqueue kernels only
-    std::vector<int64_t> sample_key, tiles0_key, tiles1_key;
+    std::vector<int64_t> sample_key, tiles0_key, tiles1_key, chrom_key;
     int64_t tiles0_n = 0, tiles1_n = 0;
 };
 
@@ -72,7 +72,7 @@ struct wc_ctx {
 
     std::vector<wc::DevBuf *> all_buffers() {
         return {&nr.col_partial, &nr.col_mean, &nr.a32, &nr.norm_lo, &nr.norm_hi, &nr.chrom_of_row, &nr.chrom_range,
-                &nr.chrom_off_dev, &nr.sample_rows, &nr.s32, &nr.s_norm_lo, &nr.s_chrom, &nr.s_range, &nr.keys1,
+                &nr.chrom_off_dev, &nr.sample_rows, &nr.sample_slot, &nr.s32, &nr.s_norm_lo, &nr.s_chrom, &nr.s_range, &nr.keys1,
                 &nr.thr, &nr.cnt, &nr.list, &nr.tiles, &nr.fb_rows, &nr.fb_count, &nr.fb_scratch,
                 &nr.stats, &nr.tiles0, &nr.pw_prog, &nr.a16, &nr.s16, &tmp_a, &tmp_b, &tmp_c, &tmp_d,
                 &ts.counts, &ts.totals, &ts.raw, &ts.proj, &ts.data, &ts.xt, &ts.xc, &ts.zt, &ts.rt, &ts.nt,

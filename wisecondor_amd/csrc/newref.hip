@@ -100,16 +100,24 @@ __global__ __launch_bounds__(256) void k_convert(const double *__restrict__ X, i
                                                  float *__restrict__ A, unsigned short *__restrict__ A16,
                                                  int64_t Kpad16, float *__restrict__ norm_lo,
                                                  float *__restrict__ norm_hi, int *__restrict__ chrom_of_row,
-                                                 int2 *__restrict__ chrom_range) {
+                                                 int2 *__restrict__ chrom_range,
+                                                 const int *__restrict__ sample_slot,
+                                                 unsigned short *__restrict__ S16, float *__restrict__ s_norm_lo,
+                                                 int *__restrict__ s_chrom, int2 *__restrict__ s_range,
+                                                 float *__restrict__ thr, int *__restrict__ cnt,
+                                                 int *__restrict__ row_stat) {
     int lane = threadIdx.x & 63;
     int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= Bpad) return;
+    const int slot = row < B ? sample_slot[row] : -1;   // >= 0: this row is one of the sampled rows
     double acc = 0.0;
     for (int64_t s = lane; s < Kpad16; s += 64) {
         float a = 0.f;
         if (row < B && s < S) a = (float)(X[row * S + s] - mean[s]);
         if (s < Kpad) A[row * Kpad + s] = a;
-        A16[row * Kpad16 + s] = f32_to_bf16(a);
+        const unsigned short h = f32_to_bf16(a);
+        A16[row * Kpad16 + s] = h;
+        if (slot >= 0) S16[(int64_t)slot * Kpad16 + s] = h;
         acc += (double)a * (double)a;
     }
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
@@ -132,31 +140,32 @@ __global__ __launch_bounds__(256) void k_convert(const double *__restrict__ X, i
         norm_lo[row] = lo;
         norm_hi[row] = hi;
         chrom_of_row[row] = ch;
+        if (slot >= 0) {
+            s_norm_lo[slot] = lo;
+            s_chrom[slot] = ch;
+            s_range[slot] = range;
+        }
+        // per-row state of a new job: nothing admitted, no candidates, not finished
+        thr[row] = -INFINITY;
+        cnt[row] = 0;
+        row_stat[row] = (int)0xFEFEFEFE;
     }
 }
 
-__global__ void k_gather_samples(const unsigned short *__restrict__ A16, int64_t Kpad16,
-                                 const float *__restrict__ norm_lo, const int *__restrict__ chrom_of_row,
-                                 const int *__restrict__ sample_rows, int64_t M, int64_t Mpad,
-                                 unsigned short *__restrict__ S16, float *__restrict__ s_norm_lo,
-                                 int *__restrict__ s_chrom, const int2 *__restrict__ chrom_range,
-                                 int2 *__restrict__ s_range) {
-    int64_t m = blockIdx.x;
-    bool real = m < M;
-    int64_t src = real ? sample_rows[m] : 0;
-    for (int64_t s = threadIdx.x; s < Kpad16; s += blockDim.x)
-        S16[m * Kpad16 + s] = real ? A16[src * Kpad16 + s] : (unsigned short)0;
+// Sample slots beyond the real rows (problems with fewer bins than sample columns): zero
+// rows that can never be candidates.
+__global__ void k_pad_samples(int64_t Kpad16, int64_t first, unsigned short *__restrict__ S16,
+                              float *__restrict__ s_norm_lo, int *__restrict__ s_chrom,
+                              int2 *__restrict__ s_range) {
+    int64_t m = first + blockIdx.x;
+    for (int64_t s = threadIdx.x; s < Kpad16; s += blockDim.x) S16[m * Kpad16 + s] = (unsigned short)0;
     if (threadIdx.x == 0) {
-        s_norm_lo[m] = real ? norm_lo[src] : INFINITY;
-        s_chrom[m] = real ? chrom_of_row[src] : -2;
-        s_range[m] = real ? chrom_range[src] : make_int2(0, 0);
+        s_norm_lo[m] = INFINITY;
+        s_chrom[m] = -2;
+        s_range[m] = make_int2(0, 0);
     }
 }
 
-__global__ void k_fill_f32(float *p, int64_t n, float v) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
-}
 
 // --------------------------------------------------------------- Gram tiles ----
 struct GramArgs {
@@ -1201,6 +1210,7 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
     if ((rc = st.chrom_range.reserve(sizeof(int2) * st.bins_pad))) return rc;
     if ((rc = st.chrom_off_dev.reserve(sizeof(int64_t) * (WC_MAX_CHROM + 1)))) return rc;
     if ((rc = st.sample_rows.reserve(sizeof(int) * M))) return rc;
+    if ((rc = st.sample_slot.reserve(sizeof(int) * st.bins_pad))) return rc;
     if ((rc = st.a16.reserve(sizeof(unsigned short) * st.bins_pad * st.k_pad16))) return rc;
     if ((rc = st.s16.reserve(sizeof(unsigned short) * M * st.k_pad16))) return rc;
     if ((rc = st.s_norm_lo.reserve(sizeof(float) * M))) return rc;
@@ -1214,8 +1224,15 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
     if ((rc = st.fb_count.reserve(sizeof(int) * 4))) return rc;
     if ((rc = st.stats.reserve(sizeof(int) * st.bins_pad))) return rc;
 
-    WC_HIP(hipMemcpyAsync(st.chrom_off_dev.p, st.chrom_off, sizeof(int64_t) * (n_chrom + 1),
-                          hipMemcpyHostToDevice, stream));
+    {
+        std::vector<int64_t> ckey(st.chrom_off, st.chrom_off + n_chrom + 1);
+        if (ckey != st.chrom_key) {     // the device copy is uploaded once per layout
+            WC_HIP(hipMemcpyAsync(st.chrom_off_dev.p, st.chrom_off, sizeof(int64_t) * (n_chrom + 1),
+                                  hipMemcpyHostToDevice, stream));
+            WC_HIP(hipStreamSynchronize(stream));
+            st.chrom_key = ckey;
+        }
+    }
     if (st.pw_for != n_samples) {
         // numpy's pairwise split tree over n_samples, flattened: leaves in order with the
         // number of pending "add the two top partial sums" steps after each
@@ -1241,8 +1258,11 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
             std::swap(perm[i], perm[pick]);
         }
         std::sort(perm.begin(), perm.begin() + real);
+        std::vector<int> slot((size_t)n_bins, -1);   // row -> sample slot
+        for (int64_t i = 0; i < real; ++i) slot[perm[i]] = (int)i;
         WC_HIP(hipMemcpyAsync(st.sample_rows.p, perm.data(), sizeof(int) * real, hipMemcpyHostToDevice, stream));
-        WC_HIP(hipStreamSynchronize(stream));  // perm goes out of scope
+        WC_HIP(hipMemcpyAsync(st.sample_slot.p, slot.data(), sizeof(int) * n_bins, hipMemcpyHostToDevice, stream));
+        WC_HIP(hipStreamSynchronize(stream));  // perm and slot go out of scope
         st.sample_key = skey;
         st.tiles0_key.clear();
         st.tiles1_key.clear();
@@ -1260,16 +1280,13 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
                        n_samples, st.bins_pad, st.k_pad, (const double *)mean2, (double)st.beta,
                        st.chrom_off_dev.as<int64_t>(), n_chrom, st.a32.as<float>(), st.a16.as<unsigned short>(),
                        st.k_pad16, st.norm_lo.as<float>(), st.norm_hi.as<float>(), st.chrom_of_row.as<int>(),
-                       st.chrom_range.as<int2>());
-    hipLaunchKernelGGL(k_gather_samples, dim3((unsigned)M), dim3(256), 0, stream,
-                       (const unsigned short *)st.a16.as<unsigned short>(), st.k_pad16, st.norm_lo.as<float>(),
-                       st.chrom_of_row.as<int>(), st.sample_rows.as<int>(), std::min<int64_t>(M, n_bins), M,
+                       st.chrom_range.as<int2>(), (const int *)st.sample_slot.as<int>(),
                        st.s16.as<unsigned short>(), st.s_norm_lo.as<float>(), st.s_chrom.as<int>(),
-                       (const int2 *)st.chrom_range.as<int2>(), st.s_range.as<int2>());
-    hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)((st.bins_pad + 255) / 256)), dim3(256), 0, stream,
-                       st.thr.as<float>(), st.bins_pad, -INFINITY);
-    WC_HIP(hipMemsetAsync(st.cnt.p, 0, sizeof(int) * st.bins_pad, stream));
-    WC_HIP(hipMemsetAsync(st.stats.p, 0xFE, sizeof(int) * st.bins_pad, stream));  // "row not finished"
+                       st.s_range.as<int2>(), st.thr.as<float>(), st.cnt.as<int>(), st.stats.as<int>());
+    if (M > n_bins)
+        hipLaunchKernelGGL(k_pad_samples, dim3((unsigned)(M - n_bins)), dim3(256), 0, stream, st.k_pad16, n_bins,
+                           st.s16.as<unsigned short>(), st.s_norm_lo.as<float>(), st.s_chrom.as<int>(),
+                           st.s_range.as<int2>());
     WC_HIP(hipGetLastError());
     st.prepared = true;
     return WC_OK;
