@@ -611,6 +611,15 @@ template <class F> __device__ inline void scan_chunk(const ScanCtx &c, const dou
     }
 }
 
+// Extreme Stouffer values (prefix-sum estimates) of one block of window rows of a job.  Only
+// the two VALUES leave this kernel: the positions of near-extreme windows are re-derived by
+// k_seg_collect and ranked by their exact values, so nothing here tracks where the extreme
+// sits (4 float64 operations per window: subtract, scale, max, min).
+//   PLDS   the job's prefix slice is staged in LDS (one coalesced read per workgroup)
+//   MASKED -mineffectsize: windows whose validity bit is clear count as 0
+// A wave takes four consecutive window lengths per trip: their 1/sqrt(len) factors are one
+// scalar load, the four prefix values of a lane are adjacent.
+template <bool MASKED, bool PLDS>
 __global__ __launch_bounds__(256) void k_seg_search(const Job *__restrict__ jobs, int n_jobs,
                                                     const Region *__restrict__ regions,
                                                     const double *__restrict__ prefix, const double *__restrict__ rs,
@@ -618,35 +627,71 @@ __global__ __launch_bounds__(256) void k_seg_search(const Job *__restrict__ jobs
                                                     const unsigned int *__restrict__ bits,
                                                     const long long *__restrict__ bit_off,
                                                     Extreme *__restrict__ partial) {
-    __shared__ double smax[256], smin[256];
-    __shared__ int sx[256], sy[256], tx[256], ty[256];
+    extern __shared__ double pl[];
+    __shared__ double red_max[4], red_min[4];
     const int j = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
     if (j >= n_jobs) return;
     const Job job = jobs[j];
-    ScanCtx c;
-    c.lo = job.lo; c.hi = job.hi; c.L = job.hi - job.lo; c.half = (c.L + 1) / 2; c.chunk = chunk;
-    if (c.L <= 0 || chunk * ROWS_HALF >= c.half) return;
+    const int L = job.hi - job.lo, half = (L + 1) / 2;
+    if (L <= 0 || chunk * ROWS_HALF >= half) return;
     if (!reg_flag[job.region]) return;  // non-finite region: exact brute-force path
-    c.P = prefix + regions[job.region].off + job.region;
-    c.wm = WindowMask{bits, bits ? bit_off[job.region] : 0, regions[job.region].n};
-    double bmax = -INFINITY, bmin = INFINITY;
-    int mx = -1, my = -1, nx = -1, ny = -1;
-    scan_chunk(c, rs, tid, [&](double v, int x, int y) {
-        if (v > bmax) { bmax = v; mx = x; my = y; }
-        if (v < bmin) { bmin = v; nx = x; ny = y; }
-    });
-    smax[tid] = bmax; smin[tid] = bmin; sx[tid] = mx; sy[tid] = my; tx[tid] = nx; ty[tid] = ny;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) {
-            if (smax[tid + o] > smax[tid]) { smax[tid] = smax[tid + o]; sx[tid] = sx[tid + o]; sy[tid] = sy[tid + o]; }
-            if (smin[tid + o] < smin[tid]) { smin[tid] = smin[tid + o]; tx[tid] = tx[tid + o]; ty[tid] = ty[tid + o]; }
-        }
+    const double *Pg = prefix + regions[job.region].off + job.region + job.lo;   // Pg[0..L]
+    const double *P = Pg;
+    if (PLDS) {
+        for (int i = tid; i <= L; i += 256) pl[i] = Pg[i];
         __syncthreads();
+        P = pl;
     }
+    const WindowMask wm{bits, MASKED ? bit_off[job.region] : 0, regions[job.region].n};
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double bmax = -INFINITY, bmin = INFINITY;
+    for (int side = 0; side < 2; ++side) {
+        int xr = chunk * ROWS_HALF + lane;
+        bool live;
+        if (side == 0) {
+            live = xr < half;
+        } else {
+            xr = L - 1 - xr;
+            live = xr >= half;
+        }
+        // longest window among the rows of this block (lane 0 has the smallest / largest start)
+        const int xr_min = side == 0 ? chunk * ROWS_HALF : L - 1 - (chunk * ROWS_HALF + 63);
+        const int max_len = L - (xr_min < 0 ? 0 : xr_min);
+        const int xl = live ? xr : 0;
+        const double px = P[xl];
+        const int room = live ? L - xl : 0;            // windows [xl, xl + len - 1] with len <= room
+        for (int base = 1 + 4 * w; base <= max_len; base += 16) {
+            double r[4], pv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                r[u] = rs[base + u];                                   // wave-uniform (table padded by 4)
+                const int len = base + u;
+                pv[u] = P[xl + (len < room ? len : room)];             // always inside the slice
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int len = base + u;
+                if (len <= room) {
+                    double v = (pv[u] - px) * r[u];
+                    if (MASKED && !wm.valid(job.lo + xl, job.lo + xl + len - 1)) v = 0.0;
+                    bmax = fmax(bmax, v);
+                    bmin = fmin(bmin, v);
+                }
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        bmax = fmax(bmax, __shfl_xor(bmax, o));
+        bmin = fmin(bmin, __shfl_xor(bmin, o));
+    }
+    if (lane == 0) { red_max[w] = bmax; red_min[w] = bmin; }
+    __syncthreads();
     if (tid == 0) {
         Extreme e;
-        e.maxv = smax[0]; e.minv = smin[0]; e.max_x = sx[0]; e.max_y = sy[0]; e.min_x = tx[0]; e.min_y = ty[0];
+        e.maxv = fmax(fmax(red_max[0], red_max[1]), fmax(red_max[2], red_max[3]));
+        e.minv = fmin(fmin(red_min[0], red_min[1]), fmin(red_min[2], red_min[3]));
+        e.max_x = e.max_y = e.min_x = e.min_y = -1;
         partial[(int64_t)j * max_chunks + chunk] = e;
     }
 }
@@ -1087,9 +1132,9 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     if ((rc = ts.prefix.reserve(sizeof(double) * (total_len + n_regions + 8)))) return rc;
     if ((rc = ts.reg_abs.reserve(sizeof(double) * n_regions))) return rc;
     if ((rc = ts.reg_flag.reserve(sizeof(int) * n_regions))) return rc;
-    if (ts.rs_len < max_n + 2) {
-        if ((rc = ts.rs.reserve(sizeof(double) * (max_n + 2)))) return rc;
-        ts.rs_len = max_n + 2;
+    if (ts.rs_len < max_n + 8) {     // the search reads four lengths at a time past the longest window
+        if ((rc = ts.rs.reserve(sizeof(double) * (max_n + 8)))) return rc;
+        ts.rs_len = max_n + 8;
         hipLaunchKernelGGL(k_fill_rs, dim3((unsigned)cdiv(ts.rs_len, 256)), dim3(256), 0, stream, ts.rs.as<double>(),
                            ts.rs_len);
     }
@@ -1145,9 +1190,17 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
         WC_HIP(hipMemsetAsync(counters + 1, 0, sizeof(int) * 3, stream));
         WC_HIP(hipMemsetAsync(ts.cand_cnt.p, 0, sizeof(int) * 2 * n_jobs, stream));
         dim3 sg((unsigned)max_chunks, (unsigned)n_jobs);
-        hipLaunchKernelGGL(k_seg_search, sg, dim3(256), 0, stream, (const Job *)cur, (int)n_jobs, regions_dev,
-                           (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
-                           (const int *)ts.reg_flag.as<int>(), max_chunks, bits, bit_off, ts.partial.as<Extreme>());
+        {
+            const bool plds = max_n + 1 <= 6144;      // the longest region's prefix slice fits 48 KB of LDS
+            const size_t dyn = plds ? sizeof(double) * (max_n + 1) : 0;
+#define WC_SEARCH(M, P_)                                                                                          \
+    hipLaunchKernelGGL((k_seg_search<M, P_>), sg, dim3(256), dyn, stream, (const Job *)cur, (int)n_jobs, regions_dev, \
+                       (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),                   \
+                       (const int *)ts.reg_flag.as<int>(), max_chunks, bits, bit_off, ts.partial.as<Extreme>())
+            if (bits) { if (plds) WC_SEARCH(true, true); else WC_SEARCH(true, false); }
+            else { if (plds) WC_SEARCH(false, true); else WC_SEARCH(false, false); }
+#undef WC_SEARCH
+        }
         hipLaunchKernelGGL(k_seg_classify, dim3((unsigned)n_jobs), dim3(64), 0, stream, (const Job *)cur, (int)n_jobs,
                            regions_dev, (const double *)ts.reg_abs.as<double>(), (const int *)ts.reg_flag.as<int>(),
                            (const Extreme *)ts.partial.as<Extreme>(), max_chunks, thr, ts.job_res.as<Extreme>(), hot,
