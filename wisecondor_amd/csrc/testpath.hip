@@ -750,6 +750,7 @@ __global__ __launch_bounds__(256) void k_seg_collect(const Job *__restrict__ job
                                                      const double *__restrict__ prefix, const double *__restrict__ rs,
                                                      const double *__restrict__ reg_abs,
                                                      const Extreme *__restrict__ job_res,
+                                                     const Extreme *__restrict__ partial, int max_chunks,
                                                      const unsigned int *__restrict__ bits,
                                                      const long long *__restrict__ bit_off, int2 *__restrict__ cand,
                                                      int *__restrict__ cand_cnt) {
@@ -765,6 +766,10 @@ __global__ __launch_bounds__(256) void k_seg_collect(const Job *__restrict__ job
     const double eps2 = 2.0 * window_eps(regions[job.region].n, reg_abs[job.region]);
     const Extreme e = job_res[j];
     const double hi_cut = e.maxv - eps2, lo_cut = e.minv + eps2;
+    {   // the search left this block's own extremes behind: most blocks hold no near-extreme window
+        const Extreme p = partial[(int64_t)j * max_chunks + chunk];
+        if (p.maxv < hi_cut && p.minv > lo_cut) return;
+    }
     scan_chunk(c, rs, tid, [&](double v, int x, int y) {
         if (v >= hi_cut) {
             int at = atomicAdd(&cand_cnt[2 * h], 1);
@@ -1220,7 +1225,8 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
                                (const Job *)cur, (const int *)hot, (const int *)counters, regions_dev,
                                (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
                                (const double *)ts.reg_abs.as<double>(), (const Extreme *)ts.job_res.as<Extreme>(),
-                               bits, bit_off, ts.cand.as<int2>(), ts.cand_cnt.as<int>());
+                               (const Extreme *)ts.partial.as<Extreme>(), max_chunks, bits, bit_off,
+                               ts.cand.as<int2>(), ts.cand_cnt.as<int>());
             hipLaunchKernelGGL(k_seg_decide, dim3((unsigned)n_hot), dim3(256), 0, stream, (const Job *)cur,
                                (const int *)hot, counters, regions_dev, z_dev, (const int2 *)ts.cand.as<int2>(),
                                (const int *)ts.cand_cnt.as<int>(), thr, min_search, bits, bit_off, ts.seg.as<Seg>(),
