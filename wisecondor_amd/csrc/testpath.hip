@@ -264,9 +264,36 @@ __global__ __launch_bounds__(256) void k_zscore(const double *__restrict__ XT, c
         }
         if ((double)kept == nT[gid]) return;
     }
+    // Two passes over the kept references in numpy's pairwise order (StreamSum).  While every
+    // lane of the wave has kept all of its values so far, element r goes to accumulator r & 7:
+    // whole groups of eight are added straight into the eight strided accumulators (eight
+    // independent loads in flight, no slot selection).  The first dropped value anywhere in
+    // the wave ends that: the rest of the list takes the general push().
     StreamSum acc;
     acc.init();
-    for (int r = 0; r < n; ++r) {
+    int fast_end = 0;      // references [0, fast_end) were consumed in whole, fully kept groups
+    {
+        bool ok = true;
+        while (ok) {
+            const int r0 = fast_end;
+            double v[8];
+            bool mine = r0 + 8 <= n;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                int g = mine ? lst[r0 + e] : -1;
+                v[e] = g >= 0 ? XC[(int64_t)g * Ns + i] : -1.0;
+                mine = mine && (v[e] >= 0.0);
+            }
+            ok = __all(mine);
+            if (ok) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc.r[e] = acc.r[e] + v[e];   // first group: 0 + v == v exactly (v >= 0)
+                fast_end = r0 + 8;
+            }
+        }
+        acc.pos = fast_end;
+    }
+    for (int r = fast_end; r < n; ++r) {
         int g = lst[r];
         double v = g >= 0 ? XC[(int64_t)g * Ns + i] : -1.0;
         if (v >= 0.0) acc.push(v);  // flagged (-1), negative and NaN values are dropped (wisetools.py:425)
@@ -274,7 +301,19 @@ __global__ __launch_bounds__(256) void k_zscore(const double *__restrict__ XT, c
     const int m = acc.pos;
     const double mean = acc.finish() / (double)m;
     acc.init();
-    for (int r = 0; r < n; ++r) {
+    for (int r0 = 0; r0 < fast_end; r0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = XC[(int64_t)lst[r0 + e] * Ns + i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            double dv = v[e] - mean;
+            double sq = dv * dv;
+            acc.r[e] = acc.r[e] + sq;
+        }
+    }
+    acc.pos = fast_end;
+    for (int r = fast_end; r < n; ++r) {
         int g = lst[r];
         double v = g >= 0 ? XC[(int64_t)g * Ns + i] : -1.0;
         if (v >= 0.0) {
