@@ -33,6 +33,7 @@ struct NewrefState {
 
 // Workspaces of the batched test path (grow-only, reused across calls).
 struct TestState {
+    std::vector<int> sel_host;      // chromosome selection currently held by `sel`
     wc::DevBuf counts, totals, raw, proj, data, xt, xc, zt, rt, nt, sdt, z, r, n, sd_avg;
     wc::DevBuf zc, rc, gpos, clean_n, regions, sel;
     wc::DevBuf res_z, res_r, cwz, calls, n_calls;
@@ -62,6 +63,16 @@ struct wc_ctx {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool side_pending = false;
+    // small pinned host block for count read-backs (a pageable destination costs a staged copy)
+    int ensure_pinned(size_t bytes) {
+        if (pinned_bytes >= bytes) return WC_OK;
+        if (pinned) (void)hipHostFree(pinned);
+        pinned = nullptr;
+        pinned_bytes = 0;
+        WC_HIP(hipHostMalloc(&pinned, bytes, hipHostMallocDefault));
+        pinned_bytes = bytes;
+        return WC_OK;
+    }
     int ensure_side_stream() {
         if (side) return WC_OK;
         WC_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));

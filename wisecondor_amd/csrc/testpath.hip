@@ -1225,6 +1225,9 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     Job *cur = ts.jobs_a.as<Job>(), *next = ts.jobs_b.as<Job>();
     int64_t n_jobs = n_regions;
     int guard = 0;
+    if ((rc = ctx->ensure_pinned(256))) return rc;
+    int *h = (int *)ctx->pinned;          // counter read-backs land in pinned memory
+    h[4] = 0;
     while (n_jobs > 0) {
         WC_CHECK(++guard < 100000, WC_E_INTERNAL, "stouffer: recursion did not terminate");
         // per-round scratch is sized by the jobs of this round, not by the worst case
@@ -1252,9 +1255,8 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
         // The number of hot jobs lives on the device.  Small rounds (latency mode, child
         // ranges) launch the follow-up kernels for the upper bound n_jobs and let surplus
         // workgroups exit, which saves a host round trip; big rounds read the count back.
-        int h[8];
         int n_hot = (int)n_jobs;
-        if (n_jobs > 512) {
+        if (n_jobs * max_chunks > 65536) {
             WC_HIP(hipMemcpyAsync(h, counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
             WC_HIP(hipStreamSynchronize(stream));
             n_hot = h[2];
@@ -1282,10 +1284,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
         n_jobs = h[1];
         std::swap(cur, next);
     }
-    int h[8];
-    WC_HIP(hipMemcpyAsync(h, counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
-    WC_HIP(hipStreamSynchronize(stream));
-    ts.last_segs = h[4];
+    ts.last_segs = h[4];                  // from the last round's read-back
     if (h[4] > 0)
         hipLaunchKernelGGL(k_seg_gather, dim3((unsigned)cdiv(h[4], 256)), dim3(256), 0, stream,
                            (const Seg *)ts.seg.as<Seg>(), h[4], max_calls, ts.out_val.as<double>(), ts.out_x.as<int>(),
@@ -1578,8 +1577,11 @@ int wc_test_batch_dev(wc_ctx *ctx, void *stream_, const wc_reference *ref, const
     if ((rc = ts.regions.reserve(sizeof(Region) * n_regions))) return rc;
     if ((rc = ts.effect.reserve(sizeof(double) * n_regions * max_calls * 5))) return rc;
     if ((rc = ts.misc.reserve(sizeof(int) * 4))) return rc;
-    WC_HIP(hipMemcpyAsync(ts.sel.p, sel.data(), sizeof(int) * n_sel, hipMemcpyHostToDevice, stream));
-    WC_HIP(hipStreamSynchronize(stream));
+    if (sel != ts.sel_host) {      // the device copy of the chromosome selection is reused across calls
+        WC_HIP(hipMemcpyAsync(ts.sel.p, sel.data(), sizeof(int) * n_sel, hipMemcpyHostToDevice, stream));
+        WC_HIP(hipStreamSynchronize(stream));
+        ts.sel_host = sel;
+    }
     hipLaunchKernelGGL(k_clean, dim3((unsigned)n_sel, (unsigned)Ns), dim3(64), 0, stream,
                        (const double *)ts.zt.as<double>(), (const double *)ts.rt.as<double>(),
                        (const double *)ts.nt.as<double>(), B, Ns, (const int64_t *)ref->moff_dev.as<int64_t>(),
@@ -1607,10 +1609,11 @@ int wc_test_batch_dev(wc_ctx *ctx, void *stream_, const wc_reference *ref, const
         hipLaunchKernelGGL(k_assemble_calls, dim3((unsigned)cdiv(Ns, 64)), dim3(64), 0, stream,
                            (const double *)ts.effect.as<double>(), (const int *)ts.out_n.as<int>(), n_sel, max_calls, Ns,
                            calls, n_calls, ts.misc.as<int>());
-        int overflow = 0;
-        WC_HIP(hipMemcpyAsync(&overflow, ts.misc.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+        if ((rc = ctx->ensure_pinned(256))) return rc;
+        int *overflow = (int *)ctx->pinned + 16;
+        WC_HIP(hipMemcpyAsync(overflow, ts.misc.p, sizeof(int), hipMemcpyDeviceToHost, stream));
         WC_HIP(hipStreamSynchronize(stream));
-        WC_CHECK(!overflow, WC_E_LIMIT, "test: a sample has more than max_calls=%d calls", max_calls);
+        WC_CHECK(!*overflow, WC_E_LIMIT, "test: a sample has more than max_calls=%d calls", max_calls);
     }
     WC_HIP(hipGetLastError());
     return WC_OK;
