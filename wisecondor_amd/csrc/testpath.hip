@@ -24,6 +24,7 @@ struct wc_reference {
 namespace {
 
 constexpr int MAX_COMP = 8;
+constexpr int SHORT_SEG = 1024;  // segments up to this length take the counting median in k_call_post
 constexpr int ROWS_HALF = 64;  // window rows per side handled by one search workgroup (one lane each)
 constexpr int CAND_CAP = 64;
 
@@ -618,11 +619,12 @@ struct ScanCtx {
 // Rows handled by (job, chunk): ROWS_HALF rows from the top of the triangle and the
 // ROWS_HALF mirrored rows from the bottom, so every workgroup sees ~ the same work.
 // A lane owns one start bin x (its prefix value stays in a register); the four waves of
-// the workgroup take the window lengths len = 1 + w, 5 + w, ...: within a wave the length
+// the workgroup (nw waves) take the window lengths len = 1 + w, 1 + w + nw, ...: within a wave the length
 // is uniform, so rs[len] is one scalar load and P[x + len] one coalesced vector load.
 template <class F> __device__ inline void scan_chunk(const ScanCtx &c, const double *__restrict__ rs, int tid, F f) {
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = (int)(blockDim.x >> 6);
     for (int side = 0; side < 2; ++side) {
         int xr = c.chunk * ROWS_HALF + lane;
         bool live;
@@ -638,7 +640,7 @@ template <class F> __device__ inline void scan_chunk(const ScanCtx &c, const dou
         const int x = c.lo + (live ? xr : 0);
         const double px = c.P[x];
         const int room = live ? c.hi - x : 0;            // windows [x, x + len - 1] with len <= room
-        for (int len = 1 + w; len <= max_len; len += 4) {
+        for (int len = 1 + w; len <= max_len; len += nw) {
             const double r = rs[len];
             if (len <= room) {
                 const int y = x + len - 1;
@@ -658,8 +660,8 @@ template <class F> __device__ inline void scan_chunk(const ScanCtx &c, const dou
 //   MASKED -mineffectsize: windows whose validity bit is clear count as 0
 // A wave takes four consecutive window lengths per trip: their 1/sqrt(len) factors are one
 // scalar load, the four prefix values of a lane are adjacent.
-template <bool MASKED, bool PLDS>
-__global__ __launch_bounds__(256) void k_seg_search(const Job *__restrict__ jobs, int n_jobs,
+template <bool MASKED, bool PLDS, int NW>   // NW waves per block: 4, or 16 for rounds with few blocks (latency bound)
+__global__ __launch_bounds__(64 * NW) void k_seg_search(const Job *__restrict__ jobs, int n_jobs,
                                                     const Region *__restrict__ regions,
                                                     const double *__restrict__ prefix, const double *__restrict__ rs,
                                                     const int *__restrict__ reg_flag, int max_chunks,
@@ -667,7 +669,7 @@ __global__ __launch_bounds__(256) void k_seg_search(const Job *__restrict__ jobs
                                                     const long long *__restrict__ bit_off,
                                                     Extreme *__restrict__ partial) {
     extern __shared__ double pl[];
-    __shared__ double red_max[4], red_min[4];
+    __shared__ double red_max[NW], red_min[NW];
     const int j = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
     if (j >= n_jobs) return;
     const Job job = jobs[j];
@@ -677,7 +679,7 @@ __global__ __launch_bounds__(256) void k_seg_search(const Job *__restrict__ jobs
     const double *Pg = prefix + regions[job.region].off + job.region + job.lo;   // Pg[0..L]
     const double *P = Pg;
     if (PLDS) {
-        for (int i = tid; i <= L; i += 256) pl[i] = Pg[i];
+        for (int i = tid; i <= L; i += 64 * NW) pl[i] = Pg[i];
         __syncthreads();
         P = pl;
     }
@@ -700,7 +702,7 @@ __global__ __launch_bounds__(256) void k_seg_search(const Job *__restrict__ jobs
         const int xl = live ? xr : 0;
         const double px = P[xl];
         const int room = live ? L - xl : 0;            // windows [xl, xl + len - 1] with len <= room
-        for (int base = 1 + 4 * w; base <= max_len; base += 16) {
+        for (int base = 1 + 4 * w; base <= max_len; base += 4 * NW) {
             double r[4], pv[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -728,8 +730,9 @@ __global__ __launch_bounds__(256) void k_seg_search(const Job *__restrict__ jobs
     __syncthreads();
     if (tid == 0) {
         Extreme e;
-        e.maxv = fmax(fmax(red_max[0], red_max[1]), fmax(red_max[2], red_max[3]));
-        e.minv = fmin(fmin(red_min[0], red_min[1]), fmin(red_min[2], red_min[3]));
+        e.maxv = red_max[0];
+        e.minv = red_min[0];
+        for (int q = 1; q < NW; ++q) { e.maxv = fmax(e.maxv, red_max[q]); e.minv = fmin(e.minv, red_min[q]); }
         e.max_x = e.max_y = e.min_x = e.min_y = -1;
         partial[(int64_t)j * max_chunks + chunk] = e;
     }
@@ -783,7 +786,7 @@ __global__ __launch_bounds__(64) void k_seg_classify(const Job *__restrict__ job
 
 // Second scan of the hot jobs: every window within 2 eps of the approximate
 // maximum (minimum) could be numpy's argmax (argmin); list them for exact scoring.
-__global__ __launch_bounds__(256) void k_seg_collect(const Job *__restrict__ jobs, const int *__restrict__ hot,
+__global__ __launch_bounds__(1024) void k_seg_collect(const Job *__restrict__ jobs, const int *__restrict__ hot,
                                                      const int *__restrict__ counters,
                                                      const Region *__restrict__ regions,
                                                      const double *__restrict__ prefix, const double *__restrict__ rs,
@@ -1036,7 +1039,29 @@ __global__ __launch_bounds__(256) void k_call_post(const Seg *__restrict__ segs,
     const bool has_nan = s_flag[1] != 0;
     if (rank >= max_calls) return;
     double lo = 0.0, hi = 0.0;
-    if (!has_nan) {
+    if (!has_nan && L <= SHORT_SEG) {
+        // short segment: each value counts how many others lie below / at-or-below it; the
+        // value whose count interval covers a middle rank is that order statistic
+        __shared__ double sv[SHORT_SEG];
+        __shared__ double s_mid[2];
+        for (int e = tid; e < L; e += 256) sv[e] = v[e];
+        __syncthreads();
+        const int k_lo = (L - 1) / 2, k_hi = L / 2;
+        for (int e = tid; e < L; e += 256) {
+            const double xv = sv[e];
+            int lt = 0, le = 0;
+            for (int u = 0; u < L; ++u) {
+                const double yv = sv[u];
+                lt += yv < xv;
+                le += yv <= xv;
+            }
+            if (lt <= k_lo && k_lo < le) s_mid[0] = xv;      // equal values write the same number
+            if (lt <= k_hi && k_hi < le) s_mid[1] = xv;
+        }
+        __syncthreads();
+        lo = s_mid[0];
+        hi = s_mid[1];
+    } else if (!has_nan) {
         lo = block_select(v, L, (L - 1) / 2, tid);
         hi = (L & 1) ? lo : block_select(v, L, L / 2, tid);
     }
@@ -1240,12 +1265,15 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
         {
             const bool plds = max_n + 1 <= 6144;      // the longest region's prefix slice fits 48 KB of LDS
             const size_t dyn = plds ? sizeof(double) * (max_n + 1) : 0;
-#define WC_SEARCH(M, P_)                                                                                          \
-    hipLaunchKernelGGL((k_seg_search<M, P_>), sg, dim3(256), dyn, stream, (const Job *)cur, (int)n_jobs, regions_dev, \
-                       (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),                   \
+#define WC_SEARCH(M, P_, NW_)                                                                                     \
+    hipLaunchKernelGGL((k_seg_search<M, P_, NW_>), sg, dim3(64 * NW_), dyn, stream, (const Job *)cur, (int)n_jobs,   \
+                       regions_dev, (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),     \
                        (const int *)ts.reg_flag.as<int>(), max_chunks, bits, bit_off, ts.partial.as<Extreme>())
-            if (bits) { if (plds) WC_SEARCH(true, true); else WC_SEARCH(true, false); }
-            else { if (plds) WC_SEARCH(false, true); else WC_SEARCH(false, false); }
+#define WC_SEARCH_NW(M, P_) do { if (wide) WC_SEARCH(M, P_, 16); else WC_SEARCH(M, P_, 4); } while (0)
+            const bool wide = n_jobs * max_chunks <= 2048;     // few blocks: sixteen waves each
+            if (bits) { if (plds) WC_SEARCH_NW(true, true); else WC_SEARCH_NW(true, false); }
+            else { if (plds) WC_SEARCH_NW(false, true); else WC_SEARCH_NW(false, false); }
+#undef WC_SEARCH_NW
 #undef WC_SEARCH
         }
         hipLaunchKernelGGL(k_seg_classify, dim3((unsigned)n_jobs), dim3(64), 0, stream, (const Job *)cur, (int)n_jobs,
@@ -1262,7 +1290,8 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
             n_hot = h[2];
         }
         if (n_hot > 0) {
-            hipLaunchKernelGGL(k_seg_collect, dim3((unsigned)max_chunks, (unsigned)n_hot), dim3(256), 0, stream,
+            // only a few blocks survive the pruning; sixteen waves each keep their scan short
+            hipLaunchKernelGGL(k_seg_collect, dim3((unsigned)max_chunks, (unsigned)n_hot), dim3(1024), 0, stream,
                                (const Job *)cur, (const int *)hot, (const int *)counters, regions_dev,
                                (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
                                (const double *)ts.reg_abs.as<double>(), (const Extreme *)ts.job_res.as<Extreme>(),
