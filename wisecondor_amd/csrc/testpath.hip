@@ -355,44 +355,49 @@ __global__ void k_flag(const double *__restrict__ zT, double thr, int64_t n, int
 __global__ __launch_bounds__(256) void k_sd_avg(const double *__restrict__ sdT, int64_t B, int64_t Ns,
                                                 double *__restrict__ out) {
     __shared__ double buf[128][64];
+    __shared__ int cnts[4][64];
     const int ss = threadIdx.x & 63, bq = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + ss;
     const bool live = i < Ns;
+    // The staging threads do everything that is not the chain: NaN terms (and bins past the
+    // end) become +0.0 -- exact for a sum of sds >= +0 -- and are left out of the count, so the
+    // adding wave issues one LDS read and one add per bin.
     double pre[32];
+    int cnt = 0;
+    auto fetch = [&](int64_t base) {
 #pragma unroll
-    for (int u = 0; u < 32; ++u) {
-        int64_t b = bq + 4 * u;
-        pre[u] = (live && b < B) ? sdT[b * Ns + i] : NAN;
-    }
+        for (int u = 0; u < 32; ++u) {
+            const int64_t b = base + bq + 4 * u;
+            const double x = (live && b < B) ? sdT[b * Ns + i] : NAN;
+            const bool ok = x == x;
+            cnt += ok;
+            pre[u] = ok ? x : 0.0;
+        }
+    };
+    fetch(0);
     double s = 0.0;
-    long long c = 0;
     for (int64_t b0 = 0; b0 < B; b0 += 128) {
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < 32; ++u) buf[bq + 4 * u][ss] = pre[u];
         __syncthreads();
-#pragma unroll
-        for (int u = 0; u < 32; ++u) {
-            int64_t b = b0 + 128 + bq + 4 * u;
-            pre[u] = (live && b < B) ? sdT[b * Ns + i] : NAN;
-        }
+        if (b0 + 128 < B) fetch(b0 + 128);
         if (threadIdx.x < 64) {
-            // bins past the end were staged as NaN and are skipped like any other NaN, so the
-            // trip count is fixed: 16 LDS reads in flight per group, then the serial adds
             for (int bb = 0; bb < 128; bb += 16) {
                 double v[16];
 #pragma unroll
                 for (int u = 0; u < 16; ++u) v[u] = buf[bb + u][ss];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    bool ok = v[u] == v[u];
-                    s = s + (ok ? v[u] : 0.0);
-                    c += ok;
-                }
+                for (int u = 0; u < 16; ++u) s = s + v[u];
             }
         }
     }
-    if (threadIdx.x < 64 && live) out[i] = s / (double)c;
+    cnts[bq][ss] = cnt;
+    __syncthreads();
+    if (threadIdx.x < 64 && live) {
+        const long long c = (long long)cnts[0][ss] + cnts[1][ss] + cnts[2][ss] + cnts[3][ss];
+        out[i] = s / (double)c;
+    }
 }
 
 // --------------------------------------------------------------- cleaning ----
