@@ -243,14 +243,32 @@ struct StreamSum {
 // fastest index so a wave reads 64 consecutive samples of one reference bin.
 // `active` (per sample) is cleared when a repeat set no new flag for that sample:
 // the next pass would reproduce the same numbers bit for bit, so it is skipped.
+// UNI: a wave holds one bin and 64 consecutive samples, so the bin, its reference list and the
+// list length are wave-uniform (scalar loads of the indexes, scalar row base + lane offset for
+// the gathers); used for batches.  Otherwise thread = flat (bin, sample) index, which keeps
+// all lanes busy when there are only a few samples (latency mode).
+template <bool UNI>
 __global__ __launch_bounds__(256) void k_zscore(const double *__restrict__ XT, const double *__restrict__ XC,
                                                 const int *__restrict__ gidx, const int *__restrict__ nref, int k,
                                                 int64_t B, int64_t Ns, const int *__restrict__ active,
                                                 double *__restrict__ zT, double *__restrict__ rT,
                                                 double *__restrict__ nT, double *__restrict__ sdT) {
-    int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= B * Ns) return;
-    int64_t b = gid / Ns, i = gid - b * Ns;
+    int64_t gid, b, i;
+    if (UNI) {
+        const int64_t n_sg = (Ns + 63) / 64;
+        const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        const int wb = __builtin_amdgcn_readfirstlane((int)(wave / n_sg));
+        if (wb >= B) return;
+        b = wb;
+        i = (wave - (int64_t)wb * n_sg) * 64 + (threadIdx.x & 63);
+        if (i >= Ns) return;
+        gid = b * Ns + i;
+    } else {
+        gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (gid >= B * Ns) return;
+        b = gid / Ns;
+        i = gid - b * Ns;
+    }
     if (active && !active[i]) return;
     const int *lst = gidx + b * k;
     const int n = nref[b];
@@ -1162,10 +1180,16 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
         const int *cur = it == 0 ? nullptr : act + (it & 1) * Ns;
         int *next = act + ((it + 1) & 1) * Ns;
         WC_HIP(hipMemsetAsync(next, 0, sizeof(int) * Ns, stream));
-        hipLaunchKernelGGL(k_zscore, dim3(g), dim3(256), 0, stream, (const double *)ts.xt.as<double>(),
-                           (const double *)ts.xc.as<double>(), (const int *)ref->gidx.as<int>(),
-                           (const int *)ref->nref.as<int>(), ref->k, ref->B, Ns, cur, ts.zt.as<double>(),
-                           ts.rt.as<double>(), ts.nt.as<double>(), ts.sdt.as<double>());
+        if (Ns >= 32)
+            hipLaunchKernelGGL(k_zscore<true>, dim3((unsigned)cdiv(ref->B * cdiv(Ns, 64), 4)), dim3(256), 0, stream,
+                               (const double *)ts.xt.as<double>(), (const double *)ts.xc.as<double>(),
+                               (const int *)ref->gidx.as<int>(), (const int *)ref->nref.as<int>(), ref->k, ref->B, Ns,
+                               cur, ts.zt.as<double>(), ts.rt.as<double>(), ts.nt.as<double>(), ts.sdt.as<double>());
+        else
+            hipLaunchKernelGGL(k_zscore<false>, dim3(g), dim3(256), 0, stream, (const double *)ts.xt.as<double>(),
+                               (const double *)ts.xc.as<double>(), (const int *)ref->gidx.as<int>(),
+                               (const int *)ref->nref.as<int>(), ref->k, ref->B, Ns, cur, ts.zt.as<double>(),
+                               ts.rt.as<double>(), ts.nt.as<double>(), ts.sdt.as<double>());
         hipLaunchKernelGGL(k_flag, dim3(g), dim3(256), 0, stream, (const double *)ts.zt.as<double>(), thr, n, Ns,
                            cur, next, ts.xc.as<double>());
     }
