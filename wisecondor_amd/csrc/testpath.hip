@@ -147,15 +147,20 @@ __global__ void k_normalize(const int *__restrict__ counts, int64_t Btot, const 
 }
 
 // applyPCA step 1 (wisetools.py:109): t = (x - mean) . components^T
+// Projection on the components: PROJ_SPLIT workgroups per sample, each over a contiguous
+// slice of the bins; k_pca_apply adds the slice sums in slice order (deterministic).
+constexpr int PROJ_SPLIT = 8;
 __global__ __launch_bounds__(256) void k_pca_project(const double *__restrict__ raw, int64_t B,
                                                      const double *__restrict__ mean, const double *__restrict__ comp,
                                                      int n_comp, double *__restrict__ proj) {
     __shared__ double sh[MAX_COMP][256];
     const double *x = raw + (int64_t)blockIdx.x * B;
+    const int64_t per = (B + PROJ_SPLIT - 1) / PROJ_SPLIT;
+    const int64_t b_lo = (int64_t)blockIdx.y * per, b_hi = b_lo + per < B ? b_lo + per : B;
     double acc[MAX_COMP];
 #pragma unroll
     for (int c = 0; c < MAX_COMP; ++c) acc[c] = 0.0;
-    for (int64_t b = threadIdx.x; b < B; b += 256) {
+    for (int64_t b = b_lo + threadIdx.x; b < b_hi; b += 256) {
         double d = x[b] - mean[b];
 #pragma unroll
         for (int c = 0; c < MAX_COMP; ++c)
@@ -170,10 +175,10 @@ __global__ __launch_bounds__(256) void k_pca_project(const double *__restrict__ 
             for (int c = 0; c < MAX_COMP; ++c) sh[c][threadIdx.x] += sh[c][threadIdx.x + o];
         __syncthreads();
     }
-    if ((int)threadIdx.x < n_comp) proj[(int64_t)blockIdx.x * MAX_COMP + threadIdx.x] = sh[threadIdx.x][0];
+    if ((int)threadIdx.x < n_comp)
+        proj[((int64_t)blockIdx.x * PROJ_SPLIT + blockIdx.y) * MAX_COMP + threadIdx.x] = sh[threadIdx.x][0];
 }
 
-// applyPCA step 2 (wisetools.py:111-113): x / (t . components + mean)
 __global__ void k_pca_apply(const double *__restrict__ raw, int64_t B, const double *__restrict__ mean,
                             const double *__restrict__ comp, int n_comp, const double *__restrict__ proj,
                             double *__restrict__ out) {
@@ -181,7 +186,11 @@ __global__ void k_pca_apply(const double *__restrict__ raw, int64_t B, const dou
     int64_t i = blockIdx.y;
     if (b >= B) return;
     double rec = 0.0;
-    for (int c = 0; c < n_comp; ++c) rec += proj[i * MAX_COMP + c] * comp[(int64_t)c * B + b];
+    for (int c = 0; c < n_comp; ++c) {
+        double t = 0.0;
+        for (int q = 0; q < PROJ_SPLIT; ++q) t += proj[(i * PROJ_SPLIT + q) * MAX_COMP + c];
+        rec += t * comp[(int64_t)c * B + b];
+    }
     rec += mean[b];
     out[i * B + b] = raw[i * B + b] / rec;
 }
@@ -1133,14 +1142,14 @@ int run_prepare(wc_ctx *ctx, const wc_reference *ref, const int *counts_dev, int
     int rc;
     if ((rc = ts.totals.reserve(sizeof(double) * Ns))) return rc;
     if ((rc = ts.raw.reserve(sizeof(double) * Ns * ref->B))) return rc;
-    if ((rc = ts.proj.reserve(sizeof(double) * Ns * MAX_COMP))) return rc;
+    if ((rc = ts.proj.reserve(sizeof(double) * Ns * MAX_COMP * PROJ_SPLIT))) return rc;
     if ((rc = ts.data.reserve(sizeof(double) * Ns * ref->B))) return rc;
     hipLaunchKernelGGL(k_sample_totals, dim3((unsigned)Ns), dim3(256), 0, stream, counts_dev, ref->Btot,
                        ts.totals.as<double>());
     dim3 g((unsigned)cdiv(ref->B, 256), (unsigned)Ns);
     hipLaunchKernelGGL(k_normalize, g, dim3(256), 0, stream, counts_dev, ref->Btot, (const int *)ref->m2g.as<int>(),
                        ref->B, (const double *)ts.totals.as<double>(), ts.raw.as<double>());
-    hipLaunchKernelGGL(k_pca_project, dim3((unsigned)Ns), dim3(256), 0, stream, (const double *)ts.raw.as<double>(),
+    hipLaunchKernelGGL(k_pca_project, dim3((unsigned)Ns, PROJ_SPLIT), dim3(256), 0, stream, (const double *)ts.raw.as<double>(),
                        ref->B, (const double *)ref->pca_mean.as<double>(), (const double *)ref->pca_comp.as<double>(),
                        ref->n_comp, ts.proj.as<double>());
     hipLaunchKernelGGL(k_pca_apply, g, dim3(256), 0, stream, (const double *)ts.raw.as<double>(), ref->B,
@@ -1494,13 +1503,13 @@ int wc_apply_pca(wc_ctx *ctx, const double *samples, int64_t n_samples, int64_t 
     int rc;
     if ((rc = ts.raw.reserve(sizeof(double) * n_samples * n_bins))) return rc;
     if ((rc = ts.data.reserve(sizeof(double) * n_samples * n_bins))) return rc;
-    if ((rc = ts.proj.reserve(sizeof(double) * n_samples * MAX_COMP))) return rc;
+    if ((rc = ts.proj.reserve(sizeof(double) * n_samples * MAX_COMP * PROJ_SPLIT))) return rc;
     if ((rc = ctx->tmp_a.reserve(sizeof(double) * n_bins))) return rc;
     if ((rc = ctx->tmp_c.reserve(sizeof(double) * std::max<int64_t>(1, (int64_t)n_comp * n_bins)))) return rc;
     WC_HIP(hipMemcpy(ts.raw.p, samples, sizeof(double) * n_samples * n_bins, hipMemcpyHostToDevice));
     WC_HIP(hipMemcpy(ctx->tmp_a.p, pca_mean, sizeof(double) * n_bins, hipMemcpyHostToDevice));
     if (n_comp) WC_HIP(hipMemcpy(ctx->tmp_c.p, pca_components, sizeof(double) * n_comp * n_bins, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_pca_project, dim3((unsigned)n_samples), dim3(256), 0, nullptr,
+    hipLaunchKernelGGL(k_pca_project, dim3((unsigned)n_samples, PROJ_SPLIT), dim3(256), 0, nullptr,
                        (const double *)ts.raw.as<double>(), n_bins, (const double *)ctx->tmp_a.as<double>(),
                        (const double *)ctx->tmp_c.as<double>(), n_comp, ts.proj.as<double>());
     dim3 g((unsigned)cdiv(n_bins, 256), (unsigned)n_samples);
