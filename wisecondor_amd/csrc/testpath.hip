@@ -699,10 +699,12 @@ __global__ __launch_bounds__(64 * NW) void k_seg_search(const Job *__restrict__ 
                                                     const int *__restrict__ reg_flag, int max_chunks,
                                                     const unsigned int *__restrict__ bits,
                                                     const long long *__restrict__ bit_off,
-                                                    Extreme *__restrict__ partial) {
+                                                    Extreme *__restrict__ partial, int *__restrict__ counters) {
     extern __shared__ double pl[];
     __shared__ double red_max[NW], red_min[NW];
     const int j = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    // first kernel of a round: next-jobs / hot / brute counts start at zero (classify runs after)
+    if (j == 0 && chunk == 0 && tid == 0) { counters[1] = 0; counters[2] = 0; counters[3] = 0; }
     if (j >= n_jobs) return;
     const Job job = jobs[j];
     const int L = job.hi - job.lo, half = (L + 1) / 2;
@@ -782,7 +784,8 @@ __global__ __launch_bounds__(64) void k_seg_classify(const Job *__restrict__ job
                                                      const double *__restrict__ reg_abs, const int *__restrict__ reg_flag,
                                                      const Extreme *__restrict__ partial, int max_chunks, double thr,
                                                      Extreme *__restrict__ job_res, int *__restrict__ hot,
-                                                     int *__restrict__ brute, int *__restrict__ counters) {
+                                                     int *__restrict__ brute, int *__restrict__ counters,
+                                                     int *__restrict__ cand_cnt) {
     const int j = blockIdx.x, lane = threadIdx.x;
     if (j >= n_jobs) return;
     const Job job = jobs[j];
@@ -812,7 +815,12 @@ __global__ __launch_bounds__(64) void k_seg_classify(const Job *__restrict__ job
         job_res[j] = e;
         double eps = window_eps(regions[job.region].n, reg_abs[job.region]);
         double big = fmax(fabs(e.maxv), fabs(e.minv));
-        if (!(big + eps < thr)) hot[atomicAdd(&counters[2], 1)] = j;
+        if (!(big + eps < thr)) {
+            const int h = atomicAdd(&counters[2], 1);
+            hot[h] = j;
+            cand_cnt[2 * h] = 0;          // candidate lists of hot job h start empty
+            cand_cnt[2 * h + 1] = 0;
+        }
     }
 }
 
@@ -1182,13 +1190,13 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
         WC_HIP(hipMemsetAsync(ts.nt.p, 0, sizeof(double) * n, stream));
         WC_HIP(hipMemsetAsync(ts.sdt.p, 0xFF, sizeof(double) * n, stream));
     }
-    // active[it & 1][sample]: did repeat it-1 add a flag for this sample?
-    if ((rc = ts.misc2.reserve(sizeof(int) * 2 * Ns))) return rc;
+    // active[it][sample]: did repeat it-1 add a flag for this sample?  (one clear for all repeats)
+    if ((rc = ts.misc2.reserve(sizeof(int) * (repeats + 1) * Ns))) return rc;
     int *act = ts.misc2.as<int>();
+    if (repeats > 0) WC_HIP(hipMemsetAsync(act, 0, sizeof(int) * (repeats + 1) * Ns, stream));
     for (int it = 0; it < repeats; ++it) {
-        const int *cur = it == 0 ? nullptr : act + (it & 1) * Ns;
-        int *next = act + ((it + 1) & 1) * Ns;
-        WC_HIP(hipMemsetAsync(next, 0, sizeof(int) * Ns, stream));
+        const int *cur = it == 0 ? nullptr : act + (int64_t)it * Ns;
+        int *next = act + (int64_t)(it + 1) * Ns;
         if (Ns >= 32)
             hipLaunchKernelGGL(k_zscore<true>, dim3((unsigned)cdiv(ref->B * cdiv(Ns, 64), 4)), dim3(256), 0, stream,
                                (const double *)ts.xt.as<double>(), (const double *)ts.xc.as<double>(),
@@ -1297,8 +1305,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
         if ((rc = ts.partial.reserve(sizeof(Extreme) * n_jobs * max_chunks))) return rc;
         if ((rc = ts.cand.reserve(sizeof(int2) * 2 * CAND_CAP * n_jobs))) return rc;
         if ((rc = ts.cand_cnt.reserve(sizeof(int) * 2 * n_jobs))) return rc;
-        WC_HIP(hipMemsetAsync(counters + 1, 0, sizeof(int) * 3, stream));
-        WC_HIP(hipMemsetAsync(ts.cand_cnt.p, 0, sizeof(int) * 2 * n_jobs, stream));
+        // round counters are reset by the search kernel, candidate counts by classify
         dim3 sg((unsigned)max_chunks, (unsigned)n_jobs);
         {
             const bool plds = max_n + 1 <= 6144;      // the longest region's prefix slice fits 48 KB of LDS
@@ -1306,7 +1313,8 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
 #define WC_SEARCH(M, P_, NW_)                                                                                     \
     hipLaunchKernelGGL((k_seg_search<M, P_, NW_>), sg, dim3(64 * NW_), dyn, stream, (const Job *)cur, (int)n_jobs,   \
                        regions_dev, (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),     \
-                       (const int *)ts.reg_flag.as<int>(), max_chunks, bits, bit_off, ts.partial.as<Extreme>())
+                       (const int *)ts.reg_flag.as<int>(), max_chunks, bits, bit_off, ts.partial.as<Extreme>(), \
+                       counters)
 #define WC_SEARCH_NW(M, P_) do { if (wide) WC_SEARCH(M, P_, 16); else WC_SEARCH(M, P_, 4); } while (0)
             const bool wide = n_jobs * max_chunks <= 2048;     // few blocks: sixteen waves each
             if (bits) { if (plds) WC_SEARCH_NW(true, true); else WC_SEARCH_NW(true, false); }
@@ -1317,7 +1325,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
         hipLaunchKernelGGL(k_seg_classify, dim3((unsigned)n_jobs), dim3(64), 0, stream, (const Job *)cur, (int)n_jobs,
                            regions_dev, (const double *)ts.reg_abs.as<double>(), (const int *)ts.reg_flag.as<int>(),
                            (const Extreme *)ts.partial.as<Extreme>(), max_chunks, thr, ts.job_res.as<Extreme>(), hot,
-                           brute, counters);
+                           brute, counters, ts.cand_cnt.as<int>());
         // The number of hot jobs lives on the device.  Small rounds (latency mode, child
         // ranges) launch the follow-up kernels for the upper bound n_jobs and let surplus
         // workgroups exit, which saves a host round trip; big rounds read the count back.
