@@ -148,7 +148,7 @@ def main():
                              device=local_rank)
     thr = float(zThreshold([int(v) for v in inp["masked_bins"]], 1000, None))
     counts_h = wt.samples_to_counts(inp["tests"], inp["chrom_bins"])
-    tb = distributed.TestBatch(reference, torch.from_numpy(counts_h).to(dev), thr)
+    tb = distributed.TestBatch(reference, torch.from_numpy(counts_h).to(dev), thr, max_calls=256)
     for _ in range(max(1, args.warmup // 2)):
         tb.run()
     sync_all()
@@ -172,7 +172,7 @@ def main():
     windows = float(sum(int(n) * (int(n) + 1) // 2 for n in inp["masked_bins"]))
     test_bytes = 5.0 * n_refs * 12.0 + windows * 8.0
     # BASELINE config 3: one sample per call (latency mode, nothing amortised over a batch)
-    tb1 = distributed.TestBatch(reference, torch.from_numpy(counts_h[:1].copy()).to(dev), thr)
+    tb1 = distributed.TestBatch(reference, torch.from_numpy(counts_h[:1].copy()).to(dev), thr, max_calls=256)
     tb1.run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
