@@ -992,17 +992,150 @@ __global__ __launch_bounds__(NT, 4) void k_finish(FinishArgs a) {
 // Exact path for rows whose certificate failed (ties at the boundary, outlier
 // rows, list overflow): every distance in float64, then k rounds of
 // lexicographic (distance, position) minimum selection.
-__global__ __launch_bounds__(256) void k_fallback(FinishArgs a, unsigned long long *scratch, int64_t Bpad) {
-    __shared__ unsigned long long rk[256];
-    __shared__ int rj[256];
+// -- exact path, two kernels --------------------------------------------------------
+// fb_fill: float64 distance keys of `row` to the candidates [j0, j1) into sc[j] (8 lanes per
+// candidate, 32 candidates per trip); same chromosome / NaN / >= 1e10 -> ~0.
+__device__ inline void fb_fill(const FinishArgs &a, int64_t row, const double *xi, int64_t j0, int64_t j1,
+                               unsigned long long *__restrict__ sc, int tid) {
+    const int ch = a.chrom_of_row[row];
+    const int64_t cs = a.chrom_off[ch], ce = a.chrom_off[ch + 1];
+    const int grp = tid >> 3, sub = tid & 7;
+    for (int64_t base = j0; base < j1; base += 32) {
+        int64_t j = base + grp;
+        bool in = j < j1;
+        double d = exact_distance(a.X + (in ? j : row) * a.S, xi, a.S, sub, a.sum_order);
+        if (in && sub == 0) {
+            bool ok = !(j >= cs && j < ce) && d < SENTINEL_DISTANCE;
+            sc[j] = ok ? wc::f64_ordered(d) : ~0ull;
+        }
+    }
+}
+
+// Radix selection (8-bit digits, most significant first) of the element of 0-based rank `want`
+// among the values v(j), j in [0, n), for which use(j) holds.  All 256 threads take part.
+template <int BITS, class V, class U>
+__device__ inline unsigned long long fb_radix_select(int64_t n, int want, V v, U use, unsigned int *hist,
+                                                     unsigned long long *s_pref, int *s_want, int tid) {
+    unsigned long long prefix = 0ull, mask = 0ull;
+    for (int shift = BITS - 8; shift >= 0; shift -= 8) {
+        hist[tid] = 0;
+        __syncthreads();
+        for (int64_t j = tid; j < n; j += 256) {
+            if (!use(j)) continue;
+            const unsigned long long key = v(j);
+            if ((key & mask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int kk = want, d = 0;
+            for (; d < 255; ++d) {
+                if (kk < (int)hist[d]) break;
+                kk -= (int)hist[d];
+            }
+            *s_want = kk;
+            *s_pref = prefix | ((unsigned long long)d << shift);
+        }
+        __syncthreads();
+        want = *s_want;
+        prefix = *s_pref;
+        mask |= 0xFFull << shift;
+        __syncthreads();
+    }
+    return prefix;
+}
+
+// fb_select: the k smallest (distance, position) pairs of sc[0..B) in order -> output row.
+// The k-th smallest key by radix selection; everything below it is taken, of the entries that
+// tie with it the lowest positions (a second selection over the positions when there are more
+// ties than places); the <= 256 chosen entries are ordered by counting.
+__device__ inline void fb_select(const FinishArgs &a, int64_t row, const unsigned long long *__restrict__ sc,
+                                 unsigned long long *selk, int *selj, unsigned int *hist, int tid) {
+    __shared__ unsigned long long s_pref;
+    __shared__ int s_int[4];
+    const int ch = a.chrom_of_row[row];
+    const int64_t cs = a.chrom_off[ch], ce = a.chrom_off[ch + 1];
+    const int64_t orow = row - a.row_begin;
+    // how many candidates carry a distance at all
+    if (tid < 4) s_int[tid] = 0;
+    __syncthreads();
+    {
+        int mine = 0;
+        for (int64_t j = tid; j < a.B; j += 256) mine += sc[j] != ~0ull;
+        for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+        if ((tid & 63) == 0) atomicAdd(&s_int[0], mine);
+    }
+    __syncthreads();
+    const int n_valid = s_int[0];
+    const int take = n_valid < a.k ? n_valid : a.k;        // entries that exist; the rest is padding
+    __syncthreads();
+    unsigned long long kth = ~0ull;
+    int jth = 0x7FFFFFFF;
+    if (take > 0) {
+        kth = fb_radix_select<64>(a.B, take - 1, [&](int64_t j) { return sc[j]; }, [&](int64_t) { return true; },
+                                  hist, &s_pref, &s_int[1], tid);
+        // entries below the k-th key, and entries equal to it
+        if (tid < 4) s_int[tid] = 0;
+        __syncthreads();
+        int below = 0, equal = 0;
+        for (int64_t j = tid; j < a.B; j += 256) {
+            const unsigned long long v = sc[j];
+            below += v < kth;
+            equal += v == kth;
+        }
+        for (int o = 32; o > 0; o >>= 1) { below += __shfl_xor(below, o); equal += __shfl_xor(equal, o); }
+        if ((tid & 63) == 0) { atomicAdd(&s_int[2], below); atomicAdd(&s_int[3], equal); }
+        __syncthreads();
+        const int n_below = s_int[2], n_equal = s_int[3], places = take - n_below;
+        __syncthreads();
+        if (n_equal > places)      // more ties than places: the lowest positions win (stable order)
+            jth = (int)fb_radix_select<32>(a.B, places - 1, [&](int64_t j) { return (unsigned long long)j; },
+                                           [&](int64_t j) { return sc[j] == kth; }, hist, &s_pref, &s_int[1], tid);
+    }
+    if (tid == 0) s_int[0] = 0;
+    __syncthreads();
+    for (int64_t j = tid; j < a.B; j += 256) {
+        const unsigned long long v = sc[j];
+        if (take > 0 && (v < kth || (v == kth && (int)j <= jth))) {
+            const int at = atomicAdd(&s_int[0], 1);
+            if (at < 256) { selk[at] = v; selj[at] = (int)j; }
+        }
+    }
+    __syncthreads();
+    // order the chosen entries by counting, write the row
+    for (int t = tid; t < a.k; t += 256) {
+        int32_t oi = -1;
+        double od = SENTINEL_DISTANCE;
+        if (t < take) {
+            const unsigned long long mine = selk[t];
+            const int myj = selj[t];
+            int rank = 0;
+            for (int u = 0; u < take; ++u) rank += (selk[u] < mine) | ((selk[u] == mine) & (selj[u] < myj));
+            oi = (int32_t)(myj < cs ? myj : myj - (ce - cs));
+            od = wc::f64_from_ordered(mine);
+            a.idx_out[orow * a.k + rank] = oi;
+            a.dist_out[orow * a.k + rank] = od;
+        } else {
+            a.idx_out[orow * a.k + t] = -1;
+            a.dist_out[orow * a.k + t] = SENTINEL_DISTANCE;
+        }
+    }
+    __syncthreads();
+}
+
+// Distances of the first FB_BLOCKS fallback rows, all workgroups together: FB_ROWS_PAR rows are
+// in flight at a time, FB_BLOCKS / FB_ROWS_PAR workgroups share a row's candidates.  (One
+// workgroup per row, as the first version had it, reads the whole matrix -- 277 MB at
+// 57 633 x 600 -- through a single CU: ~100 ms for a single outlier row.)
+constexpr int FB_ROWS_PAR = 8;
+__global__ __launch_bounds__(256) void k_fallback_fill(FinishArgs a, unsigned long long *scratch, int64_t Bpad) {
     __shared__ double xs[2048];
     const int tid = threadIdx.x;
     const int nfb = *a.fb_count;
-    unsigned long long *sc = scratch + (int64_t)blockIdx.x * Bpad;
-    for (int f = blockIdx.x; f < nfb; f += gridDim.x) {
+    const int nf = nfb < FB_BLOCKS ? nfb : FB_BLOCKS;
+    constexpr int SHARE = FB_BLOCKS / FB_ROWS_PAR;
+    const int part = blockIdx.x % SHARE, lane_row = blockIdx.x / SHARE;
+    for (int f = lane_row; f < nf; f += FB_ROWS_PAR) {
         const int64_t row = a.fb_rows[f];
-        const int ch = a.chrom_of_row[row];
-        const int64_t cs = a.chrom_off[ch], ce = a.chrom_off[ch + 1];
         const double *xi = a.X + row * a.S;
         __syncthreads();
         if (a.S <= 2048) {
@@ -1010,60 +1143,36 @@ __global__ __launch_bounds__(256) void k_fallback(FinishArgs a, unsigned long lo
             xi = xs;
         }
         __syncthreads();
-        const int grp = tid >> 3, sub = tid & 7;
-        for (int64_t base = 0; base < a.B; base += 32) {
-            int64_t j = base + grp;
-            bool in = j < a.B;
-            double d = exact_distance(a.X + (in ? j : row) * a.S, xi, a.S, sub, a.sum_order);
-            if (in && sub == 0) {
-                bool ok = !(j >= cs && j < ce) && d < SENTINEL_DISTANCE;
-                sc[j] = ok ? wc::f64_ordered(d) : ~0ull;
-            }
+        unsigned long long *sc = scratch + (int64_t)f * Bpad;
+        for (int64_t c0 = (int64_t)part * 256; c0 < a.B; c0 += (int64_t)SHARE * 256)
+            fb_fill(a, row, xi, c0, c0 + 256 < a.B ? c0 + 256 : a.B, sc, tid);
+    }
+}
+
+// Selection for the rows whose keys k_fallback_fill left in scratch (one workgroup per row);
+// fallback rows beyond FB_BLOCKS (pathological inputs) run both steps here, one row at a
+// time per workgroup, in the workgroup's own scratch slot.
+__global__ __launch_bounds__(256) void k_fallback(FinishArgs a, unsigned long long *scratch, int64_t Bpad) {
+    __shared__ unsigned long long rk[256];
+    __shared__ int rj[256];
+    __shared__ unsigned int hist[256];
+    __shared__ double xs[2048];
+    const int tid = threadIdx.x;
+    const int nfb = *a.fb_count;
+    unsigned long long *sc = scratch + (int64_t)blockIdx.x * Bpad;
+    if ((int)blockIdx.x < nfb) fb_select(a, a.fb_rows[blockIdx.x], sc, rk, rj, hist, tid);
+    for (int f = FB_BLOCKS + blockIdx.x; f < nfb; f += gridDim.x) {
+        const int64_t row = a.fb_rows[f];
+        const double *xi = a.X + row * a.S;
+        __syncthreads();
+        if (a.S <= 2048) {
+            for (int64_t s = tid; s < a.S; s += 256) xs[s] = xi[s];
+            xi = xs;
         }
         __syncthreads();
-        unsigned long long last_d = 0ull;
-        int last_j = -1;
-        const int64_t orow = row - a.row_begin;
-        bool exhausted = false;
-        for (int t = 0; t < a.k; ++t) {
-            unsigned long long bd = ~0ull;
-            int bj = 0x7FFFFFFF;
-            if (!exhausted) {
-                for (int64_t j = tid; j < a.B; j += 256) {
-                    unsigned long long v = sc[j];
-                    bool after = (v > last_d) || (v == last_d && (int)j > last_j);
-                    bool better = (v < bd) || (v == bd && (int)j < bj);
-                    if (after && better) { bd = v; bj = (int)j; }
-                }
-            }
-            rk[tid] = bd;
-            rj[tid] = bj;
-            __syncthreads();
-            for (int o = 128; o > 0; o >>= 1) {
-                if (tid < o) {
-                    unsigned long long v = rk[tid + o];
-                    int jj = rj[tid + o];
-                    if (v < rk[tid] || (v == rk[tid] && jj < rj[tid])) { rk[tid] = v; rj[tid] = jj; }
-                }
-                __syncthreads();
-            }
-            bd = rk[0];
-            bj = rj[0];
-            __syncthreads();
-            if (bd == ~0ull) exhausted = true;
-            if (tid == 0) {
-                int32_t oi = -1;
-                double od = SENTINEL_DISTANCE;
-                if (!exhausted) {
-                    oi = (int32_t)(bj < cs ? bj : bj - (ce - cs));
-                    od = wc::f64_from_ordered(bd);
-                }
-                a.idx_out[orow * a.k + t] = oi;
-                a.dist_out[orow * a.k + t] = od;
-            }
-            last_d = bd;
-            last_j = bj;
-        }
+        fb_fill(a, row, xi, 0, a.B, sc, tid);
+        __syncthreads();
+        fb_select(a, row, sc, rk, rj, hist, tid);
     }
 }
 
@@ -1484,6 +1593,8 @@ int wc_newref_finish_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t 
             else hipLaunchKernelGGL((k_finish<false, 256>), grid, dim3(256), dyn, stream, a);
         }
     }
+    hipLaunchKernelGGL(k_fallback_fill, dim3(FB_BLOCKS), dim3(256), 0, stream, a,
+                       st.fb_scratch.as<unsigned long long>(), st.bins_pad);
     hipLaunchKernelGGL(k_fallback, dim3(FB_BLOCKS), dim3(256), 0, stream, a,
                        st.fb_scratch.as<unsigned long long>(), st.bins_pad);
     WC_HIP(hipGetLastError());
