@@ -195,6 +195,31 @@ def test_segments_random_vs_oracle(wt):
         assert same_bits([w], [tri[z.shape[0] - 1]])
 
 
+def test_segments_long_regions_quiet_certificate(wt):
+    """Regions of >= 2048 bins switch the quiet-job certificate on (block bounds on the prefix
+    sums decide most jobs without a full window search): a quiet long region, a long region
+    with calls (and therefore child ranges), a threshold-grazing one and short ones in the same
+    call must still reproduce the reference's segments exactly."""
+    rng = np.random.RandomState(23)
+    quiet = rng.standard_normal(2100)
+    busy = rng.standard_normal(2100)
+    busy[300:420] += 0.9
+    busy[1500:1530] -= 1.6
+    graze = rng.standard_normal(2060) * 0.5
+    regions = [quiet, busy, graze, rng.standard_normal(70), np.array([1.5] * 30)]
+    thr = 5.0
+    whole, segs = wt.stouffer_segments(regions, thr, 3)
+    n_calls = 0
+    for z, w, s in zip(regions, whole, segs):
+        tri = wo.fill_tri(z)
+        want = wo.segment_tri(tri, z.shape[0], thr, 3)
+        assert [(x, y) for _, (x, y) in s] == [(x, y) for _, (x, y) in want], z.shape
+        assert same_bits([v for v, _ in s], [v for v, _ in want])
+        assert same_bits([w], [tri[z.shape[0] - 1]])
+        n_calls += len(want)
+    assert n_calls >= 3
+
+
 @pytest.mark.parametrize("batch", [False, True])
 def test_cfg1_whole_test(wt, cfg1, reference, batch):
     g = cfg1
