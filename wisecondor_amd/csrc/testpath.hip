@@ -692,7 +692,9 @@ __device__ inline double window_eps(int n, double abs_sum) {
 // Minimum and maximum of every 32-entry block of the concatenated prefix array (blocks are
 // aligned to the array, not to the regions: a block that straddles a region boundary bounds a
 // superset, which is still a bound).
-constexpr int QB = 32;              // rows per segment, window ends per end block
+constexpr int QB = 32;              // window ends per end block
+constexpr int Q_WORK = 1024;        // undecided (row, end block) pairs a block can queue (10 KB of LDS in all: 8 blocks per CU)
+constexpr int Q_BLOCKS = 256;       // end blocks of one job held in LDS (jobs up to ~8 k bins)
 __global__ void k_block_minmax(const double *__restrict__ prefix, int64_t total, double *__restrict__ tmin,
                                double *__restrict__ tmax) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -707,16 +709,14 @@ __global__ void k_block_minmax(const double *__restrict__ prefix, int64_t total,
 
 // Quiet-job certificate.  Most jobs (a chromosome of a sample, or a child range) hold no call:
 // every window stays below the threshold.  Proving that needs far fewer evaluations than
-// finding the extremes: for a 32-row segment of window starts and a 32-entry block of window
-// ends that begins >= 33 bins later,
-//     (P[y'] - P[x]) / sqrt(len) <= (max P over the end block - min P over the segment) / sqrt(min len)
-// (and symmetrically from below; float rounding is monotone, so the bound also covers the
-// values as the search would compute them).  Pairs whose bound does not settle it, and the
-// windows that end within ~2 blocks of their start, are evaluated one by one.  A job keeps
-// Job::pad == 0 (search and classify skip it) unless some window could reach the threshold:
-// |v| + eps < thr is the same test k_seg_classify applies to the extremes.
-constexpr int Q_WORK = 768;         // (segment, end block) pairs a block can queue for evaluation
-constexpr int Q_NEAR = 4 * QB;      // prefix entries staged per segment: its rows and the near ends
+// finding the extremes.  A lane owns a window start x (as in the search); for a 32-entry block
+// of window ends that begins past x + 32,
+//     (P[y'] - P[x]) / sqrt(len) <= (max P over the block - P[x]) / sqrt(min len)
+// and symmetrically from below (float rounding is monotone, so the bound also covers the
+// values as the search would compute them): one bound stands for 32 windows.  Blocks whose
+// bound does not settle it, and the ends before the first such block, are evaluated window by
+// window.  A job keeps Job::pad == 0 (search and classify skip it) unless some window could
+// reach the threshold: |v| + eps < thr is the same test k_seg_classify applies to the extremes.
 __global__ __launch_bounds__(256) void k_seg_quiet(Job *__restrict__ jobs, int n_jobs,
                                                    const Region *__restrict__ regions,
                                                    const double *__restrict__ prefix, const double *__restrict__ rs,
@@ -724,12 +724,12 @@ __global__ __launch_bounds__(256) void k_seg_quiet(Job *__restrict__ jobs, int n
                                                    const int *__restrict__ reg_flag, double thr,
                                                    const double *__restrict__ tmin,
                                                    const double *__restrict__ tmax) {
-    __shared__ double s_p[4][Q_NEAR];             // P[xs .. xs + 127] of each segment (clipped to the job)
-    __shared__ long long s_xs[4];                 // absolute prefix index of the segment's first row
-    __shared__ int s_nx[4];                       // rows in the segment (0: empty)
-    __shared__ double s_min[4], s_max[4];
-    __shared__ int s_work[Q_WORK];
-    __shared__ int s_nwork, s_found;
+    __shared__ int s_found, s_nwork;
+    __shared__ double s_px[2 * ROWS_HALF];        // P[x] of the block's rows (side * 64 + lane)
+    __shared__ long long s_ax[2 * ROWS_HALF];     // their absolute prefix indexes
+    __shared__ int s_work[Q_WORK];                // undecided (row, end block) pairs
+    __shared__ double s_tmx[Q_BLOCKS], s_tmn[Q_BLOCKS];   // block maxima / minima the job touches
+    __shared__ double s_pn[2][2 * ROWS_HALF];             // rows of a side and their near ends
     const int j = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
     if (j >= n_jobs) return;
     const Job job = jobs[j];
@@ -738,80 +738,87 @@ __global__ __launch_bounds__(256) void k_seg_quiet(Job *__restrict__ jobs, int n
     if (!reg_flag[job.region]) return;            // non-finite region: classify sends it to the brute path
     if (job.pad) return;                          // a sibling block already found a window
     const double eps = window_eps(regions[job.region].n, reg_abs[job.region]);
-    const long long base = regions[job.region].off + job.region + job.lo;    // absolute index of P[0] of the job
+    const long long base = regions[job.region].off + job.region + job.lo;    // absolute index of the job's P[0]
     const long long a_hi = base + L;                                          // absolute index of the last end
-    if (tid < 4) {
-        const int side = tid >> 1, hw = tid & 1;
-        int xs, xe;                                   // inclusive row range, empty when xs > xe
-        if (side == 0) {
-            xs = chunk * ROWS_HALF + hw * QB;
-            xe = xs + QB - 1;
-            if (xe > half - 1) xe = half - 1;
-        } else {
-            xe = L - 1 - (chunk * ROWS_HALF + hw * QB);
-            xs = xe - (QB - 1);
-            if (xs < half) xs = half;
-        }
-        s_xs[tid] = base + xs;
-        s_nx[tid] = xs <= xe ? xe - xs + 1 : 0;
+    const long long k_last = a_hi / QB;
+    const long long k_base = base / QB;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (k_last - k_base >= Q_BLOCKS) {           // more end blocks than the staged table holds: full search
+        if (tid == 0) jobs[j].pad = 1;
+        return;
     }
-    if (tid == 0) { s_nwork = 0; s_found = 0; }
-    __syncthreads();
-    for (int q = tid; q < 4 * Q_NEAR; q += 256) {     // rows and near ends of the four segments
-        const int sg = q / Q_NEAR, t = q % Q_NEAR;
-        const long long ai = s_xs[sg] + t;
-        s_p[sg][t] = (s_nx[sg] > 0 && ai <= a_hi) ? prefix[ai] : 0.0;
+    if (tid == 0) { s_found = 0; s_nwork = 0; }
+    for (int i = tid; i <= (int)(k_last - k_base); i += 256) {
+        s_tmx[i] = tmax[k_base + i];
+        s_tmn[i] = tmin[k_base + i];
     }
-    __syncthreads();
-    if (tid < 4 && s_nx[tid] > 0) {
-        double mn = s_p[tid][0], mx = mn;
-        for (int i = 1; i < s_nx[tid]; ++i) { mn = fmin(mn, s_p[tid][i]); mx = fmax(mx, s_p[tid][i]); }
-        s_min[tid] = mn;
-        s_max[tid] = mx;
+    {   // the 64 rows of each side and the 64 prefix entries after them (clipped to the job)
+        const int side = tid >> 7, t = tid & 127;
+        const int xr_lo = side == 0 ? chunk * ROWS_HALF : L - 1 - (chunk * ROWS_HALF + 63);
+        const long long ai = base + (xr_lo < 0 ? 0 : xr_lo) + t;
+        s_pn[side][t] = ai <= a_hi ? prefix[ai] : 0.0;
     }
     __syncthreads();
     bool found = false;
-    const long long k_last = a_hi / QB;
-    // far pairs: one bound per (segment, end block); the first far block starts >= 33 past the segment
-    const int span = (int)(k_last - (base / QB)) + 1;                 // end blocks the job touches at most
-    for (int q = tid; q < 4 * span; q += 256) {
-        const int sg = q / span;
-        if (s_nx[sg] == 0) continue;
-        const long long a_xe = s_xs[sg] + s_nx[sg] - 1;
-        const long long k = a_xe / QB + 2 + (q - sg * span);
-        if (k > k_last) continue;
-        const double m = rs[k * QB - a_xe];                           // largest 1/sqrt(len) of the pair
-        const double up = tmax[k] - s_min[sg], dn = tmin[k] - s_max[sg];
-        const double hi = up > 0.0 ? up * m : 0.0, lo = dn < 0.0 ? -dn * m : 0.0;
-        if (!(hi + eps < thr) || !(lo + eps < thr)) {
-            const int at = atomicAdd(&s_nwork, 1);
-            if (at < Q_WORK) s_work[at] = (sg << 24) | (int)(k - base / QB);
-            else found = true;                                          // queue full: give up the certificate
+    for (int side = 0; side < 2; ++side) {
+        int xr = chunk * ROWS_HALF + lane;
+        bool live;
+        if (side == 0) {
+            live = xr < half;
+        } else {
+            xr = L - 1 - xr;
+            live = xr >= half;
+        }
+        const long long ax = base + (live ? xr : 0);
+        // rows of this side and their near ends sit in LDS: s_pn[side][t] = P[a0 + t], t < 128
+        const int xr_lo = side == 0 ? chunk * ROWS_HALF : L - 1 - (chunk * ROWS_HALF + 63);
+        const long long a0 = base + (xr_lo < 0 ? 0 : xr_lo);
+        const int xo = (int)(ax - a0);                              // 0..63 for live lanes
+        const double px = live ? s_pn[side][xo] : 0.0;
+        if (w == 0) { s_px[side * ROWS_HALF + lane] = px; s_ax[side * ROWS_HALF + lane] = ax; }
+        const long long k_far = ax / QB + 2;                        // first end block that starts past ax + 32
+        // near ends, one by one; the four waves take every fourth window length (uniform per
+        // wave: its 1/sqrt(len) is a scalar load)
+        long long y_near = k_far * QB - 1;
+        if (y_near > a_hi) y_near = a_hi;
+        const int near = live ? (int)(y_near - ax) : 0;            // <= 63
+#pragma unroll 4
+        for (int len = 1 + w; len <= 2 * QB; len += 4) {
+            const double r = rs[len];
+            if (len <= near) {
+                const double v = (s_pn[side][xo + len] - px) * r;
+                if (!(fabs(v) + eps < thr)) found = true;
+            }
+        }
+        // far ends, one bound per block; the four waves take every fourth block.  The factor is
+        // an upper bound of 1/sqrt(min len) from the float32 reciprocal square root (no table
+        // gather in the loop).  Undecided (row, block) pairs are queued: evaluating them here
+        // would keep a whole wave waiting for the few lanes that need it.
+        const int xr_min = side == 0 ? chunk * ROWS_HALF : L - 1 - (chunk * ROWS_HALF + 63);
+        const long long k0 = (base + (xr_min < 0 ? 0 : xr_min)) / QB + 2;
+        for (long long k = k0 + w; k <= k_last; k += 4) {
+            const double mx = s_tmx[k - k_base], mn = s_tmn[k - k_base];     // wave-uniform LDS reads
+            if (live && k >= k_far) {
+                const double m = (double)__frsqrt_rn((float)(k * QB - ax)) * 1.000001;
+                const double up = mx - px, dn = mn - px;
+                const double hi = up > 0.0 ? up * m : 0.0, lo = dn < 0.0 ? -dn * m : 0.0;
+                if (!(hi + eps < thr) || !(lo + eps < thr)) {
+                    const int at = atomicAdd(&s_nwork, 1);
+                    if (at < Q_WORK) s_work[at] = ((side * ROWS_HALF + lane) << 24) | (int)(k - k_base);
+                    else found = true;                              // queue full: give up the certificate
+                }
+            }
         }
     }
-    // near windows: every row against the ends before its segment's first far block
-    for (int q = tid; q < 4 * QB * (3 * QB); q += 256) {
-        const int sg = q / (QB * 3 * QB), rem = q - sg * (QB * 3 * QB);
-        const int xi = rem / (3 * QB), len = 1 + rem % (3 * QB);
-        if (xi >= s_nx[sg]) continue;
-        const long long a_xe = s_xs[sg] + s_nx[sg] - 1;
-        long long y_end = (a_xe / QB + 2) * QB - 1;
-        if (y_end > a_hi) y_end = a_hi;
-        if (s_xs[sg] + xi + len > y_end) continue;
-        const double v = (s_p[sg][xi + len] - s_p[sg][xi]) * rs[len];
-        if (!(fabs(v) + eps < thr)) found = true;
-    }
     __syncthreads();
-    // queued pairs, window by window: 32 rows x 32 ends, the ends read straight from the prefix array
+    // queued pairs: 32 ends each, eight pairs per trip
     const int nwork = s_nwork < Q_WORK ? s_nwork : Q_WORK;
-    for (int wk = 0; wk < nwork; ++wk) {
-        const int sg = s_work[wk] >> 24;
-        const long long k = base / QB + (s_work[wk] & 0xFFFFFF);
-        for (int q = tid; q < QB * QB; q += 256) {
-            const int xi = q >> 5;
-            const long long ay = k * QB + (q & 31);
-            if (xi >= s_nx[sg] || ay > a_hi) continue;
-            const double v = (prefix[ay] - s_p[sg][xi]) * rs[ay - (s_xs[sg] + xi)];
+    for (int wk = tid >> 5; wk < nwork; wk += 8) {
+        const int row = s_work[wk] >> 24;
+        const long long ay = (k_base + (s_work[wk] & 0xFFFFFF)) * QB + (tid & 31);
+        if (ay <= a_hi) {
+            const double v = (prefix[ay] - s_px[row]) * rs[ay - s_ax[row]];
             if (!(fabs(v) + eps < thr)) found = true;
         }
     }
@@ -1381,9 +1388,11 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     if ((rc = ts.prefix.reserve(sizeof(double) * (total_len + n_regions + 8)))) return rc;
     if ((rc = ts.reg_abs.reserve(sizeof(double) * n_regions))) return rc;
     if ((rc = ts.reg_flag.reserve(sizeof(int) * n_regions))) return rc;
-    if (ts.rs_len < max_n + 8) {     // the search reads four lengths at a time past the longest window
-        if ((rc = ts.rs.reserve(sizeof(double) * (max_n + 8)))) return rc;
-        ts.rs_len = max_n + 8;
+    const int64_t rs_need = std::max<int64_t>(max_n + 8, 2 * QB + 8);   // the search reads four lengths at a time
+                                                                        // past the longest window, the certificate 1..64
+    if (ts.rs_len < rs_need) {
+        if ((rc = ts.rs.reserve(sizeof(double) * rs_need))) return rc;
+        ts.rs_len = rs_need;
         hipLaunchKernelGGL(k_fill_rs, dim3((unsigned)cdiv(ts.rs_len, 256)), dim3(256), 0, stream, ts.rs.as<double>(),
                            ts.rs_len);
     }
@@ -1423,10 +1432,10 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     WC_HIP(hipMemsetAsync(ts.out_n.p, 0, sizeof(int) * n_regions, stream));
     hipLaunchKernelGGL(k_region_prefix, dim3((unsigned)cdiv(n_regions, 4)), dim3(256), 0, stream, z_dev, regions_dev,
                        n_regions, ts.prefix.as<double>(), ts.reg_abs.as<double>(), ts.reg_flag.as<int>());
-    // The quiet-job certificate costs about half a full search of a 1000-bin region (its exact
-    // near field is 96 of the ~500 windows per row) and a quarter of a 5000-bin one: measured
-    // -13 % per 50 kb batch, +11 % per 250 kb batch, so it runs for long regions only.
-    const bool certify = max_n >= 2048;
+    // The quiet-job certificate (k_seg_quiet) runs before every search round: measured -7 % per
+    // 250 kb batch and -17 % per 50 kb batch on data where 10-40 % of the regions hold a call; jobs
+    // it cannot decide fall through to the full search.
+    const bool certify = true;
     if (certify) {
         const int64_t total = total_len + n_regions, nblk = cdiv(total, QB);
         if ((rc = ts.tmin.reserve(sizeof(double) * nblk))) return rc;
