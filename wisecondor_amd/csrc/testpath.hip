@@ -1142,16 +1142,28 @@ __global__ __launch_bounds__(256) void k_seg_brute(const Job *__restrict__ jobs,
 }
 
 // Order each region's segments by position (the reference's in-order recursion).
-__global__ void k_seg_gather(const Seg *__restrict__ segs, int n_segs, int max_calls, double *__restrict__ out_val,
-                             int *__restrict__ out_x, int *__restrict__ out_y, int *__restrict__ out_n) {
-    int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_segs) return;
-    const Seg me = segs[s];
+__global__ __launch_bounds__(256) void k_seg_gather(const Seg *__restrict__ segs, int n_segs, int max_calls,
+                                                    double *__restrict__ out_val, int *__restrict__ out_x,
+                                                    int *__restrict__ out_y, int *__restrict__ out_n) {
+    // rank of a segment among the segments of its region (by start bin); the segment list is
+    // streamed through LDS in tiles of 256
+    __shared__ int t_region[256], t_x[256];
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const bool live = s < n_segs;
+    Seg me;
+    me.val = 0.0; me.region = -1; me.x = 0; me.y = 0; me.pad = 0;
+    if (live) me = segs[s];
     int rank = 0;
-    for (int t = 0; t < n_segs; ++t) {
-        const Seg o = segs[t];
-        if (o.region == me.region && o.x < me.x) ++rank;
+    for (int t0 = 0; t0 < n_segs; t0 += 256) {
+        __syncthreads();
+        const int t = t0 + threadIdx.x;
+        t_region[threadIdx.x] = t < n_segs ? segs[t].region : -2;
+        t_x[threadIdx.x] = t < n_segs ? segs[t].x : 0;
+        __syncthreads();
+        const int m = n_segs - t0 < 256 ? n_segs - t0 : 256;
+        for (int u = 0; u < m; ++u) rank += (t_region[u] == me.region) & (t_x[u] < me.x);
     }
+    if (!live) return;
     atomicAdd(&out_n[me.region], 1);
     if (rank < max_calls) {
         int64_t at = (int64_t)me.region * max_calls + rank;
