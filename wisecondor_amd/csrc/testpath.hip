@@ -1096,19 +1096,21 @@ __global__ __launch_bounds__(256) void k_seg_decide(const Job *__restrict__ jobs
     const int grp = tid >> 3, sub = tid & 7;
     BestPair b;
     b.maxv = 0.0; b.minv = 0.0; b.mx = b.my = b.nx = b.ny = -1;
-    for (int base = 0; base < CAND_CAP; base += 32) {
-        int t = base + grp;
-        {
-            bool act = t < n_hi;
-            int2 w = cand[((int64_t)2 * h) * CAND_CAP + (act ? t : 0)];
-            double v = n_hi > 0 ? window_exact<true>(zz, w.x, w.y, sub, wm) : 0.0;
-            if (act && sub == 0 && better_max(v, w.x, w.y, b.maxv, b.mx, b.my)) { b.maxv = v; b.mx = w.x; b.my = w.y; }
-        }
-        {
-            bool act = t < n_lo;
-            int2 w = cand[((int64_t)2 * h + 1) * CAND_CAP + (act ? t : 0)];
-            double v = n_lo > 0 ? window_exact<true>(zz, w.x, w.y, sub, wm) : 0.0;
-            if (act && sub == 0 && better_min(v, w.x, w.y, b.minv, b.nx, b.ny)) { b.minv = v; b.nx = w.x; b.ny = w.y; }
+    // 32 groups of 8 lanes: groups 0-15 evaluate candidates for the maximum, 16-31 for the
+    // minimum, 16 of each per trip; the trip count follows the longer list (usually one trip)
+    const int which = grp >> 4, slot = grp & 15;
+    const int n_mine = which == 0 ? n_hi : n_lo, n_most = n_hi > n_lo ? n_hi : n_lo;
+    for (int base = 0; base < n_most; base += 16) {
+        const int t = base + slot;
+        const bool act = t < n_mine;
+        const int2 w = cand[((int64_t)2 * h + which) * CAND_CAP + (act ? t : 0)];
+        const double v = n_mine > 0 ? window_exact<true>(zz, w.x, w.y, sub, wm) : 0.0;
+        if (act && sub == 0) {
+            if (which == 0) {
+                if (better_max(v, w.x, w.y, b.maxv, b.mx, b.my)) { b.maxv = v; b.mx = w.x; b.my = w.y; }
+            } else {
+                if (better_min(v, w.x, w.y, b.minv, b.nx, b.ny)) { b.minv = v; b.nx = w.x; b.ny = w.y; }
+            }
         }
     }
     block_best(b, tid);
