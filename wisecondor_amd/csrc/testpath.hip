@@ -653,11 +653,14 @@ struct ScanCtx {
 // A lane owns one start bin x (its prefix value stays in a register); the four waves of
 // the workgroup (nw waves) take the window lengths len = 1 + w, 1 + w + nw, ...: within a wave the length
 // is uniform, so rs[len] is one scalar load and P[x + len] one coalesced vector load.
-template <class F> __device__ inline void scan_chunk(const ScanCtx &c, const double *__restrict__ rs, int tid, F f) {
+template <class F>
+__device__ inline void scan_chunk(const ScanCtx &c, const double *__restrict__ rs, int tid, F f,
+                                  unsigned int skip = 0u) {     // bit (side * 16 + wave): nothing to find there
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = (int)(blockDim.x >> 6);
     for (int side = 0; side < 2; ++side) {
+        if ((skip >> (side * 16 + w)) & 1u) continue;
         int xr = c.chunk * ROWS_HALF + lane;
         bool live;
         if (side == 0) {
@@ -843,7 +846,7 @@ __global__ __launch_bounds__(64 * NW) void k_seg_search(const Job *__restrict__ 
                                                     const unsigned int *__restrict__ bits,
                                                     const long long *__restrict__ bit_off,
                                                     Extreme *__restrict__ partial, int *__restrict__ counters,
-                                                    int certified) {
+                                                    int certified, double2 *__restrict__ sub) {
     extern __shared__ double pl[];
     __shared__ double red_max[NW], red_min[NW];
     const int j = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
@@ -865,7 +868,8 @@ __global__ __launch_bounds__(64 * NW) void k_seg_search(const Job *__restrict__ 
     const WindowMask wm{bits, MASKED ? bit_off[job.region] : 0, regions[job.region].n};
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    double bmax = -INFINITY, bmin = INFINITY;
+    double bmax = -INFINITY, bmin = INFINITY;      // over both sides
+    double2 *sub_blk = sub + ((int64_t)j * max_chunks + chunk) * 8;   // [side][search wave]: {max, min}
     for (int side = 0; side < 2; ++side) {
         int xr = chunk * ROWS_HALF + lane;
         bool live;
@@ -881,6 +885,7 @@ __global__ __launch_bounds__(64 * NW) void k_seg_search(const Job *__restrict__ 
         const int xl = live ? xr : 0;
         const double px = P[xl];
         const int room = live ? L - xl : 0;            // windows [xl, xl + len - 1] with len <= room
+        double smax = -INFINITY, smin = INFINITY;      // this side, this wave
         for (int base = 1 + 4 * w; base <= max_len; base += 4 * NW) {
             double r[4], pv[4];
 #pragma unroll
@@ -895,15 +900,19 @@ __global__ __launch_bounds__(64 * NW) void k_seg_search(const Job *__restrict__ 
                 if (len <= room) {
                     double v = (pv[u] - px) * r[u];
                     if (MASKED && !wm.valid(job.lo + xl, job.lo + xl + len - 1)) v = 0.0;
-                    bmax = fmax(bmax, v);
-                    bmin = fmin(bmin, v);
+                    smax = fmax(smax, v);
+                    smin = fmin(smin, v);
                 }
             }
         }
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        bmax = fmax(bmax, __shfl_xor(bmax, o));
-        bmin = fmin(bmin, __shfl_xor(bmin, o));
+        for (int o = 32; o > 0; o >>= 1) {
+            smax = fmax(smax, __shfl_xor(smax, o));
+            smin = fmin(smin, __shfl_xor(smin, o));
+        }
+        // the collect pass re-scans a (side, wave) slice only if its own extremes reach the cut
+        if (NW == 4 && lane == 0) sub_blk[side * 4 + w] = make_double2(smax, smin);
+        bmax = fmax(bmax, smax);
+        bmin = fmin(bmin, smin);
     }
     if (lane == 0) { red_max[w] = bmax; red_min[w] = bmin; }
     __syncthreads();
@@ -914,6 +923,8 @@ __global__ __launch_bounds__(64 * NW) void k_seg_search(const Job *__restrict__ 
         for (int q = 1; q < NW; ++q) { e.maxv = fmax(e.maxv, red_max[q]); e.minv = fmin(e.minv, red_min[q]); }
         e.max_x = e.max_y = e.min_x = e.min_y = -1;
         partial[(int64_t)j * max_chunks + chunk] = e;
+        if (NW != 4)      // sixteen-wave rounds are small: every slice inherits the block's extremes
+            for (int q = 0; q < 8; ++q) sub_blk[q] = make_double2(e.maxv, e.minv);
     }
 }
 
@@ -974,6 +985,7 @@ __global__ __launch_bounds__(1024) void k_seg_collect(const Job *__restrict__ jo
                                                      const double *__restrict__ reg_abs,
                                                      const Extreme *__restrict__ job_res,
                                                      const Extreme *__restrict__ partial, int max_chunks,
+                                                     const double2 *__restrict__ sub,
                                                      const unsigned int *__restrict__ bits,
                                                      const long long *__restrict__ bit_off, int2 *__restrict__ cand,
                                                      int *__restrict__ cand_cnt) {
@@ -993,6 +1005,17 @@ __global__ __launch_bounds__(1024) void k_seg_collect(const Job *__restrict__ jo
         const Extreme p = partial[(int64_t)j * max_chunks + chunk];
         if (p.maxv < hi_cut && p.minv > lo_cut) return;
     }
+    // ... and within a block, most (side, search wave) slices: this kernel's wave w16 scans the
+    // window lengths 1 + w16 (mod 16), which the search's wave w16 / 4 covered
+    unsigned int skip = 0u;
+    {
+        const double2 *sb = sub + ((int64_t)j * max_chunks + chunk) * 8;
+        for (int side = 0; side < 2; ++side)
+            for (int w16 = 0; w16 < 16; ++w16) {
+                const double2 e2 = sb[side * 4 + (w16 >> 2)];
+                if (e2.x < hi_cut && e2.y > lo_cut) skip |= 1u << (side * 16 + w16);
+            }
+    }
     scan_chunk(c, rs, tid, [&](double v, int x, int y) {
         if (v >= hi_cut) {
             int at = atomicAdd(&cand_cnt[2 * h], 1);
@@ -1002,7 +1025,7 @@ __global__ __launch_bounds__(1024) void k_seg_collect(const Job *__restrict__ jo
             int at = atomicAdd(&cand_cnt[2 * h + 1], 1);
             if (at < CAND_CAP) cand[((int64_t)2 * h + 1) * CAND_CAP + at] = make_int2(x, y);
         }
-    });
+    }, skip);
 }
 
 // The decision of TriArr.segmentTri (triarray.py:59-84) given the exact extremes.
@@ -1471,6 +1494,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
         WC_CHECK(++guard < 100000, WC_E_INTERNAL, "stouffer: recursion did not terminate");
         // per-round scratch is sized by the jobs of this round, not by the worst case
         if ((rc = ts.partial.reserve(sizeof(Extreme) * n_jobs * max_chunks))) return rc;
+        if ((rc = ts.sub.reserve(sizeof(double2) * 8 * n_jobs * max_chunks))) return rc;
         if ((rc = ts.cand.reserve(sizeof(int2) * 2 * CAND_CAP * n_jobs))) return rc;
         if ((rc = ts.cand_cnt.reserve(sizeof(int) * 2 * n_jobs))) return rc;
         // round counters are reset by the search kernel, candidate counts by classify
@@ -1488,7 +1512,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     hipLaunchKernelGGL((k_seg_search<M, P_, NW_>), sg, dim3(64 * NW_), dyn, stream, (const Job *)cur, (int)n_jobs,   \
                        regions_dev, (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),     \
                        (const int *)ts.reg_flag.as<int>(), max_chunks, bits, bit_off, ts.partial.as<Extreme>(), \
-                       counters, (int)certify)
+                       counters, (int)certify, ts.sub.as<double2>())
 #define WC_SEARCH_NW(M, P_) do { if (wide) WC_SEARCH(M, P_, 16); else WC_SEARCH(M, P_, 4); } while (0)
             const bool wide = n_jobs * max_chunks <= 2048;     // few blocks: sixteen waves each
             if (bits) { if (plds) WC_SEARCH_NW(true, true); else WC_SEARCH_NW(true, false); }
@@ -1515,8 +1539,9 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
                                (const Job *)cur, (const int *)hot, (const int *)counters, regions_dev,
                                (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
                                (const double *)ts.reg_abs.as<double>(), (const Extreme *)ts.job_res.as<Extreme>(),
-                               (const Extreme *)ts.partial.as<Extreme>(), max_chunks, bits, bit_off,
-                               ts.cand.as<int2>(), ts.cand_cnt.as<int>());
+                               (const Extreme *)ts.partial.as<Extreme>(), max_chunks,
+                               (const double2 *)ts.sub.as<double2>(), bits, bit_off, ts.cand.as<int2>(),
+                               ts.cand_cnt.as<int>());
             hipLaunchKernelGGL(k_seg_decide, dim3((unsigned)n_hot), dim3(256), 0, stream, (const Job *)cur,
                                (const int *)hot, counters, regions_dev, z_dev, (const int2 *)ts.cand.as<int2>(),
                                (const int *)ts.cand_cnt.as<int>(), thr, min_search, bits, bit_off, ts.seg.as<Seg>(),
