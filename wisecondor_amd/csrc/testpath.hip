@@ -257,23 +257,37 @@ struct StreamSum {
 // the gathers); used for batches.  Otherwise thread = flat (bin, sample) index, which keeps
 // all lanes busy when there are only a few samples (latency mode).
 template <bool UNI>
-__global__ __launch_bounds__(256) void k_zscore(const double *__restrict__ XT, const double *__restrict__ XC,
-                                                const int *__restrict__ gidx, const int *__restrict__ nref, int k,
-                                                int64_t B, int64_t Ns, const int *__restrict__ active,
-                                                double *__restrict__ zT, double *__restrict__ rT,
-                                                double *__restrict__ nT, double *__restrict__ sdT) {
+__device__ inline void zscore_body(const unsigned int block, const double *__restrict__ XT,
+                                   const double *__restrict__ XC, const int *__restrict__ gidx,
+                                   const int *__restrict__ nref, int k, int64_t B, int64_t Ns,
+                                   const int *__restrict__ active, double *__restrict__ zT, double *__restrict__ rT,
+                                   double *__restrict__ nT, double *__restrict__ sdT,
+                                   const int *__restrict__ act_list, const int *__restrict__ act_count) {
+    // Later repeats of a batch touch only the samples that got a new flag, usually a few: those
+    // go through the flat variant over (listed sample, bin) with all lanes busy, and the
+    // wave-uniform variant stands down (both are launched; the device-side count picks one).
     int64_t gid, b, i;
     if (UNI) {
+        if (act_count && (int64_t)*act_count * 4 < Ns) return;
         const int64_t n_sg = (Ns + 63) / 64;
-        const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        const int64_t wave = (int64_t)block * 4 + (threadIdx.x >> 6);
         const int wb = __builtin_amdgcn_readfirstlane((int)(wave / n_sg));
         if (wb >= B) return;
         b = wb;
         i = (wave - (int64_t)wb * n_sg) * 64 + (threadIdx.x & 63);
         if (i >= Ns) return;
         gid = b * Ns + i;
+    } else if (act_list) {
+        const int64_t n_act = *act_count;
+        if (n_act * 4 >= Ns) return;
+        const int64_t t = (int64_t)block * 256 + threadIdx.x;
+        const int64_t a = t / B;
+        if (a >= n_act) return;
+        i = act_list[a];
+        b = t - a * B;                      // consecutive lanes: consecutive bins of one sample
+        gid = b * Ns + i;
     } else {
-        gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        gid = (int64_t)block * 256 + threadIdx.x;
         if (gid >= B * Ns) return;
         b = gid / Ns;
         i = gid - b * Ns;
@@ -359,18 +373,37 @@ __global__ __launch_bounds__(256) void k_zscore(const double *__restrict__ XT, c
     sdT[gid] = sd;
 }
 
+// One launch carries both mappings: the first n_uni workgroups run the wave-uniform variant, the
+// rest the flat one (either count may be zero).
+__global__ __launch_bounds__(256) void k_zscore(unsigned int n_uni, const double *__restrict__ XT,
+                                                const double *__restrict__ XC, const int *__restrict__ gidx,
+                                                const int *__restrict__ nref, int k, int64_t B, int64_t Ns,
+                                                const int *__restrict__ active, double *__restrict__ zT,
+                                                double *__restrict__ rT, double *__restrict__ nT,
+                                                double *__restrict__ sdT, const int *__restrict__ act_list,
+                                                const int *__restrict__ act_count) {
+    if (blockIdx.x < n_uni)
+        zscore_body<true>(blockIdx.x, XT, XC, gidx, nref, k, B, Ns, active, zT, rT, nT, sdT, nullptr, act_count);
+    else
+        zscore_body<false>(blockIdx.x - n_uni, XT, XC, gidx, nref, k, B, Ns, active, zT, rT, nT, sdT, act_list,
+                           act_count);
+}
+
 // testCopy[abs(z) >= threshold] = -1 (wisetools.py:446)
 // `cur` says which samples were recomputed in this repeat; `next` receives 1 for the
 // samples that got a NEW flag (only those can change in the following repeat).
 __global__ void k_flag(const double *__restrict__ zT, double thr, int64_t n, int64_t Ns,
-                       const int *__restrict__ cur, int *__restrict__ next, double *__restrict__ XC) {
+                       const int *__restrict__ cur, int *__restrict__ next, double *__restrict__ XC,
+                       int *__restrict__ list, int *__restrict__ count) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int64_t smp = i % Ns;
     if (cur && !cur[smp]) return;
     if (fabs(zT[i]) >= thr && XC[i] != -1.0) {
         XC[i] = -1.0;
-        next[smp] = 1;
+        // first new flag of this sample in this repeat: it joins the (unordered) list of samples
+        // the next repeat has to recompute
+        if (atomicExch(&next[smp], 1) == 0) list[atomicAdd(count, 1)] = (int)smp;
     }
 }
 
@@ -1369,24 +1402,27 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
         WC_HIP(hipMemsetAsync(ts.sdt.p, 0xFF, sizeof(double) * n, stream));
     }
     // active[it][sample]: did repeat it-1 add a flag for this sample?  (one clear for all repeats)
-    if ((rc = ts.misc2.reserve(sizeof(int) * (repeats + 1) * Ns))) return rc;
+    if ((rc = ts.misc2.reserve(sizeof(int) * ((repeats + 2) * Ns + repeats + 2)))) return rc;
     int *act = ts.misc2.as<int>();
-    if (repeats > 0) WC_HIP(hipMemsetAsync(act, 0, sizeof(int) * (repeats + 1) * Ns, stream));
+    int *act_counts = act + (int64_t)(repeats + 1) * Ns;   // [repeats + 2] newly flagged samples per repeat
+    int *act_list = act_counts + repeats + 2;              // [Ns] their indexes (rewritten every repeat)
+    if (repeats > 0)     // flags and counts of all repeats cleared at once
+        WC_HIP(hipMemsetAsync(act, 0, sizeof(int) * ((repeats + 1) * Ns + repeats + 2), stream));
     for (int it = 0; it < repeats; ++it) {
         const int *cur = it == 0 ? nullptr : act + (int64_t)it * Ns;
         int *next = act + (int64_t)(it + 1) * Ns;
-        if (Ns >= 32)
-            hipLaunchKernelGGL(k_zscore<true>, dim3((unsigned)cdiv(ref->B * cdiv(Ns, 64), 4)), dim3(256), 0, stream,
-                               (const double *)ts.xt.as<double>(), (const double *)ts.xc.as<double>(),
-                               (const int *)ref->gidx.as<int>(), (const int *)ref->nref.as<int>(), ref->k, ref->B, Ns,
-                               cur, ts.zt.as<double>(), ts.rt.as<double>(), ts.nt.as<double>(), ts.sdt.as<double>());
-        else
-            hipLaunchKernelGGL(k_zscore<false>, dim3(g), dim3(256), 0, stream, (const double *)ts.xt.as<double>(),
-                               (const double *)ts.xc.as<double>(), (const int *)ref->gidx.as<int>(),
-                               (const int *)ref->nref.as<int>(), ref->k, ref->B, Ns, cur, ts.zt.as<double>(),
-                               ts.rt.as<double>(), ts.nt.as<double>(), ts.sdt.as<double>());
+        // counts[it]: samples flagged during repeat it-1 (listed in act_list by k_flag)
+        const int *alist = (it > 0 && Ns >= 32) ? act_list : nullptr;
+        const int *acount = alist ? act_counts + it : nullptr;
+        const unsigned n_uni = Ns >= 32 ? (unsigned)cdiv(ref->B * cdiv(Ns, 64), 4) : 0u;
+        const unsigned n_flat = (Ns < 32 || alist) ? g : 0u;
+        hipLaunchKernelGGL(k_zscore, dim3(n_uni + n_flat), dim3(256), 0, stream, n_uni,
+                           (const double *)ts.xt.as<double>(), (const double *)ts.xc.as<double>(),
+                           (const int *)ref->gidx.as<int>(), (const int *)ref->nref.as<int>(), ref->k, ref->B, Ns, cur,
+                           ts.zt.as<double>(), ts.rt.as<double>(), ts.nt.as<double>(), ts.sdt.as<double>(), alist,
+                           acount);
         hipLaunchKernelGGL(k_flag, dim3(g), dim3(256), 0, stream, (const double *)ts.zt.as<double>(), thr, n, Ns,
-                           cur, next, ts.xc.as<double>());
+                           cur, next, ts.xc.as<double>(), act_list, act_counts + it + 1);
     }
     // stdDevAvg is a serial sum by definition (one lane per sample); it only feeds the
     // asdef output, so it runs on the context's side stream under the segmentation work.
