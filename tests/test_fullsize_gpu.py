@@ -1,0 +1,92 @@
+"""BASELINE.json's full sizes, checked through size-independent properties (the oracle needs
+hours there): newref 600 samples x 50 kb, batched test at 50 kb."""
+import numpy as np
+import pytest
+
+from oracle import wc_oracle as wo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def wt():
+    from wisecondor_amd import wisetools
+    return wisetools
+
+
+def test_newref_600x50kb_properties(wt):
+    """Every row: k distinct in-range candidates from other chromosomes, ascending (distance, index)
+    order; spot checks: stored distances are numpy's bits, and no unlisted candidate beats the k-th."""
+    from wisecondor_amd import synth
+    data, bins, sums = synth.corrected_matrix(50000, 600, seed=0)
+    data = np.asfortranarray(data)                        # the prep-file layout: sequential summation
+    B, k = data.shape[0], 100
+    idx, dst = wt.getReference(data, bins, sums, k, 1, 1)
+    assert idx.shape == (B, k) and dst.shape == (B, k)
+    st = wt.newref_stats(0)
+    assert st["fast_rows"] + st["fallback_rows"] == B
+    chrom = np.repeat(np.arange(len(bins)), bins)
+    n_other = B - np.asarray(bins)[chrom]                 # candidates per row
+    assert (idx >= 0).all() and (idx < n_other[:, None]).all()
+    assert (np.diff(dst, axis=1) >= 0).all()
+    ties = np.diff(dst, axis=1) == 0
+    assert (np.diff(idx, axis=1)[ties] > 0).all()         # ties keep the lower index first
+    srt = np.sort(idx, axis=1)
+    assert (np.diff(srt, axis=1) > 0).all()               # no candidate twice
+    rng = np.random.RandomState(0)
+    starts = np.concatenate([[0], np.cumsum(bins)])
+    for row in rng.choice(B, 12, replace=False):
+        c = chrom[row]
+        others = np.concatenate([data[:starts[c]], data[starts[c + 1]:]])
+        with np.errstate(all="ignore"):
+            d = np.sum(np.power(others - data[row], 2), 1)      # wisetools.py:302 on the F-ordered rows
+        order = np.argsort(d, kind="stable")[:k]
+        assert np.array_equal(idx[row], order.astype(np.int32)), row
+        assert np.array_equal(dst[row].view(np.uint64), d[order].view(np.uint64)), row
+
+
+def test_batched_test_50kb_equals_single_samples(wt):
+    """cfg5's shape per GPU (here 24 samples x 50 kb): every output of the batch equals the output
+    of the same sample tested alone, and a second run of the batch is bit-identical."""
+    from wisecondor_amd import synth
+    from wisecondor_amd.wisecondor import zThreshold
+    binsize = 50000
+    profile = synth.bin_profile(binsize)
+    refs = [synth.make_sample(profile, seed=i) for i in range(40)]
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        masked, chrom_bins, mask = wt.toNumpyArray(refs)
+        corrected, pca = wt.trainPCA(masked)
+    offs = np.concatenate([[0], np.cumsum(chrom_bins)])
+    masked_bins = np.array([int(mask[offs[i]:offs[i + 1]].sum()) for i in range(22)], dtype=np.int64)
+    idx, dst = wt.getReference(corrected, masked_bins, np.cumsum(masked_bins), 100, 1, 1)
+    reference = wt.Reference(idx, dst, np.asarray(chrom_bins, dtype=np.int64), masked_bins, mask, pca.mean_,
+                             pca.components_, binsize=binsize, device=0)
+    thr = float(zThreshold([int(v) for v in masked_bins], 1000, None))
+    tests = []
+    for i in range(24):
+        events = [("7", 400, 900, 1.04)] if i % 3 == 0 else []
+        tests.append(synth.make_sample(profile, seed=500 + i, events=events))
+    a = wt.test_batch(reference, tests, thr)
+    b = wt.test_batch(reference, tests, thr)
+
+    def same(u, v):
+        if not np.array_equal(np.asarray(u["results_cwz"]).view(np.uint64), np.asarray(v["results_cwz"]).view(np.uint64)):
+            return False
+        if not np.array_equal(np.float64(u["asdef"]).view(np.uint64), np.float64(v["asdef"]).view(np.uint64)):
+            return False
+        if not np.array_equal(u["results_calls"], v["results_calls"]):
+            return False
+        for key in ("results_z", "results_r"):
+            for cu, cv in zip(u[key], v[key]):
+                if not np.array_equal(np.asarray(cu).view(np.uint64), np.asarray(cv).view(np.uint64)):
+                    return False
+        return True
+
+    assert all(same(u, v) for u, v in zip(a, b))            # a second run is bit-identical
+    planted = sum(len(a[i]["results_calls"]) for i in range(0, 24, 3))
+    assert planted >= 8                                      # the planted gains are found
+    for i in (0, 7, 23):                                     # a sample alone == the sample in the batch
+        one = wt.test_batch(reference, [tests[i]], thr)[0]
+        assert same(one, a[i]), i
