@@ -187,6 +187,91 @@ template <bool GROUP8, class F> __device__ inline double pairwise_sum(F f, int64
     return result;
 }
 
+// The same sum by a whole wave: numpy's tree is walked once to list the leaves (<= 128
+// elements each), eight leaves at a time are summed by the eight 8-lane groups of the wave,
+// and the leaf sums are folded in the tree's order.  `leaf` is LDS scratch of the calling
+// wave: 3 * WC_PW_LEAVES ints worth of offsets / lengths plus WC_PW_LEAVES doubles.
+// Every lane returns the value.  n up to WC_PW_LEAVES * 64 elements at least (leaves hold
+// 65..128 elements); longer inputs fall back to the 8-lane walk.
+#define WC_PW_LEAVES 256
+struct PwWaveScratch {
+    int off[WC_PW_LEAVES];
+    int len[WC_PW_LEAVES];
+    double sum[WC_PW_LEAVES];
+};
+template <class F> __device__ inline double pairwise_sum_wave(F f, int64_t n, int lane, PwWaveScratch &sc) {
+    const int sub = lane & 7, grp = lane >> 3;
+    if (n <= WC_PW_BLOCK) return pw_leaf_group8(f, 0, (int)n, sub);
+    if (n > (int64_t)WC_PW_LEAVES * 64) return pairwise_sum<true>(f, n, sub);
+    // 1. leaves in tree (depth-first) order; every lane walks the same tree
+    int64_t s_off[WC_PW_DEPTH], s_n[WC_PW_DEPTH];
+    int s_phase[WC_PW_DEPTH];
+    int sp = 1, n_leaves = 0;
+    s_off[0] = 0; s_n[0] = n; s_phase[0] = 0;
+    while (sp > 0) {
+        const int t = sp - 1;
+        const int64_t nn = s_n[t], off = s_off[t];
+        if (nn <= WC_PW_BLOCK) {
+            if (lane == 0) { sc.off[n_leaves] = (int)off; sc.len[n_leaves] = (int)nn; }
+            ++n_leaves;
+            --sp;
+        } else {
+            int64_t n2 = nn / 2;
+            n2 -= n2 % 8;
+            if (s_phase[t] == 0) {
+                s_phase[t] = 1;
+                s_off[sp] = off; s_n[sp] = n2; s_phase[sp] = 0; ++sp;
+            } else if (s_phase[t] == 1) {
+                s_phase[t] = 2;
+                s_off[sp] = off + n2; s_n[sp] = nn - n2; s_phase[sp] = 0; ++sp;
+            } else {
+                --sp;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // 2. eight leaves per trip, one per 8-lane group
+    for (int base = 0; base < n_leaves; base += 8) {
+        const int l = base + grp;
+        const bool mine = l < n_leaves;
+        const double v = pw_leaf_group8(f, mine ? sc.off[l] : 0, mine ? sc.len[l] : 0, sub);
+        if (mine && sub == 0) sc.sum[l] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // 3. fold: the walk again, leaf values from the table
+    double s_left[WC_PW_DEPTH];
+    double result = 0.0;
+    int next_leaf = 0;
+    sp = 1;
+    s_off[0] = 0; s_n[0] = n; s_phase[0] = 0;
+    while (sp > 0) {
+        const int t = sp - 1;
+        const int64_t nn = s_n[t], off = s_off[t];
+        if (nn <= WC_PW_BLOCK) {
+            result = sc.sum[next_leaf++];
+            --sp;
+        } else {
+            int64_t n2 = nn / 2;
+            n2 -= n2 % 8;
+            if (s_phase[t] == 0) {
+                s_phase[t] = 1;
+                s_off[sp] = off; s_n[sp] = n2; s_phase[sp] = 0; ++sp;
+            } else if (s_phase[t] == 1) {
+                s_left[t] = result;
+                s_phase[t] = 2;
+                s_off[sp] = off + n2; s_n[sp] = nn - n2; s_phase[sp] = 0; ++sp;
+            } else {
+                result = s_left[t] + result;
+                --sp;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();          // the scratch may be reused by the caller's next sum
+    return result;
+}
+
 // Small per-lane value stack addressed by a wave-uniform index; the switch keeps the
 // array in registers (a runtime subscript would send it to scratch memory).
 __device__ inline void stack_set(double (&v)[10], int i, double x) {

@@ -651,17 +651,28 @@ __device__ inline double window_exact(const double *__restrict__ zz, int x, int 
     return s / sqrt((double)(y - x + 1));
 }
 
+// The same by a whole wave (leaves of numpy's tree summed eight at a time); every lane
+// returns the value.
+__device__ inline double window_exact_wave(const double *__restrict__ zz, int x, int y, int lane,
+                                           const WindowMask &wm, wc::PwWaveScratch &sc) {
+    if (!wm.valid(x, y)) return 0.0;
+    const double *p = zz + x;
+    double s = wc::pairwise_sum_wave([&](int64_t t) { return p[t]; }, (int64_t)(y - x + 1), lane, sc);
+    return s / sqrt((double)(y - x + 1));
+}
+
 __global__ __launch_bounds__(256) void k_region_whole(const double *__restrict__ z, const Region *__restrict__ regions,
                                                       int64_t n_regions, const unsigned int *__restrict__ bits,
                                                       const long long *__restrict__ bit_off,
                                                       double *__restrict__ whole) {
-    int64_t r = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
-    int sub = threadIdx.x & 7;
-    bool in = r < n_regions;
-    Region rg = regions[in ? r : 0];
-    WindowMask wm{bits, bits ? bit_off[in ? r : 0] : 0, rg.n};
-    double v = rg.n > 0 ? window_exact<true>(z + rg.off, 0, rg.n - 1, sub, wm) : NAN;
-    if (in && sub == 0) whole[r] = v;
+    __shared__ wc::PwWaveScratch sc[4];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;       // a wave per region
+    const int64_t r = (int64_t)blockIdx.x * 4 + w;
+    if (r >= n_regions) return;
+    const Region rg = regions[r];
+    const WindowMask wm{bits, bits ? bit_off[r] : 0, rg.n};
+    const double v = rg.n > 0 ? window_exact_wave(z + rg.off, 0, rg.n - 1, lane, wm, sc[w]) : NAN;
+    if (lane == 0) whole[r] = v;
 }
 
 __global__ void k_init_jobs(const Region *__restrict__ regions, int64_t n_regions, Job *__restrict__ jobs) {
@@ -1149,23 +1160,24 @@ __global__ __launch_bounds__(256) void k_seg_decide(const Job *__restrict__ jobs
     }
     const double *zz = z + regions[job.region].off;
     const WindowMask wm{bits, bits ? bit_off[job.region] : 0, regions[job.region].n};
-    const int grp = tid >> 3, sub = tid & 7;
     BestPair b;
     b.maxv = 0.0; b.minv = 0.0; b.mx = b.my = b.nx = b.ny = -1;
-    // 32 groups of 8 lanes: groups 0-15 evaluate candidates for the maximum, 16-31 for the
-    // minimum, 16 of each per trip; the trip count follows the longer list (usually one trip)
-    const int which = grp >> 4, slot = grp & 15;
+    // a wave per candidate: waves 0-1 evaluate candidates for the maximum, waves 2-3 for the
+    // minimum, two of each per trip; the trip count follows the longer list (usually one trip)
+    __shared__ wc::PwWaveScratch sc[4];
+    const int w = tid >> 6, lane = tid & 63;
+    const int which = w >> 1, slot = w & 1;
     const int n_mine = which == 0 ? n_hi : n_lo, n_most = n_hi > n_lo ? n_hi : n_lo;
-    for (int base = 0; base < n_most; base += 16) {
+    for (int base = 0; base < n_most; base += 2) {
         const int t = base + slot;
-        const bool act = t < n_mine;
-        const int2 w = cand[((int64_t)2 * h + which) * CAND_CAP + (act ? t : 0)];
-        const double v = n_mine > 0 ? window_exact<true>(zz, w.x, w.y, sub, wm) : 0.0;
-        if (act && sub == 0) {
+        if (t >= n_mine) continue;                                  // wave-uniform
+        const int2 cw = cand[((int64_t)2 * h + which) * CAND_CAP + t];
+        const double v = window_exact_wave(zz, cw.x, cw.y, lane, wm, sc[w]);
+        if (lane == 0) {
             if (which == 0) {
-                if (better_max(v, w.x, w.y, b.maxv, b.mx, b.my)) { b.maxv = v; b.mx = w.x; b.my = w.y; }
+                if (better_max(v, cw.x, cw.y, b.maxv, b.mx, b.my)) { b.maxv = v; b.mx = cw.x; b.my = cw.y; }
             } else {
-                if (better_min(v, w.x, w.y, b.minv, b.nx, b.ny)) { b.minv = v; b.nx = w.x; b.ny = w.y; }
+                if (better_min(v, cw.x, cw.y, b.minv, b.nx, b.ny)) { b.minv = v; b.nx = cw.x; b.ny = cw.y; }
             }
         }
     }
@@ -1516,7 +1528,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
         hipLaunchKernelGGL(k_block_minmax, dim3((unsigned)cdiv(nblk, 256)), dim3(256), 0, stream,
                            (const double *)ts.prefix.as<double>(), total, ts.tmin.as<double>(), ts.tmax.as<double>());
     }
-    hipLaunchKernelGGL(k_region_whole, dim3((unsigned)cdiv(n_regions, 32)), dim3(256), 0, stream, z_dev, regions_dev,
+    hipLaunchKernelGGL(k_region_whole, dim3((unsigned)cdiv(n_regions, 4)), dim3(256), 0, stream, z_dev, regions_dev,
                        n_regions, bits, bit_off, ts.whole.as<double>());
     hipLaunchKernelGGL(k_init_jobs, dim3((unsigned)cdiv(n_regions, 256)), dim3(256), 0, stream, regions_dev, n_regions,
                        ts.jobs_a.as<Job>());
