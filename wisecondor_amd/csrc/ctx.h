@@ -19,8 +19,9 @@ struct NewrefState {
     int64_t expect = 0;             // expected candidates per row under the sampled threshold
     float beta = 0.f;               // relative half-width of the key error interval
     bool prepared = false;
+    bool split = true;              // distance tiles on the bf16 matrix cores with hi/lo operand pairs
     // device buffers
-    wc::DevBuf col_partial, col_mean, a32, norm_lo, norm_hi, chrom_of_row, chrom_range, chrom_off_dev;
+    wc::DevBuf a3, col_partial, col_mean, a32, norm_lo, norm_hi, chrom_of_row, chrom_range, chrom_off_dev;
     wc::DevBuf sample_rows, sample_slot, s32, s_norm_lo, s_chrom, s_range, a16, s16;
     wc::DevBuf keys1, thr, cnt, list, tiles;
     wc::DevBuf fb_rows, fb_count, fb_scratch, stats, tiles0, pw_prog;
@@ -82,7 +83,7 @@ struct wc_ctx {
     }
 
     std::vector<wc::DevBuf *> all_buffers() {
-        return {&nr.col_partial, &nr.col_mean, &nr.a32, &nr.norm_lo, &nr.norm_hi, &nr.chrom_of_row, &nr.chrom_range,
+        return {&nr.a3, &nr.col_partial, &nr.col_mean, &nr.a32, &nr.norm_lo, &nr.norm_hi, &nr.chrom_of_row, &nr.chrom_range,
                 &nr.chrom_off_dev, &nr.sample_rows, &nr.sample_slot, &nr.s32, &nr.s_norm_lo, &nr.s_chrom, &nr.s_range, &nr.keys1,
                 &nr.thr, &nr.cnt, &nr.list, &nr.tiles, &nr.fb_rows, &nr.fb_count, &nr.fb_scratch,
                 &nr.stats, &nr.tiles0, &nr.pw_prog, &nr.a16, &nr.s16, &tmp_a, &tmp_b, &tmp_c, &tmp_d,

@@ -16,6 +16,7 @@
 //               exceed the k-th upper bound, re-score them in float64 in numpy's
 //               pairwise order, stable sort, emit; rows whose certificate fails
 //               take an exact brute-force path on the GPU
+#include <cstring>
 #include "ctx.h"
 
 #include <algorithm>
@@ -37,6 +38,7 @@ constexpr double SENTINEL_DISTANCE = 1e10;  // wisetools.py:306
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef double f64x2_u __attribute__((ext_vector_type(2), aligned(8)));   // rows of an odd sample count start 8-byte aligned
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void k_convert(const double *__restrict__ X, i
                                                  unsigned short *__restrict__ S16, float *__restrict__ s_norm_lo,
                                                  int *__restrict__ s_chrom, int2 *__restrict__ s_range,
                                                  float *__restrict__ thr, int *__restrict__ cnt,
-                                                 int *__restrict__ row_stat) {
+                                                 int *__restrict__ row_stat, unsigned short *__restrict__ A3) {
     int lane = threadIdx.x & 63;
     int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= Bpad) return;
@@ -116,6 +118,12 @@ __global__ __launch_bounds__(256) void k_convert(const double *__restrict__ X, i
         if (row < B && s < S) a = (float)(X[row * S + s] - mean[s]);
         if (s < Kpad) A[row * Kpad + s] = a;
         const unsigned short h = f32_to_bf16(a);
+        if (A3 && s < Kpad) {      // split image: per 32-sample slab, 32 hi then 32 lo bfloat16
+            const float hi_f = __uint_as_float((unsigned int)h << 16);
+            const int64_t at = row * (2 * Kpad) + (s >> 5) * 64 + (s & 31);
+            A3[at] = h;
+            A3[at + 32] = f32_to_bf16(a - hi_f);        // a - hi is exact in float32
+        }
         A16[row * Kpad16 + s] = h;
         if (slot >= 0) S16[(int64_t)slot * Kpad16 + s] = h;
         acc += (double)a * (double)a;
@@ -173,6 +181,7 @@ struct GramArgs {
     int64_t ld;                  // padded sample count
     int nslab;                   // ld / 32
     int last_groups;             // groups of four MFMA steps of the last slab that hold samples (1..4)
+    int last_steps16;            // split mode: 16-sample MFMA steps of the last slab that hold samples (1..2)
     const float *nbP, *nbQ;      // lower norm bounds
     const int2 *range;           // per row: [first, last+1) row of its chromosome (never candidates)
     const int4 *tiles;           // {I, J, roles, 0}
@@ -212,6 +221,17 @@ __device__ inline unsigned long long pack_entry(float key, int j) {
 // with the next slab's loads in flight during the MFMA phase.  Within a slab
 // lane (i, h) feeds k = 16h + t at MFMA step t, so each lane fetches its 16
 // operands with four conflict-free ds_read_b128.
+//
+// SPLIT = true runs the same tile on the bf16 matrix cores: every float32 operand is stored as
+// a pair of bfloat16 values (hi = bf16(a), lo = bf16(a - hi); a k-slab row is 32 hi then 32 lo,
+// the same 128 bytes), and a.b is accumulated as hi.hi + hi.lo + lo.hi in float32 -- three
+// v_mfma_f32_32x32x16_bf16 (8 passes for 16 samples each) instead of eight
+// v_mfma_f32_32x32x2_f32 (16 passes for 2 samples each): 5.3x less matrix-core time.  The
+// bf16 keeps 8 significant bits: |a - hi| <= 2^-8 |a|, |a - hi - lo| <= 2^-16 |a|, so the
+// hi+lo representation (2 * 2^-16) and the dropped lo.lo term (2^-16) stay below 3.1 * 2^-16 |a||b|;
+// that goes into beta (NewrefState::beta), i.e. into the lower / upper bounds every decision
+// rests on.
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 4) void k_gram(GramArgs g) {
     __shared__ __attribute__((aligned(16))) float sm[2 * TB * LDA + 4 * TB];   // 64 * LDD <= 2 * TB * LDA
     float *As = sm;
@@ -282,22 +302,51 @@ __global__ __launch_bounds__(256, 4) void k_gram(GramArgs g) {
         // keep the prefetch above the MFMA phase: the staging registers stay live, and the
         // fragments are fetched in four groups of four steps (16 live floats) instead
         __builtin_amdgcn_sched_barrier(0);
-        const float *a0 = &As[(wr * 64 + li) * LDA + lh * 16], *a1 = a0 + 32 * LDA;
-        const float *b0 = &Bs[(wc * 64 + li) * LDA + lh * 16], *b1 = b0 + 32 * LDA;
-        // the last slab runs only the step groups that hold samples (lane half h feeds
-        // k = 16h + t; the padding beyond the sample count is zero)
-        const int ntg = slab + 1 < g.nslab ? 4 : g.last_groups;
+        if constexpr (SPLIT) {
+            // slab row = 32 hi | 32 lo bfloat16 (16 + 16 floats).  MFMA step t covers samples
+            // 16 t .. 16 t + 15 of the slab; lane half h supplies 8 consecutive ones, from the same
+            // slots for A and B.  The last slab stops after the steps that hold samples.
+            const int nt = slab + 1 < g.nslab ? 2 : g.last_steps16;
 #pragma unroll
-        for (int tg = 0; tg < 4; ++tg) {
-            if (tg >= ntg) break;
-            const f32x4 ca0 = *(const f32x4 *)(a0 + 4 * tg), ca1 = *(const f32x4 *)(a1 + 4 * tg);
-            const f32x4 cb0 = *(const f32x4 *)(b0 + 4 * tg), cb1 = *(const f32x4 *)(b1 + 4 * tg);
+            for (int t = 0; t < 2; ++t) {
+                if (t >= nt) break;
+                const int off = t * 8 + lh * 4;       // float units within the hi half; lo half: + 16
+                const float *ar = &As[(wr * 64 + li) * LDA + off], *br = &Bs[(wc * 64 + li) * LDA + off];
+                const bf16x8 a0h = *(const bf16x8 *)ar, a0l = *(const bf16x8 *)(ar + 16);
+                const bf16x8 a1h = *(const bf16x8 *)(ar + 32 * LDA), a1l = *(const bf16x8 *)(ar + 32 * LDA + 16);
+                const bf16x8 b0h = *(const bf16x8 *)br, b0l = *(const bf16x8 *)(br + 16);
+                const bf16x8 b1h = *(const bf16x8 *)(br + 32 * LDA), b1l = *(const bf16x8 *)(br + 32 * LDA + 16);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b0h, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b1h, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b0h, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b1h, acc[1][1], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0l, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b1l, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0l, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1l, acc[1][1], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0h, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b1h, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0h, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1h, acc[1][1], 0, 0, 0);
+            }
+        } else {
+            const float *a0 = &As[(wr * 64 + li) * LDA + lh * 16], *a1 = a0 + 32 * LDA;
+            const float *b0 = &Bs[(wc * 64 + li) * LDA + lh * 16], *b1 = b0 + 32 * LDA;
+            // the last slab runs only the step groups that hold samples (lane half h feeds
+            // k = 16h + t; the padding beyond the sample count is zero)
+            const int ntg = slab + 1 < g.nslab ? 4 : g.last_groups;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca0[e], cb0[e], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca0[e], cb1[e], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca1[e], cb0[e], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca1[e], cb1[e], acc[1][1], 0, 0, 0);
+            for (int tg = 0; tg < 4; ++tg) {
+                if (tg >= ntg) break;
+                const f32x4 ca0 = *(const f32x4 *)(a0 + 4 * tg), ca1 = *(const f32x4 *)(a1 + 4 * tg);
+                const f32x4 cb0 = *(const f32x4 *)(b0 + 4 * tg), cb1 = *(const f32x4 *)(b1 + 4 * tg);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca0[e], cb0[e], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca0[e], cb1[e], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca1[e], cb0[e], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca1[e], cb1[e], acc[1][1], 0, 0, 0);
+                }
             }
         }
     }
@@ -406,7 +455,6 @@ __global__ __launch_bounds__(256, 4) void k_gram(GramArgs g) {
 // So the distances to the M sampled rows use the bf16 matrix cores: 16x the fp32 MFMA
 // rate, ~0.4 % error on the dot products, i.e. a ~10 % wobble of the candidate count.
 // Same 128x128 tile / 4 waves / LDS byte layout as k_gram; a slab is 64 bf16 (128 B) deep.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __global__ __launch_bounds__(256, 4) void k_gram_thr16(const unsigned short *__restrict__ P16,
                                                        const unsigned short *__restrict__ Q16, int64_t ld16,
@@ -1303,7 +1351,16 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
     st.k_pad16 = round_up(n_samples, 64);
     st.cap = LIST_CAP;
     st.expect = LIST_CAP / 2;
-    st.beta = (float)((double)(n_samples + 16) * 5.9604644775390625e-08 * 1.001);
+    {
+        const char *e = getenv("WC_GRAM_MODE");           // "f32": float32 matrix cores; default: split bfloat16
+        st.split = !(e && strcmp(e, "f32") == 0);
+    }
+    // relative half-width of the key error interval: the float32 accumulation chain (doubled in
+    // split mode: nothing is assumed about the rounding inside the bf16 dot products beyond 2^-23
+    // per term) plus, in split mode, the hi+lo representation and the dropped lo.lo term
+    st.beta = st.split
+                  ? (float)(((double)(n_samples + 16) * 2.0 * 5.9604644775390625e-08 + 3.1 * 1.52587890625e-05) * 1.001)
+                  : (float)((double)(n_samples + 16) * 5.9604644775390625e-08 * 1.001);
     int64_t M = round_up((n_bins + 13) / 14, TB);
     if (M < 512) M = 512;
     if (M > MAX_SAMPLE_COLS) M = MAX_SAMPLE_COLS;
@@ -1313,6 +1370,7 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
     int rc;
     if ((rc = st.col_mean.reserve(sizeof(double) * 3 * n_samples))) return rc;
     if ((rc = st.a32.reserve(sizeof(float) * st.bins_pad * st.k_pad))) return rc;
+    if (st.split && (rc = st.a3.reserve(sizeof(float) * st.bins_pad * st.k_pad))) return rc;
     if ((rc = st.norm_lo.reserve(sizeof(float) * st.bins_pad))) return rc;
     if ((rc = st.norm_hi.reserve(sizeof(float) * st.bins_pad))) return rc;
     if ((rc = st.chrom_of_row.reserve(sizeof(int) * st.bins_pad))) return rc;
@@ -1391,7 +1449,8 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
                        st.k_pad16, st.norm_lo.as<float>(), st.norm_hi.as<float>(), st.chrom_of_row.as<int>(),
                        st.chrom_range.as<int2>(), (const int *)st.sample_slot.as<int>(),
                        st.s16.as<unsigned short>(), st.s_norm_lo.as<float>(), st.s_chrom.as<int>(),
-                       st.s_range.as<int2>(), st.thr.as<float>(), st.cnt.as<int>(), st.stats.as<int>());
+                       st.s_range.as<int2>(), st.thr.as<float>(), st.cnt.as<int>(), st.stats.as<int>(),
+                       st.split ? st.a3.as<unsigned short>() : (unsigned short *)nullptr);
     if (M > n_bins)
         hipLaunchKernelGGL(k_pad_samples, dim3((unsigned)(M - n_bins)), dim3(256), 0, stream, st.k_pad16, n_bins,
                            st.s16.as<unsigned short>(), st.s_norm_lo.as<float>(), st.s_chrom.as<int>(),
@@ -1523,12 +1582,13 @@ int wc_newref_collect_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t
     ctx->last_stats[3] = st.n_sample_cols;
     if (st.tiles1_n == 0) return WC_OK;
     GramArgs g{};
-    g.P = g.Q = st.a32.as<float>();
+    g.P = g.Q = st.split ? st.a3.as<float>() : st.a32.as<float>();
     g.ld = st.k_pad;
     g.nslab = (int)(st.k_pad / BK);
     {
         const int64_t rem = st.n_samples - (int64_t)(g.nslab - 1) * BK;     // samples in the last slab, 1..32
         g.last_groups = (int)((std::min<int64_t>(rem, 16) + 3) / 4);
+        g.last_steps16 = rem > 16 ? 2 : 1;
     }
     g.nbP = g.nbQ = st.norm_lo.as<float>();
     g.range = st.chrom_range.as<int2>();
@@ -1539,7 +1599,8 @@ int wc_newref_collect_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t
     g.list = st.list.as<unsigned long long>();
     g.cap = (int)st.cap;
     unsigned grid = (unsigned)(((g.ntiles + 7) / 8) * 8);
-    hipLaunchKernelGGL(k_gram, dim3(grid), dim3(256), 0, stream, g);
+    if (st.split) hipLaunchKernelGGL(k_gram<true>, dim3(grid), dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL(k_gram<false>, dim3(grid), dim3(256), 0, stream, g);
     WC_HIP(hipGetLastError());
     return WC_OK;
 }
