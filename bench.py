@@ -34,6 +34,8 @@ WORKLOADS = {
     "cfg4": (50000, 600),
 }
 PEAK_FP32_MFMA = 157.3e12  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA = 2500e12   # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak (no sparsity)
+SPLIT_PRODUCTS = 3.0       # k_gram<split>: hi.hi + hi.lo + lo.hi per float32 multiply
 
 
 def build_inputs(binsize, n_ref, n_test, seed0=0):
@@ -134,6 +136,21 @@ def main():
     t_newref = time.perf_counter() - t0
     kernel_ms = float(np.mean([ev[2 * s].elapsed_time(ev[2 * s + 1]) for s in range(args.steps)]))
     stats = wt.newref_stats(local_rank)
+    split = os.environ.get("WC_GRAM_MODE", "") != "f32"
+    f32_kernel_ms = None
+    if split and world == 1:
+        # the same pass with the distance tiles on the float32 matrix cores (north-star wording),
+        # for the record: a few steps, kernel time only
+        os.environ["WC_GRAM_MODE"] = "f32"
+        fev = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
+        job.run()
+        for s4 in range(4):
+            job.run(collect_events=(fev[2 * s4], fev[2 * s4 + 1]))
+        torch.cuda.synchronize()
+        f32_kernel_ms = float(np.mean([fev[2 * s4].elapsed_time(fev[2 * s4 + 1]) for s4 in range(4)]))
+        del os.environ["WC_GRAM_MODE"]
+        idx, dst = job.run()                      # leave the context in the default mode
+        torch.cuda.synchronize()
     tdev = dev if args.backend == "nccl" else torch.device("cpu")
     tmax = torch.tensor([t_newref], device=tdev, dtype=torch.float64)
     if world > 1:
@@ -212,8 +229,13 @@ def main():
         extra = {"workload": "cfg4: newref %d samples x %d kb bins (%d bins), kernel-level synthetic matrix"
                              % (xs, xb // 1000, XB),
                  "value": xpairs * xsteps / xt, "unit": "bin-pair distances/s", "ms_per_step": 1e3 * xt / xsteps,
-                 "steps": xsteps, "shard_mode": xjob.mode or "tiles", "k_gram_ms": xk_ms, "k_gram_tflops": xflops / (xk_ms * 1e-3) / 1e12,
-                 "k_gram_frac_of_fp32_mfma_peak": xflops / (xk_ms * 1e-3) / PEAK_FP32_MFMA}
+                 "steps": xsteps, "shard_mode": xjob.mode or "tiles", "k_gram_ms": xk_ms,
+                 "k_gram_algorithmic_tflops": xflops / (xk_ms * 1e-3) / 1e12}
+        if os.environ.get("WC_GRAM_MODE", "") != "f32":
+            extra["k_gram_executed_tflops"] = SPLIT_PRODUCTS * xflops / (xk_ms * 1e-3) / 1e12
+            extra["k_gram_frac_of_bf16_mfma_peak"] = SPLIT_PRODUCTS * xflops / (xk_ms * 1e-3) / PEAK_BF16_MFMA
+        else:
+            extra["k_gram_frac_of_fp32_mfma_peak"] = xflops / (xk_ms * 1e-3) / PEAK_FP32_MFMA
         del xjob, XX
         # the main job's context state was replaced by the extra run; nothing below needs it
 
@@ -261,7 +283,30 @@ def main():
                 traffic = 1024.0 * (2.0 * t["fetch_kb_per_launch"] + t["write_kb_per_launch"])
         # algorithmic work of the dominant kernel: one multiply-add per sample per unordered pair
         flops = (pairs / 2.0) * 2.0 * S / world
-        achieved = flops / (kernel_ms * 1e-3)
+        if split:
+            # the tiles run on the bf16 matrix cores: three bf16 products stand for one float32
+            # multiply, so the executed work is 3x the algorithmic work and the peak is the bf16 one
+            achieved = SPLIT_PRODUCTS * flops / (kernel_ms * 1e-3)
+            roof = {"kernel": "k_gram<split> (symmetric distance tiles on the bf16 matrix cores, hi/lo operand "
+                              "pairs, + candidate filter)",
+                    "bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_BF16_MFMA, "traffic": traffic,
+                    "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_traffic.json)",
+                    "kernel_ms": kernel_ms, "algorithmic_flop_per_launch": flops,
+                    "executed_flop_per_launch": SPLIT_PRODUCTS * flops,
+                    "algorithmic_tflops": flops / (kernel_ms * 1e-3) / 1e12,
+                    "algorithmic_rate_over_fp32_mfma_peak": flops / (kernel_ms * 1e-3) / PEAK_FP32_MFMA,
+                    "fp32_mfma_variant": None if f32_kernel_ms is None else {
+                        "kernel_ms": f32_kernel_ms, "achieved": flops / (f32_kernel_ms * 1e-3) / 1e12,
+                        "peak": PEAK_FP32_MFMA / 1e12, "frac": flops / (f32_kernel_ms * 1e-3) / PEAK_FP32_MFMA,
+                        "note": "WC_GRAM_MODE=f32: same tiles with v_mfma_f32_32x32x2_f32"}}
+        else:
+            achieved = flops / (kernel_ms * 1e-3)
+            roof = {"kernel": "k_gram (symmetric fp32 MFMA distance tiles + candidate filter)",
+                    "bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_FP32_MFMA, "traffic": traffic,
+                    "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_traffic.json)",
+                    "kernel_ms": kernel_ms, "algorithmic_flop_per_launch": flops}
         out = {
             "metric": "newref bin-pair distances/sec",
             "value": value,
@@ -273,7 +318,8 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32 MFMA distance + f64 exact re-score",
+            "dtype": ("bf16x3 MFMA (hi/lo pairs, f32 accumulate) distance bounds + f64 exact re-score" if split
+                      else "f32 MFMA distance bounds + f64 exact re-score"),
             "data": "synthetic",
             "config": {"workload": "%s: newref %d samples x %d kb bins (%d masked bins, refsize %d), "
                                    "then batched test of %d samples/GPU at the same bin size"
@@ -292,11 +338,7 @@ def main():
                                   "frac": samples_per_s / world * test_bytes / 8.0e12,
                                   "windows_per_s": samples_per_s * windows},
                      "calls_found": n_calls},
-            "roofline": {"kernel": "k_gram (symmetric fp32 MFMA distance tiles + candidate filter)",
-                         "bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_FP32_MFMA / 1e12,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA, "traffic": traffic,
-                         "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_traffic.json)",
-                         "kernel_ms": kernel_ms, "algorithmic_flop_per_launch": flops},
+            "roofline": roof,
             "newref_stats": stats,
             "extra": extra,
             "cpu_baseline": cpu,

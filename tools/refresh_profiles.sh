@@ -31,7 +31,7 @@ for wl in ("cfg2", "cfg4"):
     vals = {}
     for c in ("fetch_size", "write_size"):
         for row in csv.reader(open("%s/%s_%s_pmc_%s.csv" % (out, tag, wl, c))):
-            if row and "::k_gram(" in row[0]:
+            if row and "::k_gram" in row[0] and "thr16" not in row[0]:
                 vals[c] = float(row[2])
     res[wl] = {"fetch_kb_per_launch": vals.get("fetch_size"), "write_kb_per_launch": vals.get("write_size"),
                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/profile_gpu.sh, PMC=1), "
