@@ -80,10 +80,10 @@ class HipStages(object):
 
 
 # Cost model of the shard-mode choice (seconds; one MI355X per rank, xGMI between them).
-# Measured on one GPU: the symmetric distance kernel sustains ~60 % of the fp32 MFMA peak at
-# 100 samples and ~80 % at 600.  The exchange figures are planning numbers for RCCL on a
-# fully connected 8-GPU node (not measured here: the test box has one GPU).
-_MFMA_RATE = 0.6 * 157.3e12          # sustained flop/s of the distance kernel
+# Measured on one GPU: the symmetric distance kernel (bf16 hi/lo tiles) delivers ~110 TFLOP/s of
+# algorithmic work at 100 samples and ~275 at 600.  The exchange figures are planning numbers for
+# RCCL on a fully connected 8-GPU node (not measured here: the test box has one GPU).
+_MFMA_RATE = 2.0e14                  # sustained algorithmic flop/s of the distance kernel
 _COLL_LATENCY = 30e-6                # fixed cost of one small RCCL collective
 _XGMI_RATE = 100e9                   # bytes/s a rank moves in an all-to-all (several links busy)
 
