@@ -231,8 +231,8 @@ __device__ inline unsigned long long pack_entry(float key, int j) {
 // hi+lo representation (2 * 2^-16) and the dropped lo.lo term (2^-16) stay below 3.1 * 2^-16 |a||b|;
 // that goes into beta (NewrefState::beta), i.e. into the lower / upper bounds every decision
 // rests on.
-template <bool SPLIT>
-__global__ __launch_bounds__(256, 4) void k_gram(GramArgs g) {
+template <bool SPLIT, int DEPTH>   // DEPTH: k-slabs of operand loads in flight (register staged; 2 only with SPLIT)
+__global__ __launch_bounds__(256, DEPTH == 2 ? 3 : 4) void k_gram(GramArgs g) {
     __shared__ __attribute__((aligned(16))) float sm[2 * TB * LDA + 4 * TB];   // 64 * LDD <= 2 * TB * LDA
     float *As = sm;
     float *Bs = sm + TB * LDA;
@@ -282,6 +282,88 @@ __global__ __launch_bounds__(256, 4) void k_gram(GramArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    if constexpr (DEPTH == 2) {
+        // Two slabs of loads in flight: with the bf16 tiles one slab's 24 MFMAs (0.4 us) no longer
+        // cover a global round trip (~3 us under load), so the loads of slab s+2 are issued while
+        // slab s is multiplied and slab s+1 is still on its way.  Costs 32 more registers: three
+        // waves per SIMD instead of four.
+        f32x4 pa2[4], qb2[4];
+        {
+            const int64_t ko = (int64_t)(g.nslab > 1 ? 1 : 0) * BK;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                pa2[p] = *(const f32x4 *)(Pg + ko + (int64_t)p * 32 * g.ld);
+                qb2[p] = *(const f32x4 *)(Qg + ko + (int64_t)p * 32 * g.ld);
+            }
+        }
+        __builtin_amdgcn_s_setprio(2);
+#define WC_SPLIT_STEPS(NT)                                                                                      \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                            \
+        if (t >= (NT)) break;                                                                                  \
+        const int off = t * 8 + lh * 4;                                                                        \
+        const float *ar = &As[(wr * 64 + li) * LDA + off], *br = &Bs[(wc * 64 + li) * LDA + off];              \
+        const bf16x8 a0h = *(const bf16x8 *)ar, a0l = *(const bf16x8 *)(ar + 16);                              \
+        const bf16x8 a1h = *(const bf16x8 *)(ar + 32 * LDA), a1l = *(const bf16x8 *)(ar + 32 * LDA + 16);      \
+        const bf16x8 b0h = *(const bf16x8 *)br, b0l = *(const bf16x8 *)(br + 16);                              \
+        const bf16x8 b1h = *(const bf16x8 *)(br + 32 * LDA), b1l = *(const bf16x8 *)(br + 32 * LDA + 16);      \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b0h, acc[0][0], 0, 0, 0);                     \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b1h, acc[0][1], 0, 0, 0);                     \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b0h, acc[1][0], 0, 0, 0);                     \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b1h, acc[1][1], 0, 0, 0);                     \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0l, acc[0][0], 0, 0, 0);                     \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b1l, acc[0][1], 0, 0, 0);                     \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0l, acc[1][0], 0, 0, 0);                     \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1l, acc[1][1], 0, 0, 0);                     \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0h, acc[0][0], 0, 0, 0);                     \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b1h, acc[0][1], 0, 0, 0);                     \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0h, acc[1][0], 0, 0, 0);                     \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1h, acc[1][1], 0, 0, 0);                     \
+    }
+        for (int slab = 0; slab < g.nslab; slab += 2) {
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                *(f32x4 *)&As[(lrow + 32 * p) * LDA + lcol] = pa[p];
+                *(f32x4 *)&Bs[(lrow + 32 * p) * LDA + lcol] = qb[p];
+            }
+            __syncthreads();
+            {   // slab + 2 (clamped to the last slab: a harmless re-read instead of a branch)
+                const int64_t ko = (int64_t)(slab + 2 < g.nslab ? slab + 2 : g.nslab - 1) * BK;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    pa[p] = *(const f32x4 *)(Pg + ko + (int64_t)p * 32 * g.ld);
+                    qb[p] = *(const f32x4 *)(Qg + ko + (int64_t)p * 32 * g.ld);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const int nt = slab + 1 < g.nslab ? 2 : g.last_steps16;
+                WC_SPLIT_STEPS(nt)
+            }
+            if (slab + 1 >= g.nslab) break;
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                *(f32x4 *)&As[(lrow + 32 * p) * LDA + lcol] = pa2[p];
+                *(f32x4 *)&Bs[(lrow + 32 * p) * LDA + lcol] = qb2[p];
+            }
+            __syncthreads();
+            {
+                const int64_t ko = (int64_t)(slab + 3 < g.nslab ? slab + 3 : g.nslab - 1) * BK;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    pa2[p] = *(const f32x4 *)(Pg + ko + (int64_t)p * 32 * g.ld);
+                    qb2[p] = *(const f32x4 *)(Qg + ko + (int64_t)p * 32 * g.ld);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const int nt = slab + 2 < g.nslab ? 2 : g.last_steps16;
+                WC_SPLIT_STEPS(nt)
+            }
+        }
+#undef WC_SPLIT_STEPS
+    } else {
     __builtin_amdgcn_s_setprio(2);   // waves feeding the matrix cores go ahead of waves in their epilogue
     for (int slab = 0; slab < g.nslab; ++slab) {
         __syncthreads();
@@ -350,6 +432,8 @@ __global__ __launch_bounds__(256, 4) void k_gram(GramArgs g) {
             }
         }
     }
+
+    }   // DEPTH
 
     // Epilogue in two halves (rows 0-63 from the waves with wr == 0, then rows 64-127):
     // the 64 x 128 dot-product tile aliases the staging buffers, which keeps the
@@ -1599,8 +1683,13 @@ int wc_newref_collect_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t
     g.list = st.list.as<unsigned long long>();
     g.cap = (int)st.cap;
     unsigned grid = (unsigned)(((g.ntiles + 7) / 8) * 8);
-    if (st.split) hipLaunchKernelGGL(k_gram<true>, dim3(grid), dim3(256), 0, stream, g);
-    else hipLaunchKernelGGL(k_gram<false>, dim3(grid), dim3(256), 0, stream, g);
+    if (st.split) {
+        const char *e = getenv("WC_GRAM_DEPTH");
+        if (e && atoi(e) == 1) hipLaunchKernelGGL((k_gram<true, 1>), dim3(grid), dim3(256), 0, stream, g);
+        else hipLaunchKernelGGL((k_gram<true, 2>), dim3(grid), dim3(256), 0, stream, g);
+    } else {
+        hipLaunchKernelGGL((k_gram<false, 1>), dim3(grid), dim3(256), 0, stream, g);
+    }
     WC_HIP(hipGetLastError());
     return WC_OK;
 }
