@@ -142,3 +142,59 @@ def test_thresholds_are_reproducible():
             job.run()          # dirty every workspace in between
     assert np.array_equal(seen[0], seen[1]) and np.array_equal(seen[0], seen[2])
     assert np.isfinite(seen[0]).all() and (seen[0] > 0).all()
+
+
+@pytest.mark.parametrize("mode", ["split", "f32"])
+@pytest.mark.parametrize("kind", ["noise", "wide"])
+def test_listed_keys_are_lower_bounds(mode, kind, monkeypatch):
+    """Every decision of the fast path rests on key <= true distance <= key + 3*beta*(norms).
+    The candidate lists expose the keys: check the bound on every listed pair, for the bf16
+    hi/lo tiles (default) and the float32 tiles, on plain noise and on rows whose magnitudes
+    span four orders (the split operands lose the low bits of large values)."""
+    import torch
+    from wisecondor_amd import _lib, distributed, synth
+    if mode == "f32":
+        monkeypatch.setenv("WC_GRAM_MODE", "f32")
+    else:
+        monkeypatch.delenv("WC_GRAM_MODE", raising=False)
+    data, bins, _ = synth.corrected_matrix(1000000, 200, seed=8)
+    if kind == "wide":
+        rng = np.random.RandomState(3)
+        data = data * np.exp(rng.uniform(-4.0, 4.0, size=(data.shape[0], 1)))      # per-row scale e^-4 .. e^4
+        data += rng.standard_normal(data.shape) * 1e-3
+    data = np.ascontiguousarray(data)
+    X = torch.from_numpy(data).cuda()
+    job = distributed.NewrefJob(_lib.context(0), X, bins, 100, _lib.SUM_PAIRWISE)
+    st = job.st
+    st.prepare()
+    st.thresholds(0, st.n_bins)
+    st.collect(0, st.n_bins, 0, 1)
+    cap = st.cap
+    cnt = torch.zeros(st.n_bins, dtype=torch.int32, device="cuda")
+    lst = torch.zeros((st.n_bins, cap), dtype=torch.int64, device="cuda")
+    st.export(0, st.n_bins, cap, cnt, lst)
+    torch.cuda.synchronize()
+    cnt = cnt.cpu().numpy()
+    lst = lst.cpu().numpy().view(np.uint64)
+    checked = 0
+    worst = 0.0
+    for i in range(0, st.n_bins, 7):
+        n = min(int(cnt[i]), cap)
+        if n == 0:
+            continue
+        e = lst[i, :n]
+        j = (e & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        u = (e >> np.uint64(32)).astype(np.uint32)
+        bits = np.where(u & np.uint32(0x80000000), u & np.uint32(0x7FFFFFFF), ~u)
+        key = bits.astype(np.uint32).view(np.float32).astype(np.float64)
+        d = ((data[j] - data[i]) ** 2).sum(1)
+        assert (key <= d * (1 + 1e-12) + 1e-300).all(), (mode, kind, i)
+        scale = (data[j] ** 2).sum(1) + (data[i] ** 2).sum()
+        worst = max(worst, float(((d - key) / np.maximum(scale, 1e-300)).max()))
+        checked += n
+    assert checked > 10000
+    # the slack relative to |a|^2 + |b|^2 of the raw rows; on plain noise the kernel's centred rows
+    # have smaller norms than the raw ones, so this is far inside 3 * beta (the wide case centres
+    # rows of very different scale on one common centre: no such yardstick)
+    if kind == "noise":
+        assert worst < 1e-3
