@@ -1,0 +1,32 @@
+"""Time of the GPU newref prep (wc_newref_prep_gram + host eigh + wc_newref_prep_finish) on random counts.
+    python3 tools/gpu_prep_time.py [cfg2|cfg4]"""
+import ctypes, sys, time
+import numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "/root/repo")
+from wisecondor_amd import _lib, synth
+which = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+binsize, n_s = {"cfg2": (250000, 100), "cfg4": (50000, 600)}[which]
+sizes = np.ascontiguousarray(synth.chrom_bins(binsize), dtype=np.int64)
+n_total = int(sizes.sum())
+rng = np.random.RandomState(0)
+prof = rng.gamma(20.0, 1 / 20.0, n_total)
+counts = rng.poisson(prof[None, :] * 800.0, size=(n_s, n_total)).astype(np.int32)
+lib = _lib.load(); ctx = _lib.context(0)
+for it in range(3):
+    mask = np.empty(n_total, dtype=np.uint8); mbins = np.empty(len(sizes), dtype=np.int64)
+    n_b = ctypes.c_int64(); gram = np.empty((n_s, n_s))
+    t0 = time.perf_counter()
+    _lib.check(lib.wc_newref_prep_gram(ctx, _lib.ptr(counts), n_s, n_total, _lib.ptr(sizes), len(sizes),
+                                       _lib.ptr(mask), _lib.ptr(mbins), ctypes.byref(n_b), _lib.ptr(gram)))
+    t1 = time.perf_counter()
+    vals, vecs = np.linalg.eigh(gram)
+    order = np.argsort(vals)[::-1][:3]
+    evals = np.ascontiguousarray(vals[order]); evecs = np.ascontiguousarray(vecs[:, order].T)
+    t2 = time.perf_counter()
+    B = n_b.value
+    masked = np.empty((B, n_s)); corrected_t = np.empty((n_s, B)); comps = np.empty((3, B)); mean = np.empty(B)
+    _lib.check(lib.wc_newref_prep_finish(ctx, 3, _lib.ptr(evecs), _lib.ptr(evals), _lib.ptr(masked),
+                                         _lib.ptr(corrected_t), _lib.ptr(comps), _lib.ptr(mean)))
+    t3 = time.perf_counter()
+    print("%s it %d: gram (incl. H2D/D2H) %.1f ms, eigh %.1f ms, finish (incl. D2H of %d MB) %.1f ms"
+          % (which, it, 1e3 * (t1 - t0), 1e3 * (t2 - t1), (masked.nbytes + corrected_t.nbytes) >> 20, 1e3 * (t3 - t2)), flush=True)
