@@ -412,22 +412,28 @@ __global__ void k_flag(const double *__restrict__ zT, double thr, int64_t n, int
 // adds; all 256 threads of the workgroup stream 128-bin chunks of sds through LDS (the
 // next chunk's loads in flight during the adds), so the chain is add-latency bound, not
 // load-latency bound.  Skipped (NaN) terms add +0.0, exact for a sum of sds >= 0.
+// SPB samples per workgroup (64, or 16 for latency mode): the 256 threads stage chunks of
+// 128 * 64 / SPB bins, i.e. few samples get long chunks, whose sums cover the latency of the
+// next chunk's loads (one sample: 512-bin chunks, 22 load round trips instead of 87).
+template <int SPB>
 __global__ __launch_bounds__(256) void k_sd_avg(const double *__restrict__ sdT, int64_t B, int64_t Ns,
                                                 double *__restrict__ out) {
-    __shared__ double buf[128][64];
-    __shared__ int cnts[4][64];
-    const int ss = threadIdx.x & 63, bq = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * 64 + ss;
+    constexpr int PH = 256 / SPB;                 // bin phases: thread (ss, bq) stages bins bq, bq + PH, ...
+    constexpr int CH = 32 * PH;                   // bins per chunk
+    __shared__ double buf[CH][SPB];
+    __shared__ int cnts[PH][SPB];
+    const int ss = threadIdx.x % SPB, bq = threadIdx.x / SPB;
+    const int64_t i = (int64_t)blockIdx.x * SPB + ss;
     const bool live = i < Ns;
     // The staging threads do everything that is not the chain: NaN terms (and bins past the
     // end) become +0.0 -- exact for a sum of sds >= +0 -- and are left out of the count, so the
-    // adding wave issues one LDS read and one add per bin.
+    // adding lanes issue one LDS read and one add per bin.
     double pre[32];
     int cnt = 0;
     auto fetch = [&](int64_t base) {
 #pragma unroll
         for (int u = 0; u < 32; ++u) {
-            const int64_t b = base + bq + 4 * u;
+            const int64_t b = base + bq + PH * u;
             const double x = (live && b < B) ? sdT[b * Ns + i] : NAN;
             const bool ok = x == x;
             cnt += ok;
@@ -436,14 +442,14 @@ __global__ __launch_bounds__(256) void k_sd_avg(const double *__restrict__ sdT, 
     };
     fetch(0);
     double s = 0.0;
-    for (int64_t b0 = 0; b0 < B; b0 += 128) {
+    for (int64_t b0 = 0; b0 < B; b0 += CH) {
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 32; ++u) buf[bq + 4 * u][ss] = pre[u];
+        for (int u = 0; u < 32; ++u) buf[bq + PH * u][ss] = pre[u];
         __syncthreads();
-        if (b0 + 128 < B) fetch(b0 + 128);
-        if (threadIdx.x < 64) {
-            for (int bb = 0; bb < 128; bb += 16) {
+        if (b0 + CH < B) fetch(b0 + CH);
+        if (threadIdx.x < SPB) {
+            for (int bb = 0; bb < CH; bb += 16) {
                 double v[16];
 #pragma unroll
                 for (int u = 0; u < 16; ++u) v[u] = buf[bb + u][ss];
@@ -454,8 +460,9 @@ __global__ __launch_bounds__(256) void k_sd_avg(const double *__restrict__ sdT, 
     }
     cnts[bq][ss] = cnt;
     __syncthreads();
-    if (threadIdx.x < 64 && live) {
-        const long long c = (long long)cnts[0][ss] + cnts[1][ss] + cnts[2][ss] + cnts[3][ss];
+    if (threadIdx.x < SPB && live) {
+        long long c = 0;
+        for (int q = 0; q < PH; ++q) c += cnts[q][ss];
         out[i] = s / (double)c;
     }
 }
@@ -1441,8 +1448,12 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
     if ((rc = ctx->ensure_side_stream())) return rc;
     WC_HIP(hipEventRecord(ctx->ev_fork, stream));
     WC_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
-    hipLaunchKernelGGL(k_sd_avg, dim3((unsigned)cdiv(Ns, 64)), dim3(256), 0, ctx->side,
-                       (const double *)ts.sdt.as<double>(), ref->B, Ns, ts.sd_avg.as<double>());
+    if (Ns <= 16)
+        hipLaunchKernelGGL(k_sd_avg<16>, dim3((unsigned)cdiv(Ns, 16)), dim3(256), 0, ctx->side,
+                           (const double *)ts.sdt.as<double>(), ref->B, Ns, ts.sd_avg.as<double>());
+    else
+        hipLaunchKernelGGL(k_sd_avg<64>, dim3((unsigned)cdiv(Ns, 64)), dim3(256), 0, ctx->side,
+                           (const double *)ts.sdt.as<double>(), ref->B, Ns, ts.sd_avg.as<double>());
     WC_HIP(hipEventRecord(ctx->ev_join, ctx->side));
     ctx->side_pending = true;
     WC_HIP(hipGetLastError());
