@@ -196,8 +196,16 @@ __global__ void k_pca_apply(const double *__restrict__ raw, int64_t B, const dou
 }
 
 // [R, C] -> [C, R]
-__global__ void k_transpose(const double *__restrict__ in, int64_t R, int64_t C, double *__restrict__ out) {
+// out = in^T (and out2, when given: the repeats' working copy); `zero`/`n_zero`: an int array the
+// same launch clears (the repeats' flags and counts), so that no separate memset is needed
+__global__ void k_transpose(const double *__restrict__ in, int64_t R, int64_t C, double *__restrict__ out,
+                            double *__restrict__ out2, int *__restrict__ zero, int64_t n_zero) {
     __shared__ double tile[32][33];
+    if (zero) {
+        const int64_t nthreads = (int64_t)gridDim.x * gridDim.y * 256;
+        const int64_t me = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.y * 32 + threadIdx.x;
+        for (int64_t t = me; t < n_zero; t += nthreads) zero[t] = 0;
+    }
     int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
     for (int j = threadIdx.y; j < 32; j += 8) {
         int64_t r = r0 + j, c = c0 + threadIdx.x;
@@ -206,7 +214,10 @@ __global__ void k_transpose(const double *__restrict__ in, int64_t R, int64_t C,
     __syncthreads();
     for (int j = threadIdx.y; j < 32; j += 8) {
         int64_t c = c0 + j, r = r0 + threadIdx.x;
-        if (r < R && c < C) out[c * R + r] = tile[threadIdx.x][j];
+        if (r < R && c < C) {
+            out[c * R + r] = tile[threadIdx.x][j];
+            if (out2) out2[c * R + r] = tile[threadIdx.x][j];
+        }
     }
 }
 
@@ -532,10 +543,15 @@ __global__ void k_fill_rs(double *rs, int64_t n) {
 __global__ __launch_bounds__(256) void k_region_prefix(const double *__restrict__ z,
                                                        const Region *__restrict__ regions, int64_t n_regions,
                                                        double *__restrict__ prefix, double *__restrict__ reg_abs,
-                                                       int *__restrict__ reg_flag) {
+                                                       int *__restrict__ reg_flag, int *__restrict__ counters,
+                                                       int *__restrict__ out_n, int *__restrict__ misc) {
     const int lane = threadIdx.x & 63;
     int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // first kernel of a segmentation call: its counters start at zero (no separate memsets)
+    if (blockIdx.x == 0 && threadIdx.x < 8) counters[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x >= 8 && threadIdx.x < 12 && misc) misc[threadIdx.x - 8] = 0;
     if (r >= n_regions) return;
+    if (lane == 0) out_n[r] = 0;
     const Region rg = regions[r];
     const double *zz = z + rg.off;
     double *P = prefix + rg.off + r;
@@ -1397,9 +1413,10 @@ int run_prepare(wc_ctx *ctx, const wc_reference *ref, const int *counts_dev, int
     return WC_OK;
 }
 
-void launch_transpose(const double *in, int64_t R, int64_t C, double *out, hipStream_t stream) {
+void launch_transpose(const double *in, int64_t R, int64_t C, double *out, hipStream_t stream,
+                      double *out2 = nullptr, int *zero = nullptr, int64_t n_zero = 0) {
     dim3 g((unsigned)cdiv(C, 32), (unsigned)cdiv(R, 32));
-    hipLaunchKernelGGL(k_transpose, g, dim3(32, 8), 0, stream, in, R, C, out);
+    hipLaunchKernelGGL(k_transpose, g, dim3(32, 8), 0, stream, in, R, C, out, out2, zero, n_zero);
 }
 
 // repeatTest on device data [Ns, B]; leaves zt/rt/nt/sdt as [B, Ns] and sd_avg[Ns]
@@ -1411,8 +1428,14 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
     for (wc::DevBuf *b : {&ts.xt, &ts.xc, &ts.zt, &ts.rt, &ts.nt, &ts.sdt})
         if ((rc = b->reserve(sizeof(double) * n))) return rc;
     if ((rc = ts.sd_avg.reserve(sizeof(double) * Ns))) return rc;
-    launch_transpose(data_dev, Ns, ref->B, ts.xt.as<double>(), stream);
-    WC_HIP(hipMemcpyAsync(ts.xc.p, ts.xt.p, sizeof(double) * n, hipMemcpyDeviceToDevice, stream));
+    // xt = data^T, xc = its working copy (flags go in there), and the repeats' flag / count
+    // arrays cleared -- one launch
+    if ((rc = ts.misc2.reserve(sizeof(int) * ((repeats + 2) * Ns + repeats + 2)))) return rc;
+    int *act = ts.misc2.as<int>();
+    int *act_counts = act + (int64_t)(repeats + 1) * Ns;   // [repeats + 2] newly flagged samples per repeat
+    int *act_list = act_counts + repeats + 2;              // [Ns] their indexes (rewritten every repeat)
+    launch_transpose(data_dev, Ns, ref->B, ts.xt.as<double>(), stream, ts.xc.as<double>(), act,
+                     repeats > 0 ? (repeats + 1) * Ns + repeats + 2 : 0);
     const unsigned g = (unsigned)cdiv(n, 256);
     if (repeats < 1) {  // the reference would return None; give NaNs
         WC_HIP(hipMemsetAsync(ts.zt.p, 0xFF, sizeof(double) * n, stream));
@@ -1420,13 +1443,7 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
         WC_HIP(hipMemsetAsync(ts.nt.p, 0, sizeof(double) * n, stream));
         WC_HIP(hipMemsetAsync(ts.sdt.p, 0xFF, sizeof(double) * n, stream));
     }
-    // active[it][sample]: did repeat it-1 add a flag for this sample?  (one clear for all repeats)
-    if ((rc = ts.misc2.reserve(sizeof(int) * ((repeats + 2) * Ns + repeats + 2)))) return rc;
-    int *act = ts.misc2.as<int>();
-    int *act_counts = act + (int64_t)(repeats + 1) * Ns;   // [repeats + 2] newly flagged samples per repeat
-    int *act_list = act_counts + repeats + 2;              // [Ns] their indexes (rewritten every repeat)
-    if (repeats > 0)     // flags and counts of all repeats cleared at once
-        WC_HIP(hipMemsetAsync(act, 0, sizeof(int) * ((repeats + 1) * Ns + repeats + 2), stream));
+    // active[it][sample]: did repeat it-1 add a flag for this sample?  (cleared with the transpose)
     for (int it = 0; it < repeats; ++it) {
         const int *cur = it == 0 ? nullptr : act + (int64_t)it * Ns;
         int *next = act + (int64_t)(it + 1) * Ns;
@@ -1524,10 +1541,10 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     int *counters = ts.job_cnt.as<int>();  // [1] next jobs [2] hot [3] brute [4] segments
     int *hot = ts.hot.as<int>();
     int *brute = hot + job_cap;
-    WC_HIP(hipMemsetAsync(counters, 0, sizeof(int) * 8, stream));
-    WC_HIP(hipMemsetAsync(ts.out_n.p, 0, sizeof(int) * n_regions, stream));
+    if ((rc = ts.misc.reserve(sizeof(int) * 4))) return rc;
     hipLaunchKernelGGL(k_region_prefix, dim3((unsigned)cdiv(n_regions, 4)), dim3(256), 0, stream, z_dev, regions_dev,
-                       n_regions, ts.prefix.as<double>(), ts.reg_abs.as<double>(), ts.reg_flag.as<int>());
+                       n_regions, ts.prefix.as<double>(), ts.reg_abs.as<double>(), ts.reg_flag.as<int>(), counters,
+                       ts.out_n.as<int>(), ts.misc.as<int>());
     // The quiet-job certificate (k_seg_quiet) runs before every search round: measured -7 % per
     // 250 kb batch and -17 % per 50 kb batch on data where 10-40 % of the regions hold a call; jobs
     // it cannot decide fall through to the full search.
@@ -1890,8 +1907,10 @@ int wc_test_batch_dev(wc_ctx *ctx, void *stream_, const wc_reference *ref, const
                            (const double *)ts.rt.as<double>(), (const double *)ts.nt.as<double>(), Ns, ref->Btot,
                            (const int *)ref->g2m.as<int>(), (double)min_ref_bins, results_z, results_r);
     }
-    if (n_calls) WC_HIP(hipMemsetAsync(n_calls, 0, sizeof(int) * Ns, stream));
-    if (n_sel == 0) return WC_OK;
+    if (n_sel == 0) {      // nothing to segment: no calls (otherwise k_assemble_calls writes every n_calls)
+        if (n_calls) WC_HIP(hipMemsetAsync(n_calls, 0, sizeof(int) * Ns, stream));
+        return WC_OK;
+    }
     std::vector<int> sel(n_sel);
     int64_t max_n = 0;
     for (int s = 0; s < n_sel; ++s) {
@@ -1933,7 +1952,7 @@ int wc_test_batch_dev(wc_ctx *ctx, void *stream_, const wc_reference *ref, const
     if (results_cwz)
         WC_HIP(hipMemcpyAsync(results_cwz, ts.whole.p, sizeof(double) * n_regions, hipMemcpyDeviceToDevice, stream));
     if (calls && n_calls) {
-        WC_HIP(hipMemsetAsync(ts.misc.p, 0, sizeof(int) * 4, stream));
+        // ts.misc (overflow flag) was cleared by k_region_prefix
         if (ts.last_segs > 0)
             hipLaunchKernelGGL(k_call_post, dim3((unsigned)ts.last_segs), dim3(256), 0, stream,
                                (const Seg *)ts.seg.as<Seg>(), (int)ts.last_segs,
