@@ -12,8 +12,9 @@ segmentation) over --test-samples samples per GPU at the same bin size.
 Rank 0 prints ONE JSON line: `value` is the newref metric of BASELINE.json
 (ordered cross-chromosome bin-pair distances per second, whole job), the `test`
 object carries samples/s, `roofline` describes the dominant kernel (the
-symmetric fp32-MFMA distance kernel) and `cpu_baseline` the CPU oracle timed on
-this box (rank 0, N=1 only).  Inputs are synthetic (seeded), see
+symmetric distance-tile kernel: on the bf16 matrix cores with hi/lo operand pairs by
+default, with the float32-matrix-core variant timed beside it) and `cpu_baseline`
+the CPU oracle timed on this box (rank 0, N=1 only).  Inputs are synthetic (seeded), see
 wisecondor_amd/synth.py.
 """
 import argparse
