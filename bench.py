@@ -126,16 +126,19 @@ def main():
             torch.cuda.synchronize()
 
     # ------------------------------------------------------------ newref ----
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * args.steps)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * args.steps)]
     for _ in range(args.warmup):
         idx, dst = job.run()
     sync_all()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        idx, dst = job.run(collect_events=(ev[2 * s], ev[2 * s + 1]))
+        idx, dst = job.run(collect_events=(ev[3 * s], ev[3 * s + 1], ev[3 * s + 2]))
     sync_all()
     t_newref = time.perf_counter() - t0
-    kernel_ms = float(np.mean([ev[2 * s].elapsed_time(ev[2 * s + 1]) for s in range(args.steps)]))
+    kernel_ms = float(np.mean([ev[3 * s].elapsed_time(ev[3 * s + 1]) for s in range(args.steps)]))
+    finish_ms = None
+    if world == 1 or job.mode == "rows":      # tiles mode: the exchange sits between collect and finish
+        finish_ms = float(np.mean([ev[3 * s + 1].elapsed_time(ev[3 * s + 2]) for s in range(args.steps)]))
     stats = wt.newref_stats(local_rank)
     split = os.environ.get("WC_GRAM_MODE", "") != "f32"
     f32_kernel_ms = None
@@ -277,11 +280,15 @@ def main():
 
     if rank == 0:
         traffic = None
+        finish_traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if world == 1 and os.path.exists(tpath):
             t = json.load(open(tpath)).get(args.workload)
             if t:   # HBM-side bytes per launch from the committed PMC passes of this same workload
                 traffic = 1024.0 * (2.0 * t["fetch_kb_per_launch"] + t["write_kb_per_launch"])
+                tf = t.get("k_finish") or {}
+                if tf.get("fetch_kb_per_launch") is not None:
+                    finish_traffic = 1024.0 * (2.0 * tf["fetch_kb_per_launch"] + tf["write_kb_per_launch"])
         # algorithmic work of the dominant kernel: one multiply-add per sample per unordered pair
         flops = (pairs / 2.0) * 2.0 * S / world
         if split:
@@ -308,6 +315,23 @@ def main():
                     "frac": achieved / PEAK_FP32_MFMA, "traffic": traffic,
                     "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_traffic.json)",
                     "kernel_ms": kernel_ms, "algorithmic_flop_per_launch": flops}
+        # the re-score stage (B * k * S * 8 B read, B * k * 12 B written), bound by memory
+        roof_finish = None
+        if finish_ms:
+            rows_here = B / world
+            fbytes = rows_here * k * S * 8.0 + rows_here * k * 12.0
+            roof_finish = {"kernel": "k_finish (per row: k-th key, candidate compaction, float64 re-score in numpy "
+                                     "order, counting order; the two exact-fallback launches that follow are idle here)",
+                           "bound": "hbm", "achieved": fbytes / (finish_ms * 1e-3) / 1e9, "peak": 8000.0,
+                           "unit": "GB/s", "frac": fbytes / (finish_ms * 1e-3) / 8.0e12, "traffic": finish_traffic,
+                           "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_traffic.json): the "
+                                           "gathers are served by L2 / Infinity Cache, a fraction reaches HBM",
+                           "kernel_ms": finish_ms, "algorithmic_bytes_per_launch": fbytes}
+        # `roofline` is the kernel that takes longer per step
+        if roof_finish and finish_ms > kernel_ms:
+            dominant, other = roof_finish, roof
+        else:
+            dominant, other = roof, roof_finish
         out = {
             "metric": "newref bin-pair distances/sec",
             "value": value,
@@ -339,7 +363,8 @@ def main():
                                   "frac": samples_per_s / world * test_bytes / 8.0e12,
                                   "windows_per_s": samples_per_s * windows},
                      "calls_found": n_calls},
-            "roofline": roof,
+            "roofline": dominant,
+            "roofline_other": other,
             "newref_stats": stats,
             "extra": extra,
             "cpu_baseline": cpu,

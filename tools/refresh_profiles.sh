@@ -27,16 +27,26 @@ python3 - "$OUT" "$TAG" <<'PY'
 import csv, json, sys
 out, tag = sys.argv[1], sys.argv[2]
 res = {}
+note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/profile_gpu.sh, PMC=1), KB per launch; "
+        "bench.py doubles FETCH_SIZE as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads on gfx950")
 for wl in ("cfg2", "cfg4"):
-    vals = {}
+    vals = {"k_gram": {}, "k_finish": {}}
     for c in ("fetch_size", "write_size"):
+        best = {}
         for row in csv.reader(open("%s/%s_%s_pmc_%s.csv" % (out, tag, wl, c))):
-            if row and "::k_gram" in row[0] and "thr16" not in row[0]:
-                vals[c] = float(row[2])
-    res[wl] = {"fetch_kb_per_launch": vals.get("fetch_size"), "write_kb_per_launch": vals.get("write_size"),
-               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/profile_gpu.sh, PMC=1), "
-                       "KB per k_gram launch; bench.py doubles FETCH_SIZE as MI355X_MICROARCH.md prescribes for "
-                       "16 B/lane streaming reads on gfx950"}
+            if not row or row[0] == "Kernel":
+                continue
+            for kern, pat in (("k_gram", "::k_gram<"), ("k_finish", "::k_finish<")):
+                # several instantiations may appear (the float32 variant is timed too): keep the most launched
+                if pat in row[0] and int(row[1]) > best.get(kern, (0, 0.0))[0]:
+                    best[kern] = (int(row[1]), float(row[2]))
+        for kern, (_, v) in best.items():
+            vals[kern][c] = v
+    res[wl] = {"fetch_kb_per_launch": vals["k_gram"].get("fetch_size"),
+               "write_kb_per_launch": vals["k_gram"].get("write_size"),
+               "k_finish": {"fetch_kb_per_launch": vals["k_finish"].get("fetch_size"),
+                            "write_kb_per_launch": vals["k_finish"].get("write_size")},
+               "note": note}
 json.dump(res, open("%s/%s_traffic.json" % (out, tag), "w"), indent=1)
 print(json.dumps(res))
 PY

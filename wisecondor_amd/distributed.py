@@ -214,6 +214,7 @@ class NewrefJob(object):
         return idx, dst
 
     def run(self, collect_events=None):
+        """collect_events: (before collect, after collect[, after finish]) torch events on the launch stream."""
         st = self.st
         st.prepare()
         if self.world == 1:
@@ -224,6 +225,8 @@ class NewrefJob(object):
             if collect_events:
                 collect_events[1].record()
             st.finish(0, self.n_bins, self.idx, self.dst)
+            if collect_events and len(collect_events) > 2:
+                collect_events[2].record()
             return self.idx, self.dst
 
         rb, re = self.ranges[self.rank]
@@ -238,6 +241,8 @@ class NewrefJob(object):
             if collect_events:
                 collect_events[1].record()
             st.finish(rb, re, self.idx_all[self.rank], self.dst_all[self.rank])
+            if collect_events and len(collect_events) > 2:
+                collect_events[2].record()
             return self._gather_results()
 
         if not self.buffers_ready:
