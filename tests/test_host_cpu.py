@@ -152,7 +152,10 @@ def test_shard_mode_choice():
     bins250 = synth.chrom_bins(250000)
     bins50 = synth.chrom_bins(50000)
     assert d.choose_shard_mode(int(sum(bins250)), 100, bins250, 8, 1024) == "rows"
-    assert d.choose_shard_mode(int(sum(bins50)), 600, bins50, 8, 1024) == "tiles"
+    assert d.choose_shard_mode(int(sum(bins250)), 100, bins250, 2, 1024) == "rows"
+    # 600 x 50 kb: the exchange only pays while a rank's share of the tile work is long (2 ranks)
     assert d.choose_shard_mode(int(sum(bins50)), 600, bins50, 2, 1024) == "tiles"
+    assert d.choose_shard_mode(int(sum(bins50)), 600, bins50, 8, 1024) == "rows"
+    assert d.choose_shard_mode(int(sum(bins50)), 4800, bins50, 8, 1024) == "tiles"
     assert d.choose_shard_mode(int(sum(bins50)), 600, bins50, 1, 1024) == "tiles"
     assert d.exchange_capacity(1024, 8) % 32 == 0 and d.exchange_capacity(1024, 1) == 1024

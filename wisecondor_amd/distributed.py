@@ -80,10 +80,12 @@ class HipStages(object):
 
 
 # Cost model of the shard-mode choice (seconds; one MI355X per rank, xGMI between them).
-# Measured on one GPU: the symmetric distance kernel (bf16 hi/lo tiles) delivers ~110 TFLOP/s of
-# algorithmic work at 100 samples and ~275 at 600.  The exchange figures are planning numbers for
-# RCCL on a fully connected 8-GPU node (not measured here: the test box has one GPU).
-_MFMA_RATE = 2.0e14                  # sustained algorithmic flop/s of the distance kernel
+# Distance kernel, measured on one GPU (bf16 hi/lo tiles): 768 tiles in flight, a tile takes
+# 15 us + 1.75 us per 32-sample slab (cfg2: 3 663 tiles x 22 us / 768 = 0.105 ms, measured 0.100;
+# cfg4: 96 648 x 48 us / 768 = 6.07 ms, measured 6.1).  The exchange figures are planning
+# numbers for RCCL on a fully connected 8-GPU node (not measured here: the test box has one GPU).
+_TILES_IN_FLIGHT = 768.0
+_TILE_FIXED, _TILE_PER_SLAB = 15e-6, 1.75e-6
 _COLL_LATENCY = 30e-6                # fixed cost of one small RCCL collective
 _XGMI_RATE = 100e9                   # bytes/s a rank moves in an all-to-all (several links busy)
 
@@ -103,7 +105,9 @@ def choose_shard_mode(n_bins, n_samples, chrom_bins, world, cap):
         return env
     b = np.asarray(chrom_bins, dtype=np.float64)
     unordered = (float(n_bins) ** 2 - float((b * b).sum())) / 2.0
-    t_sym = unordered * 2.0 * n_samples / _MFMA_RATE / world
+    tiles = unordered / (128.0 * 128.0)
+    slabs = np.ceil(n_samples / 32.0)
+    t_sym = tiles * (_TILE_FIXED + _TILE_PER_SLAB * slabs) / _TILES_IN_FLIGHT / world
     rows = n_bins / float(world)
     t_exchange = 2 * _COLL_LATENCY + world * rows * exchange_capacity(cap, world) * 8.0 / _XGMI_RATE
     return "rows" if t_sym < t_exchange else "tiles"
