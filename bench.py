@@ -207,41 +207,45 @@ def main():
     # beside the headline so that the MFMA kernel is also seen where it is not launch bound.
     extra = None
     if not args.no_extra and args.workload != "cfg4":
-        from wisecondor_amd import synth
-        xb, xs = WORKLOADS["cfg4"]
-        xdata, xbins, _ = synth.corrected_matrix(xb, xs, seed=0)
-        XB = int(xdata.shape[0])
-        xpairs = float(XB) * XB - float((xbins.astype(np.float64) ** 2).sum())
-        XX = torch.from_numpy(xdata).to(dev)
-        del xdata
-        xjob = distributed.NewrefJob(ctx, XX, xbins, k, _lib.SUM_SEQUENTIAL, rank=rank, world=world)
-        xsteps = 3
-        xev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * xsteps)]
-        xjob.run()
-        sync_all()
-        t0 = time.perf_counter()
-        for q in range(xsteps):
-            xjob.run(collect_events=(xev[2 * q], xev[2 * q + 1]))
-        sync_all()
-        xt = time.perf_counter() - t0
-        tmax = torch.tensor([xt], device=tdev, dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        xt = float(tmax.item())
-        xk_ms = float(np.mean([xev[2 * q].elapsed_time(xev[2 * q + 1]) for q in range(xsteps)]))
-        xflops = (xpairs / 2.0) * 2.0 * xs / world
-        extra = {"workload": "cfg4: newref %d samples x %d kb bins (%d bins), kernel-level synthetic matrix"
-                             % (xs, xb // 1000, XB),
-                 "value": xpairs * xsteps / xt, "unit": "bin-pair distances/s", "ms_per_step": 1e3 * xt / xsteps,
-                 "steps": xsteps, "shard_mode": xjob.mode or "tiles", "k_gram_ms": xk_ms,
-                 "k_gram_algorithmic_tflops": xflops / (xk_ms * 1e-3) / 1e12}
-        if os.environ.get("WC_GRAM_MODE", "") != "f32":
-            extra["k_gram_executed_tflops"] = SPLIT_PRODUCTS * xflops / (xk_ms * 1e-3) / 1e12
-            extra["k_gram_frac_of_bf16_mfma_peak"] = SPLIT_PRODUCTS * xflops / (xk_ms * 1e-3) / PEAK_BF16_MFMA
-        else:
-            extra["k_gram_frac_of_fp32_mfma_peak"] = xflops / (xk_ms * 1e-3) / PEAK_FP32_MFMA
-        del xjob, XX
-        # the main job's context state was replaced by the extra run; nothing below needs it
+        try:
+            from wisecondor_amd import synth
+            xb, xs = WORKLOADS["cfg4"]
+            xdata, xbins, _ = synth.corrected_matrix(xb, xs, seed=0)
+            XB = int(xdata.shape[0])
+            xpairs = float(XB) * XB - float((xbins.astype(np.float64) ** 2).sum())
+            XX = torch.from_numpy(xdata).to(dev)
+            del xdata
+            xjob = distributed.NewrefJob(ctx, XX, xbins, k, _lib.SUM_SEQUENTIAL, rank=rank, world=world)
+            xsteps = 3
+            xev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * xsteps)]
+            xjob.run()
+            sync_all()
+            t0 = time.perf_counter()
+            for q in range(xsteps):
+                xjob.run(collect_events=(xev[2 * q], xev[2 * q + 1]))
+            sync_all()
+            xt = time.perf_counter() - t0
+            tmax = torch.tensor([xt], device=tdev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            xt = float(tmax.item())
+            xk_ms = float(np.mean([xev[2 * q].elapsed_time(xev[2 * q + 1]) for q in range(xsteps)]))
+            # tiles mode: every unordered pair once on the node; rows mode: every ordered pair
+            xflops = (xpairs if xjob.mode == "rows" else xpairs / 2.0) * 2.0 * xs / world
+            extra = {"workload": "cfg4: newref %d samples x %d kb bins (%d bins), kernel-level synthetic matrix"
+                                 % (xs, xb // 1000, XB),
+                     "value": xpairs * xsteps / xt, "unit": "bin-pair distances/s", "ms_per_step": 1e3 * xt / xsteps,
+                     "steps": xsteps, "shard_mode": xjob.mode or "tiles", "k_gram_ms": xk_ms,
+                     "k_gram_algorithmic_tflops": xflops / (xk_ms * 1e-3) / 1e12}
+            if os.environ.get("WC_GRAM_MODE", "") != "f32":
+                extra["k_gram_executed_tflops"] = SPLIT_PRODUCTS * xflops / (xk_ms * 1e-3) / 1e12
+                extra["k_gram_frac_of_bf16_mfma_peak"] = SPLIT_PRODUCTS * xflops / (xk_ms * 1e-3) / PEAK_BF16_MFMA
+            else:
+                extra["k_gram_frac_of_fp32_mfma_peak"] = xflops / (xk_ms * 1e-3) / PEAK_FP32_MFMA
+            del xjob, XX
+            # the main job's context state was replaced by the extra run; nothing below needs it
+        except Exception as exc:      # the headline line must still be printed
+            extra = {"workload": "cfg4", "error": "%s: %s" % (type(exc).__name__, exc)}
 
     # ------------------------------------------------------- cpu baseline ----
     cpu = None
@@ -290,7 +294,7 @@ def main():
                 if tf.get("fetch_kb_per_launch") is not None:
                     finish_traffic = 1024.0 * (2.0 * tf["fetch_kb_per_launch"] + tf["write_kb_per_launch"])
         # algorithmic work of the dominant kernel: one multiply-add per sample per unordered pair
-        flops = (pairs / 2.0) * 2.0 * S / world
+        flops = (pairs if job.mode == "rows" else pairs / 2.0) * 2.0 * S / world   # rows mode: ordered pairs
         if split:
             # the tiles run on the bf16 matrix cores: three bf16 products stand for one float32
             # multiply, so the executed work is 3x the algorithmic work and the peak is the bf16 one
