@@ -198,25 +198,28 @@ struct PwWaveScratch {
     int off[WC_PW_LEAVES];
     int len[WC_PW_LEAVES];
     double sum[WC_PW_LEAVES];
+    // the tree walk's stack lives here too: a runtime-indexed private array would go to scratch
+    // memory (a global round trip per step); every lane reads and writes the same slots
+    int s_off[WC_PW_DEPTH], s_n[WC_PW_DEPTH], s_phase[WC_PW_DEPTH];
+    double s_left[WC_PW_DEPTH];
 };
 template <class F> __device__ inline double pairwise_sum_wave(F f, int64_t n, int lane, PwWaveScratch &sc) {
     const int sub = lane & 7, grp = lane >> 3;
     if (n <= WC_PW_BLOCK) return pw_leaf_group8(f, 0, (int)n, sub);
     if (n > (int64_t)WC_PW_LEAVES * 64) return pairwise_sum<true>(f, n, sub);
     // 1. leaves in tree (depth-first) order; every lane walks the same tree
-    int64_t s_off[WC_PW_DEPTH], s_n[WC_PW_DEPTH];
-    int s_phase[WC_PW_DEPTH];
+    int *s_off = sc.s_off, *s_n = sc.s_n, *s_phase = sc.s_phase;
     int sp = 1, n_leaves = 0;
-    s_off[0] = 0; s_n[0] = n; s_phase[0] = 0;
+    s_off[0] = 0; s_n[0] = (int)n; s_phase[0] = 0;
     while (sp > 0) {
         const int t = sp - 1;
-        const int64_t nn = s_n[t], off = s_off[t];
+        const int nn = s_n[t], off = s_off[t];
         if (nn <= WC_PW_BLOCK) {
-            if (lane == 0) { sc.off[n_leaves] = (int)off; sc.len[n_leaves] = (int)nn; }
+            if (lane == 0) { sc.off[n_leaves] = off; sc.len[n_leaves] = nn; }
             ++n_leaves;
             --sp;
         } else {
-            int64_t n2 = nn / 2;
+            int n2 = nn / 2;
             n2 -= n2 % 8;
             if (s_phase[t] == 0) {
                 s_phase[t] = 1;
@@ -241,19 +244,19 @@ template <class F> __device__ inline double pairwise_sum_wave(F f, int64_t n, in
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // 3. fold: the walk again, leaf values from the table
-    double s_left[WC_PW_DEPTH];
+    double *s_left = sc.s_left;
     double result = 0.0;
     int next_leaf = 0;
     sp = 1;
-    s_off[0] = 0; s_n[0] = n; s_phase[0] = 0;
+    s_off[0] = 0; s_n[0] = (int)n; s_phase[0] = 0;
     while (sp > 0) {
         const int t = sp - 1;
-        const int64_t nn = s_n[t], off = s_off[t];
+        const int nn = s_n[t], off = s_off[t];
         if (nn <= WC_PW_BLOCK) {
             result = sc.sum[next_leaf++];
             --sp;
         } else {
-            int64_t n2 = nn / 2;
+            int n2 = nn / 2;
             n2 -= n2 % 8;
             if (s_phase[t] == 0) {
                 s_phase[t] = 1;
