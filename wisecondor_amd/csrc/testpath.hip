@@ -800,13 +800,16 @@ __global__ __launch_bounds__(256) void k_seg_quiet(Job *__restrict__ jobs, int n
     __shared__ int s_work[Q_WORK];                // undecided (row, end block) pairs
     __shared__ double s_tmx[Q_BLOCKS], s_tmn[Q_BLOCKS];   // block maxima / minima the job touches
     __shared__ double s_pn[2][2 * ROWS_HALF];             // rows of a side and their near ends
-    const int j = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    // gridDim.x workgroups share a job: each takes the row blocks blockIdx.x, + gridDim.x, ...
+    // (many jobs: one workgroup per job, the block table is staged once; few jobs: all row
+    // blocks in parallel)
+    const int j = blockIdx.y, tid = threadIdx.x;
     if (j >= n_jobs) return;
     const Job job = jobs[j];
     const int L = job.hi - job.lo, half = (L + 1) / 2;
-    if (L <= 0 || chunk * ROWS_HALF >= half) return;
+    if (L <= 0 || (int)blockIdx.x * ROWS_HALF >= half) return;
     if (!reg_flag[job.region]) return;            // non-finite region: classify sends it to the brute path
-    if (job.pad) return;                          // a sibling block already found a window
+    if (job.pad) return;                          // a sibling workgroup already found a window
     const double eps = window_eps(regions[job.region].n, reg_abs[job.region]);
     const long long base = regions[job.region].off + job.region + job.lo;    // absolute index of the job's P[0]
     const long long a_hi = base + L;                                          // absolute index of the last end
@@ -818,81 +821,85 @@ __global__ __launch_bounds__(256) void k_seg_quiet(Job *__restrict__ jobs, int n
         if (tid == 0) jobs[j].pad = 1;
         return;
     }
-    if (tid == 0) { s_found = 0; s_nwork = 0; }
+    if (tid == 0) s_found = 0;
     for (int i = tid; i <= (int)(k_last - k_base); i += 256) {
         s_tmx[i] = tmax[k_base + i];
         s_tmn[i] = tmin[k_base + i];
     }
-    {   // the 64 rows of each side and the 64 prefix entries after them (clipped to the job)
-        const int side = tid >> 7, t = tid & 127;
-        const int xr_lo = side == 0 ? chunk * ROWS_HALF : L - 1 - (chunk * ROWS_HALF + 63);
-        const long long ai = base + (xr_lo < 0 ? 0 : xr_lo) + t;
-        s_pn[side][t] = ai <= a_hi ? prefix[ai] : 0.0;
-    }
-    __syncthreads();
-    bool found = false;
-    for (int side = 0; side < 2; ++side) {
-        int xr = chunk * ROWS_HALF + lane;
-        bool live;
-        if (side == 0) {
-            live = xr < half;
-        } else {
-            xr = L - 1 - xr;
-            live = xr >= half;
+    for (int chunk = blockIdx.x; chunk * ROWS_HALF < half; chunk += gridDim.x) {
+        __syncthreads();                          // previous chunk's queue and rows are done with
+        if (s_found) break;
+        if (tid == 0) s_nwork = 0;
+        {   // the 64 rows of each side and the 64 prefix entries after them (clipped to the job)
+            const int side = tid >> 7, t = tid & 127;
+            const int xr_lo = side == 0 ? chunk * ROWS_HALF : L - 1 - (chunk * ROWS_HALF + 63);
+            const long long ai = base + (xr_lo < 0 ? 0 : xr_lo) + t;
+            s_pn[side][t] = ai <= a_hi ? prefix[ai] : 0.0;
         }
-        const long long ax = base + (live ? xr : 0);
-        // rows of this side and their near ends sit in LDS: s_pn[side][t] = P[a0 + t], t < 128
-        const int xr_lo = side == 0 ? chunk * ROWS_HALF : L - 1 - (chunk * ROWS_HALF + 63);
-        const long long a0 = base + (xr_lo < 0 ? 0 : xr_lo);
-        const int xo = (int)(ax - a0);                              // 0..63 for live lanes
-        const double px = live ? s_pn[side][xo] : 0.0;
-        if (w == 0) { s_px[side * ROWS_HALF + lane] = px; s_ax[side * ROWS_HALF + lane] = ax; }
-        const long long k_far = ax / QB + 2;                        // first end block that starts past ax + 32
-        // near ends, one by one; the four waves take every fourth window length (uniform per
-        // wave: its 1/sqrt(len) is a scalar load)
-        long long y_near = k_far * QB - 1;
-        if (y_near > a_hi) y_near = a_hi;
-        const int near = live ? (int)(y_near - ax) : 0;            // <= 63
-#pragma unroll 4
-        for (int len = 1 + w; len <= 2 * QB; len += 4) {
-            const double r = rs[len];
-            if (len <= near) {
-                const double v = (s_pn[side][xo + len] - px) * r;
-                if (!(fabs(v) + eps < thr)) found = true;
+        __syncthreads();
+        bool found = false;
+        for (int side = 0; side < 2; ++side) {
+            int xr = chunk * ROWS_HALF + lane;
+            bool live;
+            if (side == 0) {
+                live = xr < half;
+            } else {
+                xr = L - 1 - xr;
+                live = xr >= half;
             }
-        }
-        // far ends, one bound per block; the four waves take every fourth block.  The factor is
-        // an upper bound of 1/sqrt(min len) from the float32 reciprocal square root (no table
-        // gather in the loop).  Undecided (row, block) pairs are queued: evaluating them here
-        // would keep a whole wave waiting for the few lanes that need it.
-        const int xr_min = side == 0 ? chunk * ROWS_HALF : L - 1 - (chunk * ROWS_HALF + 63);
-        const long long k0 = (base + (xr_min < 0 ? 0 : xr_min)) / QB + 2;
-        for (long long k = k0 + w; k <= k_last; k += 4) {
-            const double mx = s_tmx[k - k_base], mn = s_tmn[k - k_base];     // wave-uniform LDS reads
-            if (live && k >= k_far) {
-                const double m = (double)__frsqrt_rn((float)(k * QB - ax)) * 1.000001;
-                const double up = mx - px, dn = mn - px;
-                const double hi = up > 0.0 ? up * m : 0.0, lo = dn < 0.0 ? -dn * m : 0.0;
-                if (!(hi + eps < thr) || !(lo + eps < thr)) {
-                    const int at = atomicAdd(&s_nwork, 1);
-                    if (at < Q_WORK) s_work[at] = ((side * ROWS_HALF + lane) << 24) | (int)(k - k_base);
-                    else found = true;                              // queue full: give up the certificate
+            const long long ax = base + (live ? xr : 0);
+            // rows of this side and their near ends sit in LDS: s_pn[side][t] = P[a0 + t], t < 128
+            const int xr_lo = side == 0 ? chunk * ROWS_HALF : L - 1 - (chunk * ROWS_HALF + 63);
+            const long long a0 = base + (xr_lo < 0 ? 0 : xr_lo);
+            const int xo = (int)(ax - a0);                              // 0..63 for live lanes
+            const double px = live ? s_pn[side][xo] : 0.0;
+            if (w == 0) { s_px[side * ROWS_HALF + lane] = px; s_ax[side * ROWS_HALF + lane] = ax; }
+            const long long k_far = ax / QB + 2;                        // first end block that starts past ax + 32
+            // near ends, one by one; the four waves take every fourth window length (uniform per
+            // wave: its 1/sqrt(len) is a scalar load)
+            long long y_near = k_far * QB - 1;
+            if (y_near > a_hi) y_near = a_hi;
+            const int near = live ? (int)(y_near - ax) : 0;            // <= 63
+#pragma unroll 4
+            for (int len = 1 + w; len <= 2 * QB; len += 4) {
+                const double r = rs[len];
+                if (len <= near) {
+                    const double v = (s_pn[side][xo + len] - px) * r;
+                    if (!(fabs(v) + eps < thr)) found = true;
+                }
+            }
+            // far ends, one bound per block; the four waves take every fourth block.  The factor is
+            // an upper bound of 1/sqrt(min len) from the float32 reciprocal square root (no table
+            // gather in the loop).  Undecided (row, block) pairs are queued: evaluating them here
+            // would keep a whole wave waiting for the few lanes that need it.
+            const long long k0 = a0 / QB + 2;
+            for (long long k = k0 + w; k <= k_last; k += 4) {
+                const double mx = s_tmx[k - k_base], mn = s_tmn[k - k_base];     // wave-uniform LDS reads
+                if (live && k >= k_far) {
+                    const double m = (double)__frsqrt_rn((float)(k * QB - ax)) * 1.000001;
+                    const double up = mx - px, dn = mn - px;
+                    const double hi = up > 0.0 ? up * m : 0.0, lo = dn < 0.0 ? -dn * m : 0.0;
+                    if (!(hi + eps < thr) || !(lo + eps < thr)) {
+                        const int at = atomicAdd(&s_nwork, 1);
+                        if (at < Q_WORK) s_work[at] = ((side * ROWS_HALF + lane) << 24) | (int)(k - k_base);
+                        else found = true;                              // queue full: give up the certificate
+                    }
                 }
             }
         }
-    }
-    __syncthreads();
-    // queued pairs: 32 ends each, eight pairs per trip
-    const int nwork = s_nwork < Q_WORK ? s_nwork : Q_WORK;
-    for (int wk = tid >> 5; wk < nwork; wk += 8) {
-        const int row = s_work[wk] >> 24;
-        const long long ay = (k_base + (s_work[wk] & 0xFFFFFF)) * QB + (tid & 31);
-        if (ay <= a_hi) {
-            const double v = (prefix[ay] - s_px[row]) * rs[ay - s_ax[row]];
-            if (!(fabs(v) + eps < thr)) found = true;
+        __syncthreads();
+        // queued pairs: 32 ends each, eight pairs per trip
+        const int nwork = s_nwork < Q_WORK ? s_nwork : Q_WORK;
+        for (int wk = tid >> 5; wk < nwork; wk += 8) {
+            const int row = s_work[wk] >> 24;
+            const long long ay = (k_base + (s_work[wk] & 0xFFFFFF)) * QB + (tid & 31);
+            if (ay <= a_hi) {
+                const double v = (prefix[ay] - s_px[row]) * rs[ay - s_ax[row]];
+                if (!(fabs(v) + eps < thr)) found = true;
+            }
         }
+        if (found) s_found = 1;
     }
-    if (found) s_found = 1;
     __syncthreads();
     if (tid == 0 && s_found) jobs[j].pad = 1;
 }
@@ -1576,7 +1583,10 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
         // round counters are reset by the search kernel, candidate counts by classify
         dim3 sg((unsigned)max_chunks, (unsigned)n_jobs);
         if (certify) {
-            hipLaunchKernelGGL(k_seg_quiet, sg, dim3(256), 0, stream, cur, (int)n_jobs, regions_dev,
+            // about 4 096 workgroups in all: one per job when there are many jobs, every row block
+            // of a job in parallel when there are few
+            const unsigned per_job = (unsigned)std::min<int64_t>(max_chunks, std::max<int64_t>(1, 4096 / n_jobs));
+            hipLaunchKernelGGL(k_seg_quiet, dim3(per_job, (unsigned)n_jobs), dim3(256), 0, stream, cur, (int)n_jobs, regions_dev,
                                (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
                                (const double *)ts.reg_abs.as<double>(), (const int *)ts.reg_flag.as<int>(), thr,
                                (const double *)ts.tmin.as<double>(), (const double *)ts.tmax.as<double>());
