@@ -1583,9 +1583,9 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
         // round counters are reset by the search kernel, candidate counts by classify
         dim3 sg((unsigned)max_chunks, (unsigned)n_jobs);
         if (certify) {
-            // about 4 096 workgroups in all: one per job when there are many jobs, every row block
+            // about 16 384 workgroups in all: one per job when there are many jobs, every row block
             // of a job in parallel when there are few
-            const unsigned per_job = (unsigned)std::min<int64_t>(max_chunks, std::max<int64_t>(1, 4096 / n_jobs));
+            const unsigned per_job = (unsigned)std::min<int64_t>(max_chunks, std::max<int64_t>(1, 16384 / n_jobs));
             hipLaunchKernelGGL(k_seg_quiet, dim3(per_job, (unsigned)n_jobs), dim3(256), 0, stream, cur, (int)n_jobs, regions_dev,
                                (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
                                (const double *)ts.reg_abs.as<double>(), (const int *)ts.reg_flag.as<int>(), thr,
