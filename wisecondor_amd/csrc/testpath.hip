@@ -481,6 +481,7 @@ __global__ __launch_bounds__(256) void k_sd_avg(const double *__restrict__ sdT, 
 // --------------------------------------------------------------- cleaning ----
 // Keep bins with refSizes >= minrefbins (wisecondor.py:215-222); one wave per
 // (sample, selected chromosome) compacts z, r and the genomic position in order.
+// zT / rT / nT here: the sample-major [Ns, B] copies (see k_inflate)
 __global__ __launch_bounds__(64) void k_clean(const double *__restrict__ zT, const double *__restrict__ rT,
                                               const double *__restrict__ nT, int64_t B, int64_t Ns,
                                               const int64_t *__restrict__ moff, const int64_t *__restrict__ goff,
@@ -496,12 +497,12 @@ __global__ __launch_bounds__(64) void k_clean(const double *__restrict__ zT, con
     for (int64_t base = cs; base < ce; base += 64) {
         int64_t b = base + lane;
         bool keep = false;
-        if (b < ce) keep = nT[b * Ns + i] >= minref;
+        if (b < ce) keep = nT[i * B + b] >= minref;
         unsigned long long mask = __ballot(keep);
         if (keep) {
             int at = count + __popcll(mask & ((1ull << lane) - 1ull));
-            zc[i * B + cs + at] = zT[b * Ns + i];
-            rc[i * B + cs + at] = rT[b * Ns + i];
+            zc[i * B + cs + at] = zT[i * B + b];
+            rc[i * B + cs + at] = rT[i * B + b];
             gpos[i * B + cs + at] = (int)(m2g[b] - goff[c]);
         }
         count += __popcll(mask);
@@ -516,17 +517,19 @@ __global__ __launch_bounds__(64) void k_clean(const double *__restrict__ zT, con
 }
 
 // inflateArrayMulti + per-chromosome split (wisetools.py:281-295, wisecondor.py:260-268)
-__global__ void k_inflate(const double *__restrict__ zT, const double *__restrict__ rT, const double *__restrict__ nT,
-                          int64_t Ns, int64_t Btot, const int *__restrict__ g2m, double minref,
+// zs / rs / ns are sample-major [Ns, B] (transposed back once after the repeats: the bin-major
+// arrays would be read with a stride of Ns doubles here)
+__global__ void k_inflate(const double *__restrict__ zs, const double *__restrict__ rs, const double *__restrict__ ns,
+                          int64_t B, int64_t Btot, const int *__restrict__ g2m, double minref,
                           double *__restrict__ res_z, double *__restrict__ res_r) {
     int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t i = blockIdx.y;
     if (g >= Btot) return;
     int m = g2m[g];
     double z = 0.0, r = 0.0;
-    if (m >= 0 && nT[(int64_t)m * Ns + i] >= minref) {
-        z = zT[(int64_t)m * Ns + i];
-        r = rT[(int64_t)m * Ns + i] - 1.0;
+    if (m >= 0 && ns[i * B + m] >= minref) {
+        z = zs[i * B + m];
+        r = rs[i * B + m] - 1.0;
     }
     if (res_z) res_z[i * Btot + g] = z;
     if (res_r) res_r[i * Btot + g] = r;
@@ -1420,6 +1423,25 @@ int run_prepare(wc_ctx *ctx, const wc_reference *ref, const int *counts_dev, int
     return WC_OK;
 }
 
+// [R, C] -> [C, R] for three arrays in one launch (blockIdx.z picks the array)
+__global__ void k_transpose3(const double *__restrict__ in0, const double *__restrict__ in1,
+                             const double *__restrict__ in2, int64_t R, int64_t C, double *__restrict__ out0,
+                             double *__restrict__ out1, double *__restrict__ out2) {
+    __shared__ double tile[32][33];
+    const double *in = blockIdx.z == 0 ? in0 : blockIdx.z == 1 ? in1 : in2;
+    double *out = blockIdx.z == 0 ? out0 : blockIdx.z == 1 ? out1 : out2;
+    int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        int64_t r = r0 + j, c = c0 + threadIdx.x;
+        if (r < R && c < C) tile[j][threadIdx.x] = in[r * C + c];
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        int64_t c = c0 + j, r = r0 + threadIdx.x;
+        if (r < R && c < C) out[c * R + r] = tile[threadIdx.x][j];
+    }
+}
+
 void launch_transpose(const double *in, int64_t R, int64_t C, double *out, hipStream_t stream,
                       double *out2 = nullptr, int *zero = nullptr, int64_t n_zero = 0) {
     dim3 g((unsigned)cdiv(C, 32), (unsigned)cdiv(R, 32));
@@ -1911,10 +1933,19 @@ int wc_test_batch_dev(wc_ctx *ctx, void *stream_, const wc_reference *ref, const
                 (void)hipMemcpyAsync(dst, c->ts.sd_avg.p, sizeof(double) * n, hipMemcpyDeviceToDevice, s);
         }
     } joiner{ctx, stream, asdef, Ns};
+    // z, ratio and reference counts back to sample-major [Ns, B] for the per-sample consumers
+    for (wc::DevBuf *b : {&ts.zs, &ts.rs2, &ts.ns2})
+        if ((rc = b->reserve(sizeof(double) * Ns * B))) return rc;
+    {
+        dim3 g3((unsigned)cdiv(Ns, 32), (unsigned)cdiv(B, 32), 3);
+        hipLaunchKernelGGL(k_transpose3, g3, dim3(32, 8), 0, stream, (const double *)ts.zt.as<double>(),
+                           (const double *)ts.rt.as<double>(), (const double *)ts.nt.as<double>(), B, Ns,
+                           ts.zs.as<double>(), ts.rs2.as<double>(), ts.ns2.as<double>());
+    }
     if (results_z || results_r) {
         dim3 g((unsigned)cdiv(ref->Btot, 256), (unsigned)Ns);
-        hipLaunchKernelGGL(k_inflate, g, dim3(256), 0, stream, (const double *)ts.zt.as<double>(),
-                           (const double *)ts.rt.as<double>(), (const double *)ts.nt.as<double>(), Ns, ref->Btot,
+        hipLaunchKernelGGL(k_inflate, g, dim3(256), 0, stream, (const double *)ts.zs.as<double>(),
+                           (const double *)ts.rs2.as<double>(), (const double *)ts.ns2.as<double>(), B, ref->Btot,
                            (const int *)ref->g2m.as<int>(), (double)min_ref_bins, results_z, results_r);
     }
     if (n_sel == 0) {      // nothing to segment: no calls (otherwise k_assemble_calls writes every n_calls)
@@ -1945,8 +1976,8 @@ int wc_test_batch_dev(wc_ctx *ctx, void *stream_, const wc_reference *ref, const
         ts.sel_host = sel;
     }
     hipLaunchKernelGGL(k_clean, dim3((unsigned)n_sel, (unsigned)Ns), dim3(64), 0, stream,
-                       (const double *)ts.zt.as<double>(), (const double *)ts.rt.as<double>(),
-                       (const double *)ts.nt.as<double>(), B, Ns, (const int64_t *)ref->moff_dev.as<int64_t>(),
+                       (const double *)ts.zs.as<double>(), (const double *)ts.rs2.as<double>(),
+                       (const double *)ts.ns2.as<double>(), B, Ns, (const int64_t *)ref->moff_dev.as<int64_t>(),
                        (const int64_t *)ref->goff_dev.as<int64_t>(), (const int *)ref->m2g.as<int>(),
                        (const int *)ts.sel.as<int>(), n_sel, (double)min_ref_bins, ts.zc.as<double>(),
                        ts.rc.as<double>(), ts.gpos.as<int>(), ts.regions.as<Region>());
