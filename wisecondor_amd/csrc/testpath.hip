@@ -541,8 +541,8 @@ __global__ void k_fill_rs(double *rs, int64_t n) {
     if (i < n) rs[i] = i > 0 ? 1.0 / sqrt((double)i) : 0.0;
 }
 
-// Prefix sums, sum |z| and a finiteness flag per region; one wave per region, each
-// lane scans a contiguous chunk (any summation order satisfies window_eps' bound).
+// Prefix sums, sum |z| and a finiteness flag per region; one wave per region (any summation
+// order satisfies window_eps' bound).
 __global__ __launch_bounds__(256) void k_region_prefix(const double *__restrict__ z,
                                                        const Region *__restrict__ regions, int64_t n_regions,
                                                        double *__restrict__ prefix, double *__restrict__ reg_abs,
@@ -558,26 +558,22 @@ __global__ __launch_bounds__(256) void k_region_prefix(const double *__restrict_
     const Region rg = regions[r];
     const double *zz = z + rg.off;
     double *P = prefix + rg.off + r;
-    const int per = (rg.n + 63) / 64;
-    const int lo = lane * per, hi = (lo + per < rg.n) ? lo + per : rg.n;
-    double s = 0.0, a = 0.0;
+    // 64 consecutive bins per trip (coalesced), inclusive wave scan, running total carried along
+    double a = 0.0, run = 0.0;
     int finite = 1;
-    for (int t = lo; t < hi; ++t) {
-        double v = zz[t];
-        if (!isfinite(v)) finite = 0;
-        s += v;
-        a += fabs(v);
-    }
-    double incl = s;
-    for (int o = 1; o < 64; o <<= 1) {
-        double up = __shfl_up(incl, o);
-        if (lane >= o) incl += up;
-    }
-    double run = incl - s;   // sum of the chunks before this lane
     if (lane == 0) P[0] = 0.0;
-    for (int t = lo; t < hi; ++t) {
-        run += zz[t];
-        P[t + 1] = run;
+    for (int t0 = 0; t0 < rg.n; t0 += 64) {
+        const int t = t0 + lane;
+        const double v = t < rg.n ? zz[t] : 0.0;
+        if (!isfinite(v)) finite = 0;
+        a += fabs(v);
+        double incl = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const double up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        if (t < rg.n) P[t + 1] = run + incl;
+        run += __shfl(incl, 63);
     }
     for (int o = 32; o > 0; o >>= 1) {
         a += __shfl_xor(a, o);
