@@ -67,6 +67,8 @@ def test_batched_test_50kb_equals_single_samples(wt):
     tests = []
     for i in range(24):
         events = [("7", 400, 900, 1.04)] if i % 3 == 0 else []
+        if i == 1:
+            events = [("2", 1000, 2500, 1.03)]          # a call longer than 1024 bins: radix-select median
         tests.append(synth.make_sample(profile, seed=500 + i, events=events))
     a = wt.test_batch(reference, tests, thr)
     b = wt.test_batch(reference, tests, thr)
@@ -90,3 +92,14 @@ def test_batched_test_50kb_equals_single_samples(wt):
     for i in (0, 7, 23):                                     # a sample alone == the sample in the batch
         one = wt.test_batch(reference, [tests[i]], thr)[0]
         assert same(one, a[i]), i
+
+    # effect size of the long call (median by radix selection) against numpy on the inflated ratios
+    long_calls = [c for c in a[1]["results_calls"] if c[2] - c[1] > 1100]
+    assert long_calls, a[1]["results_calls"]
+    for chrom, start, end, _, effect in long_calls:
+        r = np.asarray(a[1]["results_r"][int(chrom) - 1][int(start):int(end)])
+        kept = np.sort(r[r != 0.0])                      # removed bins inflate to exactly 0
+        # [start, end) misses the segment's last kept bin (the reference's end quirk), so the
+        # median of the true set sits within one order statistic of this set's middle
+        n = kept.shape[0]
+        assert kept[n // 2 - 2] <= effect <= kept[n // 2 + 2], (chrom, start, end, effect, np.median(kept))
