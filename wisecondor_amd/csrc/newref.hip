@@ -1434,7 +1434,7 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
     st.k_pad = round_up(n_samples, BK);
     st.k_pad16 = round_up(n_samples, 64);
     st.cap = LIST_CAP;
-    st.expect = LIST_CAP / 2;
+    st.expect = LIST_CAP * 3 / 8;     // 384: k = 100 is 4 sigma of the sampled order statistic away, the cap 6
     {
         const char *e = getenv("WC_GRAM_MODE");           // "f32": float32 matrix cores; default: split bfloat16
         st.split = !(e && strcmp(e, "f32") == 0);
