@@ -27,7 +27,8 @@ namespace {
 constexpr int TB = 128;        // tile edge (rows and cols)
 constexpr int BK = 32;         // k-slab depth
 constexpr int LDA = 36;        // LDS row stride of a staged slab, floats (144 B keeps b128 reads conflict free)
-constexpr int LDD = 129;       // LDS row stride of the dot-product tile
+constexpr int LDD = 129;       // LDS row stride of the dot-product tile (threshold kernel: row-major)
+constexpr int LDT = 68;        // k_gram keeps its 64 x 128 dot tile column-major: stride of a column, floats
 constexpr int ROLE_ROWS = 1;   // targets are the tile's rows (P side)
 constexpr int ROLE_COLS = 2;   // targets are the tile's columns (Q side)
 constexpr int MAX_SAMPLE_COLS = 4096;
@@ -233,7 +234,7 @@ __device__ inline unsigned long long pack_entry(float key, int j) {
 // rests on.
 template <bool SPLIT, int DEPTH>   // DEPTH: k-slabs of operand loads in flight (register staged; 2 only with SPLIT)
 __global__ __launch_bounds__(256, DEPTH == 2 ? 3 : 4) void k_gram(GramArgs g) {
-    __shared__ __attribute__((aligned(16))) float sm[2 * TB * LDA + 4 * TB];   // 64 * LDD <= 2 * TB * LDA
+    __shared__ __attribute__((aligned(16))) float sm[2 * TB * LDA + 4 * TB];   // dot tile: 128 * LDT <= 2 * TB * LDA
     float *As = sm;
     float *Bs = sm + TB * LDA;
     float *D = sm;
@@ -456,10 +457,16 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 3 : 4) void k_gram(GramArgs g) {
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        int col = wc * 64 + n * 32 + li;
-                        D[row * LDD + col] = acc[m][n][r];
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        // accumulators 4 r4 .. 4 r4 + 3 are four consecutive rows of one column: the
+                        // tile is stored column-major so that they go out as one 16-byte write
+                        // (and the column scan below comes back as 16-byte reads)
+                        const int row = m * 32 + 8 * r4 + 4 * lh;
+                        const int col = wc * 64 + n * 32 + li;
+                        f32x4 v4;
+                        v4[0] = acc[m][n][4 * r4]; v4[1] = acc[m][n][4 * r4 + 1];
+                        v4[2] = acc[m][n][4 * r4 + 2]; v4[3] = acc[m][n][4 * r4 + 3];
+                        *(f32x4 *)&D[col * LDT + row] = v4;
                     }
         }
         __syncthreads();
@@ -469,7 +476,10 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 3 : 4) void k_gram(GramArgs g) {
         if (roles & ROLE_COLS) {  // target = column x, candidates = rows [h*64 + q*32, +32) of tile I
             const float nbc = nbQs[x], th = thQs[x];
 #pragma unroll
-            for (int rr = 0; rr < 32; ++rr) dv[rr] = D[(q * 32 + rr) * LDD + x];
+            for (int g4 = 0; g4 < 8; ++g4) {
+                const f32x4 d4 = *(const f32x4 *)&D[x * LDT + q * 32 + 4 * g4];
+                dv[4 * g4] = d4[0]; dv[4 * g4 + 1] = d4[1]; dv[4 * g4 + 2] = d4[2]; dv[4 * g4 + 3] = d4[3];
+            }
             const f32x4 *nbv = (const f32x4 *)&nbPs[h * 64 + q * 32];
 #pragma unroll
             for (int g4 = 0; g4 < 8; ++g4) {
@@ -486,7 +496,7 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 3 : 4) void k_gram(GramArgs g) {
             const int r = h * 64 + lr;
             const float nbr = nbPs[r], th = thPs[r];
 #pragma unroll
-            for (int cc = 0; cc < 32; ++cc) dv[cc] = D[lr * LDD + cq * 32 + cc];
+            for (int cc = 0; cc < 32; ++cc) dv[cc] = D[(cq * 32 + cc) * LDT + lr];
             const f32x4 *nbv = (const f32x4 *)&nbQs[cq * 32];
 #pragma unroll
             for (int g4 = 0; g4 < 8; ++g4) {
@@ -512,7 +522,7 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 3 : 4) void k_gram(GramArgs g) {
                 int rr = __ffs((int)mask_c) - 1;
                 mask_c &= mask_c - 1;
                 int l = q * 32 + rr, r = h * 64 + l;
-                float key = fmaf(-2.f, D[l * LDD + x], nbPs[r] + nbc);
+                float key = fmaf(-2.f, D[x * LDT + l], nbPs[r] + nbc);
                 if (base_c < g.cap) dst[base_c] = pack_entry(key, I * TB + r);
                 ++base_c;
             }
@@ -524,7 +534,7 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 3 : 4) void k_gram(GramArgs g) {
                 int cc = __ffs((int)mask_r) - 1;
                 mask_r &= mask_r - 1;
                 int c = cq * 32 + cc;
-                float key = fmaf(-2.f, D[lr * LDD + c], nbr + nbQs[c]);
+                float key = fmaf(-2.f, D[c * LDT + lr], nbr + nbQs[c]);
                 if (base_r < g.cap) dst[base_r] = pack_entry(key, J * TB + c);
                 ++base_r;
             }
