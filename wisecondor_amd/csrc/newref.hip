@@ -27,8 +27,7 @@ namespace {
 constexpr int TB = 128;        // tile edge (rows and cols)
 constexpr int BK = 32;         // k-slab depth
 constexpr int LDA = 36;        // LDS row stride of a staged slab, floats (144 B keeps b128 reads conflict free)
-constexpr int LDD = 129;       // LDS row stride of the dot-product tile (threshold kernel: row-major)
-constexpr int LDT = 68;        // k_gram keeps its 64 x 128 dot tile column-major: stride of a column, floats
+constexpr int LDT = 68;        // the 64 x 128 dot tile of the epilogues is column-major: stride of a column, floats
 constexpr int ROLE_ROWS = 1;   // targets are the tile's rows (P side)
 constexpr int ROLE_COLS = 2;   // targets are the tile's columns (Q side)
 constexpr int MAX_SAMPLE_COLS = 4096;
@@ -633,10 +632,13 @@ __global__ __launch_bounds__(256, 4) void k_gram_thr16(const unsigned short *__r
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        int col = wc * 64 + n * 32 + li;
-                        D[row * LDD + col] = acc[m][n][r];
+                    for (int r4 = 0; r4 < 4; ++r4) {    // column-major tile, 16-byte writes (see k_gram)
+                        const int row = m * 32 + 8 * r4 + 4 * lh;
+                        const int col = wc * 64 + n * 32 + li;
+                        f32x4 v4;
+                        v4[0] = acc[m][n][4 * r4]; v4[1] = acc[m][n][4 * r4 + 1];
+                        v4[2] = acc[m][n][4 * r4 + 2]; v4[3] = acc[m][n][4 * r4 + 3];
+                        *(f32x4 *)&D[col * LDT + row] = v4;
                     }
         }
         __syncthreads();
@@ -645,9 +647,11 @@ __global__ __launch_bounds__(256, 4) void k_gram_thr16(const unsigned short *__r
         const int base_row = I * TB + h * 64 + rq * 16;
         float d0[16], d1[16];
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-            d0[rr] = D[(rq * 16 + rr) * LDD + 2 * cp];
-            d1[rr] = D[(rq * 16 + rr) * LDD + 2 * cp + 1];
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 a4 = *(const f32x4 *)&D[(2 * cp) * LDT + rq * 16 + 4 * g4];
+            const f32x4 b4 = *(const f32x4 *)&D[(2 * cp + 1) * LDT + rq * 16 + 4 * g4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { d0[4 * g4 + e] = a4[e]; d1[4 * g4 + e] = b4[e]; }
         }
         const f32x4 *nbv = (const f32x4 *)&nbPs[h * 64 + rq * 16];
         const unsigned int ex0 = run_mask(rg0.x - base_row, rg0.y - base_row);
