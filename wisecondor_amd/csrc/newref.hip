@@ -966,9 +966,10 @@ __global__ __launch_bounds__(NT, 4) void k_finish(FinishArgs a) {
     }
 
     {
-        // Exact float64 distances (wisetools.py:302) with numpy's rounding order.  One
-        // lane per candidate; 16-sample chunks of the candidate rows are staged through
-        // LDS with coalesced 128-byte loads, the next chunk in flight during the sums.
+        // Exact float64 distances (wisetools.py:302) with numpy's rounding order.  16-sample
+        // chunks of the candidate rows arrive with coalesced 128-byte loads (the next chunk in
+        // flight during the sums), are subtracted and squared by the loading lanes and staged
+        // through LDS; one lane per candidate then adds them in numpy's order.
         //   sequential order: one running sum per lane;
         //   pairwise order:   numpy's eight strided accumulators per leaf (<= 128
         //                     samples, boundaries from the host-built leaf table),
@@ -1008,24 +1009,36 @@ __global__ __launch_bounds__(NT, 4) void k_finish(FinishArgs a) {
             int2 lf = seq ? make_int2(0, 0) : a.pw_prog[0];   // {leaf end, adds after the leaf}
             for (int64_t c0 = 0; c0 < a.S; c0 += ST_CH) {
                 __syncthreads();
+                {
+                    // the staging lanes subtract and square (every lane busy, the target's two
+                    // samples read once per chunk); the candidate lanes below only add
+                    f64x2 x2;
+                    if (c0 + ST_CH <= a.S && a.xs_in_lds) {
+                        x2 = *(const f64x2 *)&xi[c0 + 2 * l8];
+                    } else {
+                        const int64_t s0 = c0 + 2 * l8;
+                        x2.x = s0 < a.S ? xi[s0] : 0.0;
+                        x2.y = s0 + 1 < a.S ? xi[s0 + 1] : 0.0;
+                    }
 #pragma unroll
-                for (int p = 0; p < NP; ++p) *(f64x2 *)&stage[(r0 + RP * p) * ST_LD + 2 * l8] = pre[p];
+                    for (int p = 0; p < NP; ++p) {
+                        const double d0 = pre[p].x - x2.x, d1 = pre[p].y - x2.y;
+                        f64x2 sq2;
+                        sq2.x = d0 * d0;
+                        sq2.y = d1 * d1;
+                        *(f64x2 *)&stage[(r0 + RP * p) * ST_LD + 2 * l8] = sq2;
+                    }
+                }
                 __syncthreads();
                 if (c0 + ST_CH < a.S) fetch((unsigned int)(c0 + ST_CH));
                 if (SEQ && tid < CB && c0 + ST_CH <= a.S && a.xs_in_lds) {
                     // full chunk, left-to-right sum: 16-byte LDS reads, no per-element control flow
                     const double *sp_ = &stage[tid * ST_LD];
-                    const double *xp_ = &xi[c0];
 #pragma unroll
                     for (int e = 0; e < ST_CH; e += 2) {
                         const f64x2 v = *(const f64x2 *)(sp_ + e);
-                        const f64x2 x2 = *(const f64x2 *)(xp_ + e);
-                        double d0 = v.x - x2.x;
-                        double s0 = d0 * d0;
-                        acc = acc + s0;
-                        double d1 = v.y - x2.y;
-                        double s1 = d1 * d1;
-                        acc = acc + s1;
+                        acc = acc + v.x;
+                        acc = acc + v.y;
                     }
                 } else if (tid < CB) {
                     const bool full = c0 + ST_CH <= a.S && a.xs_in_lds;
@@ -1037,21 +1050,15 @@ __global__ __launch_bounds__(NT, 4) void k_finish(FinishArgs a) {
                         double sq[8];
                         if (full) {   // 16-byte LDS reads, no per-element guards
                             const double *sp_ = &stage[tid * ST_LD + 8 * g];
-                            const double *xp_ = &xi[base];
 #pragma unroll
                             for (int e = 0; e < 8; e += 2) {
                                 const f64x2 v = *(const f64x2 *)(sp_ + e);
-                                const f64x2 x2 = *(const f64x2 *)(xp_ + e);
-                                double d0 = v.x - x2.x, d1 = v.y - x2.y;
-                                sq[e] = d0 * d0;
-                                sq[e + 1] = d1 * d1;
+                                sq[e] = v.x;
+                                sq[e + 1] = v.y;
                             }
                         } else {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                double df = (e < cntg) ? stage[tid * ST_LD + 8 * g + e] - xi[base + e] : 0.0;
-                                sq[e] = df * df;
-                            }
+                            for (int e = 0; e < 8; ++e) sq[e] = (e < cntg) ? stage[tid * ST_LD + 8 * g + e] : 0.0;
                         }
                         if (seq || in_tail || cntg < 8) {
                             for (int e = 0; e < cntg; ++e) acc = acc + sq[e];
