@@ -2,12 +2,15 @@
 ragged chromosome layouts (including empty and 1-bin chromosomes), k above and below the
 candidate count, duplicated rows, outlier rows, both numpy summation orders; and the
 whole `test` path on references produced by the GPU newref."""
+import os
+
 import numpy as np
 import pytest
 
 from oracle import wc_oracle as wo
 
 pytestmark = pytest.mark.gpu
+SWEEP = int(os.environ.get("WC_SWEEP", "1"))      # WC_SWEEP=16: sixteen times the seeds (soak run)
 
 
 def same_bits(a, b):
@@ -34,7 +37,7 @@ def random_layout(rng, n_chrom, lo, hi):
     return bins.astype(np.int64)
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(16 * SWEEP))
 def test_newref_random(wt, seed):
     rng = np.random.RandomState(1000 + seed)
     n_chrom = int(rng.choice([2, 3, 5, 22, 22, 24]))
@@ -67,7 +70,7 @@ def test_newref_random(wt, seed):
         assert same_bits(dst, want_d), (seed, B, S, k, part, parts)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(6 * SWEEP))
 def test_whole_test_path_random(wt, seed):
     """Reference from the GPU newref on random data, samples with planted events, oracle toolTest."""
     rng = np.random.RandomState(77 + seed)
