@@ -70,6 +70,24 @@ def test_oracle_synthetic(wt, n_samples, binsize, k, order):
     assert st["fallback_rows"] <= data.shape[0] // 20, st
 
 
+@pytest.mark.parametrize("order", ["C", "F"])
+def test_more_samples_than_the_row_cache_holds(wt, order):
+    """Above 2048 samples the target row of the float64 re-score is read from global memory
+    instead of LDS, and numpy's pairwise tree is several levels deep."""
+    rng = np.random.RandomState(11)
+    bins = np.array([70, 1, 55, 64], dtype=np.int64)
+    B, S, k = int(bins.sum()), 2500, 40
+    data = 1.0 + 0.03 * rng.standard_normal((B, S))
+    data[5] = data[150]
+    if order == "F":
+        data = np.asfortranarray(data)
+    sums = np.cumsum(bins)
+    idx, dst = wt.getReference(data, bins, sums, k, 1, 1)
+    want_i, want_d = wo.get_reference(data, bins, sums, k, 1, 1, fast=True)
+    assert np.array_equal(idx, np.asarray(want_i).reshape(-1, k))
+    assert same_bits(dst, np.asarray(want_d, dtype=np.float64).reshape(-1, k))
+
+
 def test_oracle_hard_ties_and_outliers(wt):
     """Duplicated rows (exact ties across chromosomes), an outlier bin and a NaN bin."""
     from wisecondor_amd import synth
