@@ -119,6 +119,40 @@ def test_whole_test_path_random(wt, seed):
     reference.close()
 
 
+@pytest.mark.parametrize("n_samples,k,seed", [(3, 40, 0), (40, 40, 1), (40, 128, 2), (70, 24, 3)])
+def test_repeats_heavy_flagging(wt, n_samples, k, seed):
+    """A low threshold on noisy samples: every repeat adds flags, so later repeats recompute many
+    (bin, sample) pairs with dropped references (cooperative pair kernel; full 128-entry lists
+    at k = 128; negative and NaN values dropped from the first repeat on).  numpy's bits."""
+    rng = np.random.RandomState(500 + seed)
+    bins = np.array([120, 90, 1, 140, 75, 110], dtype=np.int64)
+    sums = np.cumsum(bins)
+    B = int(bins.sum())
+    idx = np.empty((B, k), dtype=np.int32)
+    b = 0
+    for c in range(len(bins)):
+        others = B - int(bins[c])
+        for _ in range(int(bins[c])):
+            idx[b] = rng.choice(others, size=k, replace=False)
+            b += 1
+    dst = np.sort(rng.rand(B, k), axis=1)
+    dst[rng.randint(0, B, size=10)] = 2.0          # bins without any reference below the cutoff
+    cutoff = 0.8
+    data = 1.0 + 0.05 * rng.standard_normal((n_samples, B))
+    hot = rng.rand(n_samples, B) < 0.08
+    data[hot] *= 1.5
+    data[rng.rand(n_samples, B) < 0.003] = -0.5
+    data[rng.rand(n_samples, B) < 0.002] = np.nan
+    z, r, n, sd = wt.repeatTest(data, idx, dst, bins, sums, cutoff, 1.5, 6)
+    for s_ in range(n_samples):
+        with np.errstate(all="ignore"):
+            wz, wr, wn, wsd = wo.repeat_test(data[s_], idx, dst, bins, sums, cutoff, 1.5, 6)
+        assert np.array_equal(n[s_], wn), (s_,)
+        assert same_bits(z[s_], wz), (s_,)
+        assert same_bits(r[s_], wr), (s_,)
+        assert same_bits([sd[s_]], [wsd]), (s_,)
+
+
 @pytest.mark.parametrize("order", ["C", "F"])
 def test_newref_rare_paths(wt, order):
     """Clusters of exact duplicates large enough to hit the rarely taken paths: more than 64

@@ -19,6 +19,7 @@ struct wc_reference {
     int64_t goff[WC_MAX_CHROM + 1] = {0};  // genomic-bin offsets per chromosome
     double cutoff = 0.0;
     wc::DevBuf gidx, nref, pca_mean, pca_comp, m2g, g2m, moff_dev, goff_dev;
+    wc::DevBuf users_off, users;   // reverse reference lists: bins that use bin g (CSR over g)
 };
 
 namespace {
@@ -119,6 +120,30 @@ __global__ void k_ref_lists(const int *__restrict__ idx, const double *__restric
     }
     nref[b] = n;
     for (int r = n; r < k; ++r) gidx[b * k + r] = -1;
+}
+
+// Reverse lists: for every bin g the bins whose reference list holds g (order irrelevant).  A
+// new flag on (g, sample) can only change the results of those bins (wisetools.py:424-427).
+__global__ void k_count_users(const int *__restrict__ gidx, const int *__restrict__ nref, int64_t B, int k,
+                              int *__restrict__ cnt) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * k) return;
+    const int64_t b = t / k;
+    const int r = (int)(t - b * k);
+    if (r >= nref[b]) return;
+    const int g = gidx[t];
+    if (g >= 0) atomicAdd(&cnt[g], 1);
+}
+
+__global__ void k_fill_users(const int *__restrict__ gidx, const int *__restrict__ nref, int64_t B, int k,
+                             const int *__restrict__ off, int *__restrict__ cursor, int *__restrict__ users) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * k) return;
+    const int64_t b = t / k;
+    const int r = (int)(t - b * k);
+    if (r >= nref[b]) return;
+    const int g = gidx[t];
+    if (g >= 0) users[off[g] + atomicAdd(&cursor[g], 1)] = (int)b;
 }
 
 // -------------------------------------------------------- sample preparation ----
@@ -259,69 +284,20 @@ struct StreamSum {
     }
 };
 
-// trySample (wisetools.py:407-435) for every (bin, sample) pair; sample is the
-// fastest index so a wave reads 64 consecutive samples of one reference bin.
-// `active` (per sample) is cleared when a repeat set no new flag for that sample:
-// the next pass would reproduce the same numbers bit for bit, so it is skipped.
-// UNI: a wave holds one bin and 64 consecutive samples, so the bin, its reference list and the
-// list length are wave-uniform (scalar loads of the indexes, scalar row base + lane offset for
-// the gathers); used for batches.  Otherwise thread = flat (bin, sample) index, which keeps
-// all lanes busy when there are only a few samples (latency mode).
-template <bool UNI>
-__device__ inline void zscore_body(const unsigned int block, const double *__restrict__ XT,
-                                   const double *__restrict__ XC, const int *__restrict__ gidx,
-                                   const int *__restrict__ nref, int k, int64_t B, int64_t Ns,
-                                   const int *__restrict__ active, double *__restrict__ zT, double *__restrict__ rT,
-                                   double *__restrict__ nT, double *__restrict__ sdT,
-                                   const int *__restrict__ act_list, const int *__restrict__ act_count) {
-    // Later repeats of a batch touch only the samples that got a new flag, usually a few: those
-    // go through the flat variant over (listed sample, bin) with all lanes busy, and the
-    // wave-uniform variant stands down (both are launched; the device-side count picks one).
-    int64_t gid, b, i;
-    if (UNI) {
-        if (act_count && (int64_t)*act_count * 4 < Ns) return;
-        const int64_t n_sg = (Ns + 63) / 64;
-        const int64_t wave = (int64_t)block * 4 + (threadIdx.x >> 6);
-        const int wb = __builtin_amdgcn_readfirstlane((int)(wave / n_sg));
-        if (wb >= B) return;
-        b = wb;
-        i = (wave - (int64_t)wb * n_sg) * 64 + (threadIdx.x & 63);
-        if (i >= Ns) return;
-        gid = b * Ns + i;
-    } else if (act_list) {
-        const int64_t n_act = *act_count;
-        if (n_act * 4 >= Ns) return;
-        const int64_t t = (int64_t)block * 256 + threadIdx.x;
-        const int64_t a = t / B;
-        if (a >= n_act) return;
-        i = act_list[a];
-        b = t - a * B;                      // consecutive lanes: consecutive bins of one sample
-        gid = b * Ns + i;
-    } else {
-        gid = (int64_t)block * 256 + threadIdx.x;
-        if (gid >= B * Ns) return;
-        b = gid / Ns;
-        i = gid - b * Ns;
-    }
-    if (active && !active[i]) return;
+// trySample (wisetools.py:407-435) for one (bin b, sample i) pair, gid = b * Ns + i (the arrays
+// are bin-major so that a wave reads 64 consecutive samples of one reference bin).
+// Two passes over the kept references in numpy's pairwise order (StreamSum).  While every
+// active lane of the wave has kept all of its values so far, element r goes to accumulator
+// r & 7: whole groups of eight are added straight into the eight strided accumulators (eight
+// independent loads in flight, no slot selection).  The first dropped value anywhere in the
+// wave ends that: the rest of the list takes the general push().
+__device__ inline void zscore_one(const int64_t b, const int64_t i, const int64_t gid,
+                                  const double *__restrict__ XT, const double *__restrict__ XC,
+                                  const int *__restrict__ gidx, const int *__restrict__ nref, int k, int64_t Ns,
+                                  double *__restrict__ zT, double *__restrict__ rT, double *__restrict__ nT,
+                                  double *__restrict__ sdT) {
     const int *lst = gidx + b * k;
     const int n = nref[b];
-    if (active) {
-        // Later repeats: flags only accumulate, so a bin whose number of kept references
-        // did not change has exactly the same reference set and the same results.
-        int kept = 0;
-        for (int r = 0; r < n; ++r) {
-            int g = lst[r];
-            double v = g >= 0 ? XC[(int64_t)g * Ns + i] : -1.0;
-            kept += (v >= 0.0);
-        }
-        if ((double)kept == nT[gid]) return;
-    }
-    // Two passes over the kept references in numpy's pairwise order (StreamSum).  While every
-    // lane of the wave has kept all of its values so far, element r goes to accumulator r & 7:
-    // whole groups of eight are added straight into the eight strided accumulators (eight
-    // independent loads in flight, no slot selection).  The first dropped value anywhere in
-    // the wave ends that: the rest of the list takes the general push().
     StreamSum acc;
     acc.init();
     int fast_end = 0;      // references [0, fast_end) were consumed in whole, fully kept groups
@@ -384,37 +360,190 @@ __device__ inline void zscore_body(const unsigned int block, const double *__res
     sdT[gid] = sd;
 }
 
-// One launch carries both mappings: the first n_uni workgroups run the wave-uniform variant, the
-// rest the flat one (either count may be zero).
+// First repeat: every (bin, sample) pair.  The first n_uni workgroups run the wave-uniform
+// mapping (a wave holds one bin and 64 consecutive samples, so the bin, its reference list and
+// the list length are wave-uniform: scalar loads of the indexes, scalar row base + lane offset
+// for the gathers; used for batches), the rest the flat mapping thread = (bin, sample) index,
+// which keeps all lanes busy when there are only a few samples (latency mode).  Either count
+// may be zero.
 __global__ __launch_bounds__(256) void k_zscore(unsigned int n_uni, const double *__restrict__ XT,
                                                 const double *__restrict__ XC, const int *__restrict__ gidx,
                                                 const int *__restrict__ nref, int k, int64_t B, int64_t Ns,
-                                                const int *__restrict__ active, double *__restrict__ zT,
-                                                double *__restrict__ rT, double *__restrict__ nT,
-                                                double *__restrict__ sdT, const int *__restrict__ act_list,
-                                                const int *__restrict__ act_count) {
-    if (blockIdx.x < n_uni)
-        zscore_body<true>(blockIdx.x, XT, XC, gidx, nref, k, B, Ns, active, zT, rT, nT, sdT, nullptr, act_count);
-    else
-        zscore_body<false>(blockIdx.x - n_uni, XT, XC, gidx, nref, k, B, Ns, active, zT, rT, nT, sdT, act_list,
-                           act_count);
+                                                double *__restrict__ zT, double *__restrict__ rT,
+                                                double *__restrict__ nT, double *__restrict__ sdT) {
+    if (blockIdx.x < n_uni) {
+        const int64_t n_sg = (Ns + 63) / 64;
+        const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        const int wb = __builtin_amdgcn_readfirstlane((int)(wave / n_sg));
+        if (wb >= B) return;
+        const int64_t i = (wave - (int64_t)wb * n_sg) * 64 + (threadIdx.x & 63);
+        if (i >= Ns) return;
+        zscore_one(wb, i, (int64_t)wb * Ns + i, XT, XC, gidx, nref, k, Ns, zT, rT, nT, sdT);
+    } else {
+        const int64_t gid = (int64_t)(blockIdx.x - n_uni) * 256 + threadIdx.x;
+        if (gid >= B * Ns) return;
+        const int64_t b = gid / Ns;
+        zscore_one(b, gid - b * Ns, gid, XT, XC, gidx, nref, k, Ns, zT, rT, nT, sdT);
+    }
 }
 
-// testCopy[abs(z) >= threshold] = -1 (wisetools.py:446)
-// `cur` says which samples were recomputed in this repeat; `next` receives 1 for the
-// samples that got a NEW flag (only those can change in the following repeat).
-__global__ void k_flag(const double *__restrict__ zT, double thr, int64_t n, int64_t Ns,
-                       const int *__restrict__ cur, int *__restrict__ next, double *__restrict__ XC,
-                       int *__restrict__ list, int *__restrict__ count) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int64_t smp = i % Ns;
-    if (cur && !cur[smp]) return;
-    if (fabs(zT[i]) >= thr && XC[i] != -1.0) {
-        XC[i] = -1.0;
-        // first new flag of this sample in this repeat: it joins the (unordered) list of samples
-        // the next repeat has to recompute
-        if (atomicExch(&next[smp], 1) == 0) list[atomicAdd(count, 1)] = (int)smp;
+// numpy's pairwise sum of a stream of kept values by an aligned group of eight lanes: lane s
+// owns numpy's accumulator r[s].  Kept values get consecutive stream indexes c; the value with
+// index c belongs to lane c & 7, which holds it as `pend` until its group of eight is known to
+// be complete (the next value for that lane arrives, or the stream ends with >= 8 (c/8 + 1)
+// values) -- the incomplete last group is numpy's tail, added sequentially after the
+// accumulators are combined.  Fewer than eight values degenerate to numpy's plain
+// left-to-right sum.  All eight lanes return the sum.
+struct GroupSum {
+    double r, pend;
+    int pend_idx, pos;      // stream index of `pend` (-1: none), values seen so far
+    __device__ inline void init() { r = 0.0; pend = 0.0; pend_idx = -1; pos = 0; }
+    // one trip: lane j of the group offers `x` (kept or not); `sub` = lane & 7, `gbase` = lane & ~7
+    __device__ inline void trip(double x, bool kept, int sub, int gbase) {
+        const unsigned int mask = (unsigned int)(__ballot(kept) >> gbase) & 0xFFu;
+        const int cnt = __popc(mask);
+        const int q = (sub - pos) & 7;          // this lane's value is the q-th kept one of the trip, if any
+        int src = 0, seen = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool on = (mask >> e) & 1u;
+            src = (on && seen == q) ? e : src;
+            seen += on;
+        }
+        const double val = __shfl(x, gbase + src);
+        if (q < cnt) {
+            if (pend_idx >= 0) r = r + pend;    // its group is complete: a later value for this lane exists
+            pend = val;
+            pend_idx = pos + q;
+        }
+        pos += cnt;
+    }
+    __device__ inline double finish(int sub, int gbase) {
+        const int body = pos & ~7;
+        if (pend_idx >= 0 && pend_idx < body) { r = r + pend; pend_idx = -1; }
+        double res = r + __shfl_xor(r, 1);
+        res = res + __shfl_xor(res, 2);
+        res = res + __shfl_xor(res, 4);
+        const int tail = pos & 7;
+        for (int e = 0; e < tail; ++e) res = res + __shfl(pend, gbase + e);
+        return res;
+    }
+};
+
+// Later repeats: flags only accumulate, so a (bin, sample) pair whose references got no new
+// flag in the previous repeat has exactly the same reference set and the same results bit for
+// bit.  k_flag queued the pairs that did (through the reverse reference lists, each pair once:
+// the `dirty` bit); only those are recomputed.  Eight lanes per pair: each loads every eighth
+// reference (all of a pair's loads in flight at once; the values stay in registers for the
+// second pass) and the group sums in numpy's order (GroupSum).
+__global__ __launch_bounds__(256) void k_zscore_pairs(const unsigned int *__restrict__ pairs,
+                                                      const int *__restrict__ count,
+                                                      unsigned int *__restrict__ dirty,
+                                                      const double *__restrict__ XT, const double *__restrict__ XC,
+                                                      const int *__restrict__ gidx, const int *__restrict__ nref,
+                                                      int k, int64_t Ns, double *__restrict__ zT,
+                                                      double *__restrict__ rT, double *__restrict__ nT,
+                                                      double *__restrict__ sdT) {
+    const int64_t n_pairs = *count;
+    const int lane = threadIdx.x & 63, sub = lane & 7, gbase = lane & ~7;
+    for (int64_t t = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3; t < n_pairs; t += (int64_t)gridDim.x * 32) {
+        const unsigned int gid = pairs[t];
+        if (sub == 0) atomicAnd(&dirty[gid >> 5], ~(1u << (gid & 31)));
+        const int64_t b = gid / Ns, i = gid - b * Ns;
+        const int *lst = gidx + b * k;
+        const int n = nref[b];
+        // references 8 t + sub, t = 0..15 (a reference list holds at most 128 entries,
+        // wc_reference_create); beyond the list: dropped
+        double v[16];
+        {
+            int g[16];
+#pragma unroll
+            for (int t8 = 0; t8 < 16; ++t8) {
+                const int r = 8 * t8 + sub;
+                g[t8] = r < n ? lst[r] : -1;
+            }
+#pragma unroll
+            for (int t8 = 0; t8 < 16; ++t8) v[t8] = g[t8] >= 0 ? XC[(int64_t)g[t8] * Ns + i] : -1.0;
+        }
+        GroupSum acc;
+        acc.init();
+#pragma unroll
+        for (int t8 = 0; t8 < 16; ++t8) {
+            if (8 * t8 >= n) break;
+            acc.trip(v[t8], v[t8] >= 0.0, sub, gbase);   // flagged (-1), negative and NaN values are dropped (wisetools.py:425)
+        }
+        const int m = acc.pos;
+        const double mean = acc.finish(sub, gbase) / (double)m;
+        acc.init();
+#pragma unroll
+        for (int t8 = 0; t8 < 16; ++t8) {
+            if (8 * t8 >= n) break;
+            const double dv = v[t8] - mean;
+            const double sq = dv * dv;
+            acc.trip(sq, v[t8] >= 0.0, sub, gbase);
+        }
+        const double var = acc.finish(sub, gbase) / (double)m;
+        if (sub == 0) {
+            const double sd = sqrt(var);
+            const double x = XT[gid];
+            zT[gid] = (x - mean) / sd;
+            rT[gid] = x / mean;
+            nT[gid] = (double)m;
+            sdT[gid] = sd;
+        }
+    }
+}
+
+// testCopy[abs(z) >= threshold] = -1 (wisetools.py:446).  A NEW flag on (bin g, sample i)
+// queues every bin that uses g as a reference, for the same sample, for the next repeat: the
+// wave expands its new flags one after the other, 64 users per trip.
+__device__ inline void flag_wave(const int64_t gid, const bool valid, const double *__restrict__ zT, double thr,
+                                 int64_t Ns, double *__restrict__ XC, const int *__restrict__ users_off,
+                                 const int *__restrict__ users, unsigned int *__restrict__ dirty,
+                                 unsigned int *__restrict__ next_pairs, int *__restrict__ next_count) {
+    const int lane = threadIdx.x & 63;
+    bool hit = false;
+    if (valid && fabs(zT[gid]) >= thr && XC[gid] != -1.0) {
+        XC[gid] = -1.0;
+        hit = next_pairs != nullptr;      // last repeat: nothing follows
+    }
+    unsigned long long todo = __ballot(hit);
+    while (todo) {
+        const int l = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int64_t fg = __shfl(gid, l);
+        const int64_t g = fg / Ns, i = fg - g * Ns;
+        const int u1 = users_off[g + 1];
+        for (int u = users_off[g] + lane; u < u1; u += 64) {
+            const unsigned int ug = (unsigned int)((int64_t)users[u] * Ns + i);
+            const unsigned int bit = 1u << (ug & 31);
+            if (!(atomicOr(&dirty[ug >> 5], bit) & bit)) next_pairs[atomicAdd(next_count, 1)] = ug;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_flag(const double *__restrict__ zT, double thr, int64_t n, int64_t Ns,
+                                              double *__restrict__ XC, const int *__restrict__ users_off,
+                                              const int *__restrict__ users, unsigned int *__restrict__ dirty,
+                                              unsigned int *__restrict__ next_pairs, int *__restrict__ next_count) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    flag_wave(gid, gid < n, zT, thr, Ns, XC, users_off, users, dirty, next_pairs, next_count);
+}
+
+// the same over the pairs this repeat recomputed (nothing else can have changed)
+__global__ __launch_bounds__(256) void k_flag_pairs(const unsigned int *__restrict__ pairs,
+                                                    const int *__restrict__ count, const double *__restrict__ zT,
+                                                    double thr, int64_t Ns, double *__restrict__ XC,
+                                                    const int *__restrict__ users_off, const int *__restrict__ users,
+                                                    unsigned int *__restrict__ dirty,
+                                                    unsigned int *__restrict__ next_pairs,
+                                                    int *__restrict__ next_count) {
+    const int64_t n = *count;
+    const int lane = threadIdx.x & 63;
+    for (int64_t t0 = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63); t0 < n; t0 += (int64_t)gridDim.x * 256) {
+        const int64_t t = t0 + lane;
+        flag_wave(t < n ? (int64_t)pairs[t] : 0, t < n, zT, thr, Ns, XC, users_off, users, dirty, next_pairs,
+                  next_count);
     }
 }
 
@@ -1453,14 +1582,18 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
     for (wc::DevBuf *b : {&ts.xt, &ts.xc, &ts.zt, &ts.rt, &ts.nt, &ts.sdt})
         if ((rc = b->reserve(sizeof(double) * n))) return rc;
     if ((rc = ts.sd_avg.reserve(sizeof(double) * Ns))) return rc;
-    // xt = data^T, xc = its working copy (flags go in there), and the repeats' flag / count
-    // arrays cleared -- one launch
-    if ((rc = ts.misc2.reserve(sizeof(int) * ((repeats + 2) * Ns + repeats + 2)))) return rc;
-    int *act = ts.misc2.as<int>();
-    int *act_counts = act + (int64_t)(repeats + 1) * Ns;   // [repeats + 2] newly flagged samples per repeat
-    int *act_list = act_counts + repeats + 2;              // [Ns] their indexes (rewritten every repeat)
-    launch_transpose(data_dev, Ns, ref->B, ts.xt.as<double>(), stream, ts.xc.as<double>(), act,
-                     repeats > 0 ? (repeats + 1) * Ns + repeats + 2 : 0);
+    WC_CHECK(n < (1ll << 32), WC_E_LIMIT, "repeatTest: more than 2^32 (bin, sample) pairs per call");
+    // xt = data^T, xc = its working copy (flags go in there); in the same launch the repeats'
+    // pair counts and the `dirty` bitmap (one bit per pair: queued for the next repeat) are cleared
+    const int64_t n_words = cdiv(n, 32);
+    if ((rc = ts.misc2.reserve(sizeof(int) * (repeats + 2 + n_words)))) return rc;
+    if (repeats > 1)
+        for (wc::DevBuf *b : {&ts.pairs_a, &ts.pairs_b})
+            if ((rc = b->reserve(sizeof(unsigned int) * n))) return rc;
+    int *pair_counts = ts.misc2.as<int>();                       // [repeats + 2]: pairs queued for repeat it
+    unsigned int *dirty = (unsigned int *)(pair_counts + repeats + 2);
+    launch_transpose(data_dev, Ns, ref->B, ts.xt.as<double>(), stream, ts.xc.as<double>(), pair_counts,
+                     repeats > 0 ? repeats + 2 + n_words : 0);
     const unsigned g = (unsigned)cdiv(n, 256);
     if (repeats < 1) {  // the reference would return None; give NaNs
         WC_HIP(hipMemsetAsync(ts.zt.p, 0xFF, sizeof(double) * n, stream));
@@ -1468,22 +1601,33 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
         WC_HIP(hipMemsetAsync(ts.nt.p, 0, sizeof(double) * n, stream));
         WC_HIP(hipMemsetAsync(ts.sdt.p, 0xFF, sizeof(double) * n, stream));
     }
-    // active[it][sample]: did repeat it-1 add a flag for this sample?  (cleared with the transpose)
+    const int *uoff = ref->users_off.as<int>(), *ulst = ref->users.as<int>();
     for (int it = 0; it < repeats; ++it) {
-        const int *cur = it == 0 ? nullptr : act + (int64_t)it * Ns;
-        int *next = act + (int64_t)(it + 1) * Ns;
-        // counts[it]: samples flagged during repeat it-1 (listed in act_list by k_flag)
-        const int *alist = (it > 0 && Ns >= 32) ? act_list : nullptr;
-        const int *acount = alist ? act_counts + it : nullptr;
-        const unsigned n_uni = Ns >= 32 ? (unsigned)cdiv(ref->B * cdiv(Ns, 64), 4) : 0u;
-        const unsigned n_flat = (Ns < 32 || alist) ? g : 0u;
-        hipLaunchKernelGGL(k_zscore, dim3(n_uni + n_flat), dim3(256), 0, stream, n_uni,
-                           (const double *)ts.xt.as<double>(), (const double *)ts.xc.as<double>(),
-                           (const int *)ref->gidx.as<int>(), (const int *)ref->nref.as<int>(), ref->k, ref->B, Ns, cur,
-                           ts.zt.as<double>(), ts.rt.as<double>(), ts.nt.as<double>(), ts.sdt.as<double>(), alist,
-                           acount);
-        hipLaunchKernelGGL(k_flag, dim3(g), dim3(256), 0, stream, (const double *)ts.zt.as<double>(), thr, n, Ns,
-                           cur, next, ts.xc.as<double>(), act_list, act_counts + it + 1);
+        // repeat `it` recomputes the pairs queued in its list (all pairs in the first repeat) and
+        // queues, for repeat it + 1, the pairs that see one of its new flags
+        unsigned int *cur = (it & 1) ? ts.pairs_a.as<unsigned int>() : ts.pairs_b.as<unsigned int>();
+        unsigned int *next = it + 1 < repeats ? ((it & 1) ? ts.pairs_b.as<unsigned int>() : ts.pairs_a.as<unsigned int>())
+                                              : nullptr;
+        if (it == 0) {
+            const unsigned n_uni = Ns >= 32 ? (unsigned)cdiv(ref->B * cdiv(Ns, 64), 4) : 0u;
+            const unsigned n_flat = Ns >= 32 ? 0u : g;
+            hipLaunchKernelGGL(k_zscore, dim3(n_uni + n_flat), dim3(256), 0, stream, n_uni,
+                               (const double *)ts.xt.as<double>(), (const double *)ts.xc.as<double>(),
+                               (const int *)ref->gidx.as<int>(), (const int *)ref->nref.as<int>(), ref->k, ref->B, Ns,
+                               ts.zt.as<double>(), ts.rt.as<double>(), ts.nt.as<double>(), ts.sdt.as<double>());
+            hipLaunchKernelGGL(k_flag, dim3(g), dim3(256), 0, stream, (const double *)ts.zt.as<double>(), thr, n, Ns,
+                               ts.xc.as<double>(), uoff, ulst, dirty, next, pair_counts + it + 1);
+        } else {
+            const unsigned gp = (unsigned)std::min<int64_t>(g, 2048);
+            hipLaunchKernelGGL(k_zscore_pairs, dim3(gp), dim3(256), 0, stream, (const unsigned int *)cur,
+                               (const int *)(pair_counts + it), dirty, (const double *)ts.xt.as<double>(),
+                               (const double *)ts.xc.as<double>(), (const int *)ref->gidx.as<int>(),
+                               (const int *)ref->nref.as<int>(), ref->k, Ns, ts.zt.as<double>(), ts.rt.as<double>(),
+                               ts.nt.as<double>(), ts.sdt.as<double>());
+            hipLaunchKernelGGL(k_flag_pairs, dim3(gp), dim3(256), 0, stream, (const unsigned int *)cur,
+                               (const int *)(pair_counts + it), (const double *)ts.zt.as<double>(), thr, Ns,
+                               ts.xc.as<double>(), uoff, ulst, dirty, next, pair_counts + it + 1);
+        }
     }
     // stdDevAvg is a serial sum by definition (one lane per sample); it only feeds the
     // asdef output, so it runs on the context's side stream under the segmentation work.
@@ -1774,6 +1918,38 @@ wc_reference *wc_reference_create(wc_ctx *ctx, const int32_t *indexes, const dou
         wc::set_error("reference: list kernel failed: %s", hipGetErrorString(hipGetLastError()));
         return fail(ref);
     }
+    {
+        // reverse lists (users of every bin), CSR: counts on the device, offsets on the host
+        // (one-off set-up), then the fill with the counts array recycled as cursors
+        const unsigned gb = (unsigned)cdiv(n_bins * k, 256);
+        if (ref->users_off.reserve(sizeof(int) * (n_bins + 1)) || ctx->tmp_c.reserve(sizeof(int) * n_bins))
+            return fail(ref);
+        int *cnt = ctx->tmp_c.as<int>();
+        std::vector<int> host(n_bins + 1, 0);
+        bool ok = hipMemset(cnt, 0, sizeof(int) * n_bins) == hipSuccess;
+        if (ok) {
+            hipLaunchKernelGGL(k_count_users, dim3(gb), dim3(256), 0, nullptr, (const int *)ref->gidx.as<int>(),
+                               (const int *)ref->nref.as<int>(), n_bins, k, cnt);
+            ok = hipMemcpy(host.data() + 1, cnt, sizeof(int) * n_bins, hipMemcpyDeviceToHost) == hipSuccess;
+        }
+        if (ok) {
+            host[0] = 0;
+            for (int64_t g = 0; g < n_bins; ++g) host[g + 1] += host[g];
+            ok = ref->users.reserve(sizeof(int) * std::max<int64_t>(host[n_bins], 1)) == WC_OK &&
+                 hipMemcpy(ref->users_off.p, host.data(), sizeof(int) * (n_bins + 1), hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMemset(cnt, 0, sizeof(int) * n_bins) == hipSuccess;
+        }
+        if (ok) {
+            hipLaunchKernelGGL(k_fill_users, dim3(gb), dim3(256), 0, nullptr, (const int *)ref->gidx.as<int>(),
+                               (const int *)ref->nref.as<int>(), n_bins, k, (const int *)ref->users_off.as<int>(), cnt,
+                               ref->users.as<int>());
+            ok = hipDeviceSynchronize() == hipSuccess;
+        }
+        if (!ok) {
+            wc::set_error("reference: reverse lists failed: %s", hipGetErrorString(hipGetLastError()));
+            return fail(ref);
+        }
+    }
     return ref;
 }
 
@@ -1782,7 +1958,7 @@ void wc_reference_destroy(wc_reference *ref) {
     if (ref->ctx) (void)hipSetDevice(ref->ctx->device);
     (void)hipDeviceSynchronize();
     for (wc::DevBuf *b : {&ref->gidx, &ref->nref, &ref->pca_mean, &ref->pca_comp, &ref->m2g, &ref->g2m,
-                          &ref->moff_dev, &ref->goff_dev})
+                          &ref->moff_dev, &ref->goff_dev, &ref->users_off, &ref->users})
         b->release();
     delete ref;
 }
