@@ -360,13 +360,102 @@ __device__ inline void zscore_one(const int64_t b, const int64_t i, const int64_
     sdT[gid] = sd;
 }
 
+// The same for a wave that holds ONE bin and 64 samples (b wave-uniform) when every lane keeps
+// all of its values, the normal case in the first repeat: the G full groups of eight stay in
+// registers, so the references are gathered once instead of once per pass -- the gathers are
+// what the kernel waits for (about 1 KB per reference row and wave, from L2).  Anything else
+// (a dropped value anywhere in the wave, a list longer than 8 G + 7) takes zscore_one.
+template <int G>
+__device__ inline void zscore_wave(const int b, const int64_t i, const int64_t gid, const double *__restrict__ XT,
+                                   const double *__restrict__ XC, const int *__restrict__ gidx,
+                                   const int *__restrict__ nref, int k, int64_t Ns, double *__restrict__ zT,
+                                   double *__restrict__ rT, double *__restrict__ nT, double *__restrict__ sdT) {
+    const int *lst = gidx + (int64_t)b * k;
+    const int n = nref[b];
+    const int ng = n >> 3;
+    double v[8 * G];
+    bool mine = true;
+    if (ng <= G) {
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+            if (q < ng) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int g = lst[8 * q + e];
+                    v[8 * q + e] = g >= 0 ? XC[(int64_t)g * Ns + i] : -1.0;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+            if (q < ng) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) mine = mine && (v[8 * q + e] >= 0.0);
+            }
+        }
+    }
+    if (ng > G || !__all(mine)) {
+        zscore_one(b, i, gid, XT, XC, gidx, nref, k, Ns, zT, rT, nT, sdT);
+        return;
+    }
+    StreamSum acc;
+    acc.init();
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+        if (q < ng) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc.r[e] = acc.r[e] + v[8 * q + e];   // first group: 0 + v == v exactly (v >= 0)
+        }
+    }
+    acc.pos = 8 * ng;
+    double tailv[7];
+#pragma unroll
+    for (int e = 0; e < 7; ++e) {
+        const int r = 8 * ng + e;
+        const int g = r < n ? lst[r] : -1;
+        tailv[e] = g >= 0 ? XC[(int64_t)g * Ns + i] : -1.0;
+    }
+#pragma unroll
+    for (int e = 0; e < 7; ++e)
+        if (tailv[e] >= 0.0) acc.push(tailv[e]);  // flagged (-1), negative and NaN values are dropped (wisetools.py:425)
+    const int m = acc.pos;
+    const double mean = acc.finish() / (double)m;
+    acc.init();
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+        if (q < ng) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const double dv = v[8 * q + e] - mean;
+                const double sq = dv * dv;
+                acc.r[e] = acc.r[e] + sq;
+            }
+        }
+    }
+    acc.pos = 8 * ng;
+#pragma unroll
+    for (int e = 0; e < 7; ++e)
+        if (tailv[e] >= 0.0) {
+            const double dv = tailv[e] - mean;
+            const double sq = dv * dv;
+            acc.push(sq);
+        }
+    const double var = acc.finish() / (double)m;
+    const double sd = sqrt(var);
+    const double x = XT[gid];
+    zT[gid] = (x - mean) / sd;
+    rT[gid] = x / mean;
+    nT[gid] = (double)m;
+    sdT[gid] = sd;
+}
+
 // First repeat: every (bin, sample) pair.  The first n_uni workgroups run the wave-uniform
 // mapping (a wave holds one bin and 64 consecutive samples, so the bin, its reference list and
 // the list length are wave-uniform: scalar loads of the indexes, scalar row base + lane offset
 // for the gathers; used for batches), the rest the flat mapping thread = (bin, sample) index,
 // which keeps all lanes busy when there are only a few samples (latency mode).  Either count
 // may be zero.
-__global__ __launch_bounds__(256) void k_zscore(unsigned int n_uni, const double *__restrict__ XT,
+__global__ __launch_bounds__(256, 2) void k_zscore(unsigned int n_uni, const double *__restrict__ XT,
                                                 const double *__restrict__ XC, const int *__restrict__ gidx,
                                                 const int *__restrict__ nref, int k, int64_t B, int64_t Ns,
                                                 double *__restrict__ zT, double *__restrict__ rT,
@@ -378,7 +467,7 @@ __global__ __launch_bounds__(256) void k_zscore(unsigned int n_uni, const double
         if (wb >= B) return;
         const int64_t i = (wave - (int64_t)wb * n_sg) * 64 + (threadIdx.x & 63);
         if (i >= Ns) return;
-        zscore_one(wb, i, (int64_t)wb * Ns + i, XT, XC, gidx, nref, k, Ns, zT, rT, nT, sdT);
+        zscore_wave<12>(wb, i, (int64_t)wb * Ns + i, XT, XC, gidx, nref, k, Ns, zT, rT, nT, sdT);
     } else {
         const int64_t gid = (int64_t)(blockIdx.x - n_uni) * 256 + threadIdx.x;
         if (gid >= B * Ns) return;
