@@ -603,10 +603,22 @@ __device__ inline void flag_wave(const int64_t gid, const bool valid, const doub
         const int64_t fg = __shfl(gid, l);
         const int64_t g = fg / Ns, i = fg - g * Ns;
         const int u1 = users_off[g + 1];
-        for (int u = users_off[g] + lane; u < u1; u += 64) {
-            const unsigned int ug = (unsigned int)((int64_t)users[u] * Ns + i);
-            const unsigned int bit = 1u << (ug & 31);
-            if (!(atomicOr(&dirty[ug >> 5], bit) & bit)) next_pairs[atomicAdd(next_count, 1)] = ug;
+        for (int u0 = users_off[g]; u0 < u1; u0 += 64) {
+            const int u = u0 + lane;
+            unsigned int ug = 0u;
+            bool won = false;        // this lane set the pair's bit: it queues the pair
+            if (u < u1) {
+                ug = (unsigned int)((int64_t)users[u] * Ns + i);
+                const unsigned int bit = 1u << (ug & 31);
+                won = !(atomicOr(&dirty[ug >> 5], bit) & bit);
+            }
+            const unsigned long long winners = __ballot(won);
+            if (winners) {            // one reservation per trip
+                int base = 0;
+                if (lane == 0) base = atomicAdd(next_count, __popcll(winners));
+                base = __shfl(base, 0);
+                if (won) next_pairs[base + __popcll(winners & ((1ull << lane) - 1ull))] = ug;
+            }
         }
     }
 }
