@@ -449,31 +449,22 @@ __device__ inline void zscore_wave(const int b, const int64_t i, const int64_t g
     sdT[gid] = sd;
 }
 
-// First repeat: every (bin, sample) pair.  The first n_uni workgroups run the wave-uniform
-// mapping (a wave holds one bin and 64 consecutive samples, so the bin, its reference list and
-// the list length are wave-uniform: scalar loads of the indexes, scalar row base + lane offset
-// for the gathers; used for batches), the rest the flat mapping thread = (bin, sample) index,
-// which keeps all lanes busy when there are only a few samples (latency mode).  Either count
-// may be zero.
-__global__ __launch_bounds__(256, 2) void k_zscore(unsigned int n_uni, const double *__restrict__ XT,
-                                                const double *__restrict__ XC, const int *__restrict__ gidx,
-                                                const int *__restrict__ nref, int k, int64_t B, int64_t Ns,
-                                                double *__restrict__ zT, double *__restrict__ rT,
-                                                double *__restrict__ nT, double *__restrict__ sdT) {
-    if (blockIdx.x < n_uni) {
-        const int64_t n_sg = (Ns + 63) / 64;
-        const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-        const int wb = __builtin_amdgcn_readfirstlane((int)(wave / n_sg));
-        if (wb >= B) return;
-        const int64_t i = (wave - (int64_t)wb * n_sg) * 64 + (threadIdx.x & 63);
-        if (i >= Ns) return;
-        zscore_wave<12>(wb, i, (int64_t)wb * Ns + i, XT, XC, gidx, nref, k, Ns, zT, rT, nT, sdT);
-    } else {
-        const int64_t gid = (int64_t)(blockIdx.x - n_uni) * 256 + threadIdx.x;
-        if (gid >= B * Ns) return;
-        const int64_t b = gid / Ns;
-        zscore_one(b, gid - b * Ns, gid, XT, XC, gidx, nref, k, Ns, zT, rT, nT, sdT);
-    }
+// First repeat of a batch (>= 32 samples): every (bin, sample) pair, wave-uniform mapping -- a
+// wave holds one bin and 64 consecutive samples, so the bin, its reference list and the list
+// length are wave-uniform: scalar loads of the indexes, scalar row base + lane offset for the
+// gathers.  (Smaller batches: k_zscore_pairs over all pairs.)
+__global__ __launch_bounds__(256, 2) void k_zscore(const double *__restrict__ XT, const double *__restrict__ XC,
+                                                   const int *__restrict__ gidx, const int *__restrict__ nref, int k,
+                                                   int64_t B, int64_t Ns, double *__restrict__ zT,
+                                                   double *__restrict__ rT, double *__restrict__ nT,
+                                                   double *__restrict__ sdT) {
+    const int64_t n_sg = (Ns + 63) / 64;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wb = __builtin_amdgcn_readfirstlane((int)(wave / n_sg));
+    if (wb >= B) return;
+    const int64_t i = (wave - (int64_t)wb * n_sg) * 64 + (threadIdx.x & 63);
+    if (i >= Ns) return;
+    zscore_wave<12>(wb, i, (int64_t)wb * Ns + i, XT, XC, gidx, nref, k, Ns, zT, rT, nT, sdT);
 }
 
 // numpy's pairwise sum of a stream of kept values by an aligned group of eight lanes: lane s
@@ -525,19 +516,21 @@ struct GroupSum {
 // the `dirty` bit); only those are recomputed.  Eight lanes per pair: each loads every eighth
 // reference (all of a pair's loads in flight at once; the values stay in registers for the
 // second pass) and the group sums in numpy's order (GroupSum).
+// pairs == nullptr: every pair 0 .. n_all - 1 (first repeat of a small batch, where whole waves
+// per bin would be mostly empty and one thread per pair waits out ~26 dependent gathers).
 __global__ __launch_bounds__(256) void k_zscore_pairs(const unsigned int *__restrict__ pairs,
-                                                      const int *__restrict__ count,
+                                                      const int *__restrict__ count, int64_t n_all,
                                                       unsigned int *__restrict__ dirty,
                                                       const double *__restrict__ XT, const double *__restrict__ XC,
                                                       const int *__restrict__ gidx, const int *__restrict__ nref,
                                                       int k, int64_t Ns, double *__restrict__ zT,
                                                       double *__restrict__ rT, double *__restrict__ nT,
                                                       double *__restrict__ sdT) {
-    const int64_t n_pairs = *count;
+    const int64_t n_pairs = pairs ? (int64_t)*count : n_all;
     const int lane = threadIdx.x & 63, sub = lane & 7, gbase = lane & ~7;
     for (int64_t t = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3; t < n_pairs; t += (int64_t)gridDim.x * 32) {
-        const unsigned int gid = pairs[t];
-        if (sub == 0) atomicAnd(&dirty[gid >> 5], ~(1u << (gid & 31)));
+        const unsigned int gid = pairs ? pairs[t] : (unsigned int)t;
+        if (pairs && sub == 0) atomicAnd(&dirty[gid >> 5], ~(1u << (gid & 31)));
         const int64_t b = gid / Ns, i = gid - b * Ns;
         const int *lst = gidx + b * k;
         const int n = nref[b];
@@ -1710,18 +1703,25 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
         unsigned int *next = it + 1 < repeats ? ((it & 1) ? ts.pairs_b.as<unsigned int>() : ts.pairs_a.as<unsigned int>())
                                               : nullptr;
         if (it == 0) {
-            const unsigned n_uni = Ns >= 32 ? (unsigned)cdiv(ref->B * cdiv(Ns, 64), 4) : 0u;
-            const unsigned n_flat = Ns >= 32 ? 0u : g;
-            hipLaunchKernelGGL(k_zscore, dim3(n_uni + n_flat), dim3(256), 0, stream, n_uni,
-                               (const double *)ts.xt.as<double>(), (const double *)ts.xc.as<double>(),
-                               (const int *)ref->gidx.as<int>(), (const int *)ref->nref.as<int>(), ref->k, ref->B, Ns,
-                               ts.zt.as<double>(), ts.rt.as<double>(), ts.nt.as<double>(), ts.sdt.as<double>());
+            if (Ns >= 32) {
+                const unsigned n_uni = (unsigned)cdiv(ref->B * cdiv(Ns, 64), 4);
+                hipLaunchKernelGGL(k_zscore, dim3(n_uni), dim3(256), 0, stream,
+                                   (const double *)ts.xt.as<double>(), (const double *)ts.xc.as<double>(),
+                                   (const int *)ref->gidx.as<int>(), (const int *)ref->nref.as<int>(), ref->k, ref->B,
+                                   Ns, ts.zt.as<double>(), ts.rt.as<double>(), ts.nt.as<double>(), ts.sdt.as<double>());
+            } else {
+                hipLaunchKernelGGL(k_zscore_pairs, dim3((unsigned)std::min<int64_t>(cdiv(n, 32), 8192)), dim3(256), 0,
+                                   stream, (const unsigned int *)nullptr, (const int *)nullptr, n, dirty,
+                                   (const double *)ts.xt.as<double>(), (const double *)ts.xc.as<double>(),
+                                   (const int *)ref->gidx.as<int>(), (const int *)ref->nref.as<int>(), ref->k, Ns,
+                                   ts.zt.as<double>(), ts.rt.as<double>(), ts.nt.as<double>(), ts.sdt.as<double>());
+            }
             hipLaunchKernelGGL(k_flag, dim3(g), dim3(256), 0, stream, (const double *)ts.zt.as<double>(), thr, n, Ns,
                                ts.xc.as<double>(), uoff, ulst, dirty, next, pair_counts + it + 1);
         } else {
             const unsigned gp = (unsigned)std::min<int64_t>(g, 2048);
             hipLaunchKernelGGL(k_zscore_pairs, dim3(gp), dim3(256), 0, stream, (const unsigned int *)cur,
-                               (const int *)(pair_counts + it), dirty, (const double *)ts.xt.as<double>(),
+                               (const int *)(pair_counts + it), (int64_t)0, dirty, (const double *)ts.xt.as<double>(),
                                (const double *)ts.xc.as<double>(), (const int *)ref->gidx.as<int>(),
                                (const int *)ref->nref.as<int>(), ref->k, Ns, ts.zt.as<double>(), ts.rt.as<double>(),
                                ts.nt.as<double>(), ts.sdt.as<double>());
