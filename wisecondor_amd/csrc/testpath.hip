@@ -1126,6 +1126,18 @@ __global__ __launch_bounds__(256) void k_seg_quiet(Job *__restrict__ jobs, int n
     if (tid == 0 && s_found) jobs[j].pad = 1;
 }
 
+// v_max_f64 / v_min_f64 on finite values, without the canonicalisation fmax() / fmin() imply
+__device__ inline double raw_max(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ inline double raw_min(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // Extreme Stouffer values (prefix-sum estimates) of one block of window rows of a job.  Only
 // the two VALUES leave this kernel: the positions of near-extreme windows are re-derived by
 // k_seg_collect and ranked by their exact values, so nothing here tracks where the extreme
@@ -1182,7 +1194,28 @@ __global__ __launch_bounds__(64 * NW) void k_seg_search(const Job *__restrict__ 
         const double px = P[xl];
         const int room = live ? L - xl : 0;            // windows [xl, xl + len - 1] with len <= room
         double smax = -INFINITY, smin = INFINITY;      // this side, this wave
-        for (int base = 1 + 4 * w; base <= max_len; base += 4 * NW) {
+        int base = 1 + 4 * w;
+        if (!MASKED) {
+            // Lengths every live lane of the wave still has room for take no per-window test at
+            // all: subtract, scale, max, min (the two raw instructions: fmax() / fmin() would each
+            // add a canonicalising v_max_f64, and the values are finite here -- non-finite regions
+            // never reach this kernel).  Lanes without a row read row 0 and are dropped afterwards.
+            const int last_live = side == 0 ? (chunk * ROWS_HALF + 63 < half - 1 ? chunk * ROWS_HALF + 63 : half - 1)
+                                            : L - 1 - chunk * ROWS_HALF;
+            const int min_room = side == 0 ? L - last_live : L - last_live;   // smallest room among the live lanes
+            const double *pb = P + xl;
+            for (; base + 3 <= min_room; base += 4 * NW) {
+                const double r0 = rs[base], r1 = rs[base + 1], r2 = rs[base + 2], r3 = rs[base + 3];
+                const double p0 = pb[base], p1 = pb[base + 1], p2 = pb[base + 2], p3 = pb[base + 3];
+                const double v0 = (p0 - px) * r0, v1 = (p1 - px) * r1, v2 = (p2 - px) * r2, v3 = (p3 - px) * r3;
+                smax = raw_max(smax, v0); smin = raw_min(smin, v0);
+                smax = raw_max(smax, v1); smin = raw_min(smin, v1);
+                smax = raw_max(smax, v2); smin = raw_min(smin, v2);
+                smax = raw_max(smax, v3); smin = raw_min(smin, v3);
+            }
+            if (!live) { smax = -INFINITY; smin = INFINITY; }
+        }
+        for (; base <= max_len; base += 4 * NW) {
             double r[4], pv[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
