@@ -1204,6 +1204,24 @@ __global__ __launch_bounds__(64 * NW) void k_seg_search(const Job *__restrict__ 
                                             : L - 1 - chunk * ROWS_HALF;
             const int min_room = side == 0 ? L - last_live : L - last_live;   // smallest room among the live lanes
             const double *pb = P + xl;
+            // two of the wave's four-length groups per trip (one wait for eight loads); the
+            // lengths stay dealt to the waves as k_seg_collect expects: group g goes to wave g % NW
+            for (; base + 4 * NW + 3 <= min_room; base += 8 * NW) {
+                double r[8], pv[8];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    r[u] = rs[base + u];
+                    pv[u] = pb[base + u];
+                    r[4 + u] = rs[base + 4 * NW + u];
+                    pv[4 + u] = pb[base + 4 * NW + u];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double v = (pv[u] - px) * r[u];
+                    smax = raw_max(smax, v);
+                    smin = raw_min(smin, v);
+                }
+            }
             for (; base + 3 <= min_room; base += 4 * NW) {
                 const double r0 = rs[base], r1 = rs[base + 1], r2 = rs[base + 2], r3 = rs[base + 3];
                 const double p0 = pb[base], p1 = pb[base + 1], p2 = pb[base + 2], p3 = pb[base + 3];
