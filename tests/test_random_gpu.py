@@ -119,11 +119,11 @@ def test_whole_test_path_random(wt, seed):
     reference.close()
 
 
-@pytest.mark.parametrize("n_samples,k,seed", [(3, 40, 0), (40, 40, 1), (40, 128, 2), (70, 24, 3)])
+@pytest.mark.parametrize("n_samples,k,seed", [(3, 40, 0), (40, 40, 1), (40, 128, 2), (70, 24, 3), (40, 10, 4), (5, 9, 5)])
 def test_repeats_heavy_flagging(wt, n_samples, k, seed):
     """A low threshold on noisy samples: every repeat adds flags, so later repeats recompute many
     (bin, sample) pairs with dropped references (cooperative pair kernel; full 128-entry lists
-    at k = 128; negative and NaN values dropped from the first repeat on).  numpy's bits."""
+    at k = 128, fewer than eight kept values -- numpy's plain left-to-right sum -- at k = 9 / 10; negative and NaN values dropped from the first repeat on).  numpy's bits."""
     rng = np.random.RandomState(500 + seed)
     bins = np.array([120, 90, 1, 140, 75, 110], dtype=np.int64)
     sums = np.cumsum(bins)
