@@ -347,8 +347,11 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": ("bf16x3 MFMA (hi/lo pairs, f32 accumulate) distance bounds + f64 exact re-score" if split
-                      else "f32 MFMA distance bounds + f64 exact re-score"),
+            # every delivered index and distance is decided in float64 (numpy's bits); the matrix
+            # cores only bound the distances to pick the candidates that get re-scored
+            "dtype": "f64",
+            "dtype_detail": ("bf16x3 MFMA (hi/lo pairs, f32 accumulate) distance bounds + f64 exact re-score" if split
+                             else "f32 MFMA distance bounds + f64 exact re-score"),
             "data": "synthetic",
             "config": {"workload": "%s: newref %d samples x %d kb bins (%d masked bins, refsize %d), "
                                    "then batched test of %d samples/GPU at the same bin size"
