@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_convert(const double *__restrict__ X, i
     for (int64_t s = lane; s < Kpad16; s += 64) {
         float a = 0.f;
         if (row < B && s < S) a = (float)(X[row * S + s] - mean[s]);
-        if (s < Kpad) A[row * Kpad + s] = a;
+        if (A && s < Kpad) A[row * Kpad + s] = a;
         const unsigned short h = f32_to_bf16(a);
         if (A3 && s < Kpad) {      // split image: per 32-sample slab, 32 hi then 32 lo bfloat16
             const float hi_f = __uint_as_float((unsigned int)h << 16);
@@ -1474,7 +1474,8 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
 
     int rc;
     if ((rc = st.col_mean.reserve(sizeof(double) * 3 * n_samples))) return rc;
-    if ((rc = st.a32.reserve(sizeof(float) * st.bins_pad * st.k_pad))) return rc;
+    // one operand image: float32 for the fp32 matrix cores, hi/lo bfloat16 pairs for the split tiles
+    if (!st.split && (rc = st.a32.reserve(sizeof(float) * st.bins_pad * st.k_pad))) return rc;
     if (st.split && (rc = st.a3.reserve(sizeof(float) * st.bins_pad * st.k_pad))) return rc;
     if ((rc = st.norm_lo.reserve(sizeof(float) * st.bins_pad))) return rc;
     if ((rc = st.norm_hi.reserve(sizeof(float) * st.bins_pad))) return rc;
@@ -1550,7 +1551,8 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
 
     hipLaunchKernelGGL(k_convert, dim3((unsigned)(st.bins_pad / 4)), dim3(256), 0, stream, corrected, n_bins,
                        n_samples, st.bins_pad, st.k_pad, (const double *)mean2, (double)st.beta,
-                       st.chrom_off_dev.as<int64_t>(), n_chrom, st.a32.as<float>(), st.a16.as<unsigned short>(),
+                       st.chrom_off_dev.as<int64_t>(), n_chrom, st.split ? (float *)nullptr : st.a32.as<float>(),
+                       st.a16.as<unsigned short>(),
                        st.k_pad16, st.norm_lo.as<float>(), st.norm_hi.as<float>(), st.chrom_of_row.as<int>(),
                        st.chrom_range.as<int2>(), (const int *)st.sample_slot.as<int>(),
                        st.s16.as<unsigned short>(), st.s_norm_lo.as<float>(), st.s_chrom.as<int>(),
