@@ -898,7 +898,20 @@ __global__ __launch_bounds__(NT, 4) void k_finish(FinishArgs a) {
     const bool admit_all = (thr_f == WC_ADMIT_ALL);
     bool fallback = c > a.cap;
     const int n = fallback ? 0 : c;
-    for (int t = tid; t < n; t += NT) ent[t] = a.list[row * a.cap + t];
+    // the candidates' upper norm bounds are requested together with the list: the gather's
+    // round trip runs under the k-th key search instead of inside the bound computation
+    constexpr int EPT = LIST_CAP / NT;     // list entries per thread
+    float nh[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int t = tid + e * NT;
+        nh[e] = 0.f;
+        if (t < n) {
+            const unsigned long long en = a.list[row * a.cap + t];
+            ent[t] = en;
+            nh[e] = a.norm_hi[(int)(uint32_t)en];
+        }
+    }
     const double *xi = a.X + row * a.S;
     if (a.xs_in_lds) {
         for (int64_t s = tid; s < a.S; s += NT) xs_dyn[s] = xi[s];
@@ -918,12 +931,15 @@ __global__ __launch_bounds__(NT, 4) void k_finish(FinishArgs a) {
             const uint32_t kth = select_key<NT>(ent, n, a.k - 1, s_tmp, tid);
             const double nhi = (double)a.norm_hi[row];
             double my = -INFINITY;
-            for (int t = tid; t < n; t += NT) {
-                uint32_t ku = (uint32_t)(ent[t] >> 32);
-                if (ku <= kth) {
-                    int j = (int)(uint32_t)ent[t];
-                    double ub = (double)wc::f32_from_ordered(ku) + 3.0 * a.beta * (nhi + (double)a.norm_hi[j]) + 1e-36;
-                    my = fmax(my, ub);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const int t = tid + e * NT;
+                if (t < n) {
+                    uint32_t ku = (uint32_t)(ent[t] >> 32);
+                    if (ku <= kth) {
+                        double ub = (double)wc::f32_from_ordered(ku) + 3.0 * a.beta * (nhi + (double)nh[e]) + 1e-36;
+                        my = fmax(my, ub);
+                    }
                 }
             }
             for (int o = 32; o > 0; o >>= 1) my = fmax(my, __shfl_xor(my, o));
