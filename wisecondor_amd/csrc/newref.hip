@@ -893,6 +893,12 @@ __global__ __launch_bounds__(NT, 4) void k_finish(FinishArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int64_t row = a.row_begin + blockIdx.x;
     if (row >= a.row_end) return;
+    // the first 384 list slots (the expected length) are requested before the count is known:
+    // one round trip instead of two before the row's work can start
+    constexpr int SPEC = (LIST_CAP * 3 / 8) / NT;
+    unsigned long long spec[SPEC];
+#pragma unroll
+    for (int e = 0; e < SPEC; ++e) spec[e] = a.list[row * a.cap + tid + e * NT];
     const int c = a.cnt[row];
     const float thr_f = a.thr[row];
     const bool admit_all = (thr_f == WC_ADMIT_ALL);
@@ -907,7 +913,7 @@ __global__ __launch_bounds__(NT, 4) void k_finish(FinishArgs a) {
         const int t = tid + e * NT;
         nh[e] = 0.f;
         if (t < n) {
-            const unsigned long long en = a.list[row * a.cap + t];
+            const unsigned long long en = e < SPEC ? spec[e] : a.list[row * a.cap + t];
             ent[t] = en;
             nh[e] = a.norm_hi[(int)(uint32_t)en];
         }
