@@ -901,6 +901,8 @@ __global__ __launch_bounds__(NT, 4) void k_finish(FinishArgs a) {
     for (int e = 0; e < SPEC; ++e) spec[e] = a.list[row * a.cap + tid + e * NT];
     const int c = a.cnt[row];
     const float thr_f = a.thr[row];
+    const float nhi_f = a.norm_hi[row];           // needed only later: requested now
+    const int ch = a.chrom_of_row[row];
     const bool admit_all = (thr_f == WC_ADMIT_ALL);
     bool fallback = c > a.cap;
     const int n = fallback ? 0 : c;
@@ -935,7 +937,7 @@ __global__ __launch_bounds__(NT, 4) void k_finish(FinishArgs a) {
             // upper bound of the k-th true distance: the largest upper bound among the
             // entries whose lower bound is within the k smallest
             const uint32_t kth = select_key<NT>(ent, n, a.k - 1, s_tmp, tid);
-            const double nhi = (double)a.norm_hi[row];
+            const double nhi = (double)nhi_f;
             double my = -INFINITY;
 #pragma unroll
             for (int e = 0; e < EPT; ++e) {
@@ -1125,7 +1127,6 @@ __global__ __launch_bounds__(NT, 4) void k_finish(FinishArgs a) {
             }
         }
     }
-    const int ch = a.chrom_of_row[row];
     const int64_t cs = a.chrom_off[ch], ce = a.chrom_off[ch + 1];
     const int64_t orow = row - a.row_begin;
     __syncthreads();
