@@ -1033,6 +1033,7 @@ __global__ __launch_bounds__(256) void k_seg_quiet(Job *__restrict__ jobs, int n
     if (!reg_flag[job.region]) return;            // non-finite region: classify sends it to the brute path
     if (job.pad) return;                          // a sibling workgroup already found a window
     const double eps = window_eps(regions[job.region].n, reg_abs[job.region]);
+    const double T = thr - eps, T2c = T * T * (1.0 - 3e-6);   // a window below T in magnitude cannot reach thr
     const long long base = regions[job.region].off + job.region + job.lo;    // absolute index of the job's P[0]
     const long long a_hi = base + L;                                          // absolute index of the last end
     const long long k_last = a_hi / QB;
@@ -1090,18 +1091,20 @@ __global__ __launch_bounds__(256) void k_seg_quiet(Job *__restrict__ jobs, int n
                     if (!(fabs(v) + eps < thr)) found = true;
                 }
             }
-            // far ends, one bound per block; the four waves take every fourth block.  The factor is
-            // an upper bound of 1/sqrt(min len) from the float32 reciprocal square root (no table
-            // gather in the loop).  Undecided (row, block) pairs are queued: evaluating them here
-            // would keep a whole wave waiting for the few lanes that need it.
+            // far ends, one bound per block; the four waves take every fourth block.  The bound
+            // |extreme - P[x]| / sqrt(min len) is compared in squared form (no table gather, no
+            // reciprocal square root in the loop).  Undecided (row, block) pairs are queued:
+            // evaluating them here would keep a whole wave waiting for the few lanes that need it.
             const long long k0 = a0 / QB + 2;
+            if (!(T > 0.0)) found = true;        // nothing can be certified below a non-positive bound
             for (long long k = k0 + w; k <= k_last; k += 4) {
                 const double mx = s_tmx[k - k_base], mn = s_tmn[k - k_base];     // wave-uniform LDS reads
                 if (live && k >= k_far) {
-                    const double m = (double)__frsqrt_rn((float)(k * QB - ax)) * 1.000001;
+                    // (max - P[x]) / sqrt(min len) + eps < thr, squared: no reciprocal square root,
+                    // no division (the 3e-6 margin dwarfs every rounding on the way)
+                    const double t2 = T2c * (double)(int)(k * QB - ax);
                     const double up = mx - px, dn = mn - px;
-                    const double hi = up > 0.0 ? up * m : 0.0, lo = dn < 0.0 ? -dn * m : 0.0;
-                    if (!(hi + eps < thr) || !(lo + eps < thr)) {
+                    if ((up > 0.0 && up * up >= t2) || (dn < 0.0 && dn * dn >= t2)) {
                         const int at = atomicAdd(&s_nwork, 1);
                         if (at < Q_WORK) s_work[at] = ((side * ROWS_HALF + lane) << 24) | (int)(k - k_base);
                         else found = true;                              // queue full: give up the certificate
