@@ -88,6 +88,30 @@ def test_more_samples_than_the_row_cache_holds(wt, order):
     assert same_bits(dst, np.asarray(want_d, dtype=np.float64).reshape(-1, k))
 
 
+@pytest.mark.parametrize("layout", [[1, 2], [1, 1], [3, 0, 1], [1, 40], [1, 2, 1], [1, 30, 1], [1, 0, 5, 1],
+                                    [2, 3, 1], [1, 3, 2]])
+@pytest.mark.parametrize("order", ["C", "F"])
+def test_single_row_pieces(wt, layout, order):
+    """Chromosomes with at most one bin before and at most one after them: the reference's
+    chromData = concatenate(rows before, rows after) then consists of single-row pieces, which
+    carry no layout -- it comes out C ordered and numpy sums its rows pairwise even when
+    correctedData is Fortran ordered (everything else in such a file sums sample by sample).
+    Found by the seed sweep."""
+    rng = np.random.RandomState(31)
+    bins = np.array(layout, dtype=np.int64)
+    B, S, k = int(bins.sum()), 200, 5
+    data = 1.0 + 0.03 * rng.standard_normal((B, S))
+    if order == "F":
+        data = np.asfortranarray(data)
+    sums = np.cumsum(bins)
+    for parts in (1, 2):
+        for part in range(1, parts + 1):
+            idx, dst = wt.getReference(data, bins, sums, k, part, parts)
+            want_i, want_d = wo.get_reference(data, bins, sums, k, part, parts, fast=False)
+            assert np.array_equal(idx, np.asarray(want_i).reshape(-1, k)), (part, parts)
+            assert same_bits(dst, np.asarray(want_d, dtype=np.float64).reshape(-1, k)), (part, parts)
+
+
 def test_oracle_hard_ties_and_outliers(wt):
     """Duplicated rows (exact ties across chromosomes), an outlier bin and a NaN bin."""
     from wisecondor_amd import synth

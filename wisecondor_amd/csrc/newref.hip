@@ -770,6 +770,12 @@ struct FinishArgs {
     int xs_in_lds;
     const int2 *pw_prog;   // pairwise leaf table: {leaf end, adds after it}
     int pw_leaves;
+    // Sequential order only: chromosomes with at most ONE bin before them and at most one after.
+    // The reference's chromData = concatenate(rows before, rows after) (wisetools.py:386-387) is
+    // Fortran ordered only if one of the two pieces has two or more rows; single-row pieces carry
+    // no layout, the result comes out C ordered and numpy reduces its rows pairwise whatever the
+    // layout of correctedData (found by the seed sweep: 3 bins in 1 + 2, 4 bins in 1 + 2 + 1).
+    unsigned long long lone_mask;
 };
 
 // Exact distance of rows j and i with numpy's bits: subtract, square (rounded), sum
@@ -904,7 +910,7 @@ __global__ __launch_bounds__(NT, 4) void k_finish(FinishArgs a) {
     const float nhi_f = a.norm_hi[row];           // needed only later: requested now
     const int ch = a.chrom_of_row[row];
     const bool admit_all = (thr_f == WC_ADMIT_ALL);
-    bool fallback = c > a.cap;
+    bool fallback = c > a.cap || ((a.lone_mask >> ch) & 1ull);   // C-ordered chromData: exact path, pairwise order
     const int n = fallback ? 0 : c;
     // the candidates' upper norm bounds are requested together with the list: the gather's
     // round trip runs under the k-th key search instead of inside the bound computation
@@ -1179,7 +1185,8 @@ __device__ inline void fb_fill(const FinishArgs &a, int64_t row, const double *x
     for (int64_t base = j0; base < j1; base += 32) {
         int64_t j = base + grp;
         bool in = j < j1;
-        double d = exact_distance(a.X + (in ? j : row) * a.S, xi, a.S, sub, a.sum_order);
+        double d = exact_distance(a.X + (in ? j : row) * a.S, xi, a.S, sub,
+                                  ((a.lone_mask >> ch) & 1ull) ? WC_SUM_PAIRWISE : a.sum_order);
         if (in && sub == 0) {
             bool ok = !(j >= cs && j < ce) && d < SENTINEL_DISTANCE;
             sc[j] = ok ? wc::f64_ordered(d) : ~0ull;
@@ -1772,6 +1779,10 @@ int wc_newref_finish_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t 
     a.fb_count = st.fb_count.as<int>();
     a.row_stat = st.stats.as<int>();
     a.sum_order = st.sum_order;
+    a.lone_mask = 0ull;
+    if (st.sum_order == WC_SUM_SEQUENTIAL)
+        for (int c = 0; c < st.n_chrom; ++c)
+            if (st.chrom_off[c] <= 1 && st.n_bins - st.chrom_off[c + 1] <= 1) a.lone_mask |= 1ull << c;
     a.xs_in_lds = st.n_samples <= 2048;
     a.pw_prog = st.pw_prog.as<int2>();
     a.pw_leaves = st.pw_leaves;
