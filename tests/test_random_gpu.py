@@ -119,7 +119,10 @@ def test_whole_test_path_random(wt, seed):
     reference.close()
 
 
-@pytest.mark.parametrize("n_samples,k,seed", [(3, 40, 0), (40, 40, 1), (40, 128, 2), (70, 24, 3), (40, 10, 4), (5, 9, 5)])
+_FLAG_SHAPES = [(3, 40), (40, 40), (40, 128), (70, 24), (40, 10), (5, 9)]
+
+
+@pytest.mark.parametrize("n_samples,k,seed", [_FLAG_SHAPES[i % 6] + (i,) for i in range(6 * SWEEP)])
 def test_repeats_heavy_flagging(wt, n_samples, k, seed):
     """A low threshold on noisy samples: every repeat adds flags, so later repeats recompute many
     (bin, sample) pairs with dropped references (cooperative pair kernel; full 128-entry lists
@@ -151,6 +154,37 @@ def test_repeats_heavy_flagging(wt, n_samples, k, seed):
         assert same_bits(z[s_], wz), (s_,)
         assert same_bits(r[s_], wr), (s_,)
         assert same_bits([sd[s_]], [wsd]), (s_,)
+
+
+@pytest.mark.parametrize("seed", range(4 * SWEEP))
+def test_segments_random(wt, seed):
+    """Stouffer segmentation of random regions against the oracle's triangle walk: lengths around
+    the block sizes of the search (64 rows, 32-entry end blocks), planted events of both signs,
+    rounded values (exact ties between windows), thresholds from 'everything is a call' to
+    'nothing is'; coordinates and window values bit for bit."""
+    rng = np.random.RandomState(9000 + seed)
+    regions = []
+    for _ in range(12):
+        n = int(rng.choice([1, 2, 3, 5, 31, 32, 33, 63, 64, 65, 127, 128, 129, 191, 200, 256, 257, 400]))
+        z = rng.standard_normal(n) * rng.choice([0.3, 1.0, 1.0, 2.0])
+        for _ in range(int(rng.choice([0, 1, 1, 2, 4]))):
+            if n > 12:
+                a = rng.randint(0, n - 10)
+                z[a:a + rng.randint(2, 10)] += rng.choice([-1, 1]) * rng.choice([1.5, 3.0, 6.0])
+        if rng.rand() < 0.2:
+            z = np.round(z)
+        if rng.rand() < 0.1:
+            z[:] = rng.choice([0.0, 0.5, -2.0])
+        regions.append(z)
+    thr = float(rng.choice([0.5, 2.0, 3.5, 5.0, 8.0]))
+    min_search = 3
+    whole, segs = wt.stouffer_segments(regions, thr, min_search)
+    for z, w, s in zip(regions, whole, segs):
+        tri = wo.fill_tri(z)
+        want = wo.segment_tri(tri, z.shape[0], thr, min_search)
+        assert [(x, y) for _, (x, y) in s] == [(x, y) for _, (x, y) in want], (seed, z.shape, thr)
+        assert same_bits([v for v, _ in s], [v for v, _ in want]), (seed, z.shape, thr)
+        assert same_bits([w], [tri[z.shape[0] - 1]]), (seed, z.shape)
 
 
 @pytest.mark.parametrize("order", ["C", "F"])
