@@ -119,6 +119,47 @@ def test_whole_test_path_random(wt, seed):
     reference.close()
 
 
+def test_degenerate_samples(wt):
+    """Samples the reference still processes: a single read (hundreds of calls -- more than the
+    library's default room per sample, the wrapper runs it again with more), a few spikes, half
+    of the genome without reads, constant depth.  Call coordinates exact, values to 1e-8."""
+    rng = np.random.RandomState(5)
+    sizes = rng.randint(25, 60, size=22).astype(np.int64)
+    total = int(sizes.sum())
+    mask = rng.rand(total) > 0.05
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    msizes = np.array([int(mask[offs[i]:offs[i + 1]].sum()) for i in range(22)], dtype=np.int64)
+    B = int(msizes.sum())
+    corrected = 1.0 + 0.02 * rng.standard_normal((B, 20))
+    idx, dst = wt.getReference(np.asfortranarray(corrected), msizes, np.cumsum(msizes), 40, 1, 1)
+    comps = np.linalg.qr(rng.standard_normal((B, 3)))[0].T
+    mean = np.full(B, 1.0 / B) * (1 + 0.01 * rng.standard_normal(B))
+    ref = dict(binsize=np.float64(1e6), indexes=idx, distances=dst, chromosome_sizes=sizes, mask=mask,
+               masked_sizes=msizes, pca_mean=mean, pca_components=comps)
+    reference = wt.Reference(idx, dst, sizes, msizes, mask, mean, comps, binsize=1e6)
+
+    def mk(counts):
+        return {str(c + 1): np.asarray(counts[offs[c]:offs[c + 1]]).astype(np.int32) for c in range(22)}
+    lam = np.full(total, 3000.0)
+    samples = [mk(np.eye(1, total, 17).ravel()),
+               mk(np.full(total, 2000000.0)),
+               mk(rng.poisson(lam) * (1 + 50 * (rng.rand(total) < 0.01))),
+               mk(np.where(np.arange(total) < total // 2, rng.poisson(lam), 0))]
+    outs = wt.test_batch(reference, samples, 4.0, minrefbins=5, repeats=5)
+    assert len(outs[0]["results_calls"]) > wt.MAX_CALLS
+    for sample, out in zip(samples, outs):
+        with np.errstate(all="ignore"):
+            want = wo.test_sample(sample, 1e6, ref, minzscore=4.0, minrefbins=5, repeats=5)
+        wc_ = np.asarray(want["results_calls"], dtype=np.float64).reshape(-1, 5)
+        gc_ = out["results_calls"].reshape(-1, 5)
+        assert np.array_equal(gc_[:, :3], wc_[:, :3])
+        assert np.allclose(gc_[:, 3:], wc_[:, 3:], rtol=1e-8, equal_nan=True)
+        assert np.allclose(np.concatenate(out["results_z"]), np.concatenate(want["results_z"]),
+                           rtol=1e-8, atol=1e-10, equal_nan=True)
+        assert np.allclose(out["results_cwz"], want["results_cwz"], rtol=1e-8, atol=1e-9, equal_nan=True)
+    reference.close()
+
+
 _FLAG_SHAPES = [(3, 40), (40, 40), (40, 128), (70, 24), (40, 10), (5, 9)]
 
 

@@ -55,6 +55,7 @@ SIGNATURES = {
 
 SUM_PAIRWISE = 0
 SUM_SEQUENTIAL = 1
+E_ARG, E_HIP, E_LIMIT, E_INTERNAL = -1, -2, -3, -4     # WC_E_* of include/wisecondor_hip.h
 
 _lib = None
 

@@ -321,14 +321,23 @@ def test_batch(reference, samples, threshold, minrefbins=25, repeats=5, chromoso
         rz = np.empty((ns, reference.n_total))
         rr = np.empty((ns, reference.n_total))
         cwz = np.empty((ns, max(len(sel), 1)))
-        calls = np.zeros((ns, MAX_CALLS, 5))
         ncalls = np.zeros(ns, dtype=np.int32)
         asdef = np.empty(ns)
-        _lib.check(lib.wc_test_batch(reference.ctx, reference.handle, _lib.ptr(counts), ns, float(threshold),
-                                     int(minrefbins), int(repeats), float(mineffectsize), _lib.ptr(sel), len(sel),
-                                     MAX_CALLS,
-                                     _lib.ptr(rz), _lib.ptr(rr), _lib.ptr(cwz), _lib.ptr(calls),
-                                     _lib.ptr(ncalls), _lib.ptr(asdef)))
+        # The reference has no limit on the number of calls; the library's output arrays have one
+        # (max_calls per sample and chromosome).  A sample that exceeds it -- e.g. one with almost
+        # no reads -- is simply run again with more room.
+        max_calls = MAX_CALLS
+        while True:
+            calls = np.zeros((ns, max_calls, 5))
+            rc = lib.wc_test_batch(reference.ctx, reference.handle, _lib.ptr(counts), ns, float(threshold),
+                                   int(minrefbins), int(repeats), float(mineffectsize), _lib.ptr(sel), len(sel),
+                                   max_calls, _lib.ptr(rz), _lib.ptr(rr), _lib.ptr(cwz), _lib.ptr(calls),
+                                   _lib.ptr(ncalls), _lib.ptr(asdef))
+            if rc == _lib.E_LIMIT and b"max_calls" in lib.wc_last_error() and max_calls < reference.n_total:
+                max_calls *= 4
+                continue
+            _lib.check(rc)
+            break
         offs = np.concatenate([[0], np.cumsum(sizes)])
         for i in range(ns):
             out.append(dict(
