@@ -119,6 +119,41 @@ def test_whole_test_path_random(wt, seed):
     reference.close()
 
 
+@pytest.mark.parametrize("seed", range(3 * SWEEP))
+def test_segments_mineffectsize_random(wt, seed):
+    """-mineffectsize branch (fillTriMin, wisetools.py:479-487) on random regions: windows whose
+    median ratio is too close to 1 count as zero; rounded ratios (median ties), NaN ratios."""
+    rng = np.random.RandomState(12000 + seed)
+    zs, rs = [], []
+    for _ in range(8):
+        n = int(rng.choice([1, 2, 4, 5, 31, 33, 64, 77, 130, 200]))
+        z = rng.standard_normal(n)
+        r = 1.0 + 0.05 * rng.standard_normal(n)
+        if rng.rand() < 0.5:
+            r = np.round(r, 2)
+        for _ in range(int(rng.choice([0, 1, 2]))):
+            if n > 10:
+                a = rng.randint(0, n - 6)
+                w = rng.randint(2, 6)
+                sgn = rng.choice([-1, 1])
+                z[a:a + w] += sgn * rng.choice([3.0, 5.0])
+                r[a:a + w] += sgn * rng.choice([0.02, 0.1])
+        if rng.rand() < 0.15 and n > 3:
+            r[rng.randint(0, n)] = np.nan
+        zs.append(z)
+        rs.append(r)
+    thr = float(rng.choice([2.0, 3.0, 4.5]))
+    eff = float(rng.choice([0.01, 0.05, 0.15]))
+    whole, segs = wt.stouffer_segments(zs, thr, 3, ratios=rs, mineffectsize=eff)
+    for z, r, w, s in zip(zs, rs, whole, segs):
+        with np.errstate(all="ignore"):
+            tri = wo.fill_tri_min(z, r, eff)
+        want = wo.segment_tri(tri, len(z), thr, 3)
+        assert [(x, y) for _, (x, y) in s] == [(x, y) for _, (x, y) in want], (seed, len(z), thr, eff)
+        assert same_bits([v for v, _ in s], [v for v, _ in want]), (seed, len(z))
+        assert same_bits([w], [tri[len(z) - 1]]), (seed, len(z))
+
+
 def test_degenerate_samples(wt):
     """Samples the reference still processes: a single read (hundreds of calls -- more than the
     library's default room per sample, the wrapper runs it again with more), a few spikes, half
