@@ -35,9 +35,23 @@ SENTINEL_DISTANCE = 1e10  # wisetools.py:306
 # numpy's bits.  (numpy/core/src/umath/loops_utils.h.src, pairwise_sum; call
 # sites in the reference: wisetools.py:302, 426-427, 471.)
 # --------------------------------------------------------------------------
+NPY_BUFSIZE = 8192      # np.getbufsize(): add.reduce hands the inner loop at most this many elements
+
+
 def pairwise_sum(a):
-    """Sum a 1-D float64 sequence in numpy's add.reduce order."""
+    """Sum a 1-D float64 sequence in numpy's add.reduce order: pairwise within pieces of
+    NPY_BUFSIZE elements, the piece sums accumulated left to right."""
     a = np.asarray(a, dtype=np.float64)
+    if a.shape[0] > NPY_BUFSIZE:
+        res = 0.0
+        for off in range(0, a.shape[0], NPY_BUFSIZE):
+            res = res + _pairwise_piece(a[off:off + NPY_BUFSIZE])
+        return res
+    return _pairwise_piece(a)
+
+
+def _pairwise_piece(a):
+    """numpy's pairwise_sum (loops_utils.h.src) of one piece."""
     n = a.shape[0]
     if n < 8:
         res = 0.0
@@ -56,7 +70,7 @@ def pairwise_sum(a):
         return res
     half = n // 2
     half -= half % 8
-    return pairwise_sum(a[:half]) + pairwise_sum(a[half:])
+    return _pairwise_piece(a[:half]) + _pairwise_piece(a[half:])
 
 
 # --------------------------------------------------------------------------

@@ -103,3 +103,76 @@ def test_batched_test_50kb_equals_single_samples(wt):
         # median of the true set sits within one order statistic of this set's middle
         n = kept.shape[0]
         assert kept[n // 2 - 2] <= effect <= kept[n // 2 + 2], (chrom, start, end, effect, np.median(kept))
+
+
+def _extreme(z, lo, hi, sign):
+    """Largest sign * Stouffer value among the windows of z[lo:hi] -- prefix sums to find the
+    near-maximal windows (vectorised over the window end), the reference's own expression
+    np.sum(z[x:y+1]) / np.sqrt(len) to rank them, first in triangle (x-major) order on ties."""
+    n = hi - lo
+    P = np.concatenate([[0.0], np.cumsum(z[lo:hi])])
+    best, cands = -np.inf, []
+    for x in range(n):
+        ln = np.arange(1, n - x + 1)
+        v = sign * (P[x + ln] - P[x]) / np.sqrt(ln)
+        m = v.max()
+        if m >= best - 1e-9:
+            best = max(best, m)
+            cands += [(x, x + int(yy)) for yy in np.nonzero(v >= best - 1e-9)[0]]
+    exact = [(sign * (np.sum(z[lo + x:lo + y + 1]) / np.sqrt(y - x + 1)), x, y) for x, y in cands]
+    top = max(e[0] for e in exact)
+    x, y = min((e[1], e[2]) for e in exact if e[0] == top)
+    return sign * top, x, y
+
+
+def _segments(z, thr, min_search, lo, hi):
+    """triarray.py:59-84 on the windows of z[lo:hi] without the triangle."""
+    out, n = [], hi - lo
+    if n <= 0:
+        return out
+    cv, cx, cy = _extreme(z, lo, hi, +1)
+    bv, bx, by = _extreme(z, lo, hi, -1)
+    if abs(bv) > cv:
+        cv, cx, cy = bv, bx, by
+    if abs(cv) < thr:
+        return out
+    if cx > min_search:
+        out += _segments(z, thr, min_search, lo, lo + cx)
+    out.append((cv, (lo + cx, lo + cy)))
+    if cy + 1 < n - min_search:
+        out += _segments(z, thr, min_search, lo + cy + 1, hi)
+    return out
+
+
+@pytest.mark.parametrize("n", [6500, 8193, 12000])
+def test_segments_regions_beyond_the_staged_sizes(wt, n):
+    """Regions longer than the search stages in LDS (6 143 bins) and longer than the quiet
+    certificate's block table covers (8 192 bins): prefix slice read from global memory, no
+    certificate.  The oracle's triangle would need n^2 / 2 numpy calls; the restatement above
+    ranks only the near-extreme windows exactly."""
+    rng = np.random.RandomState(n)
+    z = rng.standard_normal(n)
+    z[n // 3:n // 3 + 150] += 0.8
+    z[2 * n // 3:2 * n // 3 + 40] -= 1.5
+    whole, got = wt.stouffer_segments([z, rng.standard_normal(50)], 5.0, 3)
+    want = _segments(z, 5.0, 3, 0, n)
+    assert len(want) >= 2
+    assert [xy for _, xy in got[0]] == [xy for _, xy in want]
+    assert np.array_equal(np.array([v for v, _ in got[0]]).view(np.int64), np.array([v for v, _ in want]).view(np.int64))
+    assert np.float64(whole[0]).view(np.int64) == np.float64(np.sum(z) / np.sqrt(n)).view(np.int64)
+
+
+def test_segment_longer_than_numpys_buffer(wt):
+    """A call of ~9 500 bins: np.sum over more than 8 192 contiguous values is not one pairwise
+    tree but buffer-sized pieces accumulated left to right (the whole-region value above 8 192
+    bins as well); window value and coordinates must still be numpy's."""
+    n = 12001
+    rng = np.random.RandomState(77)
+    z = rng.standard_normal(n)
+    z[1000:10500] += 0.2
+    whole, got = wt.stouffer_segments([z], 6.0, 3)
+    want = _segments(z, 6.0, 3, 0, n)
+    assert max(y - x for _, (x, y) in want) > 8192
+    assert [xy for _, xy in got[0]] == [xy for _, xy in want]
+    assert np.array_equal(np.array([v for v, _ in got[0]]).view(np.int64), np.array([v for v, _ in want]).view(np.int64))
+    assert np.float64(whole[0]).view(np.int64) == np.float64(np.sum(z) / np.sqrt(n)).view(np.int64)

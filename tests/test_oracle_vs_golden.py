@@ -47,7 +47,8 @@ def test_parts_concatenate_to_whole(golden):
 
 def test_pairwise_sum_is_numpy_order():
     rng = np.random.RandomState(0)
-    for n in list(range(0, 140)) + [255, 256, 257, 600, 1000, 4986]:
+    # beyond 8192 elements numpy's reduction runs in buffer-sized pieces
+    for n in list(range(0, 140)) + [255, 256, 257, 600, 1000, 4986, 8192, 8193, 8200, 12000, 16385, 24577]:
         a = rng.standard_normal(n) * 10.0 ** rng.uniform(-3, 3, n)
         assert wo.pairwise_sum(a) == np.sum(a), n
     # the 2-D row reduction used for distances (wisetools.py:302)

@@ -153,7 +153,7 @@ template <class F> __device__ inline double pw_leaf_group8(F f, int64_t off, int
     return r;
 }
 
-template <bool GROUP8, class F> __device__ inline double pairwise_sum(F f, int64_t n, int sub) {
+template <bool GROUP8, class F> __device__ inline double pairwise_tree(F f, int64_t n, int sub) {
     if (n <= WC_PW_BLOCK)
         return GROUP8 ? pw_leaf_group8(f, 0, (int)n, sub) : pw_leaf_serial(f, 0, (int)n);
     int64_t s_off[WC_PW_DEPTH], s_n[WC_PW_DEPTH];
@@ -203,10 +203,10 @@ struct PwWaveScratch {
     int s_off[WC_PW_DEPTH], s_n[WC_PW_DEPTH], s_phase[WC_PW_DEPTH];
     double s_left[WC_PW_DEPTH];
 };
-template <class F> __device__ inline double pairwise_sum_wave(F f, int64_t n, int lane, PwWaveScratch &sc) {
+template <class F> __device__ inline double pairwise_tree_wave(F f, int64_t n, int lane, PwWaveScratch &sc) {
     const int sub = lane & 7, grp = lane >> 3;
     if (n <= WC_PW_BLOCK) return pw_leaf_group8(f, 0, (int)n, sub);
-    if (n > (int64_t)WC_PW_LEAVES * 64) return pairwise_sum<true>(f, n, sub);
+    if (n > (int64_t)WC_PW_LEAVES * 64) return pairwise_tree<true>(f, n, sub);
     // 1. leaves in tree (depth-first) order; every lane walks the same tree
     int *s_off = sc.s_off, *s_n = sc.s_n, *s_phase = sc.s_phase;
     int sp = 1, n_leaves = 0;
@@ -273,6 +273,31 @@ template <class F> __device__ inline double pairwise_sum_wave(F f, int64_t n, in
     }
     __builtin_amdgcn_wave_barrier();          // the scratch may be reused by the caller's next sum
     return result;
+}
+
+// numpy's add.reduce itself: the reduction runs through numpy's iterator in pieces of its
+// buffer size (8192 elements, np.getbufsize()), each piece summed pairwise as above and the
+// piece sums accumulated left to right -- np.sum over a contiguous run of more than 8192
+// values is NOT one pairwise tree (found with a 8193-bin region; 60 / 60 sizes up to 55 337
+// agree with this rule on numpy 2.2.6).
+#define WC_NPY_BUFSIZE 8192
+template <bool GROUP8, class F> __device__ inline double pairwise_sum(F f, int64_t n, int sub) {
+    if (n <= WC_NPY_BUFSIZE) return pairwise_tree<GROUP8>(f, n, sub);
+    double res = 0.0;
+    for (int64_t off = 0; off < n; off += WC_NPY_BUFSIZE) {
+        const int64_t m = n - off < WC_NPY_BUFSIZE ? n - off : WC_NPY_BUFSIZE;
+        res = res + pairwise_tree<GROUP8>([&](int64_t i) { return f(off + i); }, m, sub);
+    }
+    return res;
+}
+template <class F> __device__ inline double pairwise_sum_wave(F f, int64_t n, int lane, PwWaveScratch &sc) {
+    if (n <= WC_NPY_BUFSIZE) return pairwise_tree_wave(f, n, lane, sc);
+    double res = 0.0;
+    for (int64_t off = 0; off < n; off += WC_NPY_BUFSIZE) {
+        const int64_t m = n - off < WC_NPY_BUFSIZE ? n - off : WC_NPY_BUFSIZE;
+        res = res + pairwise_tree_wave([&](int64_t i) { return f(off + i); }, m, lane, sc);
+    }
+    return res;
 }
 
 // Small per-lane value stack addressed by a wave-uniform index; the switch keeps the
