@@ -64,3 +64,27 @@ def test_hip_multi_rank_on_one_gpu(tmp_path, world, order, mode):
         got = np.load(str(tmp_path / ("rank%d.npz" % r)))
         assert np.array_equal(got["idx"], want_i), r
         assert np.array_equal(got["dst"], want_d), r
+
+
+@pytest.mark.parametrize("world,mode", [(2, "tiles"), (3, "rows"), (3, "tiles")])
+def test_hip_multi_rank_ragged_layout(tmp_path, world, mode):
+    """A layout with one-bin chromosomes at both ends (their rows sum pairwise even in the
+    Fortran-ordered file), an empty chromosome and row bands that cut through
+    chromosomes; fewer candidates than k for some rows."""
+    import torch.multiprocessing as mp
+    rng = np.random.RandomState(8)
+    bins = np.array([1, 130, 0, 97, 2, 1], dtype=np.int64)
+    B = int(bins.sum())
+    data = 1.0 + 0.03 * rng.standard_normal((B, 33))
+    data[3] = data[200]
+    k = 120
+    path_in = str(tmp_path / "in.npz")
+    np.savez(path_in, data=data, bins=bins, k=k, order=1)
+    mp.get_context("spawn")
+    mp.spawn(_worker, args=(world, _free_port(), path_in, str(tmp_path), mode), nprocs=world, join=True)
+    with np.errstate(all="ignore"):
+        want_i, want_d = wo.get_reference(np.asfortranarray(data), bins, np.cumsum(bins), k, 1, 1, fast=True)
+    for r in range(world):
+        got = np.load(str(tmp_path / ("rank%d.npz" % r)))
+        assert np.array_equal(got["idx"], want_i), r
+        assert np.array_equal(got["dst"].view(np.int64), np.asarray(want_d).view(np.int64)), r
