@@ -6,6 +6,8 @@ ratios and effect sizes within 1e-9 relative (float64 everywhere; the only
 non-bit-exact step is the PCA projection, whose BLAS summation order is not
 reproducible), stated next to each assertion.
 """
+import warnings
+
 import numpy as np
 import pytest
 
@@ -51,10 +53,21 @@ def reference(wt, cfg1):
 
 
 def test_cutoff(wt, cfg1, reference):
-    # float64 reduction in a different (deterministic) order than numpy's pairwise sum: 1e-12 relative
-    assert np.isclose(reference.cutoff, float(cfg1["cutoff"]), rtol=1e-12, atol=0)
+    # the moments are taken in numpy's order (row-major compaction, pairwise within 8192-element
+    # pieces, pieces left to right): the cutoff is the reference's double
+    assert reference.cutoff == float(cfg1["cutoff"])
     cut, _ = wt.getOptimalCutoff(cfg1["ref_distances"], 3)
-    assert np.isclose(cut, float(cfg1["cutoff"]), rtol=1e-12, atol=0)
+    assert cut == float(cfg1["cutoff"])
+    rng = np.random.RandomState(2)
+    for shape in [(1, 1), (3, 7), (90, 100), (700, 100), (8192, 1), (8193, 1), (3000, 37)]:
+        d = np.sort(rng.gamma(3.0, 0.1, size=shape), axis=1)
+        d[rng.rand(*shape) < 0.01] = 1e10                 # padding entries of short lists
+        for repeats in (1, 3):
+            got, _ = wt.getOptimalCutoff(d, repeats)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")        # a one-element set clips itself away: numpy warns
+                want, _ = wo.get_optimal_cutoff(d, repeats)
+            assert (np.isnan(got) and np.isnan(want)) or got == want, (shape, repeats)
 
 
 @pytest.mark.parametrize("name", NAMES)

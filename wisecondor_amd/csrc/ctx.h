@@ -40,7 +40,7 @@ struct TestState {
     wc::DevBuf res_z, res_r, cwz, calls, n_calls;
     // Stouffer search
     wc::DevBuf zs, rs2, ns2, sub, tmin, tmax, prefix, reg_abs, reg_flag, rs, jobs_a, jobs_b, job_cnt, partial, job_res, hot, cand, cand_cnt;
-    wc::DevBuf seg, seg_cnt, out_val, out_x, out_y, out_n, whole, effect, misc, misc2, reduce_tmp, win_bits, bit_off, pairs_a, pairs_b;
+    wc::DevBuf seg, seg_cnt, out_val, out_x, out_y, out_n, whole, effect, misc, misc2, reduce_tmp, win_bits, bit_off, pairs_a, pairs_b, cut_vals;
     int64_t rs_len = 0;
     int64_t last_segs = 0;
 };
@@ -92,6 +92,6 @@ struct wc_ctx {
                 &ts.sel, &ts.res_z, &ts.res_r, &ts.cwz, &ts.calls, &ts.n_calls, &ts.zs, &ts.rs2, &ts.ns2, &ts.sub, &ts.tmin, &ts.tmax, &ts.prefix, &ts.reg_abs,
                 &ts.reg_flag, &ts.rs, &ts.jobs_a, &ts.jobs_b, &ts.job_cnt, &ts.partial, &ts.job_res, &ts.hot,
                 &ts.cand, &ts.cand_cnt, &ts.seg, &ts.seg_cnt, &ts.out_val, &ts.out_x, &ts.out_y, &ts.out_n,
-                &ts.whole, &ts.effect, &ts.misc, &ts.misc2, &ts.reduce_tmp, &ts.win_bits, &ts.bit_off, &ts.pairs_a, &ts.pairs_b};
+                &ts.whole, &ts.effect, &ts.misc, &ts.misc2, &ts.reduce_tmp, &ts.win_bits, &ts.bit_off, &ts.pairs_a, &ts.pairs_b, &ts.cut_vals};
     }
 };

@@ -37,61 +37,112 @@ struct Seg { double val; int region, x, y, pad; };
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ------------------------------------------------------------- reductions ----
-// mode 0: sum and count of d < cutoff; mode 1: sum of (d-centre)^2 over d < cutoff
-__global__ __launch_bounds__(256) void k_moments1(const double *__restrict__ d, int64_t n, double cutoff,
-                                                  double centre, int mode, double *__restrict__ part) {
-    __shared__ double ss[256], sc[256];
-    double s = 0.0, c = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        double v = d[i];
-        if (v < cutoff) {
-            if (mode == 0) s += v; else { double t = v - centre; s += t * t; }
-            c += 1.0;
-        }
-    }
-    ss[threadIdx.x] = s; sc[threadIdx.x] = c;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) { ss[threadIdx.x] += ss[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { part[2 * blockIdx.x] = ss[0]; part[2 * blockIdx.x + 1] = sc[0]; }
+// getOptimalCutoff (wisetools.py:328-336): three rounds of mean + 3 sd over distances[mask].
+// The cutoff decides list membership by `distance < cutoff`, so the moments are taken in
+// numpy's own order rather than "some deterministic order": distances[mask] is the row-major
+// compaction of the kept values; np.mean / np.std reduce it with add.reduce, i.e. pairwise
+// within pieces of 8192 elements, the piece sums accumulated left to right (np.std: subtract
+// the mean, multiply the difference with itself, add.reduce, divide, sqrt).
+__global__ void k_cut_count(const double *__restrict__ d, int64_t rows, int k, double cutoff, int *__restrict__ cnt) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    int c = 0;
+    for (int j = 0; j < k; ++j) c += d[r * k + j] < cutoff;
+    cnt[r] = c;
 }
 
-__global__ __launch_bounds__(256) void k_moments2(const double *__restrict__ part, int nparts,
-                                                  double *__restrict__ out) {
-    __shared__ double ss[256], sc[256];
-    double s = 0.0, c = 0.0;
-    for (int i = threadIdx.x; i < nparts; i += 256) { s += part[2 * i]; c += part[2 * i + 1]; }
-    ss[threadIdx.x] = s; sc[threadIdx.x] = c;
+// exclusive scan of the per-row counts, one workgroup (rows <= a few hundred thousand)
+__global__ __launch_bounds__(1024) void k_cut_scan(const int *__restrict__ cnt, int64_t rows, long long *__restrict__ off) {
+    __shared__ long long part[1024];
+    const int tid = threadIdx.x;
+    const int64_t per = (rows + 1023) / 1024, lo = tid * per, hi = lo + per < rows ? lo + per : rows;
+    long long s = 0;
+    for (int64_t r = lo; r < hi; ++r) s += cnt[r];
+    part[tid] = s;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) { ss[threadIdx.x] += ss[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
-        __syncthreads();
+    if (tid == 0) {
+        long long run = 0;
+        for (int t = 0; t < 1024; ++t) { const long long v = part[t]; part[t] = run; run += v; }
+        off[rows] = run;
     }
-    if (threadIdx.x == 0) { out[0] = ss[0]; out[1] = sc[0]; }
+    __syncthreads();
+    long long run = part[tid];
+    for (int64_t r = lo; r < hi; ++r) { off[r] = run; run += cnt[r]; }
 }
 
-// getOptimalCutoff (wisetools.py:328-336) with the reductions on the device.
-int device_cutoff(wc_ctx *ctx, const double *d_dev, int64_t count, int repeats, hipStream_t stream, double *out) {
+__global__ void k_cut_compact(const double *__restrict__ d, int64_t rows, int k, double cutoff,
+                              const long long *__restrict__ off, double *__restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    long long at = off[r];
+    for (int j = 0; j < k; ++j) {
+        const double v = d[r * k + j];
+        if (v < cutoff) out[at++] = v;
+    }
+}
+
+// one wave per 8192-element piece: numpy's pairwise tree of the piece (mode 1: of (v - mean)^2)
+__global__ __launch_bounds__(64) void k_cut_pieces(const double *__restrict__ v, const long long *__restrict__ n_ptr,
+                                                   double mean, int mode, double *__restrict__ piece) {
+    __shared__ wc::PwWaveScratch sc;
+    const long long n = *n_ptr, lo = (long long)blockIdx.x * WC_NPY_BUFSIZE;
+    if (lo >= n) return;
+    const long long m = n - lo < WC_NPY_BUFSIZE ? n - lo : WC_NPY_BUFSIZE;
+    const double *p = v + lo;
+    const double s = wc::pairwise_tree_wave(
+        [&](int64_t i) {
+            const double x = p[i];
+            if (mode == 0) return x;
+            const double t = x - mean;
+            return t * t;
+        },
+        (int64_t)m, (int)threadIdx.x, sc);
+    if (threadIdx.x == 0) piece[blockIdx.x] = s;
+}
+
+__global__ void k_cut_fold(const double *__restrict__ piece, const long long *__restrict__ n_ptr, double *__restrict__ out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const long long n = *n_ptr, pieces = (n + WC_NPY_BUFSIZE - 1) / WC_NPY_BUFSIZE;
+    double res = 0.0;
+    if (pieces == 1) res = piece[0];
+    else for (long long c = 0; c < pieces; ++c) res = res + piece[c];
+    out[0] = res;
+    out[1] = (double)n;
+}
+
+int device_cutoff(wc_ctx *ctx, const double *d_dev, int64_t count, int repeats, hipStream_t stream, double *out,
+                  int k = 1) {
     int rc;
-    const int G = 1024;
-    if ((rc = ctx->ts.reduce_tmp.reserve(sizeof(double) * (2 * G + 2)))) return rc;
-    double *part = ctx->ts.reduce_tmp.as<double>();
-    double *res = part + 2 * G;
+    WC_CHECK(k > 0 && count % k == 0, WC_E_ARG, "cutoff: distances are not [rows, k]");
+    const int64_t rows = count / k;
+    const int64_t max_pieces = count / WC_NPY_BUFSIZE + 1;
+    TestState &ts = ctx->ts;
+    if ((rc = ts.reduce_tmp.reserve(sizeof(double) * (max_pieces + 4) + sizeof(long long) * (rows + 2) + sizeof(int) * rows)))
+        return rc;
+    if ((rc = ts.cut_vals.reserve(sizeof(double) * count))) return rc;
+    double *piece = ts.reduce_tmp.as<double>();
+    double *res = piece + max_pieces;                              // {sum, n}
+    long long *off = (long long *)(res + 4);
+    int *cnt = (int *)(off + rows + 2);
     double cutoff = INFINITY;
+    const unsigned gr = (unsigned)cdiv(rows, 256);
     for (int it = 0; it < repeats; ++it) {
         double h[2];
-        hipLaunchKernelGGL(k_moments1, dim3(G), dim3(256), 0, stream, d_dev, count, cutoff, 0.0, 0, part);
-        hipLaunchKernelGGL(k_moments2, dim3(1), dim3(256), 0, stream, (const double *)part, G, res);
-        WC_HIP(hipMemcpyAsync(h, res, sizeof(h), hipMemcpyDeviceToHost, stream));
-        WC_HIP(hipStreamSynchronize(stream));
-        double mean = h[0] / h[1];
-        hipLaunchKernelGGL(k_moments1, dim3(G), dim3(256), 0, stream, d_dev, count, cutoff, mean, 1, part);
-        hipLaunchKernelGGL(k_moments2, dim3(1), dim3(256), 0, stream, (const double *)part, G, res);
-        WC_HIP(hipMemcpyAsync(h, res, sizeof(h), hipMemcpyDeviceToHost, stream));
-        WC_HIP(hipStreamSynchronize(stream));
-        double sd = sqrt(h[0] / h[1]);
+        hipLaunchKernelGGL(k_cut_count, dim3(gr), dim3(256), 0, stream, d_dev, rows, k, cutoff, cnt);
+        hipLaunchKernelGGL(k_cut_scan, dim3(1), dim3(1024), 0, stream, (const int *)cnt, rows, off);
+        hipLaunchKernelGGL(k_cut_compact, dim3(gr), dim3(256), 0, stream, d_dev, rows, k, cutoff,
+                           (const long long *)off, ts.cut_vals.as<double>());
+        double mean = 0.0;
+        for (int mode = 0; mode < 2; ++mode) {
+            hipLaunchKernelGGL(k_cut_pieces, dim3((unsigned)max_pieces), dim3(64), 0, stream,
+                               (const double *)ts.cut_vals.as<double>(), (const long long *)(off + rows), mean, mode, piece);
+            hipLaunchKernelGGL(k_cut_fold, dim3(1), dim3(1), 0, stream, (const double *)piece,
+                               (const long long *)(off + rows), res);
+            WC_HIP(hipMemcpyAsync(h, res, sizeof(h), hipMemcpyDeviceToHost, stream));
+            WC_HIP(hipStreamSynchronize(stream));
+            if (mode == 0) mean = h[0] / h[1];
+        }
+        const double sd = sqrt(h[0] / h[1]);
         cutoff = mean + 3 * sd;
     }
     *out = cutoff;
@@ -2062,7 +2113,7 @@ wc_reference *wc_reference_create(wc_ctx *ctx, const int32_t *indexes, const dou
     }
     if (cutoff_override) {
         ref->cutoff = *cutoff_override;
-    } else if (device_cutoff(ctx, ctx->tmp_a.as<double>(), nk, cutoff_repeats, nullptr, &ref->cutoff) != WC_OK) {
+    } else if (device_cutoff(ctx, ctx->tmp_a.as<double>(), nk, cutoff_repeats, nullptr, &ref->cutoff, k) != WC_OK) {
         return fail(ref);
     }
     hipLaunchKernelGGL(k_ref_lists, dim3((unsigned)cdiv(n_bins, 128)), dim3(128), 0, nullptr,
