@@ -325,7 +325,7 @@ def main():
             rows_here = B / world
             fbytes = rows_here * k * S * 8.0 + rows_here * k * 12.0
             roof_finish = {"kernel": "k_finish (per row: k-th key, candidate compaction, float64 re-score in numpy "
-                                     "order, counting order; the two exact-fallback launches that follow are idle here)",
+                                     "order, counting order; events around this kernel alone, the exact-path launches come after)",
                            "bound": "hbm", "achieved": fbytes / (finish_ms * 1e-3) / 1e9, "peak": 8000.0,
                            "unit": "GB/s", "frac": fbytes / (finish_ms * 1e-3) / 8.0e12, "traffic": finish_traffic,
                            "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_traffic.json): the "

@@ -114,6 +114,12 @@ int wc_newref_import_lists_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int
                                int64_t src_cap, const int32_t *src_cnt, const uint64_t *src_list);
 int wc_newref_finish_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end,
                          int32_t *idx_out, double *dist_out);
+/* stage D in its two halves, for callers that time them apart: the per-row fast path, then
+ * the exact path for the rows it handed over (same arguments; finish == rescore + fallback) */
+int wc_newref_rescore_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end,
+                          int32_t *idx_out, double *dist_out);
+int wc_newref_fallback_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end,
+                           int32_t *idx_out, double *dist_out);
 
 /*
  * newref prep (upstream of the hot path): toNumpyArray's

@@ -36,6 +36,8 @@ SIGNATURES = {
     "wc_newref_export_lists_dev": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "wc_newref_import_lists_dev": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "wc_newref_finish_dev": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "wc_newref_rescore_dev": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "wc_newref_fallback_dev": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "wc_newref_prep_gram": (_i32, [_vp, _vp, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
     "wc_newref_prep_finish": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "wc_newref_prep": (_i32, [_vp, _vp, _i64, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -1747,8 +1747,10 @@ int wc_newref_collect_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t
     return WC_OK;
 }
 
-int wc_newref_finish_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t row_end, int32_t *idx_out,
-                         double *dist_out) {
+// stage D in two halves: `which` bit 0 = the per-row fast path (k_finish), bit 1 = the exact path
+// for the rows it handed over (k_fallback_fill + k_fallback; idle launches when there are none)
+static int newref_finish_part(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t row_end, int32_t *idx_out,
+                              double *dist_out, int which) {
     WC_CHECK(ctx && ctx->nr.prepared, WC_E_ARG, "newref: prepare has not run");
     NewrefState &st = ctx->nr;
     WC_CHECK(row_begin >= 0 && row_begin <= row_end && row_end <= st.n_bins, WC_E_ARG, "newref: bad row range");
@@ -1757,7 +1759,7 @@ int wc_newref_finish_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t 
     hipStream_t stream = (hipStream_t)stream_;
     int rc;
     if ((rc = st.fb_scratch.reserve(sizeof(uint64_t) * FB_BLOCKS * st.bins_pad))) return rc;
-    WC_HIP(hipMemsetAsync(st.fb_count.p, 0, sizeof(int) * 4, stream));
+    if (which & 1) WC_HIP(hipMemsetAsync(st.fb_count.p, 0, sizeof(int) * 4, stream));
     FinishArgs a{};
     a.X = st.corrected;
     a.B = st.n_bins;
@@ -1786,7 +1788,7 @@ int wc_newref_finish_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t 
     a.xs_in_lds = st.n_samples <= 2048;
     a.pw_prog = st.pw_prog.as<int2>();
     a.pw_leaves = st.pw_leaves;
-    {
+    if (which & 1) {
         const bool seq = st.sum_order == WC_SUM_SEQUENTIAL || st.n_samples < 8;
         const char *e = getenv("WC_FINISH_THREADS");
         const int nt = e ? atoi(e) : 128;   // 128 threads per row measured faster at every size tried
@@ -1800,12 +1802,29 @@ int wc_newref_finish_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t 
             else hipLaunchKernelGGL((k_finish<false, 256>), grid, dim3(256), dyn, stream, a);
         }
     }
-    hipLaunchKernelGGL(k_fallback_fill, dim3(FB_BLOCKS), dim3(256), 0, stream, a,
-                       st.fb_scratch.as<unsigned long long>(), st.bins_pad);
-    hipLaunchKernelGGL(k_fallback, dim3(FB_BLOCKS), dim3(256), 0, stream, a,
-                       st.fb_scratch.as<unsigned long long>(), st.bins_pad);
+    if (which & 2) {
+        hipLaunchKernelGGL(k_fallback_fill, dim3(FB_BLOCKS), dim3(256), 0, stream, a,
+                           st.fb_scratch.as<unsigned long long>(), st.bins_pad);
+        hipLaunchKernelGGL(k_fallback, dim3(FB_BLOCKS), dim3(256), 0, stream, a,
+                           st.fb_scratch.as<unsigned long long>(), st.bins_pad);
+    }
     WC_HIP(hipGetLastError());
     return WC_OK;
+}
+
+int wc_newref_finish_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end, int32_t *idx_out,
+                         double *dist_out) {
+    return newref_finish_part(ctx, stream, row_begin, row_end, idx_out, dist_out, 3);
+}
+
+int wc_newref_rescore_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end, int32_t *idx_out,
+                          double *dist_out) {
+    return newref_finish_part(ctx, stream, row_begin, row_end, idx_out, dist_out, 1);
+}
+
+int wc_newref_fallback_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end, int32_t *idx_out,
+                           double *dist_out) {
+    return newref_finish_part(ctx, stream, row_begin, row_end, idx_out, dist_out, 2);
 }
 
 int wc_get_reference_dev(wc_ctx *ctx, void *stream, const double *corrected, int64_t n_bins, int64_t n_samples,

@@ -72,8 +72,14 @@ class HipStages(object):
         _lib.check(self.lib.wc_newref_import_lists_dev(self.ctx, self._stream(), rb, re, cap, cnt.data_ptr(),
                                                        lst.data_ptr()))
 
-    def finish(self, rb, re, idx, dst):
-        _lib.check(self.lib.wc_newref_finish_dev(self.ctx, self._stream(), rb, re, idx.data_ptr(), dst.data_ptr()))
+    def finish(self, rb, re, idx, dst, mid_event=None):
+        """mid_event: torch event recorded between the per-row fast path and the exact path."""
+        if mid_event is None:
+            _lib.check(self.lib.wc_newref_finish_dev(self.ctx, self._stream(), rb, re, idx.data_ptr(), dst.data_ptr()))
+            return
+        _lib.check(self.lib.wc_newref_rescore_dev(self.ctx, self._stream(), rb, re, idx.data_ptr(), dst.data_ptr()))
+        mid_event.record()
+        _lib.check(self.lib.wc_newref_fallback_dev(self.ctx, self._stream(), rb, re, idx.data_ptr(), dst.data_ptr()))
 
     def empty(self, shape, dtype):
         return self.torch.empty(shape, dtype=dtype, device=self.device)
@@ -217,8 +223,14 @@ class NewrefJob(object):
         dst = self.torch.cat([self.dst_all[r][:e - b] for r, (b, e) in enumerate(self.ranges)])
         return idx, dst
 
+    def _finish(self, rb, re, idx, dst, events):
+        if events and len(events) > 2:
+            self.st.finish(rb, re, idx, dst, mid_event=events[2])
+        else:
+            self.st.finish(rb, re, idx, dst)
+
     def run(self, collect_events=None):
-        """collect_events: (before collect, after collect[, after finish]) torch events on the launch stream."""
+        """collect_events: (before collect, after collect[, after k_finish -- before the exact-path launches]) torch events on the launch stream."""
         st = self.st
         st.prepare()
         if self.world == 1:
@@ -228,9 +240,7 @@ class NewrefJob(object):
             st.collect(0, self.n_bins, 0, 1)
             if collect_events:
                 collect_events[1].record()
-            st.finish(0, self.n_bins, self.idx, self.dst)
-            if collect_events and len(collect_events) > 2:
-                collect_events[2].record()
+            self._finish(0, self.n_bins, self.idx, self.dst, collect_events)
             return self.idx, self.dst
 
         rb, re = self.ranges[self.rank]
@@ -244,9 +254,7 @@ class NewrefJob(object):
             st.collect(rb, re, 0, 1)
             if collect_events:
                 collect_events[1].record()
-            st.finish(rb, re, self.idx_all[self.rank], self.dst_all[self.rank])
-            if collect_events and len(collect_events) > 2:
-                collect_events[2].record()
+            self._finish(rb, re, self.idx_all[self.rank], self.dst_all[self.rank], collect_events)
             return self._gather_results()
 
         if not self.buffers_ready:
