@@ -236,8 +236,8 @@ def test_repeats_heavy_flagging(wt, n_samples, k, seed):
 def test_segments_random(wt, seed):
     """Stouffer segmentation of random regions against the oracle's triangle walk: lengths around
     the block sizes of the search (64 rows, 32-entry end blocks), planted events of both signs,
-    rounded values (exact ties between windows), thresholds from 'everything is a call' to
-    'nothing is'; coordinates and window values bit for bit."""
+    rounded values (exact ties between windows), NaN / inf entries, thresholds from 'everything
+    is a call' to 'nothing is'; coordinates and window values bit for bit."""
     rng = np.random.RandomState(9000 + seed)
     regions = []
     for _ in range(12):
@@ -251,13 +251,16 @@ def test_segments_random(wt, seed):
             z = np.round(z)
         if rng.rand() < 0.1:
             z[:] = rng.choice([0.0, 0.5, -2.0])
+        if rng.rand() < 0.15:          # non-finite values: numpy's NaN-first argmax decides the calls
+            z[rng.randint(0, n)] = rng.choice([np.nan, np.inf, -np.inf])
         regions.append(z)
     thr = float(rng.choice([0.5, 2.0, 3.5, 5.0, 8.0]))
     min_search = 3
     whole, segs = wt.stouffer_segments(regions, thr, min_search)
     for z, w, s in zip(regions, whole, segs):
-        tri = wo.fill_tri(z)
-        want = wo.segment_tri(tri, z.shape[0], thr, min_search)
+        with np.errstate(all="ignore"):
+            tri = wo.fill_tri(z)
+            want = wo.segment_tri(tri, z.shape[0], thr, min_search)
         assert [(x, y) for _, (x, y) in s] == [(x, y) for _, (x, y) in want], (seed, z.shape, thr)
         assert same_bits([v for v, _ in s], [v for v, _ in want]), (seed, z.shape, thr)
         assert same_bits([w], [tri[z.shape[0] - 1]]), (seed, z.shape)
