@@ -35,6 +35,19 @@ def test_golden_kernel_cases(golden, wt, name):
             assert same_bits(dst, g["%s_dst_%d_%d" % (name, part, parts)]), (name, part, parts)
 
 
+def test_golden_layout_cases(golden, wt):
+    """Single-row concatenate pieces, pinned on the reference's own output."""
+    g = golden("layout_cases.npz")
+    for name in g["newref_names"]:
+        data = g[name + "_data"]
+        if bool(g[name + "_fortran"]):
+            data = np.asfortranarray(data)
+        bins = g[name + "_bins"]
+        idx, dst = wt.getReference(data, bins, np.cumsum(bins), 3, 1, 1)
+        assert np.array_equal(idx, g[name + "_idx"]), name
+        assert same_bits(dst, g[name + "_dst"]), name
+
+
 def test_golden_cfg1_prep_seam(golden, wt):
     g = golden("cfg1_pipeline.npz")
     data = g["prep_correctedData"]

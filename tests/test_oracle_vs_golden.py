@@ -199,3 +199,26 @@ def test_cfg1_mineffectsize(golden, name):
     assert np.array_equal(got[:, :3], want[:, :3])
     assert np.allclose(got[:, 3:], want[:, 3:], rtol=1e-10)
     assert np.allclose(out["results_cwz"], g["eff_%s_results_cwz" % name], rtol=1e-10, atol=1e-10)
+
+
+def test_layout_dependent_sums(golden):
+    """Pinned on the reference itself: single-row concatenate pieces (C-ordered chromData from a
+    Fortran-ordered file) and sums beyond numpy's 8192-element buffer."""
+    g = golden("layout_cases.npz")
+    for name in g["newref_names"]:
+        data = g[name + "_data"]
+        if bool(g[name + "_fortran"]):
+            data = np.asfortranarray(data)
+        bins = g[name + "_bins"]
+        for fast in (False, True):
+            idx, dst = wo.get_reference(data, bins, np.cumsum(bins), 3, 1, 1, fast=fast)
+            assert np.array_equal(np.asarray(idx).reshape(-1, 3), g[name + "_idx"]), name
+            assert np.array_equal(np.asarray(dst, dtype=np.float64).reshape(-1, 3).view(np.int64),
+                                  g[name + "_dst"].view(np.int64)), name
+    z = g["long_z"]
+    assert wo.pairwise_sum(z) / np.sqrt(len(z)) == float(g["long_whole"])
+    assert len(g["long_seg"]) >= 1
+    for v, x, y in g["long_seg"]:
+        x, y = int(x), int(y)
+        assert wo.pairwise_sum(z[x:y + 1]) / np.sqrt(y - x + 1) == v
+    assert max(int(y) - int(x) + 1 for _, x, y in g["long_seg"]) > 8192

@@ -119,6 +119,18 @@ def test_segments_golden(wt, golden):
         assert same_bits([v for v, _ in s], [v for v, _ in want])
 
 
+def test_segments_golden_long_region(wt, golden):
+    """8400 bins, one call longer than numpy's 8192-element buffer: the reference's own output."""
+    g = golden("layout_cases.npz")
+    z = g["long_z"]
+    whole, segs = wt.stouffer_segments([z], float(g["long_thr"]), 3)
+    want = g["long_seg"]
+    got = np.array([[v, x, y] for v, (x, y) in segs[0]], dtype=np.float64).reshape(-1, 3)
+    assert np.array_equal(got[:, 1:], want[:, 1:])
+    assert same_bits(got[:, 0], want[:, 0])
+    assert same_bits([whole[0]], [g["long_whole"]])
+
+
 def test_triarr_mirror(wt, golden):
     from wisecondor_amd.triarray import TriArr
     g = golden("segments.npz")

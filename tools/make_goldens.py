@@ -102,6 +102,46 @@ def newref_cases(wt):
     return cases
 
 
+# -------------------------------------------------- layout-dependent sums ----
+def layout_cases(wt):
+    """Two places where numpy's summation order follows the memory layout / the length of the run,
+    pinned on the reference itself (found by the randomised sweeps of round 1):
+      * getReference on Fortran-ordered data when the rows before and after a chromosome are
+        single-row pieces (np.concatenate drops the Fortran order: wisetools.py:386-387);
+      * fillTri / segmentTri on a region above 8192 bins (np.sum runs in buffer-sized pieces)."""
+    out = {}
+    rng = np.random.RandomState(4242)
+    names = []
+    for name, bins, order in (("p121F", [1, 2, 1], "F"), ("p12F", [1, 2], "F"), ("p1_30_1F", [1, 30, 1], "F"),
+                              ("p11F", [1, 1], "F"), ("p23F", [2, 3], "F"), ("p12C", [1, 2], "C")):
+        bins = np.asarray(bins, dtype=np.int64)
+        data = 1.0 + 0.03 * rng.standard_normal((int(bins.sum()), 129))
+        if order == "F":
+            data = np.asfortranarray(data)
+        with quiet(), np.errstate(all="ignore"):
+            idx, dst = wt.getReference(data, list(bins), list(np.cumsum(bins)), 3, 1, 1)
+        out[name + "_data"] = np.ascontiguousarray(data)
+        out[name + "_fortran"] = np.bool_(order == "F")
+        out[name + "_bins"] = bins
+        out[name + "_idx"] = np.asarray(idx, dtype=np.int32).reshape(-1, 3)
+        out[name + "_dst"] = np.asarray(dst, dtype=np.float64).reshape(-1, 3)
+        names.append(name)
+    out["newref_names"] = np.array(names)
+    # one region of 8400 bins with a call longer than numpy's 8192-element buffer (takes minutes)
+    n = 8400
+    z = 0.5 * rng.standard_normal(n)
+    z += 0.3                              # the whole region is one call, a few bins short of either end at most
+    with np.errstate(all="ignore"):
+        tri = wt.fillTri(z)
+        segs = tri.segmentTri(6.0, 3)
+        whole = tri.getValue(0, n - 1)
+    out["long_z"] = z
+    out["long_thr"] = np.float64(6.0)
+    out["long_whole"] = np.float64(whole)
+    out["long_seg"] = np.array([[v, x, y] for v, (x, y) in segs], dtype=np.float64).reshape(-1, 3)
+    return out
+
+
 # ------------------------------------------------------------- segments ----
 def segment_cases(wt):
     """fillTri + TriArr.segmentTri goldens (wisetools.py:466-472, triarray.py:59-84)."""
@@ -327,9 +367,16 @@ def scale_cases(wt):
 
 
 def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None, help="regenerate one file only: layout")
+    args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     wt, wc, _tri = ref_loader.load(full_svd=True)
     save = ref_loader.np.savez_compressed
+    if args.only in (None, "layout"):
+        save(os.path.join(GOLD, "layout_cases.npz"), **layout_cases(wt))
+    if args.only is not None:
+        return
     save(os.path.join(GOLD, "newref_kernel.npz"), **newref_cases(wt))
     save(os.path.join(GOLD, "segments.npz"), **segment_cases(wt))
     save(os.path.join(GOLD, "scale.npz"), **scale_cases(wt))
