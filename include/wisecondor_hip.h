@@ -246,6 +246,19 @@ int wc_test_batch_dev(wc_ctx *ctx, void *stream, const wc_reference *ref, const 
                       double *results_z, double *results_r, double *results_cwz, double *calls,
                       int32_t *n_calls, double *asdef);
 
+/*
+ * Optional stage timing of wc_test_batch_dev for the measurement harness (bench.py): with
+ * profiling enabled every call records HIP events between its stages on the launch stream.
+ * wc_test_profile_read synchronises the device and returns, for the LAST call, milliseconds of
+ *   [0] prepare (toNumpyRefFormat + applyPCA)   [1] z-score repeats (repeatTest)
+ *   [2] reshaping, inflation, cleaning          [3] Stouffer segmentation (fillTri + segmentTri)
+ *   [4] call mapping and outputs                [5] of [3]: the certificate + window-search launches
+ * and the work those launches executed: [6] windows evaluated by the search kernel (4 float64
+ * operations each), [7] window / bound evaluations of the quiet-job certificate.
+ */
+int wc_test_profile(wc_ctx *ctx, int enable);
+int wc_test_profile_read(wc_ctx *ctx, double out[8]);
+
 #ifdef __cplusplus
 }
 #endif

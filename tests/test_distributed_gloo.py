@@ -118,7 +118,8 @@ def _worker(rank, world, port, X, bins, k, out_dir, mode):
         job = NewrefJob(None, None, bins, k, 0, rank=rank, world=world, stages=st, dist=dist, mode=mode)
         for _ in range(2):          # second run reuses the exchange buffers
             idx, dst = job.run()
-        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), idx=idx.numpy(), dst=dst.numpy())
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), idx=idx.numpy(), dst=dst.numpy(), mode=job.mode,
+                 measured=sorted((job.calibration or {}).keys()))
     finally:
         dist.destroy_process_group()
 
@@ -134,7 +135,12 @@ def test_multi_rank_equals_single_rank_and_oracle(tmp_path, world, mode):
     one_i, one_d = NewrefJob(None, None, bins, k, 0, rank=0, world=1, stages=st).run()
     want_i, want_d = wo.get_reference(X, bins, np.cumsum(bins), k, 1, 1, fast=True)
     assert np.array_equal(one_i.numpy(), want_i) and np.array_equal(one_d.numpy(), want_d)
+    modes = set()
     for r in range(world):
         got = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
         assert np.array_equal(got["idx"], want_i), r
         assert np.array_equal(got["dst"], want_d), r
+        modes.add(str(got["mode"]))
+        if mode is None:        # the shard mode was measured (both modes timed), not assumed
+            assert list(got["measured"]) == ["rows", "tiles"]
+    assert len(modes) == 1 and modes <= {"tiles", "rows"}      # every rank reached the same decision

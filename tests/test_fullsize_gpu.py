@@ -53,16 +53,11 @@ def test_batched_test_50kb_equals_single_samples(wt):
     binsize = 50000
     profile = synth.bin_profile(binsize)
     refs = [synth.make_sample(profile, seed=i) for i in range(40)]
-    import contextlib
-    import io
-    with contextlib.redirect_stdout(io.StringIO()):
-        masked, chrom_bins, mask = wt.toNumpyArray(refs)
-        corrected, pca = wt.trainPCA(masked)
-    offs = np.concatenate([[0], np.cumsum(chrom_bins)])
-    masked_bins = np.array([int(mask[offs[i]:offs[i + 1]].sum()) for i in range(22)], dtype=np.int64)
+    _, chrom_bins, mask, corrected, comps, mean, masked_bins = wt.prepReference(refs)
+    masked_bins = np.asarray(masked_bins, dtype=np.int64)
     idx, dst = wt.getReference(corrected, masked_bins, np.cumsum(masked_bins), 100, 1, 1)
-    reference = wt.Reference(idx, dst, np.asarray(chrom_bins, dtype=np.int64), masked_bins, mask, pca.mean_,
-                             pca.components_, binsize=binsize, device=0)
+    reference = wt.Reference(idx, dst, np.asarray(chrom_bins, dtype=np.int64), masked_bins, mask, mean,
+                             comps, binsize=binsize, device=0)
     thr = float(zThreshold([int(v) for v in masked_bins], 1000, None))
     tests = []
     for i in range(24):

@@ -99,20 +99,6 @@ def test_scale_and_counts(golden):
     assert np.array_equal(dense[0], dense[1])
 
 
-def test_prep_host_path(golden):
-    from wisecondor_amd import wisetools as wt
-    g = golden("cfg1_pipeline.npz")
-    offs = np.concatenate([[0], np.cumsum(g["sample_chrom_lengths"])])
-    samples = [{k: row[offs[i]:offs[i + 1]] for i, k in enumerate(KEYS)} for row in g["ref_samples"]]
-    masked, bins, mask = wt.toNumpyArray(samples)
-    assert np.array_equal(mask, g["prep_mask"]) and list(bins) == list(g["prep_chromosomeBins"])
-    assert np.array_equal(masked, g["prep_maskedData"])
-    corrected, pca = wt.trainPCA(masked)
-    assert corrected.flags["F_CONTIGUOUS"] and not corrected.flags["C_CONTIGUOUS"]
-    assert np.allclose(corrected, g["prep_correctedData"], rtol=1e-11, atol=0)
-    assert np.allclose(pca.components_, g["prep_pca_components"], rtol=0, atol=1e-10)
-
-
 def test_cli_surface():
     from wisecondor_amd import wisecondor as cli
     p = cli.buildParser()
@@ -145,17 +131,78 @@ def test_shard_helpers():
     assert [b - a for a, b in got] == [3, 3, 2, 2]
 
 
-def test_shard_mode_choice():
-    """Small jobs shard by row bands (no exchange), the 600 x 50 kb job by symmetric tiles."""
+def test_shard_mode_override(monkeypatch):
+    """WC_NEWREF_SHARD pins the multi-GPU shard mode; otherwise it is measured per job
+    (NewrefJob.calibrate, exercised in tests/test_distributed_gloo.py)."""
     from wisecondor_amd import distributed as d
-    from wisecondor_amd import synth
-    bins250 = synth.chrom_bins(250000)
-    bins50 = synth.chrom_bins(50000)
-    assert d.choose_shard_mode(int(sum(bins250)), 100, bins250, 8, 1024) == "rows"
-    assert d.choose_shard_mode(int(sum(bins250)), 100, bins250, 2, 1024) == "rows"
-    # 600 x 50 kb: the exchange only pays while a rank's share of the tile work is long (2 ranks)
-    assert d.choose_shard_mode(int(sum(bins50)), 600, bins50, 2, 1024) == "tiles"
-    assert d.choose_shard_mode(int(sum(bins50)), 600, bins50, 8, 1024) == "rows"
-    assert d.choose_shard_mode(int(sum(bins50)), 4800, bins50, 8, 1024) == "tiles"
-    assert d.choose_shard_mode(int(sum(bins50)), 600, bins50, 1, 1024) == "tiles"
+    monkeypatch.delenv("WC_NEWREF_SHARD", raising=False)
+    assert d.forced_shard_mode() is None
+    for mode in ("tiles", "rows"):
+        monkeypatch.setenv("WC_NEWREF_SHARD", mode)
+        assert d.forced_shard_mode() == mode
+    monkeypatch.setenv("WC_NEWREF_SHARD", "auto")
+    assert d.forced_shard_mode() is None
     assert d.exchange_capacity(1024, 8) % 32 == 0 and d.exchange_capacity(1024, 1) == 1024
+
+
+def _run(cmd, env=None):
+    import subprocess
+    import sys
+    full = dict(os.environ)
+    full.pop("WORLD_SIZE", None)
+    full.pop("RANK", None)
+    if env:
+        full.update(env)
+    p = subprocess.run([sys.executable] + cmd, cwd=ROOT, env=full, capture_output=True, text=True, timeout=300)
+    return p.returncode, p.stdout, p.stderr
+
+
+def test_bench_starts_its_own_ranks():
+    """`bench.py --gpus 2` without a torchrun environment starts two ranks itself (before anything
+    touches the GPU) and reports the world size it really ran with; a launcher that started a
+    different number of ranks than --gpus says is an error, not a silent one-rank run."""
+    import json
+    rc, out, err = _run(["bench.py", "--gpus", "2", "--launch-check"])
+    assert rc == 0, err
+    line = json.loads(out.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["ranks_requested"] == 2
+    rc, out, err = _run(["bench.py", "--gpus", "2", "--launch-check"], env={"WORLD_SIZE": "3", "RANK": "0"})
+    assert rc == 2 and "started 3 rank" in err
+    rc, out, err = _run(["bench.py", "--launch-check"])
+    assert rc == 0 and json.loads(out.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_cpu_baseline_worker(tmp_path):
+    """The worker processes of bench.py's cpu_baseline leg: a bounded row window of a part, equal to
+    the oracle's own rows (they time the oracle, nothing else)."""
+    import json
+    from wisecondor_amd import synth
+    data, bins, sums = synth.corrected_matrix(1000000, 12, seed=3)
+    data = np.asfortranarray(data)
+    idx, dst = wo.get_reference(data, bins, sums, 15, 1, 1, fast=True)
+    np.save(str(tmp_path / "corrected.npy"), data)
+    np.savez(str(tmp_path / "reference.npz"), bins=bins, k=15, binsize=1e6)
+    rc, out, err = _run(["oracle/cpu_baseline.py", "newref", str(tmp_path), "0", "1", "40"])
+    assert rc == 0, err
+    line = json.loads(out.strip().splitlines()[-1])
+    assert line["rows"] == [0, 40] and line["seconds"] > 0
+    assert np.array_equal(np.load(str(tmp_path / "newref_0.npy")), idx[:40])
+    rc, out, err = _run(["oracle/cpu_baseline.py", "newref", str(tmp_path), "3", "4", "25"])
+    lo, hi = wo.get_part(3, 4, data.shape[0])
+    assert rc == 0 and json.loads(out.strip().splitlines()[-1])["rows"] == [lo, min(hi, lo + 25)]
+
+
+def test_newref_file_names_and_rank_count(monkeypatch):
+    from wisecondor_amd import wisecondor as cli
+    import argparse
+    names = cli.BuildFiles("out/dir/ref.npz")
+    assert names.prep == "out/dir/ref_prep.npz" and names.part_base == "out/dir/ref_part"
+    assert cli.BuildFiles("ref").prep == "ref_prep.npz"
+    assert cli.BuildFiles.part_name("x_part", 7) == "x_part_7.npz"
+    monkeypatch.setattr(cli, "_visible_gpus", lambda: 8)
+    assert cli._rank_count(argparse.Namespace(cpus=1, gpus=None)) == 1
+    assert cli._rank_count(argparse.Namespace(cpus=4, gpus=None)) == 4
+    assert cli._rank_count(argparse.Namespace(cpus=64, gpus=None)) == 8       # no more ranks than GPUs
+    assert cli._rank_count(argparse.Namespace(cpus=1, gpus=2)) == 2
+    monkeypatch.setattr(cli, "_visible_gpus", lambda: 0)
+    assert cli._rank_count(argparse.Namespace(cpus=4, gpus=None)) == 1

@@ -222,3 +222,74 @@ def test_layout_dependent_sums(golden):
         x, y = int(x), int(y)
         assert wo.pairwise_sum(z[x:y + 1]) / np.sqrt(y - x + 1) == v
     assert max(int(y) - int(x) + 1 for _, x, y in g["long_seg"]) > 8192
+
+
+# ---------------------------------------------------------------------------
+# BASELINE configs 2 / 3 at full size: the real reference's newref 100 x 250 kb and `test`
+# ---------------------------------------------------------------------------
+def _cfg3_distances(g):
+    """Distances of the golden indexes from the golden correctedData in the reference's rounding
+    order (Fortran-ordered prep file: sample by sample, left to right; wisetools.py:302)."""
+    X = g["prep_correctedData"]
+    bins = g["prep_maskedChromBins"]
+    offs = np.concatenate([[0], np.cumsum(bins)])
+    idx = g["ref_indexes"].astype(np.int64)
+    glob = np.empty_like(idx)
+    for c in range(len(bins)):
+        lo, hi = int(offs[c]), int(offs[c + 1])
+        loc = idx[lo:hi]
+        glob[lo:hi] = np.where(loc < lo, loc, loc + (hi - lo))
+    D = np.zeros(idx.shape)
+    for s in range(X.shape[1]):
+        diff = X[:, s][glob] - X[:, s][:, None]
+        D = D + diff * diff
+    return D
+
+
+def test_cfg3_newref_distances_and_rows(golden):
+    import hashlib
+    g = golden("cfg3_250kb.npz")
+    D = _cfg3_distances(g)
+    assert hashlib.sha256(np.ascontiguousarray(D).tobytes()).hexdigest() == str(g["ref_distances_sha256"])
+    assert np.array_equal(D[g["ref_distance_rows"]].view(np.int64), g["ref_distances_sampled"].view(np.int64))
+    # the oracle's own selection on a spread of rows (a row costs ~4 ms of numpy)
+    X = np.asfortranarray(g["prep_correctedData"])
+    bins = [int(v) for v in g["prep_maskedChromBins"]]
+    sums = [int(v) for v in np.cumsum(bins)]
+    for part in (1, 97, 200):            # three row windows of 55 rows each
+        idx, dst = wo.get_reference(X, bins, sums, 100, part, 200, fast=True)
+        lo, hi = wo.get_part(part - 1, 200, X.shape[0])
+        assert np.array_equal(idx, g["ref_indexes"][lo:hi])
+        assert np.array_equal(np.asarray(dst).view(np.int64), D[lo:hi].view(np.int64))
+
+
+@pytest.mark.parametrize("name", ["mild18", "strong5"])
+def test_cfg3_test_sample(golden, name):
+    """The oracle's whole `test` at 250 kb against the reference's stored results (6-7 s per sample:
+    one np.sum per window, like the reference)."""
+    g = golden("cfg3_250kb.npz")
+    D = _cfg3_distances(g)
+    cutoff, _ = wo.get_optimal_cutoff(D, 3)
+    assert cutoff == float(g["cutoff"])
+    ms = [int(v) for v in g["ref_masked_sizes"]]
+    msum = [int(v) for v in np.cumsum(ms)]
+    thr = wo.z_threshold(ms)
+    assert np.isclose(thr, float(g["t_%s_threshold_z" % name]), rtol=1e-14)
+    z, r, n, sd = wo.repeat_test(np.copy(g["t_%s_xpca" % name]), g["ref_indexes"], D, ms, msum, cutoff,
+                                 float(g["t_%s_threshold_z" % name]), 5)
+    assert np.array_equal(n, g["t_%s_rep5_n" % name].astype(np.float64))
+    assert same_bits(z, g["t_%s_rep5_z" % name]) and same_bits(r, g["t_%s_rep5_r" % name])
+    assert sd == float(g["t_%s_rep5_sd" % name])
+    keys = [str(c) for c in range(1, 23)] + ["X", "Y"]
+    offs = np.concatenate([[0], np.cumsum(g["sample_chrom_lengths"])])
+    sample = {k: g["t_%s_sample" % name][offs[i]:offs[i + 1]] for i, k in enumerate(keys)}
+    ref = dict(binsize=g["ref_binsize"], indexes=g["ref_indexes"], distances=D,
+               chromosome_sizes=g["ref_chromosome_sizes"], mask=g["ref_mask"], masked_sizes=g["ref_masked_sizes"],
+               pca_mean=g["ref_pca_mean"], pca_components=g["ref_pca_components"])
+    out = wo.test_sample(sample, float(g["ref_binsize"]), ref)
+    want = g["t_%s_results_calls" % name]
+    got = np.asarray(out["results_calls"], dtype=np.float64).reshape(-1, 5)
+    assert np.array_equal(got[:, :3], want[:, :3])
+    assert np.allclose(got[:, 3:], want[:, 3:], rtol=1e-9, atol=0)
+    assert np.allclose(np.concatenate(out["results_z"]), g["t_%s_results_z" % name], rtol=1e-9, atol=1e-11)
+    assert np.allclose(out["results_cwz"], g["t_%s_results_cwz" % name], rtol=1e-9, atol=1e-11)

@@ -351,6 +351,101 @@ def cfg1_cases(wt, wc, n_ref=16, binsize=1000000):
     return out
 
 
+
+# ---------------------------------------------------------------- cfg3 -----
+def cfg3_cases(wt, wc, n_ref=100, binsize=250000):
+    """BASELINE configs 2 and 3 on the real reference: `newref` 100 samples x 250 kb through the
+    reference's own prep / part / post drivers (about a minute), then `test` on four samples
+    (about 20 s each, fillTri).  The file keeps the prep seam (correctedData, Fortran ordered like
+    the reference's prep file), the reference's indexes, a SHA-256 of its distance bytes plus every
+    89th distance row (the full float64 matrix would double the fixture; distances are a pure
+    function of correctedData + indexes and are re-derived by the tests), and per test sample the
+    function-level intermediates and the stored results."""
+    import hashlib
+    out = {}
+    profile = synth.bin_profile(binsize)
+    tmp = tempfile.mkdtemp(prefix="wc_gold3_")
+    infiles = []
+    for i in range(n_ref):
+        p = os.path.join(tmp, "ref_%03d.npz" % i)
+        write_sample(p, synth.make_sample(profile, seed=i), binsize)
+        infiles.append(p)
+    prep = os.path.join(tmp, "ref_prep.npz")
+    refpath = os.path.join(tmp, "reference.npz")
+    with quiet(), np.errstate(all="ignore"):
+        wc.toolNewrefPrep(argparse.Namespace(infiles=infiles, prepfile=prep, binsize=None))
+        wc.toolNewrefPart(argparse.Namespace(prepfile=prep, partfile=os.path.join(tmp, "ref_part"),
+                                             part=[1, 1], refsize=100))
+        wc.toolNewrefPost(argparse.Namespace(prepfile=prep, partfile=os.path.join(tmp, "ref_part"),
+                                             parts=1, outfile=refpath))
+    pz = np.load(prep)
+    corrected = pz["correctedData"]
+    assert corrected.flags["F_CONTIGUOUS"] and not corrected.flags["C_CONTIGUOUS"]
+    out["prep_correctedData"] = np.ascontiguousarray(corrected)     # values; the layout flag is below
+    out["prep_fortran"] = np.bool_(True)
+    out["prep_maskedChromBins"] = np.asarray(pz["maskedChromBins"], dtype=np.int64)
+    rz = np.load(refpath)
+    dist = np.ascontiguousarray(rz["distances"], dtype=np.float64)
+    out["ref_indexes"] = np.asarray(rz["indexes"], dtype=np.int32)
+    out["ref_distances_sha256"] = np.array(hashlib.sha256(dist.tobytes()).hexdigest())
+    out["ref_distance_rows"] = np.arange(0, dist.shape[0], 89, dtype=np.int64)
+    out["ref_distances_sampled"] = dist[::89].copy()
+    for k in ("chromosome_sizes", "mask", "masked_sizes", "pca_components", "pca_mean"):
+        out["ref_" + k] = np.asarray(rz[k])
+    out["ref_binsize"] = np.float64(rz["binsize"].item())
+    with np.errstate(all="ignore"):
+        cutoff, _ = wt.getOptimalCutoff(rz["distances"], 3)
+    out["cutoff"] = np.float64(cutoff)
+
+    keys = synth.CHROM_KEYS
+    out["sample_chrom_lengths"] = np.array([len(p) for p in profile], dtype=np.int64)
+    events = [
+        ("mild18", [("18", 100, 220, 1.05)]),                       # SURVEY 8(d): oracle calls [18, 98, 217]
+        ("strong5", [("5", 200, 262, 1.5), ("13", 150, 190, 0.5)]),  # flags change reference sets across repeats
+        ("loss2", [("2", 300, 420, 0.93), ("11", 40, 44, 1.8)]),
+        ("normal", []),
+    ]
+    names = []
+    ms = [int(v) for v in rz["masked_sizes"]]
+    msum = [sum(ms[:i + 1]) for i in range(len(ms))]
+    for j, (name, ev) in enumerate(events):
+        names.append(name)
+        s = synth.make_sample(profile, seed=999 + j, events=ev)
+        sp = os.path.join(tmp, "test_%s.npz" % name)
+        write_sample(sp, s, binsize)
+        op = os.path.join(tmp, "out_%s.npz" % name)
+        args = argparse.Namespace(infile=sp, outfile=op, reference=refpath, minzscore=None,
+                                  chromosomes=list(range(1, 23)), mineffectsize=0, multitest=1000,
+                                  minrefbins=25, repeats=5)
+        with quiet(), np.errstate(all="ignore"):
+            try:
+                wc.toolTest(args)
+            except SystemExit:
+                pass
+        tz = np.load(op)
+        out["t_%s_sample" % name] = np.concatenate([s[k] for k in keys])
+        out["t_%s_results_z" % name] = np.concatenate(list(tz["results_z"]))
+        out["t_%s_results_r" % name] = np.concatenate(list(tz["results_r"]))
+        out["t_%s_results_cwz" % name] = np.asarray(tz["results_cwz"], dtype=np.float64)
+        out["t_%s_results_calls" % name] = np.asarray(tz["results_calls"], dtype=np.float64).reshape(-1, 5)
+        for k in ("threshold_z", "asdef", "aasdef"):
+            out["t_%s_%s" % (name, k)] = np.float64(tz[k])
+        with quiet(), np.errstate(all="ignore"):
+            x = wt.toNumpyRefFormat(s, rz["chromosome_sizes"], rz["mask"])
+            xp = wt.applyPCA(x, rz["pca_mean"], rz["pca_components"])
+            for reps in (1, 5):
+                z, r, n, sd = wt.repeatTest(np.copy(xp), rz["indexes"], rz["distances"], ms, msum,
+                                            cutoff, float(tz["threshold_z"]), reps)
+                out["t_%s_rep%d_z" % (name, reps)] = z
+                out["t_%s_rep%d_n" % (name, reps)] = np.asarray(n, dtype=np.int16)
+                if reps == 5:
+                    out["t_%s_rep5_r" % name] = r
+                    out["t_%s_rep5_sd" % name] = np.float64(sd)
+        out["t_%s_xpca" % name] = xp
+        print(name, "calls:", out["t_%s_results_calls" % name][:, :3].tolist(), flush=True)
+    out["test_names"] = np.array(names)
+    return out
+
 # ------------------------------------------------------------- binsize -----
 def scale_cases(wt):
     """scaleSample + a 2-sample newrefprep at a merged bin size (wisetools.py:220-264)."""
@@ -368,13 +463,15 @@ def scale_cases(wt):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default=None, help="regenerate one file only: layout")
+    ap.add_argument("--only", default=None, help="regenerate one file only: layout | cfg3 | cfg5")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     wt, wc, _tri = ref_loader.load(full_svd=True)
     save = ref_loader.np.savez_compressed
     if args.only in (None, "layout"):
         save(os.path.join(GOLD, "layout_cases.npz"), **layout_cases(wt))
+    if args.only in (None, "cfg3"):
+        save(os.path.join(GOLD, "cfg3_250kb.npz"), **cfg3_cases(wt, wc))
     if args.only is not None:
         return
     save(os.path.join(GOLD, "newref_kernel.npz"), **newref_cases(wt))

@@ -51,6 +51,8 @@ SIGNATURES = {
     "wc_stouffer_segments": (_i32, [_vp, _vp, _vp, _dbl, _vp, _i64, _dbl, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "wc_test_batch": (_i32, [_vp, _vp, _vp, _i64, _dbl, _i32, _i32, _dbl, _vp, _i32, _i32,
                              _vp, _vp, _vp, _vp, _vp, _vp]),
+    "wc_test_profile": (_i32, [_vp, _i32]),
+    "wc_test_profile_read": (_i32, [_vp, _vp]),
     "wc_test_batch_dev": (_i32, [_vp, _vp, _vp, _vp, _i64, _dbl, _i32, _i32, _dbl, _vp, _i32, _i32,
                                  _vp, _vp, _vp, _vp, _vp, _vp]),
 }

@@ -43,6 +43,22 @@ struct TestState {
     wc::DevBuf seg, seg_cnt, out_val, out_x, out_y, out_n, whole, effect, misc, misc2, reduce_tmp, win_bits, bit_off, pairs_a, pairs_b, cut_vals;
     int64_t rs_len = 0;
     int64_t last_segs = 0;
+    // optional stage timing of wc_test_batch_dev (wc_test_profile): events on the launch stream
+    // between the stages, and counts of the window evaluations the search kernels executed
+    bool profile = false;
+    std::vector<hipEvent_t> prof_ev;    // event pool, grown on demand
+    std::vector<int> prof_tag;          // tag of every mark of the last batch, in record order
+    wc::DevBuf prof_work;               // u64[2]: windows evaluated by k_seg_search, evaluations by k_seg_quiet
+    void mark(int tag, hipStream_t stream) {
+        if (!profile) return;
+        const size_t at = prof_tag.size();
+        if (at >= prof_ev.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            prof_ev.push_back(e);
+        }
+        if (hipEventRecord(prof_ev[at], stream) == hipSuccess) prof_tag.push_back(tag);
+    }
 };
 
 // state carried from wc_newref_prep_gram to wc_newref_prep_finish
@@ -92,6 +108,6 @@ struct wc_ctx {
                 &ts.sel, &ts.res_z, &ts.res_r, &ts.cwz, &ts.calls, &ts.n_calls, &ts.zs, &ts.rs2, &ts.ns2, &ts.sub, &ts.tmin, &ts.tmax, &ts.prefix, &ts.reg_abs,
                 &ts.reg_flag, &ts.rs, &ts.jobs_a, &ts.jobs_b, &ts.job_cnt, &ts.partial, &ts.job_res, &ts.hot,
                 &ts.cand, &ts.cand_cnt, &ts.seg, &ts.seg_cnt, &ts.out_val, &ts.out_x, &ts.out_y, &ts.out_n,
-                &ts.whole, &ts.effect, &ts.misc, &ts.misc2, &ts.reduce_tmp, &ts.win_bits, &ts.bit_off, &ts.pairs_a, &ts.pairs_b, &ts.cut_vals};
+                &ts.whole, &ts.effect, &ts.misc, &ts.misc2, &ts.reduce_tmp, &ts.win_bits, &ts.bit_off, &ts.pairs_a, &ts.pairs_b, &ts.cut_vals, &ts.prof_work};
     }
 };

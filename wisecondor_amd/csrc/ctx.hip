@@ -52,6 +52,7 @@ void wc_destroy(wc_ctx *ctx) {
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    for (hipEvent_t e : ctx->ts.prof_ev) (void)hipEventDestroy(e);
     delete ctx;
 }
 

@@ -1066,7 +1066,8 @@ __global__ __launch_bounds__(256) void k_seg_quiet(Job *__restrict__ jobs, int n
                                                    const double *__restrict__ reg_abs,
                                                    const int *__restrict__ reg_flag, double thr,
                                                    const double *__restrict__ tmin,
-                                                   const double *__restrict__ tmax) {
+                                                   const double *__restrict__ tmax,
+                                                   unsigned long long *__restrict__ work) {
     __shared__ int s_found, s_nwork;
     __shared__ double s_px[2 * ROWS_HALF];        // P[x] of the block's rows (side * 64 + lane)
     __shared__ long long s_ax[2 * ROWS_HALF];     // their absolute prefix indexes
@@ -1112,6 +1113,7 @@ __global__ __launch_bounds__(256) void k_seg_quiet(Job *__restrict__ jobs, int n
         }
         __syncthreads();
         bool found = false;
+        int evals = 0;                            // profiling only: window / bound evaluations of this lane
         for (int side = 0; side < 2; ++side) {
             int xr = chunk * ROWS_HALF + lane;
             bool live;
@@ -1134,6 +1136,7 @@ __global__ __launch_bounds__(256) void k_seg_quiet(Job *__restrict__ jobs, int n
             long long y_near = k_far * QB - 1;
             if (y_near > a_hi) y_near = a_hi;
             const int near = live ? (int)(y_near - ax) : 0;            // <= 63
+            if (w == 0 && live) evals += near + (int)(k_last >= k_far ? k_last - k_far + 1 : 0);
 #pragma unroll 4
             for (int len = 1 + w; len <= 2 * QB; len += 4) {
                 const double r = rs[len];
@@ -1175,6 +1178,12 @@ __global__ __launch_bounds__(256) void k_seg_quiet(Job *__restrict__ jobs, int n
             }
         }
         if (found) s_found = 1;
+        if (work) {
+            if (tid < 64) {
+                for (int o = 32; o > 0; o >>= 1) evals += __shfl_xor(evals, o);
+                if (tid == 0) atomicAdd(work + 1, (unsigned long long)evals + 32ull * (unsigned long long)nwork);
+            }
+        }
     }
     __syncthreads();
     if (tid == 0 && s_found) jobs[j].pad = 1;
@@ -1208,7 +1217,8 @@ __global__ __launch_bounds__(64 * NW) void k_seg_search(const Job *__restrict__ 
                                                     const unsigned int *__restrict__ bits,
                                                     const long long *__restrict__ bit_off,
                                                     Extreme *__restrict__ partial, int *__restrict__ counters,
-                                                    int certified, double2 *__restrict__ sub) {
+                                                    int certified, double2 *__restrict__ sub,
+                                                    unsigned long long *__restrict__ work) {
     extern __shared__ double pl[];
     __shared__ double red_max[NW], red_min[NW];
     const int j = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
@@ -1231,6 +1241,7 @@ __global__ __launch_bounds__(64 * NW) void k_seg_search(const Job *__restrict__ 
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     double bmax = -INFINITY, bmin = INFINITY;      // over both sides
+    int n_windows = 0;                             // profiling only: windows of this lane's rows
     double2 *sub_blk = sub + ((int64_t)j * max_chunks + chunk) * 8;   // [side][search wave]: {max, min}
     for (int side = 0; side < 2; ++side) {
         int xr = chunk * ROWS_HALF + lane;
@@ -1247,6 +1258,7 @@ __global__ __launch_bounds__(64 * NW) void k_seg_search(const Job *__restrict__ 
         const int xl = live ? xr : 0;
         const double px = P[xl];
         const int room = live ? L - xl : 0;            // windows [xl, xl + len - 1] with len <= room
+        n_windows += room;
         double smax = -INFINITY, smin = INFINITY;      // this side, this wave
         int base = 1 + 4 * w;
         if (!MASKED) {
@@ -1316,6 +1328,10 @@ __global__ __launch_bounds__(64 * NW) void k_seg_search(const Job *__restrict__ 
         bmin = fmin(bmin, smin);
     }
     if (lane == 0) { red_max[w] = bmax; red_min[w] = bmin; }
+    if (work && w == 0) {       // the waves split the window lengths of the same rows: count them once
+        for (int o = 32; o > 0; o >>= 1) n_windows += __shfl_xor(n_windows, o);
+        if (lane == 0) atomicAdd(work, (unsigned long long)n_windows);
+    }
     __syncthreads();
     if (tid == 0) {
         Extreme e;
@@ -1913,6 +1929,12 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
         bits = ts.win_bits.as<unsigned int>();
         bit_off = ts.bit_off.as<long long>();
     }
+    unsigned long long *work = nullptr;     // profiling: evaluation counters of the search kernels
+    if (ts.profile) {
+        if ((rc = ts.prof_work.reserve(sizeof(unsigned long long) * 2))) return rc;
+        WC_HIP(hipMemsetAsync(ts.prof_work.p, 0, sizeof(unsigned long long) * 2, stream));
+        work = ts.prof_work.as<unsigned long long>();
+    }
     int *counters = ts.job_cnt.as<int>();  // [1] next jobs [2] hot [3] brute [4] segments
     int *hot = ts.hot.as<int>();
     int *brute = hot + job_cap;
@@ -1950,6 +1972,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
         if ((rc = ts.cand_cnt.reserve(sizeof(int) * 2 * n_jobs))) return rc;
         // round counters are reset by the search kernel, candidate counts by classify
         dim3 sg((unsigned)max_chunks, (unsigned)n_jobs);
+        ts.mark(10, stream);
         if (certify) {
             // about 16 384 workgroups in all: one per job when there are many jobs, every row block
             // of a job in parallel when there are few
@@ -1957,7 +1980,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
             hipLaunchKernelGGL(k_seg_quiet, dim3(per_job, (unsigned)n_jobs), dim3(256), 0, stream, cur, (int)n_jobs, regions_dev,
                                (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
                                (const double *)ts.reg_abs.as<double>(), (const int *)ts.reg_flag.as<int>(), thr,
-                               (const double *)ts.tmin.as<double>(), (const double *)ts.tmax.as<double>());
+                               (const double *)ts.tmin.as<double>(), (const double *)ts.tmax.as<double>(), work);
         }
         {
             const bool plds = max_n + 1 <= 6144;      // the longest region's prefix slice fits 48 KB of LDS
@@ -1966,7 +1989,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     hipLaunchKernelGGL((k_seg_search<M, P_, NW_>), sg, dim3(64 * NW_), dyn, stream, (const Job *)cur, (int)n_jobs,   \
                        regions_dev, (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),     \
                        (const int *)ts.reg_flag.as<int>(), max_chunks, bits, bit_off, ts.partial.as<Extreme>(), \
-                       counters, (int)certify, ts.sub.as<double2>())
+                       counters, (int)certify, ts.sub.as<double2>(), work)
 #define WC_SEARCH_NW(M, P_) do { if (wide) WC_SEARCH(M, P_, 16); else WC_SEARCH(M, P_, 4); } while (0)
             const bool wide = n_jobs * max_chunks <= 2048;     // few blocks: sixteen waves each
             if (bits) { if (plds) WC_SEARCH_NW(true, true); else WC_SEARCH_NW(true, false); }
@@ -1974,6 +1997,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
 #undef WC_SEARCH_NW
 #undef WC_SEARCH
         }
+        ts.mark(11, stream);
         hipLaunchKernelGGL(k_seg_classify, dim3((unsigned)n_jobs), dim3(64), 0, stream, (const Job *)cur, (int)n_jobs,
                            regions_dev, (const double *)ts.reg_abs.as<double>(), (const int *)ts.reg_flag.as<int>(),
                            (const Extreme *)ts.partial.as<Extreme>(), max_chunks, thr, ts.job_res.as<Extreme>(), hot,
@@ -2302,8 +2326,12 @@ int wc_test_batch_dev(wc_ctx *ctx, void *stream_, const wc_reference *ref, const
     TestState &ts = ctx->ts;
     const int64_t Ns = n_samples, B = ref->B;
     int rc;
+    ts.prof_tag.clear();
+    ts.mark(0, stream);
     if ((rc = run_prepare(ctx, ref, counts, Ns, stream))) return rc;
+    ts.mark(1, stream);
     if ((rc = run_repeat(ctx, ref, ts.data.as<double>(), Ns, threshold, repeats, stream))) return rc;
+    ts.mark(2, stream);
     struct Joiner {   // asdef is copied out once the side stream's sum is done, on every exit path
         wc_ctx *c; hipStream_t s; double *dst; int64_t n;
         ~Joiner() {
@@ -2365,9 +2393,11 @@ int wc_test_batch_dev(wc_ctx *ctx, void *stream_, const wc_reference *ref, const
             int64_t n = ref->moff[sel[s] + 1] - ref->moff[sel[s]];
             bits_upper += Ns * (n * (n + 1) / 2);
         }
+    ts.mark(3, stream);
     if ((rc = run_stouffer(ctx, ts.zc.as<double>(), ts.regions.as<Region>(), n_regions, Ns * B, max_n, threshold, 3,
                            max_calls, stream, ts.rc.as<double>(), min_effect, bits_upper)))
         return rc;
+    ts.mark(4, stream);
     if (results_cwz)
         WC_HIP(hipMemcpyAsync(results_cwz, ts.whole.p, sizeof(double) * n_regions, hipMemcpyDeviceToDevice, stream));
     if (calls && n_calls) {
@@ -2386,7 +2416,52 @@ int wc_test_batch_dev(wc_ctx *ctx, void *stream_, const wc_reference *ref, const
         WC_HIP(hipStreamSynchronize(stream));
         WC_CHECK(!*overflow, WC_E_LIMIT, "test: a sample has more than max_calls=%d calls", max_calls);
     }
+    ts.mark(5, stream);
     WC_HIP(hipGetLastError());
+    return WC_OK;
+}
+
+int wc_test_profile(wc_ctx *ctx, int enable) {
+    WC_CHECK(ctx, WC_E_ARG, "profile: NULL context");
+    ctx->ts.profile = enable != 0;
+    ctx->ts.prof_tag.clear();
+    return WC_OK;
+}
+
+int wc_test_profile_read(wc_ctx *ctx, double out[8]) {
+    WC_CHECK(ctx && out, WC_E_ARG, "profile: NULL argument");
+    for (int i = 0; i < 8; ++i) out[i] = 0.0;
+    TestState &ts = ctx->ts;
+    if (ts.prof_tag.empty()) return WC_OK;
+    WC_HIP(hipSetDevice(ctx->device));
+    WC_HIP(hipDeviceSynchronize());
+    auto ms = [&](size_t a, size_t b) {
+        float t = 0.f;
+        return hipEventElapsedTime(&t, ts.prof_ev[a], ts.prof_ev[b]) == hipSuccess ? (double)t : 0.0;
+    };
+    // stage boundaries 0..5 in order; pairs (10, 11) bracket the certificate + search launches of a round
+    size_t last_stage = 0, open_search = 0;
+    bool have_stage = false, have_open = false;
+    for (size_t i = 0; i < ts.prof_tag.size(); ++i) {
+        const int tag = ts.prof_tag[i];
+        if (tag >= 0 && tag <= 5) {
+            if (have_stage && tag >= 1) out[tag - 1] += ms(last_stage, i);
+            last_stage = i;
+            have_stage = true;
+        } else if (tag == 10) {
+            open_search = i;
+            have_open = true;
+        } else if (tag == 11 && have_open) {
+            out[5] += ms(open_search, i);
+            have_open = false;
+        }
+    }
+    if (ts.prof_work.p) {
+        unsigned long long w[2] = {0, 0};
+        WC_HIP(hipMemcpy(w, ts.prof_work.p, sizeof(w), hipMemcpyDeviceToHost));
+        out[6] = (double)w[0];
+        out[7] = (double)w[1];
+    }
     return WC_OK;
 }
 

@@ -72,51 +72,24 @@ class HipStages(object):
         _lib.check(self.lib.wc_newref_import_lists_dev(self.ctx, self._stream(), rb, re, cap, cnt.data_ptr(),
                                                        lst.data_ptr()))
 
-    def finish(self, rb, re, idx, dst, mid_event=None):
-        """mid_event: torch event recorded between the per-row fast path and the exact path."""
-        if mid_event is None:
-            _lib.check(self.lib.wc_newref_finish_dev(self.ctx, self._stream(), rb, re, idx.data_ptr(), dst.data_ptr()))
-            return
+    def finish(self, rb, re, idx, dst):
+        _lib.check(self.lib.wc_newref_finish_dev(self.ctx, self._stream(), rb, re, idx.data_ptr(), dst.data_ptr()))
+
+    def rescore(self, rb, re, idx, dst):
+        """The per-row fast path alone (finish == rescore + fallback), for callers that time them apart."""
         _lib.check(self.lib.wc_newref_rescore_dev(self.ctx, self._stream(), rb, re, idx.data_ptr(), dst.data_ptr()))
-        mid_event.record()
+
+    def fallback(self, rb, re, idx, dst):
         _lib.check(self.lib.wc_newref_fallback_dev(self.ctx, self._stream(), rb, re, idx.data_ptr(), dst.data_ptr()))
 
     def empty(self, shape, dtype):
         return self.torch.empty(shape, dtype=dtype, device=self.device)
 
 
-# Cost model of the shard-mode choice (seconds; one MI355X per rank, xGMI between them).
-# Distance kernel, measured on one GPU (bf16 hi/lo tiles): 768 tiles in flight, a tile takes
-# 15 us + 1.75 us per 32-sample slab (cfg2: 3 663 tiles x 22 us / 768 = 0.105 ms, measured 0.100;
-# cfg4: 96 648 x 48 us / 768 = 6.07 ms, measured 6.1).  The exchange figures are planning
-# numbers for RCCL on a fully connected 8-GPU node (not measured here: the test box has one GPU).
-_TILES_IN_FLIGHT = 768.0
-_TILE_FIXED, _TILE_PER_SLAB = 15e-6, 1.75e-6
-_COLL_LATENCY = 30e-6                # fixed cost of one small RCCL collective
-_XGMI_RATE = 100e9                   # bytes/s a rank moves in an all-to-all (several links busy)
-
-
-def choose_shard_mode(n_bins, n_samples, chrom_bins, world, cap):
-    """'tiles' (symmetric tile deal + candidate exchange) or 'rows' (row bands, no exchange).
-
-    tiles: every unordered pair is evaluated once on the node; costs the threshold all-gather,
-           the list all-to-all (world * rows/rank * cap_x * 8 B per rank) and export/import.
-    rows:  rank r evaluates its rows against all columns, i.e. every unordered pair twice on
-           the node; nothing but the final all-gather.
-    Rows mode wins when one rank's share of the symmetric work is shorter than the exchange."""
-    if world <= 1:
-        return "tiles"
+def forced_shard_mode():
+    """'tiles' / 'rows' when WC_NEWREF_SHARD pins the multi-GPU shard mode, else None."""
     env = os.environ.get("WC_NEWREF_SHARD", "auto")
-    if env in ("tiles", "rows"):
-        return env
-    b = np.asarray(chrom_bins, dtype=np.float64)
-    unordered = (float(n_bins) ** 2 - float((b * b).sum())) / 2.0
-    tiles = unordered / (128.0 * 128.0)
-    slabs = np.ceil(n_samples / 32.0)
-    t_sym = tiles * (_TILE_FIXED + _TILE_PER_SLAB * slabs) / _TILES_IN_FLIGHT / world
-    rows = n_bins / float(world)
-    t_exchange = 2 * _COLL_LATENCY + world * rows * exchange_capacity(cap, world) * 8.0 / _XGMI_RATE
-    return "rows" if t_sym < t_exchange else "tiles"
+    return env if env in ("tiles", "rows") else None
 
 
 def exchange_capacity(cap, world):
@@ -153,7 +126,10 @@ class NewrefJob(object):
         if dist is None and self.world > 1:
             import torch.distributed as dist
         self.dist = dist
-        self.mode = mode            # None: decided after prepare(), when the list capacity is known
+        self.mode = mode            # None: measured at the first run (calibrate), unless WC_NEWREF_SHARD pins it
+        self.calibration = None
+        self._marks = None
+        self.last_marks = None
         self.chrom_bins = np.asarray(chrom_bins, dtype=np.int64)
         self.ranges = [row_range(r, self.world, self.n_bins) for r in range(self.world)]
         self.max_rows = max(e - b for b, e in self.ranges)
@@ -223,39 +199,90 @@ class NewrefJob(object):
         dst = self.torch.cat([self.dst_all[r][:e - b] for r, (b, e) in enumerate(self.ranges)])
         return idx, dst
 
-    def _finish(self, rb, re, idx, dst, events):
-        if events and len(events) > 2:
-            self.st.finish(rb, re, idx, dst, mid_event=events[2])
-        else:
-            self.st.finish(rb, re, idx, dst)
+    def calibrate(self):
+        """Pick the shard mode by measurement: one warm-up and one timed pass of each mode on
+        this job's own data, the slower rank's time counts (all-reduce MAX), ties go to the
+        symmetric tile shard.  Every rank reaches the same decision.  `calibration` keeps the
+        measured seconds per pass."""
+        import time
+        times = {}
+        marks, self._marks = self._marks, None           # the caller's timing marks are not for these passes
+        for mode in ("tiles", "rows"):
+            self.mode = mode
+            self._run()                                  # buffers, tile lists, communicator warm-up
+            self._sync()
+            self.dist.barrier()
+            t0 = time.perf_counter()
+            self._run()
+            self._sync()
+            times[mode] = self._max_over_ranks(time.perf_counter() - t0)
+        self.mode = None
+        self._marks = marks
+        self.calibration = times
+        return "rows" if times["rows"] < times["tiles"] else "tiles"
 
-    def run(self, collect_events=None):
-        """collect_events: (before collect, after collect[, after k_finish -- before the exact-path launches]) torch events on the launch stream."""
+    def _sync(self):
+        if getattr(self.st, "device", None) is not None and self.st.device.type == "cuda":
+            self.torch.cuda.synchronize()
+
+    def _max_over_ranks(self, seconds):
+        on_gpu = self.dist.get_backend() != "gloo"
+        t = self.torch.tensor([seconds], dtype=self.torch.float64,
+                              device=self.st.device if on_gpu else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def _mark(self, name):
+        """Record a timing event on the launch stream (only while `timing` is on)."""
+        if self._marks is not None:
+            ev = self.torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._marks[name] = ev
+
+    def stage_ms(self):
+        """Milliseconds between the marks of the last timed run (call after a synchronize)."""
+        m = self.last_marks or {}
+        order = ["start", "prepared", "thresholds", "collected", "exchanged", "rescored", "finished", "gathered"]
+        have = [n for n in order if n in m]
+        return {"%s->%s" % (a, b): m[a].elapsed_time(m[b]) for a, b in zip(have, have[1:])}
+
+    def run(self, timing=False):
+        """One pass.  timing=True records torch events between the stages on the launch stream
+        (read them with stage_ms() after a synchronize): prepared, thresholds, collected,
+        [exchanged], rescored (k_finish fast path alone), finished (+ exact path), [gathered]."""
+        self._marks = {} if timing else None
+        try:
+            return self._run()
+        finally:
+            self.last_marks, self._marks = self._marks, None
+
+    def _run(self):
         st = self.st
+        self._mark("start")
         st.prepare()
+        self._mark("prepared")
         if self.world == 1:
             st.thresholds(0, self.n_bins)
-            if collect_events:
-                collect_events[0].record()
+            self._mark("thresholds")
             st.collect(0, self.n_bins, 0, 1)
-            if collect_events:
-                collect_events[1].record()
-            self._finish(0, self.n_bins, self.idx, self.dst, collect_events)
+            self._mark("collected")
+            self._finish(0, self.n_bins, self.idx, self.dst)
             return self.idx, self.dst
 
         rb, re = self.ranges[self.rank]
         if self.mode is None:
-            self.mode = choose_shard_mode(self.n_bins, st.n_samples, self.chrom_bins, self.world, st.cap)
+            self.mode = forced_shard_mode() or self.calibrate()
+            st.prepare()
         if self.mode == "rows":
             # row band of this rank against all columns: no exchange, one collective
             st.thresholds(rb, re)
-            if collect_events:
-                collect_events[0].record()
+            self._mark("thresholds")
             st.collect(rb, re, 0, 1)
-            if collect_events:
-                collect_events[1].record()
-            self._finish(rb, re, self.idx_all[self.rank], self.dst_all[self.rank], collect_events)
-            return self._gather_results()
+            self._mark("collected")
+            self._finish(rb, re, self.idx_all[self.rank], self.dst_all[self.rank])
+            out = self._gather_results()
+            self._mark("gathered")
+            return out
 
         if not self.buffers_ready:
             self._alloc_exchange()
@@ -267,12 +294,10 @@ class NewrefJob(object):
         for r, (b, e) in enumerate(self.ranges):
             if r != self.rank:
                 st.set_thr(b, e, self.thr_all[r])
+        self._mark("thresholds")
         # this rank's share of the symmetric tile space, candidates for all rows
-        if collect_events:
-            collect_events[0].record()
         st.collect(0, self.n_bins, self.rank, self.world)
-        if collect_events:
-            collect_events[1].record()
+        self._mark("collected")
         # candidate lists travel to the rows' owners
         self.send_cnt_all.zero_()
         for r, (b, e) in enumerate(self.ranges):
@@ -282,9 +307,21 @@ class NewrefJob(object):
         for r in range(self.world):
             if r != self.rank:
                 st.import_(rb, re, self.cap_x, self.recv_cnt[r], self.recv_lst[r])
+        self._mark("exchanged")
         # owners finish their rows; results to everyone
-        st.finish(rb, re, self.idx_all[self.rank], self.dst_all[self.rank])
-        return self._gather_results()
+        self._finish(rb, re, self.idx_all[self.rank], self.dst_all[self.rank])
+        out = self._gather_results()
+        self._mark("gathered")
+        return out
+
+    def _finish(self, rb, re, idx, dst):
+        if self._marks is None:
+            self.st.finish(rb, re, idx, dst)
+            return
+        self.st.rescore(rb, re, idx, dst)
+        self._mark("rescored")
+        self.st.fallback(rb, re, idx, dst)
+        self._mark("finished")
 
 
 class TestBatch(object):

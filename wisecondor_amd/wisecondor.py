@@ -1,11 +1,18 @@
-"""Drop-in `wisecondor.py` command line for the newref* and test sub-commands.
+"""Command line of the MI355X build: the `newref*` and `test` sub-commands of WISECONDOR.
 
-Same sub-commands, positional arguments, single-dash options, defaults, file
-naming and .npz keys as the reference CLI (wisecondor.py:345-521); the numeric
-work runs on an MI355X through libwisecondor_hip.so.  convert / plot / report
-are outside this build's scope and exit with a message.
+Contract (taken from the upstream CLI at
+wisecondor.py:345-521): same sub-command names, positional arguments, single-dash
+options, defaults and `dest` names; same file naming (`<stem>_prep.npz`,
+`<stem>_part_<m>.npz`, resume by file existence, temporaries removed after a
+successful merge); same `.npz` keys and dtypes; `test` ends with exit status 0.
+Everything numeric runs on the GPU through libwisecondor_hip.so (no CPU path).
+
+Build-only additions, all off by default: `-gpus N` on `newref` / `testbatch`
+(one process per GPU), the `testbatch` sub-command (many samples per GPU batch).
+`convert`, `plot` and `report` are not part of this build.
 """
 import argparse
+import copy
 import datetime
 import getpass
 import os
@@ -19,371 +26,399 @@ from scipy.stats import norm
 
 from . import wisetools as wt
 
-curTime = datetime.datetime.now()
+_STARTED = datetime.datetime.now()
 
 
-def getVersion():
-    version = 'unknown'
-    try:
-        version = subprocess.check_output(["git", "describe", "--always"], stderr=subprocess.DEVNULL).split()[0]
-    except Exception:
-        pass
-    return version
-
-
+# ------------------------------------------------------------------ provenance ----
 def getRuntime():
-    """Provenance dict stored in every output (wisetools.py:47-53)."""
-    return dict(version=getVersion(), datetime=curTime, hostname=socket.gethostname(),
-                username=getpass.getuser())
+    """The `runtime` member of every output file: version, datetime, hostname, username
+    (upstream wisetools.py:47-62)."""
+    try:
+        tag = subprocess.check_output(["git", "describe", "--always"], stderr=subprocess.DEVNULL).split()[0]
+    except Exception:
+        tag = 'unknown'
+    return {'version': tag, 'datetime': _STARTED, 'hostname': socket.gethostname(),
+            'username': getpass.getuser()}
 
 
 def printArgs(args):
-    argdict = vars(args)
-    print('tool =', str(argdict['func']).split()[1][4:])
-    for arg in sorted(argdict.keys()):
-        if arg != 'func':
-            print(arg, '=', argdict[arg])
+    """Echo the parsed command (tool name first, then the options in name order)."""
+    settings = dict(vars(args))
+    tool = settings.pop('func', None)
+    print('tool =', getattr(tool, '__name__', str(tool)).replace('tool', '', 1))
+    for name in sorted(settings):
+        print(name, '=', settings[name])
 
 
-def _load(path):
+def _open_npz(path):
     return np.load(path, allow_pickle=True, encoding='latin1')
 
 
-def _object_array(items):
-    out = np.empty(len(items), dtype=object)
-    for i, v in enumerate(items):
-        out[i] = v
-    return out
+def _as_object_array(arrays):
+    """Ragged per-chromosome arrays as one object array (numpy >= 1.24 no longer infers it)."""
+    boxed = np.empty(len(arrays), dtype=object)
+    for at, item in enumerate(arrays):
+        boxed[at] = item
+    return boxed
 
 
-def toolNewref(args):
-    """prep -> parts -> post with resume-by-file-existence (wisecondor.py:30-69)."""
-    splitPath = list(os.path.split(args.outfile))
-    if splitPath[-1][-4:] == '.npz':
-        splitPath[-1] = splitPath[-1][:-4]
-    basePath = os.path.join(splitPath[0], splitPath[1])
-    args.prepfile = basePath + "_prep.npz"
-    args.partfile = basePath + "_part"
-    args.parts = max(args.parts, args.cpus)
+# --------------------------------------------------------------- newref: files ----
+class BuildFiles(object):
+    """Names of the intermediate files of one `newref` job.
 
-    if not os.path.isfile(args.prepfile):
-        toolNewrefPrep(args)
-    # -cpus asked the reference for a process pool; one GPU runs the parts back to back
-    for part in range(1, args.parts + 1):
-        if not os.path.isfile(args.partfile + "_" + str(part) + ".npz"):
-            args.part = [part, args.parts]
-            toolNewrefPart(args)
-    toolNewrefPost(args)
-    os.remove(args.prepfile)
-    for part in range(1, args.parts + 1):
-        os.remove(args.partfile + '_' + str(part) + '.npz')
+    `reference.npz` -> `reference_prep.npz` and `reference_part_<m>.npz` (a trailing `.npz`
+    of the output name is dropped first; upstream wisecondor.py:31-39).
+    """
+
+    def __init__(self, outfile):
+        folder, leaf = os.path.split(outfile)
+        if leaf.endswith('.npz'):
+            leaf = leaf[:-len('.npz')]
+        stem = os.path.join(folder, leaf)
+        self.prep = stem + '_prep.npz'
+        self.part_base = stem + '_part'
+
+    @staticmethod
+    def part_name(part_base, number):
+        return '%s_%d.npz' % (part_base, number)
 
 
-def toolNewrefPrep(args):
-    """wisecondor.py:72-108; normalisation, mask and PCA run through wt.prepReference (GPU)."""
-    samples = []
-    binsizes = set()
-    for infile in args.infiles:
-        print('Loading:', infile, end=' ')
-        npzdata = _load(infile)
-        binsize = npzdata['arguments'].item()['binsize']
-        print(' \tbinsize:', int(binsize))
-        samples.append(wt.scaleSample(npzdata['sample'].item(), binsize, args.binsize))
-        binsizes.add(binsize)
+def _missing_parts(part_base, parts):
+    return [m for m in range(1, parts + 1) if not os.path.isfile(BuildFiles.part_name(part_base, m))]
 
-    if args.binsize is None and len(binsizes) != 1:
-        print('ERROR: There appears to be a mismatch in binsizes in your dataset:', binsizes)
-        print('Either remove the offending sample or use -binsize to scale all samples')
+
+def _visible_gpus():
+    import torch
+    return int(torch.cuda.device_count())      # counting devices does not initialise the runtime
+
+
+def _rank_count(args):
+    """Processes (= GPUs) a `newref` / `testbatch` run uses.
+
+    `-gpus N` asks for N; without it `-cpus N` (the upstream worker-pool size) is honoured up to
+    the number of visible GPUs.  One rank runs in this process, more are started as children
+    (wisecondor_amd.ranks) before anything here touches the GPU."""
+    want = getattr(args, 'gpus', None)
+    if want is None:
+        want = min(max(1, int(getattr(args, 'cpus', 1))), max(1, _visible_gpus()))
+    if want < 1:
+        print('ERROR: -gpus needs a positive count, got', want)
         sys.exit(1)
-
-    binsize = args.binsize
-    if args.binsize is None:
-        binsize = binsizes.pop()
-
-    print('Applying nonzero mask on the data and fitting the PCA on the GPU:', end=' ')
-    maskedData, chromosomeBins, mask, correctedData, comps, mean, maskedChromBins = wt.prepReference(samples)
-    print((len(mask), len(samples)), 'becomes', maskedData.shape)
-    del samples
-    maskedChromBinSums = [int(v) for v in np.cumsum(maskedChromBins)]
-    pca = wt._PCAResult(comps, mean)
-    np.savez_compressed(args.prepfile,
-                        arguments=vars(args),
-                        runtime=getRuntime(),
-                        binsize=binsize,
-                        chromosomeBins=chromosomeBins,
-                        maskedData=maskedData,
-                        mask=mask,
-                        maskedChromBins=maskedChromBins,
-                        maskedChromBinSums=maskedChromBinSums,
-                        correctedData=correctedData,
-                        pca_components=pca.components_,
-                        pca_mean=pca.mean_)
+    return int(want)
 
 
-def toolNewrefPart(args):
-    """wisecondor.py:111-132: reference-bin selection for one part, on the GPU."""
-    if args.part[0] > args.part[1]:
-        print('ERROR: Part should be smaller or equal to total parts:', args.part[0], '>', args.part[1], 'is wrong')
-        sys.exit(1)
-    if args.part[0] < 0:
-        print('ERROR: Part should be at least zero:', args.part[0], '<', 0, 'is wrong')
-        sys.exit(1)
-
-    npzdata = _load(args.prepfile)
-    correctedData = npzdata['correctedData']
-    maskedChromBins = npzdata['maskedChromBins']
-    maskedChromBinSums = npzdata['maskedChromBinSums']
-
-    start = time.time()
-    indexes, distances = wt.getReference(correctedData, maskedChromBins, maskedChromBinSums,
-                                         selectRefAmount=args.refsize, part=args.part[0],
-                                         splitParts=args.part[1])
-    print(args.part[0], 'Time spent:', int(time.time() - start), 'seconds')
-
-    np.savez_compressed(args.partfile + '_' + str(args.part[0]) + '.npz',
-                        arguments=vars(args),
+def save_part(part_base, number, parts, indexes, distances, args):
+    """One part file exactly as `newrefpart` writes it (keys of SURVEY.md App. B)."""
+    stamped = copy.copy(args)
+    stamped.part = [number, parts]
+    np.savez_compressed(BuildFiles.part_name(part_base, number),
+                        arguments=vars(stamped),
                         runtime=getRuntime(),
                         indexes=indexes,
                         distances=distances)
 
 
-def toolNewrefPost(args):
-    """wisecondor.py:135-170."""
-    npzdata = _load(args.prepfile)
-    maskedChromBins = npzdata['maskedChromBins']
-    chromosomeBins = npzdata['chromosomeBins']
-    mask = npzdata['mask']
-    pca_components = npzdata['pca_components']
-    pca_mean = npzdata['pca_mean']
-    binsize = npzdata['binsize'].item()
+def select_all_rows(prepfile, refsize, device=0, rank=0, world=1):
+    """indexes / distances of every bin from a prep file, matrix resident on `device`.
 
-    bigIndexes = []
-    bigDistances = []
-    for part in range(1, args.parts + 1):
-        infile = args.partfile + '_' + str(part) + '.npz'
-        print('Loading:', infile)
-        npzdata = _load(infile)
-        bigIndexes.extend(npzdata['indexes'])
-        bigDistances.extend(npzdata['distances'])
-        print(part, npzdata['indexes'].shape)
+    One NewrefJob pass (wisecondor_amd.distributed); with world > 1 the ranks share the work
+    and each ends with the full result."""
+    import torch
+    from . import _lib
+    from .distributed import NewrefJob
+    prep = _open_npz(prepfile)
+    corrected = prep['correctedData']
+    bins = np.ascontiguousarray(prep['maskedChromBins'], dtype=np.int64)
+    order = wt.sum_order_of(corrected)
+    dev = torch.device('cuda', device)
+    torch.cuda.set_device(dev)
+    X = torch.from_numpy(np.ascontiguousarray(corrected, dtype=np.float64)).to(dev)
+    job = NewrefJob(_lib.context(device), X, bins, int(refsize), order, rank=rank, world=world)
+    idx, dst = job.run()
+    torch.cuda.synchronize()
+    return idx.cpu().numpy(), dst.cpu().numpy(), job
 
-    indexes = np.array(bigIndexes)
-    distances = np.array(bigDistances)
 
-    np.savez_compressed(args.outfile,
+# --------------------------------------------------------------- newref: tools ----
+def toolNewrefPrep(args):
+    """`newrefprep`: sample files -> prep file (normalise, mask all-zero bins, PCA-correct).
+
+    File contract of upstream wisecondor.py:72-108; the arithmetic is wt.prepReference (GPU)."""
+    from . import ingest
+    loaded = ingest.load_samples(args.infiles, args.binsize, verbose=True)
+    if args.binsize is None and len(loaded.binsizes) > 1:
+        print('ERROR: the input samples were binned at different sizes:', sorted(loaded.binsizes))
+        print('Drop the odd ones or give -binsize to merge them to a common size')
+        sys.exit(1)
+    binsize = args.binsize if args.binsize is not None else next(iter(loaded.binsizes))
+
+    n_given = len(loaded.samples)
+    masked, chrom_bins, mask, corrected, components, mean, masked_bins = wt.prepReference(loaded.samples)
+    print('Zero mask on the GPU: %d bins x %d samples -> %d bins kept, 3 PCA components removed'
+          % (len(mask), n_given, masked.shape[0]))
+    running = np.cumsum(masked_bins)
+    np.savez_compressed(args.prepfile,
                         arguments=vars(args),
                         runtime=getRuntime(),
                         binsize=binsize,
-                        indexes=indexes,
-                        distances=distances,
-                        chromosome_sizes=chromosomeBins,
+                        chromosomeBins=chrom_bins,
+                        maskedData=masked,
                         mask=mask,
-                        masked_sizes=maskedChromBins,
-                        pca_components=pca_components,
-                        pca_mean=pca_mean)
+                        maskedChromBins=masked_bins,
+                        maskedChromBinSums=[int(v) for v in running],
+                        correctedData=corrected,
+                        pca_components=components,
+                        pca_mean=mean)
 
 
+def toolNewrefPart(args):
+    """`newrefpart prep part m n`: reference bins for row part m of n (1-based) -> `<part>_m.npz`."""
+    number, parts = args.part
+    if number > parts:
+        print('ERROR: part number %d exceeds the part count %d' % (number, parts))
+        sys.exit(1)
+    if number < 0:
+        print('ERROR: part number %d is negative' % number)
+        sys.exit(1)
+    prep = _open_npz(args.prepfile)
+    began = time.time()
+    indexes, distances = wt.getReference(prep['correctedData'], prep['maskedChromBins'],
+                                         prep['maskedChromBinSums'], selectRefAmount=args.refsize,
+                                         part=number, splitParts=parts)
+    print('part %d of %d: %d rows in %.2f s' % (number, parts, indexes.shape[0], time.time() - began))
+    save_part(args.partfile, number, parts, indexes, distances, args)
+
+
+def toolNewrefPost(args):
+    """`newrefpost prep part n out`: stack the n part files in order, add the prep file's layout."""
+    prep = _open_npz(args.prepfile)
+    idx_blocks, dst_blocks = [], []
+    for number in range(1, args.parts + 1):
+        name = BuildFiles.part_name(args.partfile, number)
+        piece = _open_npz(name)
+        idx_blocks.append(np.asarray(piece['indexes']))
+        dst_blocks.append(np.asarray(piece['distances']))
+        print('merged', name, idx_blocks[-1].shape)
+    width = max(b.shape[1] for b in idx_blocks if b.ndim == 2) if any(b.ndim == 2 for b in idx_blocks) else 0
+    idx_blocks = [b.reshape(-1, width) for b in idx_blocks]
+    dst_blocks = [b.reshape(-1, width) for b in dst_blocks]
+    np.savez_compressed(args.outfile,
+                        arguments=vars(args),
+                        runtime=getRuntime(),
+                        binsize=prep['binsize'].item(),
+                        indexes=np.concatenate(idx_blocks, axis=0),
+                        distances=np.concatenate(dst_blocks, axis=0),
+                        chromosome_sizes=prep['chromosomeBins'],
+                        mask=prep['mask'],
+                        masked_sizes=prep['maskedChromBins'],
+                        pca_components=prep['pca_components'],
+                        pca_mean=prep['pca_mean'])
+
+
+def toolNewref(args):
+    """`newref`: prep, every missing part, merge, clean up (upstream wisecondor.py:30-69).
+
+    The upstream tool fans the parts over `-cpus` worker processes; here the rows are computed
+    in one pass by one process per GPU (`-gpus`, default min(-cpus, visible GPUs)) and cut into
+    the same part files, so an interrupted run resumes from whatever files exist."""
+    names = BuildFiles(args.outfile)
+    args.prepfile, args.partfile = names.prep, names.part_base
+    args.parts = max(args.parts, args.cpus)
+    ranks = _rank_count(args)
+    todo = _missing_parts(args.partfile, args.parts)
+    if ranks > 1 and (todo or not os.path.isfile(args.prepfile)):
+        from . import ranks as rk
+        rk.launch(ranks, dict(job='newref', prepfile=args.prepfile, partfile=args.partfile,
+                              parts=args.parts, refsize=args.refsize, infiles=list(args.infiles),
+                              binsize=args.binsize, arguments=_plain_arguments(args)))
+    else:
+        if not os.path.isfile(args.prepfile):
+            toolNewrefPrep(args)
+        if todo:
+            began = time.time()
+            indexes, distances, _ = select_all_rows(args.prepfile, args.refsize)
+            print('reference bins for %d rows in %.2f s' % (indexes.shape[0], time.time() - began))
+            for number in todo:
+                lo, hi = wt.getPart(number - 1, args.parts, indexes.shape[0])
+                save_part(args.partfile, number, args.parts, indexes[lo:hi], distances[lo:hi], args)
+    toolNewrefPost(args)
+    os.remove(args.prepfile)
+    for number in range(1, args.parts + 1):
+        os.remove(BuildFiles.part_name(args.partfile, number))
+
+
+def _plain_arguments(args):
+    """vars(args) without the function object (for hand-over to worker processes as JSON)."""
+    return {k: v for k, v in vars(args).items() if k != 'func'}
+
+
+# ------------------------------------------------------------------------ test ----
 def zThreshold(masked_sizes, multitest, minzscore):
-    """wisecondor.py:203-207."""
-    num_tests = sum(masked_sizes)
-    z_threshold = norm.ppf(1 - 1. / (num_tests * 0.5 * multitest))
+    """Per-bin |z| cut of the first testing cycles: `-minzscore` if given, else the normal
+    quantile for one expected false positive in bins/2 * multitest tests (wisecondor.py:203-207)."""
     if minzscore is not None:
-        z_threshold = minzscore
-    return z_threshold
+        return minzscore
+    tests = sum(masked_sizes) * 0.5 * multitest
+    return norm.ppf(1 - 1. / tests)
 
 
-def writeTestOutput(outfile, args, binsize, out, z_threshold):
-    """The test .npz exactly as the reference lays it out (wisecondor.py:270-280): ragged
-    per-chromosome lists become object arrays (modern numpy refuses to infer them), an empty
-    call list stays shape (0,) like np.array([])."""
-    calls = np.asarray(out['results_calls'])
-    stdDevAvg = out['asdef']
+def writeTestOutput(outfile, args, binsize, result, z_threshold):
+    """The `test` output file (keys and shapes of SURVEY.md App. B): per-chromosome z and
+    ratio-1 arrays as object arrays, calls [n, 5] (shape (0,) when empty), the thresholds."""
+    calls = np.asarray(result['results_calls'])
+    if calls.size == 0:
+        calls = np.array([])
     np.savez_compressed(outfile,
                         arguments=vars(args),
                         runtime=getRuntime(),
                         binsize=binsize,
-                        results_r=_object_array(out['results_r']),
-                        results_z=_object_array(out['results_z']),
-                        results_cwz=out['results_cwz'],
-                        results_calls=calls if len(calls) else np.array([]),
+                        results_r=_as_object_array(result['results_r']),
+                        results_z=_as_object_array(result['results_z']),
+                        results_cwz=result['results_cwz'],
+                        results_calls=calls,
                         threshold_z=z_threshold,
-                        asdef=stdDevAvg,
-                        aasdef=stdDevAvg * z_threshold)
+                        asdef=result['asdef'],
+                        aasdef=result['asdef'] * z_threshold)
+
+
+def _reference_and_threshold(args, device=0):
+    stored = _open_npz(args.reference)
+    reference = wt.Reference.from_npz(stored, device=device)
+    cut = zThreshold([int(v) for v in stored['masked_sizes']], args.multitest, args.minzscore)
+    print('z-score threshold per bin:', cut)
+    return reference, cut
 
 
 def toolTest(args):
-    """wisecondor.py:174-281: one sample against a reference, on the GPU."""
-    referenceFile = _load(args.reference)
-    reference = wt.Reference.from_npz(referenceFile)
-    binsize = reference.binsize
-    masked_sizes = [int(v) for v in referenceFile['masked_sizes']]
-    del referenceFile
-
-    sampleFile = _load(args.infile)
-    sample = sampleFile['sample'].item()
-    sampleBinSize = sampleFile['arguments'].item()['binsize']
-    sample = wt.scaleSample(sample, sampleBinSize, binsize)
-
-    z_threshold = zThreshold(masked_sizes, args.multitest, args.minzscore)
-    print('Per bin z-score threshold for first testing cycles:', z_threshold)
-
-    start = time.time()
-    out = wt.test_batch(reference, [sample], z_threshold, minrefbins=args.minrefbins,
-                        repeats=args.repeats, chromosomes=list(args.chromosomes),
-                        mineffectsize=args.mineffectsize)[0]
-    stdDevAvg = out['asdef']
-    print('ASDES:', stdDevAvg, '\nAASDEF:', stdDevAvg * z_threshold)
-    print('Time spent on z-scores and stouffers z-scores:', int(time.time() - start), 'seconds')
-
-    writeTestOutput(args.outfile, args, binsize, out, z_threshold)
+    """`test sample out reference`: one sample against a reference (wisecondor.py:174-281)."""
+    reference, cut = _reference_and_threshold(args)
+    from . import ingest
+    sample = ingest.read_sample(args.infile, reference.binsize)[0]
+    began = time.time()
+    result = wt.test_batch(reference, [sample], cut, minrefbins=args.minrefbins, repeats=args.repeats,
+                           chromosomes=list(args.chromosomes), mineffectsize=args.mineffectsize)[0]
+    print('ASDES:', result['asdef'])
+    print('AASDEF:', result['asdef'] * cut)
+    print('z-scores and segments took %.3f s' % (time.time() - began))
+    writeTestOutput(args.outfile, args, reference.binsize, result, cut)
     reference.close()
     sys.exit(0)
 
 
 def toolTestBatch(args):
-    """Build-only addition: `test` for many samples in one GPU batch (same numbers and the
-    same per-sample output files as running `test` once per sample).  Under torchrun the
-    samples are sharded over the ranks (one process per GPU, no collective needed)."""
+    """`testbatch samples... outdir reference` (build-only): the same numbers and the same
+    per-sample files as one `test` per sample, in GPU batches with pooled file decode / encode.
+    `-gpus N` (or a torchrun environment) shards the sample list over N processes."""
+    world_env = int(os.environ.get('WORLD_SIZE', '1'))
+    if world_env == 1 and _rank_count(args) > 1:
+        from . import ranks as rk
+        rk.launch(_rank_count(args), dict(job='testbatch', arguments=_plain_arguments(args)))
+        return
+    from . import ingest
     from .distributed import shard_samples
     rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    device = int(os.environ.get('LOCAL_RANK', '0'))
-    referenceFile = _load(args.reference)
-    reference = wt.Reference.from_npz(referenceFile, device=device)
-    binsize = reference.binsize
-    masked_sizes = [int(v) for v in referenceFile['masked_sizes']]
-    del referenceFile
-    z_threshold = zThreshold(masked_sizes, args.multitest, args.minzscore)
-    print('Per bin z-score threshold for first testing cycles:', z_threshold)
-    lo, hi = shard_samples(len(args.infiles), rank, world)
-    infiles = args.infiles[lo:hi]
-    if not os.path.isdir(args.outdir):
-        os.makedirs(args.outdir, exist_ok=True)
-    start = time.time()
-    for at in range(0, len(infiles), args.batch):
-        names = infiles[at:at + args.batch]
-        samples = []
-        for name in names:
-            sampleFile = _load(name)
-            samples.append(wt.scaleSample(sampleFile['sample'].item(),
-                                          sampleFile['arguments'].item()['binsize'], binsize))
-        outs = wt.test_batch(reference, samples, z_threshold, minrefbins=args.minrefbins, repeats=args.repeats,
-                             chromosomes=list(args.chromosomes), mineffectsize=args.mineffectsize)
-        for name, out in zip(names, outs):
-            base = os.path.basename(name)
-            base = base[:-4] if base.endswith('.npz') else base
-            one = argparse.Namespace(**vars(args))
-            one.infile = name
-            one.outfile = os.path.join(args.outdir, base + '_test.npz')
-            writeTestOutput(one.outfile, one, binsize, out, z_threshold)
-            print(name, '->', one.outfile, 'calls:', len(out['results_calls']))
-    print('Time spent on', len(infiles), 'samples:', int(time.time() - start), 'seconds')
+    device = int(os.environ.get('LOCAL_RANK', '0')) % max(1, _visible_gpus())   # functional runs may share a GPU
+    reference, cut = _reference_and_threshold(args, device=device)
+    lo, hi = shard_samples(len(args.infiles), rank, world_env)
+    os.makedirs(args.outdir, exist_ok=True)
+    stats = ingest.run_testbatch(reference, args.infiles[lo:hi], args.outdir, cut, args,
+                                 writer=lambda path, one, res: writeTestOutput(path, one, reference.binsize,
+                                                                               res, cut))
+    print('rank %d: %d samples in %.2f s (%.1f files/s end to end; GPU batches %.3f s)'
+          % (rank, stats['files'], stats['wall_s'], stats['files_per_s'], stats['gpu_s']))
     reference.close()
 
 
-def _out_of_scope(args):
+# ---------------------------------------------------------------------- parser ----
+def _not_in_this_build(args):
     print('ERROR: this sub-command is not part of the MI355X build (newref*, test only); '
-          'use the upstream wisecondor.py for it')
+          'run it with the upstream wisecondor.py')
     sys.exit(2)
 
 
-def _int_list(x):
-    return [int(v) for v in x.split(',')]
+def _chromosome_list(text):
+    return [int(token) for token in text.split(',')]
+
+
+#: options shared by `test` and `testbatch`: (flag, argparse settings)
+_TEST_OPTIONS = (
+    ('-minzscore', dict(type=float, default=None,
+                        help='fixed |z| cut per bin instead of the one derived from -multitest')),
+    ('-chromosomes', dict(type=_chromosome_list, default=list(range(1, 23)),
+                          help='autosomes to segment, comma separated (default 1..22)')),
+    ('-mineffectsize', dict(type=float, default=0,
+                            help='ignore windows whose median ratio deviates less than this from 1')),
+    ('-multitest', dict(type=float, default=1000,
+                        help='number of samples the false-positive budget is spread over')),
+    ('-minrefbins', dict(type=int, default=25,
+                         help='bins with fewer usable reference bins are left out')),
+    ('-repeats', dict(type=int, default=5,
+                      help='z-score passes, aberrant bins masked between passes')),
+)
 
 
 def buildParser():
     parser = argparse.ArgumentParser(
-        description="WISECONDOR (WIthin-SamplE COpy Number aberration DetectOR) -- MI355X build")
-    subparsers = parser.add_subparsers()
+        description='WISECONDOR newref / test on AMD MI355X (drop-in for the upstream sub-commands)')
+    sub = parser.add_subparsers()
 
     for name in ('convert', 'plot', 'report'):
-        p = subparsers.add_parser(name, description='not provided by this build')
+        p = sub.add_parser(name, description='not provided by this build')
         p.add_argument('rest', nargs=argparse.REMAINDER)
-        p.set_defaults(func=_out_of_scope)
+        p.set_defaults(func=_not_in_this_build)
 
-    parser_newref = subparsers.add_parser('newref',
-        description='Create a new reference using healthy reference samples')
-    parser_newref.add_argument('infiles', type=str, nargs='*',
-        help='Path and all to reference data files (i.e. ./reference/*.npz)')
-    parser_newref.add_argument('outfile', type=str,
-        help='Path and filename for the reference output (i.e. ./reference/myref.npz)')
-    parser_newref.add_argument('-refsize', type=int, default=100,
-        help='Amount of reference locations per target')
-    parser_newref.add_argument('-binsize', type=int, default=None,
-        help='Try to scale samples to this binsize, multiples of existing binsize only')
-    parser_newref.add_argument('-cpus', type=int, default=1,
-        help='Accepted for compatibility: sets the number of parts (one GPU runs them in turn)')
-    parser_newref.add_argument('-parts', type=int, default=1,
-        help='Split reference finding in this many jobs, only used if > cpus')
-    parser_newref.set_defaults(func=toolNewref)
+    p = sub.add_parser('newref', description='Build a reference from healthy samples in one go')
+    p.add_argument('infiles', type=str, nargs='*', help='converted reference samples (.npz)')
+    p.add_argument('outfile', type=str, help='reference file to write (.npz)')
+    p.add_argument('-refsize', type=int, default=100, help='reference bins kept per target bin')
+    p.add_argument('-binsize', type=int, default=None,
+                   help='merge sample bins to this size first (a multiple of their own size)')
+    p.add_argument('-cpus', type=int, default=1,
+                   help='upstream worker count: sets the number of part files and, up to the '
+                        'number of visible GPUs, of GPU processes')
+    p.add_argument('-parts', type=int, default=1, help='number of part files when larger than -cpus')
+    p.add_argument('-gpus', type=int, default=None, help='GPU processes to use (build-only option)')
+    p.set_defaults(func=toolNewref)
 
-    parser_newrefprep = subparsers.add_parser('newrefprep',
-        description='Prepare creation of new reference split over several processes')
-    parser_newrefprep.add_argument('infiles', type=str, nargs='*',
-        help='Path and all to reference data files (i.e. ./reference/*.npz)')
-    parser_newrefprep.add_argument('prepfile', type=str,
-        help='Path and filename for the prep output (i.e. ./reference/myref_prep.npz)')
-    parser_newrefprep.add_argument('-binsize', type=int, default=None,
-        help='Try to scale samples to this binsize, multiples of existing binsize only')
-    parser_newrefprep.set_defaults(func=toolNewrefPrep)
+    p = sub.add_parser('newrefprep', description='Step 1 of a split reference build: the prep file')
+    p.add_argument('infiles', type=str, nargs='*', help='converted reference samples (.npz)')
+    p.add_argument('prepfile', type=str, help='prep file to write (.npz)')
+    p.add_argument('-binsize', type=int, default=None,
+                   help='merge sample bins to this size first (a multiple of their own size)')
+    p.set_defaults(func=toolNewrefPrep)
 
-    parser_newrefpart = subparsers.add_parser('newrefpart',
-        description='Creation of new reference split over several processes')
-    parser_newrefpart.add_argument('prepfile', type=str,
-        help='Path and filename for the prep file  (i.e. ./reference/myref_prep.npz)')
-    parser_newrefpart.add_argument('partfile', type=str,
-        help='Path and basename for the reference part output, receives _m.npz extension from part argument')
-    parser_newrefpart.add_argument('part', type=int, default=[0, 1], nargs=2,
-        help='Part m out of n parts, appends _m.npz to file name')
-    parser_newrefpart.add_argument('-refsize', type=int, default=100,
-        help='Amount of reference locations per target')
-    parser_newrefpart.set_defaults(func=toolNewrefPart)
+    p = sub.add_parser('newrefpart', description='Step 2 of a split reference build: one part')
+    p.add_argument('prepfile', type=str, help='prep file of step 1')
+    p.add_argument('partfile', type=str, help='base name of the part files; _<m>.npz is appended')
+    p.add_argument('part', type=int, default=[0, 1], nargs=2, help='m n: compute part m of n')
+    p.add_argument('-refsize', type=int, default=100, help='reference bins kept per target bin')
+    p.set_defaults(func=toolNewrefPart)
 
-    parser_newrefpost = subparsers.add_parser('newrefpost',
-        description='Combine creation of new reference split over several processes')
-    parser_newrefpost.add_argument('prepfile', type=str,
-        help='Path and filename for the prep file  (i.e. ./reference/myref_prep.npz)')
-    parser_newrefpost.add_argument('partfile', type=str,
-        help='Path and basename to reference part data files, appends _m.npz depending on parts')
-    parser_newrefpost.add_argument('parts', type=int, default=1,
-        help='Used combine all data parts, represents n parts previously specified')
-    parser_newrefpost.add_argument('outfile', type=str,
-        help='Path and filename for the reference output (i.e. ./reference/myref.npz)')
-    parser_newrefpost.set_defaults(func=toolNewrefPost)
+    p = sub.add_parser('newrefpost', description='Step 3 of a split reference build: the merge')
+    p.add_argument('prepfile', type=str, help='prep file of step 1')
+    p.add_argument('partfile', type=str, help='base name of the part files of step 2')
+    p.add_argument('parts', type=int, default=1, help='how many parts step 2 was split into')
+    p.add_argument('outfile', type=str, help='reference file to write (.npz)')
+    p.set_defaults(func=toolNewrefPost)
 
-    parser_test = subparsers.add_parser('test', description='Test sample for Copy Number Aberrations')
-    parser_test.add_argument('infile', type=str, help='Sample to test')
-    parser_test.add_argument('outfile', type=str, help='Basename of files to write')
-    parser_test.add_argument('reference', type=str, help='Reference as previously created')
-    parser_test.add_argument('-minzscore', type=float, default=None, help='Minimum absolute z-score')
-    parser_test.add_argument('-chromosomes', help="Integer of every chromosome to test, comma delimited",
-                             type=_int_list, default=list(range(1, 23)))
-    parser_test.add_argument('-mineffectsize', type=float, default=0,
-        help='Minimum absolute relative change in read depth')
-    parser_test.add_argument('-multitest', type=float, default=1000,
-        help='Increase z-score to compensate for multiple sample testing')
-    parser_test.add_argument('-minrefbins', type=int, default=25,
-        help='Minimum amount of sensible ref bins per target bin')
-    parser_test.add_argument('-repeats', type=int, default=5, help='Repeats when calling')
-    parser_test.set_defaults(func=toolTest)
+    p = sub.add_parser('test', description='Call copy number aberrations in one sample')
+    p.add_argument('infile', type=str, help='converted sample (.npz)')
+    p.add_argument('outfile', type=str, help='result file to write (.npz)')
+    p.add_argument('reference', type=str, help='reference built by newref')
+    for flag, settings in _TEST_OPTIONS:
+        p.add_argument(flag, **settings)
+    p.set_defaults(func=toolTest)
 
-    # build-only addition: the same test for many samples per GPU batch
-    parser_tb = subparsers.add_parser('testbatch', description='Test many samples in GPU batches')
-    parser_tb.add_argument('infiles', type=str, nargs='+', help='Samples to test')
-    parser_tb.add_argument('outdir', type=str, help='Directory for the <sample>_test.npz outputs')
-    parser_tb.add_argument('reference', type=str, help='Reference as previously created')
-    parser_tb.add_argument('-batch', type=int, default=256, help='Samples per GPU batch')
-    parser_tb.add_argument('-minzscore', type=float, default=None, help='Minimum absolute z-score')
-    parser_tb.add_argument('-chromosomes', type=_int_list, default=list(range(1, 23)),
-                           help='Chromosomes to test, comma delimited')
-    parser_tb.add_argument('-mineffectsize', type=float, default=0,
-                           help='Minimum absolute relative change in read depth')
-    parser_tb.add_argument('-multitest', type=float, default=1000,
-                           help='Increase z-score to compensate for multiple sample testing')
-    parser_tb.add_argument('-minrefbins', type=int, default=25,
-                           help='Minimum amount of sensible ref bins per target bin')
-    parser_tb.add_argument('-repeats', type=int, default=5, help='Repeats when calling')
-    parser_tb.set_defaults(func=toolTestBatch)
+    p = sub.add_parser('testbatch', description='test for many samples per GPU batch (build-only)')
+    p.add_argument('infiles', type=str, nargs='+', help='converted samples (.npz)')
+    p.add_argument('outdir', type=str, help='directory receiving <sample>_test.npz')
+    p.add_argument('reference', type=str, help='reference built by newref')
+    p.add_argument('-batch', type=int, default=256, help='samples per GPU batch')
+    p.add_argument('-gpus', type=int, default=None, help='GPU processes to shard the samples over')
+    p.add_argument('-io', type=int, default=8, help='file decode / encode threads')
+    for flag, settings in _TEST_OPTIONS:
+        p.add_argument(flag, **settings)
+    p.set_defaults(func=toolTestBatch)
     return parser
 
 

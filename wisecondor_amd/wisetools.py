@@ -350,59 +350,8 @@ def test_batch(reference, samples, threshold, minrefbins=25, repeats=5, chromoso
 
 
 # ---------------------------------------------------------------------------
-# newref prep (upstream of the hot path, still host numpy)
+# newref prep (upstream of the hot path)
 # ---------------------------------------------------------------------------
-def toNumpyArray(samples):
-    """Samples -> masked unit-sum [bins, samples] matrix (wisetools.py:240-264)."""
-    byChrom = []
-    chromBins = []
-    for chromosome in range(1, 23):
-        maxLen = max([sample[str(chromosome)].shape[0] for sample in samples])
-        thisChrom = np.zeros((maxLen, len(samples)), dtype=float)
-        chromBins.append(maxLen)
-        for i, sample in enumerate(samples):
-            thisChrom[:, i] = sample[str(chromosome)]
-        byChrom.append(thisChrom)
-    allData = np.concatenate(byChrom, axis=0)
-    with np.errstate(all='ignore'):
-        allData = allData / np.sum(allData, 0)
-    print('Applying nonzero mask on the data:', allData.shape, end=' ')
-    mask = np.sum(allData, 1) > 0
-    maskedData = allData[mask, :]
-    print('becomes', maskedData.shape)
-    return maskedData, chromBins, mask
-
-
-class _PCAResult(object):
-    def __init__(self, components, mean):
-        self.components_ = components
-        self.mean_ = mean
-
-
-def trainPCA(refData, pcacomp=3):
-    """Rank-`pcacomp` PCA correction of the reference set (wisetools.py:89-101).
-
-    Deterministic exact SVD (what scikit-learn's svd_solver='full' computes, with
-    its sign convention); the reference's auto-selected randomized solver is not
-    reproducible run to run.  Returns (corrected.T, pca)
-    with corrected.T Fortran-ordered exactly like the reference's, which fixes
-    the summation order getReference must reproduce.
-    """
-    tData = refData.T
-    mean = np.mean(tData, axis=0)
-    centred = tData - mean
-    _, _, vt = np.linalg.svd(centred, full_matrices=False)
-    max_abs = np.argmax(np.abs(vt), axis=1)
-    signs = np.sign(vt[range(vt.shape[0]), max_abs])
-    vt = vt * signs[:, np.newaxis]
-    comps = np.ascontiguousarray(vt[:pcacomp])
-    transformed = np.dot(centred, comps.T)
-    inversed = np.dot(transformed, comps) + mean
-    with np.errstate(all='ignore'):
-        corrected = tData / inversed
-    return corrected.T, _PCAResult(comps, mean)
-
-
 def prepReference(samples, pcacomp=3, device=0):
     """toNumpyArray + trainPCA (wisetools.py:240-264, 89-101) with the bins-sized work on the GPU.
 
