@@ -23,6 +23,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import wc_oracle as wo  # noqa: E402
 
 
+def wait_for_go(folder, part):
+    """Report ready, then wait for bench.py's common start signal (absent when run by hand)."""
+    open(os.path.join(folder, "ready_%d" % part), "w").close()
+    if os.environ.get("WC_CPU_BASELINE_NO_WAIT"):
+        return
+    t_end = time.time() + 600
+    while not os.path.exists(os.path.join(folder, "go")) and time.time() < t_end:
+        time.sleep(0.005)
+
+
 def newref(folder, part, parts, rows):
     corrected = np.load(os.path.join(folder, "corrected.npy"))       # Fortran order preserved
     ref = np.load(os.path.join(folder, "reference.npz"))
@@ -32,6 +42,7 @@ def newref(folder, part, parts, rows):
     B = corrected.shape[0]
     lo, hi = wo.get_part(part, parts, B)
     hi = min(hi, lo + rows)
+    wait_for_go(folder, part)
     # the oracle's driver works on whole parts: express [lo, hi) as part 1 of 1 of a row window by
     # calling the per-chromosome kernel exactly as get_reference does (wisetools.py:373-390)
     t0 = time.perf_counter()
@@ -56,6 +67,7 @@ def test(folder, part):
     reference["binsize"] = np.float64(ref["binsize"])
     stored = np.load(os.path.join(folder, "sample_%d.npz" % part))
     sample = {key: stored[key] for key in stored.files}
+    wait_for_go(folder, part)
     t0 = time.perf_counter()
     with np.errstate(all="ignore"):
         out = wo.test_sample(sample, float(ref["binsize"]), reference)

@@ -1,0 +1,125 @@
+"""BASELINE config 5 (batched `test`, 50 kb bins), one GPU's share: 125 samples.
+
+* The real reference's fillTri + segmentTri on the three longest 50 kb chromosomes of sample 0
+  (tests/golden/cfg5_50kb.npz; about 11 M windows each, minutes of np.sum per chromosome --
+  tools/make_goldens.py --only cfg5): segment bounds exact, segment values, the whole-chromosome
+  z and 400 random window values per chromosome bit-equal.
+* The 125-sample batch (tools/cfg5_case.py): sample 0's cleaned z vectors reproduce the golden
+  inputs bit for bit (the z-score path is deterministic and carries numpy's bits), its calls on
+  chromosomes 1-3 are the reference's segments mapped to genomic bins, the CPU oracle's
+  repeat_test agrees bit for bit with three samples of the batch, and the oracle's own
+  segmentation agrees on the short chromosomes (19-22) of those samples.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import wc_oracle as wo
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def same_bits(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if a.shape != b.shape:
+        return False
+    nan = np.isnan(a) & np.isnan(b)
+    return bool(np.all(nan | (a.view(np.int64) == b.view(np.int64))))
+
+
+@pytest.fixture(scope="module")
+def wt():
+    from wisecondor_amd import wisetools
+    return wisetools
+
+
+@pytest.fixture(scope="module")
+def g(golden):
+    return golden("cfg5_50kb.npz")
+
+
+@pytest.fixture(scope="module")
+def case(wt):
+    import cfg5_case
+    from wisecondor_amd import synth
+    c = cfg5_case.build(wt, synth)
+    yield c
+    c["reference"].close()
+
+
+def test_segments_of_the_longest_50kb_chromosomes(wt, g):
+    thr = float(g["threshold"])
+    zs = [g["z_chr%d" % c] for c in (1, 2, 3)]
+    assert [len(z) for z in zs] == [4722, 4609, 3747]
+    whole, segs = wt.stouffer_segments(zs, thr, 3)
+    for j, c in enumerate((1, 2, 3)):
+        want = g["seg_chr%d" % c]
+        got = np.array([[v, x, y] for v, (x, y) in segs[j]], dtype=np.float64).reshape(-1, 3)
+        assert np.array_equal(got[:, 1:], want[:, 1:]), (c, got, want)
+        assert same_bits(got[:, 0], want[:, 0]), c
+        assert same_bits([whole[j]], [g["whole_chr%d" % c]]), c
+    assert len(g["seg_chr1"]) >= 1 and len(g["seg_chr2"]) >= 1          # the planted gain / loss are there
+
+
+def test_window_values_of_the_triangle(wt, g):
+    """fillTri's values (wisetools.py:471) at 400 random windows per chromosome: getValue of the mirror."""
+    from wisecondor_amd.triarray import TriArr
+    for c in (1, 3):
+        tri = TriArr.from_region(g["z_chr%d" % c])
+        xs, ys, vs = g["tri_x_chr%d" % c], g["tri_y_chr%d" % c], g["tri_v_chr%d" % c]
+        # one batched call: every window as its own region
+        regions = [g["z_chr%d" % c][int(x):int(y) + 1] for x, y in zip(xs, ys)]
+        whole, _ = wt.stouffer_segments(regions, np.inf, 3)
+        assert same_bits(whole, vs), c
+        assert same_bits([tri.getValue(int(xs[0]), int(ys[0]))], [vs[0]])
+
+
+def test_batch_of_125_samples(wt, g, case):
+    import cfg5_case
+    thr = case["threshold"]
+    assert thr == float(g["threshold"])
+    assert np.array_equal(case["masked_bins"], g["masked_bins"])
+    outs = wt.test_batch(case["reference"], case["tests"], thr)
+    assert len(outs) == 125
+    assert np.array_equal([len(o["results_calls"]) for o in outs], g["n_calls_all"])
+    # sample 0: the golden's input vectors are reproduced, and its calls on chromosomes 1-3 are the
+    # reference's segments in genomic coordinates
+    zs, rs, xpca, (z, r, n, sd) = cfg5_case.cleaned_regions(wt, case, 0)
+    for c in (1, 2, 3):
+        assert same_bits(zs[c - 1], g["z_chr%d" % c]), c
+    calls0 = np.asarray(outs[0]["results_calls"], dtype=np.float64).reshape(-1, 5)
+    assert np.array_equal(calls0, g["calls_sample0"])
+    for c in (1, 2, 3):
+        mine = calls0[calls0[:, 0] == c]
+        want = g["seg_chr%d" % c]
+        assert len(mine) == len(want), c
+        assert same_bits(mine[:, 3], want[:, 0]), c                     # the call's z is the segment's value
+        for row, (v, x, y) in zip(mine, want):                          # effect = median(ratio[x..y]) - 1
+            assert row[4] == np.median(rs[c - 1][int(x):int(y) + 1]) - 1, c
+    planted = [row for row in calls0 if row[0] in (1.0, 2.0) and row[2] - row[1] > 300]
+    assert len(planted) >= 2
+    # the batch's z-scores against the CPU oracle's repeat_test, all bins, three samples
+    ref = case["reference"]
+    ms = [int(v) for v in case["masked_bins"]]
+    msum = [int(v) for v in np.cumsum(ms)]
+    for i in (0, 5, 124):
+        zs_i, rs_i, xp, (zg, rg, ng, sdg) = cfg5_case.cleaned_regions(wt, case, i)
+        with np.errstate(all="ignore"):
+            zo, ro, no, sdo = wo.repeat_test(np.copy(xp), ref.indexes, ref.distances, ms, msum, ref.cutoff, thr, 5)
+        assert np.array_equal(ng, no), i
+        assert same_bits(zg, zo) and same_bits(rg, ro), i
+        assert sdg == sdo, i
+        # and the oracle's fillTri + segmentTri on the short chromosomes of this sample
+        calls = np.asarray(outs[i]["results_calls"], dtype=np.float64).reshape(-1, 5)
+        for c in (19, 20, 21, 22):
+            tri = wo.fill_tri(zs_i[c - 1])
+            want = wo.segment_tri(tri, len(zs_i[c - 1]), thr, 3)
+            mine = calls[calls[:, 0] == c]
+            assert len(mine) == len(want), (i, c)
+            assert same_bits(mine[:, 3], [v for v, _ in want]), (i, c)
+            assert same_bits([outs[i]["results_cwz"][c - 1]], [tri[len(zs_i[c - 1]) - 1]]), (i, c)

@@ -142,3 +142,65 @@ def test_testbatch_equals_single_tests(tmp_path, golden):
         assert float(a["asdef"]) == float(b["asdef"])
         want = g["t_%s_results_calls" % n]
         assert np.array_equal(np.asarray(b["results_calls"]).reshape(-1, 5)[:, :3], want[:, :3])
+
+
+def test_newref_on_two_ranks_equals_one(tmp_path, golden, monkeypatch):
+    """`newref -cpus 2 -gpus 2`: one process per rank (here two ranks sharing the box's GPU, gloo for
+    the collectives; RCCL needs one GPU per rank), same part files, same reference as one rank."""
+    from wisecondor_amd import wisecondor as cli
+    g = golden("cfg1_pipeline.npz")
+    lengths = g["sample_chrom_lengths"]
+    infiles = []
+    for i, row in enumerate(g["ref_samples"]):
+        p = str(tmp_path / ("ref_%02d.npz" % i))
+        _write_sample(p, row, lengths, float(g["binsize"]))
+        infiles.append(p)
+    one = str(tmp_path / "one.npz")
+    cli.main(["newref"] + infiles + [one, "-refsize", "100", "-parts", "3"])
+    monkeypatch.setenv("WC_RANKS_BACKEND", "gloo")
+    two = str(tmp_path / "two.npz")
+    cli.main(["newref"] + infiles + [two, "-refsize", "100", "-cpus", "3", "-gpus", "2"])
+    assert not os.path.exists(str(tmp_path / "two_prep.npz")) and not os.path.exists(str(tmp_path / "two_part_2.npz"))
+    a = np.load(one, allow_pickle=True)
+    b = np.load(two, allow_pickle=True)
+    assert set(a.files) == set(b.files)
+    for key in ("indexes", "distances", "mask", "masked_sizes", "pca_mean", "pca_components", "chromosome_sizes"):
+        assert np.array_equal(a[key], b[key]), key
+    assert b["arguments"].item()["parts"] == 3
+
+    # testbatch on two ranks: every sample's file equals the one-rank file
+    names = ["mild18", "gain5_gap", "loss2", "normal", "gain5_past"]
+    paths = []
+    for n in names:
+        p = str(tmp_path / ("s_%s.npz" % n))
+        _write_sample(p, g["t_%s_sample" % n], lengths, float(g["binsize"]))
+        paths.append(p)
+    cli.main(["testbatch"] + paths + [str(tmp_path / "o1"), one, "-batch", "2"])
+    cli.main(["testbatch"] + paths + [str(tmp_path / "o2"), one, "-batch", "2", "-gpus", "2"])
+    for n in names:
+        x = np.load(str(tmp_path / "o1" / ("s_%s_test.npz" % n)), allow_pickle=True)
+        y = np.load(str(tmp_path / "o2" / ("s_%s_test.npz" % n)), allow_pickle=True)
+        assert np.array_equal(x["results_calls"], y["results_calls"])
+        assert np.array_equal(np.concatenate(list(x["results_z"])), np.concatenate(list(y["results_z"])))
+        assert float(x["asdef"]) == float(y["asdef"])
+        want = g["t_%s_results_calls" % n]
+        assert np.array_equal(np.asarray(y["results_calls"]).reshape(-1, 5)[:, :3], want[:, :3])
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py --gpus 2 starts two ranks itself; with the gloo backend they share the one GPU.
+    The JSON line must carry the world size it really ran with and the measured shard mode."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--no-extra", "--workload",
+                        "cfg1", "--steps", "2", "--warmup", "1", "--test-samples", "32", "--no-cpu-baseline"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["world_size"] == 2
+    assert line["config"]["shard_mode"] in ("tiles", "rows")
+    assert set(line["config"]["shard_calibration_s"]) == {"tiles", "rows"}
+    assert line["value"] > 0 and line["test"]["value"] > 0

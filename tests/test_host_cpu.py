@@ -182,12 +182,13 @@ def test_cpu_baseline_worker(tmp_path):
     idx, dst = wo.get_reference(data, bins, sums, 15, 1, 1, fast=True)
     np.save(str(tmp_path / "corrected.npy"), data)
     np.savez(str(tmp_path / "reference.npz"), bins=bins, k=15, binsize=1e6)
-    rc, out, err = _run(["oracle/cpu_baseline.py", "newref", str(tmp_path), "0", "1", "40"])
+    nowait = {"WC_CPU_BASELINE_NO_WAIT": "1"}
+    rc, out, err = _run(["oracle/cpu_baseline.py", "newref", str(tmp_path), "0", "1", "40"], env=nowait)
     assert rc == 0, err
     line = json.loads(out.strip().splitlines()[-1])
     assert line["rows"] == [0, 40] and line["seconds"] > 0
     assert np.array_equal(np.load(str(tmp_path / "newref_0.npy")), idx[:40])
-    rc, out, err = _run(["oracle/cpu_baseline.py", "newref", str(tmp_path), "3", "4", "25"])
+    rc, out, err = _run(["oracle/cpu_baseline.py", "newref", str(tmp_path), "3", "4", "25"], env=nowait)
     lo, hi = wo.get_part(3, 4, data.shape[0])
     assert rc == 0 and json.loads(out.strip().splitlines()[-1])["rows"] == [lo, min(hi, lo + 25)]
 

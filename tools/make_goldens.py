@@ -446,6 +446,37 @@ def cfg3_cases(wt, wc, n_ref=100, binsize=250000):
     out["test_names"] = np.array(names)
     return out
 
+
+# ---------------------------------------------------------------- cfg5 -----
+def cfg5_cases(wt):
+    """BASELINE config 5 (50 kb): the real reference's fillTri + segmentTri on the three longest
+    chromosomes of one sample.  The z vectors come from this repo's GPU
+    path on the deterministic case of tools/cfg5_case.py (gpurun_out/cfg5_z.npz, written on the
+    GPU box by tools/gpu_cfg5_z.py); ~11 M windows per chromosome, a few minutes of np.sum."""
+    src = np.load(os.path.join(ROOT, "gpurun_out", "cfg5_z.npz"))
+    out = {"threshold": np.float64(src["threshold"]), "calls_sample0": src["calls_sample0"],
+           "masked_bins": src["masked_bins"], "n_calls_all": src["n_calls_all"]}
+    thr = float(src["threshold"])
+    for c in (1, 2, 3):
+        z = np.asarray(src["z_chr%d" % c], dtype=np.float64)
+        with np.errstate(all="ignore"):
+            tri = wt.fillTri(z)
+            segs = tri.segmentTri(thr, 3)
+            whole = tri.getValue(0, len(z) - 1)
+        out["z_chr%d" % c] = z
+        out["r_chr%d" % c] = np.asarray(src["r_chr%d" % c], dtype=np.float64)
+        out["whole_chr%d" % c] = np.float64(whole)
+        out["seg_chr%d" % c] = np.array([[v, x, y] for v, (x, y) in segs], dtype=np.float64).reshape(-1, 3)
+        # spot values of the triangle itself (the packed array is 11 M doubles: not stored)
+        rng = np.random.RandomState(c)
+        xs = rng.randint(0, len(z), size=400)
+        ys = np.array([rng.randint(x, len(z)) for x in xs])
+        out["tri_x_chr%d" % c], out["tri_y_chr%d" % c] = xs.astype(np.int32), ys.astype(np.int32)
+        out["tri_v_chr%d" % c] = np.array([tri.getValue(int(x), int(y)) for x, y in zip(xs, ys)])
+        print("chr%d" % c, len(z), "segments", out["seg_chr%d" % c][:, 1:].tolist(),
+              "gpu said", src["gpu_seg_chr%d" % c][:, 1:].tolist(), flush=True)
+    return out
+
 # ------------------------------------------------------------- binsize -----
 def scale_cases(wt):
     """scaleSample + a 2-sample newrefprep at a merged bin size (wisetools.py:220-264)."""
@@ -472,6 +503,8 @@ def main():
         save(os.path.join(GOLD, "layout_cases.npz"), **layout_cases(wt))
     if args.only in (None, "cfg3"):
         save(os.path.join(GOLD, "cfg3_250kb.npz"), **cfg3_cases(wt, wc))
+    if args.only == "cfg5":
+        save(os.path.join(GOLD, "cfg5_50kb.npz"), **cfg5_cases(wt))
     if args.only is not None:
         return
     save(os.path.join(GOLD, "newref_kernel.npz"), **newref_cases(wt))

@@ -107,10 +107,15 @@ __global__ __launch_bounds__(256) void k_convert(const double *__restrict__ X, i
                                                  unsigned short *__restrict__ S16, float *__restrict__ s_norm_lo,
                                                  int *__restrict__ s_chrom, int2 *__restrict__ s_range,
                                                  float *__restrict__ thr, int *__restrict__ cnt,
-                                                 int *__restrict__ row_stat, unsigned short *__restrict__ A3) {
+                                                 int *__restrict__ row_stat, unsigned short *__restrict__ A3,
+                                                 double *__restrict__ X64, int64_t Sp) {
     int lane = threadIdx.x & 63;
     int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= Bpad) return;
+    // float64 image with rows padded to whole 16-sample chunks (128-byte aligned rows, zero
+    // padding): the re-score gathers read it with aligned 16-byte loads and no tail cases
+    if (X64 && row < B)
+        for (int64_t s = lane; s < Sp; s += 64) X64[row * Sp + s] = s < S ? X[row * S + s] : 0.0;
     const int slot = row < B ? sample_slot[row] : -1;   // >= 0: this row is one of the sampled rows
     double acc = 0.0;
     for (int64_t s = lane; s < Kpad16; s += 64) {
@@ -1171,6 +1176,365 @@ __global__ __launch_bounds__(NT, 4) void k_finish(FinishArgs a) {
     if (tid == 0) a.row_stat[row] = R;  // >= 0: fast path, number of float64 re-scores
 }
 
+// ------------------------------------------------------- pair engine (finish) ----
+// The same stage D as k_finish, cut into a light per-row pass and a throughput pass:
+//   k_pick     one WAVE per row (no workgroup barriers): k-th key by a bitwise search with
+//              ballot counts, upper bound U of the k-th true distance, certificate, and the
+//              candidates with key <= U written as (row, candidate) pairs into the row's
+//              RMAX pair slots; rows without a certificate (or with more pairs) go to the
+//              exact path;
+//   k_rescore  one wave per 64 pairs of a row (a row with more than `ps` pairs, ps = the
+//              workgroup's thread count, takes several trips): float64 distances in numpy's order with all
+//              lanes busy -- 16-sample chunks staged through a wave-private LDS slab (the
+//              wave's own DS operations complete in order: no barrier inside the loop) --
+//              then, after the one barrier that joins the row's waves, the counting order and
+//              the output row.
+// k_finish needs six dependent phases with workgroup barriers per row (26.6 us per row at
+// 100 samples); here the selection runs at full lane occupancy for four rows per workgroup and
+// the re-score loop never waits for another wave.
+constexpr int PS_MAX = 512;       // most threads of a k_rescore workgroup (pairs re-scored per trip)
+
+struct PickArgs {
+    FinishArgs f;
+    int *pairs;                   // [rows, RMAX] candidate rows of the fast path
+    int ps;                       // threads per k_rescore workgroup: k + margin rounded up to whole waves
+};
+
+// Selection for one row by one wave; NE list entries per lane.  Returns the number of pairs, -1
+// when the row has no certificate (exact path).
+template <int NE>
+__device__ inline int pick_row(const PickArgs &p, int64_t row, int lane, int n, bool admit_all, float thr_f,
+                               float nhi_f) {
+    const FinishArgs &a = p.f;
+    const unsigned long long *lst = a.list + row * a.cap;
+    unsigned long long ent[NE];
+    float nh[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int t = e * 64 + lane;
+        ent[e] = t < n ? lst[t] : ~0ull;
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int t = e * 64 + lane;
+        nh[e] = t < n ? a.norm_hi[(int)(uint32_t)ent[e]] : 0.f;
+    }
+    double U = INFINITY;   // admit-all rows with fewer than k candidates re-score everything
+    if (n < a.k) {
+        if (!admit_all) return -1;
+    } else {
+        // k-th smallest lower bound: its 20 leading bits (rounded up) gate a superset of the k smallest
+        uint32_t res = 0;
+        for (int bit = 31; bit >= 12; --bit) {
+            const uint32_t trial = res | (1u << bit);
+            int c = 0;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) c += __popcll(__ballot((uint32_t)(ent[e] >> 32) < trial));
+            if (c <= a.k - 1) res = trial;
+        }
+        res |= 0xFFFu;
+        // upper bound of the k-th true distance: the largest upper bound among those entries
+        const double nhi = (double)nhi_f;
+        double my = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const uint32_t ku = (uint32_t)(ent[e] >> 32);
+            if (e * 64 + lane < n && ku <= res) {
+                const double ub = (double)wc::f32_from_ordered(ku) + 3.0 * a.beta * (nhi + (double)nh[e]) + 1e-36;
+                my = fmax(my, ub);
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) my = fmax(my, __shfl_xor(my, o));
+        U = my;
+        // every candidate that was never listed has a lower bound > thr: need thr >= U
+        if (!(U == U) || (!admit_all && !(U <= (double)thr_f))) return -1;
+    }
+    int base = 0;
+    int *out = p.pairs + row * RMAX;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const bool keep = e * 64 + lane < n && (double)wc::f32_from_ordered((uint32_t)(ent[e] >> 32)) <= U;
+        const unsigned long long m = __ballot(keep);
+        const int at = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (keep && at < RMAX) out[at] = (int)(uint32_t)ent[e];
+        base += __popcll(m);
+    }
+    return base;
+}
+
+__global__ __launch_bounds__(256) void k_pick(PickArgs p) {
+    const FinishArgs &a = p.f;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = a.row_begin + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.row_end) return;
+    const int c = a.cnt[row];
+    const float thr_f = a.thr[row];
+    const float nhi_f = a.norm_hi[row];
+    const int ch = a.chrom_of_row[row];
+    const bool admit_all = (thr_f == WC_ADMIT_ALL);
+    const bool exact = c > a.cap || ((a.lone_mask >> ch) & 1ull);   // lost entries / C-ordered chromData: exact path
+    int R = -1;
+    if (!exact) R = c <= 512 ? pick_row<8>(p, row, lane, c, admit_all, thr_f, nhi_f)
+                             : pick_row<LIST_CAP / 64>(p, row, lane, c, admit_all, thr_f, nhi_f);
+    if (lane != 0) return;
+    if (R < 0 || R > RMAX) {
+        const int at = atomicAdd(a.fb_count, 1);
+        a.fb_rows[at] = (int)row;
+        a.row_stat[row] = -1;              // exact fallback path
+        return;
+    }
+    a.row_stat[row] = R;                   // >= 0: fast path, number of float64 re-scores
+}
+
+// Sum of a candidate's squared differences in numpy's order, fed chunk by chunk (ST_CH samples,
+// one lane per candidate): the sequential order is one running sum; the pairwise order keeps
+// numpy's eight strided accumulators per leaf (<= 128 samples, boundaries from the host-built
+// leaf table) and folds the leaf sums with a small value stack.
+// value stack of the pairwise fold, addressed by a wave-uniform index through a switch (stays in
+// registers); numpy's tree over S <= 8192 samples nests at most seven leaves deep
+__device__ inline void vs_set(double (&v)[8], int i, double x) {
+    switch (i) {
+        case 0: v[0] = x; break; case 1: v[1] = x; break; case 2: v[2] = x; break; case 3: v[3] = x; break;
+        case 4: v[4] = x; break; case 5: v[5] = x; break; case 6: v[6] = x; break; default: v[7] = x; break;
+    }
+}
+__device__ inline double vs_get(const double (&v)[8], int i) {
+    switch (i) {
+        case 0: return v[0]; case 1: return v[1]; case 2: return v[2]; case 3: return v[3];
+        case 4: return v[4]; case 5: return v[5]; case 6: return v[6]; default: return v[7];
+    }
+}
+
+template <bool SEQ>
+struct RowSum {
+    double acc;
+    double r[8];
+    double vs[8];
+    int sp, leaf;
+    bool in_tail;
+    int2 lf;
+    __device__ inline void init(const FinishArgs &a) {
+        acc = 0.0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = 0.0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vs[e] = 0.0;
+        sp = 0; leaf = 0; in_tail = false;
+        lf = SEQ ? make_int2(0, 0) : a.pw_prog[0];
+    }
+    // v[0..15] = this candidate's squares of samples c0 .. c0 + 15 (registers: every index below is
+    // a compile-time constant); full: all sixteen are real samples
+    __device__ inline void chunk_regs(const FinishArgs &a, const double (&v)[ST_CH], int64_t c0, bool full) {
+        if (SEQ) {
+#pragma unroll
+            for (int e = 0; e < ST_CH; ++e) acc = acc + v[e];
+            return;
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int64_t base = c0 + 8 * g;
+            if (base >= a.S) break;
+            const int cntg = full ? 8 : ((a.S - base) < 8 ? (int)(a.S - base) : 8);
+            if (in_tail || cntg < 8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (e < cntg) acc = acc + v[8 * g + e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r[e] = r[e] + v[8 * g + e];
+                leaf_end(a, base);
+            }
+        }
+    }
+    // after a complete group of eight at `base`: close the leaf when its body ends here
+    __device__ inline void leaf_end(const FinishArgs &a, int64_t base) {
+        if (base + 8 == (int64_t)(lf.x - (lf.x & 7))) {   // body of the current leaf complete
+            const double val = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = 0.0;
+            if (lf.x & 7) {          // last leaf with a tail: added after the combine
+                acc = val;
+                in_tail = true;
+            } else {
+                vs_set(vs, sp++, val);
+                for (int q = 0; q < lf.y; ++q) {
+                    const double right = vs_get(vs, --sp), left = vs_get(vs, sp - 1);
+                    vs_set(vs, sp - 1, left + right);
+                }
+                ++leaf;
+                if (leaf < a.pw_leaves) lf = a.pw_prog[leaf];
+            }
+        }
+    }
+    __device__ inline double result() {
+        if (SEQ) return acc;
+        if (in_tail) {
+            vs_set(vs, sp++, acc);
+            for (int q = 0; q < lf.y; ++q) {
+                const double right = vs_get(vs, --sp), left = vs_get(vs, sp - 1);
+                vs_set(vs, sp - 1, left + right);
+            }
+        }
+        return vs[0];
+    }
+};
+
+__device__ inline void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One workgroup (ps threads = ps / 64 waves) per row; see the header of this section.
+// Xp is the padded float64 image (rows of Sp = 16 n samples, zero padded, 128-byte aligned): every
+// chunk of every candidate row is one aligned cache line, fetched by eight lanes with 16-byte loads
+// (scalar chunk base + 32-bit lane offset: no per-load address arithmetic), and there are no tail
+// cases -- the zero padding adds +0.0 to sums that are >= +0 (or NaN), which is exact.
+// Wave slab: 64 candidate rows x 128 bytes, the 16-byte pieces of a row XOR-swizzled by
+// f(row) = bits {1, 2, 4} of the row number, which makes the transposing writes (eight lanes
+// fill one row) and the per-candidate reads (sixteen lanes, sixteen rows) conflict free without
+// padding; the piece addresses are loop invariants held in registers.
+// Dynamic LDS: [target row: Sp doubles][wave slabs: 8 KB each]; after the sums (one barrier) the
+// slab memory holds dk / jv (distances and candidates as computed) and sd / sj (in order).
+constexpr int SLAB_DOUBLES = 64 * ST_CH;
+template <bool SEQ>
+__global__ __launch_bounds__(PS_MAX, SEQ ? 4 : 3) void k_rescore(PickArgs p, const double *__restrict__ Xp, int Sp) {
+    const FinishArgs &a = p.f;
+    extern __shared__ __attribute__((aligned(16))) double rs_dyn[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t row = a.row_begin + blockIdx.x;
+    const int R = a.row_stat[row];
+    if (R < 0) return;                                   // exact path (workgroup-uniform)
+    double *xs = rs_dyn;
+    char *slab = reinterpret_cast<char *>(rs_dyn + Sp + w * SLAB_DOUBLES);
+    {
+        const double *xi = Xp + row * Sp;
+        for (int s = tid; s < Sp; s += p.ps) xs[s] = xi[s];
+    }
+    __syncthreads();
+    const int l8 = lane & 7, r0 = lane >> 3;
+    constexpr int NP = 8;                                // 8 rows per pass x 8 passes = the wave's 64 candidates
+    constexpr int TRIPS = RMAX / 128;                    // a wave's trips with the smallest workgroup (two waves)
+    auto swz = [](int r) { return ((r >> 1) & 3) | (((r >> 4) & 1) << 2); };
+    int waddr[NP], raddr[NP];                            // byte offsets in the slab: written pieces, read pieces
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int rw = r0 + 8 * q;
+        waddr[q] = rw * 128 + ((l8 ^ swz(rw)) << 4);
+        raddr[q] = lane * 128 + ((q ^ swz(lane)) << 4);
+    }
+    unsigned long long my_d[TRIPS];
+    int my_j[TRIPS];
+    int trip = 0;
+    const int nchunk = Sp / ST_CH;
+    const char *base = reinterpret_cast<const char *>(Xp);
+    for (int b0 = w * 64; b0 < R; b0 += p.ps, ++trip) {
+        const int nb = R - b0 < 64 ? R - b0 : 64;        // pairs of this wave in this trip
+        const int *cjp = p.pairs + row * RMAX + b0;
+        const int cj = cjp[lane < nb ? lane : 0];        // lanes beyond nb re-read the trip's first candidate; their sums are dropped
+        unsigned int src[NP];                            // byte offset of this lane's 16 bytes in chunk 0 of row r0 + 8 q
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+            src[q] = ((unsigned int)__shfl(cj, r0 + 8 * q) * (unsigned int)Sp + 2u * (unsigned int)l8) * 8u;
+        f64x2 pre[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) pre[q] = *(const f64x2 *)(base + src[q]);
+        RowSum<SEQ> sum;
+        sum.init(a);
+        for (int c = 0; c < nchunk; ++c) {
+            const f64x2 x2 = *(const f64x2 *)&xs[c * ST_CH + 2 * l8];
+            wave_lds_fence();                            // the previous chunk's reads are done
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const double d0 = pre[q].x - x2.x, d1 = pre[q].y - x2.y;
+                f64x2 sq2;
+                sq2.x = d0 * d0;
+                sq2.y = d1 * d1;
+                *(f64x2 *)(slab + waddr[q]) = sq2;
+            }
+            wave_lds_fence();
+            if (c + 1 < nchunk) {
+                const char *cb = base + (size_t)(c + 1) * (ST_CH * 8);      // wave-uniform chunk base
+#pragma unroll
+                for (int q = 0; q < NP; ++q) pre[q] = *(const f64x2 *)(cb + src[q]);
+            }
+            double v[ST_CH];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const f64x2 t2 = *(const f64x2 *)(slab + raddr[q]);
+                v[2 * q] = t2.x;
+                v[2 * q + 1] = t2.y;
+            }
+            sum.chunk_regs(a, v, (int64_t)c * ST_CH, (c + 1) * ST_CH <= a.S);
+        }
+        const double d = sum.result();
+        const bool ok = lane < nb && d < SENTINEL_DISTANCE;  // NaN and >= 1e10 are never admitted (wisetools.py:314)
+        const unsigned long long dd = ok ? wc::f64_ordered(d) : ~0ull;
+        const int jj = ok ? cj : 0x40000000 + b0 + lane;      // unique, after every real index
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t)
+            if (t == trip) { my_d[t] = dd; my_j[t] = jj; }
+    }
+    __syncthreads();                                     // every wave is through with its slab
+    unsigned long long *dk = reinterpret_cast<unsigned long long *>(rs_dyn + Sp);
+    unsigned long long *sd = dk + RMAX + 2;
+    int *jv = reinterpret_cast<int *>(sd + RMAX);
+    int *sj = jv + RMAX + 2;
+    {
+        int t2 = 0;
+        for (int b0 = w * 64; b0 < R; b0 += p.ps, ++t2) {
+#pragma unroll
+            for (int t = 0; t < TRIPS; ++t)
+                if (t == t2 && b0 + lane < R) { dk[b0 + lane] = my_d[t]; jv[b0 + lane] = my_j[t]; }
+        }
+    }
+    // Order by counting: element t goes to slot #{u : d_u < d_t}.  Equal distances are rare; they
+    // land on one slot and leave a hole, which sends the row through a second sweep with the
+    // index as tie-break (stable (distance, position) order, wisetools.py:313-321).
+    if (tid == 0 && (R & 1)) dk[R] = ~0ull;
+    for (int t = tid; t < R; t += p.ps) sj[t] = -1;
+    __syncthreads();
+    for (int t = tid; t < R; t += p.ps) {
+        const unsigned long long mine = dk[t];
+        int rank = 0;
+        for (int u = 0; u < R; u += 2) {
+            const u64x2 kk = *(const u64x2 *)&dk[u];
+            rank += kk.x < mine;
+            rank += kk.y < mine;
+        }
+        sd[rank] = mine;
+        sj[rank] = jv[t];
+    }
+    __syncthreads();
+    int hole = 0;
+    for (int t = tid; t < R; t += p.ps) hole |= sj[t] == -1;
+    if (__syncthreads_or(hole)) {
+        for (int t = tid; t < R; t += p.ps) {
+            const unsigned long long mine = dk[t];
+            const int myj = jv[t];
+            int rank = 0;
+            for (int u = 0; u < R; ++u) rank += (dk[u] < mine) | ((dk[u] == mine) & (jv[u] < myj));
+            sd[rank] = mine;
+            sj[rank] = myj;
+        }
+        __syncthreads();
+    }
+    const int ch = a.chrom_of_row[row];
+    const int64_t cs = a.chrom_off[ch], ce = a.chrom_off[ch + 1];
+    const int64_t orow = row - a.row_begin;
+    for (int t = tid; t < a.k; t += p.ps) {
+        int32_t oi = -1;                                 // fewer candidates than k: sentinels (wisetools.py:305-306)
+        double od = SENTINEL_DISTANCE;
+        if (t < R && sd[t] != ~0ull) {
+            const int myj = sj[t];
+            oi = (int32_t)(myj < cs ? myj : myj - (ce - cs));
+            od = wc::f64_from_ordered(sd[t]);
+        }
+        a.idx_out[orow * a.k + t] = oi;
+        a.dist_out[orow * a.k + t] = od;
+    }
+}
+
 // Exact path for rows whose certificate failed (ties at the boundary, outlier
 // rows, list overflow): every distance in float64, then k rounds of
 // lexicographic (distance, position) minimum selection.
@@ -1504,6 +1868,15 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
 
     int rc;
     if ((rc = st.col_mean.reserve(sizeof(double) * 3 * n_samples))) return rc;
+    // padded float64 image for the pair engine's gathers (32-bit byte offsets: below 4 GB; the
+    // target row and two chunk slabs per wave must fit the LDS: up to 2048 samples)
+    st.s_pad = round_up(n_samples, 16);
+    {
+        const char *eng = getenv("WC_FINISH_ENGINE");
+        st.x64_pad = !(eng && strcmp(eng, "rows") == 0) && n_samples <= 2048 &&
+                     st.bins_pad * st.s_pad * 8 < (1ll << 32);
+    }
+    if (st.x64_pad && (rc = st.x64.reserve(sizeof(double) * st.bins_pad * st.s_pad))) return rc;
     // one operand image: float32 for the fp32 matrix cores, hi/lo bfloat16 pairs for the split tiles
     if (!st.split && (rc = st.a32.reserve(sizeof(float) * st.bins_pad * st.k_pad))) return rc;
     if (st.split && (rc = st.a3.reserve(sizeof(float) * st.bins_pad * st.k_pad))) return rc;
@@ -1587,7 +1960,8 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
                        st.chrom_range.as<int2>(), (const int *)st.sample_slot.as<int>(),
                        st.s16.as<unsigned short>(), st.s_norm_lo.as<float>(), st.s_chrom.as<int>(),
                        st.s_range.as<int2>(), st.thr.as<float>(), st.cnt.as<int>(), st.stats.as<int>(),
-                       st.split ? st.a3.as<unsigned short>() : (unsigned short *)nullptr);
+                       st.split ? st.a3.as<unsigned short>() : (unsigned short *)nullptr,
+                       st.x64_pad ? st.x64.as<double>() : (double *)nullptr, st.s_pad);
     if (M > n_bins)
         hipLaunchKernelGGL(k_pad_samples, dim3((unsigned)(M - n_bins)), dim3(256), 0, stream, st.k_pad16, n_bins,
                            st.s16.as<unsigned short>(), st.s_norm_lo.as<float>(), st.s_chrom.as<int>(),
@@ -1788,7 +2162,24 @@ static int newref_finish_part(wc_ctx *ctx, void *stream_, int64_t row_begin, int
     a.xs_in_lds = st.n_samples <= 2048;
     a.pw_prog = st.pw_prog.as<int2>();
     a.pw_leaves = st.pw_leaves;
-    if (which & 1) {
+    const char *eng = getenv("WC_FINISH_ENGINE");   // "rows": the one-workgroup-per-row kernel (k_finish) for every row
+    // pair engine: workgroups of k + margin threads (whole waves); refsize beyond PS_MAX - 28 takes several trips
+    const int ps = (int)std::max<int64_t>(128, std::min<int64_t>(PS_MAX, round_up(st.k + 28, 64)));
+    if ((which & 1) && st.x64_pad && !(eng && strcmp(eng, "rows") == 0)) {
+        const bool seq = st.sum_order == WC_SUM_SEQUENTIAL || st.n_samples < 8;
+        if ((rc = st.pairs.reserve(sizeof(int) * st.bins_pad * RMAX))) return rc;
+        PickArgs p{a, st.pairs.as<int>(), ps};
+        const unsigned rows = (unsigned)(row_end - row_begin);
+        hipLaunchKernelGGL(k_pick, dim3((rows + 3) / 4), dim3(256), 0, stream, p);
+        // wave slabs; after the sums the same memory holds dk / sd / jv / sj of the counting order
+        const size_t slabs = sizeof(double) * (size_t)(ps / 64) * SLAB_DOUBLES;
+        const size_t order = (sizeof(unsigned long long) + sizeof(int)) * (2 * RMAX + 4);
+        const size_t dyn = sizeof(double) * st.s_pad + std::max(slabs, order);
+        if (seq) hipLaunchKernelGGL((k_rescore<true>), dim3(rows), dim3(ps), dyn, stream, p,
+                                    (const double *)st.x64.as<double>(), (int)st.s_pad);
+        else hipLaunchKernelGGL((k_rescore<false>), dim3(rows), dim3(ps), dyn, stream, p,
+                                (const double *)st.x64.as<double>(), (int)st.s_pad);
+    } else if (which & 1) {
         const bool seq = st.sum_order == WC_SUM_SEQUENTIAL || st.n_samples < 8;
         const char *e = getenv("WC_FINISH_THREADS");
         const int nt = e ? atoi(e) : 128;   // 128 threads per row measured faster at every size tried
