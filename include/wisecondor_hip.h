@@ -71,7 +71,8 @@ void wc_get_part(int64_t partnum, int64_t outof, int64_t bincount, int64_t *star
  *                (wisetools.py:386-387), -1 padded
  * dist_out       [row_end-row_begin, k] float64 ascending, 1e10 padded
  * Results equal the reference bit for bit (stable (distance, position) order,
- * numpy pairwise-summed float64 distances).
+ * numpy pairwise-summed float64 distances).  k <= 1024; above 256 every row is
+ * scanned exactly (the candidate lists are sized for refsize <= 256): slower, same bits.
  */
 int wc_get_reference(wc_ctx *ctx, const double *corrected, int64_t n_bins, int64_t n_samples,
                      const int64_t *chrom_bins, int n_chrom, int k, int sum_order,
@@ -163,7 +164,7 @@ typedef struct wc_reference wc_reference;
  *   pca_mean [n_bins], pca_components [n_comp, n_bins] float64.
  * cutoff_override: NULL to compute the cutoff, else the value to use (the
  * reference passes it explicitly to repeatTest, wisetools.py:438).
- * Limits: k <= 128 (one numpy pairwise block), n_comp <= 8.
+ * Limits: k <= 1024 (lists above 128 entries take a slower generic kernel), n_comp <= 8.
  */
 wc_reference *wc_reference_create(wc_ctx *ctx, const int32_t *indexes, const double *distances,
                                   int64_t n_bins, int k, const int64_t *chromosome_sizes,

@@ -168,8 +168,8 @@ def test_error_reporting_through_the_c_abi(wt):
         wt.Reference(np.zeros((4, 2), np.int32), np.ones((4, 2)), [3, 3], [2, 2], np.array([1, 1, 1, 0, 1, 0], np.uint8),
                      np.ones(4), np.zeros((0, 4)))
     with pytest.raises(_lib.WisecondorHipError, match="unsupported shape"):
-        wt.Reference(np.zeros((4, 200), np.int32), np.ones((4, 200)), [2, 2], [2, 2], np.ones(4, np.uint8),
-                     np.ones(4), np.zeros((0, 4)))           # refsize 200 > 128 in the test path
+        wt.Reference(np.zeros((4, 2000), np.int32), np.ones((4, 2000)), [2, 2], [2, 2], np.ones(4, np.uint8),
+                     np.ones(4), np.zeros((0, 4)))           # refsize 2000 > 1024 in the test path
     # and the context is still usable afterwards
     idx, dst = wt.getReference(np.arange(40.0).reshape(10, 4), [5, 5], [5, 10], 2)
     assert idx.shape == (10, 2) and np.all(idx >= 0)

@@ -293,3 +293,21 @@ def test_cfg3_test_sample(golden, name):
     assert np.allclose(got[:, 3:], want[:, 3:], rtol=1e-9, atol=0)
     assert np.allclose(np.concatenate(out["results_z"]), g["t_%s_results_z" % name], rtol=1e-9, atol=1e-11)
     assert np.allclose(out["results_cwz"], g["t_%s_results_cwz" % name], rtol=1e-9, atol=1e-11)
+
+
+def test_refsize_300_oracle(golden):
+    """-refsize 300: the oracle's selection and z-scores against the real reference."""
+    import hashlib
+    g1, g = golden("cfg1_pipeline.npz"), golden("refsize300.npz")
+    X = np.asfortranarray(g1["prep_correctedData"])
+    bins = [int(v) for v in g1["prep_maskedChromBins"]]
+    sums = [int(v) for v in np.cumsum(bins)]
+    idx, dst = wo.get_reference(X, bins, sums, 300, 1, 1, fast=True)
+    assert np.array_equal(idx, g["ref_indexes"])
+    assert hashlib.sha256(np.ascontiguousarray(dst).tobytes()).hexdigest() == str(g["ref_distances_sha256"])
+    cutoff, _ = wo.get_optimal_cutoff(dst, 3)
+    assert cutoff == float(g["cutoff"])
+    thr = float(g1["t_loss2_threshold_z"])
+    z, r, n, sd = wo.repeat_test(np.copy(g1["t_loss2_xpca"]), idx, dst, bins, sums, cutoff, thr, 5)
+    assert np.array_equal(n, g["t_loss2_rep5_n"].astype(np.float64))
+    assert same_bits(z, g["t_loss2_rep5_z"]) and sd == float(g["t_loss2_rep5_sd"])

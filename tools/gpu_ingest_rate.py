@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""End-to-end files/s of `testbatch`: N converted-sample files on local disk ->
+GPU batches -> N result files, with the decode / encode pools at 1 thread (the reference's serial
+np.load loop, wisecondor.py:193-196) and at several pool sizes.  Also times the pooled sample load
+of `newrefprep`.  Run on the GPU box; prints one JSON line."""
+import argparse
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from wisecondor_amd import ingest, synth  # noqa: E402
+from wisecondor_amd import wisecondor as cli  # noqa: E402
+from wisecondor_amd import wisetools as wt  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--files", type=int, default=512)
+ap.add_argument("--binsize", type=int, default=250000)
+ap.add_argument("--batch", type=int, default=128)
+a = ap.parse_args()
+tmp = tempfile.mkdtemp(prefix="wc_ingest_")
+profile = synth.bin_profile(a.binsize)
+refs = [synth.make_sample(profile, seed=i) for i in range(40)]
+_, chrom_bins, mask, corrected, comps, mean, masked_bins = wt.prepReference(refs)
+masked_bins = np.asarray(masked_bins, dtype=np.int64)
+idx, dst = wt.getReference(corrected, masked_bins, np.cumsum(masked_bins), 100, 1, 1)
+refpath = os.path.join(tmp, "reference.npz")
+np.savez_compressed(refpath, arguments={}, runtime={}, binsize=float(a.binsize), indexes=idx, distances=dst,
+                    chromosome_sizes=np.asarray(chrom_bins), mask=mask, masked_sizes=masked_bins,
+                    pca_components=comps, pca_mean=mean)
+paths = []
+for i in range(a.files):
+    p = os.path.join(tmp, "s_%04d.npz" % i)
+    np.savez_compressed(p, arguments={"binsize": float(a.binsize)}, runtime={}, sample=synth.make_sample(profile, seed=3000 + i), quality={})
+    paths.append(p)
+out = {"files": a.files, "binsize": a.binsize, "batch": a.batch, "testbatch": {}}
+import contextlib
+import io
+for threads in (1, 4, 16):
+    outdir = os.path.join(tmp, "out_%d" % threads)
+    argv = ["testbatch"] + paths + [outdir, refpath, "-batch", str(a.batch), "-io", str(threads)]
+    buf = io.StringIO()
+    t0 = time.time()
+    with contextlib.redirect_stdout(buf):
+        cli.main(argv)
+    wall = time.time() - t0
+    line = [ln for ln in buf.getvalue().splitlines() if ln.startswith("rank 0")][-1]
+    out["testbatch"]["io_%d" % threads] = {"wall_s_incl_reference_load": wall, "report": line}
+    shutil.rmtree(outdir, ignore_errors=True)
+for threads in (1, 16):
+    t0 = time.time()
+    ingest.load_samples(paths[:256], None, threads=threads)
+    out["load_samples_256_files_threads_%d_s" % threads] = time.time() - t0
+shutil.rmtree(tmp, ignore_errors=True)
+print(json.dumps(out))

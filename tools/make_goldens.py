@@ -477,6 +477,66 @@ def cfg5_cases(wt):
               "gpu said", src["gpu_seg_chr%d" % c][:, 1:].tolist(), flush=True)
     return out
 
+
+# ---------------------------------------------------------- refsize 300 -----
+def refsize300_cases(wt, wc):
+    """`-refsize 300` (beyond one numpy pairwise block in `test`, beyond the candidate lists' design
+    size in `newref`): the reference's newrefpart / newrefpost / test on the 1 Mb prep seam of
+    cfg1_pipeline.npz."""
+    import hashlib
+    g = np.load(os.path.join(GOLD, "cfg1_pipeline.npz"))
+    tmp = tempfile.mkdtemp(prefix="wc_gold300_")
+    prep = os.path.join(tmp, "ref_prep.npz")
+    corrected = np.asfortranarray(g["prep_correctedData"])
+    ms = [int(v) for v in g["prep_maskedChromBins"]]
+    np.savez_compressed(prep, binsize=np.float64(g["binsize"]), chromosomeBins=g["prep_chromosomeBins"],
+                        maskedData=g["prep_maskedData"], mask=g["prep_mask"], maskedChromBins=ms,
+                        maskedChromBinSums=[sum(ms[:i + 1]) for i in range(len(ms))], correctedData=corrected,
+                        pca_components=g["prep_pca_components"], pca_mean=g["prep_pca_mean"], arguments={}, runtime={})
+    assert np.load(prep)["correctedData"].flags["F_CONTIGUOUS"]
+    refpath = os.path.join(tmp, "reference.npz")
+    with quiet(), np.errstate(all="ignore"):
+        wc.toolNewrefPart(argparse.Namespace(prepfile=prep, partfile=os.path.join(tmp, "ref_part"), part=[1, 1], refsize=300))
+        wc.toolNewrefPost(argparse.Namespace(prepfile=prep, partfile=os.path.join(tmp, "ref_part"), parts=1, outfile=refpath))
+    rz = np.load(refpath)
+    dist = np.ascontiguousarray(rz["distances"], dtype=np.float64)
+    out = {"k": np.int64(300), "ref_indexes": np.asarray(rz["indexes"], dtype=np.int32),
+           "ref_distances_sha256": np.array(hashlib.sha256(dist.tobytes()).hexdigest()),
+           "ref_distance_rows": np.arange(0, dist.shape[0], 97, dtype=np.int64), "ref_distances_sampled": dist[::97].copy()}
+    with np.errstate(all="ignore"):
+        cutoff, _ = wt.getOptimalCutoff(rz["distances"], 3)
+    out["cutoff"] = np.float64(cutoff)
+    keys = synth.CHROM_KEYS
+    lengths = g["sample_chrom_lengths"]
+    offs = np.concatenate([[0], np.cumsum(lengths)])
+    msum = [sum(ms[:i + 1]) for i in range(len(ms))]
+    for name in ("gain5_gap", "loss2"):
+        flat = g["t_%s_sample" % name]
+        s = {k: np.asarray(flat[offs[i]:offs[i + 1]], dtype=np.int32) for i, k in enumerate(keys)}
+        sp = os.path.join(tmp, "test_%s.npz" % name)
+        write_sample(sp, s, float(g["binsize"]))
+        op = os.path.join(tmp, "out_%s.npz" % name)
+        args = argparse.Namespace(infile=sp, outfile=op, reference=refpath, minzscore=None,
+                                  chromosomes=list(range(1, 23)), mineffectsize=0, multitest=1000,
+                                  minrefbins=25, repeats=5)
+        with quiet(), np.errstate(all="ignore"):
+            try:
+                wc.toolTest(args)
+            except SystemExit:
+                pass
+        tz = np.load(op)
+        out["t_%s_results_z" % name] = np.concatenate(list(tz["results_z"]))
+        out["t_%s_results_cwz" % name] = np.asarray(tz["results_cwz"], dtype=np.float64)
+        out["t_%s_results_calls" % name] = np.asarray(tz["results_calls"], dtype=np.float64).reshape(-1, 5)
+        out["t_%s_asdef" % name] = np.float64(tz["asdef"])
+        with quiet(), np.errstate(all="ignore"):
+            z, r, n, sd = wt.repeatTest(np.copy(g["t_%s_xpca" % name]), rz["indexes"], rz["distances"], ms, msum,
+                                        cutoff, float(tz["threshold_z"]), 5)
+        out["t_%s_rep5_z" % name], out["t_%s_rep5_r" % name] = z, r
+        out["t_%s_rep5_n" % name], out["t_%s_rep5_sd" % name] = np.asarray(n, dtype=np.int16), np.float64(sd)
+        print(name, "max refs", int(np.max(n)), "calls", out["t_%s_results_calls" % name][:, :3].tolist(), flush=True)
+    return out
+
 # ------------------------------------------------------------- binsize -----
 def scale_cases(wt):
     """scaleSample + a 2-sample newrefprep at a merged bin size (wisetools.py:220-264)."""
@@ -494,7 +554,7 @@ def scale_cases(wt):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default=None, help="regenerate one file only: layout | cfg3 | cfg5")
+    ap.add_argument("--only", default=None, help="regenerate one file only: layout | cfg3 | cfg5 | refsize300")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     wt, wc, _tri = ref_loader.load(full_svd=True)
@@ -503,6 +563,8 @@ def main():
         save(os.path.join(GOLD, "layout_cases.npz"), **layout_cases(wt))
     if args.only in (None, "cfg3"):
         save(os.path.join(GOLD, "cfg3_250kb.npz"), **cfg3_cases(wt, wc))
+    if args.only == "refsize300":
+        save(os.path.join(GOLD, "refsize300.npz"), **refsize300_cases(wt, wc))
     if args.only == "cfg5":
         save(os.path.join(GOLD, "cfg5_50kb.npz"), **cfg5_cases(wt))
     if args.only is not None:

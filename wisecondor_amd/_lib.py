@@ -82,6 +82,7 @@ def load():
             raise WisecondorHipError(
                 "%s is missing and could not be built (%s): run `python -m wisecondor_amd.build` "
                 "(this package has no CPU fallback)" % (LIB_PATH, exc))
+    _share_torch_hip_runtime()
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
@@ -89,6 +90,26 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  The PyTorch wheel bundles its own libamdhip64.so; if this
+    library pulled the system ROCm's copy in first, a later `import torch` would initialise a second
+    runtime and see no GPU.  So when torch is installed (not necessarily imported), its copy is
+    loaded first, globally; libwisecondor_hip.so's libamdhip64.so.N then resolves to it."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def check(rc):

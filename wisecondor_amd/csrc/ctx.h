@@ -26,6 +26,7 @@ struct NewrefState {
     wc::DevBuf keys1, thr, cnt, list, tiles;
     wc::DevBuf fb_rows, fb_count, fb_scratch, stats, tiles0, pw_prog, pairs, x64;
     int64_t s_pad = 0;      // samples padded to whole 16-sample chunks (x64 row stride)
+    bool exact_only = false; // refsize beyond the candidate lists' design size: every row takes the exact path
     bool x64_pad = false;   // the padded float64 image exists (pair engine usable)
     int pw_leaves = 0;
     int64_t pw_for = -1;
@@ -44,7 +45,13 @@ struct TestState {
     wc::DevBuf zs, rs2, ns2, sub, tmin, tmax, prefix, reg_abs, reg_flag, rs, jobs_a, jobs_b, job_cnt, partial, job_res, hot, cand, cand_cnt;
     wc::DevBuf seg, seg_cnt, out_val, out_x, out_y, out_n, whole, effect, misc, misc2, reduce_tmp, win_bits, bit_off, pairs_a, pairs_b, cut_vals;
     int64_t rs_len = 0;
-    int64_t last_segs = 0;
+    int64_t last_segs = 0;       // segments of the last segmentation call; negative: -(bound), the count is on the device
+    int lat_left = 1;
+    // latency mode: the captured call (hipGraph), the arguments it was captured for, and whether
+    // an eager call of that shape has sized the workspaces
+    hipGraphExec_t lat_exec = nullptr;
+    std::vector<int64_t> lat_key;
+    bool lat_warm = false;            // latency mode: index of the counter that holds the jobs left after the last round
     // optional stage timing of wc_test_batch_dev (wc_test_profile): events on the launch stream
     // between the stages, and counts of the window evaluations the search kernels executed
     bool profile = false;
@@ -79,6 +86,8 @@ struct wc_ctx {
     size_t pinned_bytes = 0;
     int64_t last_stats[8] = {0};
     // side stream for work that only feeds an output (overlaps with the main stream)
+    hipStream_t lat_stream = nullptr;      // latency-mode calls of the test path run (and are captured) here
+    hipEvent_t ev_lat_in = nullptr;
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool side_pending = false;

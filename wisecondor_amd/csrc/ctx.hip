@@ -53,6 +53,9 @@ void wc_destroy(wc_ctx *ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     for (hipEvent_t e : ctx->ts.prof_ev) (void)hipEventDestroy(e);
+    if (ctx->ts.lat_exec) (void)hipGraphExecDestroy(ctx->ts.lat_exec);
+    if (ctx->lat_stream) (void)hipStreamDestroy(ctx->lat_stream);
+    if (ctx->ev_lat_in) (void)hipEventDestroy(ctx->ev_lat_in);
     delete ctx;
 }
 

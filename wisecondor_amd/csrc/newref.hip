@@ -32,6 +32,7 @@ constexpr int ROLE_ROWS = 1;   // targets are the tile's rows (P side)
 constexpr int ROLE_COLS = 2;   // targets are the tile's columns (Q side)
 constexpr int MAX_SAMPLE_COLS = 4096;
 constexpr int LIST_CAP = 1024;
+constexpr int K_MAX = 1024;       // largest refsize (the exact path's selection buffers); above LIST_CAP / 4 every row takes the exact path
 constexpr int FB_BLOCKS = 512;
 #define WC_ADMIT_ALL FLT_MAX
 constexpr double SENTINEL_DISTANCE = 1e10;  // wisetools.py:306
@@ -57,17 +58,24 @@ __global__ __launch_bounds__(1024) void k_col_centre(const double *__restrict__ 
     __shared__ double sh_v[64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int64_t s = (int64_t)blockIdx.x * 64 + tx;
+    // the (at most 128) sampled rows of this sample are read ONCE into registers: the three
+    // passes were three dependent memory round trips before (10 us for a kernel that moves 100 KB)
+    constexpr int PER = 8;                      // n_rows <= 128 = 16 row phases x 8
+    double val[PER];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const int64_t q = ty + 16 * e;
+        val[e] = (s < S && q < n_rows) ? X[(q * row_step) * S + s] : NAN;
+    }
     double c = 0.0, rad = 0.0;
     for (int pass = 0; pass < 3; ++pass) {
         double sum = 0.0, cnt = 0.0;
-        if (s < S) {
-#pragma unroll 8
-            for (int64_t q = ty; q < n_rows; q += 16) {
-                double v = X[(q * row_step) * S + s];
-                bool ok = isfinite(v) && (pass != 2 || fabs(v - c) <= rad);
-                sum += ok ? ((pass == 1) ? fabs(v - c) : v) : 0.0;
-                cnt += ok ? 1.0 : 0.0;
-            }
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const double v = val[e];
+            const bool ok = isfinite(v) && (pass != 2 || fabs(v - c) <= rad);
+            sum += ok ? ((pass == 1) ? fabs(v - c) : v) : 0.0;
+            cnt += ok ? 1.0 : 0.0;
         }
         sh_s[ty][tx] = sum;
         sh_c[ty][tx] = cnt;
@@ -1644,7 +1652,7 @@ __device__ inline void fb_select(const FinishArgs &a, int64_t row, const unsigne
         const unsigned long long v = sc[j];
         if (take > 0 && (v < kth || (v == kth && (int)j <= jth))) {
             const int at = atomicAdd(&s_int[0], 1);
-            if (at < 256) { selk[at] = v; selj[at] = (int)j; }
+            if (at < K_MAX) { selk[at] = v; selj[at] = (int)j; }
         }
     }
     __syncthreads();
@@ -1700,8 +1708,8 @@ __global__ __launch_bounds__(256) void k_fallback_fill(FinishArgs a, unsigned lo
 // fallback rows beyond FB_BLOCKS (pathological inputs) run both steps here, one row at a
 // time per workgroup, in the workgroup's own scratch slot.
 __global__ __launch_bounds__(256) void k_fallback(FinishArgs a, unsigned long long *scratch, int64_t Bpad) {
-    __shared__ unsigned long long rk[256];
-    __shared__ int rj[256];
+    __shared__ unsigned long long rk[K_MAX];
+    __shared__ int rj[K_MAX];
     __shared__ unsigned int hist[256];
     __shared__ double xs[2048];
     const int tid = threadIdx.x;
@@ -1721,6 +1729,16 @@ __global__ __launch_bounds__(256) void k_fallback(FinishArgs a, unsigned long lo
         __syncthreads();
         fb_select(a, row, sc, rk, rj, hist, tid);
     }
+}
+
+// refsize above LIST_CAP / 4 (the candidate lists are sized for refsize <= 256): every row of the
+// range takes the exact path.
+__global__ void k_all_exact(FinishArgs a) {
+    const int64_t row = a.row_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= a.row_end) return;
+    a.fb_rows[row - a.row_begin] = (int)row;
+    a.row_stat[row] = -1;
+    if (row == a.row_begin) *a.fb_count = (int)(a.row_end - a.row_begin);
 }
 
 // Multi-GPU exchange helpers: pack / merge per-row candidate lists.
@@ -1824,7 +1842,7 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
     WC_CHECK(n_bins > 0 && n_samples > 0 && k > 0, WC_E_ARG, "newref: empty problem");
     WC_CHECK(n_chrom > 0 && n_chrom <= WC_MAX_CHROM, WC_E_ARG, "newref: n_chrom out of range");
     WC_CHECK(n_samples <= 8192, WC_E_LIMIT, "newref: more than 8192 samples not supported");
-    WC_CHECK(k <= LIST_CAP / 4, WC_E_LIMIT, "newref: refsize above %d not supported", LIST_CAP / 4);
+    WC_CHECK(k <= K_MAX, WC_E_LIMIT, "newref: refsize above %d not supported", K_MAX);
     WC_CHECK(n_bins < (1ll << 31) - 256, WC_E_LIMIT, "newref: too many bins");
     WC_CHECK(n_bins * n_samples < (1ll << 32), WC_E_LIMIT, "newref: more than 2^32 matrix elements not supported");
     WC_CHECK(sum_order == WC_SUM_PAIRWISE || sum_order == WC_SUM_SEQUENTIAL, WC_E_ARG, "newref: bad sum_order");
@@ -1838,6 +1856,7 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
     st.k = k;
     st.corrected = corrected;
     st.sum_order = sum_order;
+    st.exact_only = k > LIST_CAP / 4;      // the lists hold ~4 k candidates per row: beyond 256 every row is scanned exactly
     st.chrom_off[0] = 0;
     for (int c = 0; c < n_chrom; ++c) {
         WC_CHECK(chrom_bins_host[c] >= 0, WC_E_ARG, "newref: negative chromosome size");
@@ -1975,7 +1994,7 @@ int wc_newref_thresholds_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int6
     WC_CHECK(ctx && ctx->nr.prepared, WC_E_ARG, "newref: prepare has not run");
     NewrefState &st = ctx->nr;
     WC_CHECK(row_begin >= 0 && row_begin <= row_end && row_end <= st.n_bins, WC_E_ARG, "newref: bad row range");
-    if (row_begin == row_end) return WC_OK;
+    if (row_begin == row_end || st.exact_only) return WC_OK;
     hipStream_t stream = (hipStream_t)stream_;
     const int ib = (int)(row_begin / TB), ie = (int)((row_end + TB - 1) / TB);
     const int mb = (int)(st.n_sample_cols / TB);
@@ -2073,7 +2092,7 @@ int wc_newref_collect_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t
     NewrefState &st = ctx->nr;
     WC_CHECK(row_begin >= 0 && row_begin <= row_end && row_end <= st.n_bins, WC_E_ARG, "newref: bad row range");
     WC_CHECK(tile_ranks >= 1 && tile_rank >= 0 && tile_rank < tile_ranks, WC_E_ARG, "newref: bad tile rank");
-    if (row_begin == row_end) return WC_OK;
+    if (row_begin == row_end || st.exact_only) return WC_OK;
     hipStream_t stream = (hipStream_t)stream_;
     std::vector<int64_t> key = {st.n_bins, row_begin, row_end, tile_rank, tile_ranks};
     for (int c = 0; c <= st.n_chrom; ++c) key.push_back(st.chrom_off[c]);
@@ -2165,7 +2184,10 @@ static int newref_finish_part(wc_ctx *ctx, void *stream_, int64_t row_begin, int
     const char *eng = getenv("WC_FINISH_ENGINE");   // "rows": the one-workgroup-per-row kernel (k_finish) for every row
     // pair engine: workgroups of k + margin threads (whole waves); refsize beyond PS_MAX - 28 takes several trips
     const int ps = (int)std::max<int64_t>(128, std::min<int64_t>(PS_MAX, round_up(st.k + 28, 64)));
-    if ((which & 1) && st.x64_pad && !(eng && strcmp(eng, "rows") == 0)) {
+    if ((which & 1) && st.exact_only) {
+        const unsigned rows = (unsigned)(row_end - row_begin);
+        hipLaunchKernelGGL(k_all_exact, dim3((rows + 255) / 256), dim3(256), 0, stream, a);
+    } else if ((which & 1) && st.x64_pad && !(eng && strcmp(eng, "rows") == 0)) {
         const bool seq = st.sum_order == WC_SUM_SEQUENTIAL || st.n_samples < 8;
         if ((rc = st.pairs.reserve(sizeof(int) * st.bins_pad * RMAX))) return rc;
         PickArgs p{a, st.pairs.as<int>(), ps};

@@ -627,6 +627,63 @@ __global__ __launch_bounds__(256) void k_zscore_pairs(const unsigned int *__rest
     }
 }
 
+// Reference lists longer than 128 entries (-refsize above 128): numpy's pairwise sum is then a
+// tree whose shape depends on the NUMBER of kept values, so the kept values are first compacted, in
+// list order, into an LDS buffer and then summed with wc::pairwise_sum over that buffer (mean,
+// then the squared deviations).  One wave per (bin, sample) pair, grid-strided; `pairs` as in
+// k_zscore_pairs (NULL: every pair).  Slower than the <= 128 kernels, same bits as numpy.
+constexpr int BIG_K = 1024;         // longest reference list (LDS buffer of a wave)
+__global__ __launch_bounds__(256) void k_zscore_big(const unsigned int *__restrict__ pairs,
+                                                    const int *__restrict__ count, int64_t n_all,
+                                                    unsigned int *__restrict__ dirty,
+                                                    const double *__restrict__ XT, const double *__restrict__ XC,
+                                                    const int *__restrict__ gidx, const int *__restrict__ nref,
+                                                    int k, int64_t Ns, double *__restrict__ zT,
+                                                    double *__restrict__ rT, double *__restrict__ nT,
+                                                    double *__restrict__ sdT) {
+    __shared__ double kept[4][BIG_K];
+    const int64_t n_pairs = pairs ? (int64_t)*count : n_all;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, sub = lane & 7;
+    double *buf = kept[w];
+    for (int64_t t = (int64_t)blockIdx.x * 4 + w; t < n_pairs; t += (int64_t)gridDim.x * 4) {
+        const unsigned int gid = pairs ? pairs[t] : (unsigned int)t;
+        if (pairs && lane == 0) atomicAnd(&dirty[gid >> 5], ~(1u << (gid & 31)));
+        const int64_t b = gid / Ns, i = gid - b * Ns;
+        const int *lst = gidx + b * k;
+        const int n = nref[b];
+        int m = 0;
+        __builtin_amdgcn_wave_barrier();
+        for (int base = 0; base < n; base += 64) {
+            const int r = base + lane;
+            const int g = r < n ? lst[r] : -1;
+            const double v = g >= 0 ? XC[(int64_t)g * Ns + i] : -1.0;
+            const bool keep = v >= 0.0;          // flagged (-1), negative and NaN values are dropped (wisetools.py:425)
+            const unsigned long long mask = __ballot(keep);
+            if (keep) buf[m + __popcll(mask & ((1ull << lane) - 1ull))] = v;
+            m += __popcll(mask);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double mean = wc::pairwise_sum<true>([&](int64_t e) { return buf[e]; }, (int64_t)m, sub) / (double)m;
+        const double var = wc::pairwise_sum<true>(
+                               [&](int64_t e) {
+                                   const double dv = buf[e] - mean;
+                                   const double sq = dv * dv;
+                                   return sq;
+                               },
+                               (int64_t)m, sub) / (double)m;
+        if (lane == 0) {
+            const double sd = sqrt(var);
+            const double x = XT[gid];
+            zT[gid] = (x - mean) / sd;
+            rT[gid] = x / mean;
+            nT[gid] = (double)m;
+            sdT[gid] = sd;
+        }
+    }
+}
+
 // testCopy[abs(z) >= threshold] = -1 (wisetools.py:446).  A NEW flag on (bin g, sample i)
 // queues every bin that uses g as a reference, for the same sample, for the next repeat: the
 // wave expands its new flags one after the other, 64 users per trip.
@@ -971,8 +1028,10 @@ __global__ __launch_bounds__(256) void k_region_whole(const double *__restrict__
     if (lane == 0) whole[r] = v;
 }
 
-__global__ void k_init_jobs(const Region *__restrict__ regions, int64_t n_regions, Job *__restrict__ jobs) {
+__global__ void k_init_jobs(const Region *__restrict__ regions, int64_t n_regions, Job *__restrict__ jobs,
+                            int *__restrict__ counters) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r == 0) { counters[1] = (int)n_regions; counters[5] = 0; counters[6] = 0; counters[7] = 0; }   // [1] / [5]: job counts of even / odd rounds (device-side loop)
     if (r >= n_regions) return;
     Job j;
     j.region = (int)r;
@@ -1067,7 +1126,8 @@ __global__ __launch_bounds__(256) void k_seg_quiet(Job *__restrict__ jobs, int n
                                                    const int *__restrict__ reg_flag, double thr,
                                                    const double *__restrict__ tmin,
                                                    const double *__restrict__ tmax,
-                                                   unsigned long long *__restrict__ work) {
+                                                   unsigned long long *__restrict__ work,
+                                                   const int *__restrict__ n_jobs_dev) {
     __shared__ int s_found, s_nwork;
     __shared__ double s_px[2 * ROWS_HALF];        // P[x] of the block's rows (side * 64 + lane)
     __shared__ long long s_ax[2 * ROWS_HALF];     // their absolute prefix indexes
@@ -1078,6 +1138,7 @@ __global__ __launch_bounds__(256) void k_seg_quiet(Job *__restrict__ jobs, int n
     // (many jobs: one workgroup per job, the block table is staged once; few jobs: all row
     // blocks in parallel)
     const int j = blockIdx.y, tid = threadIdx.x;
+    if (n_jobs_dev) n_jobs = *n_jobs_dev < n_jobs ? *n_jobs_dev : n_jobs;   // device-side round loop: n_jobs is the grid's bound
     if (j >= n_jobs) return;
     const Job job = jobs[j];
     const int L = job.hi - job.lo, half = (L + 1) / 2;
@@ -1218,12 +1279,14 @@ __global__ __launch_bounds__(64 * NW) void k_seg_search(const Job *__restrict__ 
                                                     const long long *__restrict__ bit_off,
                                                     Extreme *__restrict__ partial, int *__restrict__ counters,
                                                     int certified, double2 *__restrict__ sub,
-                                                    unsigned long long *__restrict__ work) {
+                                                    unsigned long long *__restrict__ work,
+                                                    const int *__restrict__ n_jobs_dev, int *__restrict__ next_count) {
     extern __shared__ double pl[];
     __shared__ double red_max[NW], red_min[NW];
     const int j = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
     // first kernel of a round: next-jobs / hot / brute counts start at zero (classify runs after)
-    if (j == 0 && chunk == 0 && tid == 0) { counters[1] = 0; counters[2] = 0; counters[3] = 0; }
+    if (j == 0 && chunk == 0 && tid == 0) { *next_count = 0; counters[2] = 0; counters[3] = 0; }
+    if (n_jobs_dev) n_jobs = *n_jobs_dev < n_jobs ? *n_jobs_dev : n_jobs;
     if (j >= n_jobs) return;
     const Job job = jobs[j];
     const int L = job.hi - job.lo, half = (L + 1) / 2;
@@ -1353,8 +1416,15 @@ __global__ __launch_bounds__(64) void k_seg_classify(const Job *__restrict__ job
                                                      const Extreme *__restrict__ partial, int max_chunks, double thr,
                                                      Extreme *__restrict__ job_res, int *__restrict__ hot,
                                                      int *__restrict__ brute, int *__restrict__ counters,
-                                                     int *__restrict__ cand_cnt, int certified) {
+                                                     int *__restrict__ cand_cnt, int certified,
+                                                     const int *__restrict__ n_jobs_dev) {
     const int j = blockIdx.x, lane = threadIdx.x;
+    if (n_jobs_dev) {
+        // device-side round loop: more jobs than this round's grid holds -> the caller re-runs the
+        // segmentation with the host-driven loop
+        if (j == 0 && lane == 0 && *n_jobs_dev > n_jobs) counters[6] = 1;
+        n_jobs = *n_jobs_dev < n_jobs ? *n_jobs_dev : n_jobs;
+    }
     if (j >= n_jobs) return;
     const Job job = jobs[j];
     const int L = job.hi - job.lo;
@@ -1448,7 +1518,7 @@ __global__ __launch_bounds__(1024) void k_seg_collect(const Job *__restrict__ jo
 // The decision of TriArr.segmentTri (triarray.py:59-84) given the exact extremes.
 __device__ inline void decide_emit(const Job &job, double maxv, int mx, int my, double minv, int nx, int ny,
                                    double thr, int min_search, Seg *segs, int seg_cap, Job *next, int job_cap,
-                                   int *counters) {
+                                   int *counters, int *next_count) {
     double champ = maxv;
     int cx = mx, cy = my;
     if (fabs(minv) > champ) { champ = minv; cx = nx; cy = ny; }
@@ -1461,11 +1531,11 @@ __device__ inline void decide_emit(const Job &job, double maxv, int mx, int my, 
     }
     const int xr = cx - job.lo, yr = cy - job.lo, edge = job.hi - job.lo;
     if (xr > min_search) {
-        int p = atomicAdd(&counters[1], 1);
+        int p = atomicAdd(next_count, 1);
         if (p < job_cap) { Job n; n.region = job.region; n.lo = job.lo; n.hi = cx; n.pad = 0; next[p] = n; }
     }
     if (yr + 1 < edge - min_search) {
-        int p = atomicAdd(&counters[1], 1);
+        int p = atomicAdd(next_count, 1);
         if (p < job_cap) { Job n; n.region = job.region; n.lo = cy + 1; n.hi = job.hi; n.pad = 0; next[p] = n; }
     }
 }
@@ -1521,7 +1591,7 @@ __global__ __launch_bounds__(256) void k_seg_decide(const Job *__restrict__ jobs
                                                     const unsigned int *__restrict__ bits,
                                                     const long long *__restrict__ bit_off, Seg *__restrict__ segs,
                                                     int seg_cap, Job *__restrict__ next, int job_cap,
-                                                    int *__restrict__ brute) {
+                                                    int *__restrict__ brute, int *__restrict__ next_count) {
     const int h = blockIdx.x, tid = threadIdx.x;
     if (h >= counters[2]) return;
     const int j = hot[h];
@@ -1556,7 +1626,8 @@ __global__ __launch_bounds__(256) void k_seg_decide(const Job *__restrict__ jobs
     }
     block_best(b, tid);
     if (tid == 0)
-        decide_emit(job, b.maxv, b.mx, b.my, b.minv, b.nx, b.ny, thr, min_search, segs, seg_cap, next, job_cap, counters);
+        decide_emit(job, b.maxv, b.mx, b.my, b.minv, b.nx, b.ny, thr, min_search, segs, seg_cap, next, job_cap, counters,
+                    next_count);
 }
 
 // Exact evaluation of every window of a job (non-finite input or tie overflow).
@@ -1565,7 +1636,8 @@ __global__ __launch_bounds__(256) void k_seg_brute(const Job *__restrict__ jobs,
                                                    const double *__restrict__ z, double thr, int min_search,
                                                    const unsigned int *__restrict__ bits,
                                                    const long long *__restrict__ bit_off, Seg *__restrict__ segs,
-                                                   int seg_cap, Job *__restrict__ next, int job_cap) {
+                                                   int seg_cap, Job *__restrict__ next, int job_cap,
+                                                   int *__restrict__ next_count) {
     const int q = blockIdx.x, tid = threadIdx.x;
     if (q >= counters[3]) return;
     const Job job = jobs[brute[q]];
@@ -1581,13 +1653,16 @@ __global__ __launch_bounds__(256) void k_seg_brute(const Job *__restrict__ jobs,
         }
     block_best(b, tid);
     if (tid == 0 && b.mx >= 0)
-        decide_emit(job, b.maxv, b.mx, b.my, b.minv, b.nx, b.ny, thr, min_search, segs, seg_cap, next, job_cap, counters);
+        decide_emit(job, b.maxv, b.mx, b.my, b.minv, b.nx, b.ny, thr, min_search, segs, seg_cap, next, job_cap, counters,
+                    next_count);
 }
 
 // Order each region's segments by position (the reference's in-order recursion).
 __global__ __launch_bounds__(256) void k_seg_gather(const Seg *__restrict__ segs, int n_segs, int max_calls,
                                                     double *__restrict__ out_val, int *__restrict__ out_x,
-                                                    int *__restrict__ out_y, int *__restrict__ out_n) {
+                                                    int *__restrict__ out_y, int *__restrict__ out_n,
+                                                    const int *__restrict__ n_segs_dev) {
+    if (n_segs_dev) n_segs = *n_segs_dev < n_segs ? *n_segs_dev : n_segs;      // n_segs: the grid's bound
     // rank of a segment among the segments of its region (by start bin); the segment list is
     // streamed through LDS in tiles of 256
     __shared__ int t_region[256], t_x[256];
@@ -1653,9 +1728,12 @@ __device__ inline double block_select(const double *__restrict__ v, int L, int k
 __global__ __launch_bounds__(256) void k_call_post(const Seg *__restrict__ segs, int n_segs,
                                                    const Region *__restrict__ regions, const double *__restrict__ rc,
                                                    const int *__restrict__ gpos, int max_calls,
-                                                   double *__restrict__ reg_calls) {
+                                                   double *__restrict__ reg_calls,
+                                                   const int *__restrict__ n_segs_dev) {
     __shared__ int s_flag[2];
     const int tid = threadIdx.x;
+    if (n_segs_dev) n_segs = *n_segs_dev < n_segs ? *n_segs_dev : n_segs;
+    if ((int)blockIdx.x >= n_segs) return;
     const Seg me = segs[blockIdx.x];
     if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
     __syncthreads();
@@ -1823,7 +1901,25 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
         unsigned int *cur = (it & 1) ? ts.pairs_a.as<unsigned int>() : ts.pairs_b.as<unsigned int>();
         unsigned int *next = it + 1 < repeats ? ((it & 1) ? ts.pairs_b.as<unsigned int>() : ts.pairs_a.as<unsigned int>())
                                               : nullptr;
-        if (it == 0) {
+        if (ref->k > 128) {
+            // long reference lists: the generic wave-per-pair kernel for every repeat
+            const int64_t np = it == 0 ? n : 0;
+            const unsigned gb = (unsigned)std::min<int64_t>(cdiv(n, 4), 16384);
+            hipLaunchKernelGGL(k_zscore_big, dim3(gb), dim3(256), 0, stream,
+                               it == 0 ? (const unsigned int *)nullptr : (const unsigned int *)cur,
+                               (const int *)(pair_counts + it), np, dirty, (const double *)ts.xt.as<double>(),
+                               (const double *)ts.xc.as<double>(), (const int *)ref->gidx.as<int>(),
+                               (const int *)ref->nref.as<int>(), ref->k, Ns, ts.zt.as<double>(), ts.rt.as<double>(),
+                               ts.nt.as<double>(), ts.sdt.as<double>());
+            if (it == 0)
+                hipLaunchKernelGGL(k_flag, dim3(g), dim3(256), 0, stream, (const double *)ts.zt.as<double>(), thr, n, Ns,
+                                   ts.xc.as<double>(), uoff, ulst, dirty, next, pair_counts + it + 1);
+            else
+                hipLaunchKernelGGL(k_flag_pairs, dim3((unsigned)std::min<int64_t>(g, 2048)), dim3(256), 0, stream,
+                                   (const unsigned int *)cur, (const int *)(pair_counts + it),
+                                   (const double *)ts.zt.as<double>(), thr, Ns, ts.xc.as<double>(), uoff, ulst, dirty,
+                                   next, pair_counts + it + 1);
+        } else if (it == 0) {
             if (Ns >= 32) {
                 const unsigned n_uni = (unsigned)cdiv(ref->B * cdiv(Ns, 64), 4);
                 hipLaunchKernelGGL(k_zscore, dim3(n_uni), dim3(256), 0, stream,
@@ -1879,9 +1975,15 @@ int join_side(wc_ctx *ctx, hipStream_t stream) {
 
 // Segment search over device regions.  Results: ts.out_val/out_x/out_y [n_regions, max_calls],
 // ts.out_n [n_regions], ts.whole [n_regions].
+// lat_rounds > 0 (latency mode, small batches): no host round trips -- that many search rounds are
+// enqueued with grids sized for the most jobs a round can hold (every job has at most two children)
+// and the kernels read the real job / segment counts on the device; *lat_incomplete (pinned, valid
+// after the stream has been synchronised) tells whether jobs were left over or a bound was
+// exceeded, in which case the caller runs the call again with the host-driven loop.
 int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, int64_t n_regions, int64_t total_len,
                  int64_t max_n, double thr, int min_search, int max_calls, hipStream_t stream,
-                 const double *ratio_dev = nullptr, double min_effect = 0.0, int64_t bits_upper = 0) {
+                 const double *ratio_dev = nullptr, double min_effect = 0.0, int64_t bits_upper = 0,
+                 int lat_rounds = 0) {
     TestState &ts = ctx->ts;
     int rc;
     ts.last_segs = 0;
@@ -1956,13 +2058,72 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     hipLaunchKernelGGL(k_region_whole, dim3((unsigned)cdiv(n_regions, 4)), dim3(256), 0, stream, z_dev, regions_dev,
                        n_regions, bits, bit_off, ts.whole.as<double>());
     hipLaunchKernelGGL(k_init_jobs, dim3((unsigned)cdiv(n_regions, 256)), dim3(256), 0, stream, regions_dev, n_regions,
-                       ts.jobs_a.as<Job>());
+                       ts.jobs_a.as<Job>(), counters);
     Job *cur = ts.jobs_a.as<Job>(), *next = ts.jobs_b.as<Job>();
     int64_t n_jobs = n_regions;
     int guard = 0;
     if ((rc = ctx->ensure_pinned(256))) return rc;
     int *h = (int *)ctx->pinned;          // counter read-backs land in pinned memory
     h[4] = 0;
+    if (lat_rounds > 0) {
+        const bool plds = max_n + 1 <= 6144;
+        const size_t dyn = plds ? sizeof(double) * (max_n + 1) : 0;
+        int64_t bound = n_regions;
+        {
+            const int64_t most = std::min<int64_t>(job_cap, n_regions << (lat_rounds - 1));
+            if ((rc = ts.partial.reserve(sizeof(Extreme) * most * max_chunks))) return rc;
+            if ((rc = ts.sub.reserve(sizeof(double2) * 8 * most * max_chunks))) return rc;
+            if ((rc = ts.cand.reserve(sizeof(int2) * 2 * CAND_CAP * most))) return rc;
+            if ((rc = ts.cand_cnt.reserve(sizeof(int) * 2 * most))) return rc;
+        }
+        for (int r = 0; r < lat_rounds; ++r) {
+            const int *nj = counters + ((r & 1) ? 5 : 1);
+            int *nx = counters + ((r & 1) ? 1 : 5);
+            const dim3 sg((unsigned)max_chunks, (unsigned)bound);
+            const unsigned per_job = (unsigned)std::min<int64_t>(max_chunks, std::max<int64_t>(1, 16384 / bound));
+            hipLaunchKernelGGL(k_seg_quiet, dim3(per_job, (unsigned)bound), dim3(256), 0, stream, cur, (int)bound, regions_dev,
+                               (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
+                               (const double *)ts.reg_abs.as<double>(), (const int *)ts.reg_flag.as<int>(), thr,
+                               (const double *)ts.tmin.as<double>(), (const double *)ts.tmax.as<double>(), work, nj);
+#define WC_LSEARCH(P_, NW_)                                                                                          \
+    hipLaunchKernelGGL((k_seg_search<false, P_, NW_>), sg, dim3(64 * NW_), dyn, stream, (const Job *)cur, (int)bound, \
+                       regions_dev, (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),      \
+                       (const int *)ts.reg_flag.as<int>(), max_chunks, bits, bit_off, ts.partial.as<Extreme>(),    \
+                       counters, 1, ts.sub.as<double2>(), work, nj, nx)
+            if (bound * max_chunks <= 2048) { if (plds) WC_LSEARCH(true, 16); else WC_LSEARCH(false, 16); }
+            else { if (plds) WC_LSEARCH(true, 4); else WC_LSEARCH(false, 4); }
+#undef WC_LSEARCH
+            hipLaunchKernelGGL(k_seg_classify, dim3((unsigned)bound), dim3(64), 0, stream, (const Job *)cur, (int)bound,
+                               regions_dev, (const double *)ts.reg_abs.as<double>(), (const int *)ts.reg_flag.as<int>(),
+                               (const Extreme *)ts.partial.as<Extreme>(), max_chunks, thr, ts.job_res.as<Extreme>(), hot,
+                               brute, counters, ts.cand_cnt.as<int>(), 1, nj);
+            hipLaunchKernelGGL(k_seg_collect, dim3((unsigned)max_chunks, (unsigned)bound), dim3(1024), 0, stream,
+                               (const Job *)cur, (const int *)hot, (const int *)counters, regions_dev,
+                               (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
+                               (const double *)ts.reg_abs.as<double>(), (const Extreme *)ts.job_res.as<Extreme>(),
+                               (const Extreme *)ts.partial.as<Extreme>(), max_chunks,
+                               (const double2 *)ts.sub.as<double2>(), bits, bit_off, ts.cand.as<int2>(),
+                               ts.cand_cnt.as<int>());
+            hipLaunchKernelGGL(k_seg_decide, dim3((unsigned)bound), dim3(256), 0, stream, (const Job *)cur,
+                               (const int *)hot, counters, regions_dev, z_dev, (const int2 *)ts.cand.as<int2>(),
+                               (const int *)ts.cand_cnt.as<int>(), thr, min_search, bits, bit_off, ts.seg.as<Seg>(),
+                               (int)seg_cap, next, (int)job_cap, brute, nx);
+            hipLaunchKernelGGL(k_seg_brute, dim3((unsigned)bound), dim3(256), 0, stream, (const Job *)cur,
+                               (const int *)brute, counters, regions_dev, z_dev, thr, min_search, bits, bit_off,
+                               ts.seg.as<Seg>(), (int)seg_cap, next, (int)job_cap, nx);
+            std::swap(cur, next);
+            bound = std::min<int64_t>(job_cap, 2 * bound);
+        }
+        // segments by position; their count stays on the device (the grid is sized for the bound)
+        const int seg_bound = (int)std::min<int64_t>(seg_cap, 4096);
+        hipLaunchKernelGGL(k_seg_gather, dim3((unsigned)cdiv(seg_bound, 256)), dim3(256), 0, stream,
+                           (const Seg *)ts.seg.as<Seg>(), seg_bound, max_calls, ts.out_val.as<double>(), ts.out_x.as<int>(),
+                           ts.out_y.as<int>(), ts.out_n.as<int>(), (const int *)(counters + 4));
+        ts.last_segs = -seg_bound;            // negative: a bound, the count is counters[4] on the device
+        ts.lat_left = (lat_rounds & 1) ? 5 : 1;   // counter holding the jobs left over after the last round
+        WC_HIP(hipGetLastError());
+        return WC_OK;
+    }
     while (n_jobs > 0) {
         WC_CHECK(++guard < 100000, WC_E_INTERNAL, "stouffer: recursion did not terminate");
         // per-round scratch is sized by the jobs of this round, not by the worst case
@@ -1980,7 +2141,8 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
             hipLaunchKernelGGL(k_seg_quiet, dim3(per_job, (unsigned)n_jobs), dim3(256), 0, stream, cur, (int)n_jobs, regions_dev,
                                (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
                                (const double *)ts.reg_abs.as<double>(), (const int *)ts.reg_flag.as<int>(), thr,
-                               (const double *)ts.tmin.as<double>(), (const double *)ts.tmax.as<double>(), work);
+                               (const double *)ts.tmin.as<double>(), (const double *)ts.tmax.as<double>(), work,
+                               (const int *)nullptr);
         }
         {
             const bool plds = max_n + 1 <= 6144;      // the longest region's prefix slice fits 48 KB of LDS
@@ -1989,7 +2151,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     hipLaunchKernelGGL((k_seg_search<M, P_, NW_>), sg, dim3(64 * NW_), dyn, stream, (const Job *)cur, (int)n_jobs,   \
                        regions_dev, (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),     \
                        (const int *)ts.reg_flag.as<int>(), max_chunks, bits, bit_off, ts.partial.as<Extreme>(), \
-                       counters, (int)certify, ts.sub.as<double2>(), work)
+                       counters, (int)certify, ts.sub.as<double2>(), work, (const int *)nullptr, counters + 1)
 #define WC_SEARCH_NW(M, P_) do { if (wide) WC_SEARCH(M, P_, 16); else WC_SEARCH(M, P_, 4); } while (0)
             const bool wide = n_jobs * max_chunks <= 2048;     // few blocks: sixteen waves each
             if (bits) { if (plds) WC_SEARCH_NW(true, true); else WC_SEARCH_NW(true, false); }
@@ -2001,7 +2163,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
         hipLaunchKernelGGL(k_seg_classify, dim3((unsigned)n_jobs), dim3(64), 0, stream, (const Job *)cur, (int)n_jobs,
                            regions_dev, (const double *)ts.reg_abs.as<double>(), (const int *)ts.reg_flag.as<int>(),
                            (const Extreme *)ts.partial.as<Extreme>(), max_chunks, thr, ts.job_res.as<Extreme>(), hot,
-                           brute, counters, ts.cand_cnt.as<int>(), (int)certify);
+                           brute, counters, ts.cand_cnt.as<int>(), (int)certify, (const int *)nullptr);
         // The number of hot jobs lives on the device.  Small rounds (latency mode, child
         // ranges) launch the follow-up kernels for the upper bound n_jobs and let surplus
         // workgroups exit, which saves a host round trip; big rounds read the count back.
@@ -2023,12 +2185,12 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
             hipLaunchKernelGGL(k_seg_decide, dim3((unsigned)n_hot), dim3(256), 0, stream, (const Job *)cur,
                                (const int *)hot, counters, regions_dev, z_dev, (const int2 *)ts.cand.as<int2>(),
                                (const int *)ts.cand_cnt.as<int>(), thr, min_search, bits, bit_off, ts.seg.as<Seg>(),
-                               (int)seg_cap, next, (int)job_cap, brute);
+                               (int)seg_cap, next, (int)job_cap, brute, counters + 1);
         }
         // brute list may have grown in decide; its length is only known on the device
         hipLaunchKernelGGL(k_seg_brute, dim3((unsigned)n_jobs), dim3(256), 0, stream, (const Job *)cur,
                            (const int *)brute, counters, regions_dev, z_dev, thr, min_search, bits, bit_off,
-                           ts.seg.as<Seg>(), (int)seg_cap, next, (int)job_cap);
+                           ts.seg.as<Seg>(), (int)seg_cap, next, (int)job_cap, counters + 1);
         WC_HIP(hipMemcpyAsync(h, counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
         WC_HIP(hipStreamSynchronize(stream));
         WC_CHECK(h[1] <= job_cap, WC_E_INTERNAL, "stouffer: job list overflow");
@@ -2040,7 +2202,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     if (h[4] > 0)
         hipLaunchKernelGGL(k_seg_gather, dim3((unsigned)cdiv(h[4], 256)), dim3(256), 0, stream,
                            (const Seg *)ts.seg.as<Seg>(), h[4], max_calls, ts.out_val.as<double>(), ts.out_x.as<int>(),
-                           ts.out_y.as<int>(), ts.out_n.as<int>());
+                           ts.out_y.as<int>(), ts.out_n.as<int>(), (const int *)nullptr);
     WC_HIP(hipGetLastError());
     return WC_OK;
 }
@@ -2071,9 +2233,9 @@ wc_reference *wc_reference_create(wc_ctx *ctx, const int32_t *indexes, const dou
         wc::set_error("reference: NULL argument");
         return nullptr;
     }
-    if (n_bins <= 0 || k <= 0 || k > 128 || n_chrom <= 0 || n_chrom > WC_MAX_CHROM || n_comp < 0 ||
+    if (n_bins <= 0 || k <= 0 || k > BIG_K || n_chrom <= 0 || n_chrom > WC_MAX_CHROM || n_comp < 0 ||
         n_comp > MAX_COMP) {
-        wc::set_error("reference: unsupported shape (bins %lld, refsize %d (max 128), chromosomes %d, components %d)",
+        wc::set_error("reference: unsupported shape (bins %lld, refsize %d (max 1024), chromosomes %d, components %d)",
                       (long long)n_bins, k, n_chrom, n_comp);
         return nullptr;
     }
@@ -2313,18 +2475,19 @@ int wc_stouffer_segments(wc_ctx *ctx, const double *z, const double *ratio, doub
     return WC_OK;
 }
 
-int wc_test_batch_dev(wc_ctx *ctx, void *stream_, const wc_reference *ref, const int32_t *counts, int64_t n_samples,
-                      double threshold, int min_ref_bins, int repeats, double min_effect,
-                      const int32_t *chromosomes_host, int n_sel, int max_calls, double *results_z,
-                      double *results_r, double *results_cwz, double *calls, int32_t *n_calls, double *asdef) {
-    WC_CHECK(ctx && ref && counts && n_samples > 0, WC_E_ARG, "test: bad argument");
-    WC_CHECK(n_samples <= 60000, WC_E_LIMIT, "test: more than 60000 samples per call; split the batch");
-    WC_CHECK(n_sel >= 0 && n_sel <= WC_MAX_CHROM && max_calls > 0, WC_E_ARG, "test: bad chromosome selection");
-    WC_CHECK(n_sel == 0 || chromosomes_host, WC_E_ARG, "test: NULL chromosome list");
-    hipStream_t stream = (hipStream_t)stream_;
-    WC_HIP(hipSetDevice(ctx->device));
+// Everything wc_test_batch_dev enqueues.  lat_rounds == 0: the general path (host-driven segmentation
+// rounds, synchronises per round and at the end).  lat_rounds > 0: latency mode -- no host round
+// trip at all (capturable in a hipGraph); the read-backs the caller has to look at after it
+// synchronised the stream land in ctx->pinned: int[16] = call overflow flag, int[24..31] = the
+// segmentation counters ([6] a round bound was exceeded, [lat_left] jobs left after the last round).
+static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *ref, const int32_t *counts, int64_t Ns,
+                           double threshold, int min_ref_bins, int repeats, double min_effect,
+                           const std::vector<int> &sel, int64_t max_n, int max_calls, double *results_z,
+                           double *results_r, double *results_cwz, double *calls, int32_t *n_calls, double *asdef,
+                           int lat_rounds) {
     TestState &ts = ctx->ts;
-    const int64_t Ns = n_samples, B = ref->B;
+    const int64_t B = ref->B;
+    const int n_sel = (int)sel.size();
     int rc;
     ts.prof_tag.clear();
     ts.mark(0, stream);
@@ -2358,29 +2521,13 @@ int wc_test_batch_dev(wc_ctx *ctx, void *stream_, const wc_reference *ref, const
         if (n_calls) WC_HIP(hipMemsetAsync(n_calls, 0, sizeof(int) * Ns, stream));
         return WC_OK;
     }
-    std::vector<int> sel(n_sel);
-    int64_t max_n = 0;
-    for (int s = 0; s < n_sel; ++s) {
-        int c = chromosomes_host[s] - 1;
-        WC_CHECK(c >= 0 && c < ref->n_chrom, WC_E_ARG, "test: chromosome %d out of range", chromosomes_host[s]);
-        sel[s] = c;
-        max_n = std::max(max_n, ref->moff[c + 1] - ref->moff[c]);
-    }
     const int64_t n_regions = Ns * n_sel;
-    WC_CHECK(n_regions <= 60000, WC_E_LIMIT, "test: samples x chromosomes = %lld exceeds 60000 per call; split the batch",
-             (long long)n_regions);
-    if ((rc = ts.sel.reserve(sizeof(int) * n_sel))) return rc;
     if ((rc = ts.zc.reserve(sizeof(double) * Ns * B))) return rc;
     if ((rc = ts.rc.reserve(sizeof(double) * Ns * B))) return rc;
     if ((rc = ts.gpos.reserve(sizeof(int) * Ns * B))) return rc;
     if ((rc = ts.regions.reserve(sizeof(Region) * n_regions))) return rc;
     if ((rc = ts.effect.reserve(sizeof(double) * n_regions * max_calls * 5))) return rc;
     if ((rc = ts.misc.reserve(sizeof(int) * 4))) return rc;
-    if (sel != ts.sel_host) {      // the device copy of the chromosome selection is reused across calls
-        WC_HIP(hipMemcpyAsync(ts.sel.p, sel.data(), sizeof(int) * n_sel, hipMemcpyHostToDevice, stream));
-        WC_HIP(hipStreamSynchronize(stream));
-        ts.sel_host = sel;
-    }
     hipLaunchKernelGGL(k_clean, dim3((unsigned)n_sel, (unsigned)Ns), dim3(64), 0, stream,
                        (const double *)ts.zs.as<double>(), (const double *)ts.rs2.as<double>(),
                        (const double *)ts.ns2.as<double>(), B, Ns, (const int64_t *)ref->moff_dev.as<int64_t>(),
@@ -2395,29 +2542,151 @@ int wc_test_batch_dev(wc_ctx *ctx, void *stream_, const wc_reference *ref, const
         }
     ts.mark(3, stream);
     if ((rc = run_stouffer(ctx, ts.zc.as<double>(), ts.regions.as<Region>(), n_regions, Ns * B, max_n, threshold, 3,
-                           max_calls, stream, ts.rc.as<double>(), min_effect, bits_upper)))
+                           max_calls, stream, ts.rc.as<double>(), min_effect, bits_upper, lat_rounds)))
         return rc;
     ts.mark(4, stream);
     if (results_cwz)
         WC_HIP(hipMemcpyAsync(results_cwz, ts.whole.p, sizeof(double) * n_regions, hipMemcpyDeviceToDevice, stream));
+    if ((rc = ctx->ensure_pinned(256))) return rc;
     if (calls && n_calls) {
         // ts.misc (overflow flag) was cleared by k_region_prefix
         if (ts.last_segs > 0)
             hipLaunchKernelGGL(k_call_post, dim3((unsigned)ts.last_segs), dim3(256), 0, stream,
                                (const Seg *)ts.seg.as<Seg>(), (int)ts.last_segs,
                                (const Region *)ts.regions.as<Region>(), (const double *)ts.rc.as<double>(),
-                               (const int *)ts.gpos.as<int>(), max_calls, ts.effect.as<double>());
+                               (const int *)ts.gpos.as<int>(), max_calls, ts.effect.as<double>(), (const int *)nullptr);
+        else if (ts.last_segs < 0)     // latency mode: the grid is a bound, the count sits on the device
+            hipLaunchKernelGGL(k_call_post, dim3((unsigned)(-ts.last_segs)), dim3(256), 0, stream,
+                               (const Seg *)ts.seg.as<Seg>(), (int)(-ts.last_segs),
+                               (const Region *)ts.regions.as<Region>(), (const double *)ts.rc.as<double>(),
+                               (const int *)ts.gpos.as<int>(), max_calls, ts.effect.as<double>(),
+                               (const int *)(ts.job_cnt.as<int>() + 4));
         hipLaunchKernelGGL(k_assemble_calls, dim3((unsigned)cdiv(Ns, 64)), dim3(64), 0, stream,
                            (const double *)ts.effect.as<double>(), (const int *)ts.out_n.as<int>(), n_sel, max_calls, Ns,
                            calls, n_calls, ts.misc.as<int>());
-        if ((rc = ctx->ensure_pinned(256))) return rc;
         int *overflow = (int *)ctx->pinned + 16;
         WC_HIP(hipMemcpyAsync(overflow, ts.misc.p, sizeof(int), hipMemcpyDeviceToHost, stream));
-        WC_HIP(hipStreamSynchronize(stream));
-        WC_CHECK(!*overflow, WC_E_LIMIT, "test: a sample has more than max_calls=%d calls", max_calls);
+        if (lat_rounds == 0) {
+            WC_HIP(hipStreamSynchronize(stream));
+            WC_CHECK(!*overflow, WC_E_LIMIT, "test: a sample has more than max_calls=%d calls", max_calls);
+        }
     }
+    if (lat_rounds > 0)
+        WC_HIP(hipMemcpyAsync((int *)ctx->pinned + 24, ts.job_cnt.p, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
     ts.mark(5, stream);
     WC_HIP(hipGetLastError());
+    return WC_OK;
+}
+
+int wc_test_batch_dev(wc_ctx *ctx, void *stream_, const wc_reference *ref, const int32_t *counts, int64_t n_samples,
+                      double threshold, int min_ref_bins, int repeats, double min_effect,
+                      const int32_t *chromosomes_host, int n_sel, int max_calls, double *results_z,
+                      double *results_r, double *results_cwz, double *calls, int32_t *n_calls, double *asdef) {
+    WC_CHECK(ctx && ref && counts && n_samples > 0, WC_E_ARG, "test: bad argument");
+    WC_CHECK(n_samples <= 60000, WC_E_LIMIT, "test: more than 60000 samples per call; split the batch");
+    WC_CHECK(n_sel >= 0 && n_sel <= WC_MAX_CHROM && max_calls > 0, WC_E_ARG, "test: bad chromosome selection");
+    WC_CHECK(n_sel == 0 || chromosomes_host, WC_E_ARG, "test: NULL chromosome list");
+    hipStream_t stream = (hipStream_t)stream_;
+    WC_HIP(hipSetDevice(ctx->device));
+    TestState &ts = ctx->ts;
+    const int64_t Ns = n_samples;
+    int rc;
+    std::vector<int> sel(n_sel);
+    int64_t max_n = 0;
+    for (int s = 0; s < n_sel; ++s) {
+        int c = chromosomes_host[s] - 1;
+        WC_CHECK(c >= 0 && c < ref->n_chrom, WC_E_ARG, "test: chromosome %d out of range", chromosomes_host[s]);
+        sel[s] = c;
+        max_n = std::max(max_n, ref->moff[c + 1] - ref->moff[c]);
+    }
+    WC_CHECK(Ns * n_sel <= 60000, WC_E_LIMIT, "test: samples x chromosomes = %lld exceeds 60000 per call; split the batch",
+             (long long)(Ns * n_sel));
+    if (n_sel > 0) {
+        if ((rc = ts.sel.reserve(sizeof(int) * n_sel))) return rc;
+        if (sel != ts.sel_host) {      // the device copy of the chromosome selection is reused across calls
+            WC_HIP(hipMemcpyAsync(ts.sel.p, sel.data(), sizeof(int) * n_sel, hipMemcpyHostToDevice, stream));
+            WC_HIP(hipStreamSynchronize(stream));
+            ts.sel_host = sel;
+        }
+    }
+    // Latency mode (BASELINE config 3: one sample per call): the whole call is one hipGraph replay
+    // without a host round trip -- four segmentation rounds with device-side job counts (deeper
+    // recursions, or more jobs than a round's grid holds, are detected afterwards and the call is
+    // repeated on the general path).  The first call of a shape runs eagerly (it sizes every
+    // workspace), the second one is captured, later ones replay.
+    constexpr int LAT_MAX_SAMPLES = 8, LAT_ROUNDS = 4;
+    const char *lat_env = getenv("WC_TEST_LATENCY_MODE");          // "0": general path for every call
+    const bool lat = Ns <= LAT_MAX_SAMPLES && min_effect == 0.0 && n_sel > 0 && calls && n_calls && !ts.profile &&
+                     !(lat_env && lat_env[0] == '0');
+    if (!lat)
+        return test_batch_body(ctx, stream, ref, counts, Ns, threshold, min_ref_bins, repeats, min_effect, sel, max_n,
+                               max_calls, results_z, results_r, results_cwz, calls, n_calls, asdef, 0);
+    std::vector<int64_t> key = {(int64_t)(intptr_t)ref, (int64_t)(intptr_t)counts, Ns, min_ref_bins, repeats, max_calls,
+                                (int64_t)(intptr_t)results_z, (int64_t)(intptr_t)results_r,
+                                (int64_t)(intptr_t)results_cwz, (int64_t)(intptr_t)calls, (int64_t)(intptr_t)n_calls,
+                                (int64_t)(intptr_t)asdef};
+    {
+        int64_t tbits;
+        memcpy(&tbits, &threshold, 8);
+        key.push_back(tbits);
+        for (int c : sel) key.push_back(c);
+    }
+    auto fall_back = [&]() {
+        return test_batch_body(ctx, stream, ref, counts, Ns, threshold, min_ref_bins, repeats, min_effect, sel, max_n,
+                               max_calls, results_z, results_r, results_cwz, calls, n_calls, asdef, 0);
+    };
+    if (key != ts.lat_key) {
+        // new shape: drop the old graph, run eagerly once (reserves every buffer), capture next time
+        if (ts.lat_exec) { (void)hipGraphExecDestroy(ts.lat_exec); ts.lat_exec = nullptr; }
+        ts.lat_key = key;
+        ts.lat_warm = false;
+    }
+    // the call runs on the context's own stream (the caller's may be the NULL stream, which cannot
+    // be captured), ordered after everything the caller has enqueued so far
+    if (!ctx->lat_stream) {
+        WC_HIP(hipStreamCreateWithFlags(&ctx->lat_stream, hipStreamNonBlocking));
+        WC_HIP(hipEventCreateWithFlags(&ctx->ev_lat_in, hipEventDisableTiming));
+    }
+    hipStream_t ls = ctx->lat_stream;
+    WC_HIP(hipEventRecord(ctx->ev_lat_in, stream));
+    WC_HIP(hipStreamWaitEvent(ls, ctx->ev_lat_in, 0));
+    if (!ts.lat_exec && ts.lat_warm) {
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(ls, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            ts.lat_key.clear();
+            return fall_back();
+        }
+        rc = test_batch_body(ctx, ls, ref, counts, Ns, threshold, min_ref_bins, repeats, min_effect, sel, max_n,
+                             max_calls, results_z, results_r, results_cwz, calls, n_calls, asdef, LAT_ROUNDS);
+        const hipError_t e = hipStreamEndCapture(ls, &graph);
+        if (rc != WC_OK || e != hipSuccess || !graph) {
+            if (graph) (void)hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            ts.lat_key.clear();
+            return rc != WC_OK ? rc : fall_back();
+        }
+        const hipError_t ei = hipGraphInstantiate(&ts.lat_exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ei != hipSuccess) {
+            ts.lat_exec = nullptr;
+            ts.lat_key.clear();
+            (void)hipGetLastError();
+            return fall_back();
+        }
+    }
+    if (ts.lat_exec) {
+        WC_HIP(hipGraphLaunch(ts.lat_exec, ls));
+    } else {
+        if ((rc = test_batch_body(ctx, ls, ref, counts, Ns, threshold, min_ref_bins, repeats, min_effect, sel, max_n,
+                                  max_calls, results_z, results_r, results_cwz, calls, n_calls, asdef, LAT_ROUNDS)))
+            return rc;
+        ts.lat_warm = true;
+    }
+    WC_HIP(hipStreamSynchronize(ls));
+    const int *overflow = (const int *)ctx->pinned + 16, *cnt = (const int *)ctx->pinned + 24;
+    if (cnt[6] || cnt[ts.lat_left] > 0 || cnt[4] > 4096) return fall_back();      // deeper recursion / more jobs than the bounds: general path
+    WC_CHECK(!*overflow, WC_E_LIMIT, "test: a sample has more than max_calls=%d calls", max_calls);
     return WC_OK;
 }
 
