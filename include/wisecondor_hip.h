@@ -203,6 +203,16 @@ int wc_repeat_test(wc_ctx *ctx, const wc_reference *ref, const double *data, int
                    double *sd_avg);
 
 /*
+ * stdDevAvg of trySample alone (wisetools.py:428-435): the mean of the non-NaN per-bin standard
+ * deviations, summed bin by bin like the reference's Python loop (sequential float64 rounding).
+ * sd [n_samples, n_bins] host -> out [n_samples].  The sum runs as an exact parallel scan
+ * (testpath.hip, k_sd_fast); *serial_samples (optional) receives how many samples needed the
+ * serial chain instead.
+ */
+int wc_std_dev_avg(wc_ctx *ctx, const double *sd, int64_t n_samples, int64_t n_bins, double *out,
+                   int32_t *serial_samples);
+
+/*
  * fillTri / fillTriMin (wisetools.py:466-487) + TriArr.segmentTri (triarray.py:59-84)
  * on a batch of independent regions without materialising the triangle.
  * z [total] float64: concatenated regions; region_offsets [n_regions+1].
@@ -258,6 +268,9 @@ int wc_test_batch_dev(wc_ctx *ctx, void *stream, const wc_reference *ref, const 
  * operations each), [7] window / bound evaluations of the quiet-job certificate.
  */
 int wc_test_profile(wc_ctx *ctx, int enable);
+/* Development aid: phase stamps (shader clock) of the latency-mode kernels' workgroup
+ * `block_plus_one - 1` (0: off); returns the 64 stamps of the calls since the last request. */
+int wc_debug_times(wc_ctx *ctx, int block_plus_one, unsigned long long *out64);
 int wc_test_profile_read(wc_ctx *ctx, double out[8]);
 
 #ifdef __cplusplus

@@ -278,3 +278,54 @@ def test_cfg1_options(wt, cfg1, reference):
     assert np.allclose(out["results_cwz"], g["opts_results_cwz"], rtol=1e-9)
     assert np.allclose(np.concatenate(out["results_z"]), g["opts_results_z"], rtol=1e-9, atol=1e-11)
     assert np.isclose(out["asdef"], float(g["opts_asdef"]), rtol=1e-11)
+
+
+def _seq_mean(v):
+    """trySample's stdDevAvg: Python-style sequential float64 sum of the non-NaN terms / their count."""
+    s, n = 0.0, 0
+    for x in v:
+        if x == x:
+            s += float(x)
+            n += 1
+    return s / n if n else float("nan")
+
+
+def test_std_dev_avg_parallel_form_is_exact(wt):
+    """k_sd_fast (binade-wise integer maps, segmented scan) against the sequential sum, bit for bit:
+    random magnitudes, forced rounding ties, sums that sit on powers of two, NaN gaps, zeros,
+    huge and tiny terms; and it must really be the parallel form that answered."""
+    rng = np.random.RandomState(11)
+    rows = []
+    for n in (1, 2, 7, 63, 64, 65, 1000, 1024, 1025, 11087, 57633):
+        rows.append((n, np.abs(0.03 + 0.01 * rng.standard_normal(n))))
+        v = np.abs(rng.standard_normal(n)) * 10.0 ** rng.uniform(-6, 6, size=n)       # many binade crossings
+        rows.append((n, v))
+        v = np.ldexp(rng.randint(1, 1 << 10, size=n).astype(np.float64), -12)          # few mantissa bits: ties
+        rows.append((n, v))
+        v = np.full(n, 0.25)                                                            # exact powers of two along the way
+        rows.append((n, v))
+        v = np.abs(rng.standard_normal(n))
+        v[rng.rand(n) < 0.2] = np.nan
+        v[rng.rand(n) < 0.1] = 0.0
+        rows.append((n, v))
+    serial_total = 0
+    for n, v in rows:
+        got, serial = wt.stdDevAvg(v, return_serial_count=True)
+        want = _seq_mean(v)
+        assert (np.isnan(got) and np.isnan(want)) or got == want, (n, got, want)
+        serial_total += serial
+    assert serial_total <= 2, serial_total                   # the scan, not the fallback chain, did the work
+    # ties that depend on the running sum's parity: terms of exactly half an ulp of the sum
+    v = np.concatenate([[1.0], np.full(4000, 2.0 ** -53)])
+    assert wt.stdDevAvg(v) == _seq_mean(v)
+    v = np.concatenate([[1.0 + 2.0 ** -52], np.full(4000, 2.0 ** -53), [3.0], np.full(500, 2.0 ** -52)])
+    assert wt.stdDevAvg(v) == _seq_mean(v)
+    # a batch: every sample its own answer
+    batch = np.abs(rng.standard_normal((70, 3000))) * 10.0 ** rng.uniform(-3, 3, size=(70, 1))
+    got = wt.stdDevAvg(batch)
+    assert all(got[i] == _seq_mean(batch[i]) for i in range(70))
+    # terms the parallel form declines (inf, negative): the serial chain answers, same semantics
+    v = np.abs(rng.standard_normal(500))
+    v[100] = np.inf
+    got, serial = wt.stdDevAvg(v, return_serial_count=True)
+    assert got == _seq_mean(v) and serial == 1

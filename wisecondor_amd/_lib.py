@@ -48,10 +48,12 @@ SIGNATURES = {
     "wc_optimal_cutoff": (_i32, [_vp, _vp, _i64, _i32, _vp]),
     "wc_prepare_samples": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "wc_repeat_test": (_i32, [_vp, _vp, _vp, _i64, _dbl, _i32, _vp, _vp, _vp, _vp]),
+    "wc_std_dev_avg": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "wc_stouffer_segments": (_i32, [_vp, _vp, _vp, _dbl, _vp, _i64, _dbl, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "wc_test_batch": (_i32, [_vp, _vp, _vp, _i64, _dbl, _i32, _i32, _dbl, _vp, _i32, _i32,
                              _vp, _vp, _vp, _vp, _vp, _vp]),
     "wc_test_profile": (_i32, [_vp, _i32]),
+    "wc_debug_times": (_i32, [_vp, _i32, _vp]),
     "wc_test_profile_read": (_i32, [_vp, _vp]),
     "wc_test_batch_dev": (_i32, [_vp, _vp, _vp, _vp, _i64, _dbl, _i32, _i32, _dbl, _vp, _i32, _i32,
                                  _vp, _vp, _vp, _vp, _vp, _vp]),

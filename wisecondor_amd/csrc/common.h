@@ -33,6 +33,13 @@ void set_error(const char *fmt, ...);
         }                              \
     } while (0)
 
+// Counts the (re)allocations of every DevBuf of the process: a captured hipGraph bakes device
+// addresses in, so whoever caches one compares this number before replaying it.
+inline unsigned long long &realloc_epoch() {
+    static unsigned long long epoch = 0;
+    return epoch;
+}
+
 // A grow-only device buffer; contexts keep these so repeated calls do not
 // hipMalloc/hipFree (sized for 288 GB HBM: never shrinks, never spills).
 struct DevBuf {
@@ -40,6 +47,7 @@ struct DevBuf {
     size_t bytes = 0;
     int reserve(size_t want) {
         if (want <= bytes) return WC_OK;
+        ++realloc_epoch();
         if (p) (void)hipFree(p);
         p = nullptr;
         bytes = 0;
@@ -53,6 +61,7 @@ struct DevBuf {
         return WC_OK;
     }
     void release() {
+        ++realloc_epoch();
         if (p) (void)hipFree(p);
         p = nullptr;
         bytes = 0;

@@ -51,12 +51,14 @@ struct TestState {
     // an eager call of that shape has sized the workspaces
     hipGraphExec_t lat_exec = nullptr;
     std::vector<int64_t> lat_key;
-    bool lat_warm = false;            // latency mode: index of the counter that holds the jobs left after the last round
+    bool lat_warm = false;
+    unsigned long long lat_epoch = 0;   // wc::realloc_epoch() at capture time            // latency mode: index of the counter that holds the jobs left after the last round
     // optional stage timing of wc_test_batch_dev (wc_test_profile): events on the launch stream
     // between the stages, and counts of the window evaluations the search kernels executed
     bool profile = false;
     std::vector<hipEvent_t> prof_ev;    // event pool, grown on demand
     std::vector<int> prof_tag;          // tag of every mark of the last batch, in record order
+    wc::DevBuf sd_fail;                 // per-sample flags of k_sd_fast (1: the serial kernel takes the sample)
     wc::DevBuf prof_work;               // u64[2]: windows evaluated by k_seg_search, evaluations by k_seg_quiet
     void mark(int tag, hipStream_t stream) {
         if (!profile) return;
@@ -119,6 +121,6 @@ struct wc_ctx {
                 &ts.sel, &ts.res_z, &ts.res_r, &ts.cwz, &ts.calls, &ts.n_calls, &ts.zs, &ts.rs2, &ts.ns2, &ts.sub, &ts.tmin, &ts.tmax, &ts.prefix, &ts.reg_abs,
                 &ts.reg_flag, &ts.rs, &ts.jobs_a, &ts.jobs_b, &ts.job_cnt, &ts.partial, &ts.job_res, &ts.hot,
                 &ts.cand, &ts.cand_cnt, &ts.seg, &ts.seg_cnt, &ts.out_val, &ts.out_x, &ts.out_y, &ts.out_n,
-                &ts.whole, &ts.effect, &ts.misc, &ts.misc2, &ts.reduce_tmp, &ts.win_bits, &ts.bit_off, &ts.pairs_a, &ts.pairs_b, &ts.cut_vals, &ts.prof_work};
+                &ts.whole, &ts.effect, &ts.misc, &ts.misc2, &ts.reduce_tmp, &ts.win_bits, &ts.bit_off, &ts.pairs_a, &ts.pairs_b, &ts.cut_vals, &ts.prof_work, &ts.sd_fail};
     }
 };

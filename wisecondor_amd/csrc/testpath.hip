@@ -10,9 +10,11 @@
 #include "ctx.h"
 
 #include <algorithm>
+#include <cstring>
 
 struct wc_reference {
     wc_ctx *ctx = nullptr;
+    unsigned long long serial = 0;         // unique per created reference (a freed handle's address may be reused)
     int64_t B = 0, Btot = 0;
     int k = 0, n_chrom = 0, n_comp = 0;
     int64_t moff[WC_MAX_CHROM + 1] = {0};  // masked-bin offsets per chromosome
@@ -23,6 +25,15 @@ struct wc_reference {
 };
 
 namespace {
+
+// Development aid: with WC_DEBUG_TIMES=1 the latency-mode kernels leave s_memtime stamps of their
+// phases (workgroup `DBG_BLOCK`, thread 0) in a device array read back by wc_debug_times.
+__device__ unsigned long long g_dbg[64];
+__device__ int g_dbg_on = 0;
+#define WC_STAMP(slot)                                                                      \
+    do {                                                                                    \
+        if (g_dbg_on && threadIdx.x == 0 && (int)blockIdx.x == g_dbg_on - 1) g_dbg[slot] = clock64(); \
+    } while (0)
 
 constexpr int MAX_COMP = 8;
 constexpr int SHORT_SEG = 1024;  // segments up to this length take the counting median in k_call_post
@@ -269,6 +280,88 @@ __global__ void k_pca_apply(const double *__restrict__ raw, int64_t B, const dou
     }
     rec += mean[b];
     out[i * B + b] = raw[i * B + b] / rec;
+}
+
+// Latency mode (a few samples per call): the four preparation launches as two.
+// k_lat_project: one workgroup per (sample, bin slice) -- the sample's total (every slice computes it:
+// 50 KB of counts, cheaper than a launch), the slice's normalised values on the fly and the
+// projection partial sums with k_pca_project's arithmetic exactly (256 strided accumulators per
+// slice, the same tree), so a sample comes out bit-identical to the batch kernels.
+__global__ __launch_bounds__(256) void k_lat_project(const int *__restrict__ counts, int64_t Btot,
+                                                     const int *__restrict__ m2g, int64_t B,
+                                                     const double *__restrict__ mean, const double *__restrict__ comp,
+                                                     int n_comp, double *__restrict__ totals,
+                                                     double *__restrict__ proj) {
+    __shared__ long long sh_t[256];
+    __shared__ double sh[MAX_COMP][256];
+    const int tid = threadIdx.x;
+    const int64_t i = blockIdx.x;
+    const int *row = counts + i * Btot;
+    long long acc_t = 0;
+    {
+        long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;  // the loads of a trip are in flight together
+        int64_t g = tid;
+        for (; g + 768 < Btot; g += 1024) { a0 += row[g]; a1 += row[g + 256]; a2 += row[g + 512]; a3 += row[g + 768]; }
+        for (; g < Btot; g += 256) a0 += row[g];
+        acc_t = (a0 + a1) + (a2 + a3);
+    }
+    sh_t[tid] = acc_t;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) sh_t[tid] += sh_t[tid + o];
+        __syncthreads();
+    }
+    const double total = (double)sh_t[0];          // integer sums are exact in any order
+    if (blockIdx.y == 0 && tid == 0) totals[i] = total;
+    const int64_t per = (B + PROJ_SPLIT - 1) / PROJ_SPLIT;
+    const int64_t b_lo = (int64_t)blockIdx.y * per, b_hi = b_lo + per < B ? b_lo + per : B;
+    double acc[MAX_COMP];
+#pragma unroll
+    for (int c = 0; c < MAX_COMP; ++c) acc[c] = 0.0;
+    for (int64_t b = b_lo + tid; b < b_hi; b += 256) {
+        const double xb = (double)row[m2g[b]] / total;
+        const double d = xb - mean[b];
+#pragma unroll
+        for (int c = 0; c < MAX_COMP; ++c)
+            if (c < n_comp) acc[c] += d * comp[(int64_t)c * B + b];
+    }
+#pragma unroll
+    for (int c = 0; c < MAX_COMP; ++c) sh[c][tid] = acc[c];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o)
+#pragma unroll
+            for (int c = 0; c < MAX_COMP; ++c) sh[c][tid] += sh[c][tid + o];
+        __syncthreads();
+    }
+    if (tid < n_comp) proj[(i * PROJ_SPLIT + blockIdx.y) * MAX_COMP + tid] = sh[tid][0];
+}
+
+// k_lat_apply: normalise again (one division, the same bits), reconstruct, divide; writes the sample-major
+// result and the repeats' bin-major working arrays, and clears the repeats' counters and dirty map.
+__global__ void k_lat_apply(const int *__restrict__ counts, int64_t Btot, const int *__restrict__ m2g, int64_t B,
+                            int64_t Ns, const double *__restrict__ totals, const double *__restrict__ mean,
+                            const double *__restrict__ comp, int n_comp, const double *__restrict__ proj,
+                            double *__restrict__ data, double *__restrict__ xt, double *__restrict__ xc,
+                            int *__restrict__ zero, int64_t n_zero) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = blockIdx.y;
+    {
+        const int64_t nthreads = (int64_t)gridDim.x * gridDim.y * blockDim.x;
+        for (int64_t t = i * gridDim.x * blockDim.x + b; t < n_zero; t += nthreads) zero[t] = 0;
+    }
+    if (b >= B) return;
+    double rec = 0.0;
+    for (int c = 0; c < n_comp; ++c) {
+        double t = 0.0;
+        for (int q = 0; q < PROJ_SPLIT; ++q) t += proj[(i * PROJ_SPLIT + q) * MAX_COMP + c];
+        rec += t * comp[(int64_t)c * B + b];
+    }
+    rec += mean[b];
+    const double v = ((double)counts[i * Btot + m2g[b]] / totals[i]) / rec;
+    data[i * B + b] = v;
+    xt[b * Ns + i] = v;
+    xc[b * Ns + i] = v;
 }
 
 // [R, C] -> [C, R]
@@ -569,6 +662,56 @@ struct GroupSum {
 // second pass) and the group sums in numpy's order (GroupSum).
 // pairs == nullptr: every pair 0 .. n_all - 1 (first repeat of a small batch, where whole waves
 // per bin would be mostly empty and one thread per pair waits out ~26 dependent gathers).
+// one (bin, sample) pair by an aligned group of eight lanes (sub = lane & 7, gbase = lane & ~7)
+__device__ inline void zscore_pair8(const unsigned int gid, const int sub, const int gbase,
+                                    const double *__restrict__ XT, const double *__restrict__ XC,
+                                    const int *__restrict__ gidx, const int *__restrict__ nref, int k, int64_t Ns,
+                                    double *__restrict__ zT, double *__restrict__ rT, double *__restrict__ nT,
+                                    double *__restrict__ sdT) {
+    const int64_t b = gid / Ns, i = gid - b * Ns;
+    const int *lst = gidx + b * k;
+    const int n = nref[b];
+    // references 8 t + sub, t = 0..15 (a reference list holds at most 128 entries here; longer
+    // lists take k_zscore_big); beyond the list: dropped
+    double v[16];
+    {
+        int g[16];
+#pragma unroll
+        for (int t8 = 0; t8 < 16; ++t8) {
+            const int r = 8 * t8 + sub;
+            g[t8] = r < n ? lst[r] : -1;
+        }
+#pragma unroll
+        for (int t8 = 0; t8 < 16; ++t8) v[t8] = g[t8] >= 0 ? XC[(int64_t)g[t8] * Ns + i] : -1.0;
+    }
+    GroupSum acc;
+    acc.init();
+#pragma unroll
+    for (int t8 = 0; t8 < 16; ++t8) {
+        if (8 * t8 >= n) break;
+        acc.trip(v[t8], v[t8] >= 0.0, sub, gbase);   // flagged (-1), negative and NaN values are dropped (wisetools.py:425)
+    }
+    const int m = acc.pos;
+    const double mean = acc.finish(sub, gbase) / (double)m;
+    acc.init();
+#pragma unroll
+    for (int t8 = 0; t8 < 16; ++t8) {
+        if (8 * t8 >= n) break;
+        const double dv = v[t8] - mean;
+        const double sq = dv * dv;
+        acc.trip(sq, v[t8] >= 0.0, sub, gbase);
+    }
+    const double var = acc.finish(sub, gbase) / (double)m;
+    if (sub == 0) {
+        const double sd = sqrt(var);
+        const double x = XT[gid];
+        zT[gid] = (x - mean) / sd;
+        rT[gid] = x / mean;
+        nT[gid] = (double)m;
+        sdT[gid] = sd;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_zscore_pairs(const unsigned int *__restrict__ pairs,
                                                       const int *__restrict__ count, int64_t n_all,
                                                       unsigned int *__restrict__ dirty,
@@ -582,48 +725,7 @@ __global__ __launch_bounds__(256) void k_zscore_pairs(const unsigned int *__rest
     for (int64_t t = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3; t < n_pairs; t += (int64_t)gridDim.x * 32) {
         const unsigned int gid = pairs ? pairs[t] : (unsigned int)t;
         if (pairs && sub == 0) atomicAnd(&dirty[gid >> 5], ~(1u << (gid & 31)));
-        const int64_t b = gid / Ns, i = gid - b * Ns;
-        const int *lst = gidx + b * k;
-        const int n = nref[b];
-        // references 8 t + sub, t = 0..15 (a reference list holds at most 128 entries,
-        // wc_reference_create); beyond the list: dropped
-        double v[16];
-        {
-            int g[16];
-#pragma unroll
-            for (int t8 = 0; t8 < 16; ++t8) {
-                const int r = 8 * t8 + sub;
-                g[t8] = r < n ? lst[r] : -1;
-            }
-#pragma unroll
-            for (int t8 = 0; t8 < 16; ++t8) v[t8] = g[t8] >= 0 ? XC[(int64_t)g[t8] * Ns + i] : -1.0;
-        }
-        GroupSum acc;
-        acc.init();
-#pragma unroll
-        for (int t8 = 0; t8 < 16; ++t8) {
-            if (8 * t8 >= n) break;
-            acc.trip(v[t8], v[t8] >= 0.0, sub, gbase);   // flagged (-1), negative and NaN values are dropped (wisetools.py:425)
-        }
-        const int m = acc.pos;
-        const double mean = acc.finish(sub, gbase) / (double)m;
-        acc.init();
-#pragma unroll
-        for (int t8 = 0; t8 < 16; ++t8) {
-            if (8 * t8 >= n) break;
-            const double dv = v[t8] - mean;
-            const double sq = dv * dv;
-            acc.trip(sq, v[t8] >= 0.0, sub, gbase);
-        }
-        const double var = acc.finish(sub, gbase) / (double)m;
-        if (sub == 0) {
-            const double sd = sqrt(var);
-            const double x = XT[gid];
-            zT[gid] = (x - mean) / sd;
-            rT[gid] = x / mean;
-            nT[gid] = (double)m;
-            sdT[gid] = sd;
-        }
+        zscore_pair8(gid, sub, gbase, XT, XC, gidx, nref, k, Ns, zT, rT, nT, sdT);
     }
 }
 
@@ -749,6 +851,52 @@ __global__ __launch_bounds__(256) void k_flag_pairs(const unsigned int *__restri
     }
 }
 
+// Latency mode: repeats 2 .. `repeats` in ONE launch by one workgroup.  After the first repeat a
+// sample usually has a handful of new flags, i.e. some hundred queued pairs, then none: a launch per
+// repeat and step costs more than the work.  Per repeat: recompute the queued pairs (eight lanes
+// each, as k_zscore_pairs), workgroup barrier, look for new flags among them and queue their
+// users (as k_flag_pairs), barrier.  More queued pairs than LAT_PAIR_CAP in a repeat: *overflow
+// is raised and the caller repeats the call on the general path.
+constexpr int LAT_PAIR_CAP = 1 << 16;
+__global__ __launch_bounds__(1024) void k_lat_repeats(unsigned int *__restrict__ pairs_a,
+                                                      unsigned int *__restrict__ pairs_b, int *__restrict__ pair_counts,
+                                                      int repeats, unsigned int *__restrict__ dirty,
+                                                      const double *__restrict__ XT, double *__restrict__ XC,
+                                                      const int *__restrict__ gidx, const int *__restrict__ nref, int k,
+                                                      int64_t Ns, double thr, const int *__restrict__ users_off,
+                                                      const int *__restrict__ users, double *__restrict__ zT,
+                                                      double *__restrict__ rT, double *__restrict__ nT,
+                                                      double *__restrict__ sdT, int *__restrict__ overflow) {
+    const int tid = threadIdx.x, lane = tid & 63, sub = lane & 7, gbase = lane & ~7;
+    for (int it = 1; it < repeats; ++it) {
+        unsigned int *cur = (it & 1) ? pairs_a : pairs_b;
+        unsigned int *next = it + 1 < repeats ? ((it & 1) ? pairs_b : pairs_a) : nullptr;
+        const int n = pair_counts[it];
+        if (n == 0) return;                      // nothing queued: every later repeat is identical
+        if (n > LAT_PAIR_CAP) {
+            if (tid == 0) *overflow = 1;
+            return;
+        }
+        for (int t0 = 0; t0 < n; t0 += 128) {            // 128 pairs per trip, whole waves stay together
+            const int t = t0 + (tid >> 3);
+            if (t < n) {
+                const unsigned int gid = cur[t];
+                if (sub == 0) atomicAnd(&dirty[gid >> 5], ~(1u << (gid & 31)));
+                zscore_pair8(gid, sub, gbase, XT, XC, gidx, nref, k, Ns, zT, rT, nT, sdT);
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (int t0 = 0; t0 < n; t0 += 1024) {
+            const int t = t0 + tid;
+            flag_wave(t < n ? (int64_t)cur[t] : 0, t < n, zT, thr, Ns, XC, users_off, users, dirty, next,
+                      pair_counts + it + 1);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 // stdDevAvg (wisetools.py:428-435): the reference adds the non-NaN sds bin by bin in a
 // Python loop, i.e. a strictly sequential sum per sample.  One lane per sample does the
 // adds; all 256 threads of the workgroup stream 128-bin chunks of sds through LDS (the
@@ -759,14 +907,17 @@ __global__ __launch_bounds__(256) void k_flag_pairs(const unsigned int *__restri
 // next chunk's loads (one sample: 512-bin chunks, 22 load round trips instead of 87).
 template <int SPB>
 __global__ __launch_bounds__(256) void k_sd_avg(const double *__restrict__ sdT, int64_t B, int64_t Ns,
-                                                double *__restrict__ out) {
+                                                double *__restrict__ out, const int *__restrict__ only,
+                                                double *__restrict__ out2) {
     constexpr int PH = 256 / SPB;                 // bin phases: thread (ss, bq) stages bins bq, bq + PH, ...
     constexpr int CH = 32 * PH;                   // bins per chunk
     __shared__ double buf[CH][SPB];
     __shared__ int cnts[PH][SPB];
     const int ss = threadIdx.x % SPB, bq = threadIdx.x / SPB;
     const int64_t i = (int64_t)blockIdx.x * SPB + ss;
-    const bool live = i < Ns;
+    // `only`: per-sample flags of k_sd_fast -- just the samples it could not finish are summed here
+    if (only && !__syncthreads_or(i < Ns && only[i] != 0)) return;
+    const bool live = i < Ns && (!only || only[i] != 0);
     // The staging threads do everything that is not the chain: NaN terms (and bins past the
     // end) become +0.0 -- exact for a sum of sds >= +0 -- and are left out of the count, so the
     // adding lanes issue one LDS read and one add per bin.
@@ -806,19 +957,287 @@ __global__ __launch_bounds__(256) void k_sd_avg(const double *__restrict__ sdT, 
         long long c = 0;
         for (int q = 0; q < PH; ++q) c += cnts[q][ss];
         out[i] = s / (double)c;
+        if (out2) out2[i] = s / (double)c;
     }
+}
+
+// stdDevAvg without the serial chain.  The reference's sum is sequential, s <- fl(s + x_b) bin by
+// bin, and 11 087 dependent float64 adds take ~100 us on one lane -- the longest thing on a single
+// sample's critical path.  The same BITS can be had in parallel: while s stays inside one binade
+// [2^e, 2^(e+1)), with u = 2^(e-52) the ulp there, S = s / u is an integer and
+//     fl(s + x) = u (S + q + c),   q = floor(x / u), r = x / u - q,
+//     c = 1 if r > 1/2, 0 if r < 1/2, and on a tie (r = 1/2) whatever makes S + q + c even.
+// So every element is a map S -> S + A + H[S & 1] (ties depend on the parity of S only), such maps
+// are closed under composition -- (A1, H1) then (A2, H2) is (A1 + A2, p -> H1[p] + H2[(p + A1 + H1[p]) & 1])
+// -- and composition is associative: a segmented parallel scan composes all elements of a binade
+// at once.  The binades come from an ordinary parallel prefix sum (the few elements at which its
+// exponent changes are "boundary" elements, added one by one in plain float64 by one thread, which
+// also checks that the exact running sum really has the exponent the segment assumed and really
+// stayed below 2^53 units).  Any check that fails, a non-finite term, more than SD_MAX_BOUND
+// boundaries: fail[sample] is raised and the serial kernel (k_sd_avg) computes that sample.
+// One workgroup of 1024 threads per sample; NaN terms are skipped as in the reference
+// (wisetools.py:428-430).
+constexpr int SD_MAX_BOUND = 96;
+struct SdMap { long long A; int H0, H1; };
+__device__ inline SdMap sd_compose(const SdMap &f, const SdMap &g) {     // f first, then g
+    SdMap r;
+    r.A = f.A + g.A;
+    const int p0 = (int)((0 + f.A + f.H0) & 1), p1 = (int)((1 + f.A + f.H1) & 1);
+    r.H0 = f.H0 + (p0 ? g.H1 : g.H0);
+    r.H1 = f.H1 + (p1 ? g.H1 : g.H0);
+    return r;
+}
+__device__ inline int sd_exponent(double v) {          // unbiased exponent of a positive normal double
+    return (int)((__double_as_longlong(v) >> 52) & 0x7FF) - 1023;
+}
+// REG > 0: at most REG terms per thread, fetched ONCE into registers by a fully unrolled loop (one
+// memory round trip instead of one per term and walk: 26 -> 8 us at 11 087 bins); REG == 0: any
+// count up to PER_MAX, re-read in each walk.
+template <int REG>
+__global__ __launch_bounds__(1024) void k_sd_fast(const double *__restrict__ sdT, int64_t B, int64_t Ns,
+                                                  double *__restrict__ out, int *__restrict__ fail,
+                                                  double *__restrict__ out2) {
+    constexpr int PER_MAX = 64;                      // elements per thread (B <= 65536)
+    __shared__ double sh_p[1024];                    // scan of the threads' approximate sums
+    __shared__ long long sh_A[1024];
+    __shared__ int sh_H0[1024], sh_H1[1024], sh_flag[1024], sh_nb[1024], sh_cnt[1024];
+    __shared__ long long b_A[SD_MAX_BOUND + 1];      // map of the segment that ENDS before boundary k (k = n: the tail)
+    __shared__ int b_H0[SD_MAX_BOUND + 1], b_H1[SD_MAX_BOUND + 1], b_e[SD_MAX_BOUND + 1];
+    __shared__ double b_x[SD_MAX_BOUND + 1];
+    __shared__ int s_bad;
+    __shared__ double sh_wp[16];
+    __shared__ int sh_wc[16];
+    __shared__ long long sh_wA[16];
+    __shared__ int sh_wH0[16], sh_wH1[16], sh_wf[16], sh_wn[16];
+    const int tid = threadIdx.x;
+    const int64_t i = blockIdx.x;
+    const int per = (int)((B + 1023) / 1024);
+    if (per > PER_MAX) { if (tid == 0) fail[i] = 1; return; }
+    if (tid == 0) s_bad = 0;
+    const int64_t lo = (int64_t)tid * per, hi = lo + per < B ? lo + per : B;
+    constexpr int NREG = REG > 0 ? REG : 1;
+    double xr[NREG];
+    if (REG > 0) {
+#pragma unroll
+        for (int e = 0; e < NREG; ++e) xr[e] = lo + e < hi ? sdT[(lo + e) * Ns + i] : 0.0;
+    }
+    // e-th term of this thread (REG == 0: re-read, L2-resident); NaN: not part of the sum
+    auto raw = [&](int e) { return REG > 0 ? xr[e] : sdT[(lo + e) * Ns + i]; };
+    auto term = [&](int e) {
+        const double v = raw(e);
+        return v != v ? 0.0 : v;
+    };
+    const int n_mine = (int)(hi > lo ? hi - lo : 0);
+    int cnt = 0;
+    bool bad = false;
+    double loc = 0.0;
+#pragma unroll
+    for (int e = 0; e < (REG > 0 ? NREG : PER_MAX); ++e) {
+        if (e >= n_mine) break;
+        const double v = raw(e);
+        if (v == v) {
+            ++cnt;
+            if (!(v >= 0.0) || v > 1.7e308) bad = true;
+            loc += v;
+        }
+    }
+    // approximate prefix sums: inclusive scan of the threads' sums (wave shuffles, then the sixteen
+    // wave totals), then along the thread's elements
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        double incl = loc;
+        int inc_c = cnt;
+        for (int o = 1; o < 64; o <<= 1) {
+            const double up = __shfl_up(incl, o);
+            const int upc = __shfl_up(inc_c, o);
+            if (lane >= o) { incl += up; inc_c += upc; }
+        }
+        if (lane == 63) { sh_wp[wv] = incl; sh_wc[wv] = inc_c; }
+        __syncthreads();
+        double base = 0.0;
+        int basec = 0;
+        for (int q = 0; q < wv; ++q) { base += sh_wp[q]; basec += sh_wc[q]; }
+        sh_p[tid] = base + incl;
+        sh_cnt[tid] = basec + inc_c;
+        __syncthreads();
+    }
+    double before = tid > 0 ? sh_p[tid - 1] : 0.0;
+    const int total_cnt = sh_cnt[1023];
+    // element maps, the thread's own segmented fold: `head` = composition up to (not including) the
+    // thread's first boundary, `tail` = composition after its last boundary
+    SdMap ident; ident.A = 0; ident.H0 = 0; ident.H1 = 0;
+    SdMap run = ident;
+    SdMap head = ident;
+    int n_bound = 0;
+#pragma unroll
+    for (int e = 0; e < (REG > 0 ? NREG : PER_MAX); ++e) {
+        if (e >= n_mine) break;
+        const double xv = term(e);
+        const double after = before + xv;
+        bool boundary = false;
+        if (xv > 0.0) {
+            if (before <= 0.0) boundary = true;
+            else {
+                const int eb = sd_exponent(before), ea = sd_exponent(after);
+                if (eb != ea) boundary = true;
+                else if (eb < -900 || eb > 50) bad = true;     // denormal / enormous sums: not worth the care
+                else {
+                    const double f = ldexp(xv, 52 - eb);        // x / u, exact
+                    const double qf = floor(f);
+                    const double r = f - qf;
+                    SdMap m;
+                    m.A = (long long)qf; m.H0 = 0; m.H1 = 0;
+                    if (r > 0.5) m.A += 1;
+                    else if (r == 0.5) { m.H0 = (int)(m.A & 1); m.H1 = (int)((m.A + 1) & 1); }
+                    run = sd_compose(run, m);
+                }
+            }
+        }
+        if (boundary) {
+            if (n_bound == 0) head = run;
+            ++n_bound;
+            run = ident;
+        }
+        before = after;
+    }
+    if (n_bound == 0) head = run;
+    // block-wide segmented scan over the threads: value = (flag: holds a boundary, map: its tail --
+    // or its whole fold when it holds none)
+    if (bad) s_bad = 1;
+    {
+        // inclusive segmented scan: within the wave by shuffles, then over the sixteen wave results
+        const int lane = tid & 63, wv = tid >> 6;
+        SdMap val = run;
+        int flag = n_bound > 0, nb = n_bound;
+        for (int o = 1; o < 64; o <<= 1) {
+            SdMap left;
+            left.A = __shfl_up(val.A, o);
+            left.H0 = __shfl_up(val.H0, o);
+            left.H1 = __shfl_up(val.H1, o);
+            const int lf = __shfl_up(flag, o), lnb = __shfl_up(nb, o);
+            if (lane >= o) {
+                if (!flag) { val = sd_compose(left, val); flag = lf; }
+                nb += lnb;
+            }
+        }
+        if (lane == 63) { sh_wA[wv] = val.A; sh_wH0[wv] = val.H0; sh_wH1[wv] = val.H1; sh_wf[wv] = flag; sh_wn[wv] = nb; }
+        __syncthreads();
+        // carry of the earlier waves (their open segment), composed in order
+        SdMap carryw; carryw.A = 0; carryw.H0 = 0; carryw.H1 = 0;
+        int cf = 0, cn = 0;
+        for (int q = 0; q < wv; ++q) {
+            SdMap m; m.A = sh_wA[q]; m.H0 = sh_wH0[q]; m.H1 = sh_wH1[q];
+            if (sh_wf[q]) { carryw = m; cf = 1; }
+            else carryw = sd_compose(carryw, m);
+            cn += sh_wn[q];
+        }
+        if (!flag) { val = sd_compose(carryw, val); flag = cf; }
+        nb += cn;
+        sh_A[tid] = val.A; sh_H0[tid] = val.H0; sh_H1[tid] = val.H1;
+        sh_flag[tid] = flag;
+        sh_nb[tid] = nb;
+        __syncthreads();
+    }
+    const int n_total_bound = sh_nb[1023];
+    if (n_total_bound > SD_MAX_BOUND) { if (tid == 0) fail[i] = 1; return; }
+    // carry-in of this thread: the open segment's composition over all earlier threads
+    SdMap carry = ident;
+    int k0 = 0;                                     // boundaries before this thread
+    if (tid > 0) { carry.A = sh_A[tid - 1]; carry.H0 = sh_H0[tid - 1]; carry.H1 = sh_H1[tid - 1]; k0 = sh_nb[tid - 1]; }
+    // second walk: at every boundary, publish the map of the segment that ends just before it
+    {
+        SdMap seg = carry;
+        double bef = tid > 0 ? sh_p[tid - 1] : 0.0;
+        int k = k0;
+#pragma unroll
+        for (int e = 0; e < (REG > 0 ? NREG : PER_MAX); ++e) {
+            if (e >= n_mine) break;
+            const double xv = term(e);
+            const double after = bef + xv;
+            bool boundary = false;
+            if (xv > 0.0) {
+                if (bef <= 0.0) boundary = true;
+                else {
+                    const int eb = sd_exponent(bef), ea = sd_exponent(after);
+                    if (eb != ea) boundary = true;
+                    else if (!(eb < -900 || eb > 50)) {
+                        const double f = ldexp(xv, 52 - eb);
+                        const double qf = floor(f);
+                        const double r = f - qf;
+                        SdMap m;
+                        m.A = (long long)qf; m.H0 = 0; m.H1 = 0;
+                        if (r > 0.5) m.A += 1;
+                        else if (r == 0.5) { m.H0 = (int)(m.A & 1); m.H1 = (int)((m.A + 1) & 1); }
+                        seg = sd_compose(seg, m);
+                    }
+                }
+            }
+            if (boundary) {
+                b_A[k] = seg.A; b_H0[k] = seg.H0; b_H1[k] = seg.H1;
+                b_x[k] = xv;
+                b_e[k] = sd_exponent(after);          // the exponent the following segment assumes
+                ++k;
+                seg = ident;
+            }
+            bef = after;
+        }
+        if (tid == 1023) { b_A[n_total_bound] = seg.A; b_H0[n_total_bound] = seg.H0; b_H1[n_total_bound] = seg.H1; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        bool ok = !s_bad;
+        double sum = 0.0;
+        int e_cur = 0;
+        for (int k = 0; k <= n_total_bound && ok; ++k) {
+            // the segment before boundary k (k = 0: before the first positive term, the identity)
+            if (k > 0 || n_total_bound == 0) {
+                const long long A = b_A[k];
+                if (A != 0 || b_H0[k] != 0 || b_H1[k] != 0) {
+                    if (!(sum > 0.0) || sd_exponent(sum) != e_cur) { ok = false; break; }
+                    const double u = ldexp(1.0, e_cur - 52);
+                    const long long S = (long long)(sum / u);            // exact: sum is a multiple of u below 2^53 u
+                    const long long S2 = S + A + ((S & 1) ? b_H1[k] : b_H0[k]);
+                    if (S2 >= (1ll << 53)) { ok = false; break; }
+                    sum = (double)S2 * u;
+                }
+            }
+            if (k < n_total_bound) {
+                sum = sum + b_x[k];                                     // the boundary term: a plain float64 add
+                if (!(sum > 0.0) || sd_exponent(sum) != b_e[k]) { ok = false; break; }
+                e_cur = b_e[k];
+            }
+        }
+        if (ok) {
+            out[i] = sum / (double)total_cnt;
+            if (out2) out2[i] = sum / (double)total_cnt;
+        }
+        fail[i] = ok ? 0 : 1;                      // 1: the serial kernel computes this sample
+    }
+}
+
+void launch_sd_fast(hipStream_t stream, const double *sdT, int64_t B, int64_t Ns, double *out, int *fail, double *out2) {
+    const int64_t per = (B + 1023) / 1024;
+    if (per <= 12)
+        hipLaunchKernelGGL(k_sd_fast<12>, dim3((unsigned)Ns), dim3(1024), 0, stream, sdT, B, Ns, out, fail, out2);
+    else if (per <= 24)
+        hipLaunchKernelGGL(k_sd_fast<24>, dim3((unsigned)Ns), dim3(1024), 0, stream, sdT, B, Ns, out, fail, out2);
+    else
+        hipLaunchKernelGGL(k_sd_fast<0>, dim3((unsigned)Ns), dim3(1024), 0, stream, sdT, B, Ns, out, fail, out2);
 }
 
 // --------------------------------------------------------------- cleaning ----
 // Keep bins with refSizes >= minrefbins (wisecondor.py:215-222); one wave per
 // (sample, selected chromosome) compacts z, r and the genomic position in order.
 // zT / rT / nT here: the sample-major [Ns, B] copies (see k_inflate)
+// (si, sb): strides of the z / ratio / count arrays per sample and per bin -- (B, 1) for the
+// sample-major copies, (1, Ns) to read the repeats' bin-major arrays directly (small batches)
 __global__ __launch_bounds__(64) void k_clean(const double *__restrict__ zT, const double *__restrict__ rT,
                                               const double *__restrict__ nT, int64_t B, int64_t Ns,
                                               const int64_t *__restrict__ moff, const int64_t *__restrict__ goff,
                                               const int *__restrict__ m2g, const int *__restrict__ sel, int n_sel,
                                               double minref, double *__restrict__ zc, double *__restrict__ rc,
-                                              int *__restrict__ gpos, Region *__restrict__ regions) {
+                                              int *__restrict__ gpos, Region *__restrict__ regions,
+                                              int64_t str_i, int64_t str_b) {
     const int lane = threadIdx.x;
     const int64_t i = blockIdx.y;
     const int si = blockIdx.x;
@@ -828,12 +1247,12 @@ __global__ __launch_bounds__(64) void k_clean(const double *__restrict__ zT, con
     for (int64_t base = cs; base < ce; base += 64) {
         int64_t b = base + lane;
         bool keep = false;
-        if (b < ce) keep = nT[i * B + b] >= minref;
+        if (b < ce) keep = nT[i * str_i + b * str_b] >= minref;
         unsigned long long mask = __ballot(keep);
         if (keep) {
             int at = count + __popcll(mask & ((1ull << lane) - 1ull));
-            zc[i * B + cs + at] = zT[i * B + b];
-            rc[i * B + cs + at] = rT[i * B + b];
+            zc[i * B + cs + at] = zT[i * str_i + b * str_b];
+            rc[i * B + cs + at] = rT[i * str_i + b * str_b];
             gpos[i * B + cs + at] = (int)(m2g[b] - goff[c]);
         }
         count += __popcll(mask);
@@ -852,15 +1271,15 @@ __global__ __launch_bounds__(64) void k_clean(const double *__restrict__ zT, con
 // arrays would be read with a stride of Ns doubles here)
 __global__ void k_inflate(const double *__restrict__ zs, const double *__restrict__ rs, const double *__restrict__ ns,
                           int64_t B, int64_t Btot, const int *__restrict__ g2m, double minref,
-                          double *__restrict__ res_z, double *__restrict__ res_r) {
+                          double *__restrict__ res_z, double *__restrict__ res_r, int64_t si, int64_t sb) {
     int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t i = blockIdx.y;
     if (g >= Btot) return;
     int m = g2m[g];
     double z = 0.0, r = 0.0;
-    if (m >= 0 && ns[i * B + m] >= minref) {
-        z = zs[i * B + m];
-        r = rs[i * B + m] - 1.0;
+    if (m >= 0 && ns[i * si + m * sb] >= minref) {
+        z = zs[i * si + m * sb];
+        r = rs[i * si + m * sb] - 1.0;
     }
     if (res_z) res_z[i * Btot + g] = z;
     if (res_r) res_r[i * Btot + g] = r;
@@ -1017,7 +1436,7 @@ __device__ inline double window_exact_wave(const double *__restrict__ zz, int x,
 __global__ __launch_bounds__(256) void k_region_whole(const double *__restrict__ z, const Region *__restrict__ regions,
                                                       int64_t n_regions, const unsigned int *__restrict__ bits,
                                                       const long long *__restrict__ bit_off,
-                                                      double *__restrict__ whole) {
+                                                      double *__restrict__ whole, double *__restrict__ whole2) {
     __shared__ wc::PwWaveScratch sc[4];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;       // a wave per region
     const int64_t r = (int64_t)blockIdx.x * 4 + w;
@@ -1025,7 +1444,10 @@ __global__ __launch_bounds__(256) void k_region_whole(const double *__restrict__
     const Region rg = regions[r];
     const WindowMask wm{bits, bits ? bit_off[r] : 0, rg.n};
     const double v = rg.n > 0 ? window_exact_wave(z + rg.off, 0, rg.n - 1, lane, wm, sc[w]) : NAN;
-    if (lane == 0) whole[r] = v;
+    if (lane == 0) {
+        whole[r] = v;
+        if (whole2) whole2[r] = v;             // the caller's results_cwz, when it wants no separate copy
+    }
 }
 
 __global__ void k_init_jobs(const Region *__restrict__ regions, int64_t n_regions, Job *__restrict__ jobs,
@@ -1074,13 +1496,25 @@ __device__ inline void scan_chunk(const ScanCtx &c, const double *__restrict__ r
         const int x = c.lo + (live ? xr : 0);
         const double px = c.P[x];
         const int room = live ? c.hi - x : 0;            // windows [x, x + len - 1] with len <= room
-        for (int len = 1 + w; len <= max_len; len += nw) {
-            const double r = rs[len];
-            if (len <= room) {
-                const int y = x + len - 1;
-                double v = (c.P[y + 1] - px) * r;
-                if (!c.wm.valid(x, y)) v = 0.0;
-                f(v, x, y);
+        // four window lengths per trip: their table factors and prefix values are requested
+        // together (a trip per length waits out one load latency per window)
+        for (int len0 = 1 + w; len0 <= max_len; len0 += 4 * nw) {
+            double r[4], pv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int len = len0 + u * nw;
+                r[u] = rs[len];                                    // the table is padded by 4 * 16 lengths
+                pv[u] = c.P[x + (len < room ? len : room)];         // always inside the job's slice
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int len = len0 + u * nw;
+                if (len <= room && len <= max_len) {
+                    const int y = x + len - 1;
+                    double v = (pv[u] - px) * r[u];
+                    if (!c.wm.valid(x, y)) v = 0.0;
+                    f(v, x, y);
+                }
             }
         }
     }
@@ -1119,32 +1553,24 @@ __global__ void k_block_minmax(const double *__restrict__ prefix, int64_t total,
 // bound does not settle it, and the ends before the first such block, are evaluated window by
 // window.  A job keeps Job::pad == 0 (search and classify skip it) unless some window could
 // reach the threshold: |v| + eps < thr is the same test k_seg_classify applies to the extremes.
-__global__ __launch_bounds__(256) void k_seg_quiet(Job *__restrict__ jobs, int n_jobs,
-                                                   const Region *__restrict__ regions,
-                                                   const double *__restrict__ prefix, const double *__restrict__ rs,
-                                                   const double *__restrict__ reg_abs,
-                                                   const int *__restrict__ reg_flag, double thr,
-                                                   const double *__restrict__ tmin,
-                                                   const double *__restrict__ tmax,
-                                                   unsigned long long *__restrict__ work,
-                                                   const int *__restrict__ n_jobs_dev) {
+// The certificate for one job by the calling workgroup (256 threads), over the row blocks
+// first_chunk, first_chunk + chunk_stride, ...; returns (to every thread) 0 when every window of
+// those rows stays below the threshold, 1 when some window could reach it or the job is too long
+// for the staged block table.
+__device__ inline int quiet_body(const Job job, const Region *__restrict__ regions, const double *__restrict__ prefix,
+                                 const double *__restrict__ rs, const double *__restrict__ reg_abs, double thr,
+                                 const double *__restrict__ tmin, const double *__restrict__ tmax,
+                                 unsigned long long *__restrict__ work, int first_chunk, int chunk_stride,
+                                 long long tab_k0 = 0) {     // tmin / tmax start at end block tab_k0 (a region-local table)
     __shared__ int s_found, s_nwork;
     __shared__ double s_px[2 * ROWS_HALF];        // P[x] of the block's rows (side * 64 + lane)
     __shared__ long long s_ax[2 * ROWS_HALF];     // their absolute prefix indexes
     __shared__ int s_work[Q_WORK];                // undecided (row, end block) pairs
     __shared__ double s_tmx[Q_BLOCKS], s_tmn[Q_BLOCKS];   // block maxima / minima the job touches
     __shared__ double s_pn[2][2 * ROWS_HALF];             // rows of a side and their near ends
-    // gridDim.x workgroups share a job: each takes the row blocks blockIdx.x, + gridDim.x, ...
-    // (many jobs: one workgroup per job, the block table is staged once; few jobs: all row
-    // blocks in parallel)
-    const int j = blockIdx.y, tid = threadIdx.x;
-    if (n_jobs_dev) n_jobs = *n_jobs_dev < n_jobs ? *n_jobs_dev : n_jobs;   // device-side round loop: n_jobs is the grid's bound
-    if (j >= n_jobs) return;
-    const Job job = jobs[j];
+    const int tid = threadIdx.x;
+    const bool on = tid < 256;                    // larger workgroups: the first 256 threads work, all keep the barriers
     const int L = job.hi - job.lo, half = (L + 1) / 2;
-    if (L <= 0 || (int)blockIdx.x * ROWS_HALF >= half) return;
-    if (!reg_flag[job.region]) return;            // non-finite region: classify sends it to the brute path
-    if (job.pad) return;                          // a sibling workgroup already found a window
     const double eps = window_eps(regions[job.region].n, reg_abs[job.region]);
     const double T = thr - eps, T2c = T * T * (1.0 - 3e-6);   // a window below T in magnitude cannot reach thr
     const long long base = regions[job.region].off + job.region + job.lo;    // absolute index of the job's P[0]
@@ -1154,19 +1580,18 @@ __global__ __launch_bounds__(256) void k_seg_quiet(Job *__restrict__ jobs, int n
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (k_last - k_base >= Q_BLOCKS) {           // more end blocks than the staged table holds: full search
-        if (tid == 0) jobs[j].pad = 1;
-        return;
+        return 1;
     }
     if (tid == 0) s_found = 0;
-    for (int i = tid; i <= (int)(k_last - k_base); i += 256) {
-        s_tmx[i] = tmax[k_base + i];
-        s_tmn[i] = tmin[k_base + i];
+    for (int i = tid; on && i <= (int)(k_last - k_base); i += 256) {
+        s_tmx[i] = tmax[k_base + i - tab_k0];
+        s_tmn[i] = tmin[k_base + i - tab_k0];
     }
-    for (int chunk = blockIdx.x; chunk * ROWS_HALF < half; chunk += gridDim.x) {
+    for (int chunk = first_chunk; chunk * ROWS_HALF < half; chunk += chunk_stride) {
         __syncthreads();                          // previous chunk's queue and rows are done with
         if (s_found) break;
         if (tid == 0) s_nwork = 0;
-        {   // the 64 rows of each side and the 64 prefix entries after them (clipped to the job)
+        if (on) {   // the 64 rows of each side and the 64 prefix entries after them (clipped to the job)
             const int side = tid >> 7, t = tid & 127;
             const int xr_lo = side == 0 ? chunk * ROWS_HALF : L - 1 - (chunk * ROWS_HALF + 63);
             const long long ai = base + (xr_lo < 0 ? 0 : xr_lo) + t;
@@ -1175,7 +1600,7 @@ __global__ __launch_bounds__(256) void k_seg_quiet(Job *__restrict__ jobs, int n
         __syncthreads();
         bool found = false;
         int evals = 0;                            // profiling only: window / bound evaluations of this lane
-        for (int side = 0; side < 2; ++side) {
+        for (int side = 0; on && side < 2; ++side) {
             int xr = chunk * ROWS_HALF + lane;
             bool live;
             if (side == 0) {
@@ -1230,7 +1655,7 @@ __global__ __launch_bounds__(256) void k_seg_quiet(Job *__restrict__ jobs, int n
         __syncthreads();
         // queued pairs: 32 ends each, eight pairs per trip
         const int nwork = s_nwork < Q_WORK ? s_nwork : Q_WORK;
-        for (int wk = tid >> 5; wk < nwork; wk += 8) {
+        for (int wk = tid >> 5; on && wk < nwork; wk += 8) {
             const int row = s_work[wk] >> 24;
             const long long ay = (k_base + (s_work[wk] & 0xFFFFFF)) * QB + (tid & 31);
             if (ay <= a_hi) {
@@ -1247,7 +1672,33 @@ __global__ __launch_bounds__(256) void k_seg_quiet(Job *__restrict__ jobs, int n
         }
     }
     __syncthreads();
-    if (tid == 0 && s_found) jobs[j].pad = 1;
+    const int found = s_found;
+    __syncthreads();                              // the shared tables may be reused by the caller's next job
+    return found;
+}
+
+__global__ __launch_bounds__(256) void k_seg_quiet(Job *__restrict__ jobs, int n_jobs,
+                                                   const Region *__restrict__ regions,
+                                                   const double *__restrict__ prefix, const double *__restrict__ rs,
+                                                   const double *__restrict__ reg_abs,
+                                                   const int *__restrict__ reg_flag, double thr,
+                                                   const double *__restrict__ tmin,
+                                                   const double *__restrict__ tmax,
+                                                   unsigned long long *__restrict__ work,
+                                                   const int *__restrict__ n_jobs_dev) {
+    // gridDim.x workgroups share a job: each takes the row blocks blockIdx.x, + gridDim.x, ...
+    // (many jobs: one workgroup per job, the block table is staged once; few jobs: all row
+    // blocks in parallel)
+    const int j = blockIdx.y, tid = threadIdx.x;
+    if (n_jobs_dev) n_jobs = *n_jobs_dev < n_jobs ? *n_jobs_dev : n_jobs;   // device-side round loop: n_jobs is the grid's bound
+    if (j >= n_jobs) return;
+    const Job job = jobs[j];
+    const int L = job.hi - job.lo, half = (L + 1) / 2;
+    if (L <= 0 || (int)blockIdx.x * ROWS_HALF >= half) return;
+    if (!reg_flag[job.region]) return;            // non-finite region: classify sends it to the brute path
+    if (job.pad) return;                          // a sibling workgroup already found a window
+    if (quiet_body(job, regions, prefix, rs, reg_abs, thr, tmin, tmax, work, blockIdx.x, gridDim.x) && tid == 0)
+        jobs[j].pad = 1;
 }
 
 // v_max_f64 / v_min_f64 on finite values, without the canonicalisation fmax() / fmin() imply
@@ -1270,43 +1721,14 @@ __device__ inline double raw_min(double a, double b) {
 //   MASKED -mineffectsize: windows whose validity bit is clear count as 0
 // A wave takes four consecutive window lengths per trip: their 1/sqrt(len) factors are one
 // scalar load, the four prefix values of a lane are adjacent.
-template <bool MASKED, bool PLDS, int NW>   // NW waves per block: 4, or 16 for rounds with few blocks (latency bound)
-__global__ __launch_bounds__(64 * NW) void k_seg_search(const Job *__restrict__ jobs, int n_jobs,
-                                                    const Region *__restrict__ regions,
-                                                    const double *__restrict__ prefix, const double *__restrict__ rs,
-                                                    const int *__restrict__ reg_flag, int max_chunks,
-                                                    const unsigned int *__restrict__ bits,
-                                                    const long long *__restrict__ bit_off,
-                                                    Extreme *__restrict__ partial, int *__restrict__ counters,
-                                                    int certified, double2 *__restrict__ sub,
-                                                    unsigned long long *__restrict__ work,
-                                                    const int *__restrict__ n_jobs_dev, int *__restrict__ next_count) {
-    extern __shared__ double pl[];
-    __shared__ double red_max[NW], red_min[NW];
-    const int j = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-    // first kernel of a round: next-jobs / hot / brute counts start at zero (classify runs after)
-    if (j == 0 && chunk == 0 && tid == 0) { *next_count = 0; counters[2] = 0; counters[3] = 0; }
-    if (n_jobs_dev) n_jobs = *n_jobs_dev < n_jobs ? *n_jobs_dev : n_jobs;
-    if (j >= n_jobs) return;
-    const Job job = jobs[j];
-    const int L = job.hi - job.lo, half = (L + 1) / 2;
-    if (L <= 0 || chunk * ROWS_HALF >= half) return;
-    if (!reg_flag[job.region]) return;  // non-finite region: exact brute-force path
-    if (certified && !job.pad) return;  // certified quiet by k_seg_quiet
-    const double *Pg = prefix + regions[job.region].off + job.region + job.lo;   // Pg[0..L]
-    const double *P = Pg;
-    if (PLDS) {
-        for (int i = tid; i <= L; i += 64 * NW) pl[i] = Pg[i];
-        __syncthreads();
-        P = pl;
-    }
-    const WindowMask wm{bits, MASKED ? bit_off[job.region] : 0, regions[job.region].n};
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    double bmax = -INFINITY, bmin = INFINITY;      // over both sides
-    int n_windows = 0;                             // profiling only: windows of this lane's rows
-    double2 *sub_blk = sub + ((int64_t)j * max_chunks + chunk) * 8;   // [side][search wave]: {max, min}
-    for (int side = 0; side < 2; ++side) {
+// Extremes (prefix-sum estimates) of the windows that start in one side of one block of rows of a
+// job: the wave-reduced maximum and minimum over the window lengths this wave owns (1 + 4 w .. 4 + 4 w,
+// then every 4 NW-th group).  P: the job's prefix slice (P[0..L]); job_lo only matters when MASKED.
+template <bool MASKED, int NW>
+__device__ inline void search_side(const double *P, int L, int half, int chunk, int side, const double *__restrict__ rs,
+                                   int lane, int w, int job_lo, const WindowMask &wm, double &smax_out,
+                                   double &smin_out, int &n_windows) {
+    struct { int lo; } job{job_lo};
         int xr = chunk * ROWS_HALF + lane;
         bool live;
         if (side == 0) {
@@ -1385,6 +1807,49 @@ __global__ __launch_bounds__(64 * NW) void k_seg_search(const Job *__restrict__ 
             smax = fmax(smax, __shfl_xor(smax, o));
             smin = fmin(smin, __shfl_xor(smin, o));
         }
+        smax_out = smax;
+        smin_out = smin;
+}
+
+template <bool MASKED, bool PLDS, int NW>   // NW waves per block: 4, or 16 for rounds with few blocks (latency bound)
+__global__ __launch_bounds__(64 * NW) void k_seg_search(const Job *__restrict__ jobs, int n_jobs,
+                                                    const Region *__restrict__ regions,
+                                                    const double *__restrict__ prefix, const double *__restrict__ rs,
+                                                    const int *__restrict__ reg_flag, int max_chunks,
+                                                    const unsigned int *__restrict__ bits,
+                                                    const long long *__restrict__ bit_off,
+                                                    Extreme *__restrict__ partial, int *__restrict__ counters,
+                                                    int certified, double2 *__restrict__ sub,
+                                                    unsigned long long *__restrict__ work,
+                                                    const int *__restrict__ n_jobs_dev, int *__restrict__ next_count) {
+    extern __shared__ double pl[];
+    __shared__ double red_max[NW], red_min[NW];
+    const int j = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    // first kernel of a round: next-jobs / hot / brute counts start at zero (classify runs after)
+    if (j == 0 && chunk == 0 && tid == 0) { *next_count = 0; counters[2] = 0; counters[3] = 0; }
+    if (n_jobs_dev) n_jobs = *n_jobs_dev < n_jobs ? *n_jobs_dev : n_jobs;
+    if (j >= n_jobs) return;
+    const Job job = jobs[j];
+    const int L = job.hi - job.lo, half = (L + 1) / 2;
+    if (L <= 0 || chunk * ROWS_HALF >= half) return;
+    if (!reg_flag[job.region]) return;  // non-finite region: exact brute-force path
+    if (certified && !job.pad) return;  // certified quiet by k_seg_quiet
+    const double *Pg = prefix + regions[job.region].off + job.region + job.lo;   // Pg[0..L]
+    const double *P = Pg;
+    if (PLDS) {
+        for (int i = tid; i <= L; i += 64 * NW) pl[i] = Pg[i];
+        __syncthreads();
+        P = pl;
+    }
+    const WindowMask wm{bits, MASKED ? bit_off[job.region] : 0, regions[job.region].n};
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double bmax = -INFINITY, bmin = INFINITY;      // over both sides
+    int n_windows = 0;                             // profiling only: windows of this lane's rows
+    double2 *sub_blk = sub + ((int64_t)j * max_chunks + chunk) * 8;   // [side][search wave]: {max, min}
+    for (int side = 0; side < 2; ++side) {
+        double smax, smin;
+        search_side<MASKED, NW>(P, L, half, chunk, side, rs, lane, w, job.lo, wm, smax, smin, n_windows);
         // the collect pass re-scans a (side, wave) slice only if its own extremes reach the cut
         if (NW == 4 && lane == 0) sub_blk[side * 4 + w] = make_double2(smax, smin);
         bmax = fmax(bmax, smax);
@@ -1657,6 +2122,435 @@ __global__ __launch_bounds__(256) void k_seg_brute(const Job *__restrict__ jobs,
                     next_count);
 }
 
+// numpy's pairwise sum of v[0..n) by a whole workgroup (n small enough that DEPTH halvings reach
+// leaves of <= 128 elements: a half has at most n / 2 + 7): the leaves of numpy's
+// tree (<= 128 elements each) are summed at the same time, one per group of eight lanes, then
+// folded in the tree's order.  The tree is walked by compile-time recursion (no stack in memory).
+// All threads must call; leaf_sum: LDS scratch for the leaf sums (>= (1 << DEPTH) doubles);
+// every thread returns the sum.
+template <int DEPTH>
+struct PwBlock {
+    template <class V>
+    static __device__ inline void leaves(V v, int off, int n, int &next_leaf, int group, int sub, double *leaf_sum) {
+        if (n <= WC_PW_BLOCK) {
+            if (next_leaf == group) {
+                const double s = wc::pw_leaf_group8([&](int64_t i) { return v[i]; }, off, n, sub);
+                if (sub == 0) leaf_sum[next_leaf] = s;
+            }
+            ++next_leaf;
+        } else {
+            int n2 = n / 2;
+            n2 -= n2 % 8;
+            PwBlock<DEPTH - 1>::leaves(v, off, n2, next_leaf, group, sub, leaf_sum);
+            PwBlock<DEPTH - 1>::leaves(v, off + n2, n - n2, next_leaf, group, sub, leaf_sum);
+        }
+    }
+    static __device__ inline double fold(int n, int &next_leaf, const double *leaf_sum) {
+        if (n <= WC_PW_BLOCK) return leaf_sum[next_leaf++];
+        int n2 = n / 2;
+        n2 -= n2 % 8;
+        const double l = PwBlock<DEPTH - 1>::fold(n2, next_leaf, leaf_sum);
+        const double r = PwBlock<DEPTH - 1>::fold(n - n2, next_leaf, leaf_sum);
+        return l + r;
+    }
+};
+template <>
+struct PwBlock<0> {
+    template <class V>
+    static __device__ inline void leaves(V v, int off, int n, int &next_leaf, int group, int sub, double *leaf_sum) {
+        if (next_leaf == group) {
+            const double s = wc::pw_leaf_group8([&](int64_t i) { return v[i]; }, off, n, sub);
+            if (sub == 0) leaf_sum[next_leaf] = s;
+        }
+        ++next_leaf;
+    }
+    static __device__ inline double fold(int, int &next_leaf, const double *leaf_sum) { return leaf_sum[next_leaf++]; }
+};
+
+// Latency mode: minrefbins cleaning (k_clean), prefix sums / sum |z| / finiteness (k_region_prefix),
+// the whole-region Stouffer value (k_region_whole) and the root job (k_init_jobs) of one region by one
+// workgroup of 256 threads -- four launches of one-wave-per-region kernels (sixteen dependent
+// 64-bin trips each) as one with four times fewer trips.  The prefix sums are the approximate
+// side of the search (any summation order satisfies window_eps' bound); everything decided later
+// is re-evaluated exactly, so the outputs equal the general path's bit for bit.
+__global__ __launch_bounds__(1024) void k_lat_setup(const double *__restrict__ zsrc, const double *__restrict__ rsrc,
+                                                   const double *__restrict__ nsrc, int64_t str_i, int64_t str_b,
+                                                   int64_t B, const int64_t *__restrict__ moff,
+                                                   const int64_t *__restrict__ goff, const int *__restrict__ m2g,
+                                                   const int *__restrict__ sel, int n_sel, double minref,
+                                                   double *__restrict__ zc, double *__restrict__ rc,
+                                                   int *__restrict__ gpos, Region *__restrict__ regions,
+                                                   double *__restrict__ prefix, double *__restrict__ reg_abs,
+                                                   int *__restrict__ reg_flag, double *__restrict__ whole,
+                                                   double *__restrict__ whole2, Job *__restrict__ jobs,
+                                                   int *__restrict__ counters, int *__restrict__ out_n,
+                                                   int *__restrict__ misc, int64_t n_regions) {
+    extern __shared__ double zl[];                // the region's kept z values (the prefix pass and the exact sum read them here)
+    __shared__ int s_cnt[16];
+    __shared__ double s_sum[16], s_abs[16];
+    __shared__ int s_fin[16];
+    __shared__ double s_leaf[32];
+    __shared__ wc::PwWaveScratch sc;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t r = blockIdx.x;
+    if (r == 0 && tid < 8) counters[tid] = tid == 1 ? (int)n_regions : 0;
+    if (r == 0 && tid >= 8 && tid < 12 && misc) misc[tid - 8] = 0;
+    WC_STAMP(0);
+    const int64_t i = r / n_sel;
+    const int si = (int)(r - i * n_sel);
+    const int c = sel[si];
+    const int64_t cs = moff[c], ce = moff[c + 1];
+    const int64_t off = i * B + cs;
+    // 1. keep bins with enough reference bins, in order (wisecondor.py:215-222)
+    int count = 0;
+    for (int64_t base = cs; base < ce; base += 1024) {
+        const int64_t b = base + tid;
+        bool keep = false;
+        if (b < ce) keep = nsrc[i * str_i + b * str_b] >= minref;
+        const unsigned long long mask = __ballot(keep);
+        if (lane == 0) s_cnt[w] = __popcll(mask);
+        __syncthreads();
+        int before = count;
+        for (int q = 0; q < w; ++q) before += s_cnt[q];
+        if (keep) {
+            const int at = before + __popcll(mask & ((1ull << lane) - 1ull));
+            const double zv = zsrc[i * str_i + b * str_b];
+            zc[off + at] = zv;
+            zl[at] = zv;
+            rc[off + at] = rsrc[i * str_i + b * str_b];
+            gpos[off + at] = (int)(m2g[b] - goff[c]);
+        }
+        for (int q = 0; q < 16; ++q) count += s_cnt[q];
+        __syncthreads();
+    }
+    const int n = count;
+    if (tid == 0) {
+        Region rg;
+        rg.off = off; rg.n = n; rg.pad = c;
+        regions[r] = rg;
+        out_n[r] = 0;
+        Job j;
+        j.region = (int)r; j.lo = 0; j.hi = n; j.pad = 0;
+        jobs[r] = j;
+    }
+    __syncthreads();
+    WC_STAMP(1);
+    // 2. prefix sums, sum |z|, finiteness
+    const double *zz = zl;
+    double *P = prefix + off + r;
+    if (tid == 0) P[0] = 0.0;
+    double run = 0.0, a = 0.0;
+    int finite = 1;
+    for (int t0 = 0; t0 < n; t0 += 1024) {
+        const int t = t0 + tid;
+        const double v = t < n ? zz[t] : 0.0;
+        if (!isfinite(v)) finite = 0;
+        a += fabs(v);
+        double incl = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const double up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) s_sum[w] = incl;
+        __syncthreads();
+        double before = run;
+        for (int q = 0; q < w; ++q) before += s_sum[q];
+        if (t < n) P[t + 1] = before + incl;
+        for (int q = 0; q < 16; ++q) run += s_sum[q];
+        __syncthreads();
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o);
+        finite &= __shfl_xor(finite, o);
+    }
+    if (lane == 0) { s_abs[w] = a; s_fin[w] = finite; }
+    __syncthreads();
+    if (tid == 0) {
+        double aa = 0.0;
+        int ff = 1;
+        for (int q = 0; q < 16; ++q) { aa += s_abs[q]; ff &= s_fin[q]; }
+        reg_abs[r] = aa;
+        reg_flag[r] = ff;
+    }
+    WC_STAMP(2);
+    // 3. getValue(0, n - 1): numpy's own sum of the whole region / sqrt(n) (wisecondor.py:237): the
+    // leaves of numpy's pairwise tree at once, one per group of eight lanes, then the fold
+    {
+        double v = NAN;
+        if (n > 0 && n <= 2048) {        // five halvings of <= 2048 (each half at most n / 2 + 7) end at <= 128 elements
+            int next = 0;
+            PwBlock<5>::leaves(zz, 0, n, next, tid >> 3, tid & 7, s_leaf);
+            __syncthreads();
+            next = 0;
+            v = PwBlock<5>::fold(n, next, s_leaf) / sqrt((double)n);
+        } else if (n > 0 && w == 0) {
+            const WindowMask wm{nullptr, 0, n};
+            v = window_exact_wave(zz, 0, n - 1, lane, wm, sc);
+        }
+        if (tid == 0) {
+            whole[r] = v;
+            if (whole2) whole2[r] = v;
+        }
+    }
+    WC_STAMP(3);
+}
+
+// Latency mode: the whole segmentation of a region AND its calls in ONE launch, one workgroup of
+// 1024 threads per region: for the region and then for every child range a block-local value search
+// (the general path's inner loops, sixteen waves), the candidates within 2 eps of the extremes, their exact
+// values and the reference's champion rule (triarray.py:59-84) -- the region's prefix array and the
+// job stack live in LDS; then the region's segments are put in order and turned into call rows
+// (coordinates with the reference's end quirk, median effect; wisecondor.py:239-257).  Regions are
+// independent, so no workgroup waits for another and the host never sees a round.  Anything this
+// kernel is not built for (non-finite values, more than CAND_CAP tied candidates, a deeper stack
+// than TREE_STACK, more than TREE_SEGS segments) raises counters[6]: the caller repeats the call
+// on the general path.
+constexpr int TREE_STACK = 64;
+constexpr int TREE_CHUNKS = 17;     // row blocks of the longest region the tree kernel takes (2048 bins)
+constexpr int TREE_SEGS = 128;
+constexpr int TREE_MAXLEN = 2048;
+__global__ __launch_bounds__(1024) void k_seg_tree(int *__restrict__ counters, const Region *__restrict__ regions,
+                                                   int64_t n_regions, const int *__restrict__ reg_flag,
+                                                   const double *__restrict__ prefix, const double *__restrict__ rs,
+                                                   const double *__restrict__ reg_abs, const double *__restrict__ z,
+                                                   const double *__restrict__ ratio, const int *__restrict__ gpos,
+                                                   double thr, int min_search, int max_calls,
+                                                   double *__restrict__ reg_calls, int *__restrict__ out_n,
+                                                   const Extreme *__restrict__ partial,
+                                                   const double2 *__restrict__ sub, int max_chunks) {
+    extern __shared__ double pl[];                 // the region's prefix array, n + 1 doubles (later: median scratch)
+    __shared__ Job stack[TREE_STACK];
+    __shared__ int s_sp, s_nhi, s_nlo, s_nseg, s_root;
+    __shared__ int2 c_hi[CAND_CAP], c_lo[CAND_CAP];
+    __shared__ double red_max[16], red_min[16];
+    __shared__ double ext_max[TREE_CHUNKS][2][16], ext_min[TREE_CHUNKS][2][16];   // per (row block, side, wave)
+    __shared__ wc::PwWaveScratch sc[4];
+    __shared__ BestPair s_best[4];
+    __shared__ double seg_val[TREE_SEGS];
+    __shared__ int seg_x[TREE_SEGS], seg_y[TREE_SEGS];
+    __shared__ double s_mid[2];
+    __shared__ int s_nan;
+    const int tid = threadIdx.x;
+    const int region = blockIdx.x;
+    if (region >= n_regions) return;
+    const Region rg = regions[region];
+    if (rg.n <= 0) return;
+    if (!reg_flag[region] || rg.n > TREE_MAXLEN) {     // non-finite values: the general path's exact scan
+        if (tid == 0) counters[6] = 1;
+        return;
+    }
+    WC_STAMP(8);
+    const long long a0 = rg.off + region;              // absolute index of the region's P[0]
+    const double *Pg = prefix + a0;
+    double *zl = pl + (rg.n + 1);                      // the region's z values, for the exact sums
+    for (int i = tid; i <= rg.n; i += 1024) pl[i] = Pg[i];
+    for (int i = tid; i < rg.n; i += 1024) zl[i] = z[rg.off + i];
+    if (tid == 0) { s_sp = 1; s_nseg = 0; s_root = 1; }
+    __syncthreads();
+    const double eps = window_eps(rg.n, reg_abs[region]);
+    const double *zz = zl;
+    const WindowMask wm{nullptr, 0, rg.n};
+    const int lane = tid & 63, w = tid >> 6;
+    if (tid == 0) {
+        Job root;
+        root.region = region; root.lo = 0; root.hi = rg.n; root.pad = 0;
+        stack[0] = root;
+    }
+    __syncthreads();
+    while (true) {
+        __syncthreads();
+        if (s_sp == 0) break;
+        const Job job = stack[s_sp - 1];
+        const bool is_root = s_root != 0;
+        __syncthreads();
+        if (tid == 0) { --s_sp; s_nhi = 0; s_nlo = 0; s_root = 0; }
+        __syncthreads();
+        ScanCtx c;
+        c.P = pl; c.lo = job.lo; c.hi = job.hi; c.L = job.hi - job.lo; c.half = (c.L + 1) / 2; c.chunk = 0;
+        c.wm = wm;
+        if (c.L <= 0) continue;
+        const int nch = (c.half + ROWS_HALF - 1) / ROWS_HALF;
+        // (no quiet certificate here: with sixteen waves on a range its full value search takes a
+        // few microseconds, less than the certificate's barrier rounds)
+        double emax, emin;
+        if (is_root) {
+            // the whole region was searched by k_seg_search, all row blocks in parallel on as many
+            // compute units: its per-block extremes stand in for the block-local search
+            emax = -INFINITY;
+            emin = INFINITY;
+            for (int ch = 0; ch < nch; ++ch) {
+                const Extreme pe = partial[(int64_t)region * max_chunks + ch];
+                emax = fmax(emax, pe.maxv);
+                emin = fmin(emin, pe.minv);
+            }
+            for (int t = tid; t < nch * 32; t += 1024) {
+                const int ch = t >> 5, side = (t >> 4) & 1, q = t & 15;
+                const double2 e2 = sub[((int64_t)region * max_chunks + ch) * 8 + side * 4 + (q >> 2)];
+                ext_max[ch][side][q] = e2.x;
+                ext_min[ch][side][q] = e2.y;
+            }
+            __syncthreads();
+            if (fmax(fabs(emax), fabs(emin)) + eps < thr) continue;
+        } else {
+            // value search with the general path's inner loops (four float64 operations per window);
+            // every (row block, side, wave) leaves its extremes behind for the candidate pass
+            const double *P = pl + job.lo;
+            double bmax = -INFINITY, bmin = INFINITY;
+            int dummy = 0;
+            for (int ch = 0; ch < nch; ++ch)
+                for (int side = 0; side < 2; ++side) {
+                    double smax, smin;
+                    search_side<false, 16>(P, c.L, c.half, ch, side, rs, lane, w, job.lo, wm, smax, smin, dummy);
+                    if (lane == 0) { ext_max[ch][side][w] = smax; ext_min[ch][side][w] = smin; }
+                    bmax = fmax(bmax, smax);
+                    bmin = fmin(bmin, smin);
+                }
+            if (lane == 0) { red_max[w] = bmax; red_min[w] = bmin; }
+            __syncthreads();
+            emax = red_max[0];
+            emin = red_min[0];
+            for (int q = 1; q < 16; ++q) { emax = fmax(emax, red_max[q]); emin = fmin(emin, red_min[q]); }
+            __syncthreads();
+            if (fmax(fabs(emax), fabs(emin)) + eps < thr) continue;      // no call in this range (k_seg_classify's test)
+        }
+        // windows within 2 eps of the extremes: one of them is numpy's argmax / argmin.  Only the
+        // (row block, side) pairs whose own extremes reach a cut are scanned again.
+        WC_STAMP(is_root ? 9 : 13);
+        const double hi_cut = emax - 2.0 * eps, lo_cut = emin + 2.0 * eps;
+        for (int ch = 0; ch < nch; ++ch) {
+            unsigned int skip = 0u;
+            for (int side = 0; side < 2; ++side) {
+                bool none = true;
+                for (int q = 0; q < 16; ++q)
+                    none = none && ext_max[ch][side][q] < hi_cut && ext_min[ch][side][q] > lo_cut;
+                if (none) skip |= 0xFFFFu << (side * 16);
+            }
+            if (skip == 0xFFFFFFFFu) continue;
+            c.chunk = ch;
+            scan_chunk(c, rs, tid, [&](double v, int x, int y) {
+                if (v >= hi_cut) {
+                    const int at = atomicAdd(&s_nhi, 1);
+                    if (at < CAND_CAP) c_hi[at] = make_int2(x, y);
+                }
+                if (v <= lo_cut) {
+                    const int at = atomicAdd(&s_nlo, 1);
+                    if (at < CAND_CAP) c_lo[at] = make_int2(x, y);
+                }
+            }, skip);
+        }
+        __syncthreads();
+        WC_STAMP(is_root ? 10 : 14);
+        const int n_hi = s_nhi, n_lo = s_nlo;
+        if (n_hi > CAND_CAP || n_lo > CAND_CAP) {     // massive ties: the general path evaluates everything exactly
+            if (tid == 0) counters[6] = 1;
+            return;
+        }
+        // exact values of the candidates (numpy pairwise sum / sqrt) by the first four waves: waves
+        // 0-1 the candidates for the maximum, 2-3 for the minimum
+        if (w < 4) {
+            BestPair b;
+            b.maxv = 0.0; b.minv = 0.0; b.mx = b.my = b.nx = b.ny = -1;
+            const int which = w >> 1, slot = w & 1;
+            const int n_mine = which == 0 ? n_hi : n_lo;
+            for (int t = slot; t < n_mine; t += 2) {
+                const int2 cw = which == 0 ? c_hi[t] : c_lo[t];
+                const double v = window_exact_wave(zz, cw.x, cw.y, lane, wm, sc[w]);
+                if (which == 0) {
+                    if (better_max(v, cw.x, cw.y, b.maxv, b.mx, b.my)) { b.maxv = v; b.mx = cw.x; b.my = cw.y; }
+                } else {
+                    if (better_min(v, cw.x, cw.y, b.minv, b.nx, b.ny)) { b.minv = v; b.nx = cw.x; b.ny = cw.y; }
+                }
+            }
+            if (lane == 0) s_best[w] = b;
+        }
+        __syncthreads();
+        WC_STAMP(is_root ? 11 : 15);
+        if (tid == 0) {
+            BestPair b = s_best[0];
+            if (s_best[1].mx >= 0 && better_max(s_best[1].maxv, s_best[1].mx, s_best[1].my, b.maxv, b.mx, b.my)) {
+                b.maxv = s_best[1].maxv; b.mx = s_best[1].mx; b.my = s_best[1].my;
+            }
+            b.minv = s_best[2].minv; b.nx = s_best[2].nx; b.ny = s_best[2].ny;
+            if (s_best[3].nx >= 0 && better_min(s_best[3].minv, s_best[3].nx, s_best[3].ny, b.minv, b.nx, b.ny)) {
+                b.minv = s_best[3].minv; b.nx = s_best[3].nx; b.ny = s_best[3].ny;
+            }
+            double champ = b.maxv;
+            int cx = b.mx, cy = b.my;
+            if (fabs(b.minv) > champ) { champ = b.minv; cx = b.nx; cy = b.ny; }
+            if (!(fabs(champ) < thr)) {
+                if (s_nseg < TREE_SEGS) { seg_val[s_nseg] = champ; seg_x[s_nseg] = cx; seg_y[s_nseg] = cy; ++s_nseg; }
+                else counters[6] = 1;
+                const int xr = cx - job.lo, yr = cy - job.lo, edge = job.hi - job.lo;
+                const bool left = xr > min_search, right = yr + 1 < edge - min_search;
+                if (s_sp + (left ? 1 : 0) + (right ? 1 : 0) > TREE_STACK) {
+                    counters[6] = 1;
+                } else {
+                    if (right) { Job n; n.region = job.region; n.lo = cy + 1; n.hi = job.hi; n.pad = 0; stack[s_sp++] = n; }
+                    if (left) { Job n; n.region = job.region; n.lo = job.lo; n.hi = cx; n.pad = 0; stack[s_sp++] = n; }
+                }
+            }
+        }
+    }
+    // ---- the region's calls, in position order (k_seg_gather + k_call_post of the general path)
+    __syncthreads();
+    WC_STAMP(16);
+    const int nseg = s_nseg;
+    if (tid == 0) {
+        out_n[region] = nseg;
+        atomicAdd(&counters[4], nseg);
+    }
+    const double *rr = ratio + rg.off;
+    for (int sidx = 0; sidx < nseg; ++sidx) {
+        const int x = seg_x[sidx], y = seg_y[sidx], L = y - x + 1;
+        int rank = 0;
+        for (int u = 0; u < nseg; ++u) rank += seg_x[u] < x;
+        if (rank >= max_calls) continue;                   // k_assemble_calls reports the overflow from out_n
+        __syncthreads();
+        if (tid == 0) s_nan = 0;
+        __syncthreads();
+        double *sv = pl;                                   // the prefix array is not needed any more
+        for (int e = tid; e < L; e += 1024) {
+            const double v = rr[x + e];
+            sv[e] = v;
+            if (v != v) s_nan = 1;
+        }
+        __syncthreads();
+        const bool has_nan = s_nan != 0;
+        if (!has_nan) {
+            // every value counts the values below / at-or-below it; the value whose interval covers
+            // a middle rank is that order statistic (np.median: mean of the middle pair)
+            const int k_lo = (L - 1) / 2, k_hi = L / 2;
+            for (int e = tid; e < L; e += 1024) {
+                const double xv = sv[e];
+                int lt = 0, le = 0;
+                for (int u = 0; u < L; ++u) {
+                    const double yv = sv[u];
+                    lt += yv < xv;
+                    le += yv <= xv;
+                }
+                if (lt <= k_lo && k_lo < le) s_mid[0] = xv;      // equal values write the same number
+                if (lt <= k_hi && k_hi < le) s_mid[1] = xv;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double med = (L & 1) ? s_mid[0] : (s_mid[0] + s_mid[1]) / 2.0;
+            if (has_nan) med = NAN;
+            // the end walk of the reference restarts at `start` and re-counts it:
+            // end = position(survivor y-1) + 1, or start itself when y == x
+            const int start = gpos[rg.off + x];
+            const int end = (y > x) ? gpos[rg.off + y - 1] + 1 : start;
+            double *o = reg_calls + ((int64_t)region * max_calls + rank) * 5;
+            o[0] = (double)(rg.pad + 1);
+            o[1] = (double)start;
+            o[2] = (double)end;
+            o[3] = seg_val[sidx];
+            o[4] = med - 1.0;
+        }
+    }
+    WC_STAMP(17);
+}
+
 // Order each region's segments by position (the reference's in-order recursion).
 __global__ __launch_bounds__(256) void k_seg_gather(const Seg *__restrict__ segs, int n_segs, int max_calls,
                                                     double *__restrict__ out_val, int *__restrict__ out_x,
@@ -1795,10 +2689,9 @@ __global__ __launch_bounds__(256) void k_call_post(const Seg *__restrict__ segs,
     }
 }
 
-__global__ void k_assemble_calls(const double *__restrict__ reg_calls, const int *__restrict__ out_n, int n_sel,
-                                 int max_calls, int64_t Ns, double *__restrict__ calls, int *__restrict__ n_calls,
-                                 int *__restrict__ overflow) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ inline void assemble_one(const double *__restrict__ reg_calls, const int *__restrict__ out_n, int n_sel,
+                                    int max_calls, int64_t Ns, double *__restrict__ calls, int *__restrict__ n_calls,
+                                    int *__restrict__ overflow, int64_t i) {
     if (i >= Ns) return;
     int total = 0;
     for (int s = 0; s < n_sel; ++s) {
@@ -1817,6 +2710,34 @@ __global__ void k_assemble_calls(const double *__restrict__ reg_calls, const int
     }
     n_calls[i] = total < max_calls ? total : max_calls;
 }
+
+// (host_status, latency mode, one workgroup: the status words for the host go straight to pinned
+// memory -- [16] call overflow, [24..31] the segmentation counters, [32] k_lat_repeats' overflow flag,
+// [33] stdDevAvg left to the serial kernel)
+__global__ void k_assemble_calls(const double *__restrict__ reg_calls, const int *__restrict__ out_n, int n_sel,
+                                 int max_calls, int64_t Ns, double *__restrict__ calls, int *__restrict__ n_calls,
+                                 int *__restrict__ overflow, int *__restrict__ host_status,
+                                 const int *__restrict__ counters, const int *__restrict__ rep_overflow,
+                                 const int *__restrict__ sd_fail) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (host_status) {
+        assemble_one(reg_calls, out_n, n_sel, max_calls, Ns, calls, n_calls, overflow, i);
+        __syncthreads();
+        const int t = threadIdx.x;
+        if (t == 0) host_status[16] = overflow[0];
+        if (t < 8) host_status[24 + t] = counters[t];
+        if (t == 8) host_status[32] = rep_overflow[0];
+        if (t == 9) {
+            int f = 0;
+            for (int64_t q = 0; q < Ns; ++q) f |= sd_fail[q];
+            host_status[33] = f;
+        }
+        __threadfence_system();
+        return;
+    }
+    assemble_one(reg_calls, out_n, n_sel, max_calls, Ns, calls, n_calls, overflow, i);
+}
+
 
 // ------------------------------------------------------------ host drivers ----
 int run_prepare(wc_ctx *ctx, const wc_reference *ref, const int *counts_dev, int64_t Ns, hipStream_t stream) {
@@ -1867,8 +2788,10 @@ void launch_transpose(const double *in, int64_t R, int64_t C, double *out, hipSt
 }
 
 // repeatTest on device data [Ns, B]; leaves zt/rt/nt/sdt as [B, Ns] and sd_avg[Ns]
+// lat: latency mode -- k_lat_prepare has already written xt / xc and cleared the counters; the first
+// repeat runs as usual, repeats 2.. in one launch (k_lat_repeats; its overflow flag is pair_counts[repeats + 1])
 int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int64_t Ns, double thr, int repeats,
-               hipStream_t stream) {
+               hipStream_t stream, bool lat = false, double *asdef_out = nullptr) {
     TestState &ts = ctx->ts;
     const int64_t n = ref->B * Ns;
     int rc;
@@ -1885,8 +2808,9 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
             if ((rc = b->reserve(sizeof(unsigned int) * n))) return rc;
     int *pair_counts = ts.misc2.as<int>();                       // [repeats + 2]: pairs queued for repeat it
     unsigned int *dirty = (unsigned int *)(pair_counts + repeats + 2);
-    launch_transpose(data_dev, Ns, ref->B, ts.xt.as<double>(), stream, ts.xc.as<double>(), pair_counts,
-                     repeats > 0 ? repeats + 2 + n_words : 0);
+    if (!lat)
+        launch_transpose(data_dev, Ns, ref->B, ts.xt.as<double>(), stream, ts.xc.as<double>(), pair_counts,
+                         repeats > 0 ? repeats + 2 + n_words : 0);
     const unsigned g = (unsigned)cdiv(n, 256);
     if (repeats < 1) {  // the reference would return None; give NaNs
         WC_HIP(hipMemsetAsync(ts.zt.p, 0xFF, sizeof(double) * n, stream));
@@ -1896,6 +2820,14 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
     }
     const int *uoff = ref->users_off.as<int>(), *ulst = ref->users.as<int>();
     for (int it = 0; it < repeats; ++it) {
+        if (lat && it == 1) {
+            hipLaunchKernelGGL(k_lat_repeats, dim3(1), dim3(1024), 0, stream, ts.pairs_a.as<unsigned int>(),
+                               ts.pairs_b.as<unsigned int>(), pair_counts, repeats, dirty,
+                               (const double *)ts.xt.as<double>(), ts.xc.as<double>(), (const int *)ref->gidx.as<int>(),
+                               (const int *)ref->nref.as<int>(), ref->k, Ns, thr, uoff, ulst, ts.zt.as<double>(),
+                               ts.rt.as<double>(), ts.nt.as<double>(), ts.sdt.as<double>(), pair_counts + repeats + 1);
+            break;
+        }
         // repeat `it` recomputes the pairs queued in its list (all pairs in the first repeat) and
         // queues, for repeat it + 1, the pairs that see one of its new flags
         unsigned int *cur = (it & 1) ? ts.pairs_a.as<unsigned int>() : ts.pairs_b.as<unsigned int>();
@@ -1947,17 +2879,38 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
                                ts.xc.as<double>(), uoff, ulst, dirty, next, pair_counts + it + 1);
         }
     }
-    // stdDevAvg is a serial sum by definition (one lane per sample); it only feeds the
-    // asdef output, so it runs on the context's side stream under the segmentation work.
-    if ((rc = ctx->ensure_side_stream())) return rc;
-    WC_HIP(hipEventRecord(ctx->ev_fork, stream));
-    WC_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
-    if (Ns <= 16)
-        hipLaunchKernelGGL(k_sd_avg<16>, dim3((unsigned)cdiv(Ns, 16)), dim3(256), 0, ctx->side,
-                           (const double *)ts.sdt.as<double>(), ref->B, Ns, ts.sd_avg.as<double>());
+    // stdDevAvg only feeds the asdef output: it runs on the context's side stream under the
+    // segmentation work (latency mode: on the launch stream -- the parallel form takes a few
+    // microseconds, a second stream in the captured graph costs more -- straight into `asdef_out`).
+    hipStream_t sds = stream;
+    {
+        if ((rc = ctx->ensure_side_stream())) return rc;
+        WC_HIP(hipEventRecord(ctx->ev_fork, stream));
+        WC_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+        sds = ctx->side;
+    }
+    // the parallel form first (exact, see k_sd_fast); the serial chain only for samples it gave up on
+    const char *sd_env = getenv("WC_SD_AVG");                   // "serial": the chain for every sample
+    const int *only = nullptr;
+    double *out2 = lat ? asdef_out : nullptr;
+    if (!(sd_env && strcmp(sd_env, "serial") == 0) && ref->B <= 65536) {
+        if ((rc = ts.sd_fail.reserve(sizeof(int) * Ns))) return rc;
+        launch_sd_fast(sds, ts.sdt.as<double>(), ref->B, Ns, ts.sd_avg.as<double>(), ts.sd_fail.as<int>(), out2);
+        only = ts.sd_fail.as<int>();
+    }
+    if (lat && !only) {        // the status word reads the flags: none raised
+        if ((rc = ts.sd_fail.reserve(sizeof(int) * Ns))) return rc;
+        WC_HIP(hipMemsetAsync(ts.sd_fail.p, 0, sizeof(int) * Ns, sds));
+    }
+    if (lat && only) {
+        // latency mode: a sample the parallel form gave up on sends the call to the general path
+        // (status word 33) instead of costing every call a launch
+    } else if (Ns <= 16)
+        hipLaunchKernelGGL(k_sd_avg<16>, dim3((unsigned)cdiv(Ns, 16)), dim3(256), 0, sds,
+                           (const double *)ts.sdt.as<double>(), ref->B, Ns, ts.sd_avg.as<double>(), only, out2);
     else
-        hipLaunchKernelGGL(k_sd_avg<64>, dim3((unsigned)cdiv(Ns, 64)), dim3(256), 0, ctx->side,
-                           (const double *)ts.sdt.as<double>(), ref->B, Ns, ts.sd_avg.as<double>());
+        hipLaunchKernelGGL(k_sd_avg<64>, dim3((unsigned)cdiv(Ns, 64)), dim3(256), 0, sds,
+                           (const double *)ts.sdt.as<double>(), ref->B, Ns, ts.sd_avg.as<double>(), only, out2);
     WC_HIP(hipEventRecord(ctx->ev_join, ctx->side));
     ctx->side_pending = true;
     WC_HIP(hipGetLastError());
@@ -1983,7 +2936,7 @@ int join_side(wc_ctx *ctx, hipStream_t stream) {
 int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, int64_t n_regions, int64_t total_len,
                  int64_t max_n, double thr, int min_search, int max_calls, hipStream_t stream,
                  const double *ratio_dev = nullptr, double min_effect = 0.0, int64_t bits_upper = 0,
-                 int lat_rounds = 0) {
+                 int lat_rounds = 0, double *whole_copy = nullptr) {
     TestState &ts = ctx->ts;
     int rc;
     ts.last_segs = 0;
@@ -1994,7 +2947,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     if ((rc = ts.prefix.reserve(sizeof(double) * (total_len + n_regions + 8)))) return rc;
     if ((rc = ts.reg_abs.reserve(sizeof(double) * n_regions))) return rc;
     if ((rc = ts.reg_flag.reserve(sizeof(int) * n_regions))) return rc;
-    const int64_t rs_need = std::max<int64_t>(max_n + 8, 2 * QB + 8);   // the search reads four lengths at a time
+    const int64_t rs_need = std::max<int64_t>(max_n + 80, 2 * QB + 80);   // the search reads four lengths at a time (the candidate scan one trip ahead)
                                                                         // past the longest window, the certificate 1..64
     if (ts.rs_len < rs_need) {
         if ((rc = ts.rs.reserve(sizeof(double) * rs_need))) return rc;
@@ -2056,7 +3009,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
                            (const double *)ts.prefix.as<double>(), total, ts.tmin.as<double>(), ts.tmax.as<double>());
     }
     hipLaunchKernelGGL(k_region_whole, dim3((unsigned)cdiv(n_regions, 4)), dim3(256), 0, stream, z_dev, regions_dev,
-                       n_regions, bits, bit_off, ts.whole.as<double>());
+                       n_regions, bits, bit_off, ts.whole.as<double>(), whole_copy);
     hipLaunchKernelGGL(k_init_jobs, dim3((unsigned)cdiv(n_regions, 256)), dim3(256), 0, stream, regions_dev, n_regions,
                        ts.jobs_a.as<Job>(), counters);
     Job *cur = ts.jobs_a.as<Job>(), *next = ts.jobs_b.as<Job>();
@@ -2065,65 +3018,6 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     if ((rc = ctx->ensure_pinned(256))) return rc;
     int *h = (int *)ctx->pinned;          // counter read-backs land in pinned memory
     h[4] = 0;
-    if (lat_rounds > 0) {
-        const bool plds = max_n + 1 <= 6144;
-        const size_t dyn = plds ? sizeof(double) * (max_n + 1) : 0;
-        int64_t bound = n_regions;
-        {
-            const int64_t most = std::min<int64_t>(job_cap, n_regions << (lat_rounds - 1));
-            if ((rc = ts.partial.reserve(sizeof(Extreme) * most * max_chunks))) return rc;
-            if ((rc = ts.sub.reserve(sizeof(double2) * 8 * most * max_chunks))) return rc;
-            if ((rc = ts.cand.reserve(sizeof(int2) * 2 * CAND_CAP * most))) return rc;
-            if ((rc = ts.cand_cnt.reserve(sizeof(int) * 2 * most))) return rc;
-        }
-        for (int r = 0; r < lat_rounds; ++r) {
-            const int *nj = counters + ((r & 1) ? 5 : 1);
-            int *nx = counters + ((r & 1) ? 1 : 5);
-            const dim3 sg((unsigned)max_chunks, (unsigned)bound);
-            const unsigned per_job = (unsigned)std::min<int64_t>(max_chunks, std::max<int64_t>(1, 16384 / bound));
-            hipLaunchKernelGGL(k_seg_quiet, dim3(per_job, (unsigned)bound), dim3(256), 0, stream, cur, (int)bound, regions_dev,
-                               (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
-                               (const double *)ts.reg_abs.as<double>(), (const int *)ts.reg_flag.as<int>(), thr,
-                               (const double *)ts.tmin.as<double>(), (const double *)ts.tmax.as<double>(), work, nj);
-#define WC_LSEARCH(P_, NW_)                                                                                          \
-    hipLaunchKernelGGL((k_seg_search<false, P_, NW_>), sg, dim3(64 * NW_), dyn, stream, (const Job *)cur, (int)bound, \
-                       regions_dev, (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),      \
-                       (const int *)ts.reg_flag.as<int>(), max_chunks, bits, bit_off, ts.partial.as<Extreme>(),    \
-                       counters, 1, ts.sub.as<double2>(), work, nj, nx)
-            if (bound * max_chunks <= 2048) { if (plds) WC_LSEARCH(true, 16); else WC_LSEARCH(false, 16); }
-            else { if (plds) WC_LSEARCH(true, 4); else WC_LSEARCH(false, 4); }
-#undef WC_LSEARCH
-            hipLaunchKernelGGL(k_seg_classify, dim3((unsigned)bound), dim3(64), 0, stream, (const Job *)cur, (int)bound,
-                               regions_dev, (const double *)ts.reg_abs.as<double>(), (const int *)ts.reg_flag.as<int>(),
-                               (const Extreme *)ts.partial.as<Extreme>(), max_chunks, thr, ts.job_res.as<Extreme>(), hot,
-                               brute, counters, ts.cand_cnt.as<int>(), 1, nj);
-            hipLaunchKernelGGL(k_seg_collect, dim3((unsigned)max_chunks, (unsigned)bound), dim3(1024), 0, stream,
-                               (const Job *)cur, (const int *)hot, (const int *)counters, regions_dev,
-                               (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
-                               (const double *)ts.reg_abs.as<double>(), (const Extreme *)ts.job_res.as<Extreme>(),
-                               (const Extreme *)ts.partial.as<Extreme>(), max_chunks,
-                               (const double2 *)ts.sub.as<double2>(), bits, bit_off, ts.cand.as<int2>(),
-                               ts.cand_cnt.as<int>());
-            hipLaunchKernelGGL(k_seg_decide, dim3((unsigned)bound), dim3(256), 0, stream, (const Job *)cur,
-                               (const int *)hot, counters, regions_dev, z_dev, (const int2 *)ts.cand.as<int2>(),
-                               (const int *)ts.cand_cnt.as<int>(), thr, min_search, bits, bit_off, ts.seg.as<Seg>(),
-                               (int)seg_cap, next, (int)job_cap, brute, nx);
-            hipLaunchKernelGGL(k_seg_brute, dim3((unsigned)bound), dim3(256), 0, stream, (const Job *)cur,
-                               (const int *)brute, counters, regions_dev, z_dev, thr, min_search, bits, bit_off,
-                               ts.seg.as<Seg>(), (int)seg_cap, next, (int)job_cap, nx);
-            std::swap(cur, next);
-            bound = std::min<int64_t>(job_cap, 2 * bound);
-        }
-        // segments by position; their count stays on the device (the grid is sized for the bound)
-        const int seg_bound = (int)std::min<int64_t>(seg_cap, 4096);
-        hipLaunchKernelGGL(k_seg_gather, dim3((unsigned)cdiv(seg_bound, 256)), dim3(256), 0, stream,
-                           (const Seg *)ts.seg.as<Seg>(), seg_bound, max_calls, ts.out_val.as<double>(), ts.out_x.as<int>(),
-                           ts.out_y.as<int>(), ts.out_n.as<int>(), (const int *)(counters + 4));
-        ts.last_segs = -seg_bound;            // negative: a bound, the count is counters[4] on the device
-        ts.lat_left = (lat_rounds & 1) ? 5 : 1;   // counter holding the jobs left over after the last round
-        WC_HIP(hipGetLastError());
-        return WC_OK;
-    }
     while (n_jobs > 0) {
         WC_CHECK(++guard < 100000, WC_E_INTERNAL, "stouffer: recursion did not terminate");
         // per-round scratch is sized by the jobs of this round, not by the worst case
@@ -2207,6 +3101,75 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     return WC_OK;
 }
 
+// Latency mode's cleaning + segmentation: k_lat_setup, k_block_minmax, k_seg_tree, k_seg_gather --
+// no host round trip; counters[4] (segments) and [6] (give-up flag) are looked at by the caller
+// after it synchronised.  Results as run_stouffer leaves them (ts.out_*, ts.whole, ts.seg).
+int run_seg_lat(wc_ctx *ctx, const wc_reference *ref, const double *zsrc, const double *rsrc, const double *nsrc,
+                int64_t str_i, int64_t str_b, int64_t Ns, int n_sel, int64_t max_n, double thr, int min_ref_bins,
+                int max_calls, hipStream_t stream, double *whole_copy) {
+    TestState &ts = ctx->ts;
+    const int64_t B = ref->B, n_regions = Ns * n_sel, total_len = Ns * B;
+    int rc;
+    const int64_t seg_cap = n_regions * (int64_t)max_calls + 64;
+    if ((rc = ts.prefix.reserve(sizeof(double) * (total_len + n_regions + 8)))) return rc;
+    if ((rc = ts.reg_abs.reserve(sizeof(double) * n_regions))) return rc;
+    if ((rc = ts.reg_flag.reserve(sizeof(int) * n_regions))) return rc;
+    const int64_t rs_need = std::max<int64_t>(max_n + 80, 2 * QB + 80);
+    if (ts.rs_len < rs_need) {
+        if ((rc = ts.rs.reserve(sizeof(double) * rs_need))) return rc;
+        ts.rs_len = rs_need;
+        hipLaunchKernelGGL(k_fill_rs, dim3((unsigned)cdiv(ts.rs_len, 256)), dim3(256), 0, stream, ts.rs.as<double>(),
+                           ts.rs_len);
+    }
+    if ((rc = ts.jobs_a.reserve(sizeof(Job) * (n_regions + 64)))) return rc;
+    if ((rc = ts.job_cnt.reserve(sizeof(int) * 8))) return rc;
+    if ((rc = ts.seg.reserve(sizeof(Seg) * seg_cap))) return rc;
+    if ((rc = ts.out_val.reserve(sizeof(double) * n_regions * max_calls))) return rc;
+    if ((rc = ts.out_x.reserve(sizeof(int) * n_regions * max_calls))) return rc;
+    if ((rc = ts.out_y.reserve(sizeof(int) * n_regions * max_calls))) return rc;
+    if ((rc = ts.out_n.reserve(sizeof(int) * n_regions))) return rc;
+    if ((rc = ts.whole.reserve(sizeof(double) * n_regions))) return rc;
+    if ((rc = ts.misc.reserve(sizeof(int) * 4))) return rc;
+    const int64_t total = total_len + n_regions, nblk = cdiv(total, QB);
+    if ((rc = ts.tmin.reserve(sizeof(double) * nblk))) return rc;
+    if ((rc = ts.tmax.reserve(sizeof(double) * nblk))) return rc;
+    int *counters = ts.job_cnt.as<int>();
+    hipLaunchKernelGGL(k_lat_setup, dim3((unsigned)n_regions), dim3(1024), sizeof(double) * (max_n + 1), stream, zsrc, rsrc, nsrc, str_i, str_b, B,
+                       (const int64_t *)ref->moff_dev.as<int64_t>(), (const int64_t *)ref->goff_dev.as<int64_t>(),
+                       (const int *)ref->m2g.as<int>(), (const int *)ts.sel.as<int>(), n_sel, (double)min_ref_bins,
+                       ts.zc.as<double>(), ts.rc.as<double>(), ts.gpos.as<int>(), ts.regions.as<Region>(),
+                       ts.prefix.as<double>(), ts.reg_abs.as<double>(), ts.reg_flag.as<int>(), ts.whole.as<double>(),
+                       whole_copy, ts.jobs_a.as<Job>(), counters, ts.out_n.as<int>(), ts.misc.as<int>(), n_regions);
+    // the regions' value search with all row blocks in parallel (the general path's kernel, no
+    // certificate); the tree kernel starts from its per-block extremes
+    const int max_chunks = (int)std::max<int64_t>(1, cdiv((max_n + 1) / 2, ROWS_HALF));
+    if ((rc = ts.partial.reserve(sizeof(Extreme) * n_regions * max_chunks))) return rc;
+    if ((rc = ts.sub.reserve(sizeof(double2) * 8 * n_regions * max_chunks))) return rc;
+    {
+        const dim3 sg((unsigned)max_chunks, (unsigned)n_regions);
+        const size_t dyn = sizeof(double) * (max_n + 1);
+#define WC_LSEARCH(NW_)                                                                                              \
+    hipLaunchKernelGGL((k_seg_search<false, true, NW_>), sg, dim3(64 * NW_), dyn, stream,                            \
+                       (const Job *)ts.jobs_a.as<Job>(), (int)n_regions, (const Region *)ts.regions.as<Region>(),    \
+                       (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),                   \
+                       (const int *)ts.reg_flag.as<int>(), max_chunks, (const unsigned int *)nullptr,                \
+                       (const long long *)nullptr, ts.partial.as<Extreme>(), counters, 0, ts.sub.as<double2>(),      \
+                       (unsigned long long *)nullptr, (const int *)nullptr, counters + 5)
+        if (n_regions * max_chunks <= 2048) WC_LSEARCH(16); else WC_LSEARCH(4);
+#undef WC_LSEARCH
+    }
+    hipLaunchKernelGGL(k_seg_tree, dim3((unsigned)n_regions), dim3(1024), sizeof(double) * (2 * max_n + 2), stream, counters,
+                       (const Region *)ts.regions.as<Region>(), n_regions, (const int *)ts.reg_flag.as<int>(),
+                       (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
+                       (const double *)ts.reg_abs.as<double>(), (const double *)ts.zc.as<double>(),
+                       (const double *)ts.rc.as<double>(), (const int *)ts.gpos.as<int>(), thr, 3, max_calls,
+                       ts.effect.as<double>(), ts.out_n.as<int>(), (const Extreme *)ts.partial.as<Extreme>(),
+                       (const double2 *)ts.sub.as<double2>(), max_chunks);
+    ts.last_segs = 0;                     // the calls are already in ts.effect / ts.out_n
+    WC_HIP(hipGetLastError());
+    return WC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -2244,6 +3207,8 @@ wc_reference *wc_reference_create(wc_ctx *ctx, const int32_t *indexes, const dou
         return nullptr;
     }
     wc_reference *ref = new wc_reference();
+    static unsigned long long next_serial = 0;
+    ref->serial = ++next_serial;
     ref->ctx = ctx;
     ref->B = n_bins;
     ref->k = k;
@@ -2424,6 +3389,41 @@ int wc_repeat_test(wc_ctx *ctx, const wc_reference *ref, const double *data, int
     return WC_OK;
 }
 
+int wc_std_dev_avg(wc_ctx *ctx, const double *sd, int64_t n_samples, int64_t n_bins, double *out,
+                   int32_t *serial_samples) {
+    WC_CHECK(ctx && sd && out && n_samples > 0 && n_bins > 0, WC_E_ARG, "stdDevAvg: bad argument");
+    WC_HIP(hipSetDevice(ctx->device));
+    TestState &ts = ctx->ts;
+    const int64_t n = n_samples * n_bins;
+    int rc;
+    if ((rc = ts.data.reserve(sizeof(double) * n))) return rc;
+    if ((rc = ts.sdt.reserve(sizeof(double) * n))) return rc;
+    if ((rc = ts.sd_avg.reserve(sizeof(double) * n_samples))) return rc;
+    if ((rc = ts.sd_fail.reserve(sizeof(int) * n_samples))) return rc;
+    WC_HIP(hipMemcpy(ts.data.p, sd, sizeof(double) * n, hipMemcpyHostToDevice));
+    launch_transpose(ts.data.as<double>(), n_samples, n_bins, ts.sdt.as<double>(), nullptr);     // bin-major like the repeats
+    WC_HIP(hipMemset(ts.sd_fail.p, 0, sizeof(int) * n_samples));
+    const int *only = nullptr;
+    if (n_bins <= 65536) {
+        launch_sd_fast(nullptr, ts.sdt.as<double>(), n_bins, n_samples, ts.sd_avg.as<double>(), ts.sd_fail.as<int>(),
+                       nullptr);
+        only = ts.sd_fail.as<int>();
+    }
+    hipLaunchKernelGGL(k_sd_avg<64>, dim3((unsigned)cdiv(n_samples, 64)), dim3(256), 0, nullptr,
+                       (const double *)ts.sdt.as<double>(), n_bins, n_samples, ts.sd_avg.as<double>(), only,
+                       (double *)nullptr);
+    WC_HIP(hipDeviceSynchronize());
+    WC_HIP(hipMemcpy(out, ts.sd_avg.p, sizeof(double) * n_samples, hipMemcpyDeviceToHost));
+    if (serial_samples) {
+        std::vector<int> f(n_samples, 1);
+        if (only) WC_HIP(hipMemcpy(f.data(), ts.sd_fail.p, sizeof(int) * n_samples, hipMemcpyDeviceToHost));
+        int c = 0;
+        for (int v : f) c += v != 0;
+        *serial_samples = c;
+    }
+    return WC_OK;
+}
+
 int wc_stouffer_segments(wc_ctx *ctx, const double *z, const double *ratio, double min_effect,
                          const int64_t *region_offsets, int64_t n_regions, double threshold, int min_search,
                          int max_calls, double *region_z, int32_t *n_calls, double *call_value, int32_t *call_x,
@@ -2491,31 +3491,61 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
     int rc;
     ts.prof_tag.clear();
     ts.mark(0, stream);
-    if ((rc = run_prepare(ctx, ref, counts, Ns, stream))) return rc;
+    const bool lat = lat_rounds > 0;
+    if (lat) {
+        // totals, normalisation, PCA and the repeats' working arrays in one launch
+        const int64_t n = B * Ns, n_words = cdiv(n, 32);
+        if ((rc = ts.totals.reserve(sizeof(double) * Ns))) return rc;
+        if ((rc = ts.raw.reserve(sizeof(double) * n))) return rc;
+        if ((rc = ts.data.reserve(sizeof(double) * n))) return rc;
+        if ((rc = ts.xt.reserve(sizeof(double) * n))) return rc;
+        if ((rc = ts.xc.reserve(sizeof(double) * n))) return rc;
+        if ((rc = ts.misc2.reserve(sizeof(int) * (repeats + 2 + n_words)))) return rc;
+        if ((rc = ts.proj.reserve(sizeof(double) * Ns * MAX_COMP * PROJ_SPLIT))) return rc;
+        hipLaunchKernelGGL(k_lat_project, dim3((unsigned)Ns, PROJ_SPLIT), dim3(256), 0, stream, counts, ref->Btot,
+                           (const int *)ref->m2g.as<int>(), B, (const double *)ref->pca_mean.as<double>(),
+                           (const double *)ref->pca_comp.as<double>(), ref->n_comp, ts.totals.as<double>(),
+                           ts.proj.as<double>());
+        hipLaunchKernelGGL(k_lat_apply, dim3((unsigned)cdiv(B, 256), (unsigned)Ns), dim3(256), 0, stream, counts,
+                           ref->Btot, (const int *)ref->m2g.as<int>(), B, Ns, (const double *)ts.totals.as<double>(),
+                           (const double *)ref->pca_mean.as<double>(), (const double *)ref->pca_comp.as<double>(),
+                           ref->n_comp, (const double *)ts.proj.as<double>(), ts.data.as<double>(), ts.xt.as<double>(),
+                           ts.xc.as<double>(), ts.misc2.as<int>(), repeats + 2 + n_words);
+    } else if ((rc = run_prepare(ctx, ref, counts, Ns, stream))) {
+        return rc;
+    }
     ts.mark(1, stream);
-    if ((rc = run_repeat(ctx, ref, ts.data.as<double>(), Ns, threshold, repeats, stream))) return rc;
+    if ((rc = run_repeat(ctx, ref, ts.data.as<double>(), Ns, threshold, repeats, stream, lat, asdef))) return rc;
     ts.mark(2, stream);
     struct Joiner {   // asdef is copied out once the side stream's sum is done, on every exit path
-        wc_ctx *c; hipStream_t s; double *dst; int64_t n;
+        wc_ctx *c; hipStream_t s; double *dst; int64_t n; bool on;
         ~Joiner() {
-            if (join_side(c, s) == WC_OK && dst)
+            if (on && join_side(c, s) == WC_OK && dst)
                 (void)hipMemcpyAsync(dst, c->ts.sd_avg.p, sizeof(double) * n, hipMemcpyDeviceToDevice, s);
         }
-    } joiner{ctx, stream, asdef, Ns};
+    } joiner{ctx, stream, asdef, Ns, !lat};
+    struct LatJoin {   // latency mode: asdef is written by the kernel itself; the side branch still has to rejoin
+        wc_ctx *c; hipStream_t s; bool on;
+        ~LatJoin() { if (on) (void)join_side(c, s); }
+    } lat_join{ctx, stream, lat};
     // z, ratio and reference counts back to sample-major [Ns, B] for the per-sample consumers
-    for (wc::DevBuf *b : {&ts.zs, &ts.rs2, &ts.ns2})
-        if ((rc = b->reserve(sizeof(double) * Ns * B))) return rc;
-    {
+    // (latency mode: the few samples are read straight from the bin-major arrays)
+    const double *zsrc = ts.zt.as<double>(), *rsrc = ts.rt.as<double>(), *nsrc = ts.nt.as<double>();
+    int64_t str_i = 1, str_b = Ns;
+    if (!lat) {
+        for (wc::DevBuf *b : {&ts.zs, &ts.rs2, &ts.ns2})
+            if ((rc = b->reserve(sizeof(double) * Ns * B))) return rc;
         dim3 g3((unsigned)cdiv(Ns, 32), (unsigned)cdiv(B, 32), 3);
         hipLaunchKernelGGL(k_transpose3, g3, dim3(32, 8), 0, stream, (const double *)ts.zt.as<double>(),
                            (const double *)ts.rt.as<double>(), (const double *)ts.nt.as<double>(), B, Ns,
                            ts.zs.as<double>(), ts.rs2.as<double>(), ts.ns2.as<double>());
+        zsrc = ts.zs.as<double>(); rsrc = ts.rs2.as<double>(); nsrc = ts.ns2.as<double>();
+        str_i = B; str_b = 1;
     }
     if (results_z || results_r) {
         dim3 g((unsigned)cdiv(ref->Btot, 256), (unsigned)Ns);
-        hipLaunchKernelGGL(k_inflate, g, dim3(256), 0, stream, (const double *)ts.zs.as<double>(),
-                           (const double *)ts.rs2.as<double>(), (const double *)ts.ns2.as<double>(), B, ref->Btot,
-                           (const int *)ref->g2m.as<int>(), (double)min_ref_bins, results_z, results_r);
+        hipLaunchKernelGGL(k_inflate, g, dim3(256), 0, stream, zsrc, rsrc, nsrc, B, ref->Btot,
+                           (const int *)ref->g2m.as<int>(), (double)min_ref_bins, results_z, results_r, str_i, str_b);
     }
     if (n_sel == 0) {      // nothing to segment: no calls (otherwise k_assemble_calls writes every n_calls)
         if (n_calls) WC_HIP(hipMemsetAsync(n_calls, 0, sizeof(int) * Ns, stream));
@@ -2528,24 +3558,29 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
     if ((rc = ts.regions.reserve(sizeof(Region) * n_regions))) return rc;
     if ((rc = ts.effect.reserve(sizeof(double) * n_regions * max_calls * 5))) return rc;
     if ((rc = ts.misc.reserve(sizeof(int) * 4))) return rc;
-    hipLaunchKernelGGL(k_clean, dim3((unsigned)n_sel, (unsigned)Ns), dim3(64), 0, stream,
-                       (const double *)ts.zs.as<double>(), (const double *)ts.rs2.as<double>(),
-                       (const double *)ts.ns2.as<double>(), B, Ns, (const int64_t *)ref->moff_dev.as<int64_t>(),
-                       (const int64_t *)ref->goff_dev.as<int64_t>(), (const int *)ref->m2g.as<int>(),
-                       (const int *)ts.sel.as<int>(), n_sel, (double)min_ref_bins, ts.zc.as<double>(),
-                       ts.rc.as<double>(), ts.gpos.as<int>(), ts.regions.as<Region>());
-    int64_t bits_upper = 0;
-    if (min_effect != 0.0)
-        for (int s = 0; s < n_sel; ++s) {
-            int64_t n = ref->moff[sel[s] + 1] - ref->moff[sel[s]];
-            bits_upper += Ns * (n * (n + 1) / 2);
-        }
-    ts.mark(3, stream);
-    if ((rc = run_stouffer(ctx, ts.zc.as<double>(), ts.regions.as<Region>(), n_regions, Ns * B, max_n, threshold, 3,
-                           max_calls, stream, ts.rc.as<double>(), min_effect, bits_upper, lat_rounds)))
-        return rc;
+    if (lat) {
+        if ((rc = run_seg_lat(ctx, ref, zsrc, rsrc, nsrc, str_i, str_b, Ns, n_sel, max_n, threshold, min_ref_bins,
+                              max_calls, stream, results_cwz)))
+            return rc;
+    } else {
+        hipLaunchKernelGGL(k_clean, dim3((unsigned)n_sel, (unsigned)Ns), dim3(64), 0, stream, zsrc, rsrc, nsrc, B, Ns,
+                           (const int64_t *)ref->moff_dev.as<int64_t>(), (const int64_t *)ref->goff_dev.as<int64_t>(),
+                           (const int *)ref->m2g.as<int>(), (const int *)ts.sel.as<int>(), n_sel, (double)min_ref_bins,
+                           ts.zc.as<double>(), ts.rc.as<double>(), ts.gpos.as<int>(), ts.regions.as<Region>(), str_i,
+                           str_b);
+        int64_t bits_upper = 0;
+        if (min_effect != 0.0)
+            for (int s2 = 0; s2 < n_sel; ++s2) {
+                int64_t n = ref->moff[sel[s2] + 1] - ref->moff[sel[s2]];
+                bits_upper += Ns * (n * (n + 1) / 2);
+            }
+        ts.mark(3, stream);
+        if ((rc = run_stouffer(ctx, ts.zc.as<double>(), ts.regions.as<Region>(), n_regions, Ns * B, max_n, threshold, 3,
+                               max_calls, stream, ts.rc.as<double>(), min_effect, bits_upper, 0, nullptr)))
+            return rc;
+    }
     ts.mark(4, stream);
-    if (results_cwz)
+    if (results_cwz && !lat)
         WC_HIP(hipMemcpyAsync(results_cwz, ts.whole.p, sizeof(double) * n_regions, hipMemcpyDeviceToDevice, stream));
     if ((rc = ctx->ensure_pinned(256))) return rc;
     if (calls && n_calls) {
@@ -2555,24 +3590,19 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
                                (const Seg *)ts.seg.as<Seg>(), (int)ts.last_segs,
                                (const Region *)ts.regions.as<Region>(), (const double *)ts.rc.as<double>(),
                                (const int *)ts.gpos.as<int>(), max_calls, ts.effect.as<double>(), (const int *)nullptr);
-        else if (ts.last_segs < 0)     // latency mode: the grid is a bound, the count sits on the device
-            hipLaunchKernelGGL(k_call_post, dim3((unsigned)(-ts.last_segs)), dim3(256), 0, stream,
-                               (const Seg *)ts.seg.as<Seg>(), (int)(-ts.last_segs),
-                               (const Region *)ts.regions.as<Region>(), (const double *)ts.rc.as<double>(),
-                               (const int *)ts.gpos.as<int>(), max_calls, ts.effect.as<double>(),
-                               (const int *)(ts.job_cnt.as<int>() + 4));
-        hipLaunchKernelGGL(k_assemble_calls, dim3((unsigned)cdiv(Ns, 64)), dim3(64), 0, stream,
+        if (lat && (rc = join_side(ctx, stream))) return rc;      // the status words read k_sd_fast's flags
+        hipLaunchKernelGGL(k_assemble_calls, dim3((unsigned)cdiv(Ns, 64)), dim3(64), 0, stream,   // latency mode: Ns <= 8, one workgroup
                            (const double *)ts.effect.as<double>(), (const int *)ts.out_n.as<int>(), n_sel, max_calls, Ns,
-                           calls, n_calls, ts.misc.as<int>());
+                           calls, n_calls, ts.misc.as<int>(), lat ? (int *)ctx->pinned : (int *)nullptr,
+                           (const int *)ts.job_cnt.as<int>(), (const int *)(ts.misc2.as<int>() + repeats + 1),
+                           (const int *)ts.sd_fail.as<int>());
         int *overflow = (int *)ctx->pinned + 16;
-        WC_HIP(hipMemcpyAsync(overflow, ts.misc.p, sizeof(int), hipMemcpyDeviceToHost, stream));
-        if (lat_rounds == 0) {
+        if (!lat) {
+            WC_HIP(hipMemcpyAsync(overflow, ts.misc.p, sizeof(int), hipMemcpyDeviceToHost, stream));
             WC_HIP(hipStreamSynchronize(stream));
             WC_CHECK(!*overflow, WC_E_LIMIT, "test: a sample has more than max_calls=%d calls", max_calls);
         }
     }
-    if (lat_rounds > 0)
-        WC_HIP(hipMemcpyAsync((int *)ctx->pinned + 24, ts.job_cnt.p, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
     ts.mark(5, stream);
     WC_HIP(hipGetLastError());
     return WC_OK;
@@ -2614,14 +3644,15 @@ int wc_test_batch_dev(wc_ctx *ctx, void *stream_, const wc_reference *ref, const
     // recursions, or more jobs than a round's grid holds, are detected afterwards and the call is
     // repeated on the general path).  The first call of a shape runs eagerly (it sizes every
     // workspace), the second one is captured, later ones replay.
-    constexpr int LAT_MAX_SAMPLES = 8, LAT_ROUNDS = 4;
+    constexpr int LAT_MAX_SAMPLES = 8, LAT_ROUNDS = 1;
     const char *lat_env = getenv("WC_TEST_LATENCY_MODE");          // "0": general path for every call
     const bool lat = Ns <= LAT_MAX_SAMPLES && min_effect == 0.0 && n_sel > 0 && calls && n_calls && !ts.profile &&
+                     ref->k <= 128 && repeats >= 1 && max_n <= 2048 && ref->B * Ns < (1ll << 31) &&
                      !(lat_env && lat_env[0] == '0');
     if (!lat)
         return test_batch_body(ctx, stream, ref, counts, Ns, threshold, min_ref_bins, repeats, min_effect, sel, max_n,
                                max_calls, results_z, results_r, results_cwz, calls, n_calls, asdef, 0);
-    std::vector<int64_t> key = {(int64_t)(intptr_t)ref, (int64_t)(intptr_t)counts, Ns, min_ref_bins, repeats, max_calls,
+    std::vector<int64_t> key = {(int64_t)ref->serial, (int64_t)(intptr_t)counts, Ns, min_ref_bins, repeats, max_calls,
                                 (int64_t)(intptr_t)results_z, (int64_t)(intptr_t)results_r,
                                 (int64_t)(intptr_t)results_cwz, (int64_t)(intptr_t)calls, (int64_t)(intptr_t)n_calls,
                                 (int64_t)(intptr_t)asdef};
@@ -2635,6 +3666,7 @@ int wc_test_batch_dev(wc_ctx *ctx, void *stream_, const wc_reference *ref, const
         return test_batch_body(ctx, stream, ref, counts, Ns, threshold, min_ref_bins, repeats, min_effect, sel, max_n,
                                max_calls, results_z, results_r, results_cwz, calls, n_calls, asdef, 0);
     };
+    if (ts.lat_exec && ts.lat_epoch != wc::realloc_epoch()) ts.lat_key.clear();   // a workspace moved since the capture
     if (key != ts.lat_key) {
         // new shape: drop the old graph, run eagerly once (reserves every buffer), capture next time
         if (ts.lat_exec) { (void)hipGraphExecDestroy(ts.lat_exec); ts.lat_exec = nullptr; }
@@ -2648,9 +3680,15 @@ int wc_test_batch_dev(wc_ctx *ctx, void *stream_, const wc_reference *ref, const
         WC_HIP(hipEventCreateWithFlags(&ctx->ev_lat_in, hipEventDisableTiming));
     }
     hipStream_t ls = ctx->lat_stream;
-    WC_HIP(hipEventRecord(ctx->ev_lat_in, stream));
-    WC_HIP(hipStreamWaitEvent(ls, ctx->ev_lat_in, 0));
-    if (!ts.lat_exec && ts.lat_warm) {
+    if (stream != nullptr) {
+        ls = stream;                      // a real stream: launch (and capture) on it directly
+    } else {
+        WC_HIP(hipEventRecord(ctx->ev_lat_in, stream));
+        WC_HIP(hipStreamWaitEvent(ls, ctx->ev_lat_in, 0));
+    }
+    const bool eager = lat_env && lat_env[0] == '2';              // "2": the latency kernels, launched one by one
+    if (!ts.lat_exec && ts.lat_warm && ts.lat_epoch != wc::realloc_epoch()) ts.lat_warm = false;   // workspaces moved: size them again
+    if (!ts.lat_exec && ts.lat_warm && !eager) {
         hipGraph_t graph = nullptr;
         if (hipStreamBeginCapture(ls, hipStreamCaptureModeThreadLocal) != hipSuccess) {
             (void)hipGetLastError();
@@ -2664,10 +3702,11 @@ int wc_test_batch_dev(wc_ctx *ctx, void *stream_, const wc_reference *ref, const
             if (graph) (void)hipGraphDestroy(graph);
             (void)hipGetLastError();
             ts.lat_key.clear();
-            return rc != WC_OK ? rc : fall_back();
+            return fall_back();
         }
         const hipError_t ei = hipGraphInstantiate(&ts.lat_exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
+        ts.lat_epoch = wc::realloc_epoch();
         if (ei != hipSuccess) {
             ts.lat_exec = nullptr;
             ts.lat_key.clear();
@@ -2682,11 +3721,23 @@ int wc_test_batch_dev(wc_ctx *ctx, void *stream_, const wc_reference *ref, const
                                   max_calls, results_z, results_r, results_cwz, calls, n_calls, asdef, LAT_ROUNDS)))
             return rc;
         ts.lat_warm = true;
+        ts.lat_epoch = wc::realloc_epoch();
     }
     WC_HIP(hipStreamSynchronize(ls));
     const int *overflow = (const int *)ctx->pinned + 16, *cnt = (const int *)ctx->pinned + 24;
-    if (cnt[6] || cnt[ts.lat_left] > 0 || cnt[4] > 4096) return fall_back();      // deeper recursion / more jobs than the bounds: general path
+    // anything the latency kernels are not built for -> the general path computes the call again
+    // (non-finite region, tie overflow, deep stack: cnt[6]; many segments; many queued pairs)
+    if (cnt[6] || ((const int *)ctx->pinned)[32] || ((const int *)ctx->pinned)[33]) return fall_back();
     WC_CHECK(!*overflow, WC_E_LIMIT, "test: a sample has more than max_calls=%d calls", max_calls);
+    return WC_OK;
+}
+
+int wc_debug_times(wc_ctx *ctx, int block_plus_one, unsigned long long *out64) {
+    WC_CHECK(ctx, WC_E_ARG, "debug: NULL context");
+    WC_HIP(hipSetDevice(ctx->device));
+    WC_HIP(hipDeviceSynchronize());
+    if (out64) WC_HIP(hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * 64));
+    WC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_on), &block_plus_one, sizeof(int)));
     return WC_OK;
 }
 

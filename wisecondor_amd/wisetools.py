@@ -234,6 +234,18 @@ def repeatTest(testData, indexes, distances, chromosomeBins, chromosomeBinSums, 
     return z, r, n, sd
 
 
+def stdDevAvg(stdDevs, device=0, return_serial_count=False):
+    """Mean of the non-NaN standard deviations, added bin by bin like trySample's Python loop
+    (wisetools.py:428-435).  stdDevs: [bins] or [samples, bins]."""
+    sd = np.ascontiguousarray(np.atleast_2d(stdDevs), dtype=np.float64)
+    out = np.empty(sd.shape[0])
+    serial = ctypes.c_int32(0)
+    _lib.check(_lib.load().wc_std_dev_avg(_lib.context(device), _lib.ptr(sd), sd.shape[0], sd.shape[1],
+                                          _lib.ptr(out), ctypes.byref(serial)))
+    res = out[0] if np.ndim(stdDevs) == 1 else out
+    return (res, serial.value) if return_serial_count else res
+
+
 def stouffer_segments(regions, threshold, min_search=3, device=0, ratios=None, mineffectsize=0):
     """fillTri / fillTriMin + segmentTri for a list of 1-D z arrays
     (wisetools.py:466-487, triarray.py:59-84).
