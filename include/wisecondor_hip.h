@@ -145,6 +145,14 @@ int wc_newref_prep_gram(wc_ctx *ctx, const int32_t *counts, int64_t n_samples, i
 int wc_newref_prep_finish(wc_ctx *ctx, int n_comp, const double *eigvecs, const double *eigvals,
                           double *masked_data_out, double *corrected_t_out, double *pca_components_out,
                           double *pca_mean_out);
+/* Device-resident finish: the bins-sized results stay in HBM for wc_newref_*_dev (no 2 x B x S x 8 B
+ * trip through the host).  corrected_bs_dev [n_masked, n_samples] row-major device memory holding the
+ * values of the reference's Fortran-ordered correctedData (wisetools.py:101: pass WC_SUM_SEQUENTIAL
+ * to newref); masked_dev [n_masked, n_samples] device memory; pca_components_out / pca_mean_out host
+ * memory.  Every output may be NULL. */
+int wc_newref_prep_finish_dev(wc_ctx *ctx, int n_comp, const double *eigvecs, const double *eigvals,
+                              double *masked_dev, double *corrected_bs_dev, double *pca_components_out,
+                              double *pca_mean_out);
 int wc_newref_prep(wc_ctx *ctx, const int32_t *counts, int64_t n_samples, int64_t n_total_bins,
                    const int64_t *chromosome_bins, int n_chrom, int n_comp, uint8_t *mask_out,
                    int64_t *masked_chrom_bins_out, int64_t *n_masked_out, double *masked_data_out,

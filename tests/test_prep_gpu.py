@@ -50,3 +50,43 @@ def test_prep_one_call_c_api(golden):
     assert np.array_equal(masked, want[0]) and np.array_equal(mean, want[5])
     assert np.allclose(comps, want[4], rtol=0, atol=1e-9)
     assert np.allclose(ct.T, want[3], rtol=1e-10, atol=0)
+
+
+def test_prep_device_resident_equals_host_form(golden):
+    """device_out=True hands newref the same values without the trip through the host."""
+    import torch
+    from wisecondor_amd import wisetools as wt
+    g = golden("cfg1_pipeline.npz")
+    offs = np.concatenate([[0], np.cumsum(g["sample_chrom_lengths"])])
+    samples = [{k: row[offs[i]:offs[i + 1]] for i, k in enumerate(KEYS)} for row in g["ref_samples"]]
+    host = wt.prepReference(samples)
+    dev = wt.prepReference(samples, device_out=True)
+    assert isinstance(dev[3], torch.Tensor) and dev[3].is_cuda and dev[3].is_contiguous()
+    assert np.array_equal(dev[0].cpu().numpy(), host[0])
+    assert np.array_equal(dev[3].cpu().numpy(), np.ascontiguousarray(host[3]))   # same bits, row-major
+    assert np.array_equal(dev[4], host[4]) and np.array_equal(dev[5], host[5])
+    assert list(dev[6]) == list(host[6]) and np.array_equal(dev[2], host[2])
+
+
+@pytest.mark.parametrize("n_s,n_total", [(7, 300), (64, 4097), (100, 2500), (130, 999)])
+def test_prep_gram_on_the_matrix_cores(n_s, n_total):
+    """The split-K float64 MFMA SYRK against numpy on ragged shapes (tile and panel tails, odd bin counts)."""
+    import ctypes
+    from wisecondor_amd import _lib
+    rng = np.random.RandomState(n_s)
+    counts = rng.poisson(rng.gamma(5.0, 8.0, n_total)[None, :] * rng.uniform(0.5, 2.0, n_s)[:, None]).astype(np.int32)
+    counts[:, rng.choice(n_total, n_total // 10, replace=False)] = 0          # masked-out bins
+    sizes = np.ascontiguousarray([n_total - 21 * 3] + [3] * 21, dtype=np.int64)
+    lib, ctx = _lib.load(), _lib.context(0)
+    mask, mbins = np.empty(n_total, dtype=np.uint8), np.empty(22, dtype=np.int64)
+    nb, gram = ctypes.c_int64(), np.empty((n_s, n_s))
+    _lib.check(lib.wc_newref_prep_gram(ctx, _lib.ptr(counts), n_s, n_total, _lib.ptr(sizes), 22, _lib.ptr(mask),
+                                       _lib.ptr(mbins), ctypes.byref(nb), _lib.ptr(gram)))
+    norm = counts / counts.sum(axis=1, keepdims=True).astype(np.float64)
+    keep = norm.sum(axis=0) > 0
+    assert np.array_equal(mask.astype(bool), keep) and nb.value == int(keep.sum())
+    x = norm[:, keep]
+    xc = x - x.mean(axis=0)
+    want = xc @ xc.T
+    assert np.array_equal(gram, gram.T)
+    assert np.allclose(gram, want, rtol=1e-11, atol=1e-12 * np.abs(want).max())

@@ -1,9 +1,10 @@
-"""Time of the GPU newref prep (wc_newref_prep_gram + host eigh + wc_newref_prep_finish) on random counts.
+"""Time of the GPU newref prep (wc_newref_prep_gram + host eigh of the leading pairs + wc_newref_prep_finish[_dev]) on random counts.
     python3 tools/gpu_prep_time.py [cfg2|cfg4]"""
 import ctypes, sys, time
 import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "/root/repo")
-from wisecondor_amd import _lib, synth
+import torch
+from wisecondor_amd import _lib, synth, wisetools as wt
 which = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 binsize, n_s = {"cfg2": (250000, 100), "cfg4": (50000, 600)}[which]
 sizes = np.ascontiguousarray(synth.chrom_bins(binsize), dtype=np.int64)
@@ -19,14 +20,20 @@ for it in range(3):
     _lib.check(lib.wc_newref_prep_gram(ctx, _lib.ptr(counts), n_s, n_total, _lib.ptr(sizes), len(sizes),
                                        _lib.ptr(mask), _lib.ptr(mbins), ctypes.byref(n_b), _lib.ptr(gram)))
     t1 = time.perf_counter()
-    vals, vecs = np.linalg.eigh(gram)
-    order = np.argsort(vals)[::-1][:3]
-    evals = np.ascontiguousarray(vals[order]); evecs = np.ascontiguousarray(vecs[:, order].T)
+    evals, evecs = wt._leading_eigenpairs(gram, 3)
     t2 = time.perf_counter()
     B = n_b.value
-    masked = np.empty((B, n_s)); corrected_t = np.empty((n_s, B)); comps = np.empty((3, B)); mean = np.empty(B)
+    masked = wt._pinned((B, n_s)); corrected_t = wt._pinned((n_s, B)); comps = np.empty((3, B)); mean = np.empty(B)
     _lib.check(lib.wc_newref_prep_finish(ctx, 3, _lib.ptr(evecs), _lib.ptr(evals), _lib.ptr(masked),
                                          _lib.ptr(corrected_t), _lib.ptr(comps), _lib.ptr(mean)))
     t3 = time.perf_counter()
-    print("%s it %d: gram (incl. H2D/D2H) %.1f ms, eigh %.1f ms, finish (incl. D2H of %d MB) %.1f ms"
-          % (which, it, 1e3 * (t1 - t0), 1e3 * (t2 - t1), (masked.nbytes + corrected_t.nbytes) >> 20, 1e3 * (t3 - t2)), flush=True)
+    dm = torch.empty((B, n_s), dtype=torch.float64, device="cuda"); dc = torch.empty_like(dm)
+    torch.cuda.synchronize()
+    t4 = time.perf_counter()
+    _lib.check(lib.wc_newref_prep_finish_dev(ctx, 3, _lib.ptr(evecs), _lib.ptr(evals), ctypes.c_void_p(dm.data_ptr()),
+                                             ctypes.c_void_p(dc.data_ptr()), _lib.ptr(comps), _lib.ptr(mean)))
+    t5 = time.perf_counter()
+    print("%s it %d: gram (incl. H2D of the counts, mask round trip) %.1f ms, eigh (leading 3) %.1f ms, finish to pinned host "
+          "(D2H of %d MB) %.1f ms, finish device-resident %.1f ms"
+          % (which, it, 1e3 * (t1 - t0), 1e3 * (t2 - t1), (masked.nbytes + corrected_t.nbytes) >> 20, 1e3 * (t3 - t2),
+             1e3 * (t5 - t4)), flush=True)

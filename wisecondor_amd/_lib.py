@@ -40,6 +40,7 @@ SIGNATURES = {
     "wc_newref_fallback_dev": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "wc_newref_prep_gram": (_i32, [_vp, _vp, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
     "wc_newref_prep_finish": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "wc_newref_prep_finish_dev": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "wc_newref_prep": (_i32, [_vp, _vp, _i64, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "wc_reference_create": (_vp, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp]),
     "wc_apply_pca": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _i32, _vp]),

@@ -10,6 +10,7 @@
 namespace {
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline int64_t round_up(int64_t a, int64_t b) { return cdiv(a, b) * b; }
 
 // per-sample totals over all bins: integer sums are exact in any order (wisetools.py:255)
 __global__ __launch_bounds__(256) void k_prep_totals(const int *__restrict__ counts, int64_t Btot,
@@ -63,30 +64,95 @@ __global__ void k_prep_centre(const double *__restrict__ masked, const double *_
     for (int64_t s = 0; s < S; ++s) xc[s * B + b] = tdata[s * B + b] - m;
 }
 
-// Gram matrix G[s, t] = sum_b xc[s, b] * xc[t, b]: 16x16 output tile per block, bins in
-// chunks of 64 through LDS, fixed summation order (deterministic)
-__global__ __launch_bounds__(256) void k_prep_gram(const double *__restrict__ xc, int64_t S, int64_t B,
-                                                   double *__restrict__ G) {
-    __shared__ double As[16][65], Bs[16][65];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int64_t s0 = (int64_t)blockIdx.y * 16, t0 = (int64_t)blockIdx.x * 16;
-    if (t0 > s0) return;   // symmetric: lower triangle of tiles only
-    double acc = 0.0;
-    for (int64_t b0 = 0; b0 < B; b0 += 64) {
-        for (int e = threadIdx.x; e < 16 * 64; e += 256) {
-            int r = e >> 6, c = e & 63;
-            int64_t b = b0 + c;
-            As[r][c] = (s0 + r < S && b < B) ? xc[(s0 + r) * B + b] : 0.0;
-            Bs[r][c] = (t0 + r < S && b < B) ? xc[(t0 + r) * B + b] : 0.0;
+// Gram matrix G[s, t] = sum_b xc[s, b] * xc[t, b] on the float64 matrix cores
+// (v_mfma_f64_16x16x4_f64), as a split-K SYRK: one workgroup = one 64 x 64 tile of the lower
+// triangle x one slice of the bins; four waves, each a 32 x 32 quadrant as 2 x 2 MFMA blocks.
+// 32-bin panels of both operands go through LDS (row stride 34 doubles: the sixteen rows of a
+// fragment read land on distinct banks).  Slice results are written as partial tiles and summed
+// in slice order by k_prep_gram_reduce: deterministic, no atomics.
+// Operand maps (cdna_hip_programming.md, f64 form): A[i = lane & 15][k = lane >> 4],
+// B[k = lane >> 4][j = lane & 15], C/D col = lane & 15, row = (lane >> 4) + 4 * reg.
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+using f64x2p = __attribute__((ext_vector_type(2))) double;
+constexpr int SY_T = 64, SY_KB = 32, SY_LD = SY_KB + 2;
+__global__ __launch_bounds__(256) void k_prep_syrk(const double *__restrict__ xc, int64_t S, int64_t B,
+                                                   const int2 *__restrict__ tiles, int64_t bins_per_slice,
+                                                   double *__restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) double As[SY_T * SY_LD], Bs[SY_T * SY_LD];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int2 tile = tiles[blockIdx.x];
+    const int64_t s0 = (int64_t)tile.x * SY_T, t0 = (int64_t)tile.y * SY_T;
+    const int64_t b_lo = (int64_t)blockIdx.y * bins_per_slice;
+    const int64_t b_hi = b_lo + bins_per_slice < B ? b_lo + bins_per_slice : B;
+    const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
+    const int fi = lane & 15, fk = lane >> 4;
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = f64x4{0.0, 0.0, 0.0, 0.0};
+    const int lr = tid >> 2, lc = (tid & 3) * 8;          // this thread's row and first column of a panel
+    const bool a_row = s0 + lr < S, b_row = t0 + lr < S;
+    const double *ga = xc + (a_row ? s0 + lr : 0) * B, *gb = xc + (b_row ? t0 + lr : 0) * B;
+    for (int64_t b0 = b_lo; b0 < b_hi; b0 += SY_KB) {
+        double va[8], vb[8];
+        if (b0 + lc + 8 <= b_hi && (((b0 + lc) & 1) == 0) && ((B & 1) == 0)) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const f64x2p pa = *(const f64x2p *)(ga + b0 + lc + e), pb = *(const f64x2p *)(gb + b0 + lc + e);
+                va[e] = pa.x; va[e + 1] = pa.y;
+                vb[e] = pb.x; vb[e + 1] = pb.y;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool in = b0 + lc + e < b_hi;
+                va[e] = in ? ga[b0 + lc + e] : 0.0;
+                vb[e] = in ? gb[b0 + lc + e] : 0.0;
+            }
+        }
+        __syncthreads();                                  // the previous panel's fragment reads are done
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            As[lr * SY_LD + lc + e] = a_row ? va[e] : 0.0;
+            Bs[lr * SY_LD + lc + e] = b_row ? vb[e] : 0.0;
         }
         __syncthreads();
-#pragma unroll 8
-        for (int c = 0; c < 64; ++c) acc += As[ty][c] * Bs[tx][c];
-        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < SY_KB; kk += 4) {
+            double fa[2], fb[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) fa[m] = As[(wr + 16 * m + fi) * SY_LD + kk + fk];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) fb[n] = Bs[(wc + 16 * n + fi) * SY_LD + kk + fk];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[m], fb[n], acc[m][n], 0, 0, 0);
+        }
     }
-    if (s0 + ty < S && t0 + tx < S) {
-        G[(s0 + ty) * S + t0 + tx] = acc;
-        G[(t0 + tx) * S + s0 + ty] = acc;
+    double *out = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (SY_T * SY_T);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                out[(wr + 16 * m + fk + 4 * r) * SY_T + wc + 16 * n + fi] = acc[m][n][r];
+}
+
+// G[s, t] = G[t, s] = sum over the slices, in slice order, of the partial tile entries
+__global__ __launch_bounds__(256) void k_prep_gram_reduce(const double *__restrict__ partial, const int2 *__restrict__ tiles,
+                                                          int n_tiles, int n_slices, int64_t S, double *__restrict__ G) {
+    const int2 tile = tiles[blockIdx.x];
+    for (int e = threadIdx.x; e < SY_T * SY_T; e += 256) {
+        const int64_t s = (int64_t)tile.x * SY_T + (e >> 6), t = (int64_t)tile.y * SY_T + (e & 63);
+        if (s >= S || t >= S || t > s) continue;
+        double sum = 0.0;
+        for (int q = 0; q < n_slices; ++q) sum = sum + partial[((int64_t)q * n_tiles + blockIdx.x) * (SY_T * SY_T) + e];
+        G[s * S + t] = sum;
+        G[t * S + s] = sum;
     }
 }
 
@@ -95,11 +161,18 @@ __global__ void k_prep_components(const double *__restrict__ xc, int64_t S, int6
                                   int n_comp, double *__restrict__ comp) {
     int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    for (int c = 0; c < n_comp; ++c) {
-        double acc = 0.0;
-        for (int64_t s = 0; s < S; ++s) acc += w[(int64_t)c * S + s] * xc[s * B + b];
-        comp[(int64_t)c * B + b] = acc;
+    double acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.0;
+    for (int64_t s = 0; s < S; ++s) {                    // one read of the column for all components
+        const double v = xc[s * B + b];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < n_comp) acc[c] += w[(int64_t)c * S + s] * v;
     }
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        if (c < n_comp) comp[(int64_t)c * B + b] = acc[c];
 }
 
 // transformed[s, c] = sum_b xc[s, b] * comp[c, b]  (pca.transform, wisetools.py:94)
@@ -140,6 +213,33 @@ __global__ void k_prep_correct(const double *__restrict__ tdata, int64_t B, cons
     for (int c = 0; c < n_comp; ++c) inv += tr[s * 8 + c] * comp[(int64_t)c * B + b];
     inv += mean[b];
     corrected_t[s * B + b] = tdata[s * B + b] / inv;
+}
+
+// The same values in the layout newref takes, corrected[b, s] (row-major [bins, samples]):
+// 32 x 32 tiles through LDS so that both the reads (along b) and the writes (along s) are coalesced
+__global__ __launch_bounds__(256) void k_prep_correct_bs(const double *__restrict__ tdata, int64_t S, int64_t B,
+                                                         const double *__restrict__ mean, const double *__restrict__ comp,
+                                                         int n_comp, const double *__restrict__ tr,
+                                                         double *__restrict__ corrected_bs) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t b0 = (int64_t)blockIdx.x * 32, s0 = (int64_t)blockIdx.y * 32;
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t s = s0 + j, b = b0 + tx;
+        double v = 0.0;
+        if (s < S && b < B) {
+            double inv = 0.0;
+            for (int c = 0; c < n_comp; ++c) inv += tr[s * 8 + c] * comp[(int64_t)c * B + b];
+            inv += mean[b];
+            v = tdata[s * B + b] / inv;
+        }
+        tile[j][tx] = v;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t b = b0 + j, s = s0 + tx;
+        if (b < B && s < S) corrected_bs[b * S + s] = tile[tx][j];
+    }
 }
 
 // Cyclic Jacobi eigen-decomposition of a small symmetric matrix (host, float64).
@@ -248,19 +348,37 @@ int wc_newref_prep_gram(wc_ctx *ctx, const int32_t *counts, int64_t n_samples, i
     hipLaunchKernelGGL(k_prep_centre, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, nullptr,
                        (const double *)ts.raw.as<double>(), (const double *)ts.data.as<double>(), S, B, mean,
                        ts.xt.as<double>());
-    dim3 gg((unsigned)cdiv(S, 16), (unsigned)cdiv(S, 16));
-    hipLaunchKernelGGL(k_prep_gram, gg, dim3(256), 0, nullptr, (const double *)ts.xt.as<double>(), S, B, G);
+    {
+        // lower triangle of 64 x 64 tiles x bin slices: about 2 000 workgroups, slices of whole panels
+        std::vector<int2> tiles;
+        const int nt = (int)cdiv(S, SY_T);
+        for (int a = 0; a < nt; ++a)
+            for (int b = 0; b <= a; ++b) tiles.push_back(make_int2(a, b));
+        const int n_tiles = (int)tiles.size();
+        int64_t n_slices = std::max<int64_t>(1, std::min<int64_t>(256, 2048 / n_tiles));
+        int64_t per = round_up(cdiv(B, n_slices), SY_KB);
+        per = std::max<int64_t>(per, 4 * SY_KB);
+        n_slices = cdiv(B, per);
+        if ((rc = ts.misc.reserve(sizeof(int2) * n_tiles + 16))) return rc;
+        if ((rc = ts.zt.reserve(sizeof(double) * n_slices * n_tiles * SY_T * SY_T))) return rc;
+        WC_HIP(hipMemcpy(ts.misc.p, tiles.data(), sizeof(int2) * n_tiles, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_prep_syrk, dim3((unsigned)n_tiles, (unsigned)n_slices), dim3(256), 0, nullptr,
+                           (const double *)ts.xt.as<double>(), S, B, (const int2 *)ts.misc.as<int2>(), per,
+                           ts.zt.as<double>());
+        hipLaunchKernelGGL(k_prep_gram_reduce, dim3((unsigned)n_tiles), dim3(256), 0, nullptr,
+                           (const double *)ts.zt.as<double>(), (const int2 *)ts.misc.as<int2>(), n_tiles,
+                           (int)n_slices, S, G);
+    }
     WC_HIP(hipDeviceSynchronize());
     WC_HIP(hipMemcpy(gram_out, G, sizeof(double) * S * S, hipMemcpyDeviceToHost));
     g_prep.S = S; g_prep.Btot = Btot; g_prep.B = B; g_prep.ready = true;
     return WC_OK;
 }
 
-int wc_newref_prep_finish(wc_ctx *ctx, int n_comp, const double *eigvecs, const double *eigvals,
-                          double *masked_data_out, double *corrected_t_out, double *pca_components_out,
-                          double *pca_mean_out) {
-    WC_CHECK(ctx && eigvecs && eigvals && masked_data_out && corrected_t_out && pca_components_out && pca_mean_out,
-             WC_E_ARG, "prep: NULL argument");
+// Device part of the finish step: components (sign fixed), projection, corrected_t [S, B] in ts.xc.
+// Leaves maskedData in ts.raw, components / mean in ts.z; returns the host copy of the components.
+static int prep_finish_body(wc_ctx *ctx, int n_comp, const double *eigvecs, const double *eigvals,
+                            std::vector<double> &hc, bool want_t) {
     PrepState &g_prep = ctx->prep;
     WC_CHECK(g_prep.ready, WC_E_ARG, "prep: wc_newref_prep_gram has not run");
     const int64_t S = g_prep.S, B = g_prep.B;
@@ -278,7 +396,7 @@ int wc_newref_prep_finish(wc_ctx *ctx, int n_comp, const double *eigvecs, const 
     hipLaunchKernelGGL(k_prep_components, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, nullptr,
                        (const double *)ts.xt.as<double>(), S, B, (const double *)w, n_comp, comp);
     // scikit-learn's svd_flip (v based): the largest |entry| of every component is positive
-    std::vector<double> hc((size_t)n_comp * B);
+    hc.resize((size_t)n_comp * B);
     WC_HIP(hipMemcpy(hc.data(), comp, sizeof(double) * n_comp * B, hipMemcpyDeviceToHost));
     for (int c = 0; c < n_comp; ++c) {
         double *row = hc.data() + (size_t)c * B;
@@ -291,15 +409,59 @@ int wc_newref_prep_finish(wc_ctx *ctx, int n_comp, const double *eigvecs, const 
     WC_HIP(hipMemcpy(comp, hc.data(), sizeof(double) * n_comp * B, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_prep_transform, dim3((unsigned)S), dim3(256), 0, nullptr, (const double *)ts.xt.as<double>(),
                        B, (const double *)comp, n_comp, ts.proj.as<double>());
-    dim3 gb((unsigned)cdiv(B, 256), (unsigned)S);
-    hipLaunchKernelGGL(k_prep_correct, gb, dim3(256), 0, nullptr, (const double *)ts.data.as<double>(), B,
-                       (const double *)mean, (const double *)comp, n_comp, (const double *)ts.proj.as<double>(),
-                       ts.xc.as<double>());
+    if (want_t) {
+        dim3 gb((unsigned)cdiv(B, 256), (unsigned)S);
+        hipLaunchKernelGGL(k_prep_correct, gb, dim3(256), 0, nullptr, (const double *)ts.data.as<double>(), B,
+                           (const double *)mean, (const double *)comp, n_comp, (const double *)ts.proj.as<double>(),
+                           ts.xc.as<double>());
+    }
+    WC_HIP(hipGetLastError());
+    return WC_OK;
+}
+
+int wc_newref_prep_finish(wc_ctx *ctx, int n_comp, const double *eigvecs, const double *eigvals,
+                          double *masked_data_out, double *corrected_t_out, double *pca_components_out,
+                          double *pca_mean_out) {
+    WC_CHECK(ctx && eigvecs && eigvals && masked_data_out && corrected_t_out && pca_components_out && pca_mean_out,
+             WC_E_ARG, "prep: NULL argument");
+    std::vector<double> hc;
+    int rc = prep_finish_body(ctx, n_comp, eigvecs, eigvals, hc, true);
+    if (rc) return rc;
+    TestState &ts = ctx->ts;
+    const int64_t S = ctx->prep.S, B = ctx->prep.B;
+    const double *mean = ts.z.as<double>() + S * S + 8 * S + 8 * B;
     WC_HIP(hipDeviceSynchronize());
     WC_HIP(hipMemcpy(masked_data_out, ts.raw.p, sizeof(double) * B * S, hipMemcpyDeviceToHost));
     WC_HIP(hipMemcpy(corrected_t_out, ts.xc.p, sizeof(double) * B * S, hipMemcpyDeviceToHost));
     memcpy(pca_components_out, hc.data(), sizeof(double) * n_comp * B);
     WC_HIP(hipMemcpy(pca_mean_out, mean, sizeof(double) * B, hipMemcpyDeviceToHost));
+    return WC_OK;
+}
+
+// Device-resident variant: the bins-sized results stay in HBM.  corrected_bs_dev [B, S] row-major is
+// the layout wc_newref_*_dev take (the values of the reference's Fortran-ordered correctedData:
+// pass WC_SUM_SEQUENTIAL); masked_dev [B, S]; components [n_comp, B] and mean [B] on the host
+// (small).  Every output may be NULL.
+int wc_newref_prep_finish_dev(wc_ctx *ctx, int n_comp, const double *eigvecs, const double *eigvals,
+                              double *masked_dev, double *corrected_bs_dev, double *pca_components_out,
+                              double *pca_mean_out) {
+    WC_CHECK(ctx && eigvecs && eigvals, WC_E_ARG, "prep: NULL argument");
+    std::vector<double> hc;
+    int rc = prep_finish_body(ctx, n_comp, eigvecs, eigvals, hc, false);
+    if (rc) return rc;
+    TestState &ts = ctx->ts;
+    const int64_t S = ctx->prep.S, B = ctx->prep.B;
+    const double *comp = ts.z.as<double>() + S * S + 8 * S, *mean = comp + 8 * B;
+    if (corrected_bs_dev) {
+        dim3 g((unsigned)cdiv(B, 32), (unsigned)cdiv(S, 32));
+        hipLaunchKernelGGL(k_prep_correct_bs, g, dim3(256), 0, nullptr, (const double *)ts.data.as<double>(), S, B,
+                           mean, comp, n_comp, (const double *)ts.proj.as<double>(), corrected_bs_dev);
+    }
+    if (masked_dev)
+        WC_HIP(hipMemcpyAsync(masked_dev, ts.raw.p, sizeof(double) * B * S, hipMemcpyDeviceToDevice, nullptr));
+    if (pca_components_out) memcpy(pca_components_out, hc.data(), sizeof(double) * n_comp * B);
+    if (pca_mean_out) WC_HIP(hipMemcpy(pca_mean_out, mean, sizeof(double) * B, hipMemcpyDeviceToHost));
+    WC_HIP(hipDeviceSynchronize());
     return WC_OK;
 }
 

@@ -364,14 +364,41 @@ def test_batch(reference, samples, threshold, minrefbins=25, repeats=5, chromoso
 # ---------------------------------------------------------------------------
 # newref prep (upstream of the hot path)
 # ---------------------------------------------------------------------------
-def prepReference(samples, pcacomp=3, device=0):
+def _leading_eigenpairs(gram, n):
+    """The n largest eigenvalues (descending) and unit eigenvectors (rows) of the symmetric `gram`."""
+    n_s = gram.shape[0]
+    try:
+        from scipy.linalg import eigh as _eigh          # LAPACK dsyevr on the wanted pairs only
+        vals, vecs = _eigh(gram, subset_by_index=(max(0, n_s - n), n_s - 1), driver='evr')
+    except Exception:                                    # no scipy: numpy's full decomposition
+        vals, vecs = np.linalg.eigh(gram)
+    order = np.argsort(vals)[::-1][:n]
+    return np.ascontiguousarray(vals[order]), np.ascontiguousarray(vecs[:, order].T)
+
+
+def _pinned(shape):
+    """float64 host array in page-locked memory (a device-to-host copy into it runs at the link's
+    rate, several times the pageable rate); plain numpy when torch cannot pin."""
+    try:
+        import torch
+        return torch.empty(shape, dtype=torch.float64, pin_memory=True).numpy()   # the array keeps the tensor alive
+    except Exception:
+        return np.empty(shape)
+
+
+def prepReference(samples, pcacomp=3, device=0, device_out=False):
     """toNumpyArray + trainPCA (wisetools.py:240-264, 89-101) with the bins-sized work on the GPU.
 
-    The Gram matrix of the centred [samples, bins] data comes from the GPU, numpy's
-    LAPACK solves its small [samples, samples] eigenproblem, and the GPU finishes
-    (components, projection, reconstruction, division).  Returns
+    The Gram matrix of the centred [samples, bins] data comes from the GPU (float64 matrix
+    cores), LAPACK solves its small [samples, samples] eigenproblem for the leading pairs, and
+    the GPU finishes (components, projection, reconstruction, division).  Returns
     (maskedData [B,S], chromosomeBins, mask, correctedData [B,S] Fortran-ordered like the
     reference's, pca_components [n,B], pca_mean [B], maskedChromBins).
+
+    device_out=True keeps the two bins x samples matrices in HBM: maskedData and correctedData
+    come back as torch tensors on the device, correctedData as the C-ordered [B,S] tensor that
+    getReference / NewrefJob take directly -- its values are those of the reference's
+    Fortran-ordered array, so pass sum_order=_lib.SUM_SEQUENTIAL.
     """
     lib = _lib.load()
     ctx = _lib.context(device)
@@ -385,15 +412,21 @@ def prepReference(samples, pcacomp=3, device=0):
     gram = np.empty((n_s, n_s))
     _lib.check(lib.wc_newref_prep_gram(ctx, _lib.ptr(counts), n_s, n_total, _lib.ptr(sizes), len(sizes),
                                        _lib.ptr(mask), _lib.ptr(mbins), ctypes.byref(n_b), _lib.ptr(gram)))
-    vals, vecs = np.linalg.eigh(gram)
-    order = np.argsort(vals)[::-1][:pcacomp]
-    evals = np.ascontiguousarray(vals[order])
-    evecs = np.ascontiguousarray(vecs[:, order].T)
+    evals, evecs = _leading_eigenpairs(gram, pcacomp)
     B = n_b.value
-    masked = np.empty((B, n_s))
-    corrected_t = np.empty((n_s, B))
     comps = np.empty((pcacomp, B))
     mean = np.empty(B)
+    if device_out:
+        import torch
+        dev = torch.device('cuda', device)
+        masked = torch.empty((B, n_s), dtype=torch.float64, device=dev)
+        corrected = torch.empty((B, n_s), dtype=torch.float64, device=dev)
+        _lib.check(lib.wc_newref_prep_finish_dev(ctx, int(pcacomp), _lib.ptr(evecs), _lib.ptr(evals),
+                                                 ctypes.c_void_p(masked.data_ptr()),
+                                                 ctypes.c_void_p(corrected.data_ptr()), _lib.ptr(comps), _lib.ptr(mean)))
+        return masked, chromBins, mask.astype(bool), corrected, comps, mean, [int(v) for v in mbins]
+    masked = _pinned((B, n_s))
+    corrected_t = _pinned((n_s, B))
     _lib.check(lib.wc_newref_prep_finish(ctx, int(pcacomp), _lib.ptr(evecs), _lib.ptr(evals), _lib.ptr(masked),
                                          _lib.ptr(corrected_t), _lib.ptr(comps), _lib.ptr(mean)))
     return masked, chromBins, mask.astype(bool), corrected_t.T, comps, mean, [int(v) for v in mbins]
