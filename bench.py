@@ -142,6 +142,25 @@ def hbm_bytes(entry):
     return 1024.0 * (2.0 * entry["fetch_kb_per_launch"] + entry.get("write_kb_per_launch", 0.0))
 
 
+def committed_busy(workload):
+    """VALU / LDS busy fractions of the re-score kernels from the committed counter passes, or None."""
+    path = os.path.join(ROOT, "profiles", "%s_pmc_busy.json" % ROUND)
+    if not os.path.exists(path):
+        return None
+    runs = json.load(open(path))
+    for run, kernels in sorted(runs.items()):
+        if run.endswith(workload):
+            out = {}
+            for name, row in kernels.items():
+                if name.startswith("k_rescore") or name.startswith("k_pick"):
+                    out[name] = {n: round(row[n], 3) for n in ("valu_busy", "lds_busy", "waves_per_simd", "eff_clock_ghz")
+                                 if n in row}
+            if out:
+                out["source"] = "profiles/%s_pmc_busy.json (%s)" % (ROUND, run)
+                return out
+    return None
+
+
 # ------------------------------------------------------------- cpu baseline ----
 def cpu_model():
     try:
@@ -473,6 +492,18 @@ def main():
                      "steps": xsteps, "shard_mode": xjob.mode or "single", "shard_calibration_s": xjob.calibration,
                      "stages_ms": xstages, "k_gram_ms": xk_ms,
                      "k_gram_algorithmic_tflops": xflops / (xk_ms * 1e-3) / 1e12}
+            # the re-score stage on this matrix: uncorrelated rows share no candidates, the 295 MB float64
+            # image does not fit the 32 MB of L2, and the gathers come from HBM / Infinity Cache
+            xr_ms = xstages.get("collected->rescored")
+            if xr_ms:
+                xr_bytes = float(XB) / world * k * xs * 8.0 + float(XB) / world * k * 12.0
+                extra["rescore_ms"] = xr_ms
+                extra["rescore_roofline"] = {"bound": "hbm", "achieved": xr_bytes / (xr_ms * 1e-3) / 1e9,
+                                             "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                                             "frac": xr_bytes / (xr_ms * 1e-3) / PEAK_HBM,
+                                             "algorithmic_bytes_per_launch": xr_bytes,
+                                             "note": "L2 hit rate 15 %, TCC_EA0_RDREQ 194 M x 128 B = 24.8 GB per launch "
+                                                     "(profiles/%s_pmc_busy.json, r2T_cfg4 / r2D_cfg4)" % ROUND}
             if os.environ.get("WC_GRAM_MODE", "") != "f32":
                 extra["k_gram_executed_tflops"] = SPLIT_PRODUCTS * xflops / (xk_ms * 1e-3) / 1e12
                 extra["k_gram_frac_of_bf16_mfma_peak"] = SPLIT_PRODUCTS * xflops / (xk_ms * 1e-3) / PEAK_BF16_MFMA
@@ -539,22 +570,36 @@ def main():
         if finish_ms:
             rows_here = B / world
             fbytes = rows_here * k * S * 8.0 + rows_here * k * 12.0
-            gathered = float(stats.get("rescored", 0)) * S * 8.0      # what the kernel really pulls through L2
+            gathered = float(stats.get("rescored", 0)) * S * 8.0      # what the kernels really pull through L2
             ft = hbm_bytes(traffic.get("k_finish"))
-            roof_finish = {"kernel": "float64 re-score stage (k-th key, candidate compaction, exact distances in numpy "
-                                     "order, counting order; events around this stage alone, the exact-path launches "
-                                     "come after)",
-                           "bound": "hbm", "achieved": fbytes / (finish_ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9,
-                           "unit": "GB/s", "frac": fbytes / (finish_ms * 1e-3) / PEAK_HBM, "traffic": ft,
-                           "traffic_unit": "HBM-side bytes per launch (rocprofv3 PMC, %s)" % traffic.get("source"),
-                           "kernel_ms": finish_ms, "algorithmic_bytes_per_launch": fbytes,
-                           "binding": "L2 / Infinity-Cache gathers and VALU+LDS issue, not HBM: `frac` prices the "
-                                      "algorithmic gather bytes against the HBM peak as the contract asks; the "
-                                      "counters beside it say what the memory system really saw",
-                           "hbm_counter_frac": None if ft is None else ft / (finish_ms * 1e-3) / PEAK_HBM,
-                           "l2_model_frac": gathered / (finish_ms * 1e-3) / PEAK_L2,
-                           "gathered_bytes_per_launch": gathered,
-                           "busy_counters": traffic.get("k_finish_busy")}
+            hbm_alg = fbytes / (finish_ms * 1e-3) / PEAK_HBM
+            hbm_cnt = None if ft is None else ft / (finish_ms * 1e-3) / PEAK_HBM
+            l2_frac = gathered / (finish_ms * 1e-3) / PEAK_L2
+            busy = committed_busy(args.workload)
+            # which roof binds is read from the counters: when the memory-side counters see less than half
+            # of what the HBM roof would allow (the image is re-read out of L2 / Infinity Cache), the stage
+            # is priced against the L2 gather bandwidth instead, with the issue-side busy fractions beside it
+            hbm_binds = hbm_cnt is not None and hbm_cnt >= 0.5 and hbm_alg <= 1.0
+            common = {"kernel": "float64 re-score stage: k_pick (k-th key, bound, certificate, compaction) + k_rescore "
+                                "(exact distances in numpy's order, counting order); events around this stage alone, "
+                                "the exact-path launches come after",
+                      "kernel_ms": finish_ms, "algorithmic_bytes_per_launch": fbytes,
+                      "gathered_bytes_per_launch": gathered, "traffic": ft,
+                      "traffic_unit": "HBM-side bytes per launch (rocprofv3 PMC, %s)" % traffic.get("source"),
+                      "hbm_algorithmic_frac": hbm_alg, "hbm_counter_frac": hbm_cnt, "l2_gather_frac": l2_frac,
+                      "issue_busy": busy}
+            if hbm_binds:
+                roof_finish = dict(common, bound="hbm", achieved=fbytes / (finish_ms * 1e-3) / 1e9, peak=PEAK_HBM / 1e9,
+                                   unit="GB/s", frac=hbm_alg)
+            else:
+                roof_finish = dict(common, bound="l2", achieved=gathered / (finish_ms * 1e-3) / 1e9, peak=PEAK_L2 / 1e9,
+                                   unit="GB/s", frac=l2_frac,
+                                   binding="the candidate rows are gathered out of L2 / Infinity Cache (neighbouring "
+                                           "targets share candidates), not HBM: hbm_algorithmic_frac prices the "
+                                           "SURVEY 8(d) bytes against the HBM peak as the contract words it and may "
+                                           "exceed 1; `frac` is the gathered bytes over the aggregate L2 bandwidth; "
+                                           "issue_busy holds the VALU / LDS busy fractions of k_rescore from "
+                                           "profiles/%s_pmc_busy.json -- the stage is issue and gather-latency bound" % ROUND)
         # `roofline` is the kernel that takes longer per step
         if roof_finish and finish_ms > gram_ms:
             dominant, other = roof_finish, roof_gram

@@ -1231,16 +1231,37 @@ __device__ inline int pick_row(const PickArgs &p, int64_t row, int lane, int n, 
     if (n < a.k) {
         if (!admit_all) return -1;
     } else {
-        // k-th smallest lower bound: its 20 leading bits (rounded up) gate a superset of the k smallest
-        uint32_t res = 0;
-        for (int bit = 31; bit >= 12; --bit) {
-            const uint32_t trial = res | (1u << bit);
+        // A separator `res` with at least k keys <= res: bisection of the key VALUES between the smallest
+        // and the largest listed key (ordered float bits).  It stops as soon as exactly k keys lie at
+        // or below the trial -- after about log2(n) + 2 steps, when the interval is narrower than the
+        // gap behind the k-th key -- or when the interval is down to 4096 codes (ties, near ties: a
+        // superset of the k smallest, as good for the bound below).
+        uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+            if (e * 64 + lane < n) {
+                const uint32_t ku = (uint32_t)(ent[e] >> 32);
+                kmin = ku < kmin ? ku : kmin;
+                kmax = ku > kmax ? ku : kmax;
+            }
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t a2 = (uint32_t)__shfl_xor((int)kmin, o), b2 = (uint32_t)__shfl_xor((int)kmax, o);
+            kmin = a2 < kmin ? a2 : kmin;
+            kmax = b2 > kmax ? b2 : kmax;
+        }
+        // invariant: #(key <= lo) < k <= #(key <= hi); lo starts one below the smallest key
+        // (as a 33-bit value: kmin may be 0)
+        long long lo = (long long)kmin - 1, hi = (long long)kmax;
+        uint32_t res = kmax;
+        while (hi - lo > 4096) {
+            const uint32_t trial = (uint32_t)(lo + ((hi - lo) >> 1));
             int c = 0;
 #pragma unroll
-            for (int e = 0; e < NE; ++e) c += __popcll(__ballot((uint32_t)(ent[e] >> 32) < trial));
-            if (c <= a.k - 1) res = trial;
+            for (int e = 0; e < NE; ++e) c += __popcll(__ballot((uint32_t)(ent[e] >> 32) <= trial));
+            // entries beyond n carry ~0 keys: never counted (trial < 2^32 - 1 whenever the loop runs)
+            if (c >= a.k) { hi = (long long)trial; res = trial; if (c == a.k) break; }
+            else lo = (long long)trial;
         }
-        res |= 0xFFFu;
         // upper bound of the k-th true distance: the largest upper bound among those entries
         const double nhi = (double)nhi_f;
         double my = -INFINITY;
