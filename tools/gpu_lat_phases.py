@@ -24,7 +24,7 @@ for region in range(22):
     tb.run()
     _lib.check(lib.wc_debug_times(ctx, 0, _lib.ptr(out)))
     t = out.astype(np.int64)
-    d = lambda a, b: (t[b] - t[a]) / 100.0 if t[a] and t[b] else float("nan")      # s_memtime: 100 MHz
+    d = lambda a, b: (t[b] - t[a]) / 2100.0 if t[a] and t[b] else float("nan")      # clock64: shader cycles, ~2.1 GHz
     print("region %2d setup: clean %.1f prefix %.1f whole %.1f | tree: load %.1f collect %.1f decide %.1f rest->calls %.1f calls %.1f | child collect %.1f decide %.1f (us)"
           % (region, d(0, 1), d(1, 2), d(2, 3), d(8, 9), d(9, 10), d(10, 11), d(11, 16), d(16, 17), d(13, 14), d(14, 15)))
     out[:] = 0

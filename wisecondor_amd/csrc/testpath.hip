@@ -30,10 +30,11 @@ namespace {
 // phases (workgroup `DBG_BLOCK`, thread 0) in a device array read back by wc_debug_times.
 __device__ unsigned long long g_dbg[64];
 __device__ int g_dbg_on = 0;
-#define WC_STAMP(slot)                                                                      \
+#define WC_STAMP_AT(slot, blk)                                                              \
     do {                                                                                    \
-        if (g_dbg_on && threadIdx.x == 0 && (int)blockIdx.x == g_dbg_on - 1) g_dbg[slot] = clock64(); \
+        if (g_dbg_on && threadIdx.x == 0 && (int)(blk) == g_dbg_on - 1) g_dbg[slot] = clock64(); \
     } while (0)
+#define WC_STAMP(slot) WC_STAMP_AT(slot, blockIdx.x)
 
 constexpr int MAX_COMP = 8;
 constexpr int SHORT_SEG = 1024;  // segments up to this length take the counting median in k_call_post
@@ -299,10 +300,16 @@ __global__ __launch_bounds__(256) void k_lat_project(const int *__restrict__ cou
     const int *row = counts + i * Btot;
     long long acc_t = 0;
     {
-        long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;  // the loads of a trip are in flight together
-        int64_t g = tid;
-        for (; g + 768 < Btot; g += 1024) { a0 += row[g]; a1 += row[g + 256]; a2 += row[g + 512]; a3 += row[g + 768]; }
-        for (; g < Btot; g += 256) a0 += row[g];
+        // sixteen loads of a trip in flight together (one memory round trip per 4096 bins: three trips at
+        // 250 kb instead of twelve)
+        long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int64_t g0 = tid; g0 < Btot; g0 += 4096) {
+            int v[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = g0 + 256 * e < Btot ? row[g0 + 256 * e] : 0;
+#pragma unroll
+            for (int e = 0; e < 16; e += 4) { a0 += v[e]; a1 += v[e + 1]; a2 += v[e + 2]; a3 += v[e + 3]; }
+        }
         acc_t = (a0 + a1) + (a2 + a3);
     }
     sh_t[tid] = acc_t;
@@ -318,12 +325,33 @@ __global__ __launch_bounds__(256) void k_lat_project(const int *__restrict__ cou
     double acc[MAX_COMP];
 #pragma unroll
     for (int c = 0; c < MAX_COMP; ++c) acc[c] = 0.0;
-    for (int64_t b = b_lo + tid; b < b_hi; b += 256) {
-        const double xb = (double)row[m2g[b]] / total;
-        const double d = xb - mean[b];
+    // the same terms in the same order per accumulator as the loop `for b: acc[c] += d * comp[c][b]`, with
+    // the loads of four consecutive trips issued together (index, then count / mean / components)
+    for (int64_t b0 = b_lo + tid; b0 < b_hi; b0 += 1024) {
+        int gi[4];
+        double mn[4], cp[4][MAX_COMP];
 #pragma unroll
-        for (int c = 0; c < MAX_COMP; ++c)
-            if (c < n_comp) acc[c] += d * comp[(int64_t)c * B + b];
+        for (int e = 0; e < 4; ++e) gi[e] = b0 + 256 * e < b_hi ? m2g[b0 + 256 * e] : -1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t b = b0 + 256 * e;
+            const bool in = b < b_hi;
+            mn[e] = in ? mean[b] : 0.0;
+#pragma unroll
+            for (int c = 0; c < MAX_COMP; ++c) cp[e][c] = (in && c < n_comp) ? comp[(int64_t)c * B + b] : 0.0;
+        }
+        int cv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cv[e] = gi[e] >= 0 ? row[gi[e]] : 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (gi[e] < 0) continue;
+            const double xb = (double)cv[e] / total;
+            const double d = xb - mn[e];
+#pragma unroll
+            for (int c = 0; c < MAX_COMP; ++c)
+                if (c < n_comp) acc[c] += d * cp[e][c];
+        }
     }
 #pragma unroll
     for (int c = 0; c < MAX_COMP; ++c) sh[c][tid] = acc[c];
@@ -331,7 +359,8 @@ __global__ __launch_bounds__(256) void k_lat_project(const int *__restrict__ cou
     for (int o = 128; o > 0; o >>= 1) {
         if (tid < o)
 #pragma unroll
-            for (int c = 0; c < MAX_COMP; ++c) sh[c][tid] += sh[c][tid + o];
+            for (int c = 0; c < MAX_COMP; ++c)
+                if (c < n_comp) sh[c][tid] += sh[c][tid + o];
         __syncthreads();
     }
     if (tid < n_comp) proj[(i * PROJ_SPLIT + blockIdx.y) * MAX_COMP + tid] = sh[tid][0];
@@ -684,24 +713,59 @@ __device__ inline void zscore_pair8(const unsigned int gid, const int sub, const
 #pragma unroll
         for (int t8 = 0; t8 < 16; ++t8) v[t8] = g[t8] >= 0 ? XC[(int64_t)g[t8] * Ns + i] : -1.0;
     }
-    GroupSum acc;
-    acc.init();
+    // Nothing dropped in this pair (the usual case before any flag): kept value number c is reference c,
+    // so lane `sub` IS numpy's accumulator r[sub] -- the body of the list is a plain chain of adds per
+    // lane and the stream bookkeeping of GroupSum (ballots, lane searches, shuffles per trip) is not
+    // needed; combine and tail are GroupSum::finish's.
+    bool all_kept = true;
 #pragma unroll
-    for (int t8 = 0; t8 < 16; ++t8) {
-        if (8 * t8 >= n) break;
-        acc.trip(v[t8], v[t8] >= 0.0, sub, gbase);   // flagged (-1), negative and NaN values are dropped (wisetools.py:425)
-    }
-    const int m = acc.pos;
-    const double mean = acc.finish(sub, gbase) / (double)m;
-    acc.init();
+    for (int t8 = 0; t8 < 16; ++t8) all_kept = all_kept && (8 * t8 + sub >= n || v[t8] >= 0.0);
+    const bool group_kept = ((unsigned int)(__ballot(all_kept) >> gbase) & 0xFFu) == 0xFFu;
+    int m;
+    double mean, var;
+    if (group_kept) {
+        const int nb8 = n >> 3, tail = n & 7;
+        auto group_sum = [&](auto term) {
+            double r = 0.0, pend = 0.0;
 #pragma unroll
-    for (int t8 = 0; t8 < 16; ++t8) {
-        if (8 * t8 >= n) break;
-        const double dv = v[t8] - mean;
-        const double sq = dv * dv;
-        acc.trip(sq, v[t8] >= 0.0, sub, gbase);
+            for (int t8 = 0; t8 < 16; ++t8) {
+                const double x = term(t8);
+                if (t8 < nb8) r = r + x;
+                pend = t8 == nb8 ? x : pend;
+            }
+            double res = r + __shfl_xor(r, 1);
+            res = res + __shfl_xor(res, 2);
+            res = res + __shfl_xor(res, 4);
+            for (int e = 0; e < tail; ++e) res = res + __shfl(pend, gbase + e);
+            return res;
+        };
+        m = n;
+        mean = group_sum([&](int t8) { return v[t8]; }) / (double)m;
+        var = group_sum([&](int t8) {
+                  const double dv = v[t8] - mean;
+                  const double sq = dv * dv;
+                  return sq;
+              }) / (double)m;
+    } else {
+        GroupSum acc;
+        acc.init();
+#pragma unroll
+        for (int t8 = 0; t8 < 16; ++t8) {
+            if (8 * t8 >= n) break;
+            acc.trip(v[t8], v[t8] >= 0.0, sub, gbase);   // flagged (-1), negative and NaN values are dropped (wisetools.py:425)
+        }
+        m = acc.pos;
+        mean = acc.finish(sub, gbase) / (double)m;
+        acc.init();
+#pragma unroll
+        for (int t8 = 0; t8 < 16; ++t8) {
+            if (8 * t8 >= n) break;
+            const double dv = v[t8] - mean;
+            const double sq = dv * dv;
+            acc.trip(sq, v[t8] >= 0.0, sub, gbase);
+        }
+        var = acc.finish(sub, gbase) / (double)m;
     }
-    const double var = acc.finish(sub, gbase) / (double)m;
     if (sub == 0) {
         const double sd = sqrt(var);
         const double x = XT[gid];
@@ -994,9 +1058,8 @@ __device__ inline int sd_exponent(double v) {          // unbiased exponent of a
 // memory round trip instead of one per term and walk: 26 -> 8 us at 11 087 bins); REG == 0: any
 // count up to PER_MAX, re-read in each walk.
 template <int REG>
-__global__ __launch_bounds__(1024) void k_sd_fast(const double *__restrict__ sdT, int64_t B, int64_t Ns,
-                                                  double *__restrict__ out, int *__restrict__ fail,
-                                                  double *__restrict__ out2) {
+__device__ inline void sd_fast_block(const int64_t i, const double *__restrict__ sdT, int64_t B, int64_t Ns,
+                                     double *__restrict__ out, int *__restrict__ fail, double *__restrict__ out2) {
     constexpr int PER_MAX = 64;                      // elements per thread (B <= 65536)
     __shared__ double sh_p[1024];                    // scan of the threads' approximate sums
     __shared__ long long sh_A[1024];
@@ -1010,7 +1073,6 @@ __global__ __launch_bounds__(1024) void k_sd_fast(const double *__restrict__ sdT
     __shared__ long long sh_wA[16];
     __shared__ int sh_wH0[16], sh_wH1[16], sh_wf[16], sh_wn[16];
     const int tid = threadIdx.x;
-    const int64_t i = blockIdx.x;
     const int per = (int)((B + 1023) / 1024);
     if (per > PER_MAX) { if (tid == 0) fail[i] = 1; return; }
     if (tid == 0) s_bad = 0;
@@ -1214,6 +1276,22 @@ __global__ __launch_bounds__(1024) void k_sd_fast(const double *__restrict__ sdT
         fail[i] = ok ? 0 : 1;                      // 1: the serial kernel computes this sample
     }
 }
+
+template <int REG>
+__global__ __launch_bounds__(1024) void k_sd_fast(const double *__restrict__ sdT, int64_t B, int64_t Ns,
+                                                  double *__restrict__ out, int *__restrict__ fail,
+                                                  double *__restrict__ out2) {
+    sd_fast_block<REG>(blockIdx.x, sdT, B, Ns, out, fail, out2);
+}
+
+// what the latency mode appends to another kernel's grid (k_seg_tree): `blocks` workgroups, one per sample
+struct SdRider {
+    int blocks;
+    const double *sdT;
+    int64_t B, Ns;
+    double *out, *out2;
+    int *fail;
+};
 
 void launch_sd_fast(hipStream_t stream, const double *sdT, int64_t B, int64_t Ns, double *out, int *fail, double *out2) {
     const int64_t per = (B + 1023) / 1024;
@@ -1824,6 +1902,7 @@ __global__ __launch_bounds__(64 * NW) void k_seg_search(const Job *__restrict__ 
                                                     const int *__restrict__ n_jobs_dev, int *__restrict__ next_count) {
     extern __shared__ double pl[];
     __shared__ double red_max[NW], red_min[NW];
+    __shared__ double side_max[2][NW], side_min[2][NW];
     const int j = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
     // first kernel of a round: next-jobs / hot / brute counts start at zero (classify runs after)
     if (j == 0 && chunk == 0 && tid == 0) { *next_count = 0; counters[2] = 0; counters[3] = 0; }
@@ -1852,6 +1931,7 @@ __global__ __launch_bounds__(64 * NW) void k_seg_search(const Job *__restrict__ 
         search_side<MASKED, NW>(P, L, half, chunk, side, rs, lane, w, job.lo, wm, smax, smin, n_windows);
         // the collect pass re-scans a (side, wave) slice only if its own extremes reach the cut
         if (NW == 4 && lane == 0) sub_blk[side * 4 + w] = make_double2(smax, smin);
+        if (NW != 4 && lane == 0) { side_max[side][w] = smax; side_min[side][w] = smin; }
         bmax = fmax(bmax, smax);
         bmin = fmin(bmin, smin);
     }
@@ -1868,8 +1948,15 @@ __global__ __launch_bounds__(64 * NW) void k_seg_search(const Job *__restrict__ 
         for (int q = 1; q < NW; ++q) { e.maxv = fmax(e.maxv, red_max[q]); e.minv = fmin(e.minv, red_min[q]); }
         e.max_x = e.max_y = e.min_x = e.min_y = -1;
         partial[(int64_t)j * max_chunks + chunk] = e;
-        if (NW != 4)      // sixteen-wave rounds are small: every slice inherits the block's extremes
-            for (int q = 0; q < 8; ++q) sub_blk[q] = make_double2(e.maxv, e.minv);
+    }
+    if (NW != 4 && tid < 8) {
+        // sixteen search waves: the collect pass's wave w16 scans the lengths with (len - 1) % 16 == w16,
+        // which the search waves (w16 >> 2) + 4 m covered (groups of four lengths dealt round robin):
+        // slot [side][g] holds the extremes over the search waves w with w % 4 == g
+        const int side = tid >> 2, g = tid & 3;
+        double mx = -INFINITY, mn = INFINITY;
+        for (int q = g; q < NW; q += 4) { mx = fmax(mx, side_max[side][q]); mn = fmin(mn, side_min[side][q]); }
+        sub_blk[side * 4 + g] = make_double2(mx, mn);
     }
 }
 
@@ -2309,15 +2396,15 @@ constexpr int TREE_STACK = 64;
 constexpr int TREE_CHUNKS = 17;     // row blocks of the longest region the tree kernel takes (2048 bins)
 constexpr int TREE_SEGS = 128;
 constexpr int TREE_MAXLEN = 2048;
-__global__ __launch_bounds__(1024) void k_seg_tree(int *__restrict__ counters, const Region *__restrict__ regions,
-                                                   int64_t n_regions, const int *__restrict__ reg_flag,
-                                                   const double *__restrict__ prefix, const double *__restrict__ rs,
-                                                   const double *__restrict__ reg_abs, const double *__restrict__ z,
-                                                   const double *__restrict__ ratio, const int *__restrict__ gpos,
-                                                   double thr, int min_search, int max_calls,
-                                                   double *__restrict__ reg_calls, int *__restrict__ out_n,
-                                                   const Extreme *__restrict__ partial,
-                                                   const double2 *__restrict__ sub, int max_chunks) {
+__device__ inline void seg_tree_region(const int region, int *__restrict__ counters, const Region *__restrict__ regions,
+                                       int64_t n_regions, const int *__restrict__ reg_flag,
+                                       const double *__restrict__ prefix, const double *__restrict__ rs,
+                                       const double *__restrict__ reg_abs, const double *__restrict__ z,
+                                       const double *__restrict__ ratio, const int *__restrict__ gpos,
+                                       double thr, int min_search, int max_calls,
+                                       double *__restrict__ reg_calls, int *__restrict__ out_n,
+                                       const Extreme *__restrict__ partial,
+                                       const double2 *__restrict__ sub, int max_chunks) {
     extern __shared__ double pl[];                 // the region's prefix array, n + 1 doubles (later: median scratch)
     __shared__ Job stack[TREE_STACK];
     __shared__ int s_sp, s_nhi, s_nlo, s_nseg, s_root;
@@ -2330,8 +2417,8 @@ __global__ __launch_bounds__(1024) void k_seg_tree(int *__restrict__ counters, c
     __shared__ int seg_x[TREE_SEGS], seg_y[TREE_SEGS];
     __shared__ double s_mid[2];
     __shared__ int s_nan;
+    __shared__ unsigned int s_reach[TREE_CHUNKS];
     const int tid = threadIdx.x;
-    const int region = blockIdx.x;
     if (region >= n_regions) return;
     const Region rg = regions[region];
     if (rg.n <= 0) return;
@@ -2339,7 +2426,7 @@ __global__ __launch_bounds__(1024) void k_seg_tree(int *__restrict__ counters, c
         if (tid == 0) counters[6] = 1;
         return;
     }
-    WC_STAMP(8);
+    WC_STAMP_AT(8, region);
     const long long a0 = rg.off + region;              // absolute index of the region's P[0]
     const double *Pg = prefix + a0;
     double *zl = pl + (rg.n + 1);                      // the region's z values, for the exact sums
@@ -2394,17 +2481,21 @@ __global__ __launch_bounds__(1024) void k_seg_tree(int *__restrict__ counters, c
         } else {
             // value search with the general path's inner loops (four float64 operations per window);
             // every (row block, side, wave) leaves its extremes behind for the candidate pass
+            // Four (row block, side) pairs at a time, four waves each: a pair costs a fixed round of
+            // loads and reductions whatever its size, and a child range has up to 2 x 17 of them.
             const double *P = pl + job.lo;
             double bmax = -INFINITY, bmin = INFINITY;
             int dummy = 0;
-            for (int ch = 0; ch < nch; ++ch)
-                for (int side = 0; side < 2; ++side) {
-                    double smax, smin;
-                    search_side<false, 16>(P, c.L, c.half, ch, side, rs, lane, w, job.lo, wm, smax, smin, dummy);
-                    if (lane == 0) { ext_max[ch][side][w] = smax; ext_min[ch][side][w] = smin; }
-                    bmax = fmax(bmax, smax);
-                    bmin = fmin(bmin, smin);
-                }
+            const int grp = w >> 2, w4 = w & 3;
+            for (int cs = grp; cs < 2 * nch; cs += 4) {
+                const int ch = cs >> 1, side = cs & 1;
+                double smax, smin;
+                search_side<false, 4>(P, c.L, c.half, ch, side, rs, lane, w4, job.lo, wm, smax, smin, dummy);
+                // slots 4 w4 .. 4 w4 + 3: the candidate pass's waves that scan this search wave's lengths
+                if (lane < 4) { ext_max[ch][side][4 * w4 + lane] = smax; ext_min[ch][side][4 * w4 + lane] = smin; }
+                bmax = fmax(bmax, smax);
+                bmin = fmin(bmin, smin);
+            }
             if (lane == 0) { red_max[w] = bmax; red_min[w] = bmin; }
             __syncthreads();
             emax = red_max[0];
@@ -2415,17 +2506,22 @@ __global__ __launch_bounds__(1024) void k_seg_tree(int *__restrict__ counters, c
         }
         // windows within 2 eps of the extremes: one of them is numpy's argmax / argmin.  Only the
         // (row block, side) pairs whose own extremes reach a cut are scanned again.
-        WC_STAMP(is_root ? 9 : 13);
+        WC_STAMP_AT(is_root ? 9 : 13, region);
         const double hi_cut = emax - 2.0 * eps, lo_cut = emin + 2.0 * eps;
+        // which (row block, side, wave) slices reach a cut: one thread per stored extreme, one LDS word per block
+        // (every thread walking the 32 extremes of every block itself, with short-circuit tests, was a
+        // chain of ~250 dependent LDS reads: 11 us at the root of a 900-bin region)
+        for (int t = tid; t < nch; t += 1024) s_reach[t] = 0u;
+        __syncthreads();
+        for (int t = tid; t < nch * 32; t += 1024) {
+            const bool reach = !((&ext_max[0][0][0])[t] < hi_cut && (&ext_min[0][0][0])[t] > lo_cut);
+            if (reach) atomicOr(&s_reach[t >> 5], 1u << (t & 31));      // bit side * 16 + candidate-pass wave
+        }
+        __syncthreads();
         for (int ch = 0; ch < nch; ++ch) {
-            unsigned int skip = 0u;
-            for (int side = 0; side < 2; ++side) {
-                bool none = true;
-                for (int q = 0; q < 16; ++q)
-                    none = none && ext_max[ch][side][q] < hi_cut && ext_min[ch][side][q] > lo_cut;
-                if (none) skip |= 0xFFFFu << (side * 16);
-            }
-            if (skip == 0xFFFFFFFFu) continue;
+            const unsigned int reach = s_reach[ch];
+            if (reach == 0u) continue;
+            const unsigned int skip = ~reach;
             c.chunk = ch;
             scan_chunk(c, rs, tid, [&](double v, int x, int y) {
                 if (v >= hi_cut) {
@@ -2439,7 +2535,7 @@ __global__ __launch_bounds__(1024) void k_seg_tree(int *__restrict__ counters, c
             }, skip);
         }
         __syncthreads();
-        WC_STAMP(is_root ? 10 : 14);
+        WC_STAMP_AT(is_root ? 10 : 14, region);
         const int n_hi = s_nhi, n_lo = s_nlo;
         if (n_hi > CAND_CAP || n_lo > CAND_CAP) {     // massive ties: the general path evaluates everything exactly
             if (tid == 0) counters[6] = 1;
@@ -2464,7 +2560,7 @@ __global__ __launch_bounds__(1024) void k_seg_tree(int *__restrict__ counters, c
             if (lane == 0) s_best[w] = b;
         }
         __syncthreads();
-        WC_STAMP(is_root ? 11 : 15);
+        WC_STAMP_AT(is_root ? 11 : 15, region);
         if (tid == 0) {
             BestPair b = s_best[0];
             if (s_best[1].mx >= 0 && better_max(s_best[1].maxv, s_best[1].mx, s_best[1].my, b.maxv, b.mx, b.my)) {
@@ -2493,7 +2589,7 @@ __global__ __launch_bounds__(1024) void k_seg_tree(int *__restrict__ counters, c
     }
     // ---- the region's calls, in position order (k_seg_gather + k_call_post of the general path)
     __syncthreads();
-    WC_STAMP(16);
+    WC_STAMP_AT(16, region);
     const int nseg = s_nseg;
     if (tid == 0) {
         out_n[region] = nseg;
@@ -2548,7 +2644,7 @@ __global__ __launch_bounds__(1024) void k_seg_tree(int *__restrict__ counters, c
             o[4] = med - 1.0;
         }
     }
-    WC_STAMP(17);
+    WC_STAMP_AT(17, region);
 }
 
 // Order each region's segments by position (the reference's in-order recursion).
@@ -2739,6 +2835,118 @@ __global__ void k_assemble_calls(const double *__restrict__ reg_calls, const int
 }
 
 
+// Latency mode's last launch.  One 1024-thread workgroup per region walks the region's recursion
+// (seg_tree_region); the same grid carries three riders that would otherwise be launches (or a
+// forked graph branch) of their own:
+//   * the first sd.blocks workgroups compute stdDevAvg (k_sd_fast's body, one per sample) -- a second
+//     stream for that one kernel cost ~20 us of fork and join bubbles per call;
+//   * the next inf.blocks workgroups write results_z / results_r (k_inflate's arithmetic);
+//   * the LAST workgroup to finish (a counter in counters[7]) gathers the calls of every sample and
+//     publishes the status words to the host (k_assemble_calls' job).
+struct InflateRider {
+    int blocks;
+    const double *zs, *rs, *ns;
+    int64_t B, Btot, Ns, si, sb;
+    const int *g2m;
+    double minref;
+    double *res_z, *res_r;
+};
+struct AssembleRider {
+    int on, n_sel, max_calls;
+    int64_t Ns;
+    double *calls;
+    int *n_calls, *overflow, *host_status;
+    const int *rep_overflow, *sd_fail;
+    const double *reg_calls;
+};
+__global__ __launch_bounds__(1024) void k_seg_tree(int *__restrict__ counters, const Region *__restrict__ regions,
+                                                   int64_t n_regions, const int *__restrict__ reg_flag,
+                                                   const double *__restrict__ prefix, const double *__restrict__ rs,
+                                                   const double *__restrict__ reg_abs, const double *__restrict__ z,
+                                                   const double *__restrict__ ratio, const int *__restrict__ gpos,
+                                                   double thr, int min_search, int max_calls,
+                                                   double *__restrict__ reg_calls, int *__restrict__ out_n,
+                                                   const Extreme *__restrict__ partial,
+                                                   const double2 *__restrict__ sub, int max_chunks, SdRider sd,
+                                                   InflateRider inf, AssembleRider as) {
+    const int blk = (int)blockIdx.x;
+    if (blk < sd.blocks) {
+        const int64_t per = (sd.B + 1023) / 1024;
+        if (per <= 12) sd_fast_block<12>(blk, sd.sdT, sd.B, sd.Ns, sd.out, sd.fail, sd.out2);
+        else if (per <= 24) sd_fast_block<24>(blk, sd.sdT, sd.B, sd.Ns, sd.out, sd.fail, sd.out2);
+        else sd_fast_block<0>(blk, sd.sdT, sd.B, sd.Ns, sd.out, sd.fail, sd.out2);
+    } else if (blk < sd.blocks + inf.blocks) {
+        const int64_t n = inf.Btot * inf.Ns;
+        for (int64_t t = (int64_t)(blk - sd.blocks) * 1024 + threadIdx.x; t < n; t += (int64_t)inf.blocks * 1024) {
+            const int64_t i = t / inf.Btot, g = t - i * inf.Btot;
+            const int m = inf.g2m[g];
+            double zv = 0.0, rv = 0.0;
+            if (m >= 0 && inf.ns[i * inf.si + m * inf.sb] >= inf.minref) {
+                zv = inf.zs[i * inf.si + m * inf.sb];
+                rv = inf.rs[i * inf.si + m * inf.sb] - 1.0;
+            }
+            if (inf.res_z) inf.res_z[t] = zv;
+            if (inf.res_r) inf.res_r[t] = rv;
+        }
+    } else {
+        seg_tree_region(blk - sd.blocks - inf.blocks, counters, regions, n_regions, reg_flag, prefix, rs, reg_abs, z, ratio,
+                        gpos, thr, min_search, max_calls, reg_calls, out_n, partial, sub, max_chunks);
+    }
+    if (!as.on) return;
+    __shared__ int s_last;
+    __threadfence();                                   // this workgroup's results, before its arrival is counted
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&counters[7], 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    const int t = threadIdx.x;
+    {
+        // k_assemble_calls' job with the loads in parallel: the other workgroups' results come from
+        // memory (other XCDs' L2s), a chain of dependent reads per sample would cost a round trip each.
+        // Thread (i, c) = (t >> 6, t & 63) reads the call count of region c of sample i; a serial scan per
+        // sample over <= WC_MAX_CHROM counts in LDS; then every thread copies its region's rows.
+        __shared__ int a_n[8][64], a_off[8][65];
+        const int i = t >> 6, c = t & 63;
+        const bool mine = t < 512 && i < as.Ns && c < as.n_sel;
+        int n = 0;
+        if (mine) {
+            n = ((volatile const int *)out_n)[i * as.n_sel + c];
+            if (n > as.max_calls) { *as.overflow = 1; n = as.max_calls; }
+        }
+        if (t < 512) a_n[i][c] = n;
+        __syncthreads();
+        if (t < 8 && t < as.Ns) {
+            int total = 0;
+            for (int q = 0; q < as.n_sel; ++q) { a_off[t][q] = total; total += a_n[t][q]; }
+            if (total > as.max_calls) *as.overflow = 1;
+            as.n_calls[t] = total < as.max_calls ? total : as.max_calls;
+        }
+        __syncthreads();
+        if (mine) {
+            const int64_t r = (int64_t)i * as.n_sel + c;
+            for (int q = 0; q < n; ++q) {
+                const int at = a_off[i][c] + q;
+                if (at >= as.max_calls) break;
+                for (int f = 0; f < 5; ++f)
+                    as.calls[((int64_t)i * as.max_calls + at) * 5 + f] =
+                        ((volatile const double *)as.reg_calls)[(r * as.max_calls + q) * 5 + f];
+            }
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    if (t == 0) as.host_status[16] = ((volatile int *)as.overflow)[0];
+    if (t < 8) as.host_status[24 + t] = ((volatile int *)counters)[t];
+    if (t == 8) as.host_status[32] = as.rep_overflow[0];
+    if (t == 9) {
+        int f = 0;
+        for (int64_t q = 0; q < as.Ns; ++q) f |= ((volatile const int *)as.sd_fail)[q];
+        as.host_status[33] = f;
+    }
+    __threadfence_system();
+}
+
 // ------------------------------------------------------------ host drivers ----
 int run_prepare(wc_ctx *ctx, const wc_reference *ref, const int *counts_dev, int64_t Ns, hipStream_t stream) {
     TestState &ts = ctx->ts;
@@ -2882,6 +3090,16 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
     // stdDevAvg only feeds the asdef output: it runs on the context's side stream under the
     // segmentation work (latency mode: on the launch stream -- the parallel form takes a few
     // microseconds, a second stream in the captured graph costs more -- straight into `asdef_out`).
+    const char *sd_env0 = getenv("WC_SD_AVG");
+    ts.lat_ride = false;
+    if (lat && !(sd_env0 && strcmp(sd_env0, "serial") == 0) && ref->B <= 65536) {
+        // latency mode: the parallel form rides in k_seg_tree's grid (run_seg_lat) -- no second stream,
+        // whose fork and join cost more than the kernel; a sample it gives up on raises status word 33
+        if ((rc = ts.sd_fail.reserve(sizeof(int) * Ns))) return rc;
+        ts.lat_ride = true;
+        ts.lat_ride_out2 = asdef_out;
+        return WC_OK;
+    }
     hipStream_t sds = stream;
     {
         if ((rc = ctx->ensure_side_stream())) return rc;
@@ -3106,7 +3324,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
 // after it synchronised.  Results as run_stouffer leaves them (ts.out_*, ts.whole, ts.seg).
 int run_seg_lat(wc_ctx *ctx, const wc_reference *ref, const double *zsrc, const double *rsrc, const double *nsrc,
                 int64_t str_i, int64_t str_b, int64_t Ns, int n_sel, int64_t max_n, double thr, int min_ref_bins,
-                int max_calls, hipStream_t stream, double *whole_copy) {
+                int max_calls, hipStream_t stream, double *whole_copy, InflateRider inf, AssembleRider as) {
     TestState &ts = ctx->ts;
     const int64_t B = ref->B, n_regions = Ns * n_sel, total_len = Ns * B;
     int rc;
@@ -3158,13 +3376,25 @@ int run_seg_lat(wc_ctx *ctx, const wc_reference *ref, const double *zsrc, const 
         if (n_regions * max_chunks <= 2048) WC_LSEARCH(16); else WC_LSEARCH(4);
 #undef WC_LSEARCH
     }
-    hipLaunchKernelGGL(k_seg_tree, dim3((unsigned)n_regions), dim3(1024), sizeof(double) * (2 * max_n + 2), stream, counters,
+    SdRider rider{};
+    if (ts.lat_ride) {
+        rider.blocks = (int)Ns;
+        rider.sdT = ts.sdt.as<double>();
+        rider.B = B;
+        rider.Ns = Ns;
+        rider.out = ts.sd_avg.as<double>();
+        rider.out2 = ts.lat_ride_out2;
+        rider.fail = ts.sd_fail.as<int>();
+    }
+    as.reg_calls = ts.effect.as<double>();
+    as.sd_fail = ts.sd_fail.as<int>();
+    hipLaunchKernelGGL(k_seg_tree, dim3((unsigned)(n_regions + rider.blocks + inf.blocks)), dim3(1024), sizeof(double) * (2 * max_n + 2), stream, counters,
                        (const Region *)ts.regions.as<Region>(), n_regions, (const int *)ts.reg_flag.as<int>(),
                        (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
                        (const double *)ts.reg_abs.as<double>(), (const double *)ts.zc.as<double>(),
                        (const double *)ts.rc.as<double>(), (const int *)ts.gpos.as<int>(), thr, 3, max_calls,
                        ts.effect.as<double>(), ts.out_n.as<int>(), (const Extreme *)ts.partial.as<Extreme>(),
-                       (const double2 *)ts.sub.as<double2>(), max_chunks);
+                       (const double2 *)ts.sub.as<double2>(), max_chunks, rider, inf, as);
     ts.last_segs = 0;                     // the calls are already in ts.effect / ts.out_n
     WC_HIP(hipGetLastError());
     return WC_OK;
@@ -3542,7 +3772,13 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
         zsrc = ts.zs.as<double>(); rsrc = ts.rs2.as<double>(); nsrc = ts.ns2.as<double>();
         str_i = B; str_b = 1;
     }
-    if (results_z || results_r) {
+    // latency mode with something to segment: results_z / results_r are written by rider workgroups of the
+    // last launch (k_seg_tree) instead of a launch of their own on the critical path
+    const char *ride_env = getenv("WC_LAT_RIDERS");            // bit 0: inflate rider (default), bit 1: assemble rider
+    const int ride_mask = ride_env ? atoi(ride_env) : 1;      // the assemble rider measured 8 us slower than its own launch (device-scope fences)
+    const bool ride_inf = lat && n_sel > 0 && calls && n_calls && (ride_mask & 1);
+    const bool ride = lat && n_sel > 0 && calls && n_calls && (ride_mask & 2);
+    if ((results_z || results_r) && !ride_inf) {
         dim3 g((unsigned)cdiv(ref->Btot, 256), (unsigned)Ns);
         hipLaunchKernelGGL(k_inflate, g, dim3(256), 0, stream, zsrc, rsrc, nsrc, B, ref->Btot,
                            (const int *)ref->g2m.as<int>(), (double)min_ref_bins, results_z, results_r, str_i, str_b);
@@ -3559,9 +3795,35 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
     if ((rc = ts.effect.reserve(sizeof(double) * n_regions * max_calls * 5))) return rc;
     if ((rc = ts.misc.reserve(sizeof(int) * 4))) return rc;
     if (lat) {
+        if ((rc = ctx->ensure_pinned(256))) return rc;
+        InflateRider inf{};
+        AssembleRider as{};
+        if (ride_inf && (results_z || results_r)) {
+            {
+                inf.blocks = (int)std::min<int64_t>(16, cdiv(ref->Btot * Ns, 1024));
+                inf.zs = zsrc; inf.rs = rsrc; inf.ns = nsrc;
+                inf.B = B; inf.Btot = ref->Btot; inf.Ns = Ns; inf.si = str_i; inf.sb = str_b;
+                inf.g2m = ref->g2m.as<int>();
+                inf.minref = (double)min_ref_bins;
+                inf.res_z = results_z; inf.res_r = results_r;
+            }
+        }
+        if (ride) {
+            as.on = 1; as.n_sel = n_sel; as.max_calls = max_calls; as.Ns = Ns;
+            as.calls = calls; as.n_calls = n_calls; as.overflow = ts.misc.as<int>();
+            as.host_status = (int *)ctx->pinned;
+            as.rep_overflow = ts.misc2.as<int>() + repeats + 1;
+        }
+        if (ride && (rc = join_side(ctx, stream))) return rc;     // WC_SD_AVG=serial: the flags come from the side stream
         if ((rc = run_seg_lat(ctx, ref, zsrc, rsrc, nsrc, str_i, str_b, Ns, n_sel, max_n, threshold, min_ref_bins,
-                              max_calls, stream, results_cwz)))
+                              max_calls, stream, results_cwz, inf, as)))
             return rc;
+        if (ride) {
+            ts.mark(4, stream);
+            ts.mark(5, stream);
+            WC_HIP(hipGetLastError());
+            return WC_OK;
+        }
     } else {
         hipLaunchKernelGGL(k_clean, dim3((unsigned)n_sel, (unsigned)Ns), dim3(64), 0, stream, zsrc, rsrc, nsrc, B, Ns,
                            (const int64_t *)ref->moff_dev.as<int64_t>(), (const int64_t *)ref->goff_dev.as<int64_t>(),
