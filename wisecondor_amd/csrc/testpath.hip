@@ -300,15 +300,15 @@ __global__ __launch_bounds__(256) void k_lat_project(const int *__restrict__ cou
     const int *row = counts + i * Btot;
     long long acc_t = 0;
     {
-        // sixteen loads of a trip in flight together (one memory round trip per 4096 bins: three trips at
+        // thirty-two loads of a trip in flight together (one memory round trip per 8192 bins: two trips at
         // 250 kb instead of twelve)
         long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        for (int64_t g0 = tid; g0 < Btot; g0 += 4096) {
-            int v[16];
+        for (int64_t g0 = tid; g0 < Btot; g0 += 8192) {
+            int v[32];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = g0 + 256 * e < Btot ? row[g0 + 256 * e] : 0;
+            for (int e = 0; e < 32; ++e) v[e] = g0 + 256 * e < Btot ? row[g0 + 256 * e] : 0;
 #pragma unroll
-            for (int e = 0; e < 16; e += 4) { a0 += v[e]; a1 += v[e + 1]; a2 += v[e + 2]; a3 += v[e + 3]; }
+            for (int e = 0; e < 32; e += 4) { a0 += v[e]; a1 += v[e + 1]; a2 += v[e + 2]; a3 += v[e + 3]; }
         }
         acc_t = (a0 + a1) + (a2 + a3);
     }
@@ -326,25 +326,25 @@ __global__ __launch_bounds__(256) void k_lat_project(const int *__restrict__ cou
 #pragma unroll
     for (int c = 0; c < MAX_COMP; ++c) acc[c] = 0.0;
     // the same terms in the same order per accumulator as the loop `for b: acc[c] += d * comp[c][b]`, with
-    // the loads of four consecutive trips issued together (index, then count / mean / components)
-    for (int64_t b0 = b_lo + tid; b0 < b_hi; b0 += 1024) {
-        int gi[4];
-        double mn[4], cp[4][MAX_COMP];
+    // the loads of eight consecutive trips issued together (index, then count / mean / components)
+    for (int64_t b0 = b_lo + tid; b0 < b_hi; b0 += 2048) {
+        int gi[8];
+        double mn[8], cp[8][MAX_COMP];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) gi[e] = b0 + 256 * e < b_hi ? m2g[b0 + 256 * e] : -1;
+        for (int e = 0; e < 8; ++e) gi[e] = b0 + 256 * e < b_hi ? m2g[b0 + 256 * e] : -1;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 8; ++e) {
             const int64_t b = b0 + 256 * e;
             const bool in = b < b_hi;
             mn[e] = in ? mean[b] : 0.0;
 #pragma unroll
             for (int c = 0; c < MAX_COMP; ++c) cp[e][c] = (in && c < n_comp) ? comp[(int64_t)c * B + b] : 0.0;
         }
-        int cv[4];
+        int cv[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) cv[e] = gi[e] >= 0 ? row[gi[e]] : 0;
+        for (int e = 0; e < 8; ++e) cv[e] = gi[e] >= 0 ? row[gi[e]] : 0;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 8; ++e) {
             if (gi[e] < 0) continue;
             const double xb = (double)cv[e] / total;
             const double d = xb - mn[e];
@@ -853,13 +853,14 @@ __global__ __launch_bounds__(256) void k_zscore_big(const unsigned int *__restri
 // testCopy[abs(z) >= threshold] = -1 (wisetools.py:446).  A NEW flag on (bin g, sample i)
 // queues every bin that uses g as a reference, for the same sample, for the next repeat: the
 // wave expands its new flags one after the other, 64 users per trip.
-__device__ inline void flag_wave(const int64_t gid, const bool valid, const double *__restrict__ zT, double thr,
-                                 int64_t Ns, double *__restrict__ XC, const int *__restrict__ users_off,
-                                 const int *__restrict__ users, unsigned int *__restrict__ dirty,
-                                 unsigned int *__restrict__ next_pairs, int *__restrict__ next_count) {
+// (zv, xcv: this lane's z-score and working value, already loaded)
+__device__ inline void flag_wave_vals(const int64_t gid, const bool valid, const double zv, const double xcv, double thr,
+                                      int64_t Ns, double *__restrict__ XC, const int *__restrict__ users_off,
+                                      const int *__restrict__ users, unsigned int *__restrict__ dirty,
+                                      unsigned int *__restrict__ next_pairs, int *__restrict__ next_count) {
     const int lane = threadIdx.x & 63;
     bool hit = false;
-    if (valid && fabs(zT[gid]) >= thr && XC[gid] != -1.0) {
+    if (valid && fabs(zv) >= thr && xcv != -1.0) {
         XC[gid] = -1.0;
         hit = next_pairs != nullptr;      // last repeat: nothing follows
     }
@@ -888,6 +889,14 @@ __device__ inline void flag_wave(const int64_t gid, const bool valid, const doub
             }
         }
     }
+}
+
+__device__ inline void flag_wave(const int64_t gid, const bool valid, const double *__restrict__ zT, double thr,
+                                 int64_t Ns, double *__restrict__ XC, const int *__restrict__ users_off,
+                                 const int *__restrict__ users, unsigned int *__restrict__ dirty,
+                                 unsigned int *__restrict__ next_pairs, int *__restrict__ next_count) {
+    flag_wave_vals(gid, valid, valid ? zT[gid] : 0.0, valid ? XC[gid] : -1.0, thr, Ns, XC, users_off, users, dirty,
+                   next_pairs, next_count);
 }
 
 __global__ __launch_bounds__(256) void k_flag(const double *__restrict__ zT, double thr, int64_t n, int64_t Ns,
@@ -930,8 +939,29 @@ __global__ __launch_bounds__(1024) void k_lat_repeats(unsigned int *__restrict__
                                                       int64_t Ns, double thr, const int *__restrict__ users_off,
                                                       const int *__restrict__ users, double *__restrict__ zT,
                                                       double *__restrict__ rT, double *__restrict__ nT,
-                                                      double *__restrict__ sdT, int *__restrict__ overflow) {
+                                                      double *__restrict__ sdT, int *__restrict__ overflow,
+                                                      int first_n) {
     const int tid = threadIdx.x, lane = tid & 63, sub = lane & 7, gbase = lane & ~7;
+    if (first_n > 0) {
+        // the flag pass of the first repeat (k_flag's job) for up to 16 384 pairs: the z-scores and working
+        // values of all of a thread's pairs are requested together, one memory round trip
+        constexpr int FT = 16;
+        double zv[FT], xv[FT];
+#pragma unroll
+        for (int e = 0; e < FT; ++e) {
+            const int t = e * 1024 + tid;
+            zv[e] = t < first_n ? zT[t] : 0.0;
+            xv[e] = t < first_n ? XC[t] : -1.0;
+        }
+#pragma unroll
+        for (int e = 0; e < FT; ++e) {
+            const int t = e * 1024 + tid;
+            if (e * 1024 < first_n)
+                flag_wave_vals(t, t < first_n, zv[e], xv[e], thr, Ns, XC, users_off, users, dirty, pairs_a, pair_counts + 1);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
     for (int it = 1; it < repeats; ++it) {
         unsigned int *cur = (it & 1) ? pairs_a : pairs_b;
         unsigned int *next = it + 1 < repeats ? ((it & 1) ? pairs_b : pairs_a) : nullptr;
@@ -3027,13 +3057,16 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
         WC_HIP(hipMemsetAsync(ts.sdt.p, 0xFF, sizeof(double) * n, stream));
     }
     const int *uoff = ref->users_off.as<int>(), *ulst = ref->users.as<int>();
+    // latency mode, a sample or two: the first repeat's flag pass runs at the head of k_lat_repeats
+    const bool lat_flag_inside = lat && repeats > 1 && ref->k <= 128 && n <= 16384;
     for (int it = 0; it < repeats; ++it) {
         if (lat && it == 1) {
             hipLaunchKernelGGL(k_lat_repeats, dim3(1), dim3(1024), 0, stream, ts.pairs_a.as<unsigned int>(),
                                ts.pairs_b.as<unsigned int>(), pair_counts, repeats, dirty,
                                (const double *)ts.xt.as<double>(), ts.xc.as<double>(), (const int *)ref->gidx.as<int>(),
                                (const int *)ref->nref.as<int>(), ref->k, Ns, thr, uoff, ulst, ts.zt.as<double>(),
-                               ts.rt.as<double>(), ts.nt.as<double>(), ts.sdt.as<double>(), pair_counts + repeats + 1);
+                               ts.rt.as<double>(), ts.nt.as<double>(), ts.sdt.as<double>(), pair_counts + repeats + 1,
+                               lat_flag_inside ? (int)n : 0);
             break;
         }
         // repeat `it` recomputes the pairs queued in its list (all pairs in the first repeat) and
@@ -3073,8 +3106,9 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
                                    (const int *)ref->gidx.as<int>(), (const int *)ref->nref.as<int>(), ref->k, Ns,
                                    ts.zt.as<double>(), ts.rt.as<double>(), ts.nt.as<double>(), ts.sdt.as<double>());
             }
-            hipLaunchKernelGGL(k_flag, dim3(g), dim3(256), 0, stream, (const double *)ts.zt.as<double>(), thr, n, Ns,
-                               ts.xc.as<double>(), uoff, ulst, dirty, next, pair_counts + it + 1);
+            if (!lat_flag_inside)
+                hipLaunchKernelGGL(k_flag, dim3(g), dim3(256), 0, stream, (const double *)ts.zt.as<double>(), thr, n, Ns,
+                                   ts.xc.as<double>(), uoff, ulst, dirty, next, pair_counts + it + 1);
         } else {
             const unsigned gp = (unsigned)std::min<int64_t>(g, 2048);
             hipLaunchKernelGGL(k_zscore_pairs, dim3(gp), dim3(256), 0, stream, (const unsigned int *)cur,
