@@ -90,3 +90,24 @@ def test_prep_gram_on_the_matrix_cores(n_s, n_total):
     want = xc @ xc.T
     assert np.array_equal(gram, gram.T)
     assert np.allclose(gram, want, rtol=1e-11, atol=1e-12 * np.abs(want).max())
+
+
+def test_prep_between_two_test_calls_leaves_the_test_path_intact(golden):
+    """prep borrows workspaces of the context's test path (among them the buffer that caches the
+    chromosome selection on the device): a `test` call after a prep must not see stale contents."""
+    from wisecondor_amd import wisetools as wt
+    g = golden("cfg1_pipeline.npz")
+    offs = np.concatenate([[0], np.cumsum(g["sample_chrom_lengths"])])
+    samples = [{k: row[offs[i]:offs[i + 1]] for i, k in enumerate(KEYS)} for row in g["ref_samples"]]
+    reference = wt.Reference(g["ref_indexes"], g["ref_distances"], g["ref_chromosome_sizes"], g["ref_masked_sizes"],
+                             g["ref_mask"], g["ref_pca_mean"], g["ref_pca_components"], binsize=float(g["ref_binsize"]))
+    try:
+        before = wt.test_batch(reference, samples[:3], 5.0)
+        wt.prepReference(samples)
+        after = wt.test_batch(reference, samples[:3], 5.0)
+    finally:
+        reference.close()
+    for a, b in zip(before, after):
+        assert np.array_equal(np.asarray(a["results_calls"]), np.asarray(b["results_calls"]))
+        assert np.array_equal(np.concatenate(a["results_z"]), np.concatenate(b["results_z"]), equal_nan=True)
+        assert np.array_equal(a["results_cwz"], b["results_cwz"], equal_nan=True)

@@ -340,6 +340,7 @@ int wc_newref_prep_gram(wc_ctx *ctx, const int32_t *counts, int64_t n_samples, i
     if ((rc = ts.z.reserve(sizeof(double) * (S * S + 8 * S + 8 * B + B)))) return rc;
     if ((rc = ts.proj.reserve(sizeof(double) * 8 * S))) return rc;
     double *G = ts.z.as<double>(), *mean = G + S * S + 8 * S + 8 * B;
+    ts.sel_host.clear();      // the test path caches its chromosome selection in this buffer: not valid any more
     WC_HIP(hipMemcpy(ts.sel.p, m2g.data(), sizeof(int) * B, hipMemcpyHostToDevice));
     dim3 gb((unsigned)cdiv(B, 256), (unsigned)S);
     hipLaunchKernelGGL(k_prep_normalize, gb, dim3(256), 0, nullptr, (const int *)ts.counts.as<int>(), S, Btot,
