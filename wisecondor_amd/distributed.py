@@ -209,17 +209,25 @@ class NewrefJob(object):
         marks, self._marks = self._marks, None           # the caller's timing marks are not for these passes
         for mode in ("tiles", "rows"):
             self.mode = mode
-            self._run()                                  # buffers, tile lists, communicator warm-up
-            self._sync()
-            self.dist.barrier()
-            t0 = time.perf_counter()
-            self._run()
-            self._sync()
-            times[mode] = self._max_over_ranks(time.perf_counter() - t0)
+            try:
+                self._run()                              # buffers, tile lists, communicator warm-up
+                self._sync()
+                self.dist.barrier()
+                t0 = time.perf_counter()
+                self._run()
+                self._sync()
+                times[mode] = self._max_over_ranks(time.perf_counter() - t0)
+            except Exception as exc:                     # pragma: no cover - needs a backend without the collective
+                # an exchange collective this backend does not offer fails on every rank alike (argument
+                # checks happen before any communication): the row bands need the all-gather only
+                if mode == "rows":
+                    raise
+                times[mode] = None
+                times["tiles_error"] = "%s: %s" % (type(exc).__name__, exc)
         self.mode = None
         self._marks = marks
         self.calibration = times
-        return "rows" if times["rows"] < times["tiles"] else "tiles"
+        return "rows" if times["tiles"] is None or times["rows"] < times["tiles"] else "tiles"
 
     def _sync(self):
         if getattr(self.st, "device", None) is not None and self.st.device.type == "cuda":
