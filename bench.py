@@ -502,7 +502,7 @@ def main():
                                              "peak": PEAK_HBM / 1e9, "unit": "GB/s",
                                              "frac": xr_bytes / (xr_ms * 1e-3) / PEAK_HBM,
                                              "algorithmic_bytes_per_launch": xr_bytes,
-                                             "note": "L2 hit rate 15 %, TCC_EA0_RDREQ 194 M x 128 B = 24.8 GB per launch "
+                                             "note": "L2 hit rate 15 %%, TCC_EA0_RDREQ 194 M x 128 B = 24.8 GB per launch "
                                                      "(profiles/%s_pmc_busy.json, r2T_cfg4 / r2D_cfg4)" % ROUND}
             if os.environ.get("WC_GRAM_MODE", "") != "f32":
                 extra["k_gram_executed_tflops"] = SPLIT_PRODUCTS * xflops / (xk_ms * 1e-3) / 1e12
