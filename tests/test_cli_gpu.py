@@ -204,3 +204,31 @@ def test_bench_two_ranks_on_one_gpu():
     assert line["config"]["shard_mode"] in ("tiles", "rows")
     assert set(line["config"]["shard_calibration_s"]) == {"tiles", "rows"}
     assert line["value"] > 0 and line["test"]["value"] > 0
+
+
+def test_bench_line_is_complete_on_one_gpu():
+    """The default bench command in a short form (cfg2, the 600 x 50 kb extra, no CPU leg): one JSON line
+    with every object the measurement contract names, every fraction at most 1, no swallowed error."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--test-samples", "32",
+                        "--no-cpu-baseline"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 4 and line["warmup"] == 1
+    assert line["metric"] == "newref bin-pair distances/sec" and line["value"] > 1e10
+    for roof in (line["roofline"], line["roofline_other"]):
+        assert roof["bound"] in ("hbm", "mfma", "l2") and 0 < roof["frac"] <= 1.0, roof
+        assert roof["achieved"] > 0 and roof["peak"] > 0 and roof["kernel_ms"] > 0
+    extra = line["extra"]
+    assert "error" not in extra, extra
+    assert extra["ms_per_step"] > 0 and 0 < extra["k_gram_frac_of_bf16_mfma_peak"] <= 1.0
+    assert 0 < extra["rescore_roofline"]["frac"] <= 1.05            # runs at the HBM roof on uncorrelated rows
+    test = line["test"]
+    assert test["value"] > 0 and 0 < test["roofline"]["frac"] <= 1.0
+    assert test["single_sample_latency_ms"] < test["ms_per_batch"]
+    assert set(line["stages_ms"]) >= {"start->prepared", "prepared->thresholds", "thresholds->collected",
+                                      "collected->rescored", "rescored->finished"}
