@@ -1087,21 +1087,35 @@ __device__ inline int sd_exponent(double v) {          // unbiased exponent of a
 // REG > 0: at most REG terms per thread, fetched ONCE into registers by a fully unrolled loop (one
 // memory round trip instead of one per term and walk: 26 -> 8 us at 11 087 bins); REG == 0: any
 // count up to PER_MAX, re-read in each walk.
+struct SdShared {
+    double sh_p[1024];                    // scan of the threads' approximate sums
+    long long sh_A[1024];
+    int sh_H0[1024], sh_H1[1024], sh_flag[1024], sh_nb[1024], sh_cnt[1024];
+    long long b_A[SD_MAX_BOUND + 1];      // map of the segment that ENDS before boundary k (k = n: the tail)
+    int b_H0[SD_MAX_BOUND + 1], b_H1[SD_MAX_BOUND + 1], b_e[SD_MAX_BOUND + 1];
+    double b_x[SD_MAX_BOUND + 1];
+    int s_bad;
+    double sh_wp[16];
+    int sh_wc[16];
+    long long sh_wA[16];
+    int sh_wH0[16], sh_wH1[16], sh_wf[16], sh_wn[16];
+};
 template <int REG>
-__device__ inline void sd_fast_block(const int64_t i, const double *__restrict__ sdT, int64_t B, int64_t Ns,
+__device__ inline void sd_fast_block(const int64_t i, SdShared *sm, const double *__restrict__ sdT, int64_t B, int64_t Ns,
                                      double *__restrict__ out, int *__restrict__ fail, double *__restrict__ out2) {
     constexpr int PER_MAX = 64;                      // elements per thread (B <= 65536)
-    __shared__ double sh_p[1024];                    // scan of the threads' approximate sums
-    __shared__ long long sh_A[1024];
-    __shared__ int sh_H0[1024], sh_H1[1024], sh_flag[1024], sh_nb[1024], sh_cnt[1024];
-    __shared__ long long b_A[SD_MAX_BOUND + 1];      // map of the segment that ENDS before boundary k (k = n: the tail)
-    __shared__ int b_H0[SD_MAX_BOUND + 1], b_H1[SD_MAX_BOUND + 1], b_e[SD_MAX_BOUND + 1];
-    __shared__ double b_x[SD_MAX_BOUND + 1];
-    __shared__ int s_bad;
-    __shared__ double sh_wp[16];
-    __shared__ int sh_wc[16];
-    __shared__ long long sh_wA[16];
-    __shared__ int sh_wH0[16], sh_wH1[16], sh_wf[16], sh_wn[16];
+    // the workgroup's scratch (caller-provided LDS: static in k_sd_fast, the dynamic region in k_seg_tree)
+    double *sh_p = sm->sh_p;
+    long long *sh_A = sm->sh_A;
+    int *sh_H0 = sm->sh_H0, *sh_H1 = sm->sh_H1, *sh_flag = sm->sh_flag, *sh_nb = sm->sh_nb, *sh_cnt = sm->sh_cnt;
+    long long *b_A = sm->b_A;
+    int *b_H0 = sm->b_H0, *b_H1 = sm->b_H1, *b_e = sm->b_e;
+    double *b_x = sm->b_x;
+    int &s_bad = sm->s_bad;
+    double *sh_wp = sm->sh_wp;
+    int *sh_wc = sm->sh_wc;
+    long long *sh_wA = sm->sh_wA;
+    int *sh_wH0 = sm->sh_wH0, *sh_wH1 = sm->sh_wH1, *sh_wf = sm->sh_wf, *sh_wn = sm->sh_wn;
     const int tid = threadIdx.x;
     const int per = (int)((B + 1023) / 1024);
     if (per > PER_MAX) { if (tid == 0) fail[i] = 1; return; }
@@ -1311,7 +1325,8 @@ template <int REG>
 __global__ __launch_bounds__(1024) void k_sd_fast(const double *__restrict__ sdT, int64_t B, int64_t Ns,
                                                   double *__restrict__ out, int *__restrict__ fail,
                                                   double *__restrict__ out2) {
-    sd_fast_block<REG>(blockIdx.x, sdT, B, Ns, out, fail, out2);
+    __shared__ SdShared sm;
+    sd_fast_block<REG>(blockIdx.x, &sm, sdT, B, Ns, out, fail, out2);
 }
 
 // what the latency mode appends to another kernel's grid (k_seg_tree): `blocks` workgroups, one per sample
@@ -2901,10 +2916,12 @@ __global__ __launch_bounds__(1024) void k_seg_tree(int *__restrict__ counters, c
                                                    InflateRider inf, AssembleRider as) {
     const int blk = (int)blockIdx.x;
     if (blk < sd.blocks) {
+        extern __shared__ double pl[];                 // the launch's dynamic LDS: at least sizeof(SdShared) with a rider
+        SdShared *sm = reinterpret_cast<SdShared *>(pl);
         const int64_t per = (sd.B + 1023) / 1024;
-        if (per <= 12) sd_fast_block<12>(blk, sd.sdT, sd.B, sd.Ns, sd.out, sd.fail, sd.out2);
-        else if (per <= 24) sd_fast_block<24>(blk, sd.sdT, sd.B, sd.Ns, sd.out, sd.fail, sd.out2);
-        else sd_fast_block<0>(blk, sd.sdT, sd.B, sd.Ns, sd.out, sd.fail, sd.out2);
+        if (per <= 12) sd_fast_block<12>(blk, sm, sd.sdT, sd.B, sd.Ns, sd.out, sd.fail, sd.out2);
+        else if (per <= 24) sd_fast_block<24>(blk, sm, sd.sdT, sd.B, sd.Ns, sd.out, sd.fail, sd.out2);
+        else sd_fast_block<0>(blk, sm, sd.sdT, sd.B, sd.Ns, sd.out, sd.fail, sd.out2);
     } else if (blk < sd.blocks + inf.blocks) {
         const int64_t n = inf.Btot * inf.Ns;
         for (int64_t t = (int64_t)(blk - sd.blocks) * 1024 + threadIdx.x; t < n; t += (int64_t)inf.blocks * 1024) {
@@ -3422,7 +3439,8 @@ int run_seg_lat(wc_ctx *ctx, const wc_reference *ref, const double *zsrc, const 
     }
     as.reg_calls = ts.effect.as<double>();
     as.sd_fail = ts.sd_fail.as<int>();
-    hipLaunchKernelGGL(k_seg_tree, dim3((unsigned)(n_regions + rider.blocks + inf.blocks)), dim3(1024), sizeof(double) * (2 * max_n + 2), stream, counters,
+    const size_t tree_lds = std::max<size_t>(sizeof(double) * (2 * max_n + 2), rider.blocks ? sizeof(SdShared) : 0);
+    hipLaunchKernelGGL(k_seg_tree, dim3((unsigned)(n_regions + rider.blocks + inf.blocks)), dim3(1024), tree_lds, stream, counters,
                        (const Region *)ts.regions.as<Region>(), n_regions, (const int *)ts.reg_flag.as<int>(),
                        (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
                        (const double *)ts.reg_abs.as<double>(), (const double *)ts.zc.as<double>(),
