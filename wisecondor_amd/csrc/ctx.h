@@ -59,6 +59,7 @@ struct TestState {
     std::vector<hipEvent_t> prof_ev;    // event pool, grown on demand
     std::vector<int> prof_tag;          // tag of every mark of the last batch, in record order
     wc::DevBuf sd_fail;                 // per-sample flags of k_sd_fast (1: the serial kernel takes the sample)
+    bool tree_done = false;             // run_stouffer: the tree kernel finished the recursion and wrote the call rows
     bool lat_ride = false;              // latency mode: stdDevAvg rides in k_seg_tree's grid (run_repeat -> run_seg_lat)
     double *lat_ride_out2 = nullptr;
     wc::DevBuf prof_work;               // u64[2]: windows evaluated by k_seg_search, evaluations by k_seg_quiet

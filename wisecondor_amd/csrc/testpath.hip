@@ -2913,7 +2913,8 @@ __global__ __launch_bounds__(1024) void k_seg_tree(int *__restrict__ counters, c
                                                    double *__restrict__ reg_calls, int *__restrict__ out_n,
                                                    const Extreme *__restrict__ partial,
                                                    const double2 *__restrict__ sub, int max_chunks, SdRider sd,
-                                                   InflateRider inf, AssembleRider as) {
+                                                   InflateRider inf, AssembleRider as,
+                                                   const int *__restrict__ hot_list, const int *__restrict__ hot_count) {
     const int blk = (int)blockIdx.x;
     if (blk < sd.blocks) {
         extern __shared__ double pl[];                 // the launch's dynamic LDS: at least sizeof(SdShared) with a rider
@@ -2936,7 +2937,11 @@ __global__ __launch_bounds__(1024) void k_seg_tree(int *__restrict__ counters, c
             if (inf.res_r) inf.res_r[t] = rv;
         }
     } else {
-        seg_tree_region(blk - sd.blocks - inf.blocks, counters, regions, n_regions, reg_flag, prefix, rs, reg_abs, z, ratio,
+        // the general path's first round hands over its hot jobs (job index == region index there):
+        // workgroup h walks region hot_list[h]; the grid is an upper bound, surplus workgroups leave
+        int region = blk - sd.blocks - inf.blocks;
+        if (hot_list) region = region < *hot_count ? hot_list[region] : (int)n_regions;
+        seg_tree_region(region, counters, regions, n_regions, reg_flag, prefix, rs, reg_abs, z, ratio,
                         gpos, thr, min_search, max_calls, reg_calls, out_n, partial, sub, max_chunks);
     }
     if (!as.on) return;
@@ -3202,13 +3207,25 @@ int join_side(wc_ctx *ctx, hipStream_t stream) {
 // and the kernels read the real job / segment counts on the device; *lat_incomplete (pinned, valid
 // after the stream has been synchronised) tells whether jobs were left over or a bound was
 // exceeded, in which case the caller runs the call again with the host-driven loop.
+// `tail` (optional; the batched `test` call): where call rows go.  When the regions fit the tree kernel
+// (<= TREE_MAXLEN bins, no -mineffectsize mask) the first round's hot regions are walked to the end by
+// k_seg_tree, one workgroup per region -- collect, decide, every child range, the order of the
+// segments and the call rows -- instead of one host-driven round per recursion level: rounds two and
+// later are a handful of short ranges each and cost a launch series and a count read-back apiece.
+// ts.tree_done tells the caller that ts.effect / ts.out_n already hold the calls.
+struct TreeTail {
+    const double *ratio;     // cleaned ratios, as z_dev
+    const int *gpos;         // genomic position of every kept bin
+    double *reg_calls;       // [n_regions, max_calls, 5]
+};
 int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, int64_t n_regions, int64_t total_len,
                  int64_t max_n, double thr, int min_search, int max_calls, hipStream_t stream,
                  const double *ratio_dev = nullptr, double min_effect = 0.0, int64_t bits_upper = 0,
-                 int lat_rounds = 0, double *whole_copy = nullptr) {
+                 int lat_rounds = 0, double *whole_copy = nullptr, const TreeTail *tail = nullptr) {
     TestState &ts = ctx->ts;
     int rc;
     ts.last_segs = 0;
+    ts.tree_done = false;
     if (n_regions == 0) return WC_OK;
     const int64_t job_cap = n_regions + total_len / 4 + 64;
     const int64_t seg_cap = n_regions * (int64_t)max_calls + 64;
@@ -3336,6 +3353,31 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
             WC_HIP(hipStreamSynchronize(stream));
             n_hot = h[2];
         }
+        const char *tree_env = getenv("WC_TEST_TREE_TAIL");        // "0": host-driven rounds only
+        if (guard == 1 && tail && !bits && max_n <= TREE_MAXLEN && n_hot > 0 && !(tree_env && tree_env[0] == '0')) {
+            SdRider no_sd{};
+            InflateRider no_inf{};
+            AssembleRider no_as{};
+            hipLaunchKernelGGL(k_seg_tree, dim3((unsigned)n_hot), dim3(1024), sizeof(double) * (2 * max_n + 2), stream,
+                               counters, regions_dev, n_regions, (const int *)ts.reg_flag.as<int>(),
+                               (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
+                               (const double *)ts.reg_abs.as<double>(), z_dev, tail->ratio, tail->gpos, thr, min_search,
+                               max_calls, tail->reg_calls, ts.out_n.as<int>(), (const Extreme *)ts.partial.as<Extreme>(),
+                               (const double2 *)ts.sub.as<double2>(), max_chunks, no_sd, no_inf, no_as,
+                               (const int *)hot, (const int *)(counters + 2));
+            WC_HIP(hipMemcpyAsync(h, counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
+            WC_HIP(hipStreamSynchronize(stream));
+            if (h[3] == 0 && h[6] == 0) {          // no job for the exact scan, nothing the tree kernel gave up on
+                WC_CHECK(h[4] <= seg_cap, WC_E_LIMIT, "stouffer: more than max_calls=%d segments per region", max_calls);
+                ts.tree_done = true;
+                WC_HIP(hipGetLastError());
+                return WC_OK;
+            }
+            // rare: start the round's second half again on the host-driven path
+            WC_HIP(hipMemsetAsync(ts.out_n.p, 0, sizeof(int) * n_regions, stream));
+            WC_HIP(hipMemsetAsync(counters + 4, 0, sizeof(int), stream));
+            WC_HIP(hipMemsetAsync(counters + 6, 0, sizeof(int), stream));
+        }
         if (n_hot > 0) {
             // only a few blocks survive the pruning; sixteen waves each keep their scan short
             hipLaunchKernelGGL(k_seg_collect, dim3((unsigned)max_chunks, (unsigned)n_hot), dim3(1024), 0, stream,
@@ -3446,7 +3488,8 @@ int run_seg_lat(wc_ctx *ctx, const wc_reference *ref, const double *zsrc, const 
                        (const double *)ts.reg_abs.as<double>(), (const double *)ts.zc.as<double>(),
                        (const double *)ts.rc.as<double>(), (const int *)ts.gpos.as<int>(), thr, 3, max_calls,
                        ts.effect.as<double>(), ts.out_n.as<int>(), (const Extreme *)ts.partial.as<Extreme>(),
-                       (const double2 *)ts.sub.as<double2>(), max_chunks, rider, inf, as);
+                       (const double2 *)ts.sub.as<double2>(), max_chunks, rider, inf, as, (const int *)nullptr,
+                       (const int *)nullptr);
     ts.last_segs = 0;                     // the calls are already in ts.effect / ts.out_n
     WC_HIP(hipGetLastError());
     return WC_OK;
@@ -3889,8 +3932,10 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
                 bits_upper += Ns * (n * (n + 1) / 2);
             }
         ts.mark(3, stream);
+        const TreeTail tail{ts.rc.as<double>(), ts.gpos.as<int>(), ts.effect.as<double>()};
         if ((rc = run_stouffer(ctx, ts.zc.as<double>(), ts.regions.as<Region>(), n_regions, Ns * B, max_n, threshold, 3,
-                               max_calls, stream, ts.rc.as<double>(), min_effect, bits_upper, 0, nullptr)))
+                               max_calls, stream, ts.rc.as<double>(), min_effect, bits_upper, 0, nullptr,
+                               calls && n_calls ? &tail : nullptr)))
             return rc;
     }
     ts.mark(4, stream);
