@@ -103,3 +103,43 @@ def test_latency_mode_gives_up_cleanly(wt):
         _same(_run(wt, reference, samples, "2", minrefbins=5, repeats=2), general)
     finally:
         reference.close()
+
+
+def _run_tail(wt, reference, samples, tail, **kw):
+    old = os.environ.get("WC_TEST_TREE_TAIL")
+    try:
+        if tail is None:
+            os.environ.pop("WC_TEST_TREE_TAIL", None)
+        else:
+            os.environ["WC_TEST_TREE_TAIL"] = tail
+        return wt.test_batch(reference, samples, 4.5, **kw)
+    finally:
+        if old is None:
+            os.environ.pop("WC_TEST_TREE_TAIL", None)
+        else:
+            os.environ["WC_TEST_TREE_TAIL"] = old
+
+
+def test_batch_tree_tail_equals_host_rounds(wt):
+    """Batches (more than eight samples): after the first segmentation round the hot regions are finished
+    by the tree kernel; the host-driven rounds (WC_TEST_TREE_TAIL=0) must give the same calls -- also
+    when one sample makes the tree kernel give up (more than 128 segments in a region) and the round is
+    started again on the host-driven path."""
+    sizes = [1500, 2, 40, 700, 64, 65, 129, 5] + [30] * 14
+    reference, rng, sizes, offs, total = _genome(wt, 321, sizes)
+    try:
+        samples = []
+        for i in range(12):
+            events = [(0, 100 + 31 * i, 300 + 31 * i, 1.25), (0, 900, 930, 0.6), (3, 40 * (i % 6), 40 * (i % 6) + 80, 0.8),
+                      (6, 10, 20, 1.5)]
+            samples.append(_sample(rng, sizes, offs, total, events))
+        host = _run_tail(wt, reference, samples, "0", minrefbins=10, repeats=3)
+        assert sum(len(o["results_calls"]) for o in host) >= 36
+        _same(_run_tail(wt, reference, samples, None, minrefbins=10, repeats=3), host)
+        busy = [(0, a, a + 3, 1.5 if (a // 8) % 2 else 0.5) for a in range(8, 1480, 8)]
+        samples[5] = _sample(rng, sizes, offs, total, busy)
+        host = _run_tail(wt, reference, samples, "0", minrefbins=5, repeats=2)
+        assert len(host[5]["results_calls"]) > 128
+        _same(_run_tail(wt, reference, samples, None, minrefbins=5, repeats=2), host)
+    finally:
+        reference.close()
