@@ -145,15 +145,16 @@ __global__ __launch_bounds__(256) void k_prep_syrk(const double *__restrict__ xc
 // G[s, t] = G[t, s] = sum over the slices, in slice order, of the partial tile entries
 __global__ __launch_bounds__(256) void k_prep_gram_reduce(const double *__restrict__ partial, const int2 *__restrict__ tiles,
                                                           int n_tiles, int n_slices, int64_t S, double *__restrict__ G) {
+    // grid (tiles, 16): one entry per thread -- the slice loop is a chain of adds, the parallelism has to
+    // come from the entries
     const int2 tile = tiles[blockIdx.x];
-    for (int e = threadIdx.x; e < SY_T * SY_T; e += 256) {
-        const int64_t s = (int64_t)tile.x * SY_T + (e >> 6), t = (int64_t)tile.y * SY_T + (e & 63);
-        if (s >= S || t >= S || t > s) continue;
-        double sum = 0.0;
-        for (int q = 0; q < n_slices; ++q) sum = sum + partial[((int64_t)q * n_tiles + blockIdx.x) * (SY_T * SY_T) + e];
-        G[s * S + t] = sum;
-        G[t * S + s] = sum;
-    }
+    const int e = (int)blockIdx.y * 256 + (int)threadIdx.x;
+    const int64_t s = (int64_t)tile.x * SY_T + (e >> 6), t = (int64_t)tile.y * SY_T + (e & 63);
+    if (s >= S || t >= S || t > s) return;
+    double sum = 0.0;
+    for (int q = 0; q < n_slices; ++q) sum = sum + partial[((int64_t)q * n_tiles + blockIdx.x) * (SY_T * SY_T) + e];
+    G[s * S + t] = sum;
+    G[t * S + s] = sum;
 }
 
 // components[c, b] = sum_s w[c, s] * xc[s, b]   (w = eigenvector / singular value)
@@ -366,7 +367,7 @@ int wc_newref_prep_gram(wc_ctx *ctx, const int32_t *counts, int64_t n_samples, i
         hipLaunchKernelGGL(k_prep_syrk, dim3((unsigned)n_tiles, (unsigned)n_slices), dim3(256), 0, nullptr,
                            (const double *)ts.xt.as<double>(), S, B, (const int2 *)ts.misc.as<int2>(), per,
                            ts.zt.as<double>());
-        hipLaunchKernelGGL(k_prep_gram_reduce, dim3((unsigned)n_tiles), dim3(256), 0, nullptr,
+        hipLaunchKernelGGL(k_prep_gram_reduce, dim3((unsigned)n_tiles, SY_T * SY_T / 256), dim3(256), 0, nullptr,
                            (const double *)ts.zt.as<double>(), (const int2 *)ts.misc.as<int2>(), n_tiles,
                            (int)n_slices, S, G);
     }
