@@ -1084,6 +1084,25 @@ __device__ inline SdMap sd_compose(const SdMap &f, const SdMap &g) {     // f fi
 __device__ inline int sd_exponent(double v) {          // unbiased exponent of a positive normal double
     return (int)((__double_as_longlong(v) >> 52) & 0x7FF) - 1023;
 }
+// The map of adding x > 0 to a sum that stays in the binade of unbiased exponent eb (so x < 2^eb): with
+// u = 2^(eb - 52) the sum's unit, x / u = q + r, q integer; round to nearest adds q (+ 1 when r > 1/2),
+// and a tie (r = 1/2) goes to the even neighbour, which depends on the sum's parity.  All in integer
+// arithmetic on x's significand: x = mant * 2^(E - 1075), x / u = mant / 2^s with s = (eb + 1023) - E >= 1.
+__device__ inline SdMap sd_element_map(double xv, int eb) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(xv);
+    const int ex = (int)(bits >> 52) & 0x7FF;
+    const unsigned long long mant = (bits & 0xFFFFFFFFFFFFFull) | (ex ? 0x10000000000000ull : 0ull);
+    const int s = (eb + 1023) - (ex ? ex : 1);
+    SdMap m;
+    m.A = 0; m.H0 = 0; m.H1 = 0;
+    if (s >= 1 && s <= 53) {                             // s > 53: x < u / 2, the sum does not move (s < 1 cannot happen: x < 2^eb)
+        const unsigned long long q = mant >> s, rem = mant & ((1ull << s) - 1ull), half = 1ull << (s - 1);
+        m.A = (long long)q;
+        if (rem > half) m.A += 1;
+        else if (rem == half) { m.H0 = (int)(q & 1ull); m.H1 = (int)((q + 1ull) & 1ull); }
+    }
+    return m;
+}
 // REG > 0: at most REG terms per thread, fetched ONCE into registers by a fully unrolled loop (one
 // memory round trip instead of one per term and walk: 26 -> 8 us at 11 087 bins); REG == 0: any
 // count up to PER_MAX, re-read in each walk.
@@ -1187,16 +1206,7 @@ __device__ inline void sd_fast_block(const int64_t i, SdShared *sm, const double
                 const int eb = sd_exponent(before), ea = sd_exponent(after);
                 if (eb != ea) boundary = true;
                 else if (eb < -900 || eb > 50) bad = true;     // denormal / enormous sums: not worth the care
-                else {
-                    const double f = ldexp(xv, 52 - eb);        // x / u, exact
-                    const double qf = floor(f);
-                    const double r = f - qf;
-                    SdMap m;
-                    m.A = (long long)qf; m.H0 = 0; m.H1 = 0;
-                    if (r > 0.5) m.A += 1;
-                    else if (r == 0.5) { m.H0 = (int)(m.A & 1); m.H1 = (int)((m.A + 1) & 1); }
-                    run = sd_compose(run, m);
-                }
+                else run = sd_compose(run, sd_element_map(xv, eb));
             }
         }
         if (boundary) {
@@ -1266,16 +1276,7 @@ __device__ inline void sd_fast_block(const int64_t i, SdShared *sm, const double
                 else {
                     const int eb = sd_exponent(bef), ea = sd_exponent(after);
                     if (eb != ea) boundary = true;
-                    else if (!(eb < -900 || eb > 50)) {
-                        const double f = ldexp(xv, 52 - eb);
-                        const double qf = floor(f);
-                        const double r = f - qf;
-                        SdMap m;
-                        m.A = (long long)qf; m.H0 = 0; m.H1 = 0;
-                        if (r > 0.5) m.A += 1;
-                        else if (r == 0.5) { m.H0 = (int)(m.A & 1); m.H1 = (int)((m.A + 1) & 1); }
-                        seg = sd_compose(seg, m);
-                    }
+                    else if (!(eb < -900 || eb > 50)) seg = sd_compose(seg, sd_element_map(xv, eb));
                 }
             }
             if (boundary) {
