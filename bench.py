@@ -523,6 +523,38 @@ def main():
             # the main job's context state was replaced by the extra run; nothing below needs it
         except Exception as exc:      # the headline line must still be printed
             extra = {"workload": "cfg4", "error": "%s: %s" % (type(exc).__name__, exc)}
+        # BASELINE.json config 5, one GPU's share: batched test of 125 samples at 50 kb bins (reference from
+        # 100 samples through the GPU prep + newref, untimed)
+        try:
+            inp5 = build_inputs(50000, 100, 125, seed0=500, device=local_rank)
+            bins5 = np.ascontiguousarray(inp5["masked_bins"])
+            X5 = torch.from_numpy(np.ascontiguousarray(inp5["corrected"])).to(dev)
+            job5 = distributed.NewrefJob(ctx, X5, bins5, k, wt.sum_order_of(inp5["corrected"]))
+            idx5, dst5 = job5.run()
+            torch.cuda.synchronize()
+            ref5 = wt.Reference(idx5.cpu().numpy(), dst5.cpu().numpy(), inp5["chrom_bins"], inp5["masked_bins"],
+                                inp5["mask"], inp5["pca_mean"], inp5["pca_components"], binsize=50000, device=local_rank)
+            thr5 = float(zThreshold([int(v) for v in inp5["masked_bins"]], 1000, None))
+            tb5 = distributed.TestBatch(ref5, torch.from_numpy(wt.samples_to_counts(inp5["tests"], inp5["chrom_bins"])).to(dev),
+                                        thr5, max_calls=256)
+            for _ in range(2):
+                tb5.run()
+            sync_all()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                tb5.run()
+            sync_all()
+            t5 = max_over_ranks(time.perf_counter() - t0) / 5
+            extra = dict(extra or {})
+            extra["test_50kb"] = {"workload": "cfg5, one GPU's share: batched test of 125 samples x 50 kb bins (%d masked bins)"
+                                              % int(bins5.sum()),
+                                  "value": world * 125 / t5, "unit": "samples/s", "ms_per_batch": 1e3 * t5,
+                                  "samples_per_gpu": 125, "calls_found": int(tb5.n_calls.sum().item())}
+            ref5.close()
+            del tb5, job5, X5
+        except Exception as exc:
+            extra = dict(extra or {})
+            extra["test_50kb"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
     # ------------------------------------------------------- cpu baseline ----
     cpu = None

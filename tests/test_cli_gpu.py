@@ -227,6 +227,8 @@ def test_bench_line_is_complete_on_one_gpu():
     assert "error" not in extra, extra
     assert extra["ms_per_step"] > 0 and 0 < extra["k_gram_frac_of_bf16_mfma_peak"] <= 1.0
     assert 0 < extra["rescore_roofline"]["frac"] <= 1.05            # runs at the HBM roof on uncorrelated rows
+    assert "error" not in extra["test_50kb"], extra["test_50kb"]
+    assert extra["test_50kb"]["value"] > 1000 and extra["test_50kb"]["calls_found"] > 0
     test = line["test"]
     assert test["value"] > 0 and 0 < test["roofline"]["frac"] <= 1.0
     assert test["single_sample_latency_ms"] < test["ms_per_batch"]
