@@ -210,28 +210,39 @@ __global__ void k_fill_users(const int *__restrict__ gidx, const int *__restrict
 }
 
 // -------------------------------------------------------- sample preparation ----
+// Per-sample read totals, TOT_SPLIT workgroups per sample over contiguous slices of the bins; the
+// partial sums are integers (exact in any order), k_normalize adds the slices up.
+constexpr int TOT_SPLIT = 16;
 __global__ __launch_bounds__(256) void k_sample_totals(const int *__restrict__ counts, int64_t Btot,
-                                                       double *__restrict__ totals) {
-    __shared__ long long sh[256];
+                                                       long long *__restrict__ partial) {
+    __shared__ long long sh[4];
     const int *row = counts + (int64_t)blockIdx.x * Btot;
+    const int64_t per = (Btot + TOT_SPLIT - 1) / TOT_SPLIT;
+    const int64_t lo = (int64_t)blockIdx.y * per, hi = lo + per < Btot ? lo + per : Btot;
     long long s = 0;
-    for (int64_t g = threadIdx.x; g < Btot; g += 256) s += row[g];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-        __syncthreads();
+    for (int64_t g0 = lo + threadIdx.x; g0 < hi; g0 += 256 * 8) {      // eight loads of a trip in flight together
+        int v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = g0 + 256 * e < hi ? row[g0 + 256 * e] : 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[e];
     }
-    if (threadIdx.x == 0) totals[blockIdx.x] = (double)sh[0];  // integer sums are exact in any order
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * TOT_SPLIT + blockIdx.y] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
 // toNumpyRefFormat (wisetools.py:275-276): x = counts / total, masked bins only
 __global__ void k_normalize(const int *__restrict__ counts, int64_t Btot, const int *__restrict__ m2g, int64_t B,
-                            const double *__restrict__ totals, double *__restrict__ raw) {
+                            const long long *__restrict__ partial, double *__restrict__ raw) {
     int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t i = blockIdx.y;
     if (b >= B) return;
-    raw[i * B + b] = (double)counts[i * Btot + m2g[b]] / totals[i];
+    long long t = 0;
+#pragma unroll
+    for (int q = 0; q < TOT_SPLIT; ++q) t += partial[i * TOT_SPLIT + q];
+    raw[i * B + b] = (double)counts[i * Btot + m2g[b]] / (double)t;
 }
 
 // applyPCA step 1 (wisetools.py:109): t = (x - mean) . components^T
@@ -1355,33 +1366,53 @@ void launch_sd_fast(hipStream_t stream, const double *sdT, int64_t B, int64_t Ns
 // zT / rT / nT here: the sample-major [Ns, B] copies (see k_inflate)
 // (si, sb): strides of the z / ratio / count arrays per sample and per bin -- (B, 1) for the
 // sample-major copies, (1, Ns) to read the repeats' bin-major arrays directly (small batches)
-__global__ __launch_bounds__(64) void k_clean(const double *__restrict__ zT, const double *__restrict__ rT,
-                                              const double *__restrict__ nT, int64_t B, int64_t Ns,
-                                              const int64_t *__restrict__ moff, const int64_t *__restrict__ goff,
-                                              const int *__restrict__ m2g, const int *__restrict__ sel, int n_sel,
-                                              double minref, double *__restrict__ zc, double *__restrict__ rc,
-                                              int *__restrict__ gpos, Region *__restrict__ regions,
-                                              int64_t str_i, int64_t str_b) {
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(1024) void k_clean(const double *__restrict__ zT, const double *__restrict__ rT,
+                                                const double *__restrict__ nT, int64_t B, int64_t Ns,
+                                                const int64_t *__restrict__ moff, const int64_t *__restrict__ goff,
+                                                const int *__restrict__ m2g, const int *__restrict__ sel, int n_sel,
+                                                double minref, double *__restrict__ zc, double *__restrict__ rc,
+                                                int *__restrict__ gpos, Region *__restrict__ regions,
+                                                int64_t str_i, int64_t str_b) {
+    // one 1 024-thread workgroup per (sample, chromosome): 1 024 bins per trip, the kept ones compacted in
+    // order (ballot within a wave, the sixteen wave counts through LDS).  One wave per region walked a 50 kb
+    // chromosome in 74 dependent trips (0.22 ms per 125-sample batch).
+    __shared__ int s_cnt[2][16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t i = blockIdx.y;
     const int si = blockIdx.x;
     const int c = sel[si];
     const int64_t cs = moff[c], ce = moff[c + 1];
-    int count = 0;
-    for (int64_t base = cs; base < ce; base += 64) {
-        int64_t b = base + lane;
+    int count = 0, trip = 0;
+    for (int64_t base = cs; base < ce; base += 1024, trip ^= 1) {
+        const int64_t b = base + tid;
         bool keep = false;
-        if (b < ce) keep = nT[i * str_i + b * str_b] >= minref;
-        unsigned long long mask = __ballot(keep);
-        if (keep) {
-            int at = count + __popcll(mask & ((1ull << lane) - 1ull));
-            zc[i * B + cs + at] = zT[i * str_i + b * str_b];
-            rc[i * B + cs + at] = rT[i * str_i + b * str_b];
-            gpos[i * B + cs + at] = (int)(m2g[b] - goff[c]);
+        double zv = 0.0, rv = 0.0;
+        int gp = 0;
+        if (b < ce) {
+            keep = nT[i * str_i + b * str_b] >= minref;
+            zv = zT[i * str_i + b * str_b];
+            rv = rT[i * str_i + b * str_b];
+            gp = (int)(m2g[b] - goff[c]);
         }
-        count += __popcll(mask);
+        const unsigned long long mask = __ballot(keep);
+        if (lane == 0) s_cnt[trip][w] = __popcll(mask);
+        __syncthreads();                     // (the other buffer is written in the next trip: one barrier per trip)
+        int before = 0, total = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int n = s_cnt[trip][q];
+            before += q < w ? n : 0;
+            total += n;
+        }
+        if (keep) {
+            const int at = count + before + __popcll(mask & ((1ull << lane) - 1ull));
+            zc[i * B + cs + at] = zv;
+            rc[i * B + cs + at] = rv;
+            gpos[i * B + cs + at] = gp;
+        }
+        count += total;
     }
-    if (lane == 0) {
+    if (tid == 0) {
         Region rg;
         rg.off = i * B + cs;
         rg.n = count;
@@ -1436,18 +1467,34 @@ __global__ __launch_bounds__(256) void k_region_prefix(const double *__restrict_
     double a = 0.0, run = 0.0;
     int finite = 1;
     if (lane == 0) P[0] = 0.0;
-    for (int t0 = 0; t0 < rg.n; t0 += 64) {
-        const int t = t0 + lane;
-        const double v = t < rg.n ? zz[t] : 0.0;
-        if (!isfinite(v)) finite = 0;
-        a += fabs(v);
-        double incl = v;
-        for (int o = 1; o < 64; o <<= 1) {
-            const double up = __shfl_up(incl, o);
-            if (lane >= o) incl += up;
+    // four trips at a time: their loads and wave scans are independent, only the running total chains them
+    // (the same additions in the same order as one trip after the other)
+    for (int t0 = 0; t0 < rg.n; t0 += 256) {
+        double v[4], incl[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + 64 * u + lane;
+            v[u] = t < rg.n ? zz[t] : 0.0;
         }
-        if (t < rg.n) P[t + 1] = run + incl;
-        run += __shfl(incl, 63);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!isfinite(v[u])) finite = 0;
+            a += fabs(v[u]);
+            incl[u] = v[u];
+        }
+        for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double up = __shfl_up(incl[u], o);
+                if (lane >= o) incl[u] += up;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + 64 * u + lane;
+            if (t < rg.n) P[t + 1] = run + incl[u];
+            run += __shfl(incl[u], 63);
+        }
     }
     for (int o = 32; o > 0; o >>= 1) {
         a += __shfl_xor(a, o);
@@ -2731,6 +2778,7 @@ __global__ __launch_bounds__(256) void k_seg_gather(const Seg *__restrict__ segs
 // all 256 threads of the workgroup take part.
 __device__ inline double block_select(const double *__restrict__ v, int L, int k, int tid) {
     __shared__ unsigned int hist[256];
+    __shared__ unsigned int s_wsum[4];
     __shared__ unsigned long long s_prefix;
     __shared__ int s_k;
     unsigned long long prefix = 0ull, mask = 0ull;
@@ -2742,14 +2790,24 @@ __device__ inline double block_select(const double *__restrict__ v, int L, int k
             if ((key & mask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            int kk = k, d = 0;
-            for (; d < 255; ++d) {
-                if (kk < (int)hist[d]) break;
-                kk -= (int)hist[d];
+        {
+            // the digit whose bucket holds rank k: prefix sums of the 256 counts by the 256 threads (a walk
+            // by one thread is 255 dependent LDS reads per digit: 8 us, of a 10 us pass)
+            const unsigned int h = hist[tid];
+            unsigned int incl = h;
+            const int lane = tid & 63, wv = tid >> 6;
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned int up = __shfl_up(incl, o);
+                if (lane >= o) incl += up;
             }
-            s_k = kk;
-            s_prefix = prefix | ((unsigned long long)d << shift);
+            if (lane == 63) s_wsum[wv] = incl;
+            __syncthreads();
+            for (int q = 0; q < wv; ++q) incl += s_wsum[q];
+            const unsigned int excl = incl - h;
+            if ((unsigned int)k >= excl && (unsigned int)k < incl) {     // exactly one bucket (k < number of values)
+                s_k = k - (int)excl;
+                s_prefix = prefix | ((unsigned long long)tid << shift);
+            }
         }
         __syncthreads();
         k = s_k;
@@ -3004,15 +3062,15 @@ __global__ __launch_bounds__(1024) void k_seg_tree(int *__restrict__ counters, c
 int run_prepare(wc_ctx *ctx, const wc_reference *ref, const int *counts_dev, int64_t Ns, hipStream_t stream) {
     TestState &ts = ctx->ts;
     int rc;
-    if ((rc = ts.totals.reserve(sizeof(double) * Ns))) return rc;
+    if ((rc = ts.totals.reserve(sizeof(long long) * Ns * TOT_SPLIT))) return rc;
     if ((rc = ts.raw.reserve(sizeof(double) * Ns * ref->B))) return rc;
     if ((rc = ts.proj.reserve(sizeof(double) * Ns * MAX_COMP * PROJ_SPLIT))) return rc;
     if ((rc = ts.data.reserve(sizeof(double) * Ns * ref->B))) return rc;
-    hipLaunchKernelGGL(k_sample_totals, dim3((unsigned)Ns), dim3(256), 0, stream, counts_dev, ref->Btot,
-                       ts.totals.as<double>());
+    hipLaunchKernelGGL(k_sample_totals, dim3((unsigned)Ns, TOT_SPLIT), dim3(256), 0, stream, counts_dev, ref->Btot,
+                       ts.totals.as<long long>());
     dim3 g((unsigned)cdiv(ref->B, 256), (unsigned)Ns);
     hipLaunchKernelGGL(k_normalize, g, dim3(256), 0, stream, counts_dev, ref->Btot, (const int *)ref->m2g.as<int>(),
-                       ref->B, (const double *)ts.totals.as<double>(), ts.raw.as<double>());
+                       ref->B, (const long long *)ts.totals.as<long long>(), ts.raw.as<double>());
     hipLaunchKernelGGL(k_pca_project, dim3((unsigned)Ns, PROJ_SPLIT), dim3(256), 0, stream, (const double *)ts.raw.as<double>(),
                        ref->B, (const double *)ref->pca_mean.as<double>(), (const double *)ref->pca_comp.as<double>(),
                        ref->n_comp, ts.proj.as<double>());
@@ -3921,7 +3979,7 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
             return WC_OK;
         }
     } else {
-        hipLaunchKernelGGL(k_clean, dim3((unsigned)n_sel, (unsigned)Ns), dim3(64), 0, stream, zsrc, rsrc, nsrc, B, Ns,
+        hipLaunchKernelGGL(k_clean, dim3((unsigned)n_sel, (unsigned)Ns), dim3(1024), 0, stream, zsrc, rsrc, nsrc, B, Ns,
                            (const int64_t *)ref->moff_dev.as<int64_t>(), (const int64_t *)ref->goff_dev.as<int64_t>(),
                            (const int *)ref->m2g.as<int>(), (const int *)ts.sel.as<int>(), n_sel, (double)min_ref_bins,
                            ts.zc.as<double>(), ts.rc.as<double>(), ts.gpos.as<int>(), ts.regions.as<Region>(), str_i,
