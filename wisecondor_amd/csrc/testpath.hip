@@ -1132,7 +1132,8 @@ struct SdShared {
 };
 template <int REG>
 __device__ inline void sd_fast_block(const int64_t i, SdShared *sm, const double *__restrict__ sdT, int64_t B, int64_t Ns,
-                                     double *__restrict__ out, int *__restrict__ fail, double *__restrict__ out2) {
+                                     double *__restrict__ out, int *__restrict__ fail, double *__restrict__ out2,
+                                     int64_t sb, int64_t si) {     // element (bin b, sample i) at sdT[b * sb + i * si]
     constexpr int PER_MAX = 64;                      // elements per thread (B <= 65536)
     // the workgroup's scratch (caller-provided LDS: static in k_sd_fast, the dynamic region in k_seg_tree)
     double *sh_p = sm->sh_p;
@@ -1155,28 +1156,40 @@ __device__ inline void sd_fast_block(const int64_t i, SdShared *sm, const double
     double xr[NREG];
     if (REG > 0) {
 #pragma unroll
-        for (int e = 0; e < NREG; ++e) xr[e] = lo + e < hi ? sdT[(lo + e) * Ns + i] : 0.0;
+        for (int e = 0; e < NREG; ++e) xr[e] = lo + e < hi ? sdT[(lo + e) * sb + i * si] : 0.0;
     }
-    // e-th term of this thread (REG == 0: re-read, L2-resident); NaN: not part of the sum
-    auto raw = [&](int e) { return REG > 0 ? xr[e] : sdT[(lo + e) * Ns + i]; };
-    auto term = [&](int e) {
-        const double v = raw(e);
-        return v != v ? 0.0 : v;
-    };
     const int n_mine = (int)(hi > lo ? hi - lo : 0);
+    // f(value) for this thread's elements in order: from the registers (REG > 0), or re-read eight at a time
+    // (REG == 0: one load per iteration was a memory round trip per element and walk -- 0.4 ms per
+    // 125-sample batch at 50 kb)
+    auto for_each = [&](auto f) {
+        if (REG > 0) {
+#pragma unroll
+            for (int e = 0; e < NREG; ++e) {
+                if (e >= n_mine) break;
+                f(xr[e]);
+            }
+        } else {
+            for (int e0 = 0; e0 < n_mine; e0 += 8) {
+                double b8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) b8[u] = e0 + u < n_mine ? sdT[(lo + e0 + u) * sb + i * si] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (e0 + u < n_mine) f(b8[u]);
+            }
+        }
+    };
     int cnt = 0;
     bool bad = false;
     double loc = 0.0;
-#pragma unroll
-    for (int e = 0; e < (REG > 0 ? NREG : PER_MAX); ++e) {
-        if (e >= n_mine) break;
-        const double v = raw(e);
+    for_each([&](double v) {
         if (v == v) {
             ++cnt;
             if (!(v >= 0.0) || v > 1.7e308) bad = true;
             loc += v;
         }
-    }
+    });
     // approximate prefix sums: inclusive scan of the threads' sums (wave shuffles, then the sixteen
     // wave totals), then along the thread's elements
     {
@@ -1205,10 +1218,8 @@ __device__ inline void sd_fast_block(const int64_t i, SdShared *sm, const double
     SdMap run = ident;
     SdMap head = ident;
     int n_bound = 0;
-#pragma unroll
-    for (int e = 0; e < (REG > 0 ? NREG : PER_MAX); ++e) {
-        if (e >= n_mine) break;
-        const double xv = term(e);
+    for_each([&](double raw_v) {
+        const double xv = raw_v != raw_v ? 0.0 : raw_v;      // NaN: not part of the sum
         const double after = before + xv;
         bool boundary = false;
         if (xv > 0.0) {
@@ -1226,7 +1237,7 @@ __device__ inline void sd_fast_block(const int64_t i, SdShared *sm, const double
             run = ident;
         }
         before = after;
-    }
+    });
     if (n_bound == 0) head = run;
     // block-wide segmented scan over the threads: value = (flag: holds a boundary, map: its tail --
     // or its whole fold when it holds none)
@@ -1276,10 +1287,8 @@ __device__ inline void sd_fast_block(const int64_t i, SdShared *sm, const double
         SdMap seg = carry;
         double bef = tid > 0 ? sh_p[tid - 1] : 0.0;
         int k = k0;
-#pragma unroll
-        for (int e = 0; e < (REG > 0 ? NREG : PER_MAX); ++e) {
-            if (e >= n_mine) break;
-            const double xv = term(e);
+        for_each([&](double raw_v) {
+            const double xv = raw_v != raw_v ? 0.0 : raw_v;
             const double after = bef + xv;
             bool boundary = false;
             if (xv > 0.0) {
@@ -1298,7 +1307,7 @@ __device__ inline void sd_fast_block(const int64_t i, SdShared *sm, const double
                 seg = ident;
             }
             bef = after;
-        }
+        });
         if (tid == 1023) { b_A[n_total_bound] = seg.A; b_H0[n_total_bound] = seg.H0; b_H1[n_total_bound] = seg.H1; }
     }
     __syncthreads();
@@ -1336,9 +1345,9 @@ __device__ inline void sd_fast_block(const int64_t i, SdShared *sm, const double
 template <int REG>
 __global__ __launch_bounds__(1024) void k_sd_fast(const double *__restrict__ sdT, int64_t B, int64_t Ns,
                                                   double *__restrict__ out, int *__restrict__ fail,
-                                                  double *__restrict__ out2) {
+                                                  double *__restrict__ out2, int64_t sb, int64_t si) {
     __shared__ SdShared sm;
-    sd_fast_block<REG>(blockIdx.x, &sm, sdT, B, Ns, out, fail, out2);
+    sd_fast_block<REG>(blockIdx.x, &sm, sdT, B, Ns, out, fail, out2, sb, si);
 }
 
 // what the latency mode appends to another kernel's grid (k_seg_tree): `blocks` workgroups, one per sample
@@ -1348,16 +1357,18 @@ struct SdRider {
     int64_t B, Ns;
     double *out, *out2;
     int *fail;
+    int64_t sb, si;
 };
 
-void launch_sd_fast(hipStream_t stream, const double *sdT, int64_t B, int64_t Ns, double *out, int *fail, double *out2) {
+void launch_sd_fast(hipStream_t stream, const double *sdT, int64_t B, int64_t Ns, double *out, int *fail, double *out2,
+                    int64_t sb, int64_t si) {
     const int64_t per = (B + 1023) / 1024;
     if (per <= 12)
-        hipLaunchKernelGGL(k_sd_fast<12>, dim3((unsigned)Ns), dim3(1024), 0, stream, sdT, B, Ns, out, fail, out2);
+        hipLaunchKernelGGL(k_sd_fast<12>, dim3((unsigned)Ns), dim3(1024), 0, stream, sdT, B, Ns, out, fail, out2, sb, si);
     else if (per <= 24)
-        hipLaunchKernelGGL(k_sd_fast<24>, dim3((unsigned)Ns), dim3(1024), 0, stream, sdT, B, Ns, out, fail, out2);
+        hipLaunchKernelGGL(k_sd_fast<24>, dim3((unsigned)Ns), dim3(1024), 0, stream, sdT, B, Ns, out, fail, out2, sb, si);
     else
-        hipLaunchKernelGGL(k_sd_fast<0>, dim3((unsigned)Ns), dim3(1024), 0, stream, sdT, B, Ns, out, fail, out2);
+        hipLaunchKernelGGL(k_sd_fast<0>, dim3((unsigned)Ns), dim3(1024), 0, stream, sdT, B, Ns, out, fail, out2, sb, si);
 }
 
 // --------------------------------------------------------------- cleaning ----
@@ -2979,9 +2990,9 @@ __global__ __launch_bounds__(1024) void k_seg_tree(int *__restrict__ counters, c
         extern __shared__ double pl[];                 // the launch's dynamic LDS: at least sizeof(SdShared) with a rider
         SdShared *sm = reinterpret_cast<SdShared *>(pl);
         const int64_t per = (sd.B + 1023) / 1024;
-        if (per <= 12) sd_fast_block<12>(blk, sm, sd.sdT, sd.B, sd.Ns, sd.out, sd.fail, sd.out2);
-        else if (per <= 24) sd_fast_block<24>(blk, sm, sd.sdT, sd.B, sd.Ns, sd.out, sd.fail, sd.out2);
-        else sd_fast_block<0>(blk, sm, sd.sdT, sd.B, sd.Ns, sd.out, sd.fail, sd.out2);
+        if (per <= 12) sd_fast_block<12>(blk, sm, sd.sdT, sd.B, sd.Ns, sd.out, sd.fail, sd.out2, sd.sb, sd.si);
+        else if (per <= 24) sd_fast_block<24>(blk, sm, sd.sdT, sd.B, sd.Ns, sd.out, sd.fail, sd.out2, sd.sb, sd.si);
+        else sd_fast_block<0>(blk, sm, sd.sdT, sd.B, sd.Ns, sd.out, sd.fail, sd.out2, sd.sb, sd.si);
     } else if (blk < sd.blocks + inf.blocks) {
         const int64_t n = inf.Btot * inf.Ns;
         for (int64_t t = (int64_t)(blk - sd.blocks) * 1024 + threadIdx.x; t < n; t += (int64_t)inf.blocks * 1024) {
@@ -3228,7 +3239,17 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
     double *out2 = lat ? asdef_out : nullptr;
     if (!(sd_env && strcmp(sd_env, "serial") == 0) && ref->B <= 65536) {
         if ((rc = ts.sd_fail.reserve(sizeof(int) * Ns))) return rc;
-        launch_sd_fast(sds, ts.sdt.as<double>(), ref->B, Ns, ts.sd_avg.as<double>(), ts.sd_fail.as<int>(), out2);
+        if (Ns > 8) {
+            // a batch: the sums run over a sample-major copy (a sample's standard deviations contiguous): in
+            // the bin-major array every element of a sample sits in a cache line of its own, and 125
+            // workgroups walking 55 337 such lines three times kept the side stream busy for 0.4 ms
+            if ((rc = ts.sds.reserve(sizeof(double) * n))) return rc;
+            launch_transpose((const double *)ts.sdt.as<double>(), ref->B, Ns, ts.sds.as<double>(), sds);
+            launch_sd_fast(sds, ts.sds.as<double>(), ref->B, Ns, ts.sd_avg.as<double>(), ts.sd_fail.as<int>(), out2, 1,
+                           ref->B);
+        } else {
+            launch_sd_fast(sds, ts.sdt.as<double>(), ref->B, Ns, ts.sd_avg.as<double>(), ts.sd_fail.as<int>(), out2, Ns, 1);
+        }
         only = ts.sd_fail.as<int>();
     }
     if (lat && !only) {        // the status word reads the flags: none raised
@@ -3537,6 +3558,8 @@ int run_seg_lat(wc_ctx *ctx, const wc_reference *ref, const double *zsrc, const 
         rider.out = ts.sd_avg.as<double>();
         rider.out2 = ts.lat_ride_out2;
         rider.fail = ts.sd_fail.as<int>();
+        rider.sb = Ns;
+        rider.si = 1;
     }
     as.reg_calls = ts.effect.as<double>();
     as.sd_fail = ts.sd_fail.as<int>();
@@ -3789,8 +3812,8 @@ int wc_std_dev_avg(wc_ctx *ctx, const double *sd, int64_t n_samples, int64_t n_b
     WC_HIP(hipMemset(ts.sd_fail.p, 0, sizeof(int) * n_samples));
     const int *only = nullptr;
     if (n_bins <= 65536) {
-        launch_sd_fast(nullptr, ts.sdt.as<double>(), n_bins, n_samples, ts.sd_avg.as<double>(), ts.sd_fail.as<int>(),
-                       nullptr);
+        launch_sd_fast(nullptr, ts.data.as<double>(), n_bins, n_samples, ts.sd_avg.as<double>(), ts.sd_fail.as<int>(),
+                       nullptr, 1, n_bins);       // the caller's layout: a sample's values contiguous
         only = ts.sd_fail.as<int>();
     }
     hipLaunchKernelGGL(k_sd_avg<64>, dim3((unsigned)cdiv(n_samples, 64)), dim3(256), 0, nullptr,
