@@ -2785,34 +2785,39 @@ __global__ __launch_bounds__(256) void k_seg_gather(const Seg *__restrict__ segs
     }
 }
 
+constexpr int CP_THREADS = 1024;     // threads of a k_call_post workgroup (one per segment)
 // k-th smallest (0-based) of v[0..L) by radix selection on the ordered 64-bit image;
-// all 256 threads of the workgroup take part.
+// all CP_THREADS threads of the workgroup take part.
 __device__ inline double block_select(const double *__restrict__ v, int L, int k, int tid) {
+    // CP_THREADS threads; the 256 digit buckets are scanned by the first four waves
     __shared__ unsigned int hist[256];
     __shared__ unsigned int s_wsum[4];
     __shared__ unsigned long long s_prefix;
     __shared__ int s_k;
     unsigned long long prefix = 0ull, mask = 0ull;
     for (int shift = 56; shift >= 0; shift -= 8) {
-        hist[tid] = 0;
+        if (tid < 256) hist[tid] = 0;
         __syncthreads();
-        for (int e = tid; e < L; e += 256) {
+        for (int e = tid; e < L; e += CP_THREADS) {
             unsigned long long key = wc::f64_ordered(v[e]);
             if ((key & mask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
         }
         __syncthreads();
-        {
-            // the digit whose bucket holds rank k: prefix sums of the 256 counts by the 256 threads (a walk
-            // by one thread is 255 dependent LDS reads per digit: 8 us, of a 10 us pass)
-            const unsigned int h = hist[tid];
-            unsigned int incl = h;
-            const int lane = tid & 63, wv = tid >> 6;
+        unsigned int h = 0, incl = 0;
+        const int lane = tid & 63, wv = tid >> 6;
+        if (tid < 256) {
+            // the digit whose bucket holds rank k: prefix sums of the 256 counts (a walk by one thread is
+            // 255 dependent LDS reads per digit)
+            h = hist[tid];
+            incl = h;
             for (int o = 1; o < 64; o <<= 1) {
                 const unsigned int up = __shfl_up(incl, o);
                 if (lane >= o) incl += up;
             }
             if (lane == 63) s_wsum[wv] = incl;
-            __syncthreads();
+        }
+        __syncthreads();
+        if (tid < 256) {
             for (int q = 0; q < wv; ++q) incl += s_wsum[q];
             const unsigned int excl = incl - h;
             if ((unsigned int)k >= excl && (unsigned int)k < incl) {     // exactly one bucket (k < number of values)
@@ -2828,9 +2833,7 @@ __device__ inline double block_select(const double *__restrict__ v, int L, int k
     }
     return wc::f64_from_ordered(prefix);
 }
-
-// Call coordinates and effect size (wisecondor.py:239-257): one workgroup per segment.
-__global__ __launch_bounds__(256) void k_call_post(const Seg *__restrict__ segs, int n_segs,
+__global__ __launch_bounds__(CP_THREADS) void k_call_post(const Seg *__restrict__ segs, int n_segs,
                                                    const Region *__restrict__ regions, const double *__restrict__ rc,
                                                    const int *__restrict__ gpos, int max_calls,
                                                    double *__restrict__ reg_calls,
@@ -2843,7 +2846,7 @@ __global__ __launch_bounds__(256) void k_call_post(const Seg *__restrict__ segs,
     if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
     __syncthreads();
     int rank = 0;
-    for (int t = tid; t < n_segs; t += 256) {
+    for (int t = tid; t < n_segs; t += CP_THREADS) {
         const Seg o = segs[t];
         rank += (o.region == me.region && o.x < me.x);
     }
@@ -2851,7 +2854,7 @@ __global__ __launch_bounds__(256) void k_call_post(const Seg *__restrict__ segs,
     const Region rg = regions[me.region];
     const int x = me.x, y = me.y, L = y - x + 1;
     const double *v = rc + rg.off + x;
-    for (int e = tid; e < L; e += 256)
+    for (int e = tid; e < L; e += CP_THREADS)
         if (v[e] != v[e]) s_flag[1] = 1;
     __syncthreads();
     rank = s_flag[0];
@@ -2863,10 +2866,10 @@ __global__ __launch_bounds__(256) void k_call_post(const Seg *__restrict__ segs,
         // value whose count interval covers a middle rank is that order statistic
         __shared__ double sv[SHORT_SEG];
         __shared__ double s_mid[2];
-        for (int e = tid; e < L; e += 256) sv[e] = v[e];
+        for (int e = tid; e < L; e += CP_THREADS) sv[e] = v[e];
         __syncthreads();
         const int k_lo = (L - 1) / 2, k_hi = L / 2;
-        for (int e = tid; e < L; e += 256) {
+        for (int e = tid; e < L; e += CP_THREADS) {
             const double xv = sv[e];
             int lt = 0, le = 0;
             for (int u = 0; u < L; ++u) {
@@ -4027,7 +4030,7 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
     if (calls && n_calls) {
         // ts.misc (overflow flag) was cleared by k_region_prefix
         if (ts.last_segs > 0)
-            hipLaunchKernelGGL(k_call_post, dim3((unsigned)ts.last_segs), dim3(256), 0, stream,
+            hipLaunchKernelGGL(k_call_post, dim3((unsigned)ts.last_segs), dim3(CP_THREADS), 0, stream,
                                (const Seg *)ts.seg.as<Seg>(), (int)ts.last_segs,
                                (const Region *)ts.regions.as<Region>(), (const double *)ts.rc.as<double>(),
                                (const int *)ts.gpos.as<int>(), max_calls, ts.effect.as<double>(), (const int *)nullptr);
