@@ -1649,6 +1649,7 @@ struct ScanCtx {
     const double *P;   // prefix of the region
     int lo, hi, L, half, chunk;
     WindowMask wm;
+    int clip_lo = 0, clip_hi = 0x7fffffff;   // scan only the windows inside [clip_lo, clip_hi) (a sub-range of the job)
 };
 
 // Rows handled by (job, chunk): ROWS_HALF rows from the top of the triangle and the
@@ -1674,10 +1675,13 @@ __device__ inline void scan_chunk(const ScanCtx &c, const double *__restrict__ r
         }
         // longest window among the rows of this block (lane 0 has the smallest / largest start)
         const int xr_min = side == 0 ? c.chunk * ROWS_HALF : c.L - 1 - (c.chunk * ROWS_HALF + 63);
-        const int max_len = c.L - (xr_min < 0 ? 0 : xr_min);
+        int max_len = c.L - (xr_min < 0 ? 0 : xr_min);
         const int x = c.lo + (live ? xr : 0);
+        const int end = c.hi < c.clip_hi ? c.hi : c.clip_hi;
+        live = live && x >= c.clip_lo && x < end;
+        if (end - c.clip_lo < max_len) max_len = end - c.clip_lo > 0 ? end - c.clip_lo : 0;
         const double px = c.P[x];
-        const int room = live ? c.hi - x : 0;            // windows [x, x + len - 1] with len <= room
+        const int room = live ? end - x : 0;             // windows [x, x + len - 1] with len <= room
         // four window lengths per trip: their table factors and prefix values are requested
         // together (a trip per length waits out one load latency per window)
         for (int len0 = 1 + w; len0 <= max_len; len0 += 4 * nw) {
@@ -2522,6 +2526,8 @@ __device__ inline void seg_tree_region(const int region, int *__restrict__ count
     __shared__ double s_mid[2];
     __shared__ int s_nan;
     __shared__ unsigned int s_reach[TREE_CHUNKS];
+    __shared__ unsigned int s_loud[TREE_CHUNKS];       // slices of the range [s_ext_lo, s_ext_hi) that may hold a call
+    __shared__ int s_ext_lo, s_ext_hi, s_found;
     const int tid = threadIdx.x;
     if (region >= n_regions) return;
     const Region rg = regions[region];
@@ -2536,7 +2542,7 @@ __device__ inline void seg_tree_region(const int region, int *__restrict__ count
     double *zl = pl + (rg.n + 1);                      // the region's z values, for the exact sums
     for (int i = tid; i <= rg.n; i += 1024) pl[i] = Pg[i];
     for (int i = tid; i < rg.n; i += 1024) zl[i] = z[rg.off + i];
-    if (tid == 0) { s_sp = 1; s_nseg = 0; s_root = 1; }
+    if (tid == 0) { s_sp = 1; s_nseg = 0; s_root = 1; s_ext_lo = 0; s_ext_hi = -1; }
     __syncthreads();
     const double eps = window_eps(rg.n, reg_abs[region]);
     const double *zz = zl;
@@ -2548,6 +2554,18 @@ __device__ inline void seg_tree_region(const int region, int *__restrict__ count
         stack[0] = root;
     }
     __syncthreads();
+    // which slices of the job whose extremes sit in ext_max / ext_min may hold a call (same test as a whole
+    // range's: the larger magnitude + eps against the threshold); bit side * 16 + wave of s_loud[row block]
+    auto loud_slices = [&](int nch_job) {
+        for (int t = tid; t < nch_job; t += 1024) s_loud[t] = 0u;
+        __syncthreads();
+        for (int t = tid; t < nch_job * 32; t += 1024) {
+            const double mx = (&ext_max[0][0][0])[t], mn = (&ext_min[0][0][0])[t];
+            const bool empty = mx == -INFINITY && mn == INFINITY;       // a slice without a window
+            if (!empty && !(fmax(fabs(mx), fabs(mn)) + eps < thr)) atomicOr(&s_loud[t >> 5], 1u << (t & 31));
+        }
+        __syncthreads();
+    };
     while (true) {
         __syncthreads();
         if (s_sp == 0) break;
@@ -2582,7 +2600,37 @@ __device__ inline void seg_tree_region(const int region, int *__restrict__ count
             }
             __syncthreads();
             if (fmax(fabs(emax), fabs(emin)) + eps < thr) continue;
+            loud_slices(nch);
+            if (tid == 0) { s_ext_lo = job.lo; s_ext_hi = job.hi; }
         } else {
+            // A range inside the range whose slice extremes are still at hand (a child of the job just
+            // decided, or of the root): every window of it lies in one of those slices, and a slice
+            // whose own extremes stay below the threshold cannot hold a call.  Only the windows of the few
+            // loud slices that fall inside this range are evaluated -- a few thousand instead of the
+            // range's L^2 / 2 -- and if none reaches the threshold the range is done.
+            if (s_ext_lo <= job.lo && job.hi <= s_ext_hi) {
+                ScanCtx pc;
+                pc.P = pl; pc.lo = s_ext_lo; pc.hi = s_ext_hi; pc.L = pc.hi - pc.lo; pc.half = (pc.L + 1) / 2;
+                pc.wm = wm;
+                pc.clip_lo = job.lo; pc.clip_hi = job.hi;
+                const int pnch = (pc.half + ROWS_HALF - 1) / ROWS_HALF;
+                if (tid == 0) s_found = 0;
+                __syncthreads();
+                bool found = false;
+                for (int ch = 0; ch < pnch; ++ch) {
+                    const unsigned int loud = s_loud[ch];
+                    if (loud == 0u) continue;
+                    pc.chunk = ch;
+                    scan_chunk(pc, rs, tid, [&](double v, int, int) {
+                        if (!(fabs(v) + eps < thr)) found = true;
+                    }, ~loud);
+                }
+                if (found) s_found = 1;
+                __syncthreads();
+                const bool quiet = s_found == 0;
+                __syncthreads();
+                if (quiet) continue;
+            }
             // value search with the general path's inner loops (four float64 operations per window);
             // every (row block, side, wave) leaves its extremes behind for the candidate pass
             // Four (row block, side) pairs at a time, four waves each: a pair costs a fixed round of
@@ -2606,7 +2654,12 @@ __device__ inline void seg_tree_region(const int region, int *__restrict__ count
             emin = red_min[0];
             for (int q = 1; q < 16; ++q) { emax = fmax(emax, red_max[q]); emin = fmin(emin, red_min[q]); }
             __syncthreads();
-            if (fmax(fabs(emax), fabs(emin)) + eps < thr) continue;      // no call in this range (k_seg_classify's test)
+            if (fmax(fabs(emax), fabs(emin)) + eps < thr) {              // no call in this range (k_seg_classify's test)
+                if (tid == 0) s_ext_hi = -1;                             // the slice extremes at hand are this range's now: drop them
+                continue;
+            }
+            loud_slices(nch);
+            if (tid == 0) { s_ext_lo = job.lo; s_ext_hi = job.hi; }
         }
         // windows within 2 eps of the extremes: one of them is numpy's argmax / argmin.  Only the
         // (row block, side) pairs whose own extremes reach a cut are scanned again.
