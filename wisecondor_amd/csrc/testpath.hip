@@ -1394,7 +1394,8 @@ __global__ __launch_bounds__(1024) void k_clean(const double *__restrict__ zT, c
     const int c = sel[si];
     const int64_t cs = moff[c], ce = moff[c + 1];
     int count = 0, trip = 0;
-    for (int64_t base = cs; base < ce; base += 1024, trip ^= 1) {
+    const int nt = (int)blockDim.x, nwaves = nt >> 6;      // 64 .. 1 024 threads: the launch sizes the workgroup to the regions
+    for (int64_t base = cs; base < ce; base += nt, trip ^= 1) {
         const int64_t b = base + tid;
         bool keep = false;
         double zv = 0.0, rv = 0.0;
@@ -1407,6 +1408,7 @@ __global__ __launch_bounds__(1024) void k_clean(const double *__restrict__ zT, c
         }
         const unsigned long long mask = __ballot(keep);
         if (lane == 0) s_cnt[trip][w] = __popcll(mask);
+        if (tid < 16 && tid >= nwaves) s_cnt[trip][tid] = 0;       // waves this workgroup does not have
         __syncthreads();                     // (the other buffer is written in the next trip: one barrier per trip)
         int before = 0, total = 0;
 #pragma unroll
@@ -4058,7 +4060,8 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
             return WC_OK;
         }
     } else {
-        hipLaunchKernelGGL(k_clean, dim3((unsigned)n_sel, (unsigned)Ns), dim3(1024), 0, stream, zsrc, rsrc, nsrc, B, Ns,
+        hipLaunchKernelGGL(k_clean, dim3((unsigned)n_sel, (unsigned)Ns),
+                           dim3((unsigned)std::min<int64_t>(1024, std::max<int64_t>(64, cdiv(max_n, 256) * 64))), 0, stream, zsrc, rsrc, nsrc, B, Ns,
                            (const int64_t *)ref->moff_dev.as<int64_t>(), (const int64_t *)ref->goff_dev.as<int64_t>(),
                            (const int *)ref->m2g.as<int>(), (const int *)ts.sel.as<int>(), n_sel, (double)min_ref_bins,
                            ts.zc.as<double>(), ts.rc.as<double>(), ts.gpos.as<int>(), ts.regions.as<Region>(), str_i,
