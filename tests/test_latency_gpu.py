@@ -143,3 +143,22 @@ def test_batch_tree_tail_equals_host_rounds(wt):
         _same(_run_tail(wt, reference, samples, None, minrefbins=5, repeats=2), host)
     finally:
         reference.close()
+
+
+@pytest.mark.parametrize("kw", [dict(chromosomes=[1, 5, 22], minrefbins=10, repeats=1),
+                                dict(chromosomes=[4], minrefbins=10, repeats=5),
+                                dict(minrefbins=39, repeats=2),          # nearly every bin is cleaned away
+                                dict(minrefbins=41, repeats=2)])         # every bin is: empty regions
+def test_latency_mode_options(wt, kw):
+    """Chromosome subsets, a single repeat, regions emptied by the minrefbins filter: same answers from the
+    latency kernels, their graph replay and the general path."""
+    sizes = [300, 2, 40, 200, 64, 65, 129, 5] + [30] * 14
+    reference, rng, sizes, offs, total = _genome(wt, 777, sizes)
+    try:
+        samples = [_sample(rng, sizes, offs, total, [(0, 40, 90, 1.3), (3, 20, 60, 0.7), (21, 3, 12, 1.6)])
+                   for _ in range(3)]
+        general = _run(wt, reference, samples, "0", **kw)
+        _same(_run(wt, reference, samples, "2", **kw), general)
+        _same(_run(wt, reference, samples, None, **kw), general)
+    finally:
+        reference.close()
