@@ -3550,9 +3550,11 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     return WC_OK;
 }
 
-// Latency mode's cleaning + segmentation: k_lat_setup, k_block_minmax, k_seg_tree, k_seg_gather --
-// no host round trip; counters[4] (segments) and [6] (give-up flag) are looked at by the caller
-// after it synchronised.  Results as run_stouffer leaves them (ts.out_*, ts.whole, ts.seg).
+// Latency mode's cleaning + segmentation: k_lat_setup, k_seg_search (root windows of every region, all
+// row blocks in parallel), k_seg_tree (one workgroup per region walks the recursion and writes the call
+// rows; stdDevAvg and the result inflation ride in its grid) -- no host round trip; counters[4]
+// (segments) and [6] (give-up flag) are looked at by the caller after it synchronised.  The calls are
+// left in ts.effect / ts.out_n, the whole-chromosome values in ts.whole.
 int run_seg_lat(wc_ctx *ctx, const wc_reference *ref, const double *zsrc, const double *rsrc, const double *nsrc,
                 int64_t str_i, int64_t str_b, int64_t Ns, int n_sel, int64_t max_n, double thr, int min_ref_bins,
                 int max_calls, hipStream_t stream, double *whole_copy, InflateRider inf, AssembleRider as) {
@@ -4139,11 +4141,11 @@ int wc_test_batch_dev(wc_ctx *ctx, void *stream_, const wc_reference *ref, const
             ts.sel_host = sel;
         }
     }
-    // Latency mode (BASELINE config 3: one sample per call): the whole call is one hipGraph replay
-    // without a host round trip -- four segmentation rounds with device-side job counts (deeper
-    // recursions, or more jobs than a round's grid holds, are detected afterwards and the call is
-    // repeated on the general path).  The first call of a shape runs eagerly (it sizes every
-    // workspace), the second one is captured, later ones replay.
+    // Latency mode (BASELINE config 3: one sample per call): the whole call is one hipGraph replay of
+    // eight launches without a host round trip; what the fixed-shape kernels cannot hold (deep or wide
+    // recursions, too many queued pairs, a failed stdDevAvg assumption) is detected afterwards through
+    // status words and the call is repeated on the general path.  The first call of a shape runs
+    // eagerly (it sizes every workspace), the second one is captured, later ones replay.
     constexpr int LAT_MAX_SAMPLES = 8, LAT_ROUNDS = 1;
     const char *lat_env = getenv("WC_TEST_LATENCY_MODE");          // "0": general path for every call
     const bool lat = Ns <= LAT_MAX_SAMPLES && min_effect == 0.0 && n_sel > 0 && calls && n_calls && !ts.profile &&
