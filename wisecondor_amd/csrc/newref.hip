@@ -4,18 +4,20 @@
 // target bin, squared-L2 distance across the sample axis to every bin on another
 // chromosome, keep the k nearest in stable (distance, position) order.
 //
-// Pipeline (DESIGN.md section "newref"):
-//   prepare     robust per-sample centre, float64 -> float32, row norms with a
-//               rigorous error interval
-//   thresholds  fp32-MFMA Gram tiles of all rows x M pseudo-random sample rows ->
+// Pipeline:
+//   prepare     robust per-sample centre; float64 -> float32 operand image stored as bfloat16 hi / lo
+//               pairs (float32 with WC_GRAM_MODE=f32), a bfloat16 image for the threshold estimate, a
+//               padded float64 image for the re-score; row norms with a rigorous error interval
+//   thresholds  bf16-MFMA Gram tiles of all rows x M pseudo-random sample rows -> 16-bit key codes ->
 //               per-row admission threshold from an order statistic
-//   collect     symmetric fp32-MFMA Gram tiles over the cross-chromosome triangle;
-//               epilogue turns dot products into LOWER BOUNDS of the true
-//               distance and appends the few that pass the row threshold
-//   finish      per row: sort candidates, keep those whose lower bound does not
-//               exceed the k-th upper bound, re-score them in float64 in numpy's
-//               pairwise order, stable sort, emit; rows whose certificate fails
-//               take an exact brute-force path on the GPU
+//   collect     symmetric MFMA Gram tiles over the cross-chromosome triangle (three bf16 products
+//               per multiply, or float32 MFMA); the epilogue turns dot products into LOWER BOUNDS
+//               of the true distance and appends the few that pass the row threshold
+//   re-score    k_pick: per row (one wave) a separator for the k-th lower bound, the upper bound U,
+//               the certificate, the candidates with bound <= U as pairs; k_rescore: their exact
+//               float64 distances in numpy's summation order, counting order, output.  Rows whose
+//               certificate fails (and every row beyond refsize 256) take an exact path on the GPU
+//               (k_fallback_fill / k_fallback, k_all_exact).  WC_FINISH_ENGINE=rows: round 1's k_finish.
 #include <cstring>
 #include "ctx.h"
 
