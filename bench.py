@@ -105,6 +105,15 @@ def build_inputs(binsize, n_ref, n_test, seed0=0, device=0):
     profile = synth.bin_profile(binsize)
     samples = [synth.make_sample(profile, seed=seed0 + i) for i in range(n_ref)]
     _, chrom_bins, mask, corrected, comps, mean, masked_bins = wt.prepReference(samples, device=device)
+    # the same prep again, device resident and timed (newrefprep's numerics; host counts in,
+    # correctedData left in HBM for newref): what a caller pays between `convert`ed samples and stage A
+    import time as _time
+    import torch as _torch
+    _torch.cuda.synchronize()
+    _t0 = _time.perf_counter()
+    wt.prepReference(samples, device=device, device_out=True)
+    _torch.cuda.synchronize()
+    prep_ms = 1e3 * (_time.perf_counter() - _t0)
     masked_bins = np.asarray(masked_bins, dtype=np.int64)
     rng = np.random.RandomState(4242)
     tests = []
@@ -118,7 +127,7 @@ def build_inputs(binsize, n_ref, n_test, seed0=0, device=0):
             events.append((str(c), a, a + n // 4, f))
         tests.append(synth.make_sample(profile, seed=1000 + i, events=events))
     return dict(corrected=corrected, chrom_bins=np.asarray(chrom_bins, dtype=np.int64), mask=mask,
-                masked_bins=masked_bins, pca_mean=mean, pca_components=comps, tests=tests)
+                masked_bins=masked_bins, pca_mean=mean, pca_components=comps, tests=tests, prep_ms=prep_ms)
 
 
 def committed_traffic(workload):
@@ -668,6 +677,10 @@ def main():
                        "world_size": dist.get_world_size() if world > 1 else 1,
                        "shard_mode": job.mode or "single", "shard_calibration_s": job.calibration},
             "stages_ms": stages,
+            "prep": {"what": "newrefprep numerics on the GPU (normalise, mask, float64 MFMA Gram, host LAPACK for the "
+                             "leading eigenpairs, components, correctedData left in HBM), %d samples, host counts in; "
+                             "includes the marshalling of the sample dicts" % S,
+                     "ms": inp.get("prep_ms")},
             "test": {"metric": "test samples/sec", "value": samples_per_s, "unit": "samples/s",
                      "ms_per_batch": 1e3 * t_test / test_steps, "samples_per_gpu": args.test_samples,
                      "single_sample_latency_ms": single_ms, "roofline": test_roof, "calls_found": n_calls},

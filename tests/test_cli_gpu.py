@@ -229,6 +229,7 @@ def test_bench_line_is_complete_on_one_gpu():
     assert 0 < extra["rescore_roofline"]["frac"] <= 1.3             # at the HBM roof on uncorrelated rows (15 % of the gathers hit L2)
     assert "error" not in extra["test_50kb"], extra["test_50kb"]
     assert extra["test_50kb"]["value"] > 1000 and extra["test_50kb"]["calls_found"] > 0
+    assert line["prep"]["ms"] > 0
     test = line["test"]
     assert test["value"] > 0 and 0 < test["roofline"]["frac"] <= 1.0
     assert test["single_sample_latency_ms"] < test["ms_per_batch"]
