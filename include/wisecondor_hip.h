@@ -102,6 +102,11 @@ int wc_newref_thresholds_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64
 /* copy thresholds of rows [row_begin,row_end) out of / into the context (device float[rows]) */
 int wc_newref_get_thresholds_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end, float *out);
 int wc_newref_set_thresholds_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end, const float *in);
+/* the error interval every decision of the fast path rests on (device float[rows] each): a listed
+ * key of the pair (i, j) obeys  key <= distance(i, j) <= key + slack[i] + slack[j];  lo[i] is the
+ * row's lower norm bound (key = lo[i] + lo[j] - 2 dot).  For tests of the bound itself. */
+int wc_newref_get_bounds_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end, float *lo_out,
+                             float *slack_out);
 int wc_newref_collect_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end,
                           int tile_rank, int tile_ranks);
 /* candidate-list exchange: pack the lists of rows [row_begin,row_end) into

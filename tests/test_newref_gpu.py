@@ -199,24 +199,30 @@ def test_thresholds_are_reproducible():
     assert np.isfinite(seen[0]).all() and (seen[0] > 0).all()
 
 
-@pytest.mark.parametrize("mode", ["split", "f32"])
-@pytest.mark.parametrize("kind", ["noise", "wide"])
+@pytest.mark.parametrize("mode", ["f16", "split", "f32"])
+@pytest.mark.parametrize("kind", ["noise", "wide", "huge", "tiny"])
 def test_listed_keys_are_lower_bounds(mode, kind, monkeypatch):
-    """Every decision of the fast path rests on key <= true distance <= key + 3*beta*(norms).
-    The candidate lists expose the keys: check the bound on every listed pair, for the bf16
-    hi/lo tiles (default) and the float32 tiles, on plain noise and on rows whose magnitudes
-    span four orders (the split operands lose the low bits of large values)."""
+    """Every decision of the fast path rests on key <= true distance <= key + slack_i + slack_j.
+    The candidate lists expose the keys and wc_newref_get_bounds_dev the slacks: check both sides
+    on every listed pair, for the one-product float16 tiles (default), the bf16 hi/lo tiles and
+    the float32 tiles, on plain noise, on rows whose magnitudes span four orders (16-bit operands
+    lose the low bits of large values; float16 also clamps and flushes), and on matrices far
+    outside float16's own range (1e6 and 1e-9 times the usual magnitudes: the image is scaled)."""
     import torch
     from wisecondor_amd import _lib, distributed, synth
-    if mode == "f32":
-        monkeypatch.setenv("WC_GRAM_MODE", "f32")
-    else:
+    if mode == "f16":
         monkeypatch.delenv("WC_GRAM_MODE", raising=False)
+    else:
+        monkeypatch.setenv("WC_GRAM_MODE", mode)
     data, bins, _ = synth.corrected_matrix(1000000, 200, seed=8)
     if kind == "wide":
         rng = np.random.RandomState(3)
         data = data * np.exp(rng.uniform(-4.0, 4.0, size=(data.shape[0], 1)))      # per-row scale e^-4 .. e^4
         data += rng.standard_normal(data.shape) * 1e-3
+    elif kind == "huge":
+        data = data * 1e6
+    elif kind == "tiny":
+        data = data * 1e-9
     data = np.ascontiguousarray(data)
     X = torch.from_numpy(data).cuda()
     job = distributed.NewrefJob(_lib.context(0), X, bins, 100, _lib.SUM_PAIRWISE)
@@ -229,6 +235,11 @@ def test_listed_keys_are_lower_bounds(mode, kind, monkeypatch):
     lst = torch.zeros((st.n_bins, cap), dtype=torch.int64, device="cuda")
     st.export(0, st.n_bins, cap, cnt, lst)
     torch.cuda.synchronize()
+    lo_t = torch.zeros(st.n_bins, dtype=torch.float32, device="cuda")
+    slack_t = torch.zeros(st.n_bins, dtype=torch.float32, device="cuda")
+    st.get_bounds(0, st.n_bins, lo_t, slack_t)
+    torch.cuda.synchronize()
+    slack = slack_t.cpu().numpy().astype(np.float64)
     cnt = cnt.cpu().numpy()
     lst = lst.cpu().numpy().view(np.uint64)
     checked = 0
@@ -244,6 +255,7 @@ def test_listed_keys_are_lower_bounds(mode, kind, monkeypatch):
         key = bits.astype(np.uint32).view(np.float32).astype(np.float64)
         d = ((data[j] - data[i]) ** 2).sum(1)
         assert (key <= d * (1 + 1e-12) + 1e-300).all(), (mode, kind, i)
+        assert (d <= key + (slack[i] + slack[j]) * (1 + 1e-12) + 1e-300).all(), (mode, kind, i)
         scale = (data[j] ** 2).sum(1) + (data[i] ** 2).sum()
         worst = max(worst, float(((d - key) / np.maximum(scale, 1e-300)).max()))
         checked += n
@@ -253,3 +265,13 @@ def test_listed_keys_are_lower_bounds(mode, kind, monkeypatch):
     # rows of very different scale on one common centre: no such yardstick)
     if kind == "noise":
         assert worst < 1e-3
+    if kind != "wide":
+        # the fast path must actually carry these rows: a bound so loose that everything falls back
+        # to the exact scan would pass the checks above
+        from wisecondor_amd import wisetools as wt
+        job.run()
+        torch.cuda.synchronize()
+        stats = wt.newref_stats()
+        assert stats["fallback_rows"] == 0 and stats["fast_rows"] == st.n_bins, stats
+        assert stats["rescored"] < 1.25 * 100 * st.n_bins, stats       # ~k candidates per row, not the whole list
+

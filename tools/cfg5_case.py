@@ -16,18 +16,9 @@ N_TEST = 125
 GOLDEN_CHROMS = (0, 1, 2)        # chromosomes 1-3: 4986, 4864, 3961 bins before masking
 
 
-def build(wt, synth, n_test=N_TEST):
-    """Reference (device resident) + the test cohort.  Sample 0 carries a gain on chromosome 1
-    and a loss on chromosome 2 (chromosome 3 stays clean); every fifth other sample a mild event."""
-    from wisecondor_amd.wisecondor import zThreshold
-    profile = synth.bin_profile(BINSIZE)
-    refs = [synth.make_sample(profile, seed=i) for i in range(N_REF)]
-    _, chrom_bins, mask, corrected, comps, mean, masked_bins = wt.prepReference(refs)
-    masked_bins = np.asarray(masked_bins, dtype=np.int64)
-    idx, dst = wt.getReference(corrected, masked_bins, np.cumsum(masked_bins), 100, 1, 1)
-    reference = wt.Reference(idx, dst, np.asarray(chrom_bins, dtype=np.int64), masked_bins, mask, mean, comps,
-                             binsize=BINSIZE, device=0)
-    thr = float(zThreshold([int(v) for v in masked_bins], 1000, None))
+def test_samples(synth, profile, n_test=N_TEST):
+    """The test cohort (no GPU needed): sample 0 carries a gain on chromosome 1 and a loss on
+    chromosome 2 (chromosome 3 stays clean); every fifth other sample a mild event."""
     rng = np.random.RandomState(77)
     tests = []
     for i in range(n_test):
@@ -40,6 +31,22 @@ def build(wt, synth, n_test=N_TEST):
             a = int(rng.randint(0, n - n // 5))
             events = [(str(c), a, a + n // 5, 1.0 + rng.choice([-1, 1]) * rng.uniform(0.02, 0.05))]
         tests.append(synth.make_sample(profile, seed=5000 + i, events=events))
+    return tests
+
+
+def build(wt, synth, n_test=N_TEST):
+    """Reference (device resident) + the test cohort.  Sample 0 carries a gain on chromosome 1
+    and a loss on chromosome 2 (chromosome 3 stays clean); every fifth other sample a mild event."""
+    from wisecondor_amd.wisecondor import zThreshold
+    profile = synth.bin_profile(BINSIZE)
+    refs = [synth.make_sample(profile, seed=i) for i in range(N_REF)]
+    _, chrom_bins, mask, corrected, comps, mean, masked_bins = wt.prepReference(refs)
+    masked_bins = np.asarray(masked_bins, dtype=np.int64)
+    idx, dst = wt.getReference(corrected, masked_bins, np.cumsum(masked_bins), 100, 1, 1)
+    reference = wt.Reference(idx, dst, np.asarray(chrom_bins, dtype=np.int64), masked_bins, mask, mean, comps,
+                             binsize=BINSIZE, device=0)
+    thr = float(zThreshold([int(v) for v in masked_bins], 1000, None))
+    tests = test_samples(synth, profile, n_test)
     return dict(reference=reference, threshold=thr, tests=tests, masked_bins=masked_bins,
                 chrom_bins=np.asarray(chrom_bins, dtype=np.int64), indexes=idx, distances=dst,
                 corrected=corrected)

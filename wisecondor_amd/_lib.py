@@ -31,6 +31,7 @@ SIGNATURES = {
     "wc_newref_thresholds_dev": (_i32, [_vp, _vp, _i64, _i64]),
     "wc_newref_get_thresholds_dev": (_i32, [_vp, _vp, _i64, _i64, _vp]),
     "wc_newref_set_thresholds_dev": (_i32, [_vp, _vp, _i64, _i64, _vp]),
+    "wc_newref_get_bounds_dev": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "wc_newref_collect_dev": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32]),
     "wc_newref_list_capacity": (_i64, [_vp]),
     "wc_newref_export_lists_dev": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),

@@ -19,12 +19,14 @@ struct NewrefState {
     int64_t expect = 0;             // expected candidates per row under the sampled threshold
     float beta = 0.f;               // relative half-width of the key error interval
     bool prepared = false;
-    bool split = true;              // distance tiles on the bf16 matrix cores with hi/lo operand pairs
+    bool split = false;             // distance tiles on the bf16 matrix cores with hi/lo operand pairs
+    int gram_mode = 2;              // 0 float32 matrix cores, 1 bf16 hi/lo pairs, 2 one float16 product (default)
+    double tau = 0.0;               // f16 mode: weight of the representation-error split (k_convert)
     // device buffers
     wc::DevBuf a3, col_partial, col_mean, a32, norm_lo, norm_hi, chrom_of_row, chrom_range, chrom_off_dev;
     wc::DevBuf sample_rows, sample_slot, s32, s_norm_lo, s_chrom, s_range, a16, s16;
     wc::DevBuf keys1, thr, cnt, list, tiles;
-    wc::DevBuf fb_rows, fb_count, fb_scratch, stats, tiles0, pw_prog, pairs, x64;
+    wc::DevBuf fb_rows, fb_count, fb_scratch, stats, tiles0, pw_prog, pairs, x64, m2;
     int64_t s_pad = 0;      // samples padded to whole 16-sample chunks (x64 row stride)
     bool exact_only = false; // refsize beyond the candidate lists' design size: every row takes the exact path
     bool x64_pad = false;   // the padded float64 image exists (pair engine usable)
@@ -118,7 +120,7 @@ struct wc_ctx {
         return {&nr.a3, &nr.col_partial, &nr.col_mean, &nr.a32, &nr.norm_lo, &nr.norm_hi, &nr.chrom_of_row, &nr.chrom_range,
                 &nr.chrom_off_dev, &nr.sample_rows, &nr.sample_slot, &nr.s32, &nr.s_norm_lo, &nr.s_chrom, &nr.s_range, &nr.keys1,
                 &nr.thr, &nr.cnt, &nr.list, &nr.tiles, &nr.fb_rows, &nr.fb_count, &nr.fb_scratch,
-                &nr.stats, &nr.tiles0, &nr.pw_prog, &nr.pairs, &nr.x64, &nr.a16, &nr.s16, &tmp_a, &tmp_b, &tmp_c, &tmp_d,
+                &nr.stats, &nr.tiles0, &nr.pw_prog, &nr.pairs, &nr.x64, &nr.m2, &nr.a16, &nr.s16, &tmp_a, &tmp_b, &tmp_c, &tmp_d,
                 &ts.counts, &ts.totals, &ts.raw, &ts.proj, &ts.data, &ts.xt, &ts.xc, &ts.zt, &ts.rt, &ts.nt,
                 &ts.sdt, &ts.z, &ts.r, &ts.n, &ts.sd_avg, &ts.zc, &ts.rc, &ts.gpos, &ts.clean_n, &ts.regions,
                 &ts.sel, &ts.res_z, &ts.res_r, &ts.cwz, &ts.calls, &ts.n_calls, &ts.zs, &ts.rs2, &ts.ns2, &ts.sds, &ts.sub, &ts.tmin, &ts.tmax, &ts.prefix, &ts.reg_abs,

@@ -42,6 +42,7 @@ constexpr double SENTINEL_DISTANCE = 1e10;  // wisetools.py:306
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef double f64x2_u __attribute__((ext_vector_type(2), aligned(8)));   // rows of an odd sample count start 8-byte aligned
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
@@ -89,8 +90,10 @@ __global__ __launch_bounds__(1024) void k_col_centre(const double *__restrict__ 
         }
         __syncthreads();
         if (pass == 0) c = sh_v[tx];
-        else if (pass == 1) rad = 8.0 * sh_v[tx];
-        else if (ty == 0 && s < S) centre[s] = sh_v[tx];
+        else if (pass == 1) {
+            rad = 8.0 * sh_v[tx];
+            if (ty == 0 && s < S) centre[S + s] = sh_v[tx];   // mean absolute deviation: the f16 image's scale comes from it
+        } else if (ty == 0 && s < S) centre[s] = sh_v[tx];
         __syncthreads();
     }
 }
@@ -103,11 +106,33 @@ __device__ inline unsigned short f32_to_bf16(float f) {
     return (unsigned short)(b >> 16);
 }
 
-// One wave per row: centred float32 image (+ a bfloat16 image used only for the
-// admission-threshold estimate), norm interval, chromosome id.
+// float32 -> float16 bits for the one-product tiles: value * gam (a power of two) clamped to the
+// finite float16 range, rounded to nearest even, subnormal results flushed to zero (so that the
+// image is exactly what any matrix-core denormal mode sees).  NaN stays NaN.
+__device__ inline unsigned short f32_to_f16_scaled(float a, double gam, double inv_gam, double &back) {
+    double sd = (double)a * gam;
+    sd = sd > 65504.0 ? 65504.0 : (sd < -65504.0 ? -65504.0 : sd);
+    _Float16 h = (_Float16)(float)sd;           // (float)sd is exact: a has 24 bits, gam is a power of two
+    if (fabs((double)(float)h) < 6.103515625e-05) h = (_Float16)0.f;
+    back = (double)(float)h * inv_gam;          // the value the tiles multiply, exactly
+    unsigned short bits;
+    __builtin_memcpy(&bits, &h, 2);
+    return bits;
+}
+
+// One wave per row: centred operand image(s), norm interval, chromosome id.
+//   MODE16 = 0: float32 image A or bfloat16 hi/lo pairs A3 for the collect tiles, a bfloat16 image
+//               A16 for the admission-threshold estimate;
+//   MODE16 = 1: ONE float16 image (A16; values scaled by the power of two gam) for both.  The row's
+//               representation error e = |a - h| and |h|^2 are accumulated in float64, and the
+//               lower bound loses w = e^2 / tau + tau max(|a|^2, |h|^2) on top of the float32 chain:
+//               2 |a_i.a_j - h_i.h_j| <= 2 (e_i |a_j| + |h_i| e_j) <= w_i + w_j for any tau > 0
+//               ("one product per multiply").
+// norm_hi holds the row's SLACK: key <= true distance <= key + slack_i + slack_j.
+template <int MODE16>
 __global__ __launch_bounds__(256) void k_convert(const double *__restrict__ X, int64_t B, int64_t S,
                                                  int64_t Bpad, int64_t Kpad,
-                                                 const double *__restrict__ mean, double beta,
+                                                 const double *__restrict__ mean, double beta, double tau,
                                                  const int64_t *__restrict__ chrom_off, int n_chrom,
                                                  float *__restrict__ A, unsigned short *__restrict__ A16,
                                                  int64_t Kpad16, float *__restrict__ norm_lo,
@@ -118,7 +143,7 @@ __global__ __launch_bounds__(256) void k_convert(const double *__restrict__ X, i
                                                  int *__restrict__ s_chrom, int2 *__restrict__ s_range,
                                                  float *__restrict__ thr, int *__restrict__ cnt,
                                                  int *__restrict__ row_stat, unsigned short *__restrict__ A3,
-                                                 double *__restrict__ X64, int64_t Sp) {
+                                                 double *__restrict__ X64, int64_t Sp, float *__restrict__ m2_out) {
     int lane = threadIdx.x & 63;
     int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= Bpad) return;
@@ -127,32 +152,68 @@ __global__ __launch_bounds__(256) void k_convert(const double *__restrict__ X, i
     if (X64 && row < B)
         for (int64_t s = lane; s < Sp; s += 64) X64[row * Sp + s] = s < S ? X[row * S + s] : 0.0;
     const int slot = row < B ? sample_slot[row] : -1;   // >= 0: this row is one of the sampled rows
-    double acc = 0.0;
+    double gam = 1.0, inv_gam = 1.0;
+    if (MODE16) {
+        // every wave derives the same scale: typical |a| * gam lands in [4, 8) (float16 keeps
+        // 2^13 above that and 2^16 below it in its normal range)
+        double t = 0.0, c = 0.0;
+        for (int64_t s = lane; s < S; s += 64) {
+            const double m = mean[S + s];
+            if (isfinite(m) && m > 0.0) { t += m; c += 1.0; }
+        }
+        for (int o = 32; o > 0; o >>= 1) { t += __shfl_xor(t, o); c += __shfl_xor(c, o); }
+        if (c > 0.0 && isfinite(t)) {
+            int e = ilogb(t / c);
+            e = e < -60 ? -60 : (e > 60 ? 60 : e);
+            gam = ldexp(1.0, 2 - e);
+            inv_gam = ldexp(1.0, e - 2);
+        }
+        if (row == 0 && lane == 0) *m2_out = (float)(-2.0 * inv_gam * inv_gam);
+    }
+    double acc = 0.0, e2 = 0.0, hn = 0.0;
     for (int64_t s = lane; s < Kpad16; s += 64) {
         float a = 0.f;
         if (row < B && s < S) a = (float)(X[row * S + s] - mean[s]);
-        if (A && s < Kpad) A[row * Kpad + s] = a;
-        const unsigned short h = f32_to_bf16(a);
-        if (A3 && s < Kpad) {      // split image: per 32-sample slab, 32 hi then 32 lo bfloat16
-            const float hi_f = __uint_as_float((unsigned int)h << 16);
-            const int64_t at = row * (2 * Kpad) + (s >> 5) * 64 + (s & 31);
-            A3[at] = h;
-            A3[at + 32] = f32_to_bf16(a - hi_f);        // a - hi is exact in float32
+        unsigned short h;
+        if (MODE16) {
+            double back;
+            h = f32_to_f16_scaled(a, gam, inv_gam, back);
+            const double err = (double)a - back;
+            e2 += err * err;
+            hn += back * back;
+        } else {
+            if (A && s < Kpad) A[row * Kpad + s] = a;
+            h = f32_to_bf16(a);
+            if (A3 && s < Kpad) {      // split image: per 32-sample slab, 32 hi then 32 lo bfloat16
+                const float hi_f = __uint_as_float((unsigned int)h << 16);
+                const int64_t at = row * (2 * Kpad) + (s >> 5) * 64 + (s & 31);
+                A3[at] = h;
+                A3[at + 32] = f32_to_bf16(a - hi_f);        // a - hi is exact in float32
+            }
         }
         A16[row * Kpad16 + s] = h;
         if (slot >= 0) S16[(int64_t)slot * Kpad16 + s] = h;
         acc += (double)a * (double)a;
     }
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    for (int o = 32; o > 0; o >>= 1) {
+        acc += __shfl_xor(acc, o);
+        if (MODE16) { e2 += __shfl_xor(e2, o); hn += __shfl_xor(hn, o); }
+    }
     if (lane == 0) {
         float lo = INFINITY, hi = INFINITY;
         int ch = -1;
         int2 range = make_int2(0, 0);   // rows of this row's chromosome (padding rows: none)
         if (row < B) {
-            if (isfinite(acc) && acc < 1e37) {
+            if (isfinite(acc) && acc < 1e37 && (!MODE16 || (isfinite(e2) && isfinite(hn)))) {
                 // key = lo_i + lo_j - 2 dot must never exceed the true distance
-                lo = __double2float_rd(acc * (1.0 - beta) - 1e-37);
-                hi = __double2float_ru(acc * (1.0 + 1e-9));
+                if (MODE16) {
+                    const double m = fmax(acc, hn);
+                    lo = __double2float_rd(acc - (e2 / tau + tau * m) * (1.0 + 1e-9) - beta * m - 1e-37);
+                    hi = __double2float_ru(2.0 * (acc - (double)lo) * (1.0 + 1e-6) + 1e-37);
+                } else {
+                    lo = __double2float_rd(acc * (1.0 - beta) - 1e-37);
+                    hi = __double2float_ru(3.0 * beta * acc * (1.0 + 1e-9) * (1.0 + 1e-6));
+                }
             }
             int c = 0;
             while (c + 1 < n_chrom && row >= chrom_off[c + 1]) ++c;
@@ -196,7 +257,8 @@ struct GramArgs {
     int64_t ld;                  // padded sample count
     int nslab;                   // ld / 32
     int last_groups;             // groups of four MFMA steps of the last slab that hold samples (1..4)
-    int last_steps16;            // split mode: 16-sample MFMA steps of the last slab that hold samples (1..2)
+    int last_steps16;            // split / f16 modes: 16-sample MFMA steps of the last slab that hold samples (1..2 / 1..4)
+    const float *m2;             // f16 mode: -2 / gam^2 (the operand image is scaled by gam); NULL: -2
     const float *nbP, *nbQ;      // lower norm bounds
     const int2 *range;           // per row: [first, last+1) row of its chromosome (never candidates)
     const int4 *tiles;           // {I, J, roles, 0}
@@ -237,7 +299,7 @@ __device__ inline unsigned long long pack_entry(float key, int j) {
 // lane (i, h) feeds k = 16h + t at MFMA step t, so each lane fetches its 16
 // operands with four conflict-free ds_read_b128.
 //
-// SPLIT = true runs the same tile on the bf16 matrix cores: every float32 operand is stored as
+// MODE = GRAM_SPLIT runs the same tile on the bf16 matrix cores: every float32 operand is stored as
 // a pair of bfloat16 values (hi = bf16(a), lo = bf16(a - hi); a k-slab row is 32 hi then 32 lo,
 // the same 128 bytes), and a.b is accumulated as hi.hi + hi.lo + lo.hi in float32 -- three
 // v_mfma_f32_32x32x16_bf16 (8 passes for 16 samples each) instead of eight
@@ -246,7 +308,81 @@ __device__ inline unsigned long long pack_entry(float key, int j) {
 // hi+lo representation (2 * 2^-16) and the dropped lo.lo term (2^-16) stay below 3.1 * 2^-16 |a||b|;
 // that goes into beta (NewrefState::beta), i.e. into the lower / upper bounds every decision
 // rests on.
-template <bool SPLIT, int DEPTH>   // DEPTH: k-slabs of operand loads in flight (register staged; 2 only with SPLIT)
+// MODE = GRAM_F16 (the default) needs ONE product per multiply: the operand image is float16
+// (11 significant bits, scaled by a power of two), a k-slab row is 64 samples in the same 128
+// bytes, and the representation error of every row is known exactly (k_convert) and charged to
+// that row's norm bounds -- half the operand bytes, a third of the matrix-core work of the
+// bf16 pairs, about 2.3x their bound width (a few more candidates per row to re-score).
+constexpr int GRAM_F32 = 0, GRAM_SPLIT = 1, GRAM_F16 = 2;
+
+// the MFMA steps of one staged slab; nt = steps that hold samples (GRAM_F32: groups of four steps)
+template <int MODE>
+__device__ __forceinline__ void gram_steps(const float *As, const float *Bs, f32x16 (&acc)[2][2], int nt, int wr,
+                                           int wc, int li, int lh) {
+    if constexpr (MODE == GRAM_F16) {
+        // MFMA step t covers samples 16 t .. 16 t + 15 of the slab; lane half h supplies 8 consecutive
+        // ones, from the same slots for A and B
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t >= nt) break;
+            const int off = t * 8 + lh * 4;   // float units: (16 t + 8 h) halfs
+            const f16x8 a0 = *(const f16x8 *)&As[(wr * 64 + li) * LDA + off];
+            const f16x8 a1 = *(const f16x8 *)&As[(wr * 64 + 32 + li) * LDA + off];
+            const f16x8 b0 = *(const f16x8 *)&Bs[(wc * 64 + li) * LDA + off];
+            const f16x8 b1 = *(const f16x8 *)&Bs[(wc * 64 + 32 + li) * LDA + off];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    } else if constexpr (MODE == GRAM_SPLIT) {
+        // slab row = 32 hi | 32 lo bfloat16 (16 + 16 floats).  MFMA step t covers samples
+        // 16 t .. 16 t + 15 of the slab; lane half h supplies 8 consecutive ones, from the same
+        // slots for A and B.  The last slab stops after the steps that hold samples.
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (t >= nt) break;
+            const int off = t * 8 + lh * 4;       // float units within the hi half; lo half: + 16
+            const float *ar = &As[(wr * 64 + li) * LDA + off], *br = &Bs[(wc * 64 + li) * LDA + off];
+            const bf16x8 a0h = *(const bf16x8 *)ar, a0l = *(const bf16x8 *)(ar + 16);
+            const bf16x8 a1h = *(const bf16x8 *)(ar + 32 * LDA), a1l = *(const bf16x8 *)(ar + 32 * LDA + 16);
+            const bf16x8 b0h = *(const bf16x8 *)br, b0l = *(const bf16x8 *)(br + 16);
+            const bf16x8 b1h = *(const bf16x8 *)(br + 32 * LDA), b1l = *(const bf16x8 *)(br + 32 * LDA + 16);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b0h, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b1h, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b0h, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b1h, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0l, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b1l, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0l, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1l, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0h, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b1h, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0h, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1h, acc[1][1], 0, 0, 0);
+        }
+    } else {
+        const float *a0 = &As[(wr * 64 + li) * LDA + lh * 16], *a1 = a0 + 32 * LDA;
+        const float *b0 = &Bs[(wc * 64 + li) * LDA + lh * 16], *b1 = b0 + 32 * LDA;
+        // the last slab runs only the step groups that hold samples (lane half h feeds
+        // k = 16h + t; the padding beyond the sample count is zero)
+#pragma unroll
+        for (int tg = 0; tg < 4; ++tg) {
+            if (tg >= nt) break;
+            const f32x4 ca0 = *(const f32x4 *)(a0 + 4 * tg), ca1 = *(const f32x4 *)(a1 + 4 * tg);
+            const f32x4 cb0 = *(const f32x4 *)(b0 + 4 * tg), cb1 = *(const f32x4 *)(b1 + 4 * tg);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca0[e], cb0[e], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca0[e], cb1[e], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca1[e], cb0[e], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca1[e], cb1[e], acc[1][1], 0, 0, 0);
+            }
+        }
+    }
+}
+
+template <int MODE, int DEPTH>   // DEPTH: k-slabs of operand loads in flight (register staged; 2 not with GRAM_F32)
 __global__ __launch_bounds__(256, DEPTH == 2 ? 3 : 4) void k_gram(GramArgs g) {
     __shared__ __attribute__((aligned(16))) float sm[2 * TB * LDA + 4 * TB];   // dot tile: 128 * LDT <= 2 * TB * LDA
     float *As = sm;
@@ -268,6 +404,7 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 3 : 4) void k_gram(GramArgs g) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
     const int li = lane & 31, lh = lane >> 5;
+    const float m2 = MODE == GRAM_F16 ? *g.m2 : -2.f;
 
     if (tid < TB) {
         int64_t gp = (int64_t)I * TB + tid;
@@ -280,6 +417,7 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 3 : 4) void k_gram(GramArgs g) {
         thQs[c] = g.thr[gq];
     }
 
+    // a slab row is 128 bytes in every mode (32 floats / 32 hi + 32 lo bfloat16 / 64 float16)
     const int lrow = tid >> 3, lcol = (tid & 7) * 4;
     const float *Pg = g.P + ((int64_t)I * TB + lrow) * g.ld + lcol;
     const float *Qg = g.Q + ((int64_t)J * TB + lrow) * g.ld + lcol;
@@ -296,9 +434,12 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 3 : 4) void k_gram(GramArgs g) {
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    // steps of a full slab / of the last one
+    const int full = MODE == GRAM_F16 ? 4 : (MODE == GRAM_SPLIT ? 2 : 4);
+    const int last = MODE == GRAM_F32 ? g.last_groups : g.last_steps16;
 
     if constexpr (DEPTH == 2) {
-        // Two slabs of loads in flight: with the bf16 tiles one slab's 24 MFMAs (0.4 us) no longer
+        // Two slabs of loads in flight: with the 16-bit tiles one slab's MFMAs (0.4 us) no longer
         // cover a global round trip (~3 us under load), so the loads of slab s+2 are issued while
         // slab s is multiplied and slab s+1 is still on its way.  Costs 32 more registers: three
         // waves per SIMD instead of four.
@@ -312,28 +453,6 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 3 : 4) void k_gram(GramArgs g) {
             }
         }
         __builtin_amdgcn_s_setprio(2);
-#define WC_SPLIT_STEPS(NT)                                                                                      \
-    _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                            \
-        if (t >= (NT)) break;                                                                                  \
-        const int off = t * 8 + lh * 4;                                                                        \
-        const float *ar = &As[(wr * 64 + li) * LDA + off], *br = &Bs[(wc * 64 + li) * LDA + off];              \
-        const bf16x8 a0h = *(const bf16x8 *)ar, a0l = *(const bf16x8 *)(ar + 16);                              \
-        const bf16x8 a1h = *(const bf16x8 *)(ar + 32 * LDA), a1l = *(const bf16x8 *)(ar + 32 * LDA + 16);      \
-        const bf16x8 b0h = *(const bf16x8 *)br, b0l = *(const bf16x8 *)(br + 16);                              \
-        const bf16x8 b1h = *(const bf16x8 *)(br + 32 * LDA), b1l = *(const bf16x8 *)(br + 32 * LDA + 16);      \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b0h, acc[0][0], 0, 0, 0);                     \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b1h, acc[0][1], 0, 0, 0);                     \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b0h, acc[1][0], 0, 0, 0);                     \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b1h, acc[1][1], 0, 0, 0);                     \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0l, acc[0][0], 0, 0, 0);                     \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b1l, acc[0][1], 0, 0, 0);                     \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0l, acc[1][0], 0, 0, 0);                     \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1l, acc[1][1], 0, 0, 0);                     \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0h, acc[0][0], 0, 0, 0);                     \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b1h, acc[0][1], 0, 0, 0);                     \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0h, acc[1][0], 0, 0, 0);                     \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1h, acc[1][1], 0, 0, 0);                     \
-    }
         for (int slab = 0; slab < g.nslab; slab += 2) {
             __syncthreads();
 #pragma unroll
@@ -351,10 +470,7 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 3 : 4) void k_gram(GramArgs g) {
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            {
-                const int nt = slab + 1 < g.nslab ? 2 : g.last_steps16;
-                WC_SPLIT_STEPS(nt)
-            }
+            gram_steps<MODE>(As, Bs, acc, slab + 1 < g.nslab ? full : last, wr, wc, li, lh);
             if (slab + 1 >= g.nslab) break;
             __syncthreads();
 #pragma unroll
@@ -372,12 +488,8 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 3 : 4) void k_gram(GramArgs g) {
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            {
-                const int nt = slab + 2 < g.nslab ? 2 : g.last_steps16;
-                WC_SPLIT_STEPS(nt)
-            }
+            gram_steps<MODE>(As, Bs, acc, slab + 2 < g.nslab ? full : last, wr, wc, li, lh);
         }
-#undef WC_SPLIT_STEPS
     } else {
     __builtin_amdgcn_s_setprio(2);   // waves feeding the matrix cores go ahead of waves in their epilogue
     for (int slab = 0; slab < g.nslab; ++slab) {
@@ -399,53 +511,7 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 3 : 4) void k_gram(GramArgs g) {
         // keep the prefetch above the MFMA phase: the staging registers stay live, and the
         // fragments are fetched in four groups of four steps (16 live floats) instead
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (SPLIT) {
-            // slab row = 32 hi | 32 lo bfloat16 (16 + 16 floats).  MFMA step t covers samples
-            // 16 t .. 16 t + 15 of the slab; lane half h supplies 8 consecutive ones, from the same
-            // slots for A and B.  The last slab stops after the steps that hold samples.
-            const int nt = slab + 1 < g.nslab ? 2 : g.last_steps16;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if (t >= nt) break;
-                const int off = t * 8 + lh * 4;       // float units within the hi half; lo half: + 16
-                const float *ar = &As[(wr * 64 + li) * LDA + off], *br = &Bs[(wc * 64 + li) * LDA + off];
-                const bf16x8 a0h = *(const bf16x8 *)ar, a0l = *(const bf16x8 *)(ar + 16);
-                const bf16x8 a1h = *(const bf16x8 *)(ar + 32 * LDA), a1l = *(const bf16x8 *)(ar + 32 * LDA + 16);
-                const bf16x8 b0h = *(const bf16x8 *)br, b0l = *(const bf16x8 *)(br + 16);
-                const bf16x8 b1h = *(const bf16x8 *)(br + 32 * LDA), b1l = *(const bf16x8 *)(br + 32 * LDA + 16);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b0h, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b1h, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b0h, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b1h, acc[1][1], 0, 0, 0);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0l, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b1l, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0l, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1l, acc[1][1], 0, 0, 0);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0h, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b1h, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0h, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1h, acc[1][1], 0, 0, 0);
-            }
-        } else {
-            const float *a0 = &As[(wr * 64 + li) * LDA + lh * 16], *a1 = a0 + 32 * LDA;
-            const float *b0 = &Bs[(wc * 64 + li) * LDA + lh * 16], *b1 = b0 + 32 * LDA;
-            // the last slab runs only the step groups that hold samples (lane half h feeds
-            // k = 16h + t; the padding beyond the sample count is zero)
-            const int ntg = slab + 1 < g.nslab ? 4 : g.last_groups;
-#pragma unroll
-            for (int tg = 0; tg < 4; ++tg) {
-                if (tg >= ntg) break;
-                const f32x4 ca0 = *(const f32x4 *)(a0 + 4 * tg), ca1 = *(const f32x4 *)(a1 + 4 * tg);
-                const f32x4 cb0 = *(const f32x4 *)(b0 + 4 * tg), cb1 = *(const f32x4 *)(b1 + 4 * tg);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca0[e], cb0[e], acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca0[e], cb1[e], acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca1[e], cb0[e], acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca1[e], cb1[e], acc[1][1], 0, 0, 0);
-                }
-            }
-        }
+        gram_steps<MODE>(As, Bs, acc, slab + 1 < g.nslab ? full : last, wr, wc, li, lh);
     }
 
     }   // DEPTH
@@ -500,7 +566,7 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 3 : 4) void k_gram(GramArgs g) {
                 const f32x4 nb4 = nbv[g4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float key = fmaf(-2.f, dv[4 * g4 + e], nb4[e] + nbc);
+                    float key = fmaf(m2, dv[4 * g4 + e], nb4[e] + nbc);
                     mask_c |= (key <= th) ? (1u << (4 * g4 + e)) : 0u;
                 }
             }
@@ -517,7 +583,7 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 3 : 4) void k_gram(GramArgs g) {
                 const f32x4 nb4 = nbv[g4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float key = fmaf(-2.f, dv[4 * g4 + e], nbr + nb4[e]);
+                    float key = fmaf(m2, dv[4 * g4 + e], nbr + nb4[e]);
                     mask_r |= (key <= th) ? (1u << (4 * g4 + e)) : 0u;
                 }
             }
@@ -536,7 +602,7 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 3 : 4) void k_gram(GramArgs g) {
                 int rr = __ffs((int)mask_c) - 1;
                 mask_c &= mask_c - 1;
                 int l = q * 32 + rr, r = h * 64 + l;
-                float key = fmaf(-2.f, D[x * LDT + l], nbPs[r] + nbc);
+                float key = fmaf(m2, D[x * LDT + l], nbPs[r] + nbc);
                 if (base_c < g.cap) dst[base_c] = pack_entry(key, I * TB + r);
                 ++base_c;
             }
@@ -548,7 +614,7 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 3 : 4) void k_gram(GramArgs g) {
                 int cc = __ffs((int)mask_r) - 1;
                 mask_r &= mask_r - 1;
                 int c = cq * 32 + cc;
-                float key = fmaf(-2.f, D[c * LDT + lr], nbr + nbQs[c]);
+                float key = fmaf(m2, D[c * LDT + lr], nbr + nbQs[c]);
                 if (base_r < g.cap) dst[base_r] = pack_entry(key, J * TB + c);
                 ++base_r;
             }
@@ -564,13 +630,15 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 3 : 4) void k_gram(GramArgs g) {
 // rate, ~0.4 % error on the dot products, i.e. a ~10 % wobble of the candidate count.
 // Same 128x128 tile / 4 waves / LDS byte layout as k_gram; a slab is 64 bf16 (128 B) deep.
 
+template <bool F16>   // operands are float16 (scaled by gam, *m2 = -2 / gam^2) instead of bfloat16
 __global__ __launch_bounds__(256, 4) void k_gram_thr16(const unsigned short *__restrict__ P16,
                                                        const unsigned short *__restrict__ Q16, int64_t ld16,
                                                        int nslab, const float *__restrict__ nbP,
                                                        const float *__restrict__ nbQ,
                                                        const int2 *__restrict__ rangeQ,
                                                        const int4 *__restrict__ tiles, int ntiles,
-                                                       unsigned int *__restrict__ keys, int64_t ldo) {
+                                                       unsigned int *__restrict__ keys, int64_t ldo,
+                                                       const float *__restrict__ m2p) {
     __shared__ __attribute__((aligned(16))) float sm[2 * TB * LDA + 2 * TB];
     float *As = sm;
     float *Bs = sm + TB * LDA;
@@ -626,16 +694,28 @@ __global__ __launch_bounds__(256, 4) void k_gram_thr16(const unsigned short *__r
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int off = t * 8 + lh * 4;   // float units: (16 t + 8 h) bf16 = 32 t + 16 h bytes
-            const bf16x8 a0 = *(const bf16x8 *)&As[(wr * 64 + li) * LDA + off];
-            const bf16x8 a1 = *(const bf16x8 *)&As[(wr * 64 + 32 + li) * LDA + off];
-            const bf16x8 b0 = *(const bf16x8 *)&Bs[(wc * 64 + li) * LDA + off];
-            const bf16x8 b1 = *(const bf16x8 *)&Bs[(wc * 64 + 32 + li) * LDA + off];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            if constexpr (F16) {
+                const f16x8 a0 = *(const f16x8 *)&As[(wr * 64 + li) * LDA + off];
+                const f16x8 a1 = *(const f16x8 *)&As[(wr * 64 + 32 + li) * LDA + off];
+                const f16x8 b0 = *(const f16x8 *)&Bs[(wc * 64 + li) * LDA + off];
+                const f16x8 b1 = *(const f16x8 *)&Bs[(wc * 64 + 32 + li) * LDA + off];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+            } else {
+                const bf16x8 a0 = *(const bf16x8 *)&As[(wr * 64 + li) * LDA + off];
+                const bf16x8 a1 = *(const bf16x8 *)&As[(wr * 64 + 32 + li) * LDA + off];
+                const bf16x8 b0 = *(const bf16x8 *)&Bs[(wc * 64 + li) * LDA + off];
+                const bf16x8 b1 = *(const bf16x8 *)&Bs[(wc * 64 + 32 + li) * LDA + off];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            }
         }
     }
+    const float m2 = F16 ? *m2p : -2.f;
     const int cp = tid & 63, rq = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float nbc0 = nbQs[2 * cp], nbc1 = nbQs[2 * cp + 1];
     const int2 rg0 = rangeQ[(int64_t)J * TB + 2 * cp], rg1 = rangeQ[(int64_t)J * TB + 2 * cp + 1];
@@ -678,8 +758,8 @@ __global__ __launch_bounds__(256, 4) void k_gram_thr16(const unsigned short *__r
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int rr = 4 * g4 + e;
-                unsigned int c0 = key_code16(fmaf(-2.f, d0[rr], nb4[e] + nbc0));
-                unsigned int c1 = key_code16(fmaf(-2.f, d1[rr], nb4[e] + nbc1));
+                unsigned int c0 = key_code16(fmaf(m2, d0[rr], nb4[e] + nbc0));
+                unsigned int c1 = key_code16(fmaf(m2, d1[rr], nb4[e] + nbc1));
                 if ((ex0 >> rr) & 1u) c0 = 0xFFFFu;     // same chromosome: never a candidate
                 if ((ex1 >> rr) & 1u) c1 = 0xFFFFu;
                 out[(int64_t)rr * (ldo >> 1)] = c0 | (c1 << 16);
@@ -966,7 +1046,7 @@ __global__ __launch_bounds__(NT, 4) void k_finish(FinishArgs a) {
                 if (t < n) {
                     uint32_t ku = (uint32_t)(ent[t] >> 32);
                     if (ku <= kth) {
-                        double ub = (double)wc::f32_from_ordered(ku) + 3.0 * a.beta * (nhi + (double)nh[e]) + 1e-36;
+                        double ub = (double)wc::f32_from_ordered(ku) + (nhi + (double)nh[e]) + 1e-36;
                         my = fmax(my, ub);
                     }
                 }
@@ -1271,7 +1351,7 @@ __device__ inline int pick_row(const PickArgs &p, int64_t row, int lane, int n, 
         for (int e = 0; e < NE; ++e) {
             const uint32_t ku = (uint32_t)(ent[e] >> 32);
             if (e * 64 + lane < n && ku <= res) {
-                const double ub = (double)wc::f32_from_ordered(ku) + 3.0 * a.beta * (nhi + (double)nh[e]) + 1e-36;
+                const double ub = (double)wc::f32_from_ordered(ku) + (nhi + (double)nh[e]) + 1e-36;
                 my = fmax(my, ub);
             }
         }
@@ -1893,15 +1973,20 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
     st.cap = LIST_CAP;
     st.expect = LIST_CAP * 3 / 8;     // 384: k = 100 is 4 sigma of the sampled order statistic away, the cap 6
     {
-        const char *e = getenv("WC_GRAM_MODE");           // "f32": float32 matrix cores; default: split bfloat16
-        st.split = !(e && strcmp(e, "f32") == 0);
+        // "f32": float32 matrix cores; "split": bfloat16 hi/lo pairs (three products per multiply);
+        // default "f16": one float16 product per multiply, representation error charged per row
+        const char *e = getenv("WC_GRAM_MODE");
+        st.gram_mode = (e && strcmp(e, "f32") == 0) ? 0 : ((e && strcmp(e, "split") == 0) ? 1 : 2);
+        st.split = st.gram_mode == 1;
     }
     // relative half-width of the key error interval: the float32 accumulation chain (doubled in
-    // split mode: nothing is assumed about the rounding inside the bf16 dot products beyond 2^-23
-    // per term) plus, in split mode, the hi+lo representation and the dropped lo.lo term
-    st.beta = st.split
-                  ? (float)(((double)(n_samples + 16) * 2.0 * 5.9604644775390625e-08 + 3.1 * 1.52587890625e-05) * 1.001)
-                  : (float)((double)(n_samples + 16) * 5.9604644775390625e-08 * 1.001);
+    // the 16-bit modes: nothing is assumed about the rounding inside the matrix cores' dot products
+    // beyond 2^-23 per term) plus, in split mode, the hi+lo representation and the dropped lo.lo
+    // term.  The f16 mode charges its representation error per row (k_convert, tau).
+    const double chain = (double)(n_samples + 16) * 5.9604644775390625e-08;
+    st.beta = st.gram_mode == 1 ? (float)((2.0 * chain + 3.1 * 1.52587890625e-05) * 1.001)
+              : st.gram_mode == 2 ? (float)(2.0 * chain * 1.001) : (float)(chain * 1.001);
+    st.tau = 2.44140625e-04;      // 2^-12: round-to-nearest float16 leaves |a - h| ~ 1.9e-4 |a| (rms)
     int64_t M = round_up((n_bins + 13) / 14, TB);
     if (M < 512) M = 512;
     if (M > MAX_SAMPLE_COLS) M = MAX_SAMPLE_COLS;
@@ -1920,8 +2005,9 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
     }
     if (st.x64_pad && (rc = st.x64.reserve(sizeof(double) * st.bins_pad * st.s_pad))) return rc;
     // one operand image: float32 for the fp32 matrix cores, hi/lo bfloat16 pairs for the split tiles
-    if (!st.split && (rc = st.a32.reserve(sizeof(float) * st.bins_pad * st.k_pad))) return rc;
-    if (st.split && (rc = st.a3.reserve(sizeof(float) * st.bins_pad * st.k_pad))) return rc;
+    if (st.gram_mode == 0 && (rc = st.a32.reserve(sizeof(float) * st.bins_pad * st.k_pad))) return rc;
+    if (st.gram_mode == 1 && (rc = st.a3.reserve(sizeof(float) * st.bins_pad * st.k_pad))) return rc;
+    if ((rc = st.m2.reserve(sizeof(float) * 4))) return rc;
     if ((rc = st.norm_lo.reserve(sizeof(float) * st.bins_pad))) return rc;
     if ((rc = st.norm_hi.reserve(sizeof(float) * st.bins_pad))) return rc;
     if ((rc = st.chrom_of_row.reserve(sizeof(int) * st.bins_pad))) return rc;
@@ -1994,16 +2080,20 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
                            n_bins, n_samples, n_rows, row_step, mean2);
     }
 
-    hipLaunchKernelGGL(k_convert, dim3((unsigned)(st.bins_pad / 4)), dim3(256), 0, stream, corrected, n_bins,
-                       n_samples, st.bins_pad, st.k_pad, (const double *)mean2, (double)st.beta,
-                       st.chrom_off_dev.as<int64_t>(), n_chrom, st.split ? (float *)nullptr : st.a32.as<float>(),
-                       st.a16.as<unsigned short>(),
-                       st.k_pad16, st.norm_lo.as<float>(), st.norm_hi.as<float>(), st.chrom_of_row.as<int>(),
-                       st.chrom_range.as<int2>(), (const int *)st.sample_slot.as<int>(),
-                       st.s16.as<unsigned short>(), st.s_norm_lo.as<float>(), st.s_chrom.as<int>(),
-                       st.s_range.as<int2>(), st.thr.as<float>(), st.cnt.as<int>(), st.stats.as<int>(),
-                       st.split ? st.a3.as<unsigned short>() : (unsigned short *)nullptr,
-                       st.x64_pad ? st.x64.as<double>() : (double *)nullptr, st.s_pad);
+#define WC_CONVERT(M16)                                                                                         \
+    hipLaunchKernelGGL(k_convert<M16>, dim3((unsigned)(st.bins_pad / 4)), dim3(256), 0, stream, corrected, n_bins, \
+                       n_samples, st.bins_pad, st.k_pad, (const double *)mean2, (double)st.beta, st.tau,           \
+                       st.chrom_off_dev.as<int64_t>(), n_chrom,                                                    \
+                       st.gram_mode == 0 ? st.a32.as<float>() : (float *)nullptr, st.a16.as<unsigned short>(),    \
+                       st.k_pad16, st.norm_lo.as<float>(), st.norm_hi.as<float>(), st.chrom_of_row.as<int>(),      \
+                       st.chrom_range.as<int2>(), (const int *)st.sample_slot.as<int>(),                           \
+                       st.s16.as<unsigned short>(), st.s_norm_lo.as<float>(), st.s_chrom.as<int>(),                \
+                       st.s_range.as<int2>(), st.thr.as<float>(), st.cnt.as<int>(), st.stats.as<int>(),            \
+                       st.gram_mode == 1 ? st.a3.as<unsigned short>() : (unsigned short *)nullptr,                 \
+                       st.x64_pad ? st.x64.as<double>() : (double *)nullptr, st.s_pad, st.m2.as<float>())
+    if (st.gram_mode == 2) WC_CONVERT(1);
+    else WC_CONVERT(0);
+#undef WC_CONVERT
     if (M > n_bins)
         hipLaunchKernelGGL(k_pad_samples, dim3((unsigned)(M - n_bins)), dim3(256), 0, stream, st.k_pad16, n_bins,
                            st.s16.as<unsigned short>(), st.s_norm_lo.as<float>(), st.s_chrom.as<int>(),
@@ -2037,12 +2127,16 @@ int wc_newref_thresholds_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int6
     {
         const int ntiles = (int)st.tiles0_n;
         unsigned grid = (unsigned)(((ntiles + 7) / 8) * 8);
-        hipLaunchKernelGGL(k_gram_thr16, dim3(grid), dim3(256), 0, stream,
-                           (const unsigned short *)st.a16.as<unsigned short>(),
-                           (const unsigned short *)st.s16.as<unsigned short>(), st.k_pad16, (int)(st.k_pad16 / 64),
-                           (const float *)st.norm_lo.as<float>(), (const float *)st.s_norm_lo.as<float>(),
-                           (const int2 *)st.s_range.as<int2>(), (const int4 *)st.tiles0.as<int4>(), ntiles,
-                           st.keys1.as<unsigned int>(), st.n_sample_cols);
+#define WC_THR16(F16)                                                                                           \
+    hipLaunchKernelGGL(k_gram_thr16<F16>, dim3(grid), dim3(256), 0, stream,                                        \
+                       (const unsigned short *)st.a16.as<unsigned short>(),                                        \
+                       (const unsigned short *)st.s16.as<unsigned short>(), st.k_pad16, (int)(st.k_pad16 / 64),    \
+                       (const float *)st.norm_lo.as<float>(), (const float *)st.s_norm_lo.as<float>(),             \
+                       (const int2 *)st.s_range.as<int2>(), (const int4 *)st.tiles0.as<int4>(), ntiles,            \
+                       st.keys1.as<unsigned int>(), st.n_sample_cols, (const float *)st.m2.as<float>())
+        if (st.gram_mode == 2) WC_THR16(true);
+        else WC_THR16(false);
+#undef WC_THR16
     }
     unsigned sg = (unsigned)((row_end - row_begin + 3) / 4);
     {
@@ -2071,6 +2165,19 @@ int wc_newref_get_thresholds_dev(wc_ctx *ctx, void *stream, int64_t row_begin, i
     if (row_end > row_begin)
         WC_HIP(hipMemcpyAsync(out, ctx->nr.thr.as<float>() + row_begin, sizeof(float) * (row_end - row_begin),
                               hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return WC_OK;
+}
+
+int wc_newref_get_bounds_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end, float *lo_out,
+                             float *slack_out) {
+    WC_CHECK(ctx && ctx->nr.prepared && lo_out && slack_out, WC_E_ARG, "newref: bad argument");
+    WC_CHECK(row_begin >= 0 && row_begin <= row_end && row_end <= ctx->nr.n_bins, WC_E_ARG, "newref: bad row range");
+    if (row_end > row_begin) {
+        WC_HIP(hipMemcpyAsync(lo_out, ctx->nr.norm_lo.as<float>() + row_begin, sizeof(float) * (row_end - row_begin),
+                              hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        WC_HIP(hipMemcpyAsync(slack_out, ctx->nr.norm_hi.as<float>() + row_begin, sizeof(float) * (row_end - row_begin),
+                              hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
     return WC_OK;
 }
 
@@ -2135,13 +2242,23 @@ int wc_newref_collect_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t
     ctx->last_stats[3] = st.n_sample_cols;
     if (st.tiles1_n == 0) return WC_OK;
     GramArgs g{};
-    g.P = g.Q = st.split ? st.a3.as<float>() : st.a32.as<float>();
-    g.ld = st.k_pad;
-    g.nslab = (int)(st.k_pad / BK);
-    {
+    if (st.gram_mode == 2) {
+        // the float16 image the threshold estimate used: rows of k_pad16 halfs, 64 samples per slab
+        g.P = g.Q = st.a16.as<float>();
+        g.ld = st.k_pad16 / 2;
+        g.nslab = (int)(st.k_pad16 / 64);
+        const int64_t rem = st.n_samples - (int64_t)(g.nslab - 1) * 64;     // samples in the last slab, 1..64
+        g.last_groups = 4;
+        g.last_steps16 = (int)((rem + 15) / 16);
+        g.m2 = st.m2.as<float>();
+    } else {
+        g.P = g.Q = st.split ? st.a3.as<float>() : st.a32.as<float>();
+        g.ld = st.k_pad;
+        g.nslab = (int)(st.k_pad / BK);
         const int64_t rem = st.n_samples - (int64_t)(g.nslab - 1) * BK;     // samples in the last slab, 1..32
         g.last_groups = (int)((std::min<int64_t>(rem, 16) + 3) / 4);
         g.last_steps16 = rem > 16 ? 2 : 1;
+        g.m2 = nullptr;
     }
     g.nbP = g.nbQ = st.norm_lo.as<float>();
     g.range = st.chrom_range.as<int2>();
@@ -2152,12 +2269,18 @@ int wc_newref_collect_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t
     g.list = st.list.as<unsigned long long>();
     g.cap = (int)st.cap;
     unsigned grid = (unsigned)(((g.ntiles + 7) / 8) * 8);
-    if (st.split) {
+    {
         const char *e = getenv("WC_GRAM_DEPTH");
-        if (e && atoi(e) == 1) hipLaunchKernelGGL((k_gram<true, 1>), dim3(grid), dim3(256), 0, stream, g);
-        else hipLaunchKernelGGL((k_gram<true, 2>), dim3(grid), dim3(256), 0, stream, g);
-    } else {
-        hipLaunchKernelGGL((k_gram<false, 1>), dim3(grid), dim3(256), 0, stream, g);
+        const bool d1 = e && atoi(e) == 1;
+        if (st.gram_mode == 2) {
+            if (d1) hipLaunchKernelGGL((k_gram<GRAM_F16, 1>), dim3(grid), dim3(256), 0, stream, g);
+            else hipLaunchKernelGGL((k_gram<GRAM_F16, 2>), dim3(grid), dim3(256), 0, stream, g);
+        } else if (st.gram_mode == 1) {
+            if (d1) hipLaunchKernelGGL((k_gram<GRAM_SPLIT, 1>), dim3(grid), dim3(256), 0, stream, g);
+            else hipLaunchKernelGGL((k_gram<GRAM_SPLIT, 2>), dim3(grid), dim3(256), 0, stream, g);
+        } else {
+            hipLaunchKernelGGL((k_gram<GRAM_F32, 1>), dim3(grid), dim3(256), 0, stream, g);
+        }
     }
     WC_HIP(hipGetLastError());
     return WC_OK;

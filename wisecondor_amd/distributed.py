@@ -58,6 +58,9 @@ class HipStages(object):
     def get_thr(self, rb, re, out):
         _lib.check(self.lib.wc_newref_get_thresholds_dev(self.ctx, self._stream(), rb, re, out.data_ptr()))
 
+    def get_bounds(self, rb, re, lo, slack):
+        _lib.check(self.lib.wc_newref_get_bounds_dev(self.ctx, self._stream(), rb, re, lo.data_ptr(), slack.data_ptr()))
+
     def set_thr(self, rb, re, src):
         _lib.check(self.lib.wc_newref_set_thresholds_dev(self.ctx, self._stream(), rb, re, src.data_ptr()))
 
