@@ -56,7 +56,7 @@ def run_reference(i):
     refpath = os.path.join(tmp, "reference.npz")
     np.savez(refpath, **ref)
     sp = os.path.join(tmp, "sample.npz")
-    np.savez(sp, sample=sample, binsize=cfg5_case.BINSIZE, quality={}, arguments={}, runtime={})
+    np.savez(sp, sample=sample, quality={}, arguments={"binsize": float(cfg5_case.BINSIZE)}, runtime={})
     op = os.path.join(tmp, "out.npz")
     args = argparse.Namespace(infile=sp, outfile=op, reference=refpath, minzscore=None,
                               chromosomes=list(range(1, 23)), mineffectsize=0, multitest=1000,

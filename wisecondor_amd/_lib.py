@@ -87,7 +87,9 @@ def load():
                 "%s is missing and could not be built (%s): run `python -m wisecondor_amd.build` "
                 "(this package has no CPU fallback)" % (LIB_PATH, exc))
     _share_torch_hip_runtime()
-    lib = ctypes.CDLL(LIB_PATH)
+    # WC_LIB_PATH: a differently built copy of the library (kernel A/B experiments); same C ABI
+    lib = ctypes.CDLL(os.environ.get("WC_LIB_PATH") or LIB_PATH)
+    _warn_if_two_hip_runtimes()
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res
@@ -112,8 +114,27 @@ def _share_torch_hip_runtime():
     if os.path.exists(path):
         try:
             ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
-        except OSError:
-            pass
+        except OSError as exc:
+            import warnings
+            warnings.warn("wisecondor_amd: could not preload torch's HIP runtime %s (%s); importing torch "
+                          "after this library may initialise a second runtime that sees no GPU" % (path, exc))
+
+
+def _warn_if_two_hip_runtimes():
+    """The preload above only helps if libwisecondor_hip.so's DT_NEEDED soname resolves to torch's
+    copy.  With a different soname both runtimes get mapped and the second one sees no GPU: say so
+    instead of failing later with an unrelated error."""
+    try:
+        with open("/proc/self/maps") as f:
+            libs = {line.split()[-1] for line in f if "libamdhip64.so" in line}
+    except OSError:
+        return
+    real = {os.path.realpath(p) for p in libs}
+    if len(real) > 1:
+        import warnings
+        warnings.warn("wisecondor_amd: two HIP runtimes are mapped in this process (%s); the library was "
+                      "built against a different libamdhip64 than the one torch bundles -- rebuild it with "
+                      "the matching ROCm or expect 'no HIP device' errors" % ", ".join(sorted(real)))
 
 
 def check(rc):

@@ -1,6 +1,7 @@
 // Shared helpers for the gfx950 WISECONDOR kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -35,8 +36,8 @@ void set_error(const char *fmt, ...);
 
 // Counts the (re)allocations of every DevBuf of the process: a captured hipGraph bakes device
 // addresses in, so whoever caches one compares this number before replaying it.
-inline unsigned long long &realloc_epoch() {
-    static unsigned long long epoch = 0;
+inline std::atomic<unsigned long long> &realloc_epoch() {
+    static std::atomic<unsigned long long> epoch{0};
     return epoch;
 }
 

@@ -35,6 +35,11 @@ struct NewrefState {
     // host-side caches so that repeated calls on the same layout enqueue kernels only
     std::vector<int64_t> sample_key, tiles0_key, tiles1_key, chrom_key;
     int64_t tiles0_n = 0, tiles1_n = 0;
+    // wc_get_reference_dev: the whole pass as one hipGraph once the same call has been seen twice
+    hipGraphExec_t pass_exec = nullptr;
+    std::vector<int64_t> pass_key, pass_fail_key;   // the call the graph (or the warm eager pass) belongs to / one whose capture failed
+    unsigned long long pass_epoch = 0;              // wc::realloc_epoch() when the workspaces were last known to be in place
+    bool pass_warm = false;
 };
 
 // Workspaces of the batched test path (grow-only, reused across calls).
@@ -52,7 +57,7 @@ struct TestState {
     // latency mode: the captured call (hipGraph), the arguments it was captured for, and whether
     // an eager call of that shape has sized the workspaces
     hipGraphExec_t lat_exec = nullptr;
-    std::vector<int64_t> lat_key;
+    std::vector<int64_t> lat_key, lat_fail_key;   // lat_fail_key: a shape whose capture failed stays on the eager latency kernels
     bool lat_warm = false;
     unsigned long long lat_epoch = 0;   // wc::realloc_epoch() at capture time            // latency mode: index of the counter that holds the jobs left after the last round
     // optional stage timing of wc_test_batch_dev (wc_test_profile): events on the launch stream
@@ -94,7 +99,7 @@ struct wc_ctx {
     int64_t last_stats[8] = {0};
     // side stream for work that only feeds an output (overlaps with the main stream)
     hipStream_t lat_stream = nullptr;      // latency-mode calls of the test path run (and are captured) here
-    hipEvent_t ev_lat_in = nullptr;
+    hipEvent_t ev_lat_in = nullptr, ev_lat_out = nullptr;
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool side_pending = false;

@@ -152,6 +152,16 @@ __global__ __launch_bounds__(256) void k_convert(const double *__restrict__ X, i
     if (X64 && row < B)
         for (int64_t s = lane; s < Sp; s += 64) X64[row * Sp + s] = s < S ? X[row * S + s] : 0.0;
     const int slot = row < B ? sample_slot[row] : -1;   // >= 0: this row is one of the sampled rows
+    // chromosome of the row: lane c holds the end of chromosome c, the row's chromosome is the
+    // number of ends at or below it (the serial search was up to 22 dependent loads on lane 0)
+    int ch_w = -1;
+    int2 range_w = make_int2(0, 0);
+    if (row < B) {
+        const int64_t endc = lane < n_chrom ? chrom_off[lane + 1] : (int64_t)0x7FFFFFFFFFFFFFFFll;
+        int c = __popcll(__ballot(lane < n_chrom - 1 && row >= endc));
+        ch_w = c;
+        range_w = make_int2((int)(c ? __shfl(endc, c - 1) : 0), (int)__shfl(endc, c));
+    }
     double gam = 1.0, inv_gam = 1.0;
     if (MODE16) {
         // every wave derives the same scale: typical |a| * gam lands in [4, 8) (float16 keeps
@@ -215,10 +225,8 @@ __global__ __launch_bounds__(256) void k_convert(const double *__restrict__ X, i
                     hi = __double2float_ru(3.0 * beta * acc * (1.0 + 1e-9) * (1.0 + 1e-6));
                 }
             }
-            int c = 0;
-            while (c + 1 < n_chrom && row >= chrom_off[c + 1]) ++c;
-            ch = c;
-            range = make_int2((int)chrom_off[c], (int)chrom_off[c + 1]);
+            ch = ch_w;
+            range = range_w;
         }
         chrom_range[row] = range;
         norm_lo[row] = lo;
@@ -1294,7 +1302,7 @@ struct PickArgs {
 // when the row has no certificate (exact path).
 template <int NE>
 __device__ inline int pick_row(const PickArgs &p, int64_t row, int lane, int n, bool admit_all, float thr_f,
-                               float nhi_f) {
+                               float nhi_f, const unsigned long long (&spec)[8]) {
     const FinishArgs &a = p.f;
     const unsigned long long *lst = a.list + row * a.cap;
     unsigned long long ent[NE];
@@ -1302,7 +1310,7 @@ __device__ inline int pick_row(const PickArgs &p, int64_t row, int lane, int n, 
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
         const int t = e * 64 + lane;
-        ent[e] = t < n ? lst[t] : ~0ull;
+        ent[e] = t < n ? (e < 8 ? spec[e] : lst[t]) : ~0ull;
     }
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
@@ -1378,6 +1386,11 @@ __global__ __launch_bounds__(256) void k_pick(PickArgs p) {
     const int lane = threadIdx.x & 63;
     const int64_t row = a.row_begin + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.row_end) return;
+    // the first 512 list slots (the expected length is 384) are requested together with the count:
+    // one round trip less before the row's work can start (slots beyond the count are never used)
+    unsigned long long spec[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) spec[e] = a.list[row * a.cap + e * 64 + lane];
     const int c = a.cnt[row];
     const float thr_f = a.thr[row];
     const float nhi_f = a.norm_hi[row];
@@ -1385,8 +1398,8 @@ __global__ __launch_bounds__(256) void k_pick(PickArgs p) {
     const bool admit_all = (thr_f == WC_ADMIT_ALL);
     const bool exact = c > a.cap || ((a.lone_mask >> ch) & 1ull);   // lost entries / C-ordered chromData: exact path
     int R = -1;
-    if (!exact) R = c <= 512 ? pick_row<8>(p, row, lane, c, admit_all, thr_f, nhi_f)
-                             : pick_row<LIST_CAP / 64>(p, row, lane, c, admit_all, thr_f, nhi_f);
+    if (!exact) R = c <= 512 ? pick_row<8>(p, row, lane, c, admit_all, thr_f, nhi_f, spec)
+                             : pick_row<LIST_CAP / 64>(p, row, lane, c, admit_all, thr_f, nhi_f, spec);
     if (lane != 0) return;
     if (R < 0 || R > RMAX) {
         const int at = atomicAdd(a.fb_count, 1);
@@ -1514,14 +1527,18 @@ __global__ __launch_bounds__(PS_MAX, SEQ ? 4 : 3) void k_rescore(PickArgs p, con
     extern __shared__ __attribute__((aligned(16))) double rs_dyn[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t row = a.row_begin + blockIdx.x;
+    // the row's state, its own values and the first trip's pairs are requested together: three
+    // dependent round trips were a third of a row's life at 100 samples (the pair slots beyond the
+    // row's count hold stale indexes; they are replaced below before anything is gathered)
+    const int cj_first = p.pairs[row * RMAX + tid];      // tid < ps <= RMAX
     const int R = a.row_stat[row];
-    if (R < 0) return;                                   // exact path (workgroup-uniform)
     double *xs = rs_dyn;
     char *slab = reinterpret_cast<char *>(rs_dyn + Sp + w * SLAB_DOUBLES);
     {
         const double *xi = Xp + row * Sp;
         for (int s = tid; s < Sp; s += p.ps) xs[s] = xi[s];
     }
+    if (R < 0) return;                                   // exact path (workgroup-uniform)
     __syncthreads();
     const int l8 = lane & 7, r0 = lane >> 3;
     constexpr int NP = 8;                                // 8 rows per pass x 8 passes = the wave's 64 candidates
@@ -1542,7 +1559,8 @@ __global__ __launch_bounds__(PS_MAX, SEQ ? 4 : 3) void k_rescore(PickArgs p, con
     for (int b0 = w * 64; b0 < R; b0 += p.ps, ++trip) {
         const int nb = R - b0 < 64 ? R - b0 : 64;        // pairs of this wave in this trip
         const int *cjp = p.pairs + row * RMAX + b0;
-        const int cj = cjp[lane < nb ? lane : 0];        // lanes beyond nb re-read the trip's first candidate; their sums are dropped
+        int cj = trip == 0 ? cj_first : cjp[lane < nb ? lane : 0];
+        if (trip == 0) cj = __shfl(cj, lane < nb ? lane : 0);   // lanes beyond nb take the trip's first candidate; their sums are dropped
         unsigned int src[NP];                            // byte offset of this lane's 16 bytes in chunk 0 of row r0 + 8 q
 #pragma unroll
         for (int q = 0; q < NP; ++q)
@@ -2386,15 +2404,111 @@ int wc_newref_fallback_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t
     return newref_finish_part(ctx, stream, row_begin, row_end, idx_out, dist_out, 2);
 }
 
-int wc_get_reference_dev(wc_ctx *ctx, void *stream, const double *corrected, int64_t n_bins, int64_t n_samples,
-                         const int64_t *chrom_bins_host, int n_chrom, int k, int sum_order,
-                         int64_t row_begin, int64_t row_end, int32_t *idx_out, double *dist_out) {
+static int newref_pass(wc_ctx *ctx, void *stream, const double *corrected, int64_t n_bins, int64_t n_samples,
+                       const int64_t *chrom_bins_host, int n_chrom, int k, int sum_order, int64_t row_begin,
+                       int64_t row_end, int32_t *idx_out, double *dist_out) {
     int rc = wc_newref_prepare_dev(ctx, stream, corrected, n_bins, n_samples, chrom_bins_host, n_chrom, k,
                                    sum_order);
     if (rc) return rc;
     if ((rc = wc_newref_thresholds_dev(ctx, stream, row_begin, row_end))) return rc;
     if ((rc = wc_newref_collect_dev(ctx, stream, row_begin, row_end, 0, 1))) return rc;
     return wc_newref_finish_dev(ctx, stream, row_begin, row_end, idx_out, dist_out);
+}
+
+static int64_t env_word(const char *name) {     // the switches are read per call: a changed one is a different pass
+    const char *e = getenv(name);
+    int64_t h = 1469598103934665603ll;
+    for (; e && *e; ++e) h = (h ^ (unsigned char)*e) * 1099511628211ll;
+    return e ? h : 0;
+}
+
+// WC_NEWREF_GRAPH=1: the whole pass (ten launches) is replayed as ONE hipGraph from the third
+// identical call on: the first call sizes the workspaces and uploads the tables, the second one is
+// captured.  A graph bakes addresses in, so it is keyed on every argument, on the switches and on
+// wc::realloc_epoch(); a capture that fails is remembered and that call stays eager.  Off by
+// default: measured at 100 samples x 250 kb the replay is no faster than the eager launch series
+// (0.221 vs 0.216 ms on a stream of its own, 0.258 vs 0.220 ms behind the NULL stream, where the
+// graph needs a private stream and two event hops) -- the launches are queued ahead of the GPU
+// anyway, and the dispatch gaps between dependent kernels are the same inside a graph.
+int wc_get_reference_dev(wc_ctx *ctx, void *stream_, const double *corrected, int64_t n_bins, int64_t n_samples,
+                         const int64_t *chrom_bins_host, int n_chrom, int k, int sum_order,
+                         int64_t row_begin, int64_t row_end, int32_t *idx_out, double *dist_out) {
+    WC_CHECK(ctx && corrected && chrom_bins_host, WC_E_ARG, "newref: NULL argument");
+    NewrefState &st = ctx->nr;
+    const char *ge = getenv("WC_NEWREF_GRAPH");
+    const bool want = ge && ge[0] == '1' && n_chrom > 0 && n_chrom <= WC_MAX_CHROM && row_end > row_begin;
+    std::vector<int64_t> key;
+    if (want) {
+        key = {(int64_t)(intptr_t)corrected, n_bins, n_samples, n_chrom, k, sum_order, row_begin, row_end,
+               (int64_t)(intptr_t)idx_out, (int64_t)(intptr_t)dist_out, (int64_t)(intptr_t)stream_,
+               env_word("WC_GRAM_MODE"), env_word("WC_GRAM_DEPTH"), env_word("WC_FINISH_ENGINE"),
+               env_word("WC_FINISH_THREADS")};
+        for (int c = 0; c < n_chrom; ++c) key.push_back(chrom_bins_host[c]);
+    }
+    if (st.pass_exec && (key != st.pass_key || st.pass_epoch != wc::realloc_epoch())) {
+        (void)hipGraphExecDestroy(st.pass_exec);
+        st.pass_exec = nullptr;
+        st.pass_warm = false;
+    }
+    if (!want || key == st.pass_fail_key) {
+        st.pass_key.clear();
+        st.pass_warm = false;
+        return newref_pass(ctx, stream_, corrected, n_bins, n_samples, chrom_bins_host, n_chrom, k, sum_order,
+                           row_begin, row_end, idx_out, dist_out);
+    }
+    if (key != st.pass_key || st.pass_epoch != wc::realloc_epoch()) st.pass_warm = false;
+    if (!st.pass_exec && !st.pass_warm) {
+        // first sight of this call: eager (reserves, uploads); the next one can be captured
+        int rc = newref_pass(ctx, stream_, corrected, n_bins, n_samples, chrom_bins_host, n_chrom, k, sum_order,
+                             row_begin, row_end, idx_out, dist_out);
+        st.pass_key = key;
+        st.pass_warm = rc == WC_OK;
+        st.pass_epoch = wc::realloc_epoch();
+        return rc;
+    }
+    WC_HIP(hipSetDevice(ctx->device));
+    hipStream_t stream = (hipStream_t)stream_;
+    hipStream_t ls = stream;
+    if (stream == nullptr) {        // the NULL stream cannot be captured: the context's own stream, ordered behind it
+        if (!ctx->lat_stream) {
+            WC_HIP(hipStreamCreateWithFlags(&ctx->lat_stream, hipStreamNonBlocking));
+            WC_HIP(hipEventCreateWithFlags(&ctx->ev_lat_in, hipEventDisableTiming));
+            WC_HIP(hipEventCreateWithFlags(&ctx->ev_lat_out, hipEventDisableTiming));
+        }
+        ls = ctx->lat_stream;
+    }
+    if (!st.pass_exec) {
+        hipGraph_t graph = nullptr;
+        bool ok = hipStreamBeginCapture(ls, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        int rc = WC_OK;
+        if (ok) {
+            rc = newref_pass(ctx, ls, corrected, n_bins, n_samples, chrom_bins_host, n_chrom, k, sum_order, row_begin,
+                             row_end, idx_out, dist_out);
+            ok = hipStreamEndCapture(ls, &graph) == hipSuccess && graph && rc == WC_OK &&
+                 st.pass_epoch == wc::realloc_epoch();
+        }
+        if (ok) ok = hipGraphInstantiate(&st.pass_exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (graph) (void)hipGraphDestroy(graph);
+        if (!ok) {
+            (void)hipGetLastError();
+            st.pass_exec = nullptr;
+            st.pass_fail_key = key;
+            st.pass_key.clear();
+            st.pass_warm = false;
+            return newref_pass(ctx, stream_, corrected, n_bins, n_samples, chrom_bins_host, n_chrom, k, sum_order,
+                               row_begin, row_end, idx_out, dist_out);
+        }
+    }
+    if (ls != stream) {
+        WC_HIP(hipEventRecord(ctx->ev_lat_in, stream));
+        WC_HIP(hipStreamWaitEvent(ls, ctx->ev_lat_in, 0));
+    }
+    WC_HIP(hipGraphLaunch(st.pass_exec, ls));
+    if (ls != stream) {
+        WC_HIP(hipEventRecord(ctx->ev_lat_out, ls));
+        WC_HIP(hipStreamWaitEvent(stream, ctx->ev_lat_out, 0));
+    }
+    return WC_OK;
 }
 
 int wc_get_reference(wc_ctx *ctx, const double *corrected, int64_t n_bins, int64_t n_samples,

@@ -4180,6 +4180,7 @@ int wc_test_batch_dev(wc_ctx *ctx, void *stream_, const wc_reference *ref, const
     if (!ctx->lat_stream) {
         WC_HIP(hipStreamCreateWithFlags(&ctx->lat_stream, hipStreamNonBlocking));
         WC_HIP(hipEventCreateWithFlags(&ctx->ev_lat_in, hipEventDisableTiming));
+        WC_HIP(hipEventCreateWithFlags(&ctx->ev_lat_out, hipEventDisableTiming));
     }
     hipStream_t ls = ctx->lat_stream;
     if (stream != nullptr) {
@@ -4188,13 +4189,14 @@ int wc_test_batch_dev(wc_ctx *ctx, void *stream_, const wc_reference *ref, const
         WC_HIP(hipEventRecord(ctx->ev_lat_in, stream));
         WC_HIP(hipStreamWaitEvent(ls, ctx->ev_lat_in, 0));
     }
-    const bool eager = lat_env && lat_env[0] == '2';              // "2": the latency kernels, launched one by one
+    // "2": the latency kernels, launched one by one; a shape whose capture failed once stays there
+    const bool eager = (lat_env && lat_env[0] == '2') || key == ts.lat_fail_key;
     if (!ts.lat_exec && ts.lat_warm && ts.lat_epoch != wc::realloc_epoch()) ts.lat_warm = false;   // workspaces moved: size them again
     if (!ts.lat_exec && ts.lat_warm && !eager) {
         hipGraph_t graph = nullptr;
         if (hipStreamBeginCapture(ls, hipStreamCaptureModeThreadLocal) != hipSuccess) {
             (void)hipGetLastError();
-            ts.lat_key.clear();
+            ts.lat_fail_key = key;
             return fall_back();
         }
         rc = test_batch_body(ctx, ls, ref, counts, Ns, threshold, min_ref_bins, repeats, min_effect, sel, max_n,
@@ -4203,7 +4205,7 @@ int wc_test_batch_dev(wc_ctx *ctx, void *stream_, const wc_reference *ref, const
         if (rc != WC_OK || e != hipSuccess || !graph) {
             if (graph) (void)hipGraphDestroy(graph);
             (void)hipGetLastError();
-            ts.lat_key.clear();
+            ts.lat_fail_key = key;
             return fall_back();
         }
         const hipError_t ei = hipGraphInstantiate(&ts.lat_exec, graph, nullptr, nullptr, 0);
@@ -4211,7 +4213,7 @@ int wc_test_batch_dev(wc_ctx *ctx, void *stream_, const wc_reference *ref, const
         ts.lat_epoch = wc::realloc_epoch();
         if (ei != hipSuccess) {
             ts.lat_exec = nullptr;
-            ts.lat_key.clear();
+            ts.lat_fail_key = key;
             (void)hipGetLastError();
             return fall_back();
         }

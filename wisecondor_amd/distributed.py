@@ -52,6 +52,14 @@ class HipStages(object):
                                                   self.order))
         self.cap = int(self.lib.wc_newref_list_capacity(self.ctx))
 
+    def full_pass(self, idx, dst):
+        """All four stages for every row in one C call (wc_get_reference_dev): the library replays
+        the launch series as one hipGraph from the third identical call on."""
+        _lib.check(self.lib.wc_get_reference_dev(self.ctx, self._stream(), self.X.data_ptr(), self.n_bins,
+                                                 self.n_samples, _lib.ptr(self.bins), len(self.bins), self.k,
+                                                 self.order, 0, self.n_bins, idx.data_ptr(), dst.data_ptr()))
+        self.cap = int(self.lib.wc_newref_list_capacity(self.ctx))
+
     def thresholds(self, rb, re):
         _lib.check(self.lib.wc_newref_thresholds_dev(self.ctx, self._stream(), rb, re))
 
@@ -269,6 +277,9 @@ class NewrefJob(object):
 
     def _run(self):
         st = self.st
+        if self.world == 1 and self._marks is None and hasattr(st, "full_pass"):
+            st.full_pass(self.idx, self.dst)
+            return self.idx, self.dst
         self._mark("start")
         st.prepare()
         self._mark("prepared")
