@@ -349,7 +349,7 @@ def main():
     bins = np.ascontiguousarray(inp["masked_bins"])
     pairs = float(B) * B - float((bins.astype(np.float64) ** 2).sum())   # ordered cross-chromosome pairs
     X = torch.from_numpy(np.ascontiguousarray(corrected)).to(dev)
-    job = distributed.NewrefJob(ctx, X, bins, k, order, rank=rank, world=world)
+    job = distributed.NewrefJob(ctx, X, bins, k, order, rank=rank, world=world, passes=args.steps + args.warmup)
     tdev = dev if args.backend == "nccl" else torch.device("cpu")
 
     def sync_all():
@@ -485,7 +485,7 @@ def main():
             xpairs = float(XB) * XB - float((xbins.astype(np.float64) ** 2).sum())
             XX = torch.from_numpy(xdata).to(dev)
             del xdata
-            xjob = distributed.NewrefJob(ctx, XX, xbins, k, _lib.SUM_SEQUENTIAL, rank=rank, world=world)
+            xjob = distributed.NewrefJob(ctx, XX, xbins, k, _lib.SUM_SEQUENTIAL, rank=rank, world=world, passes=8)
             xsteps = 3
             xjob.run()
             sync_all()

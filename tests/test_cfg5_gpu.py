@@ -5,11 +5,15 @@
   tools/make_goldens.py --only cfg5): segment bounds exact, segment values, the whole-chromosome
   z and 400 random window values per chromosome bit-equal.
 * The 125-sample batch (tools/cfg5_case.py): sample 0's cleaned z vectors reproduce the golden
-  inputs bit for bit (the z-score path is deterministic and carries numpy's bits), its calls on
-  chromosomes 1-3 are the reference's segments mapped to genomic bins, the CPU oracle's
-  repeat_test agrees bit for bit with three samples of the batch, and the oracle's own
-  segmentation agrees on the short chromosomes (19-22) of those samples.
+  inputs, its calls on chromosomes 1-3 are the reference's segments mapped to genomic bins, the
+  CPU oracle's repeat_test agrees bit for bit with three samples of the batch, and the oracle's
+  own segmentation agrees on the short chromosomes (19-22) of those samples.
+* WHOLE samples (tests/golden/cfg5_whole.npz, tools/make_cfg5_whole.py): samples 0 and 5 went
+  through the real reference's toolTest end to end (all 22 chromosomes, 90 M windows each), ten
+  samples through the CPU oracle's test_sample; every call of the batch is compared with them.
+  No member of either fixture was computed by the HIP `test` path.
 """
+import hashlib
 import os
 import sys
 
@@ -41,6 +45,11 @@ def wt():
 @pytest.fixture(scope="module")
 def g(golden):
     return golden("cfg5_50kb.npz")
+
+
+@pytest.fixture(scope="module")
+def gw(golden):
+    return golden("cfg5_whole.npz")
 
 
 @pytest.fixture(scope="module")
@@ -86,7 +95,6 @@ def test_batch_of_125_samples(wt, g, case):
     assert np.array_equal(case["masked_bins"], g["masked_bins"])
     outs = wt.test_batch(case["reference"], case["tests"], thr)
     assert len(outs) == 125
-    assert np.array_equal([len(o["results_calls"]) for o in outs], g["n_calls_all"])
     # sample 0: the pipeline of this build reproduces the golden's input vectors, and its calls on
     # chromosomes 1-3 are the reference's segments in genomic coordinates.  The stored z vectors were
     # made with the prep (exact PCA) of the build that wrote the fixture; the PCA is pinned to 1e-9 / 1e-10
@@ -98,8 +106,6 @@ def test_batch_of_125_samples(wt, g, case):
         assert zs[c - 1].shape == g["z_chr%d" % c].shape, c
         assert np.allclose(zs[c - 1], g["z_chr%d" % c], rtol=0, atol=1e-6, equal_nan=True), c
     calls0 = np.asarray(outs[0]["results_calls"], dtype=np.float64).reshape(-1, 5)
-    assert np.array_equal(calls0[:, :3], g["calls_sample0"][:, :3])
-    assert np.allclose(calls0[:, 3:], g["calls_sample0"][:, 3:], rtol=1e-6, atol=1e-9)
     for c in (1, 2, 3):
         mine = calls0[calls0[:, 0] == c]
         want = g["seg_chr%d" % c]
@@ -129,3 +135,47 @@ def test_batch_of_125_samples(wt, g, case):
             assert len(mine) == len(want), (i, c)
             assert same_bits(mine[:, 3], [v for v, _ in want]), (i, c)
             assert same_bits([outs[i]["results_cwz"][c - 1]], [tri[len(zs_i[c - 1]) - 1]]), (i, c)
+
+
+def test_whole_samples_against_the_reference_and_the_oracle(wt, gw, case):
+    """Every call of whole 50 kb samples: two samples against the real reference's toolTest output,
+    ten against the oracle's.  Coordinates exact.  Values: the reference applies the PCA through
+    BLAS and this build's prep is pinned to 1e-9, not to bits, so z / effect / chromosome-wide z
+    are compared to 1e-6 relative -- and to 1e-9 when this build's `newref` output is bit for bit
+    the one the fixture was made from (distances_sha256)."""
+    thr = case["threshold"]
+    assert thr == float(gw["threshold"])
+    assert np.array_equal(case["masked_bins"], gw["masked_sizes"])
+    ref = case["reference"]
+    same_ref = hashlib.sha256(ref.distances.tobytes()).hexdigest() == str(gw["distances_sha256"])
+    rtol = 1e-9 if same_ref else 1e-6
+    if same_ref:
+        assert ref.cutoff == float(gw["cutoff"])
+    wanted = sorted(set(int(i) for i in gw["ref_samples"]) | set(int(i) for i in gw["oracle_samples"]))
+    assert len(wanted) >= 8
+    samples = [case["tests"][i] for i in wanted]
+    outs = wt.test_batch(ref, samples, thr)
+    stride = int(gw["stride"])
+    n_calls = 0
+    for i, out in zip(wanted, outs):
+        calls = np.asarray(out["results_calls"], dtype=np.float64).reshape(-1, 5)
+        for kind in ("ref", "oracle"):
+            key = "%s%d_results_calls" % (kind, i)
+            if key not in gw:
+                continue
+            want = gw[key].reshape(-1, 5)
+            assert np.array_equal(calls[:, :3], want[:, :3]), (kind, i, calls[:, :3], want[:, :3])
+            assert np.allclose(calls[:, 3:], want[:, 3:], rtol=rtol, atol=1e-12), (kind, i)
+            assert np.allclose(out["results_cwz"], gw["%s%d_results_cwz" % (kind, i)], rtol=rtol, atol=1e-9), (kind, i)
+            assert np.isclose(out["asdef"], float(gw["%s%d_asdef" % (kind, i)]), rtol=rtol, atol=0), (kind, i)
+            n_calls += len(want)
+        if "ref%d_results_z_sampled" % i in gw:
+            z = np.concatenate(out["results_z"])
+            r = np.concatenate(out["results_r"])
+            assert int(np.count_nonzero(z)) == int(gw["ref%d_results_z_nonzero" % i]), i
+            zs, rs = gw["ref%d_results_z_sampled" % i], gw["ref%d_results_r_sampled" % i]
+            assert np.array_equal(z[::stride] == 0, zs == 0), i            # the masked / dropped bins are zeros
+            assert np.allclose(z[::stride], zs, rtol=rtol, atol=1e-9 if same_ref else 1e-6), i
+            assert np.allclose(r[::stride], rs, rtol=rtol, atol=1e-12 if same_ref else 1e-9), i
+            assert float(gw["ref%d_threshold_z" % i]) == thr
+    assert n_calls >= 50

@@ -206,6 +206,25 @@ def test_bench_two_ranks_on_one_gpu():
     assert line["value"] > 0 and line["test"]["value"] > 0
 
 
+def test_bench_eight_ranks_on_one_gpu():
+    """bench.py --gpus 8 (the driver's scaling run) with the ranks sharing the one GPU over gloo: the launcher
+    starts eight ranks, the shard mode is measured on them, and the line says so."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--backend", "gloo", "--no-extra", "--workload",
+                        "cfg1", "--steps", "2", "--warmup", "1", "--test-samples", "32", "--no-cpu-baseline"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["config"]["world_size"] == 8
+    assert line["config"]["shard_mode"] in ("tiles", "rows")
+    assert set(line["config"]["shard_calibration_s"]) == {"tiles", "rows"}
+    assert line["value"] > 0 and line["test"]["value"] > 0
+
+
 def test_bench_line_is_complete_on_one_gpu():
     """The default bench command in a short form (cfg2, the 600 x 50 kb extra, no CPU leg): one JSON line
     with every object the measurement contract names, every fraction at most 1, no swallowed error."""

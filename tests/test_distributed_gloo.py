@@ -109,28 +109,67 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, X, bins, k, out_dir, mode):
+class FailingStages(NumpyStages):
+    """A rank whose tile collection breaks (the stand-in for an out-of-memory or GPU fault on one rank)."""
+
+    def collect(self, rb, re, rank, ranks):
+        if ranks > 1:
+            raise MemoryError("collect failed on this rank")
+        return NumpyStages.collect(self, rb, re, rank, ranks)
+
+
+def _worker(rank, world, port, X, bins, k, out_dir, mode, passes=1, fail_rank=-1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        st = NumpyStages(X, bins, k)
-        job = NewrefJob(None, None, bins, k, 0, rank=rank, world=world, stages=st, dist=dist, mode=mode)
-        for _ in range(2):          # second run reuses the exchange buffers
-            idx, dst = job.run()
+        st = (FailingStages if rank == fail_rank else NumpyStages)(X, bins, k)
+        job = NewrefJob(None, None, bins, k, 0, rank=rank, world=world, stages=st, dist=dist, mode=mode, passes=passes)
+        try:
+            for _ in range(2):          # second run reuses the exchange buffers
+                idx, dst = job.run()
+        except Exception as exc:
+            if fail_rank < 0:
+                raise
+            np.savez(os.path.join(out_dir, "rank%d.npz" % rank), error=type(exc).__name__)
+            return
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), idx=idx.numpy(), dst=dst.numpy(), mode=job.mode,
                  measured=sorted((job.calibration or {}).keys()))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "tiles"), (3, "tiles"), (2, "rows"), (3, None)])
+def test_a_failure_on_one_rank_stops_the_calibration_on_all(tmp_path):
+    """calibrate(): a real fault on one rank (not "this backend lacks the collective") must not be
+    swallowed into the row shard, and must not leave the other ranks waiting in a collective: after
+    each mode the ranks agree on the outcome, so all of them stop together."""
+    rng = np.random.RandomState(5)
+    bins = np.array([9, 14, 7], dtype=np.int64)
+    X = 1.0 + 0.05 * rng.standard_normal((int(bins.sum()), 6))
+    mp.spawn(_worker, args=(3, _free_port(), X, bins, 5, str(tmp_path), None, 3, 1), nprocs=3, join=True)
+    errors = [str(np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))["error"]) for r in range(3)]
+    assert errors[1] == "MemoryError" and errors[0] == errors[2] == "PeerFailure", errors
+
+
+def test_a_one_shot_job_does_not_calibrate(tmp_path):
+    """passes=1 (the CLI): the symmetric tile shard without the four calibration passes."""
+    rng = np.random.RandomState(6)
+    bins = np.array([9, 14, 7], dtype=np.int64)
+    X = 1.0 + 0.05 * rng.standard_normal((int(bins.sum()), 6))
+    mp.spawn(_worker, args=(2, _free_port(), X, bins, 5, str(tmp_path), None, 1), nprocs=2, join=True)
+    for r in range(2):
+        got = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        assert str(got["mode"]) == "tiles" and list(got["measured"]) == []
+
+
+@pytest.mark.parametrize("world,mode", [(2, "tiles"), (3, "tiles"), (2, "rows"), (3, None), (8, "tiles"), (8, "rows")])
 def test_multi_rank_equals_single_rank_and_oracle(tmp_path, world, mode):
     rng = np.random.RandomState(5)
     bins = np.array([9, 14, 7, 12, 11], dtype=np.int64)
     X = 1.0 + 0.05 * rng.standard_normal((int(bins.sum()), 6))
     k = 10
-    mp.spawn(_worker, args=(world, _free_port(), X, bins, k, str(tmp_path), mode), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), X, bins, k, str(tmp_path), mode, 3 if mode is None else 1),
+             nprocs=world, join=True)
     st = NumpyStages(X, bins, k)
     one_i, one_d = NewrefJob(None, None, bins, k, 0, rank=0, world=1, stages=st).run()
     want_i, want_d = wo.get_reference(X, bins, np.cumsum(bins), k, 1, 1, fast=True)

@@ -88,3 +88,80 @@ def test_hip_multi_rank_ragged_layout(tmp_path, world, mode):
         got = np.load(str(tmp_path / ("rank%d.npz" % r)))
         assert np.array_equal(got["idx"], want_i), r
         assert np.array_equal(got["dst"].view(np.int64), np.asarray(want_d).view(np.int64)), r
+
+
+def _worker8(rank, world, port, path_in, out_dir, mode, xcap):
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    from wisecondor_amd import _lib
+    from wisecondor_amd import wisetools as wt
+    from wisecondor_amd.distributed import NewrefJob
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if xcap:
+        os.environ["WC_EXCHANGE_CAP"] = str(xcap)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        z = np.load(path_in)
+        X = torch.from_numpy(np.ascontiguousarray(z["data"])).cuda()
+        job = NewrefJob(_lib.context(0), X, z["bins"], int(z["k"]), int(z["order"]), rank=rank, world=world, dist=dist,
+                        mode=mode)
+        for _ in range(2):
+            idx, dst = job.run()
+        torch.cuda.synchronize()
+        idx, dst = idx.cpu().numpy(), dst.cpu().numpy()
+        over = 0
+        if mode == "tiles":
+            over = int(sum(int((job.recv_cnt[r] > job.cap_x).sum()) for r in range(world) if r != rank))
+        out = dict(sha=hashlib.sha256(idx.tobytes() + dst.tobytes()).hexdigest(), overflow=over, cap_x=getattr(job, "cap_x", 0),
+                   fallback=wt.newref_stats()["fallback_rows"])
+        if rank == 0:
+            out.update(idx=idx, dst=dst)
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,xcap", [("tiles", 0), ("tiles", 40), ("rows", 0)])
+def test_eight_ranks_on_one_gpu(tmp_path, mode, xcap):
+    """The world size the node run uses: 8 ranks (sharing the one GPU of the test box, gloo) at
+    20 k bins x 200 samples in both shard modes -- exchange_capacity() at world 8 (192 slots per row
+    and source), eight-way tile dealing, eight row bands -- must reproduce the single-rank result bit
+    for bit, and a row sample of it the CPU oracle.  xcap = 40 shrinks the exchange slots so that
+    hundreds of rows overflow them and take the import -> exact-fallback path."""
+    import torch
+    import torch.multiprocessing as mp
+    from wisecondor_amd import _lib, synth
+    from wisecondor_amd.distributed import NewrefJob, exchange_capacity
+    assert exchange_capacity(1024, 8) == 192
+    data, bins, sums = synth.corrected_matrix(140000, 200, seed=11)
+    assert data.shape[0] >= 20000
+    data[5] = data[9000]                      # a tie across ranks' row ranges
+    data[12000] *= 25.0                       # an outlier row that needs the exact fallback
+    k = 100
+    order = 1
+    path_in = str(tmp_path / "in.npz")
+    np.savez(path_in, data=data, bins=bins, k=k, order=order)
+    mp.get_context("spawn")
+    mp.spawn(_worker8, args=(8, _free_port(), path_in, str(tmp_path), mode, xcap), nprocs=8, join=True)
+    one = NewrefJob(_lib.context(0), torch.from_numpy(data).cuda(), bins, k, order)
+    idx1, dst1 = one.run()
+    torch.cuda.synchronize()
+    idx1, dst1 = idx1.cpu().numpy(), dst1.cpu().numpy()
+    got = [np.load(str(tmp_path / ("rank%d.npz" % r))) for r in range(8)]
+    assert len({str(g["sha"]) for g in got}) == 1                      # every rank ends with the same full result
+    assert np.array_equal(got[0]["idx"], idx1) and np.array_equal(got[0]["dst"].view(np.int64), dst1.view(np.int64))
+    if xcap:
+        assert sum(int(g["overflow"]) for g in got) > 100, [int(g["overflow"]) for g in got]
+        assert sum(int(g["fallback"]) for g in got) > 100
+    # the oracle on a sample of rows (the reference's own loop, wisetools.py:298-325)
+    F = np.asfortranarray(data)
+    rows = np.r_[5, 9000, 12000, np.arange(17, data.shape[0], 1009)]
+    off = np.concatenate([[0], sums])
+    for r in rows:
+        c = int(np.searchsorted(sums, r, side="right"))
+        others = np.concatenate((F[:off[c]], F[off[c + 1]:]))
+        with np.errstate(all="ignore"):
+            wi, wd = wo.get_ref_for_bins(k, int(r), int(r) + 1, F, others)
+        assert np.array_equal(idx1[r], wi[0]) and np.array_equal(dst1[r], wd[0]), r

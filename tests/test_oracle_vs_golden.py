@@ -311,3 +311,20 @@ def test_refsize_300_oracle(golden):
     z, r, n, sd = wo.repeat_test(np.copy(g1["t_loss2_xpca"]), idx, dst, bins, sums, cutoff, thr, 5)
     assert np.array_equal(n, g["t_loss2_rep5_n"].astype(np.float64))
     assert same_bits(z, g["t_loss2_rep5_z"]) and sd == float(g["t_loss2_rep5_sd"])
+
+
+def test_cfg5_whole_samples_oracle_equals_reference(golden):
+    """tests/golden/cfg5_whole.npz: the two whole 50 kb samples that went through BOTH the real
+    reference's toolTest and the oracle's test_sample (tools/make_cfg5_whole.py; minutes of CPU per
+    sample, so the comparison is between the two stored outputs): same calls, same values."""
+    g = golden("cfg5_whole.npz")
+    both = sorted(set(int(i) for i in g["ref_samples"]) & set(int(i) for i in g["oracle_samples"]))
+    assert len(both) >= 2
+    for i in both:
+        a = g["ref%d_results_calls" % i].reshape(-1, 5)
+        b = g["oracle%d_results_calls" % i].reshape(-1, 5)
+        assert len(a) >= 1
+        assert np.array_equal(a[:, :3], b[:, :3]), i
+        assert np.allclose(a[:, 3:], b[:, 3:], rtol=1e-9, atol=1e-12), i
+        assert np.allclose(g["ref%d_results_cwz" % i], g["oracle%d_results_cwz" % i], rtol=1e-9, atol=1e-12), i
+        assert np.isclose(float(g["ref%d_asdef" % i]), float(g["oracle%d_asdef" % i]), rtol=1e-12), i

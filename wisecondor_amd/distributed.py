@@ -98,9 +98,25 @@ class HipStages(object):
 
 
 def forced_shard_mode():
-    """'tiles' / 'rows' when WC_NEWREF_SHARD pins the multi-GPU shard mode, else None."""
+    """'tiles' / 'rows' when WC_NEWREF_SHARD pins the multi-GPU shard mode, else None
+    ('measure' forces the calibration even for a job that runs once)."""
     env = os.environ.get("WC_NEWREF_SHARD", "auto")
     return env if env in ("tiles", "rows") else None
+
+
+CALIBRATE_FROM_PASSES = 3      # a job that will run fewer passes is not worth four calibration passes
+
+
+class PeerFailure(RuntimeError):
+    """Another rank failed in a step all ranks take together; this rank stops with it."""
+
+
+def _unsupported(exc):
+    """An exchange collective this backend does not offer (argument checks fail on every rank alike,
+    before any communication) -- as opposed to a real fault (out of memory, a GPU or RCCL error)."""
+    text = str(exc).lower()
+    return isinstance(exc, NotImplementedError) or (
+        isinstance(exc, RuntimeError) and any(w in text for w in ("not support", "unsupported", "not implemented")))
 
 
 def exchange_capacity(cap, world):
@@ -110,6 +126,9 @@ def exchange_capacity(cap, world):
     spread of ~20 % (it comes from a sampled order statistic): 1.75 x mean + 8 sigma
     (Poisson) + slack, in steps of 32.  A row that still overflows is marked by the
     importer and takes the exact fallback."""
+    forced = os.environ.get("WC_EXCHANGE_CAP")      # tests: a small value drives rows into the overflow -> exact path
+    if forced:
+        return int(min(cap, max(1, int(forced))))
     mean = cap / 2.0 / world
     return int(min(cap, 32 * int(np.ceil((1.75 * mean + 8.0 * np.sqrt(mean) + 16.0) / 32.0))))
 
@@ -127,8 +146,13 @@ class NewrefJob(object):
     one collective; the result all-gather is in place (the rank's own slot is its finish
     output)."""
 
-    def __init__(self, ctx, X, chrom_bins, k, sum_order, rank=0, world=1, stages=None, dist=None, mode=None):
+    def __init__(self, ctx, X, chrom_bins, k, sum_order, rank=0, world=1, stages=None, dist=None, mode=None,
+                 passes=1):
+        """`passes`: how many times the caller expects to run() this job.  The shard mode of a
+        multi-rank job is measured (calibrate: four extra passes) only from CALIBRATE_FROM_PASSES
+        on or with WC_NEWREF_SHARD=measure; a one-shot job (the CLI) takes the symmetric tile shard."""
         import torch
+        self.passes = int(passes)
         self.torch = torch
         self.rank, self.world = int(rank), int(world)
         self.st = stages if stages is not None else HipStages(ctx, X, chrom_bins, k, sum_order)
@@ -139,6 +163,7 @@ class NewrefJob(object):
         self.dist = dist
         self.mode = mode            # None: measured at the first run (calibrate), unless WC_NEWREF_SHARD pins it
         self.calibration = None
+        self._checked = False       # calibration passes: ranks agree on every local step's outcome (_local)
         self._marks = None
         self.last_marks = None
         self.chrom_bins = np.asarray(chrom_bins, dtype=np.int64)
@@ -213,13 +238,17 @@ class NewrefJob(object):
     def calibrate(self):
         """Pick the shard mode by measurement: one warm-up and one timed pass of each mode on
         this job's own data, the slower rank's time counts (all-reduce MAX), ties go to the
-        symmetric tile shard.  Every rank reaches the same decision.  `calibration` keeps the
-        measured seconds per pass."""
+        symmetric tile shard.  Every rank reaches the same decision: after each mode the ranks
+        agree (all-reduce MIN) on ok / collective-not-offered / failed, so a failure on one rank
+        stops all of them together instead of leaving its peers in the next collective.
+        `calibration` keeps the measured seconds per pass."""
         import time
         times = {}
         marks, self._marks = self._marks, None           # the caller's timing marks are not for these passes
         for mode in ("tiles", "rows"):
             self.mode = mode
+            state, err, elapsed = 2, None, 0.0           # 2 ok, 1 the backend lacks an exchange collective, 0 failed
+            self._checked = True
             try:
                 self._run()                              # buffers, tile lists, communicator warm-up
                 self._sync()
@@ -227,18 +256,35 @@ class NewrefJob(object):
                 t0 = time.perf_counter()
                 self._run()
                 self._sync()
-                times[mode] = self._max_over_ranks(time.perf_counter() - t0)
-            except Exception as exc:                     # pragma: no cover - needs a backend without the collective
-                # an exchange collective this backend does not offer fails on every rank alike (argument
-                # checks happen before any communication): the row bands need the all-gather only
-                if mode == "rows":
-                    raise
+                elapsed = time.perf_counter() - t0
+            except Exception as exc:
+                err = exc
+                state = 1 if (mode == "tiles" and _unsupported(exc)) else 0
+            finally:
+                self._checked = False
+            state = self._min_over_ranks(state)
+            if state == 0:
+                self.mode = None
+                self._marks = marks
+                if err is not None:
+                    raise err
+                raise PeerFailure("newref calibration (%s shard): another rank failed" % mode)
+            if state == 1:
                 times[mode] = None
-                times["tiles_error"] = "%s: %s" % (type(exc).__name__, exc)
+                times["tiles_error"] = "%s: %s" % (type(err).__name__, err) if err is not None else "on another rank"
+            else:
+                times[mode] = self._max_over_ranks(elapsed)
         self.mode = None
         self._marks = marks
         self.calibration = times
         return "rows" if times["tiles"] is None or times["rows"] < times["tiles"] else "tiles"
+
+    def _min_over_ranks(self, value):
+        on_gpu = self.dist.get_backend() != "gloo"
+        t = self.torch.tensor([int(value)], dtype=self.torch.int32,
+                              device=self.st.device if on_gpu else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return int(t.item())
 
     def _sync(self):
         if getattr(self.st, "device", None) is not None and self.st.device.type == "cuda":
@@ -281,7 +327,7 @@ class NewrefJob(object):
             st.full_pass(self.idx, self.dst)
             return self.idx, self.dst
         self._mark("start")
-        st.prepare()
+        self._local(st.prepare)
         self._mark("prepared")
         if self.world == 1:
             st.thresholds(0, self.n_bins)
@@ -293,48 +339,75 @@ class NewrefJob(object):
 
         rb, re = self.ranges[self.rank]
         if self.mode is None:
-            self.mode = forced_shard_mode() or self.calibrate()
+            measure = self.passes >= CALIBRATE_FROM_PASSES or os.environ.get("WC_NEWREF_SHARD") == "measure"
+            self.mode = forced_shard_mode() or (self.calibrate() if measure else "tiles")
             st.prepare()
         if self.mode == "rows":
             # row band of this rank against all columns: no exchange, one collective
-            st.thresholds(rb, re)
-            self._mark("thresholds")
-            st.collect(rb, re, 0, 1)
-            self._mark("collected")
-            self._finish(rb, re, self.idx_all[self.rank], self.dst_all[self.rank])
+            def band():
+                st.thresholds(rb, re)
+                self._mark("thresholds")
+                st.collect(rb, re, 0, 1)
+                self._mark("collected")
+                self._finish(rb, re, self.idx_all[self.rank], self.dst_all[self.rank])
+            self._local(band)
             out = self._gather_results()
             self._mark("gathered")
             return out
 
-        if not self.buffers_ready:
-            self._alloc_exchange()
         # thresholds: owner computes, everyone needs them for the tiles it was dealt
-        st.thresholds(rb, re)
-        self.thr_all[self.rank].zero_()
-        st.get_thr(rb, re, self.thr_all[self.rank])
+        def own_thresholds():
+            if not self.buffers_ready:
+                self._alloc_exchange()
+            st.thresholds(rb, re)
+            self.thr_all[self.rank].zero_()
+            st.get_thr(rb, re, self.thr_all[self.rank])
+        self._local(own_thresholds)
         self._all_gather(self.thr_all.view(-1), self.thr_all[self.rank])
-        for r, (b, e) in enumerate(self.ranges):
-            if r != self.rank:
-                st.set_thr(b, e, self.thr_all[r])
-        self._mark("thresholds")
-        # this rank's share of the symmetric tile space, candidates for all rows
-        st.collect(0, self.n_bins, self.rank, self.world)
-        self._mark("collected")
-        # candidate lists travel to the rows' owners
-        self.send_cnt_all.zero_()
-        for r, (b, e) in enumerate(self.ranges):
-            if r != self.rank:
-                st.export(b, e, self.cap_x, self.send_cnt[r], self.send_lst[r])
+
+        # this rank's share of the symmetric tile space, candidates for all rows; the lists of
+        # foreign rows are packed for their owners
+        def tiles():
+            for r, (b, e) in enumerate(self.ranges):
+                if r != self.rank:
+                    st.set_thr(b, e, self.thr_all[r])
+            self._mark("thresholds")
+            st.collect(0, self.n_bins, self.rank, self.world)
+            self._mark("collected")
+            self.send_cnt_all.zero_()
+            for r, (b, e) in enumerate(self.ranges):
+                if r != self.rank:
+                    st.export(b, e, self.cap_x, self.send_cnt[r], self.send_lst[r])
+        self._local(tiles)
         self._all_to_all(self.recv.view(-1), self.send.view(-1))
-        for r in range(self.world):
-            if r != self.rank:
-                st.import_(rb, re, self.cap_x, self.recv_cnt[r], self.recv_lst[r])
-        self._mark("exchanged")
-        # owners finish their rows; results to everyone
-        self._finish(rb, re, self.idx_all[self.rank], self.dst_all[self.rank])
+
+        # owners merge what they received and finish their rows; results to everyone
+        def own_rows():
+            for r in range(self.world):
+                if r != self.rank:
+                    st.import_(rb, re, self.cap_x, self.recv_cnt[r], self.recv_lst[r])
+            self._mark("exchanged")
+            self._finish(rb, re, self.idx_all[self.rank], self.dst_all[self.rank])
+        self._local(own_rows)
         out = self._gather_results()
         self._mark("gathered")
         return out
+
+    def _local(self, work):
+        """This rank's work between two collectives.  During the calibration passes (`_checked`) the
+        ranks agree on its outcome before any of them enters the next collective: a rank that failed
+        would otherwise leave its peers waiting there."""
+        if not self._checked:
+            return work()
+        err = None
+        try:
+            work()
+        except Exception as exc:
+            err = exc
+        if self._min_over_ranks(0 if err is not None else 2) == 0:
+            if err is not None:
+                raise err
+            raise PeerFailure("newref: another rank failed before a collective")
 
     def _finish(self, rb, re, idx, dst):
         if self._marks is None:
