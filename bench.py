@@ -38,12 +38,14 @@ WORKLOADS = {
 }
 # MI355X_MICROARCH.md
 PEAK_FP32_MFMA = 157.3e12   # v_mfma_f32_32x32x2_f32 dense
-PEAK_BF16_MFMA = 2500e12    # v_mfma_f32_32x32x16_bf16 dense (no sparsity)
+PEAK_BF16_MFMA = 2500e12    # v_mfma_f32_32x32x16_bf16 / _f16 dense (no sparsity)
 PEAK_HBM = 8.0e12           # bytes/s, spec (6.3e12 achievable by a copy)
 PEAK_L2 = 34.5e12           # bytes/s aggregate over the 8 XCDs
 PEAK_FP64_VALU_OPS = 39.3e12  # float64 vector add / mul / max per second (78.6 TFLOP/s counts an FMA as two)
 SPLIT_PRODUCTS = 3.0        # k_gram<split>: hi.hi + hi.lo + lo.hi per float32 multiply
-ROUND = "r02"
+PEAK_MALL = 10.0e12         # bytes/s the Infinity Cache sustains towards the L2s (order of magnitude, MI355X_MICROARCH.md)
+ROUND = "r03"
+LATENCY_LAUNCHES = 8        # kernels of one latency-mode `test` call
 
 
 # --------------------------------------------------------------- rank launch ----
@@ -109,9 +111,11 @@ def build_inputs(binsize, n_ref, n_test, seed0=0, device=0):
     # correctedData left in HBM for newref): what a caller pays between `convert`ed samples and stage A
     import time as _time
     import torch as _torch
+    dense = wt.samples_to_counts(samples, chrom_bins)           # what an ingest loop holds (wisecondor_amd/ingest.py)
+    wt.prepReference(None, device=device, device_out=True, counts=dense, chrom_bins=chrom_bins)
     _torch.cuda.synchronize()
     _t0 = _time.perf_counter()
-    wt.prepReference(samples, device=device, device_out=True)
+    wt.prepReference(None, device=device, device_out=True, counts=dense, chrom_bins=chrom_bins)
     _torch.cuda.synchronize()
     prep_ms = 1e3 * (_time.perf_counter() - _t0)
     masked_bins = np.asarray(masked_bins, dtype=np.int64)
@@ -142,6 +146,18 @@ def committed_traffic(workload):
                 t["source"] = "profiles/%s_traffic.json" % rnd
                 return t
     return {}
+
+
+def committed_latency_trace():
+    """Kernel durations of one latency-mode replay from the committed rocprofv3 kernel trace
+    (profiles/<round>_latency_trace.json, written by tools/refresh_profiles.sh), or None."""
+    for rnd in (ROUND, "r02"):
+        path = os.path.join(ROOT, "profiles", "%s_latency_trace.json" % rnd)
+        if os.path.exists(path):
+            t = json.load(open(path))
+            t["source"] = "profiles/%s_latency_trace.json" % rnd
+            return t
+    return None
 
 
 def hbm_bytes(entry):
@@ -200,38 +216,23 @@ def usable_cores():
     return n
 
 
-def run_cpu_baseline(inp, binsize, k, idx_gpu, reference_arrays, tb_calls, budget_s=8.0):
-    """The oracle (`kind: port`, the reference's own structure: numpy temporaries + Python
-    insertion scan; one np.sum per Stouffer window) on this box's host cores, in child
-    processes (oracle/cpu_baseline.py): one core, then all cores with the reference's process
-    model (`newref -cpus N`: N processes over N row parts, wisecondor.py:47-56; `test`: N
-    independent samples in N processes).  Bounded samples of the same workload."""
-    import numpy as np
-    corrected = inp["corrected"]
-    B, S = corrected.shape
-    bins = inp["masked_bins"]
-    cores = usable_cores()
-    workers = max(1, min(cores, 256))
-    tmp = tempfile.mkdtemp(prefix="wc_cpu_")
-    np.save(os.path.join(tmp, "corrected.npy"), corrected)       # keeps the Fortran order (summation order)
-    np.savez(os.path.join(tmp, "reference.npz"), bins=bins, k=k, binsize=binsize, **reference_arrays)
-    n_tests = min(len(inp["tests"]), workers)
-    for i in range(n_tests):
-        np.savez(os.path.join(tmp, "sample_%d.npz" % i), **inp["tests"][i])
-    # rows per process so that one process works for about budget_s (the numpy distance touches
-    # ~B * S elements three times per target row)
-    rows = int(max(8, min(B, budget_s * 1.0e9 / (float(B) * S))))
-    script = os.path.join(ROOT, "oracle", "cpu_baseline.py")
-    quiet_env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+class CpuWorkers(object):
+    """Child processes of oracle/cpu_baseline.py over one scratch directory: the workers load their
+    inputs, report ready and wait for `go`, so that interpreter start-up and file reads of one worker
+    do not eat into the timed work of another."""
 
-    def run(n_proc, what):
-        # the workers load their inputs, report ready and wait for `go`: interpreter start-up and
-        # file reads of one worker do not eat into the timed work of another
+    def __init__(self):
+        self.tmp = tempfile.mkdtemp(prefix="wc_cpu_")
+        self.script = os.path.join(ROOT, "oracle", "cpu_baseline.py")
+        self.env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+
+    def run(self, n_proc, what, rows=0):
+        tmp = self.tmp
         for name in os.listdir(tmp):
             if name.startswith("ready_") or name == "go":
                 os.remove(os.path.join(tmp, name))
-        procs = [subprocess.Popen([sys.executable, script, what, tmp, str(p), str(n_proc), str(rows)],
-                                  stdout=subprocess.PIPE, env=quiet_env) for p in range(n_proc)]
+        procs = [subprocess.Popen([sys.executable, self.script, what, tmp, str(p), str(n_proc), str(rows)],
+                                  stdout=subprocess.PIPE, env=self.env) for p in range(n_proc)]
         while sum(name.startswith("ready_") for name in os.listdir(tmp)) < n_proc:
             if any(p.poll() not in (None, 0) for p in procs):
                 raise RuntimeError("a cpu_baseline worker failed")
@@ -241,47 +242,194 @@ def run_cpu_baseline(inp, binsize, k, idx_gpu, reference_arrays, tb_calls, budge
         outs = [json.loads(p.communicate()[0].decode().strip().splitlines()[-1]) for p in procs]
         return time.perf_counter() - t0, outs
 
-    sums = np.cumsum(bins)
+    def close(self):
+        import shutil
+        shutil.rmtree(self.tmp, ignore_errors=True)
 
-    def pairs_of(lo, hi):
-        return float(sum(B - bins[np.searchsorted(sums, r, side="right")] for r in range(lo, hi)))
 
-    out = {"unit": "bin-pair distances/s", "kind": "port", "cpu_model": cpu_model(), "host_cores": cores}
-    # one core
-    _, o1 = run(1, "newref")
-    lo, hi = o1[0]["rows"]
-    ok = bool(np.array_equal(np.load(os.path.join(tmp, "newref_0.npy")), idx_gpu[lo:hi]))
-    out.update({"value": pairs_of(lo, hi) / o1[0]["seconds"], "cores": 1,
-                "sample": "oracle get_reference on target rows [%d,%d) of %d x all candidates, %.1f s"
-                          % (lo, hi, B, o1[0]["seconds"]),
-                "matches_gpu_indices": ok})
-    # all cores, the reference's -cpus N model (wall time includes starting the processes, as it does there)
-    wall, oN = run(workers, "newref")
-    busy = max(o["seconds"] for o in oN)
-    done = sum(pairs_of(*o["rows"]) for o in oN)
-    out["all_cores"] = {"value": done / wall, "unit": "bin-pair distances/s", "cores": workers,
-                        "sample": "%d processes (newref -cpus %d model), up to %d target rows each: %.1f s wall "
-                                  "from a common start, slowest process %.1f s" % (workers, workers, rows, wall, busy)}
-    # test: one sample on one core, then one sample per core
-    _, t1 = run(1, "test")
-    gpu_calls = tb_calls(0)
-    cpu_calls = np.asarray(t1[0]["calls"], dtype=np.float64).reshape(-1, 5)
-    out["test"] = {"value": 1.0 / t1[0]["seconds"], "unit": "samples/s", "cores": 1, "kind": "port",
-                   "sample": "oracle test_sample on 1 of the batch's samples, %.1f s" % t1[0]["seconds"],
-                   "matches_gpu_calls": bool(cpu_calls.shape == gpu_calls.shape and
-                                             np.array_equal(cpu_calls[:, :3], gpu_calls[:, :3]))}
-    if n_tests > 1:
-        wall, tN = run(n_tests, "test")
-        busy = max(o["seconds"] for o in tN)
-        out["test"]["all_cores"] = {"value": n_tests / wall, "unit": "samples/s", "cores": n_tests,
-                                    "sample": "%d independent samples in %d processes: %.1f s wall from a common "
-                                              "start, slowest process %.1f s" % (n_tests, n_tests, wall, busy)}
-    ratio_path = os.path.join(ROOT, "profiles", "%s_oracle_vs_reference.json" % ROUND)
-    if os.path.exists(ratio_path):      # measured in the development container, where the reference can run
-        out["port_vs_reference"] = json.load(open(ratio_path))
-    import shutil
-    shutil.rmtree(tmp, ignore_errors=True)
+def cpu_newref_leg(corrected, bins, k, binsize, idx_gpu, rows, all_cores=True):
+    """The oracle's get_reference (`kind: port`: numpy temporaries + Python insertion scan, the
+    reference's own structure) on `rows` target rows x all candidates: one core, then all cores with
+    the reference's `newref -cpus N` process model (N processes over N row parts, wisecondor.py:47-56)."""
+    import numpy as np
+    B, S = corrected.shape
+    cores = usable_cores()
+    workers = max(1, min(cores, 256))
+    w = CpuWorkers()
+    try:
+        np.save(os.path.join(w.tmp, "corrected.npy"), corrected)     # keeps the memory order (summation order)
+        np.savez(os.path.join(w.tmp, "reference.npz"), bins=bins, k=k, binsize=binsize)
+        sums = np.cumsum(bins)
+
+        def pairs_of(lo, hi):
+            return float(sum(B - bins[np.searchsorted(sums, r, side="right")] for r in range(lo, hi)))
+
+        out = {"unit": "bin-pair distances/s", "kind": "port", "cpu_model": cpu_model(), "host_cores": cores}
+        _, o1 = w.run(1, "newref", rows)
+        lo, hi = o1[0]["rows"]
+        ok = bool(np.array_equal(np.load(os.path.join(w.tmp, "newref_0.npy")), idx_gpu[lo:hi]))
+        out.update({"value": pairs_of(lo, hi) / o1[0]["seconds"], "cores": 1,
+                    "sample": "oracle get_reference on target rows [%d,%d) of %d x all candidates (%d samples), %.1f s"
+                              % (lo, hi, B, S, o1[0]["seconds"]),
+                    "matches_gpu_indices": ok})
+        if all_cores:
+            # wall time includes nothing but the work: the processes start from a common signal
+            wall, oN = w.run(workers, "newref", rows)
+            busy = max(o["seconds"] for o in oN)
+            done = sum(pairs_of(*o["rows"]) for o in oN)
+            out["all_cores"] = {"value": done / wall, "unit": "bin-pair distances/s", "cores": workers,
+                                "sample": "%d processes (newref -cpus %d model), up to %d target rows each: %.1f s wall "
+                                          "from a common start, slowest process %.1f s" % (workers, workers, rows, wall, busy)}
+        return out
+    finally:
+        w.close()
+
+
+def cpu_test_leg(inp, binsize, k, reference_arrays, tb_calls):
+    """The oracle's test_sample (one np.sum per Stouffer window): one sample on one core, then one
+    sample per core (the reference's `test` is single-process: N samples in N processes)."""
+    import numpy as np
+    cores = usable_cores()
+    workers = max(1, min(cores, 256))
+    w = CpuWorkers()
+    try:
+        np.savez(os.path.join(w.tmp, "reference.npz"), bins=inp["masked_bins"], k=k, binsize=binsize, **reference_arrays)
+        n_tests = min(len(inp["tests"]), workers)
+        for i in range(n_tests):
+            np.savez(os.path.join(w.tmp, "sample_%d.npz" % i), **inp["tests"][i])
+        _, t1 = w.run(1, "test")
+        gpu_calls = tb_calls(0)
+        cpu_calls = np.asarray(t1[0]["calls"], dtype=np.float64).reshape(-1, 5)
+        out = {"value": 1.0 / t1[0]["seconds"], "unit": "samples/s", "cores": 1, "kind": "port",
+               "sample": "oracle test_sample on 1 of the batch's samples, %.1f s" % t1[0]["seconds"],
+               "matches_gpu_calls": bool(cpu_calls.shape == gpu_calls.shape and
+                                         np.array_equal(cpu_calls[:, :3], gpu_calls[:, :3]))}
+        if n_tests > 1:
+            wall, tN = w.run(n_tests, "test")
+            busy = max(o["seconds"] for o in tN)
+            out["all_cores"] = {"value": n_tests / wall, "unit": "samples/s", "cores": n_tests,
+                                "sample": "%d independent samples in %d processes: %.1f s wall from a common "
+                                          "start, slowest process %.1f s" % (n_tests, n_tests, wall, busy)}
+        return out
+    finally:
+        w.close()
+
+
+def cpu_segments_leg(regions, thr, total_windows, gpu_segments):
+    """the oracle's fillTri + segmentTri (the part that is ~90 % of the
+    reference's `test`) on one sample's longest chromosomes, one process each, scaled to a whole
+    sample by window count.  gpu_segments: per region the (value) list the GPU path called there."""
+    import numpy as np
+    w = CpuWorkers()
+    try:
+        for i, z in enumerate(regions):
+            np.save(os.path.join(w.tmp, "region_%d.npy" % i), np.ascontiguousarray(z, dtype=np.float64))
+        np.save(os.path.join(w.tmp, "region_thr.npy"), np.float64(thr))
+        wall, outs = w.run(len(regions), "segments")
+        cpu_s = sum(o["seconds"] for o in outs)
+        win = sum(o["windows"] for o in outs)
+        same = all(len(o["segments"]) == len(g) and
+                   np.array_equal(np.array([v for v, _, _ in o["segments"]], dtype=np.float64).view(np.int64),
+                                  np.asarray(g, dtype=np.float64).view(np.int64))
+                   for o, g in zip(outs, gpu_segments))
+        per_sample_s = cpu_s * total_windows / float(win)
+        return {"value": 1.0 / per_sample_s, "unit": "samples/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
+                "sample": "oracle fill_tri + segment_tri on one sample's %d longest chromosomes (%s bins, %d of the "
+                          "sample's %d windows), one process each: %.1f core-seconds, %.1f s wall; scaled to a whole "
+                          "sample by window count (the z-score repeats, ~8 %% of the reference's test, not included)"
+                          % (len(regions), "/".join(str(o["bins"]) for o in outs), win, int(total_windows), cpu_s, wall),
+                "windows_per_core_second": win / cpu_s,
+                "matches_gpu_segments": bool(same)}
+    finally:
+        w.close()
+
+
+def run_cpu_baseline(inp, binsize, k, idx_gpu, reference_arrays, tb_calls, budget_s=8.0):
+    """cpu_baseline of the headline workload: the newref leg (one core + all cores) with the test leg
+    under `test`, and the oracle / reference time ratio measured in the development container."""
+    corrected = inp["corrected"]
+    B, S = corrected.shape
+    # rows per process so that one process works for about budget_s (the numpy distance touches
+    # ~B * S elements three times per target row)
+    rows = int(max(8, min(B, budget_s * 1.0e9 / (float(B) * S))))
+    out = cpu_newref_leg(corrected, inp["masked_bins"], k, binsize, idx_gpu, rows)
+    out["test"] = cpu_test_leg(inp, binsize, k, reference_arrays, tb_calls)
+    for rnd in (ROUND, "r02"):
+        ratio_path = os.path.join(ROOT, "profiles", "%s_oracle_vs_reference.json" % rnd)
+        if os.path.exists(ratio_path):      # measured in the development container, where the reference can run
+            out["port_vs_reference"] = json.load(open(ratio_path))
+            break
     return out
+
+
+# ---------------------------------------------------------------- rooflines ----
+GRAM_KERNELS = {
+    "f16": ("k_gram<f16> (symmetric distance tiles, ONE float16 matrix-core product per multiply, every row's "
+            "representation error charged to its norm bounds, + candidate filter)", 1.0, PEAK_BF16_MFMA),
+    "split": ("k_gram<split> (symmetric distance tiles on the bf16 matrix cores, hi/lo operand pairs: three "
+              "products per multiply, + candidate filter)", SPLIT_PRODUCTS, PEAK_BF16_MFMA),
+    "f32": ("k_gram<f32> (symmetric fp32 MFMA distance tiles + candidate filter)", 1.0, PEAK_FP32_MFMA),
+}
+
+
+def gram_roofline(mode, flops, gram_ms, variants, traffic):
+    """The distance-tile kernel against the matrix-core peak of the operand type it runs on: executed flops
+    (products per multiply x 2 S per unordered pair) over the event time, with SURVEY.md 8(d)'s wording
+    (algorithmic flops against the fp32 MFMA peak) beside it."""
+    name, products, peak = GRAM_KERNELS[mode]
+    achieved = products * flops / (gram_ms * 1e-3)
+    roof = {"kernel": name, "bound": "mfma", "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
+            "frac": achieved / peak, "frac_executed_vs_16bit_mfma_peak": None if mode == "f32" else achieved / peak,
+            "frac_algorithmic_vs_fp32_mfma": flops / (gram_ms * 1e-3) / PEAK_FP32_MFMA,
+            "traffic": hbm_bytes(traffic),
+            "traffic_unit": "HBM-side bytes per launch (rocprofv3 PMC, %s)" % traffic.get("source"),
+            "kernel_ms": gram_ms, "algorithmic_flop_per_launch": flops, "executed_flop_per_launch": products * flops,
+            "algorithmic_tflops": flops / (gram_ms * 1e-3) / 1e12,
+            "note": "algorithmic work = 2 S flop per unordered cross-chromosome pair (SURVEY.md 8d); at the small "
+                    "configs the tile's life is its epilogue (candidate filter + list appends), not its MFMAs"}
+    others = {}
+    for other, ms in sorted(variants.items()):
+        _, pr, pk = GRAM_KERNELS[other]
+        others[other] = {"kernel_ms": ms, "executed_tflops": pr * flops / (ms * 1e-3) / 1e12, "peak": pk / 1e12,
+                         "frac": pr * flops / (ms * 1e-3) / pk}
+    roof["other_tile_modes"] = others or None
+    return roof
+
+
+def test_roofline(prof, n_refs, windows, n_samples, ms_per_batch):
+    """`test` has no single binding roof: per-stage times of one batch (events on the launch stream inside
+    the library), the z-score stage's gathered bytes against the L2 bandwidth (the sample matrix sits in
+    L2 / Infinity Cache, not HBM), the window search's own float64 rate against the vector peak, and the
+    SURVEY.md 8(d) byte model (which charges 8 B per window for a triangle that is never written)."""
+    search_ms = float(prof[5])
+    search_ops = 4.0 * float(prof[6]) + 6.0 * float(prof[7])   # sub, scale, max, min per window; ~6 per bound
+    valu_frac = (search_ops / (search_ms * 1e-3) / PEAK_FP64_VALU_OPS) if search_ms > 0 else None
+    test_bytes = 5.0 * n_refs * 12.0 + windows * 8.0
+    byte_frac = n_samples * test_bytes / (ms_per_batch * 1e-3) / PEAK_HBM
+    z_ms = float(prof[1])
+    z_bytes = n_samples * n_refs * 8.0                          # first repeat: every reference value once
+    return {
+        "bound": "fp64-valu" if byte_frac > 1.0 else "hbm",
+        "frac": valu_frac if byte_frac > 1.0 else byte_frac,
+        "fp64_valu_frac": valu_frac,
+        "fp64_valu_detail": {"kernels": "k_seg_quiet + k_seg_search, all rounds of one batch (events on the launch stream)",
+                             "ms": search_ms, "windows_evaluated": float(prof[6]),
+                             "certificate_evaluations": float(prof[7]), "fp64_ops": search_ops,
+                             "peak_ops_per_s": PEAK_FP64_VALU_OPS},
+        "zscore_gather": {"kernels": "k_zscore + the later repeats' pair kernels", "ms": z_ms,
+                          "gathered_bytes_per_batch": z_bytes,
+                          "achieved_GBps": (z_bytes / (z_ms * 1e-3) / 1e9) if z_ms > 0 else None,
+                          "l2_peak_GBps": PEAK_L2 / 1e9,
+                          "l2_frac": (z_bytes / (z_ms * 1e-3) / PEAK_L2) if z_ms > 0 else None},
+        "hbm_byte_model": {"model": "5 repeats x gathered refs x 12 B + 8 B per Stouffer window (SURVEY.md 8d); "
+                                    "triangle never materialised", "bytes_per_sample": test_bytes,
+                           "achieved_GBps": n_samples * test_bytes / (ms_per_batch * 1e-3) / 1e9,
+                           "peak_GBps": PEAK_HBM / 1e9, "frac": byte_frac},
+        "windows_decided_per_s": n_samples * windows / (ms_per_batch * 1e-3),
+        "stage_ms_per_batch": {"prepare": float(prof[0]), "zscore_repeats": z_ms,
+                               "reshape_clean": float(prof[2]), "segmentation": float(prof[3]),
+                               "calls_outputs": float(prof[4]), "of_segmentation_search": search_ms},
+    }
 
 
 # --------------------------------------------------------------------- main ----
@@ -375,32 +523,49 @@ def main():
     for _ in range(max(1, args.warmup)):
         idx, dst = job.run()                          # (the first pass of a multi-rank job also measures the shard mode)
     sync_all()
-    marks = []
     t0 = time.perf_counter()
+    for s in range(args.steps):
+        idx, dst = job.run()                          # the timed region: K plain passes, nothing else
+    sync_all()
+    t_newref = max_over_ranks(time.perf_counter() - t0)
+    # the same K passes again with events between the stages (on the launch stream): kernel times
+    # for the roofline objects; the events cost ~15 % of a 0.2 ms pass, so they stay out of `value`
+    marks = []
     for s in range(args.steps):
         idx, dst = job.run(timing=True)
         marks.append(job.last_marks)
     sync_all()
-    t_newref = max_over_ranks(time.perf_counter() - t0)
     stages = mean_stages(job, marks)
     gram_ms = stages.get("thresholds->collected")
-    finish_ms = stages.get("collected->rescored", stages.get("exchanged->rescored"))
+    pick_ms = stages.get("collected->picked", stages.get("exchanged->picked"))
+    rescore_ms = stages.get("picked->rescored")
+    finish_ms = None if rescore_ms is None else rescore_ms + (pick_ms or 0.0)
+    if finish_ms is None:
+        finish_ms = stages.get("collected->rescored", stages.get("exchanged->rescored"))
     stats = wt.newref_stats(local_rank)
-    split = os.environ.get("WC_GRAM_MODE", "") != "f32"
-    f32_gram_ms = None
-    if split and world == 1:
-        # the same pass with the distance tiles on the float32 matrix cores (north-star wording),
-        # for the record: a few steps, kernel time only
-        os.environ["WC_GRAM_MODE"] = "f32"
-        job.run()
-        f32_marks = []
-        for _ in range(4):
-            job.run(timing=True)
-            f32_marks.append(job.last_marks)
-        torch.cuda.synchronize()
-        f32_gram_ms = mean_stages(job, f32_marks)["thresholds->collected"]
-        del os.environ["WC_GRAM_MODE"]
-        idx, dst = job.run()                      # leave the context in the default mode
+    gram_mode = os.environ.get("WC_GRAM_MODE", "") or "f16"
+    if gram_mode not in ("f16", "split", "f32"):
+        gram_mode = "f16"
+    variants = {}
+    if world == 1:
+        # the same pass with the distance tiles in the other two forms, for the record (kernel time only):
+        # float32 matrix cores (the north-star's wording) and bf16 hi/lo pairs (round 2's default)
+        for other in ("f32", "split", "f16"):
+            if other == gram_mode:
+                continue
+            os.environ["WC_GRAM_MODE"] = other
+            job.run()
+            v_marks = []
+            for _ in range(4):
+                job.run(timing=True)
+                v_marks.append(job.last_marks)
+            torch.cuda.synchronize()
+            variants[other] = mean_stages(job, v_marks)["thresholds->collected"]
+        if gram_mode == "f16":
+            os.environ.pop("WC_GRAM_MODE", None)
+        else:
+            os.environ["WC_GRAM_MODE"] = gram_mode
+        idx, dst = job.run()                      # leave the context in the mode of the timed passes
         torch.cuda.synchronize()
     ms_per_step = 1e3 * t_newref / args.steps
     value = pairs * args.steps / t_newref
@@ -432,15 +597,13 @@ def main():
     _lib.check(lib.wc_test_profile(ctx, 0))
     n_refs = float((reference.distances < reference.cutoff).sum())
     windows = float(sum(int(n) * (int(n) + 1) // 2 for n in inp["masked_bins"]))
-    test_bytes = 5.0 * n_refs * 12.0 + windows * 8.0        # SURVEY.md 8(d) materialised-triangle model
-    search_ms = float(prof[5])
-    search_ops = 4.0 * float(prof[6]) + 6.0 * float(prof[7])   # sub, scale, max, min per window; ~6 per bound
     # BASELINE config 3: one sample per call (latency mode, nothing amortised over a batch)
     tb1 = distributed.TestBatch(reference, torch.from_numpy(counts_h[:1].copy()).to(dev), thr, max_calls=256)
     # on a stream of its own, as a service thread would call it: on the NULL stream the library has to hop
     # to an internal stream through an event first (a hipGraph cannot be captured on the NULL stream)
     side = torch.cuda.Stream()
     torch.cuda.synchronize()
+    floor = np.zeros(2)
     with torch.cuda.stream(side):
         for _ in range(4):      # the first call sizes the workspaces, the second captures the hipGraph
             tb1.run()
@@ -450,27 +613,20 @@ def main():
             tb1.run()
         torch.cuda.synchronize()
         single_ms = 1e3 * (time.perf_counter() - t0) / 50
-    byte_frac = samples_per_s / world * test_bytes / PEAK_HBM
-    valu_frac = (search_ops / (search_ms * 1e-3) / PEAK_FP64_VALU_OPS) if search_ms > 0 else None
-    test_roof = {
-        # the byte model charges 8 B per window for a triangle that is never written; when it
-        # exceeds 1 the window-search kernels' own float64 rate is the fraction
-        "bound": "fp64-valu" if byte_frac > 1.0 else "hbm",
-        "frac": valu_frac if byte_frac > 1.0 else byte_frac,
-        "fp64_valu_frac": valu_frac,
-        "fp64_valu_detail": {"kernels": "k_seg_quiet + k_seg_search, all rounds of one batch (events on the launch stream)",
-                             "ms": search_ms, "windows_evaluated": float(prof[6]),
-                             "certificate_evaluations": float(prof[7]), "fp64_ops": search_ops,
-                             "peak_ops_per_s": PEAK_FP64_VALU_OPS},
-        "hbm_byte_model": {"model": "5 repeats x gathered refs x 12 B + 8 B per Stouffer window (SURVEY.md 8d); "
-                                    "triangle never materialised", "bytes_per_sample": test_bytes,
-                           "achieved_GBps": samples_per_s / world * test_bytes / 1e9, "peak_GBps": PEAK_HBM / 1e9,
-                           "frac": byte_frac},
-        "windows_decided_per_s": samples_per_s * windows,
-        "stage_ms_per_batch": {"prepare": float(prof[0]), "zscore_repeats": float(prof[1]),
-                               "reshape_clean": float(prof[2]), "segmentation": float(prof[3]),
-                               "calls_outputs": float(prof[4]), "of_segmentation_search": search_ms},
-    }
+        _lib.check(lib.wc_launch_floor_us(ctx, side.cuda_stream, LATENCY_LAUNCHES, 50, _lib.ptr(floor)))
+    lat_kernels = committed_latency_trace()
+    latency = {"workload": "cfg3: test of ONE sample x %d kb bins per call (PCA-apply, 5 z-score repeats, segmentation, "
+                           "calls), one hipGraph replay + one synchronize per call" % (binsize // 1000),
+               "ms_per_call": single_ms, "samples_per_s": 1e3 / single_ms,
+               "launches_in_graph": LATENCY_LAUNCHES,
+               "launch_floor_us": float(floor[0]),
+               "launch_floor_note": "a chain of %d dependent EMPTY launches on the same stream, measured here with "
+                                    "events: what the launch series costs before any kernel does work" % LATENCY_LAUNCHES,
+               "kernel_us_sum": None if not lat_kernels else lat_kernels.get("kernel_us_sum"),
+               "kernel_us": None if not lat_kernels else lat_kernels.get("kernels"),
+               "kernel_source": None if not lat_kernels else lat_kernels.get("source"),
+               "frac_of_call_in_launch_floor": float(floor[0]) * 1e-3 / single_ms}
+    test_roof = test_roofline(prof, n_refs, windows, args.test_samples, 1e3 * t_test / test_steps)
 
     # ------------------------------------------- extra: newref at 600 x 50 kb ----
     # BASELINE.json config 4 (the at-scale shape), kernel-level synthetic matrix; reported
@@ -518,11 +674,34 @@ def main():
                                              "algorithmic_bytes_per_launch": xr_bytes,
                                              "note": "L2 hit rate 15 %%, TCC_EA0_RDREQ 194 M x 128 B = 24.8 GB per launch "
                                                      "(profiles/%s_pmc_busy.json, r2T_cfg4 / r2D_cfg4)" % ROUND}
-            if os.environ.get("WC_GRAM_MODE", "") != "f32":
-                extra["k_gram_executed_tflops"] = SPLIT_PRODUCTS * xflops / (xk_ms * 1e-3) / 1e12
-                extra["k_gram_frac_of_bf16_mfma_peak"] = SPLIT_PRODUCTS * xflops / (xk_ms * 1e-3) / PEAK_BF16_MFMA
-            else:
-                extra["k_gram_frac_of_fp32_mfma_peak"] = xflops / (xk_ms * 1e-3) / PEAK_FP32_MFMA
+            _, xprod, xpeak = GRAM_KERNELS[gram_mode]
+            extra["k_gram_mode"] = gram_mode
+            extra["k_gram_executed_tflops"] = xprod * xflops / (xk_ms * 1e-3) / 1e12
+            extra["k_gram_frac_of_mfma_peak"] = xprod * xflops / (xk_ms * 1e-3) / xpeak
+            extra["k_gram_frac_algorithmic_vs_fp32_mfma"] = xflops / (xk_ms * 1e-3) / PEAK_FP32_MFMA
+            if world == 1:
+                xvar = {}
+                for other in ("f32", "split", "f16"):
+                    if other == gram_mode:
+                        continue
+                    os.environ["WC_GRAM_MODE"] = other
+                    xjob.run()
+                    xjob.run(timing=True)
+                    torch.cuda.synchronize()
+                    xvar[other] = xjob.stage_ms()["thresholds->collected"]
+                if gram_mode == "f16":
+                    os.environ.pop("WC_GRAM_MODE", None)
+                else:
+                    os.environ["WC_GRAM_MODE"] = gram_mode
+                xidx, _ = xjob.run()
+                torch.cuda.synchronize()
+                extra["k_gram_ms_other_tile_modes"] = xvar
+                if rank == 0 and not args.no_cpu_baseline:
+                    # >= 8 target rows x the full candidate set on the host
+                    try:
+                        extra["cpu_baseline"] = cpu_newref_leg(XX.cpu().numpy(), xbins, k, xb, xidx.cpu().numpy(), 8)
+                    except Exception as exc:
+                        extra["cpu_baseline"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
             xt_traffic = committed_traffic("cfg4")
             if world == 1 and xt_traffic:
                 extra["k_gram_hbm_bytes_per_launch"] = hbm_bytes(xt_traffic)
@@ -554,11 +733,38 @@ def main():
                 tb5.run()
             sync_all()
             t5 = max_over_ranks(time.perf_counter() - t0) / 5
+            prof5 = np.zeros(8)
+            _lib.check(lib.wc_test_profile(ctx, 1))
+            tb5.run()
+            _lib.check(lib.wc_test_profile_read(ctx, _lib.ptr(prof5)))
+            _lib.check(lib.wc_test_profile(ctx, 0))
+            n_refs5 = float((ref5.distances < ref5.cutoff).sum())
+            windows5 = float(sum(int(n) * (int(n) + 1) // 2 for n in bins5))
             extra = dict(extra or {})
             extra["test_50kb"] = {"workload": "cfg5, one GPU's share: batched test of 125 samples x 50 kb bins (%d masked bins)"
                                               % int(bins5.sum()),
                                   "value": world * 125 / t5, "unit": "samples/s", "ms_per_batch": 1e3 * t5,
-                                  "samples_per_gpu": 125, "calls_found": int(tb5.n_calls.sum().item())}
+                                  "samples_per_gpu": 125, "calls_found": int(tb5.n_calls.sum().item()),
+                                  "roofline": test_roofline(prof5, n_refs5, windows5, 125, 1e3 * t5)}
+            if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                # one sample x the three longest chromosomes on the host
+                try:
+                    counts5 = wt.samples_to_counts(inp5["tests"][:1], inp5["chrom_bins"])
+                    data5 = np.empty((1, ref5.n_bins))
+                    _lib.check(lib.wc_prepare_samples(ref5.ctx, ref5.handle, _lib.ptr(counts5), 1, _lib.ptr(data5), None))
+                    z5, r5, n5, _ = wt.repeatTest(data5[0], None, None, None, None, None, thr5, 5, reference=ref5)
+                    keep5 = n5 >= 25
+                    offs5 = np.concatenate([[0], np.cumsum(bins5)])
+                    longest = sorted(np.argsort(-bins5)[:3])
+                    regions = [z5[offs5[c]:offs5[c + 1]][keep5[offs5[c]:offs5[c + 1]]] for c in longest]
+                    nc0 = int(tb5.n_calls[0].item())
+                    calls0 = tb5.calls[0, :nc0].cpu().numpy()
+                    gsegs = [calls0[calls0[:, 0] == c + 1][:, 3] for c in longest]
+                    clean_windows = float(sum(int(keep5[offs5[c]:offs5[c + 1]].sum()) *
+                                              (int(keep5[offs5[c]:offs5[c + 1]].sum()) + 1) // 2 for c in range(22)))
+                    extra["test_50kb"]["cpu_baseline"] = cpu_segments_leg(regions, thr5, clean_windows, gsegs)
+                except Exception as exc:
+                    extra["test_50kb"]["cpu_baseline"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
             ref5.close()
             del tb5, job5, X5
         except Exception as exc:
@@ -584,30 +790,7 @@ def main():
         traffic = committed_traffic(args.workload) if world == 1 else {}
         # ---- k_gram: algorithmic work = one multiply-add per sample per unordered pair
         flops = (pairs if job.mode == "rows" else pairs / 2.0) * 2.0 * S / world   # rows mode: ordered pairs
-        if split:
-            # the tiles run on the bf16 matrix cores: three bf16 products stand for one float32
-            # multiply, so the executed work is 3x the algorithmic work and the peak is the bf16 one
-            achieved = SPLIT_PRODUCTS * flops / (gram_ms * 1e-3)
-            roof_gram = {"kernel": "k_gram<split> (symmetric distance tiles on the bf16 matrix cores, hi/lo operand "
-                                   "pairs, + candidate filter)",
-                         "bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_MFMA, "traffic": hbm_bytes(traffic),
-                         "traffic_unit": "HBM-side bytes per launch (rocprofv3 PMC, %s)" % traffic.get("source"),
-                         "kernel_ms": gram_ms, "algorithmic_flop_per_launch": flops,
-                         "executed_flop_per_launch": SPLIT_PRODUCTS * flops,
-                         "algorithmic_tflops": flops / (gram_ms * 1e-3) / 1e12,
-                         "algorithmic_rate_over_fp32_mfma_peak": flops / (gram_ms * 1e-3) / PEAK_FP32_MFMA,
-                         "fp32_mfma_variant": None if f32_gram_ms is None else {
-                             "kernel_ms": f32_gram_ms, "achieved": flops / (f32_gram_ms * 1e-3) / 1e12,
-                             "peak": PEAK_FP32_MFMA / 1e12, "frac": flops / (f32_gram_ms * 1e-3) / PEAK_FP32_MFMA,
-                             "note": "WC_GRAM_MODE=f32: same tiles with v_mfma_f32_32x32x2_f32"}}
-        else:
-            achieved = flops / (gram_ms * 1e-3)
-            roof_gram = {"kernel": "k_gram (symmetric fp32 MFMA distance tiles + candidate filter)",
-                         "bound": "mfma", "achieved": achieved / 1e12, "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA, "traffic": hbm_bytes(traffic),
-                         "traffic_unit": "HBM-side bytes per launch (rocprofv3 PMC, %s)" % traffic.get("source"),
-                         "kernel_ms": gram_ms, "algorithmic_flop_per_launch": flops}
+        roof_gram = gram_roofline(gram_mode, flops, gram_ms, variants, traffic)
         # ---- the float64 re-score stage: algorithmic bytes = the candidate rows it must read
         # (rows x k x S x 8 B) + the output it writes.  The rows are gathered, and
         # neighbouring targets share candidates, so L2 / Infinity Cache serve most of the reads:
@@ -627,9 +810,9 @@ def main():
             # is priced against the L2 gather bandwidth instead, with the issue-side busy fractions beside it
             hbm_binds = hbm_cnt is not None and hbm_cnt >= 0.5 and hbm_alg <= 1.0
             common = {"kernel": "float64 re-score stage: k_pick (k-th key, bound, certificate, compaction) + k_rescore "
-                                "(exact distances in numpy's order, counting order); events around this stage alone, "
+                                "(exact distances in numpy's order, counting order); events around each of the two, "
                                 "the exact-path launches come after",
-                      "kernel_ms": finish_ms, "algorithmic_bytes_per_launch": fbytes,
+                      "kernel_ms": finish_ms, "k_pick_ms": pick_ms, "k_rescore_ms": rescore_ms, "algorithmic_bytes_per_launch": fbytes,
                       "gathered_bytes_per_launch": gathered, "traffic": ft,
                       "traffic_unit": "HBM-side bytes per launch (rocprofv3 PMC, %s)" % traffic.get("source"),
                       "hbm_algorithmic_frac": hbm_alg, "hbm_counter_frac": hbm_cnt, "l2_gather_frac": l2_frac,
@@ -646,8 +829,9 @@ def main():
                                            "exceed 1; `frac` is the gathered bytes over the aggregate L2 bandwidth; "
                                            "issue_busy holds the VALU / LDS busy fractions of k_rescore from "
                                            "profiles/%s_pmc_busy.json -- the stage is issue and gather-latency bound" % ROUND)
-        # `roofline` is the kernel that takes longer per step
-        if roof_finish and finish_ms > gram_ms:
+        # `roofline` is the single kernel that takes longest per step (k_gram against k_rescore alone;
+        # the re-score stage keeps its own object either way)
+        if roof_finish and (rescore_ms or finish_ms) > gram_ms:
             dominant, other = roof_finish, roof_gram
         else:
             dominant, other = roof_gram, roof_finish
@@ -667,8 +851,12 @@ def main():
             # every delivered index and distance is decided in float64 (numpy's bits); the matrix
             # cores only bound the distances to pick the candidates that get re-scored
             "dtype": "f64",
-            "dtype_detail": ("bf16x3 MFMA (hi/lo pairs, f32 accumulate) distance bounds + f64 exact re-score" if split
-                             else "f32 MFMA distance bounds + f64 exact re-score"),
+            "dtype_detail": {"f16": "f16 MFMA (one product per multiply, f32 accumulate, per-row representation error "
+                                    "in the bounds) distance bounds + f64 exact re-score",
+                             "split": "bf16x3 MFMA (hi/lo pairs, f32 accumulate) distance bounds + f64 exact re-score",
+                             "f32": "f32 MFMA distance bounds + f64 exact re-score"}[gram_mode],
+            "timing": "value / ms_per_step: %d plain passes between two synchronizes; stages_ms and the roofline "
+                      "kernel times: %d further passes with events between the stages" % (args.steps, args.steps),
             "data": "synthetic",
             "config": {"workload": "%s: newref %d samples x %d kb bins (%d masked bins, refsize %d), "
                                    "then batched test of %d samples/GPU at the same bin size"
@@ -678,12 +866,12 @@ def main():
                        "shard_mode": job.mode or "single", "shard_calibration_s": job.calibration},
             "stages_ms": stages,
             "prep": {"what": "newrefprep numerics on the GPU (normalise, mask, float64 MFMA Gram, host LAPACK for the "
-                             "leading eigenpairs, components, correctedData left in HBM), %d samples, host counts in; "
-                             "includes the marshalling of the sample dicts" % S,
+                             "leading eigenpairs, components, correctedData left in HBM), %d samples, dense int32 host counts in" % S,
                      "ms": inp.get("prep_ms")},
             "test": {"metric": "test samples/sec", "value": samples_per_s, "unit": "samples/s",
                      "ms_per_batch": 1e3 * t_test / test_steps, "samples_per_gpu": args.test_samples,
-                     "single_sample_latency_ms": single_ms, "roofline": test_roof, "calls_found": n_calls},
+                     "single_sample_latency_ms": single_ms, "latency": latency, "roofline": test_roof,
+                     "calls_found": n_calls},
             "roofline": dominant,
             "roofline_other": other,
             "newref_stats": stats,

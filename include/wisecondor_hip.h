@@ -126,6 +126,15 @@ int wc_newref_rescore_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t 
                           int32_t *idx_out, double *dist_out);
 int wc_newref_fallback_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end,
                            int32_t *idx_out, double *dist_out);
+/* the fast path's own two kernels apart (rescore == pick + rescore_pairs): candidate selection with
+ * the certificate, then the exact float64 distances and their order (wisetools.py:302, 305-324) */
+int wc_newref_pick_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end,
+                       int32_t *idx_out, double *dist_out);
+int wc_newref_rescore_pairs_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end,
+                                int32_t *idx_out, double *dist_out);
+/* measurement helper: microseconds a chain of n dependent empty kernel launches takes on `stream`
+ * (mean over reps) -- the launch floor bench.py prices the one-sample `test` latency against */
+int wc_launch_floor_us(wc_ctx *ctx, void *stream, int n, int reps, double *out);
 
 /*
  * newref prep (upstream of the hot path): toNumpyArray's

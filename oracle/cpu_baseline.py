@@ -2,6 +2,7 @@
 
     python oracle/cpu_baseline.py newref <dir> <part> <parts> <rows>
     python oracle/cpu_baseline.py test   <dir> <part> <parts> <rows>
+    python oracle/cpu_baseline.py segments <dir> <part> <parts> <rows>
 
 Runs the CPU oracle (oracle/wc_oracle.py, the reference's own algorithmic structure) on a
 bounded share of the benchmark workload that bench.py left in <dir>, and prints one JSON line
@@ -9,6 +10,10 @@ with the seconds it took.  `newref`: worker p of n takes <rows> target rows from
 the reference's part p of n (getPart, wisetools.py:358-361) against all candidates -- the
 reference's `-cpus n` process model (wisecondor.py:47-56) on a bounded row count.  `test`:
 worker p tests sample p (one sample per process; the reference's `test` is single-process).
+`segments`: worker p runs the part of `test` that dominates it -- fillTri + segmentTri
+(wisetools.py:466-472, triarray.py:59-84), one np.sum per window -- on the cleaned z vector
+<dir>/region_<p>.npy of one chromosome (config 5 on one sample x the three
+longest chromosomes, scaled by window count).
 """
 import contextlib
 import io
@@ -76,9 +81,25 @@ def test(folder, part):
     print(json.dumps({"seconds": seconds, "calls": calls.tolist()}))
 
 
+def segments(folder, part):
+    z = np.load(os.path.join(folder, "region_%d.npy" % part))
+    thr = float(np.load(os.path.join(folder, "region_thr.npy")))
+    wait_for_go(folder, part)
+    t0 = time.perf_counter()
+    with np.errstate(all="ignore"):
+        tri = wo.fill_tri(z)
+        segs = wo.segment_tri(tri, len(z), thr, 3)
+        whole = float(tri[len(z) - 1])
+    seconds = time.perf_counter() - t0
+    print(json.dumps({"seconds": seconds, "bins": int(len(z)), "windows": int(len(z)) * (int(len(z)) + 1) // 2,
+                      "segments": [[float(v), int(x), int(y)] for v, (x, y) in segs], "whole": whole}))
+
+
 if __name__ == "__main__":
     what, folder, part, parts, rows = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
     if what == "newref":
         newref(folder, part, parts, rows)
+    elif what == "segments":
+        segments(folder, part)
     else:
         test(folder, part)

@@ -244,7 +244,11 @@ def test_bench_line_is_complete_on_one_gpu():
         assert roof["achieved"] > 0 and roof["peak"] > 0 and roof["kernel_ms"] > 0
     extra = line["extra"]
     assert "error" not in extra, extra
-    assert extra["ms_per_step"] > 0 and 0 < extra["k_gram_frac_of_bf16_mfma_peak"] <= 1.0
+    assert extra["ms_per_step"] > 0 and 0 < extra["k_gram_frac_of_mfma_peak"] <= 1.0
+    assert line["roofline"]["kernel"].startswith("k_gram") or line["roofline"]["kernel"].startswith("float64 re-score")
+    assert line["test"]["latency"]["launch_floor_us"] > 0 and line["test"]["latency"]["ms_per_call"] > 0
+    assert 0 < extra["test_50kb"]["roofline"]["fp64_valu_frac"] <= 1.0
+    assert extra["test_50kb"]["roofline"]["zscore_gather"]["l2_frac"] <= 1.0
     assert 0 < extra["rescore_roofline"]["frac"] <= 1.3             # at the HBM roof on uncorrelated rows (15 % of the gathers hit L2)
     assert "error" not in extra["test_50kb"], extra["test_50kb"]
     assert extra["test_50kb"]["value"] > 1000 and extra["test_50kb"]["calls_found"] > 0

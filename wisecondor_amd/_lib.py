@@ -39,6 +39,9 @@ SIGNATURES = {
     "wc_newref_finish_dev": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "wc_newref_rescore_dev": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "wc_newref_fallback_dev": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "wc_newref_pick_dev": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "wc_newref_rescore_pairs_dev": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "wc_launch_floor_us": (_i32, [_vp, _vp, _i32, _i32, _vp]),
     "wc_newref_prep_gram": (_i32, [_vp, _vp, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
     "wc_newref_prep_finish": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "wc_newref_prep_finish_dev": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),

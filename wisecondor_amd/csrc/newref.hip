@@ -2316,7 +2316,7 @@ static int newref_finish_part(wc_ctx *ctx, void *stream_, int64_t row_begin, int
     hipStream_t stream = (hipStream_t)stream_;
     int rc;
     if ((rc = st.fb_scratch.reserve(sizeof(uint64_t) * FB_BLOCKS * st.bins_pad))) return rc;
-    if (which & 1) WC_HIP(hipMemsetAsync(st.fb_count.p, 0, sizeof(int) * 4, stream));
+    if (which & 5) WC_HIP(hipMemsetAsync(st.fb_count.p, 0, sizeof(int) * 4, stream));
     FinishArgs a{};
     a.X = st.corrected;
     a.B = st.n_bins;
@@ -2348,21 +2348,24 @@ static int newref_finish_part(wc_ctx *ctx, void *stream_, int64_t row_begin, int
     const char *eng = getenv("WC_FINISH_ENGINE");   // "rows": the one-workgroup-per-row kernel (k_finish) for every row
     // pair engine: workgroups of k + margin threads (whole waves); refsize beyond PS_MAX - 28 takes several trips
     const int ps = (int)std::max<int64_t>(128, std::min<int64_t>(PS_MAX, round_up(st.k + 28, 64)));
+    const bool pair_engine = st.x64_pad && !(eng && strcmp(eng, "rows") == 0) && !st.exact_only;
+    if ((which & 12) && !pair_engine) which = (which & ~12) | ((which & 4) ? 1 : 0);   // no halves outside the pair engine: all of it in the first call
     if ((which & 1) && st.exact_only) {
         const unsigned rows = (unsigned)(row_end - row_begin);
         hipLaunchKernelGGL(k_all_exact, dim3((rows + 255) / 256), dim3(256), 0, stream, a);
-    } else if ((which & 1) && st.x64_pad && !(eng && strcmp(eng, "rows") == 0)) {
+    } else if ((which & 13) && pair_engine) {
         const bool seq = st.sum_order == WC_SUM_SEQUENTIAL || st.n_samples < 8;
         if ((rc = st.pairs.reserve(sizeof(int) * st.bins_pad * RMAX))) return rc;
         PickArgs p{a, st.pairs.as<int>(), ps};
         const unsigned rows = (unsigned)(row_end - row_begin);
-        hipLaunchKernelGGL(k_pick, dim3((rows + 3) / 4), dim3(256), 0, stream, p);
+        if (which & 5) hipLaunchKernelGGL(k_pick, dim3((rows + 3) / 4), dim3(256), 0, stream, p);
         // wave slabs; after the sums the same memory holds dk / sd / jv / sj of the counting order
         const size_t slabs = sizeof(double) * (size_t)(ps / 64) * SLAB_DOUBLES;
         const size_t order = (sizeof(unsigned long long) + sizeof(int)) * (2 * RMAX + 4);
         const size_t dyn = sizeof(double) * st.s_pad + std::max(slabs, order);
-        if (seq) hipLaunchKernelGGL((k_rescore<true>), dim3(rows), dim3(ps), dyn, stream, p,
-                                    (const double *)st.x64.as<double>(), (int)st.s_pad);
+        if (!(which & 9)) {
+        } else if (seq) hipLaunchKernelGGL((k_rescore<true>), dim3(rows), dim3(ps), dyn, stream, p,
+                                           (const double *)st.x64.as<double>(), (int)st.s_pad);
         else hipLaunchKernelGGL((k_rescore<false>), dim3(rows), dim3(ps), dyn, stream, p,
                                 (const double *)st.x64.as<double>(), (int)st.s_pad);
     } else if (which & 1) {
@@ -2402,6 +2405,45 @@ int wc_newref_rescore_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t 
 int wc_newref_fallback_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end, int32_t *idx_out,
                            double *dist_out) {
     return newref_finish_part(ctx, stream, row_begin, row_end, idx_out, dist_out, 2);
+}
+
+int wc_newref_pick_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end, int32_t *idx_out,
+                       double *dist_out) {
+    return newref_finish_part(ctx, stream, row_begin, row_end, idx_out, dist_out, 4);
+}
+
+int wc_newref_rescore_pairs_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end, int32_t *idx_out,
+                                double *dist_out) {
+    return newref_finish_part(ctx, stream, row_begin, row_end, idx_out, dist_out, 8);
+}
+
+__global__ void k_noop(int *p) {
+    if (p && threadIdx.x == 9999) *p = 0;
+}
+
+// Launch floor of this box: a chain of `n` dependent empty launches on `stream`, timed with events
+// over `reps` repetitions; out[0] = microseconds per chain.  What a series of n tiny kernels costs
+// before any of them does work (bench.py prices the one-sample latency path against it).
+int wc_launch_floor_us(wc_ctx *ctx, void *stream_, int n, int reps, double *out) {
+    WC_CHECK(ctx && out && n > 0 && reps > 0, WC_E_ARG, "launch floor: bad argument");
+    WC_HIP(hipSetDevice(ctx->device));
+    hipStream_t stream = (hipStream_t)stream_;
+    hipEvent_t e0, e1;
+    WC_HIP(hipEventCreate(&e0));
+    WC_HIP(hipEventCreate(&e1));
+    for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, stream, (int *)nullptr);
+    WC_HIP(hipStreamSynchronize(stream));
+    WC_HIP(hipEventRecord(e0, stream));
+    for (int r = 0; r < reps; ++r)
+        for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, stream, (int *)nullptr);
+    WC_HIP(hipEventRecord(e1, stream));
+    WC_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    WC_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    out[0] = 1e3 * (double)ms / (double)reps;
+    return WC_OK;
 }
 
 static int newref_pass(wc_ctx *ctx, void *stream, const double *corrected, int64_t n_bins, int64_t n_samples,

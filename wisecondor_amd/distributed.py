@@ -90,6 +90,13 @@ class HipStages(object):
         """The per-row fast path alone (finish == rescore + fallback), for callers that time them apart."""
         _lib.check(self.lib.wc_newref_rescore_dev(self.ctx, self._stream(), rb, re, idx.data_ptr(), dst.data_ptr()))
 
+    def pick(self, rb, re, idx, dst):
+        _lib.check(self.lib.wc_newref_pick_dev(self.ctx, self._stream(), rb, re, idx.data_ptr(), dst.data_ptr()))
+
+    def rescore_pairs(self, rb, re, idx, dst):
+        _lib.check(self.lib.wc_newref_rescore_pairs_dev(self.ctx, self._stream(), rb, re, idx.data_ptr(),
+                                                        dst.data_ptr()))
+
     def fallback(self, rb, re, idx, dst):
         _lib.check(self.lib.wc_newref_fallback_dev(self.ctx, self._stream(), rb, re, idx.data_ptr(), dst.data_ptr()))
 
@@ -307,7 +314,7 @@ class NewrefJob(object):
     def stage_ms(self):
         """Milliseconds between the marks of the last timed run (call after a synchronize)."""
         m = self.last_marks or {}
-        order = ["start", "prepared", "thresholds", "collected", "exchanged", "rescored", "finished", "gathered"]
+        order = ["start", "prepared", "thresholds", "collected", "exchanged", "picked", "rescored", "finished", "gathered"]
         have = [n for n in order if n in m]
         return {"%s->%s" % (a, b): m[a].elapsed_time(m[b]) for a, b in zip(have, have[1:])}
 
@@ -413,7 +420,12 @@ class NewrefJob(object):
         if self._marks is None:
             self.st.finish(rb, re, idx, dst)
             return
-        self.st.rescore(rb, re, idx, dst)
+        if hasattr(self.st, "pick"):
+            self.st.pick(rb, re, idx, dst)
+            self._mark("picked")
+            self.st.rescore_pairs(rb, re, idx, dst)
+        else:
+            self.st.rescore(rb, re, idx, dst)
         self._mark("rescored")
         self.st.fallback(rb, re, idx, dst)
         self._mark("finished")

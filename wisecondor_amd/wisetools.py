@@ -386,7 +386,7 @@ def _pinned(shape):
         return np.empty(shape)
 
 
-def prepReference(samples, pcacomp=3, device=0, device_out=False):
+def prepReference(samples, pcacomp=3, device=0, device_out=False, counts=None, chrom_bins=None):
     """toNumpyArray + trainPCA (wisetools.py:240-264, 89-101) with the bins-sized work on the GPU.
 
     The Gram matrix of the centred [samples, bins] data comes from the GPU (float64 matrix
@@ -399,11 +399,18 @@ def prepReference(samples, pcacomp=3, device=0, device_out=False):
     come back as torch tensors on the device, correctedData as the C-ordered [B,S] tensor that
     getReference / NewrefJob take directly -- its values are those of the reference's
     Fortran-ordered array, so pass sum_order=_lib.SUM_SEQUENTIAL.
+
+    counts / chrom_bins: the samples already as the dense int32 [samples, bins] matrix of
+    samples_to_counts (a caller that ingests many files keeps them that way); `samples` is ignored.
     """
     lib = _lib.load()
     ctx = _lib.context(device)
-    chromBins = [max(len(s[str(c)]) for s in samples) for c in range(1, 23)]
-    counts = samples_to_counts(samples, chromBins)
+    if counts is None:
+        chromBins = [max(len(s[str(c)]) for s in samples) for c in range(1, 23)]
+        counts = samples_to_counts(samples, chromBins)
+    else:
+        chromBins = [int(v) for v in chrom_bins]
+        counts = np.ascontiguousarray(counts, dtype=np.int32)
     n_s, n_total = counts.shape
     sizes = np.ascontiguousarray(chromBins, dtype=np.int64)
     mask = np.empty(n_total, dtype=np.uint8)
