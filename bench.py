@@ -771,6 +771,50 @@ def main():
             extra = dict(extra or {})
             extra["test_50kb"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
+    # ---------------------------------------------------- extra: ingest ----
+    # `testbatch` end to end -- converted-sample files on local disk -> GPU batches ->
+    # one result file per sample -- in files/s, beside the samples/s of the kernels alone
+    if rank == 0 and world == 1 and not args.no_extra:
+        try:
+            import contextlib
+            import io
+            import shutil
+            from wisecondor_amd import wisecondor as cli
+            tmp_io = tempfile.mkdtemp(prefix="wc_ingest_")
+            n_files = 4096        # the box spreads a process's threads over its cores only after ~1 s of load
+            refpath = os.path.join(tmp_io, "reference.npz")
+            np.savez(refpath, arguments={}, runtime={}, binsize=float(binsize), indexes=idx_h, distances=dst_h,
+                     chromosome_sizes=inp["chrom_bins"], mask=inp["mask"], masked_sizes=inp["masked_bins"],
+                     pca_components=inp["pca_components"], pca_mean=inp["pca_mean"])
+            paths_io = []
+            for i in range(n_files):
+                p_io = os.path.join(tmp_io, "s_%04d.npz" % i)
+                if i < 64:
+                    np.savez_compressed(p_io, arguments={"binsize": float(binsize)}, runtime={},
+                                        sample=inp["tests"][i % len(inp["tests"])], quality={})
+                else:
+                    shutil.copyfile(paths_io[i % 64], p_io)
+                paths_io.append(p_io)
+            io_threads = usable_cores()
+            buf_io = io.StringIO()
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(buf_io):
+                cli.main(["testbatch"] + paths_io + [os.path.join(tmp_io, "out"), refpath, "-batch", "512", "-io",
+                                                     str(io_threads)])
+            wall_io = time.perf_counter() - t0
+            rep = [ln for ln in buf_io.getvalue().splitlines() if ln.startswith("rank 0")][-1]
+            files_per_s = float(rep.split("(")[1].split(" files/s")[0])
+            extra = dict(extra or {})
+            extra["ingest"] = {"what": "testbatch end to end: %d converted-sample files (%d kb bins) on local disk -> native "
+                                       "decode pool -> GPU batches of 512 -> native encode pool (zlib level 1, run-length) -> %d result "
+                                       "files" % (n_files, binsize // 1000, n_files),
+                               "files_per_s": files_per_s, "unit": "files/s", "io_threads": io_threads,
+                               "wall_s_incl_reference_load": wall_io, "report": rep}
+            shutil.rmtree(tmp_io, ignore_errors=True)
+        except Exception as exc:
+            extra = dict(extra or {})
+            extra["ingest"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+
     # ------------------------------------------------------- cpu baseline ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -137,6 +137,38 @@ int wc_newref_rescore_pairs_dev(wc_ctx *ctx, void *stream, int64_t row_begin, in
 int wc_launch_floor_us(wc_ctx *ctx, void *stream, int n, int reps, double *out);
 
 /*
+ * Native sample ingest and result output for many files (replaces the
+ * np.load loop of wisecondor.py:75-80 / 193-196 and the np.savez_compressed of wisecondor.py:270-280
+ * for batches).  Host only, plain threads, no GPU.
+ *
+ * wc_read_samples: file i of `paths` (a converted sample: members `sample` = pickled dict
+ *   chromosome -> integer array, `arguments` = pickled dict with 'binsize') -> row i of counts_out
+ *   (int32 [n_files, row_stride]): chromosomes '1'..'n_chrom', each padded with zeros / truncated to
+ *   chrom_sizes[c] (toNumpyRefFormat, wisetools.py:268-274), bins merged when to_binsize is a whole
+ *   multiple of the file's own bin size (scaleSample, wisetools.py:220-237; to_binsize <= 0: keep).
+ *   binsize_out[i] = the file's own bin size.  status[i]: WC_OK, or WC_NPZ_* -- then the row is
+ *   undefined and the caller reads that file the slow way (np.load), which also words the error.
+ * wc_write_test_results: one `test` output file per row (keys / dtypes / shapes of the reference's,
+ *   SURVEY.md App. B): arguments (args_npy[i]: the ready-made .npy member bytes, a pickled dict),
+ *   runtime (shared bytes), binsize, results_r / results_z (object arrays of n_chrom float64 arrays cut
+ *   from row i of r / z at chrom_sizes), results_cwz [n_sel], results_calls [n, 5] (shape (0,) when
+ *   empty), threshold_z, asdef, aasdef = asdef * threshold_z.  level: zlib level of the members
+ *   (0 = stored).  status[i]: WC_OK or WC_NPZ_IO.
+ * Both return WC_OK unless an argument is unusable; per-file outcomes are in status.
+ */
+#define WC_NPZ_UNSUPPORTED 1   /* not a file this reader understands (layout, pickle opcode, dtype) */
+#define WC_NPZ_IO 2            /* could not read / write the file */
+#define WC_NPZ_BINSIZE 3       /* the file's bin size cannot be scaled to to_binsize */
+int wc_read_samples(const char *const *paths, int n_files, int n_threads, const int64_t *chrom_sizes, int n_chrom,
+                    double to_binsize, int32_t *counts_out, int64_t row_stride, double *binsize_out, int *status);
+int wc_write_test_results(int n_files, int n_threads, const char *const *out_paths,
+                          const unsigned char *const *args_npy, const int64_t *args_len,
+                          const unsigned char *runtime_npy, int64_t runtime_len, double binsize, double threshold_z,
+                          const int64_t *chrom_sizes, int n_chrom, const double *z, const double *r,
+                          int64_t row_stride, const double *cwz, int n_sel, const double *calls,
+                          const int32_t *n_calls, int max_calls, const double *asdef, int level, int *status);
+
+/*
  * newref prep (upstream of the hot path): toNumpyArray's
  * normalisation + all-zero-bin mask (wisetools.py:240-264) and trainPCA
  * (wisetools.py:89-101) as a deterministic exact PCA (float64 Gram matrix on the GPU,

@@ -43,6 +43,17 @@ def test_reference_report_and_plot_read_our_output(tmp_path, golden):
     cli.writeTestOutput(str(tmp_path / "none.npz"), args, float(g["binsize"]), empty, out["threshold_z"])
     assert np.load(str(tmp_path / "none.npz"), allow_pickle=True)["results_calls"].shape == (0,)
 
+    # the same result through the native batch writer (csrc/npzio.cpp): the reference's report must
+    # read that file as well
+    from wisecondor_amd import ingest
+    sizes = [int(v) for v in g["ref_chromosome_sizes"]]
+    native = str(tmp_path / "sample_native.npz")
+    calls = np.asarray(out["results_calls"], dtype=np.float64).reshape(1, -1, 5)
+    ingest.write_results([native], [args], {"version": "t"}, float(g["binsize"]), float(out["threshold_z"]), sizes,
+                         np.concatenate(out["results_z"])[None, :].copy(), np.concatenate(out["results_r"])[None, :].copy(),
+                         np.asarray(out["results_cwz"], dtype=np.float64)[None, :].copy(), np.ascontiguousarray(calls),
+                         np.array([calls.shape[1]], dtype=np.int32), np.array([out["asdef"]], dtype=np.float64))
+
     wt, wc, _ = ref_loader.load()
     convert_out = str(tmp_path / "sample.npz")
     quality = dict(mapped=1, unmapped=0, no_coordinate=0, filter_rmdup=0, filter_mapq=0, pre_retro=1,
@@ -53,6 +64,10 @@ def test_reference_report_and_plot_read_our_output(tmp_path, golden):
     with contextlib.redirect_stdout(buf):
         wc.toolReport(argparse.Namespace(testfile=convert_out, resultfile=outfile, mineffect=1.5))
     text = buf.getvalue()
+    buf2 = io.StringIO()
+    with contextlib.redirect_stdout(buf2):
+        wc.toolReport(argparse.Namespace(testfile=convert_out, resultfile=native, mineffect=1.5))
+    assert buf2.getvalue() == text
     assert "# Test results: #" in text
     assert "-157.33\t-49.85" in text            # the chr2 loss: z-score and effect in per cent
     assert "2:100000000-140000000" in text

@@ -1,0 +1,189 @@
+"""The native sample reader / result writer (csrc/npzio.cpp) against numpy's
+own np.load / np.savez on the same files.  Host only: runs without a GPU."""
+import argparse
+import io
+import os
+import pickle
+import struct
+import zipfile
+
+import numpy as np
+import pytest
+
+from wisecondor_amd import ingest
+from wisecondor_amd import wisetools as wt
+
+KEYS = [str(c) for c in range(1, 23)] + ["X", "Y"]
+
+
+def _sample(seed, lengths, dtype=np.int32):
+    rng = np.random.RandomState(seed)
+    return {k: rng.poisson(40.0, size=n).astype(dtype) for k, n in zip(KEYS, lengths)}
+
+
+def _npy_object(obj, protocol):
+    buf = io.BytesIO()
+    np.lib.format.write_array_header_1_0(buf, {"descr": "|O", "fortran_order": False, "shape": ()})
+    return buf.getvalue() + pickle.dumps(np.array(obj, dtype=object), protocol=protocol)
+
+
+def _write_with_protocol(path, sample, binsize, protocol, compress=True):
+    with zipfile.ZipFile(path, "w", zipfile.ZIP_DEFLATED if compress else zipfile.ZIP_STORED) as z:
+        z.writestr("arguments.npy", _npy_object({"binsize": binsize, "infile": "x.bam", "retdist": 4}, protocol))
+        z.writestr("runtime.npy", _npy_object({}, protocol))
+        z.writestr("sample.npy", _npy_object(sample, protocol))
+        z.writestr("quality.npy", _npy_object({"mapped": 1}, protocol))
+
+
+def _py2_pickle_of_sample(sample, binsize=None):
+    """The opcode stream Python 2's numpy wrote for `np.array(dict, dtype=object)`: protocol 2, GLOBAL
+    references, str (not bytes) payloads in BINSTRING / SHORT_BINSTRING -- what the reference's own
+    `convert` leaves on disk."""
+    def s_(b):
+        return (b"U" + bytes([len(b)]) + b) if len(b) < 256 else (b"T" + struct.pack("<i", len(b)) + b)
+
+    def int_(v):
+        return b"K" + bytes([v]) if 0 <= v < 256 else (b"M" + struct.pack("<H", v) if v < 65536 else b"J" + struct.pack("<i", v))
+
+    def dtype_(code, endian, flags):
+        return (b"cnumpy\ndtype\n" + s_(code) + b"K\x00K\x01\x87R(K\x03" + s_(endian) + b"NNNJ\xff\xff\xff\xffJ\xff\xff\xff\xff"
+                + int_(flags) + b"tb")
+    recon = b"cnumpy.core.multiarray\n_reconstruct\ncnumpy\nndarray\nK\x00\x85" + s_(b"b") + b"\x87R"
+    out = b"\x80\x02" + recon + b"(K\x01)" + dtype_(b"O8", b"|", 63) + b"\x89]}("
+    if binsize is not None:
+        out += s_(b"binsize") + b"G" + struct.pack(">d", binsize)
+    else:
+        for k, v in sample.items():
+            v = np.ascontiguousarray(v, dtype="<i4")
+            out += s_(k.encode()) + recon + b"(K\x01" + int_(len(v)) + b"\x85" + dtype_(b"i4", b"<", 0) + b"\x89" + s_(v.tobytes()) + b"tb"
+    out += b"uatb."
+    buf = io.BytesIO()
+    np.lib.format.write_array_header_1_0(buf, {"descr": "|O", "fortran_order": False, "shape": ()})
+    return buf.getvalue() + out
+
+
+def _reference_rows(paths, sizes, to_binsize):
+    rows = np.zeros((len(paths), int(np.sum(sizes))), dtype=np.int32)
+    for i, p in enumerate(paths):
+        ingest._count_row(p, to_binsize, sizes, rows[i])
+    return rows
+
+
+def test_reader_matches_np_load(tmp_path):
+    sizes = [30 + 2 * c for c in range(22)]
+    paths = []
+    # ragged files: some chromosomes longer (truncate), some shorter (zero pad) than the reference's
+    for i in range(6):
+        lengths = [max(1, n + (i - 3) * (c % 3)) for c, n in enumerate(sizes)] + [17, 9]
+        p = str(tmp_path / ("s%d.npz" % i))
+        np.savez_compressed(p, arguments={"binsize": 250000.0, "infile": "a.bam"}, runtime={},
+                            sample=_sample(i, lengths, np.int64 if i == 4 else np.int32), quality={})
+        paths.append(p)
+    # older pickle protocols, stored (not deflated) members, integer bin size
+    for proto in (2, 3):
+        p = str(tmp_path / ("p%d.npz" % proto))
+        _write_with_protocol(p, _sample(10 + proto, sizes + [5, 5]), 250000 if proto == 2 else 250000.0, proto,
+                             compress=proto == 3)
+        paths.append(p)
+    want = _reference_rows(paths, sizes, 250000.0)
+    got = np.full_like(want, -7)
+    slow = []
+    own = ingest.read_counts(paths, sizes, 250000.0, got, threads=3, fallbacks=slow)
+    assert slow == []                                   # every one of these went through the native reader
+    assert np.array_equal(got, want)
+    assert np.all(own == 250000.0)
+
+
+def test_reader_python2_files_and_scaling(tmp_path):
+    sizes = [12 + c for c in range(22)]
+    fine = [5 * n - (c % 4) for c, n in enumerate(sizes)] + [40, 11]        # 50 kb bins, ragged ends
+    sample = _sample(3, fine)
+    p2 = str(tmp_path / "py2.npz")
+    with zipfile.ZipFile(p2, "w", zipfile.ZIP_DEFLATED) as z:
+        z.writestr("sample.npy", _py2_pickle_of_sample(sample))
+        z.writestr("arguments.npy", _py2_pickle_of_sample(None, binsize=50000.0))
+    back = np.load(p2, allow_pickle=True, encoding="latin1")
+    assert back["arguments"].item()["binsize"] == 50000.0 and np.array_equal(back["sample"].item()["7"], sample["7"])
+    p3 = str(tmp_path / "py3.npz")
+    np.savez_compressed(p3, arguments={"binsize": 50000.0}, runtime={}, sample=sample, quality={})
+    want = _reference_rows([p2, p3], sizes, 250000.0)
+    assert want.sum() > 0 and np.array_equal(want[0], want[1])
+    got = np.zeros_like(want)
+    slow = []
+    own = ingest.read_counts([p2, p3], sizes, 250000.0, got, threads=2, fallbacks=slow)
+    assert slow == []
+    assert np.array_equal(got, want) and list(own) == [50000.0, 50000.0]
+    # no scaling asked: the fine bins, padded / truncated
+    want = _reference_rows([p2], sizes, None)
+    got = np.zeros_like(want)
+    ingest.read_counts([p2], sizes, None, got)
+    assert np.array_equal(got, want)
+
+
+def test_reader_falls_back_and_reports(tmp_path):
+    sizes = [10] * 22
+    odd = {k: np.arange(10, dtype=np.float16) for k in KEYS}               # a dtype the native reader does not take
+    p = str(tmp_path / "odd.npz")
+    np.savez_compressed(p, arguments={"binsize": 1e6}, runtime={}, sample=odd, quality={})
+    got = np.zeros((1, 220), dtype=np.int32)
+    slow = []
+    ingest.read_counts([p], sizes, 1e6, got, fallbacks=slow)
+    assert slow == [0]
+    assert np.array_equal(got[0, :10], np.arange(10))
+    # an impossible rescale is the reference's ERROR + exit(1) (wisetools.py:224-226), worded by the Python path
+    with pytest.raises(SystemExit):
+        ingest.read_counts([p], sizes, 1500000.0, got)
+    with pytest.raises(Exception):
+        ingest.read_counts([str(tmp_path / "missing.npz")], sizes, 1e6, got)
+
+
+def test_writer_matches_np_savez(tmp_path):
+    from wisecondor_amd import wisecondor as cli
+    rng = np.random.RandomState(5)
+    sizes = [7 + (c % 5) for c in range(22)]
+    n_total, n = int(np.sum(sizes)), 4
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    z = rng.standard_normal((n, n_total))
+    z[:, ::7] = 0.0
+    r = rng.standard_normal((n, n_total)) * 0.01
+    cwz = rng.standard_normal((n, 22))
+    calls = rng.standard_normal((n, 8, 5))
+    n_calls = np.array([3, 0, 8, 1], dtype=np.int32)
+    asdef = rng.uniform(0.9, 1.1, size=n)
+    args = cli.buildParser().parse_args(["test", "in.npz", "out.npz", "ref.npz"])
+    per_file, outs = [], []
+    for i in range(n):
+        one = argparse.Namespace(**vars(args))
+        one.infile, one.outfile = "in_%d.npz" % i, str(tmp_path / ("native_%d.npz" % i))
+        per_file.append(one)
+        outs.append(one.outfile)
+    runtime = {"version": "abc", "datetime": "now", "hostname": "h", "username": "u"}
+    for level in (1, 0):
+        ingest.write_results(outs, per_file, runtime, 250000.0, 5.25, sizes, z, r, cwz, calls, n_calls, asdef,
+                             threads=3, level=level)
+        for i in range(n):
+            result = dict(results_z=[z[i, offs[c]:offs[c + 1]] for c in range(22)],
+                          results_r=[r[i, offs[c]:offs[c + 1]] for c in range(22)],
+                          results_cwz=cwz[i], results_calls=calls[i, :n_calls[i]], asdef=float(asdef[i]))
+            ref_path = str(tmp_path / ("python_%d.npz" % i))
+            cli.writeTestOutput(ref_path, per_file[i], 250000.0, result, 5.25)
+            a = np.load(ref_path, allow_pickle=True)
+            b = np.load(outs[i], allow_pickle=True)
+            assert sorted(a.files) == sorted(b.files)
+            for key in a.files:
+                x, y = a[key], b[key]
+                if key == "runtime":
+                    assert y.item() == runtime
+                    continue
+                assert x.dtype == y.dtype and x.shape == y.shape, key
+                if x.dtype == object and x.shape == ():
+                    assert x.item() == y.item(), key
+                elif x.dtype == object:
+                    assert all(p.dtype == q.dtype and np.array_equal(p, q) for p, q in zip(x, y)), key
+                else:
+                    assert np.array_equal(x, y), key
+            assert b["results_calls"].shape == ((n_calls[i], 5) if n_calls[i] else (0,))
+            with zipfile.ZipFile(outs[i]) as zf:
+                assert zf.testzip() is None
+                assert {m.compress_type for m in zf.infolist() if m.file_size > 64} == \
+                    {zipfile.ZIP_DEFLATED if level else zipfile.ZIP_STORED}

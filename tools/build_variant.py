@@ -24,7 +24,7 @@ try:
     subprocess.check_call([_hipcc()] + FLAGS + ["-c", tmp, "-o", obj])
 finally:
     os.remove(tmp)
-objs = [obj if s == fname else os.path.join(CSRC, s.replace(".hip", ".o")) for s in SOURCES]
+objs = [obj if s == fname else os.path.join(CSRC, os.path.splitext(s)[0] + ".o") for s in SOURCES]
 out = os.path.join(ROOT, "wisecondor_amd", "ab", "lib_%s.so" % name)
-subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-lz"])
 print(out)

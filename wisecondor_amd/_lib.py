@@ -42,6 +42,9 @@ SIGNATURES = {
     "wc_newref_pick_dev": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "wc_newref_rescore_pairs_dev": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "wc_launch_floor_us": (_i32, [_vp, _vp, _i32, _i32, _vp]),
+    "wc_read_samples": (_i32, [_vp, _i32, _i32, _vp, _i32, _dbl, _vp, _i64, _vp, _vp]),
+    "wc_write_test_results": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _i32, _vp, _vp, _i64, _vp,
+                                     _i32, _vp, _vp, _i32, _vp, _i32, _vp]),
     "wc_newref_prep_gram": (_i32, [_vp, _vp, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
     "wc_newref_prep_finish": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "wc_newref_prep_finish_dev": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -142,7 +145,9 @@ def _warn_if_two_hip_runtimes():
 
 def check(rc):
     if rc != 0:
-        raise WisecondorHipError("wisecondor_hip error %d: %s" % (rc, load().wc_last_error().decode()))
+        err = WisecondorHipError("wisecondor_hip error %d: %s" % (rc, load().wc_last_error().decode()))
+        err.code = rc          # one of E_ARG / E_HIP / E_LIMIT / E_INTERNAL
+        raise err
 
 
 def ptr(arr):

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwisecondor_hip.so")
-SOURCES = ["ctx.hip", "newref.hip", "testpath.hip", "prep.hip"]
+SOURCES = ["ctx.hip", "newref.hip", "testpath.hip", "prep.hip", "npzio.cpp"]   # npzio.cpp: host only (zip / pickle / zlib)
 # -fno-slp-vectorize: the SLP vectoriser pairs float32 operations into v_pk_add_f32 /
 # v_pk_fma_f32; an in-place pair whose low half reads the destination's high half
 # (v_pk_add_f32 v[74:75], v[84:85], v[74:75] op_sel:[0,1]) returned run-to-run different
@@ -45,7 +45,7 @@ def build_library(force=False, verbose=True):
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
         cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -54,7 +54,7 @@ def build_library(force=False, verbose=True):
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on %s" % src)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -4,18 +4,22 @@ The upstream tools read one converted sample after the other with np.load inside
 driver loop (wisecondor.py:75-80, 193-196) and `test` handles one file per process.
 Once the GPU side takes a fraction of a millisecond per sample, decoding the .npz
 members (zip inflate + unpickle of the chromosome dict) and encoding the result files
-is the ceiling, so both run in thread pools (zlib releases the GIL), batches are
-double buffered, and the dense count rows are staged in pinned host memory for the
-copy engine.  Nothing numeric happens here.
+is the ceiling -- and in Python both hold the GIL for most of their time.  So both run in
+the library's C++ thread pools (csrc/npzio.cpp: zip, a small pickle machine, zlib), batches are
+double buffered, and the dense count rows are staged in pinned host memory for the copy
+engine.  Nothing numeric happens here.
 """
 import argparse
 import collections
 import concurrent.futures
+import ctypes
 import os
+import pickle
 import time
 
 import numpy as np
 
+from . import _lib
 from . import wisetools as wt
 
 LoadedSamples = collections.namedtuple('LoadedSamples', 'samples binsizes')
@@ -45,6 +49,75 @@ def _count_row(path, to_binsize, sizes, out_row):
     out_row[:] = wt.samples_to_counts([sample], sizes)[0]
 
 
+# ---------------------------------------------------------------- native I/O ----
+def _c_strings(items):
+    arr = (ctypes.c_char_p * len(items))()
+    arr[:] = [os.fsencode(p) for p in items]
+    return arr
+
+
+def read_counts(paths, chrom_sizes, to_binsize, out_rows, threads=8, fallbacks=None):
+    """Rows of `out_rows` (int32 [>= len(paths), sum(chrom_sizes)], C-contiguous rows) = the dense
+    count vectors of the sample files, decoded by the library's C++ thread pool
+    (wc_read_samples: zip inflate, the pickled chromosome dict, scaleSample, pad / truncate).
+    A file the native reader does not understand is read with np.load instead -- same result,
+    and np.load's own error if the file is broken.  Returns the files' own bin sizes; `fallbacks`
+    (a list) collects the positions of the files that took the np.load path."""
+    n = len(paths)
+    sizes = np.ascontiguousarray(chrom_sizes, dtype=np.int64)
+    assert out_rows.dtype == np.int32 and out_rows.shape[1] == int(sizes.sum()) and out_rows.strides[1] == 4
+    own = np.zeros(n, dtype=np.float64)
+    status = np.zeros(n, dtype=np.int32)
+    if n == 0:
+        return own
+    _lib.check(_lib.load().wc_read_samples(_c_strings(paths), n, int(threads), _lib.ptr(sizes), len(sizes),
+                                           float(to_binsize or 0.0), ctypes.c_void_p(out_rows.ctypes.data),
+                                           out_rows.strides[0] // 4, _lib.ptr(own), _lib.ptr(status)))
+    if fallbacks is not None:
+        fallbacks.extend(int(i) for i in np.nonzero(status)[0])      # (tests: which files the native reader passed on)
+    for i in np.nonzero(status)[0]:
+        sample, size = read_sample(paths[i], to_binsize)      # raises what the reference would report
+        out_rows[i, :] = wt.samples_to_counts([sample], sizes)[0]
+        own[i] = size
+    return own
+
+
+def _object_npy(obj):
+    """Bytes of the .npy member np.savez writes for a Python object (a 0-d object array)."""
+    header = b"{'descr': '|O', 'fortran_order': False, 'shape': (), }"
+    pad = (64 - (10 + len(header) + 1) % 64) % 64
+    header = header + b' ' * pad + b'\n'
+    body = pickle.dumps(np.array(obj, dtype=object), protocol=3)
+    return b'\x93NUMPY\x01\x00' + len(header).to_bytes(2, 'little') + header + body
+
+
+def write_results(out_paths, per_file_args, runtime, binsize, threshold_z, chrom_sizes, z, r, cwz, calls, n_calls,
+                  asdef, threads=8, level=1):
+    """One `test` output file per row through the library's C++ thread pool (wc_write_test_results):
+    the keys, dtypes and shapes of writeTestOutput's files.  z, r: float64
+    [n, sum(chrom_sizes)]; cwz [n, n_sel]; calls [n, max_calls, 5]; n_calls int32 [n]; asdef [n]."""
+    n = len(out_paths)
+    if n == 0:
+        return
+    sizes = np.ascontiguousarray(chrom_sizes, dtype=np.int64)
+    blobs = [_object_npy(vars(a) if not isinstance(a, dict) else a) for a in per_file_args]
+    blob_ptrs = (ctypes.c_char_p * n)()
+    blob_ptrs[:] = blobs
+    lens = np.array([len(b) for b in blobs], dtype=np.int64)
+    rt = _object_npy(runtime)
+    status = np.zeros(n, dtype=np.int32)
+    for a in (z, r, cwz, calls, asdef):
+        assert a.dtype == np.float64 and a.flags['C_CONTIGUOUS']
+    assert n_calls.dtype == np.int32 and z.shape[1] == int(sizes.sum())
+    _lib.check(_lib.load().wc_write_test_results(
+        n, int(threads), _c_strings(out_paths), blob_ptrs, _lib.ptr(lens), rt, len(rt), float(binsize),
+        float(threshold_z), _lib.ptr(sizes), len(sizes), _lib.ptr(z), _lib.ptr(r), z.shape[1], _lib.ptr(cwz),
+        cwz.shape[1], _lib.ptr(calls), _lib.ptr(n_calls), calls.shape[1], _lib.ptr(asdef), int(level), _lib.ptr(status)))
+    bad = np.nonzero(status)[0]
+    if len(bad):
+        raise IOError('could not write %d result file(s), first: %s' % (len(bad), out_paths[bad[0]]))
+
+
 class _Staging(object):
     """Pinned host buffers of one in-flight batch."""
 
@@ -57,16 +130,33 @@ class _Staging(object):
         self.calls = torch.empty((batch, max_calls, 5), dtype=torch.float64, **pin)
         self.n_calls = torch.empty((batch,), dtype=torch.int32, **pin)
         self.asdef = torch.empty((batch,), dtype=torch.float64, **pin)
+        self.write_done = None     # future of the writer that still reads these buffers
 
 
-def run_testbatch(reference, paths, outdir, threshold, args, writer, max_calls=256):
+def output_names(paths, outdir):
+    """<outdir>/<leaf>_test.npz per input; two inputs with the same leaf name would overwrite each
+    other's result, so that is an error up front."""
+    names, seen = [], {}
+    for path in paths:
+        leaf = os.path.basename(path)
+        leaf = leaf[:-4] if leaf.endswith('.npz') else leaf
+        if leaf in seen:
+            raise ValueError('testbatch: %s and %s would both be written to %s_test.npz; rename one of them'
+                             % (seen[leaf], path, leaf))
+        seen[leaf] = path
+        names.append(os.path.join(outdir, leaf + '_test.npz'))
+    return names
+
+
+def run_testbatch(reference, paths, outdir, threshold, args, writer=None, max_calls=256, runtime=None):
     """`test` for every file of `paths` in GPU batches of args.batch samples.
 
-    Pipeline per batch: decode (thread pool) -> pinned counts -> H2D -> wc_test_batch_dev ->
-    D2H into pinned results -> encode + write (thread pool).  Decode of batch i+1 and the
-    writes of batch i-1 overlap the GPU work of batch i.  Returns timing figures
-    (files, wall_s, files_per_s, gpu_s).  `writer(path, per_sample_args, result)` stores one
-    result file."""
+    Pipeline per batch: decode (C++ thread pool) -> pinned counts -> H2D -> wc_test_batch_dev ->
+    D2H into pinned results -> encode + write (C++ thread pool).  The decode of batch i+1 and the
+    writes of batch i-1 overlap the GPU work of batch i (two Python helper threads that only wait on
+    the native calls, which release the GIL).  Returns timing figures (files, wall_s, files_per_s,
+    gpu_s).  `writer(path, per_sample_args, result)`, when given, stores each result file in Python
+    instead (the pre-native path, kept for comparison)."""
     import torch
     from .distributed import TestBatch
     began = time.time()
@@ -78,72 +168,87 @@ def run_testbatch(reference, paths, outdir, threshold, args, writer, max_calls=2
     sizes = [int(v) for v in reference.chromosome_sizes]
     offs = np.concatenate([[0], np.cumsum(sizes)])
     sel = list(args.chromosomes)
-    batch = max(1, min(int(args.batch), n))
+    # wc_test_batch_dev takes at most 60000 (sample, chromosome) regions per call
+    batch = max(1, min(int(args.batch), n, 60000 // max(1, len(sel))))
     io_threads = max(1, int(getattr(args, 'io', 8)))
+    level = int(getattr(args, 'ziplevel', 1))
+    outs = output_names(paths, outdir)
     stage = [_Staging(torch, batch, reference.n_total, len(sel), max_calls) for _ in range(2)]
     dev_counts = torch.zeros((batch, reference.n_total), dtype=torch.int32, device=dev)
-    tb = TestBatch(reference, dev_counts, threshold, minrefbins=args.minrefbins, repeats=args.repeats,
-                   chromosomes=sel, max_calls=max_calls, mineffectsize=args.mineffectsize)
-    readers = concurrent.futures.ThreadPoolExecutor(max_workers=io_threads)
-    writers = concurrent.futures.ThreadPoolExecutor(max_workers=io_threads)
+
+    def new_batch(counts, calls_cap):
+        return TestBatch(reference, counts, threshold, minrefbins=args.minrefbins, repeats=args.repeats,
+                         chromosomes=sel, max_calls=calls_cap, mineffectsize=args.mineffectsize)
+    tb = new_batch(dev_counts, max_calls)
+    helpers = concurrent.futures.ThreadPoolExecutor(max_workers=2)
+    py_writers = concurrent.futures.ThreadPoolExecutor(max_workers=io_threads) if writer else None
     gpu_s = 0.0
-    pending_writes = []
+    pending = []
 
     def start_decode(at, slot):
         names = paths[at:at + batch]
-        rows = stage[slot].counts.numpy()
-        return names, [readers.submit(_count_row, name, reference.binsize, sizes, rows[i])
-                       for i, name in enumerate(names)]
+        rows = stage[slot].counts.numpy()               # (the result writers never touch the counts buffer)
+        return at, names, helpers.submit(read_counts, names, sizes, reference.binsize, rows, io_threads)
 
-    def emit(names, slot):
+    def emit(at, names, slot, ns):
         st = stage[slot]
+        per_file = []
+        for i, name in enumerate(names):
+            # what one `test` call would record: its own infile / outfile, not the batch's whole file list
+            one = argparse.Namespace(**{k: v for k, v in vars(args).items() if k not in ('infiles', 'func')})
+            one.infile = name
+            one.outfile = outs[at + i]
+            per_file.append(one)
+        if writer is None:
+            st.write_done = helpers.submit(
+                write_results, outs[at:at + ns], per_file, runtime, reference.binsize, threshold, sizes,
+                st.z.numpy()[:ns], st.r.numpy()[:ns], st.cwz.numpy()[:ns], st.calls.numpy()[:ns],
+                st.n_calls.numpy()[:ns], st.asdef.numpy()[:ns], io_threads, level)
+            pending.append(st.write_done)
+            return
         z, r = st.z.numpy(), st.r.numpy()
         cwz, calls, n_calls, asdef = st.cwz.numpy(), st.calls.numpy(), st.n_calls.numpy(), st.asdef.numpy()
-        for i, name in enumerate(names):
+        for i, one in enumerate(per_file):
             result = dict(
                 results_z=[z[i, offs[c]:offs[c + 1]].copy() for c in range(len(sizes))],
                 results_r=[r[i, offs[c]:offs[c + 1]].copy() for c in range(len(sizes))],
                 results_cwz=cwz[i].copy(), results_calls=calls[i, :n_calls[i]].copy(), asdef=float(asdef[i]))
-            leaf = os.path.basename(name)
-            leaf = leaf[:-4] if leaf.endswith('.npz') else leaf
-            one = argparse.Namespace(**vars(args))
-            one.infile = name
-            one.outfile = os.path.join(outdir, leaf + '_test.npz')
-            pending_writes.append(writers.submit(writer, one.outfile, one, result))
+            pending.append(py_writers.submit(writer, one.outfile, one, result))
 
     try:
         nxt = start_decode(0, 0)
         for bi, at in enumerate(range(0, n, batch)):
             slot = bi & 1
-            names, futs = nxt
-            for f in futs:
-                f.result()
+            at_, names, fut = nxt
+            fut.result()
             if at + batch < n:
                 nxt = start_decode(at + batch, slot ^ 1)
             ns = len(names)
             t0 = time.time()
+            st = stage[slot]
+            if st.write_done is not None:
+                st.write_done.result()                  # the writer of two batches ago is done with these buffers
+                st.write_done = None
             while True:
-                dev_counts[:ns].copy_(stage[slot].counts[:ns], non_blocking=True)
-                run = tb if ns == batch else TestBatch(reference, dev_counts[:ns], threshold,
-                                                      minrefbins=args.minrefbins, repeats=args.repeats,
-                                                      chromosomes=sel, max_calls=tb.max_calls,
-                                                      mineffectsize=args.mineffectsize)
+                dev_counts[:ns].copy_(st.counts[:ns], non_blocking=True)
+                run = tb if ns == batch else new_batch(dev_counts[:ns], tb.max_calls)
                 try:
                     run.run()
-                except Exception as exc:
+                except _lib.WisecondorHipError as exc:
                     # a sample with more calls than the output holds (e.g. hardly any reads):
                     # the reference has no such limit, so run the batch again with more room
-                    if 'max_calls' in str(exc) and tb.max_calls < reference.n_total:
+                    if getattr(exc, 'code', 0) == _lib.E_LIMIT and 'max_calls' in str(exc) \
+                            and tb.max_calls < reference.n_total:
                         grown = tb.max_calls * 4
-                        tb = TestBatch(reference, dev_counts, threshold, minrefbins=args.minrefbins,
-                                       repeats=args.repeats, chromosomes=sel, max_calls=grown,
-                                       mineffectsize=args.mineffectsize)
-                        for s in (0, 1):
-                            stage[s].calls = torch.empty((batch, grown, 5), dtype=torch.float64, pin_memory=True)
+                        tb = new_batch(dev_counts, grown)
+                        for s_ in (0, 1):
+                            if stage[s_].write_done is not None:
+                                stage[s_].write_done.result()
+                                stage[s_].write_done = None
+                            stage[s_].calls = torch.empty((batch, grown, 5), dtype=torch.float64, pin_memory=True)
                         continue
                     raise
                 break
-            st = stage[slot]
             st.z[:ns].copy_(run.results_z, non_blocking=True)
             st.r[:ns].copy_(run.results_r, non_blocking=True)
             st.cwz[:ns].copy_(run.cwz, non_blocking=True)
@@ -152,13 +257,12 @@ def run_testbatch(reference, paths, outdir, threshold, args, writer, max_calls=2
             st.asdef[:ns].copy_(run.asdef, non_blocking=True)
             torch.cuda.synchronize()
             gpu_s += time.time() - t0
-            # this slot's host buffers are rewritten two batches from now: the writers of that
-            # earlier batch must be done with their (copied) slices before then -- they copy above
-            emit(names, slot)
-        for f in pending_writes:
+            emit(at, names, slot, ns)
+        for f in pending:
             f.result()
     finally:
-        readers.shutdown(wait=True)
-        writers.shutdown(wait=True)
+        helpers.shutdown(wait=True)
+        if py_writers:
+            py_writers.shutdown(wait=True)
     wall = time.time() - began
     return dict(files=n, wall_s=wall, files_per_s=n / wall if wall > 0 else 0.0, gpu_s=gpu_s)

@@ -321,9 +321,11 @@ def toolTestBatch(args):
     reference, cut = _reference_and_threshold(args, device=device)
     lo, hi = shard_samples(len(args.infiles), rank, world_env)
     os.makedirs(args.outdir, exist_ok=True)
-    stats = ingest.run_testbatch(reference, args.infiles[lo:hi], args.outdir, cut, args,
-                                 writer=lambda path, one, res: writeTestOutput(path, one, reference.binsize,
-                                                                               res, cut))
+    py_writer = None
+    if os.environ.get('WC_INGEST_PYTHON_WRITER'):      # the pre-native writer (np.savez_compressed per file), for comparison
+        py_writer = lambda path, one, res: writeTestOutput(path, one, reference.binsize, res, cut)   # noqa: E731
+    stats = ingest.run_testbatch(reference, args.infiles[lo:hi], args.outdir, cut, args, writer=py_writer,
+                                 runtime=getRuntime())
     print('rank %d: %d samples in %.2f s (%.1f files/s end to end; GPU batches %.3f s)'
           % (rank, stats['files'], stats['wall_s'], stats['files_per_s'], stats['gpu_s']))
     reference.close()
@@ -416,6 +418,9 @@ def buildParser():
     p.add_argument('-batch', type=int, default=256, help='samples per GPU batch')
     p.add_argument('-gpus', type=int, default=None, help='GPU processes to shard the samples over')
     p.add_argument('-io', type=int, default=8, help='file decode / encode threads')
+    p.add_argument('-ziplevel', type=int, default=1,
+                   help='zlib level of the result files (0 = stored, 1 = run-length deflate: the same size at a third of '
+                        'the time on these arrays, 6 = what np.savez_compressed uses)')
     for flag, settings in _TEST_OPTIONS:
         p.add_argument(flag, **settings)
     p.set_defaults(func=toolTestBatch)
