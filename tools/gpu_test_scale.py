@@ -19,8 +19,9 @@ ref = wt.Reference(idx.cpu().numpy(), dst.cpu().numpy(), inp["chrom_bins"], inp[
                    inp["pca_mean"], inp["pca_components"], binsize=binsize)
 thr = float(zThreshold([int(v) for v in inp["masked_bins"]], 1000, None))
 counts = torch.from_numpy(wt.samples_to_counts(inp["tests"], inp["chrom_bins"])).cuda()
-tb = distributed.TestBatch(ref, counts, thr)
-for it in range(3):
+tb = distributed.TestBatch(ref, counts, thr, max_calls=256)
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+for it in range(reps):
     torch.cuda.synchronize(); t0 = time.time(); tb.run(); torch.cuda.synchronize(); dt = time.time() - t0
     print("batch of %d samples x %d bins: %.2f ms -> %.0f samples/s, calls %d, mem %.1f GB" % (
         ns, corrected.shape[0], dt * 1e3, ns / dt, int(tb.n_calls.sum()), torch.cuda.mem_get_info()[1] / 1e9 - torch.cuda.mem_get_info()[0] / 1e9), flush=True)

@@ -67,6 +67,9 @@ struct TestState {
     std::vector<int> prof_tag;          // tag of every mark of the last batch, in record order
     wc::DevBuf sd_fail;                 // per-sample flags of k_sd_fast (1: the serial kernel takes the sample)
     bool tree_done = false;             // run_stouffer: the tree kernel finished the recursion and wrote the call rows
+    bool tree_pending = false;          // ... but its status words are still on their way to pinned memory (deferred check)
+    bool no_tree = false;               // repeat of a batch the tree kernel passed on: host-driven rounds only
+    int64_t tree_seg_cap = 0;
     bool lat_ride = false;              // latency mode: stdDevAvg rides in k_seg_tree's grid (run_repeat -> run_seg_lat)
     double *lat_ride_out2 = nullptr;
     wc::DevBuf prof_work;               // u64[2]: windows evaluated by k_seg_search, evaluations by k_seg_quiet

@@ -3355,6 +3355,7 @@ struct TreeTail {
     const double *ratio;     // cleaned ratios, as z_dev
     const int *gpos;         // genomic position of every kept bin
     double *reg_calls;       // [n_regions, max_calls, 5]
+    bool defer_status;       // the caller reads the tree kernel's status words after its own synchronize
 };
 int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, int64_t n_regions, int64_t total_len,
                  int64_t max_n, double thr, int min_search, int max_calls, hipStream_t stream,
@@ -3364,6 +3365,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     int rc;
     ts.last_segs = 0;
     ts.tree_done = false;
+    ts.tree_pending = false;
     if (n_regions == 0) return WC_OK;
     const int64_t job_cap = n_regions + total_len / 4 + 64;
     const int64_t seg_cap = n_regions * (int64_t)max_calls + 64;
@@ -3492,7 +3494,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
             n_hot = h[2];
         }
         const char *tree_env = getenv("WC_TEST_TREE_TAIL");        // "0": host-driven rounds only
-        if (guard == 1 && tail && !bits && max_n <= TREE_MAXLEN && n_hot > 0 && !(tree_env && tree_env[0] == '0')) {
+        if (guard == 1 && tail && !bits && max_n <= TREE_MAXLEN && n_hot > 0 && !ts.no_tree && !(tree_env && tree_env[0] == '0')) {
             SdRider no_sd{};
             InflateRider no_inf{};
             AssembleRider no_as{};
@@ -3504,6 +3506,16 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
                                (const double2 *)ts.sub.as<double2>(), max_chunks, no_sd, no_inf, no_as,
                                (const int *)hot, (const int *)(counters + 2));
             WC_HIP(hipMemcpyAsync(h, counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
+            if (tail->defer_status) {
+                // the caller looks at the counters after ITS synchronize (one host round trip per batch
+                // instead of two): h[3] / h[6] non-zero = the tree kernel passed on some region, and the
+                // caller repeats the batch with host-driven rounds
+                ts.tree_done = true;
+                ts.tree_pending = true;
+                ts.tree_seg_cap = seg_cap;
+                WC_HIP(hipGetLastError());
+                return WC_OK;
+            }
             WC_HIP(hipStreamSynchronize(stream));
             if (h[3] == 0 && h[6] == 0) {          // no job for the exact scan, nothing the tree kernel gave up on
                 WC_CHECK(h[4] <= seg_cap, WC_E_LIMIT, "stouffer: more than max_calls=%d segments per region", max_calls);
@@ -4075,7 +4087,7 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
                 bits_upper += Ns * (n * (n + 1) / 2);
             }
         ts.mark(3, stream);
-        const TreeTail tail{ts.rc.as<double>(), ts.gpos.as<int>(), ts.effect.as<double>()};
+        const TreeTail tail{ts.rc.as<double>(), ts.gpos.as<int>(), ts.effect.as<double>(), calls && n_calls && !ts.profile};
         if ((rc = run_stouffer(ctx, ts.zc.as<double>(), ts.regions.as<Region>(), n_regions, Ns * B, max_n, threshold, 3,
                                max_calls, stream, ts.rc.as<double>(), min_effect, bits_upper, 0, nullptr,
                                calls && n_calls ? &tail : nullptr)))
@@ -4102,6 +4114,21 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
         if (!lat) {
             WC_HIP(hipMemcpyAsync(overflow, ts.misc.p, sizeof(int), hipMemcpyDeviceToHost, stream));
             WC_HIP(hipStreamSynchronize(stream));
+            if (ts.tree_pending) {
+                // the tree kernel's status words arrived with this synchronize (run_stouffer queued the copy)
+                ts.tree_pending = false;
+                const int *h = (const int *)ctx->pinned;
+                if (h[3] != 0 || h[6] != 0) {
+                    // rare (non-finite region, tie overflow, deep recursion): the whole batch again with
+                    // host-driven rounds -- the same results by construction, one batch time lost
+                    ts.no_tree = true;
+                    rc = test_batch_body(ctx, stream, ref, counts, Ns, threshold, min_ref_bins, repeats, min_effect, sel,
+                                         max_n, max_calls, results_z, results_r, results_cwz, calls, n_calls, asdef, lat_rounds);
+                    ts.no_tree = false;
+                    return rc;
+                }
+                WC_CHECK(h[4] <= ts.tree_seg_cap, WC_E_LIMIT, "stouffer: more than max_calls=%d segments per region", max_calls);
+            }
             WC_CHECK(!*overflow, WC_E_LIMIT, "test: a sample has more than max_calls=%d calls", max_calls);
         }
     }
