@@ -154,6 +154,65 @@ def test_segments_mineffectsize_random(wt, seed):
         assert same_bits([w], [tri[len(z) - 1]]), (seed, len(z))
 
 
+@pytest.mark.parametrize("seed", range(2 * SWEEP))
+def test_mineffectsize_boundary_values(wt, seed):
+    """The counting form of the median filter decides |median - 1| >= t from counts against two
+    boundary doubles; ratios sitting exactly on, one ulp inside and one ulp outside those boundaries,
+    heavy ties, infinities and NaN must come out as np.median + the reference's comparison say
+    (even window lengths average the two middle values first)."""
+    rng = np.random.RandomState(15000 + seed)
+    eff = float(rng.choice([0.01, 0.05, 0.1, 0.5, 1.0, 2.5]))
+    hi, lo = 1.0 + eff, 1.0 - eff
+    pool = [hi, np.nextafter(hi, 0.0), np.nextafter(hi, 9.0), lo, np.nextafter(lo, 9.0), np.nextafter(lo, -9.0), 1.0,
+            1.0 + eff / 2, 1.0 - eff / 2, 1.0 + 2 * eff, 1.0 - 2 * eff]
+    zs, rs = [], []
+    for _ in range(10):
+        n = int(rng.choice([2, 3, 4, 7, 16, 40, 65, 90]))
+        z = rng.standard_normal(n) + rng.choice([0.0, 1.5])
+        r = rng.choice(pool, size=n)
+        if rng.rand() < 0.3:
+            r = np.where(rng.rand(n) < 0.5, r, 1.0 + 3 * eff * rng.standard_normal(n))
+        if rng.rand() < 0.2:
+            r[rng.randint(0, n)] = rng.choice([np.inf, -np.inf, np.nan])
+        zs.append(z)
+        rs.append(r)
+    thr = float(rng.choice([1.5, 2.5]))
+    whole, segs = wt.stouffer_segments(zs, thr, 3, ratios=rs, mineffectsize=eff)
+    for z, r, w, s in zip(zs, rs, whole, segs):
+        with np.errstate(all="ignore"):
+            tri = wo.fill_tri_min(z, r, eff)
+        want = wo.segment_tri(tri, len(z), thr, 3)
+        assert [(x, y) for _, (x, y) in s] == [(x, y) for _, (x, y) in want], (seed, len(z), thr, eff, r)
+        assert same_bits([v for v, _ in s], [v for v, _ in want]), (seed, len(z))
+        assert same_bits([w], [tri[len(z) - 1]]), (seed, len(z))
+
+
+def test_mineffectsize_counting_equals_sorted_insert_on_long_regions(wt, monkeypatch):
+    """Regions far too long for the oracle's O(n^3) fillTriMin (3000 and 5000 bins, the 50 kb size): the
+    O(1)-per-window counting kernel against the sorted-insert kernel it replaces (WC_MINEFFECT=sorted,
+    itself pinned on the reference's goldens)."""
+    rng = np.random.RandomState(77)
+    zs, rs = [], []
+    for n in (3000, 5000, 1237):
+        z = rng.standard_normal(n)
+        r = np.round(1.0 + 0.03 * rng.standard_normal(n), 3)
+        a = n // 3
+        z[a:a + n // 10] += 0.8
+        r[a:a + n // 10] += 0.04
+        r[rng.randint(0, n, size=3)] = np.nan
+        zs.append(z)
+        rs.append(r)
+    monkeypatch.delenv("WC_MINEFFECT", raising=False)
+    whole_a, segs_a = wt.stouffer_segments(zs, 4.0, 3, ratios=rs, mineffectsize=0.02)
+    monkeypatch.setenv("WC_MINEFFECT", "sorted")
+    whole_b, segs_b = wt.stouffer_segments(zs, 4.0, 3, ratios=rs, mineffectsize=0.02)
+    assert sum(len(s) for s in segs_a) >= 3
+    for sa, sb in zip(segs_a, segs_b):
+        assert [(x, y) for _, (x, y) in sa] == [(x, y) for _, (x, y) in sb]
+        assert same_bits([v for v, _ in sa], [v for v, _ in sb])
+    assert same_bits(whole_a, whole_b)
+
+
 def test_degenerate_samples(wt):
     """Samples the reference still processes: a single read (hundreds of calls -- more than the
     library's default room per sample, the wrapper runs it again with more), a few spikes, half

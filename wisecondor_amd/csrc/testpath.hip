@@ -1533,6 +1533,72 @@ struct WindowMask {
     }
 };
 
+// -mineffectsize in O(1) per window (wisetools.py:479-487: a window counts only if
+// abs(median(ratio[x..y]) - 1) >= threshold).  One LANE per first bin x; the lanes of a wave walk their
+// windows' last bins in lock step (coalesced loads, every lane at the same window length m).  The
+// comparison is monotone in the median, so there are two doubles u_hi >= 1 >= u_lo (found on the host
+// with the very same expression) with  "valid  <=>  median >= u_hi  or  median <= u_lo",  and an order
+// statistic against a fixed value is a COUNT: with c = #(elements >= u_hi),
+//   m odd:   median >= u_hi  <=>  c >= (m + 1) / 2;
+//   m even:  c >= m / 2 + 1 -> both middle elements >= u_hi -> valid;  c <= m / 2 - 1 -> not (on this side);
+//            c == m / 2 -> the middle elements are max(elements < u_hi) and min(elements >= u_hi): the
+//            median (a + b) / 2 is formed exactly as numpy forms it and compared as the reference does
+// (and the mirror image with #(elements <= u_lo)).  Per lane: two counters, four running extremes, a NaN
+// flag (np.median of a window with a NaN is NaN: the comparison fails).  The sorted-insert kernel below
+// (O(n) per window) is kept as WC_MINEFFECT=sorted for cross-checks.
+__global__ __launch_bounds__(256) void k_window_valid_count(const double *__restrict__ ratio,
+                                                           const Region *__restrict__ regions,
+                                                           const long long *__restrict__ bit_off, double min_effect,
+                                                           double u_hi, double u_lo,
+                                                           unsigned int *__restrict__ bits) {
+    const Region rg = regions[blockIdx.y];
+    const int x = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int x0 = (int)(blockIdx.x * blockDim.x + (threadIdx.x & ~63));     // the wave's first start
+    if (x0 >= rg.n) return;
+    const bool live = x < rg.n;
+    const double *rr = ratio + rg.off;
+    const long long row_base = bit_off[blockIdx.y] + (long long)x * rg.n - ((long long)x * (x - 1)) / 2;
+    const long long first_word = row_base >> 5, last_word = (row_base + (rg.n - 1 - x)) >> 5;
+    int c_hi = 0, c_lo = 0;
+    bool nan = false;
+    double below_hi = -INFINITY, from_hi = INFINITY;     // max of the elements < u_hi, min of those >= u_hi
+    double upto_lo = -INFINITY, above_lo = INFINITY;     // max of the elements <= u_lo, min of those > u_lo
+    unsigned int word = 0;
+    long long word_idx = first_word;
+    const int steps = rg.n - x0;                         // the wave's longest row
+    for (int d = 0; d < steps; ++d) {
+        const int y = x + d;
+        if (!live || y >= rg.n) continue;
+        const double v = rr[y];
+        if (v != v) nan = true;
+        if (v >= u_hi) { ++c_hi; from_hi = fmin(from_hi, v); } else if (v == v) below_hi = fmax(below_hi, v);
+        if (v <= u_lo) { ++c_lo; upto_lo = fmax(upto_lo, v); } else if (v == v) above_lo = fmin(above_lo, v);
+        const int m = d + 1;
+        bool ok;
+        if (m & 1) {
+            const int k = (m + 1) >> 1;
+            ok = c_hi >= k || c_lo >= k;
+        } else {
+            const int h = m >> 1;
+            ok = c_hi > h || c_lo > h;
+            if (!ok && c_hi == h) ok = fabs((below_hi + from_hi) / 2.0 - 1.0) >= min_effect;
+            if (!ok && c_lo == h) ok = fabs((upto_lo + above_lo) / 2.0 - 1.0) >= min_effect;
+        }
+        if (nan) ok = false;
+        const long long lin = row_base + d;
+        if ((lin >> 5) != word_idx) {
+            if (word) {
+                if (word_idx == first_word || word_idx == last_word) atomicOr(&bits[word_idx], word);
+                else bits[word_idx] = word;              // a word inside the row: nobody else writes it (zeroed by the caller)
+            }
+            word = 0;
+            word_idx = lin >> 5;
+        }
+        if (ok) word |= 1u << (lin & 31);
+    }
+    if (live && word) atomicOr(&bits[word_idx], word);
+}
+
 // One wave per (region, first bin x): the windows [x, y], y = x..n-1, by inserting
 // ratio[y] into a sorted LDS array (count-smaller + shift) and reading the median off
 // the middle.  np.median averages the two middle values for even lengths; a NaN in the
@@ -3398,15 +3464,44 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     const long long *bit_off = nullptr;
     if (min_effect != 0.0) {
         WC_CHECK(ratio_dev, WC_E_ARG, "segments: mineffectsize needs the ratio vector");
-        WC_CHECK(max_n * 8 <= 160 * 1024 - 1024, WC_E_LIMIT, "segments: region too long for the median filter");
         const int64_t words = bits_upper / 32 + 2;
         if ((rc = ts.win_bits.reserve(sizeof(unsigned int) * words))) return rc;
         if ((rc = ts.bit_off.reserve(sizeof(long long) * n_regions))) return rc;
         WC_HIP(hipMemsetAsync(ts.win_bits.p, 0, sizeof(unsigned int) * words, stream));
         hipLaunchKernelGGL(k_bit_offsets, dim3(1), dim3(1), 0, stream, regions_dev, n_regions, ts.bit_off.as<long long>());
-        hipLaunchKernelGGL(k_window_valid, dim3((unsigned)max_n, (unsigned)n_regions), dim3(64),
-                           sizeof(double) * (max_n + 1), stream, ratio_dev, regions_dev,
-                           (const long long *)ts.bit_off.as<long long>(), min_effect, ts.win_bits.as<unsigned int>());
+        const char *me = getenv("WC_MINEFFECT");         // "sorted": the O(n) per window sorted-insert kernel
+        if (me && strcmp(me, "sorted") == 0) {
+            WC_CHECK(max_n * 8 <= 64 * 1024 - 1024, WC_E_LIMIT, "segments: region too long for the sorted-insert median filter");
+            hipLaunchKernelGGL(k_window_valid, dim3((unsigned)max_n, (unsigned)n_regions), dim3(64),
+                               sizeof(double) * (max_n + 1), stream, ratio_dev, regions_dev,
+                               (const long long *)ts.bit_off.as<long long>(), min_effect, ts.win_bits.as<unsigned int>());
+        } else {
+            // u_hi: the smallest double >= 1 with fabs(u - 1.0) >= min_effect; u_lo: the largest <= 1 -- found
+            // with the kernel's own expression by bisection over the ordered bit patterns (monotone on each side)
+            auto passes = [&](double u) { return fabs(u - 1.0) >= min_effect; };
+            double u_hi = NAN, u_lo = NAN;
+            if (passes(INFINITY)) {
+                uint64_t lo = wc::f64_ordered(1.0), hi = wc::f64_ordered(INFINITY);     // passes(hi) holds
+                if (passes(1.0)) hi = lo;
+                while (lo < hi) {
+                    const uint64_t mid = lo + ((hi - lo) >> 1);
+                    if (passes(wc::f64_from_ordered(mid))) hi = mid; else lo = mid + 1;
+                }
+                u_hi = wc::f64_from_ordered(hi);
+            }
+            if (passes(-INFINITY)) {
+                uint64_t lo = wc::f64_ordered(-INFINITY), hi = wc::f64_ordered(1.0);     // passes(lo) holds
+                if (passes(1.0)) lo = hi;
+                while (lo < hi) {
+                    const uint64_t mid = lo + ((hi - lo + 1) >> 1);
+                    if (passes(wc::f64_from_ordered(mid))) lo = mid; else hi = mid - 1;
+                }
+                u_lo = wc::f64_from_ordered(lo);
+            }
+            hipLaunchKernelGGL(k_window_valid_count, dim3((unsigned)cdiv(max_n, 256), (unsigned)n_regions), dim3(256), 0,
+                               stream, ratio_dev, regions_dev, (const long long *)ts.bit_off.as<long long>(), min_effect,
+                               u_hi, u_lo, ts.win_bits.as<unsigned int>());
+        }
         bits = ts.win_bits.as<unsigned int>();
         bit_off = ts.bit_off.as<long long>();
     }
