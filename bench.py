@@ -665,6 +665,8 @@ def main():
             # the re-score stage on this matrix: uncorrelated rows share no candidates, the 295 MB float64
             # image does not fit the 32 MB of L2, and the gathers come from HBM / Infinity Cache
             xr_ms = xstages.get("collected->rescored")
+            if xr_ms is None and "picked->rescored" in xstages:
+                xr_ms = xstages["picked->rescored"] + xstages.get("collected->picked", xstages.get("exchanged->picked", 0.0))
             if xr_ms:
                 xr_bytes = float(XB) / world * k * xs * 8.0 + float(XB) / world * k * 12.0
                 extra["rescore_ms"] = xr_ms

@@ -257,4 +257,6 @@ def test_bench_line_is_complete_on_one_gpu():
     assert test["value"] > 0 and 0 < test["roofline"]["frac"] <= 1.0
     assert test["single_sample_latency_ms"] < test["ms_per_batch"]
     assert set(line["stages_ms"]) >= {"start->prepared", "prepared->thresholds", "thresholds->collected",
-                                      "collected->rescored", "rescored->finished"}
+                                      "collected->picked", "picked->rescored", "rescored->finished"}
+    assert "error" not in extra.get("ingest", {}), extra.get("ingest")
+    assert extra["ingest"]["files_per_s"] > 100

@@ -528,15 +528,20 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 3 : 4) void k_gram(GramArgs g) {
     // the 64 x 128 dot-product tile aliases the staging buffers, which keeps the
     // workgroup at 39 KB of LDS -> four workgroups per CU cover each other's
     // load / barrier / epilogue phases with MFMA work.
-    // Each thread scans 32 candidates for a column target and 32 for a row target: all 32
-    // dot products are fetched first (independent LDS reads), the candidates' norm bounds
-    // come as wave-uniform 16-byte broadcasts, and same-chromosome candidates -- a
-    // contiguous run of the tile's rows / columns -- are cleared from the pass mask at once.
+    // ONE sweep evaluates every key of the half once (round 2 evaluated each twice, once per role):
+    // thread (x, q) owns column x and 32 of the half's rows.  Its keys against the column target's
+    // threshold give the column role's pass mask; the same keys against the ROW targets' thresholds --
+    // wave-uniform, the row is the loop variable -- are one v_cmp whose 64-bit result IS the row's
+    // pass mask over the wave's 64 columns (no ballot instruction, no second LDS read of the tile);
+    // lane 0 parks it in LDS.  After a barrier sixteen lanes per wave finish the rows: two masks per
+    // row, same-chromosome columns cleared as a run, ONE list reservation per row and half (round 2:
+    // four), keys of the few set bits rebuilt from the tile.
     __builtin_amdgcn_s_setprio(0);
     const int x = tid & 127, q = __builtin_amdgcn_readfirstlane(tid >> 7);   // column x, 32-row half q
-    const int lr = tid & 63, cq = __builtin_amdgcn_readfirstlane(tid >> 6);  // row lr, 32-column quarter cq
     const int2 rgq = g.range[(int64_t)J * TB + x];
-    const int2 rgp0 = g.range[(int64_t)I * TB + lr], rgp1 = g.range[(int64_t)I * TB + 64 + lr];
+    unsigned long long *rowmask = reinterpret_cast<unsigned long long *>(sm + 128 * LDT);   // [64 rows][2 column halves]
+    const int rl = w * 16 + (lane & 15);                                   // the row this lane helps to finish (four lanes per row)
+    const int2 rgr0 = g.range[(int64_t)I * TB + rl], rgr1 = g.range[(int64_t)I * TB + 64 + rl];
     for (int h = 0; h < 2; ++h) {
         __syncthreads();
         if (wr == h) {
@@ -559,50 +564,65 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 3 : 4) void k_gram(GramArgs g) {
         }
         __syncthreads();
 
-        unsigned int mask_c = 0u, mask_r = 0u;
-        float dv[32];
-        if (roles & ROLE_COLS) {  // target = column x, candidates = rows [h*64 + q*32, +32) of tile I
-            const float nbc = nbQs[x], th = thQs[x];
+        unsigned int mask_c = 0u;
+        {
+            const float nbc = nbQs[x], thc = (roles & ROLE_COLS) ? thQs[x] : -INFINITY;
+            float dv[32];
 #pragma unroll
             for (int g4 = 0; g4 < 8; ++g4) {
                 const f32x4 d4 = *(const f32x4 *)&D[x * LDT + q * 32 + 4 * g4];
                 dv[4 * g4] = d4[0]; dv[4 * g4 + 1] = d4[1]; dv[4 * g4 + 2] = d4[2]; dv[4 * g4 + 3] = d4[3];
             }
             const f32x4 *nbv = (const f32x4 *)&nbPs[h * 64 + q * 32];
+            const f32x4 *thv = (const f32x4 *)&thPs[h * 64 + q * 32];
 #pragma unroll
             for (int g4 = 0; g4 < 8; ++g4) {
-                const f32x4 nb4 = nbv[g4];
+                const f32x4 nb4 = nbv[g4], th4 = thv[g4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float key = fmaf(m2, dv[4 * g4 + e], nb4[e] + nbc);
-                    mask_c |= (key <= th) ? (1u << (4 * g4 + e)) : 0u;
+                    const float key = fmaf(m2, dv[4 * g4 + e], nb4[e] + nbc);
+                    mask_c |= (key <= thc) ? (1u << (4 * g4 + e)) : 0u;
+                    const unsigned long long hit = __ballot(key <= th4[e]);      // a compare into a scalar pair
+                    // every lane stores the (uniform) mask to the row's slot: one LDS write, no exec games
+                    rowmask[(q * 32 + 4 * g4 + e) * 2 + (w & 1)] = hit;
                 }
             }
             mask_c &= ~run_mask(rgq.x - (I * TB + h * 64 + q * 32), rgq.y - (I * TB + h * 64 + q * 32));
         }
-        if (roles & ROLE_ROWS) {  // target = row h*64 + lr, candidates = columns [cq*32, +32) of tile J
-            const int r = h * 64 + lr;
-            const float nbr = nbPs[r], th = thPs[r];
-#pragma unroll
-            for (int cc = 0; cc < 32; ++cc) dv[cc] = D[(cq * 32 + cc) * LDT + lr];
-            const f32x4 *nbv = (const f32x4 *)&nbQs[cq * 32];
-#pragma unroll
-            for (int g4 = 0; g4 < 8; ++g4) {
-                const f32x4 nb4 = nbv[g4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float key = fmaf(m2, dv[4 * g4 + e], nbr + nb4[e]);
-                    mask_r |= (key <= th) ? (1u << (4 * g4 + e)) : 0u;
+        // the column role's reservation flies while the rows are finished
+        int base_c = 0;
+        const int64_t gq = (int64_t)J * TB + x;
+        if (mask_c) base_c = atomicAdd(&g.cnt[gq], __popc(mask_c));
+        __syncthreads();
+        if (roles & ROLE_ROWS) {
+            // four lanes per row (lane = 16 part + row-in-wave): each takes a 32-column quarter of the row's
+            // 128-bit mask; part 0 reserves for all four, the base comes back by a shuffle
+            const int part = lane >> 4;
+            const unsigned long long m64 = rowmask[rl * 2 + (part >> 1)];
+            unsigned int mm = (unsigned int)(m64 >> (32 * (part & 1)));
+            const int2 rg = h ? rgr1 : rgr0;
+            mm &= ~run_mask(rg.x - (J * TB + 32 * part), rg.y - (J * TB + 32 * part));   // the row's own chromosome
+            const int mine = __popc(mm);
+            const int c1 = __shfl(mine, (lane & 15) + 16), c2 = __shfl(mine, (lane & 15) + 32), c3 = __shfl(mine, (lane & 15) + 48);
+            const int r = h * 64 + rl;
+            const int64_t gp = (int64_t)I * TB + r;
+            int base_r = 0;
+            if (part == 0 && mine + c1 + c2 + c3 > 0) base_r = atomicAdd(&g.cnt[gp], mine + c1 + c2 + c3);
+            base_r = __shfl(base_r, lane & 15);
+            const int c0 = __shfl(mine, lane & 15);
+            base_r += (part > 0 ? c0 : 0) + (part > 1 ? c1 : 0) + (part > 2 ? c2 : 0);
+            if (mm) {
+                const float nbr = nbPs[r];
+                unsigned long long *dst = g.list + gp * g.cap;
+                while (mm) {
+                    const int c = 32 * part + (__ffs((int)mm) - 1);
+                    mm &= mm - 1;
+                    const float key = fmaf(m2, D[c * LDT + rl], nbr + nbQs[c]);
+                    if (base_r < g.cap) dst[base_r] = pack_entry(key, J * TB + c);
+                    ++base_r;
                 }
             }
-            const int2 rg = h ? rgp1 : rgp0;
-            mask_r &= ~run_mask(rg.x - (J * TB + cq * 32), rg.y - (J * TB + cq * 32));
         }
-        // both list reservations are in flight together
-        int base_c = 0, base_r = 0;
-        const int64_t gq = (int64_t)J * TB + x, gp = (int64_t)I * TB + h * 64 + lr;
-        if (mask_c) base_c = atomicAdd(&g.cnt[gq], __popc(mask_c));
-        if (mask_r) base_r = atomicAdd(&g.cnt[gp], __popc(mask_r));
         if (mask_c) {
             const float nbc = nbQs[x];
             unsigned long long *dst = g.list + gq * g.cap;
@@ -613,18 +633,6 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 3 : 4) void k_gram(GramArgs g) {
                 float key = fmaf(m2, D[x * LDT + l], nbPs[r] + nbc);
                 if (base_c < g.cap) dst[base_c] = pack_entry(key, I * TB + r);
                 ++base_c;
-            }
-        }
-        if (mask_r) {
-            const float nbr = nbPs[h * 64 + lr];
-            unsigned long long *dst = g.list + gp * g.cap;
-            while (mask_r) {
-                int cc = __ffs((int)mask_r) - 1;
-                mask_r &= mask_r - 1;
-                int c = cq * 32 + cc;
-                float key = fmaf(m2, D[c * LDT + lr], nbr + nbQs[c]);
-                if (base_r < g.cap) dst[base_r] = pack_entry(key, J * TB + c);
-                ++base_r;
             }
         }
     }
@@ -1990,6 +1998,10 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
     st.k_pad16 = round_up(n_samples, 64);
     st.cap = LIST_CAP;
     st.expect = LIST_CAP * 3 / 8;     // 384: k = 100 is 4 sigma of the sampled order statistic away, the cap 6
+    if (const char *e = getenv("WC_NEWREF_EXPECT")) {      // tuning switch: candidates per row the sampled threshold aims for
+        const int v = atoi(e);
+        if (v >= 2 * k && v <= LIST_CAP / 2) st.expect = v;
+    }
     {
         // "f32": float32 matrix cores; "split": bfloat16 hi/lo pairs (three products per multiply);
         // default "f16": one float16 product per multiply, representation error charged per row
