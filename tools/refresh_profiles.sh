@@ -23,6 +23,44 @@ for WL in cfg2 cfg4; do
   done
 done
 python3 bench.py 2> "$OUT/bench_stderr.log" | tail -1 > "$OUT/${TAG}_bench_cfg2_unprofiled.json"
+# batched `test` at 50 kb (config 5's per-GPU share) and one sample per call (config 3): kernel statistics
+( cd /tmp && export TMPDIR=/tmp
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof_${TAG}_cfg5" -o t -- python3 "$REPO/tools/gpu_test_scale.py" 125 50000 10 > "$OUT/cfg5_run.log" 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof_${TAG}_test250" -o t -- python3 "$REPO/tools/gpu_test_scale.py" 128 250000 20 > "$OUT/test250_run.log" 2>&1
+  rocprofv3 --kernel-trace --output-format csv -d "$REPO/gpurun_out/prof_${TAG}_lat" -o t -- python3 "$REPO/tools/gpu_lat_trace.py" 40 > "$OUT/lat_run.log" 2>&1 )
+cp "$(find gpurun_out/prof_${TAG}_cfg5 -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_cfg5_test_kernel_stats.csv"
+cp "$(find gpurun_out/prof_${TAG}_test250 -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_test250_kernel_stats.csv"
+python3 - "$(find gpurun_out/prof_${TAG}_lat -name '*kernel_trace.csv' | head -1)" "$OUT/${TAG}_latency_trace.json" <<'PY'
+import csv, json, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+def short(n):
+    return n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+# one latency-mode call = the launches from k_lat_project to k_assemble_calls; average the last 20 calls
+starts = [i for i, r in enumerate(rows) if "k_lat_project" in r["Kernel_Name"]]
+calls = []
+for a, b in zip(starts[-21:-1], starts[-20:]):
+    seq = rows[a:b]
+    calls.append(([(short(r["Kernel_Name"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in seq],
+                  (int(seq[-1]["End_Timestamp"]) - int(seq[0]["Start_Timestamp"])) / 1e3))
+names = [n for n, _ in calls[-1][0]]
+same = [c for c in calls if [n for n, _ in c[0]] == names]
+per = [{"kernel": names[i], "us": sum(c[0][i][1] for c in same) / len(same)} for i in range(len(names))]
+json.dump({"what": "one latency-mode test call (one 250 kb sample) under rocprofv3 --kernel-trace: mean over %d replays of the "
+                   "captured graph" % len(same),
+           "launches": len(names), "kernels": per, "kernel_us_sum": sum(p["us"] for p in per),
+           "span_us_first_start_to_last_end": sum(c[1] for c in same) / len(same)}, open(sys.argv[2], "w"), indent=1)
+print(open(sys.argv[2]).read())
+PY
+# busy / cache counters of the newref kernels (one pass per counter set)
+bash tools/pmc_run.sh ${TAG}A_cfg2 "SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" tools/gpu_newref_only.py cfg2 10 > "$OUT/pmcA_cfg2.log" 2>&1
+bash tools/pmc_run.sh ${TAG}A_cfg4 "SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" tools/gpu_newref_only.py cfg4 3 > "$OUT/pmcA_cfg4.log" 2>&1
+bash tools/pmc_run.sh ${TAG}T_cfg2 "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" tools/gpu_newref_only.py cfg2 10 > "$OUT/pmcT_cfg2.log" 2>&1
+bash tools/pmc_run.sh ${TAG}T_cfg4 "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" tools/gpu_newref_only.py cfg4 3 > "$OUT/pmcT_cfg4.log" 2>&1
+bash tools/pmc_run.sh ${TAG}W_cfg2 "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS" tools/gpu_newref_only.py cfg2 10 > "$OUT/pmcW_cfg2.log" 2>&1
+bash tools/pmc_run.sh ${TAG}W_cfg4 "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS" tools/gpu_newref_only.py cfg4 3 > "$OUT/pmcW_cfg4.log" 2>&1
+python3 tools/busy_summary.py $TAG gpurun_out/${TAG}A_cfg2 gpurun_out/${TAG}A_cfg4 gpurun_out/${TAG}T_cfg2 gpurun_out/${TAG}T_cfg4 gpurun_out/${TAG}W_cfg2 gpurun_out/${TAG}W_cfg4 > "$OUT/busy.log" 2>&1
+cp profiles/${TAG}_pmc_busy.md profiles/${TAG}_pmc_busy.json "$OUT/" 2>/dev/null
 python3 - "$OUT" "$TAG" <<'PY'
 import csv, json, sys
 out, tag = sys.argv[1], sys.argv[2]

@@ -2436,7 +2436,8 @@ struct PwBlock<0> {
 // 64-bin trips each) as one with four times fewer trips.  The prefix sums are the approximate
 // side of the search (any summation order satisfies window_eps' bound); everything decided later
 // is re-evaluated exactly, so the outputs equal the general path's bit for bit.
-__global__ __launch_bounds__(1024) void k_lat_setup(const double *__restrict__ zsrc, const double *__restrict__ rsrc,
+template <int NT>     // workgroup size: 1024 for a handful of regions (latency mode), 256 for a batch's thousands
+__global__ __launch_bounds__(NT) void k_lat_setup(const double *__restrict__ zsrc, const double *__restrict__ rsrc,
                                                    const double *__restrict__ nsrc, int64_t str_i, int64_t str_b,
                                                    int64_t B, const int64_t *__restrict__ moff,
                                                    const int64_t *__restrict__ goff, const int *__restrict__ m2g,
@@ -2449,9 +2450,10 @@ __global__ __launch_bounds__(1024) void k_lat_setup(const double *__restrict__ z
                                                    int *__restrict__ counters, int *__restrict__ out_n,
                                                    int *__restrict__ misc, int64_t n_regions) {
     extern __shared__ double zl[];                // the region's kept z values (the prefix pass and the exact sum read them here)
-    __shared__ int s_cnt[16];
-    __shared__ double s_sum[16], s_abs[16];
-    __shared__ int s_fin[16];
+    constexpr int NW = NT / 64;
+    __shared__ int s_cnt[NW];
+    __shared__ double s_sum[NW], s_abs[NW];
+    __shared__ int s_fin[NW];
     __shared__ double s_leaf[32];
     __shared__ wc::PwWaveScratch sc;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -2466,7 +2468,7 @@ __global__ __launch_bounds__(1024) void k_lat_setup(const double *__restrict__ z
     const int64_t off = i * B + cs;
     // 1. keep bins with enough reference bins, in order (wisecondor.py:215-222)
     int count = 0;
-    for (int64_t base = cs; base < ce; base += 1024) {
+    for (int64_t base = cs; base < ce; base += NT) {
         const int64_t b = base + tid;
         bool keep = false;
         if (b < ce) keep = nsrc[i * str_i + b * str_b] >= minref;
@@ -2483,7 +2485,7 @@ __global__ __launch_bounds__(1024) void k_lat_setup(const double *__restrict__ z
             rc[off + at] = rsrc[i * str_i + b * str_b];
             gpos[off + at] = (int)(m2g[b] - goff[c]);
         }
-        for (int q = 0; q < 16; ++q) count += s_cnt[q];
+        for (int q = 0; q < NW; ++q) count += s_cnt[q];
         __syncthreads();
     }
     const int n = count;
@@ -2504,7 +2506,7 @@ __global__ __launch_bounds__(1024) void k_lat_setup(const double *__restrict__ z
     if (tid == 0) P[0] = 0.0;
     double run = 0.0, a = 0.0;
     int finite = 1;
-    for (int t0 = 0; t0 < n; t0 += 1024) {
+    for (int t0 = 0; t0 < n; t0 += NT) {
         const int t = t0 + tid;
         const double v = t < n ? zz[t] : 0.0;
         if (!isfinite(v)) finite = 0;
@@ -2519,7 +2521,7 @@ __global__ __launch_bounds__(1024) void k_lat_setup(const double *__restrict__ z
         double before = run;
         for (int q = 0; q < w; ++q) before += s_sum[q];
         if (t < n) P[t + 1] = before + incl;
-        for (int q = 0; q < 16; ++q) run += s_sum[q];
+        for (int q = 0; q < NW; ++q) run += s_sum[q];
         __syncthreads();
     }
     for (int o = 32; o > 0; o >>= 1) {
@@ -2531,7 +2533,7 @@ __global__ __launch_bounds__(1024) void k_lat_setup(const double *__restrict__ z
     if (tid == 0) {
         double aa = 0.0;
         int ff = 1;
-        for (int q = 0; q < 16; ++q) { aa += s_abs[q]; ff &= s_fin[q]; }
+        for (int q = 0; q < NW; ++q) { aa += s_abs[q]; ff &= s_fin[q]; }
         reg_abs[r] = aa;
         reg_flag[r] = ff;
     }
@@ -3423,10 +3425,26 @@ struct TreeTail {
     double *reg_calls;       // [n_regions, max_calls, 5]
     bool defer_status;       // the caller reads the tree kernel's status words after its own synchronize
 };
+// Batches whose regions fit the fused set-up kernel (<= TREE_MAXLEN bins, no -mineffectsize mask): cleaning,
+// prefix sums, whole-region values and the root jobs in ONE launch (k_lat_setup<256>) instead of k_clean +
+// k_region_prefix + k_region_whole + k_init_jobs + the copy of the whole-region values.
+struct FusedSetup {
+    const double *zsrc, *rsrc, *nsrc;
+    int64_t str_i, str_b, B;
+    const int64_t *moff, *goff;
+    const int *m2g, *sel;
+    int n_sel;
+    double minref;
+    double *zc, *rc;
+    int *gpos;
+    Region *regions;
+    double *whole_copy;
+};
 int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, int64_t n_regions, int64_t total_len,
                  int64_t max_n, double thr, int min_search, int max_calls, hipStream_t stream,
                  const double *ratio_dev = nullptr, double min_effect = 0.0, int64_t bits_upper = 0,
-                 int lat_rounds = 0, double *whole_copy = nullptr, const TreeTail *tail = nullptr) {
+                 int lat_rounds = 0, double *whole_copy = nullptr, const TreeTail *tail = nullptr,
+                 const FusedSetup *fused = nullptr) {
     TestState &ts = ctx->ts;
     int rc;
     ts.last_segs = 0;
@@ -3515,6 +3533,14 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     int *hot = ts.hot.as<int>();
     int *brute = hot + job_cap;
     if ((rc = ts.misc.reserve(sizeof(int) * 4))) return rc;
+    if (fused)
+        hipLaunchKernelGGL(k_lat_setup<256>, dim3((unsigned)n_regions), dim3(256), sizeof(double) * (max_n + 1), stream,
+                           fused->zsrc, fused->rsrc, fused->nsrc, fused->str_i, fused->str_b, fused->B, fused->moff,
+                           fused->goff, fused->m2g, fused->sel, fused->n_sel, fused->minref, fused->zc, fused->rc,
+                           fused->gpos, fused->regions, ts.prefix.as<double>(), ts.reg_abs.as<double>(),
+                           ts.reg_flag.as<int>(), ts.whole.as<double>(), fused->whole_copy, ts.jobs_a.as<Job>(), counters,
+                           ts.out_n.as<int>(), ts.misc.as<int>(), n_regions);
+    else
     hipLaunchKernelGGL(k_region_prefix, dim3((unsigned)cdiv(n_regions, 4)), dim3(256), 0, stream, z_dev, regions_dev,
                        n_regions, ts.prefix.as<double>(), ts.reg_abs.as<double>(), ts.reg_flag.as<int>(), counters,
                        ts.out_n.as<int>(), ts.misc.as<int>());
@@ -3529,10 +3555,12 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
         hipLaunchKernelGGL(k_block_minmax, dim3((unsigned)cdiv(nblk, 256)), dim3(256), 0, stream,
                            (const double *)ts.prefix.as<double>(), total, ts.tmin.as<double>(), ts.tmax.as<double>());
     }
-    hipLaunchKernelGGL(k_region_whole, dim3((unsigned)cdiv(n_regions, 4)), dim3(256), 0, stream, z_dev, regions_dev,
-                       n_regions, bits, bit_off, ts.whole.as<double>(), whole_copy);
-    hipLaunchKernelGGL(k_init_jobs, dim3((unsigned)cdiv(n_regions, 256)), dim3(256), 0, stream, regions_dev, n_regions,
-                       ts.jobs_a.as<Job>(), counters);
+    if (!fused) {
+        hipLaunchKernelGGL(k_region_whole, dim3((unsigned)cdiv(n_regions, 4)), dim3(256), 0, stream, z_dev, regions_dev,
+                           n_regions, bits, bit_off, ts.whole.as<double>(), whole_copy);
+        hipLaunchKernelGGL(k_init_jobs, dim3((unsigned)cdiv(n_regions, 256)), dim3(256), 0, stream, regions_dev, n_regions,
+                           ts.jobs_a.as<Job>(), counters);
+    }
     Job *cur = ts.jobs_a.as<Job>(), *next = ts.jobs_b.as<Job>();
     int64_t n_jobs = n_regions;
     int guard = 0;
@@ -3692,7 +3720,7 @@ int run_seg_lat(wc_ctx *ctx, const wc_reference *ref, const double *zsrc, const 
     if ((rc = ts.tmin.reserve(sizeof(double) * nblk))) return rc;
     if ((rc = ts.tmax.reserve(sizeof(double) * nblk))) return rc;
     int *counters = ts.job_cnt.as<int>();
-    hipLaunchKernelGGL(k_lat_setup, dim3((unsigned)n_regions), dim3(1024), sizeof(double) * (max_n + 1), stream, zsrc, rsrc, nsrc, str_i, str_b, B,
+    hipLaunchKernelGGL(k_lat_setup<1024>, dim3((unsigned)n_regions), dim3(1024), sizeof(double) * (max_n + 1), stream, zsrc, rsrc, nsrc, str_i, str_b, B,
                        (const int64_t *)ref->moff_dev.as<int64_t>(), (const int64_t *)ref->goff_dev.as<int64_t>(),
                        (const int *)ref->m2g.as<int>(), (const int *)ts.sel.as<int>(), n_sel, (double)min_ref_bins,
                        ts.zc.as<double>(), ts.rc.as<double>(), ts.gpos.as<int>(), ts.regions.as<Region>(),
@@ -4132,6 +4160,7 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
         return WC_OK;
     }
     const int64_t n_regions = Ns * n_sel;
+    bool cwz_done = false;        // the fused set-up kernel wrote results_cwz itself
     if ((rc = ts.zc.reserve(sizeof(double) * Ns * B))) return rc;
     if ((rc = ts.rc.reserve(sizeof(double) * Ns * B))) return rc;
     if ((rc = ts.gpos.reserve(sizeof(int) * Ns * B))) return rc;
@@ -4169,6 +4198,9 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
             return WC_OK;
         }
     } else {
+        const char *fs_env = getenv("WC_TEST_FUSED_SETUP");        // "0": the separate set-up kernels
+        const bool fuse = min_effect == 0.0 && max_n <= TREE_MAXLEN && !(fs_env && fs_env[0] == '0');
+        if (!fuse)
         hipLaunchKernelGGL(k_clean, dim3((unsigned)n_sel, (unsigned)Ns),
                            dim3((unsigned)std::min<int64_t>(1024, std::max<int64_t>(64, cdiv(max_n, 256) * 64))), 0, stream, zsrc, rsrc, nsrc, B, Ns,
                            (const int64_t *)ref->moff_dev.as<int64_t>(), (const int64_t *)ref->goff_dev.as<int64_t>(),
@@ -4183,13 +4215,17 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
             }
         ts.mark(3, stream);
         const TreeTail tail{ts.rc.as<double>(), ts.gpos.as<int>(), ts.effect.as<double>(), calls && n_calls && !ts.profile};
+        const FusedSetup fsu{zsrc, rsrc, nsrc, str_i, str_b, B, ref->moff_dev.as<int64_t>(), ref->goff_dev.as<int64_t>(),
+                             ref->m2g.as<int>(), ts.sel.as<int>(), n_sel, (double)min_ref_bins, ts.zc.as<double>(),
+                             ts.rc.as<double>(), ts.gpos.as<int>(), ts.regions.as<Region>(), results_cwz};
+        cwz_done = fuse && results_cwz;
         if ((rc = run_stouffer(ctx, ts.zc.as<double>(), ts.regions.as<Region>(), n_regions, Ns * B, max_n, threshold, 3,
                                max_calls, stream, ts.rc.as<double>(), min_effect, bits_upper, 0, nullptr,
-                               calls && n_calls ? &tail : nullptr)))
+                               calls && n_calls ? &tail : nullptr, fuse ? &fsu : nullptr)))
             return rc;
     }
     ts.mark(4, stream);
-    if (results_cwz && !lat)
+    if (results_cwz && !lat && !cwz_done)
         WC_HIP(hipMemcpyAsync(results_cwz, ts.whole.p, sizeof(double) * n_regions, hipMemcpyDeviceToDevice, stream));
     if ((rc = ctx->ensure_pinned(256))) return rc;
     if (calls && n_calls) {
