@@ -364,8 +364,9 @@ def run_cpu_baseline(inp, binsize, k, idx_gpu, reference_arrays, tb_calls, budge
 
 # ---------------------------------------------------------------- rooflines ----
 GRAM_KERNELS = {
-    "f16": ("k_gram<f16> (symmetric distance tiles, ONE float16 matrix-core product per multiply, every row's "
-            "representation error charged to its norm bounds, + candidate filter)", 1.0, PEAK_BF16_MFMA),
+    "f16": ("k_gram_glds (symmetric distance tiles, ONE float16 matrix-core product per multiply, every row's "
+            "representation error charged to its norm bounds, operand slabs by LDS-DMA, + candidate filter)", 1.0,
+            PEAK_BF16_MFMA),
     "split": ("k_gram<split> (symmetric distance tiles on the bf16 matrix cores, hi/lo operand pairs: three "
               "products per multiply, + candidate filter)", SPLIT_PRODUCTS, PEAK_BF16_MFMA),
     "f32": ("k_gram<f32> (symmetric fp32 MFMA distance tiles + candidate filter)", 1.0, PEAK_FP32_MFMA),

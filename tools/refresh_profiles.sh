@@ -77,8 +77,9 @@ for wl in ("cfg2", "cfg4"):
             if not row or row[0] == "Kernel":
                 continue
             for kern, pat in kernels:
-                # several instantiations may appear (the float32 variant is timed too): keep the most launched
-                if pat in row[0] and int(row[1]) > best.get(kern, (0, 0.0))[0]:
+                # several instantiations may appear (the other tile modes are timed too): keep the most launched
+                hit = pat in row[0] or (kern == "k_gram" and "::k_gram_glds" in row[0])
+                if hit and int(row[1]) > best.get(kern, (0, 0.0))[0]:
                     best[kern] = (int(row[1]), float(row[2]))
         for kern, (_, v) in best.items():
             vals[kern][c] = v

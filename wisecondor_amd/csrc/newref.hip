@@ -267,6 +267,7 @@ struct GramArgs {
     int last_groups;             // groups of four MFMA steps of the last slab that hold samples (1..4)
     int last_steps16;            // split / f16 modes: 16-sample MFMA steps of the last slab that hold samples (1..2 / 1..4)
     const float *m2;             // f16 mode: -2 / gam^2 (the operand image is scaled by gam); NULL: -2
+    int nslab32, last_steps32;   // LDS-DMA kernel: 32-sample slabs, 16-sample steps of the last one that hold samples (1..2)
     const float *nbP, *nbQ;      // lower norm bounds
     const int2 *range;           // per row: [first, last+1) row of its chromosome (never candidates)
     const int4 *tiles;           // {I, J, roles, 0}
@@ -385,6 +386,127 @@ __device__ __forceinline__ void gram_steps(const float *As, const float *Bs, f32
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca0[e], cb1[e], acc[0][1], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca1[e], cb0[e], acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca1[e], cb1[e], acc[1][1], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// The tile's epilogue (shared by the register-staged and the LDS-DMA tile kernels): dot products ->
+// lower-bound keys -> the few that pass a target's threshold appended to that target's list.
+__device__ __forceinline__ void gram_epilogue(const GramArgs &g, float *sm, float *D, const float *nbPs, const float *nbQs,
+                                              const float *thPs, const float *thQs, f32x16 (&acc)[2][2], const int I,
+                                              const int J, const int roles, const float m2, const int tid,
+                                              const int lane, const int w, const int wr, const int wc, const int li,
+                                              const int lh) {
+    // Epilogue in two halves (rows 0-63 from the waves with wr == 0, then rows 64-127):
+    // the 64 x 128 dot-product tile aliases the staging buffers, which keeps the
+    // workgroup at 39 KB of LDS -> four workgroups per CU cover each other's
+    // load / barrier / epilogue phases with MFMA work.
+    // ONE sweep evaluates every key of the half once (round 2 evaluated each twice, once per role):
+    // thread (x, q) owns column x and 32 of the half's rows.  Its keys against the column target's
+    // threshold give the column role's pass mask; the same keys against the ROW targets' thresholds --
+    // wave-uniform, the row is the loop variable -- are one v_cmp whose 64-bit result IS the row's
+    // pass mask over the wave's 64 columns (no ballot instruction, no second LDS read of the tile);
+    // lane 0 parks it in LDS.  After a barrier sixteen lanes per wave finish the rows: two masks per
+    // row, same-chromosome columns cleared as a run, ONE list reservation per row and half (round 2:
+    // four), keys of the few set bits rebuilt from the tile.
+    __builtin_amdgcn_s_setprio(0);
+    const int x = tid & 127, q = __builtin_amdgcn_readfirstlane(tid >> 7);   // column x, 32-row half q
+    const int2 rgq = g.range[(int64_t)J * TB + x];
+    unsigned long long *rowmask = reinterpret_cast<unsigned long long *>(sm + 128 * LDT);   // [64 rows][2 column halves]
+    const int rl = w * 16 + (lane & 15);                                   // the row this lane helps to finish (four lanes per row)
+    const int2 rgr0 = g.range[(int64_t)I * TB + rl], rgr1 = g.range[(int64_t)I * TB + 64 + rl];
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+        if (wr == h) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        // accumulators 4 r4 .. 4 r4 + 3 are four consecutive rows of one column: the
+                        // tile is stored column-major so that they go out as one 16-byte write
+                        // (and the column scan below comes back as 16-byte reads)
+                        const int row = m * 32 + 8 * r4 + 4 * lh;
+                        const int col = wc * 64 + n * 32 + li;
+                        f32x4 v4;
+                        v4[0] = acc[m][n][4 * r4]; v4[1] = acc[m][n][4 * r4 + 1];
+                        v4[2] = acc[m][n][4 * r4 + 2]; v4[3] = acc[m][n][4 * r4 + 3];
+                        *(f32x4 *)&D[col * LDT + row] = v4;
+                    }
+        }
+        __syncthreads();
+
+        unsigned int mask_c = 0u;
+        {
+            const float nbc = nbQs[x], thc = (roles & ROLE_COLS) ? thQs[x] : -INFINITY;
+            float dv[32];
+#pragma unroll
+            for (int g4 = 0; g4 < 8; ++g4) {
+                const f32x4 d4 = *(const f32x4 *)&D[x * LDT + q * 32 + 4 * g4];
+                dv[4 * g4] = d4[0]; dv[4 * g4 + 1] = d4[1]; dv[4 * g4 + 2] = d4[2]; dv[4 * g4 + 3] = d4[3];
+            }
+            const f32x4 *nbv = (const f32x4 *)&nbPs[h * 64 + q * 32];
+            const f32x4 *thv = (const f32x4 *)&thPs[h * 64 + q * 32];
+#pragma unroll
+            for (int g4 = 0; g4 < 8; ++g4) {
+                const f32x4 nb4 = nbv[g4], th4 = thv[g4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float key = fmaf(m2, dv[4 * g4 + e], nb4[e] + nbc);
+                    mask_c |= (key <= thc) ? (1u << (4 * g4 + e)) : 0u;
+                    const unsigned long long hit = __ballot(key <= th4[e]);      // a compare into a scalar pair
+                    // every lane stores the (uniform) mask to the row's slot: one LDS write, no exec games
+                    rowmask[(q * 32 + 4 * g4 + e) * 2 + (w & 1)] = hit;
+                }
+            }
+            mask_c &= ~run_mask(rgq.x - (I * TB + h * 64 + q * 32), rgq.y - (I * TB + h * 64 + q * 32));
+        }
+        // the column role's reservation flies while the rows are finished
+        int base_c = 0;
+        const int64_t gq = (int64_t)J * TB + x;
+        if (mask_c) base_c = atomicAdd(&g.cnt[gq], __popc(mask_c));
+        __syncthreads();
+        if (roles & ROLE_ROWS) {
+            // four lanes per row (lane = 16 part + row-in-wave): each takes a 32-column quarter of the row's
+            // 128-bit mask; part 0 reserves for all four, the base comes back by a shuffle
+            const int part = lane >> 4;
+            const unsigned long long m64 = rowmask[rl * 2 + (part >> 1)];
+            unsigned int mm = (unsigned int)(m64 >> (32 * (part & 1)));
+            const int2 rg = h ? rgr1 : rgr0;
+            mm &= ~run_mask(rg.x - (J * TB + 32 * part), rg.y - (J * TB + 32 * part));   // the row's own chromosome
+            const int mine = __popc(mm);
+            const int c1 = __shfl(mine, (lane & 15) + 16), c2 = __shfl(mine, (lane & 15) + 32), c3 = __shfl(mine, (lane & 15) + 48);
+            const int r = h * 64 + rl;
+            const int64_t gp = (int64_t)I * TB + r;
+            int base_r = 0;
+            if (part == 0 && mine + c1 + c2 + c3 > 0) base_r = atomicAdd(&g.cnt[gp], mine + c1 + c2 + c3);
+            base_r = __shfl(base_r, lane & 15);
+            const int c0 = __shfl(mine, lane & 15);
+            base_r += (part > 0 ? c0 : 0) + (part > 1 ? c1 : 0) + (part > 2 ? c2 : 0);
+            if (mm) {
+                const float nbr = nbPs[r];
+                unsigned long long *dst = g.list + gp * g.cap;
+                while (mm) {
+                    const int c = 32 * part + (__ffs((int)mm) - 1);
+                    mm &= mm - 1;
+                    const float key = fmaf(m2, D[c * LDT + rl], nbr + nbQs[c]);
+                    if (base_r < g.cap) dst[base_r] = pack_entry(key, J * TB + c);
+                    ++base_r;
+                }
+            }
+        }
+        if (mask_c) {
+            const float nbc = nbQs[x];
+            unsigned long long *dst = g.list + gq * g.cap;
+            while (mask_c) {
+                int rr = __ffs((int)mask_c) - 1;
+                mask_c &= mask_c - 1;
+                int l = q * 32 + rr, r = h * 64 + l;
+                float key = fmaf(m2, D[x * LDT + l], nbPs[r] + nbc);
+                if (base_c < g.cap) dst[base_c] = pack_entry(key, I * TB + r);
+                ++base_c;
             }
         }
     }
@@ -524,120 +646,109 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 3 : 4) void k_gram(GramArgs g) {
 
     }   // DEPTH
 
-    // Epilogue in two halves (rows 0-63 from the waves with wr == 0, then rows 64-127):
-    // the 64 x 128 dot-product tile aliases the staging buffers, which keeps the
-    // workgroup at 39 KB of LDS -> four workgroups per CU cover each other's
-    // load / barrier / epilogue phases with MFMA work.
-    // ONE sweep evaluates every key of the half once (round 2 evaluated each twice, once per role):
-    // thread (x, q) owns column x and 32 of the half's rows.  Its keys against the column target's
-    // threshold give the column role's pass mask; the same keys against the ROW targets' thresholds --
-    // wave-uniform, the row is the loop variable -- are one v_cmp whose 64-bit result IS the row's
-    // pass mask over the wave's 64 columns (no ballot instruction, no second LDS read of the tile);
-    // lane 0 parks it in LDS.  After a barrier sixteen lanes per wave finish the rows: two masks per
-    // row, same-chromosome columns cleared as a run, ONE list reservation per row and half (round 2:
-    // four), keys of the few set bits rebuilt from the tile.
-    __builtin_amdgcn_s_setprio(0);
-    const int x = tid & 127, q = __builtin_amdgcn_readfirstlane(tid >> 7);   // column x, 32-row half q
-    const int2 rgq = g.range[(int64_t)J * TB + x];
-    unsigned long long *rowmask = reinterpret_cast<unsigned long long *>(sm + 128 * LDT);   // [64 rows][2 column halves]
-    const int rl = w * 16 + (lane & 15);                                   // the row this lane helps to finish (four lanes per row)
-    const int2 rgr0 = g.range[(int64_t)I * TB + rl], rgr1 = g.range[(int64_t)I * TB + 64 + rl];
-    for (int h = 0; h < 2; ++h) {
-        __syncthreads();
-        if (wr == h) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-#pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) {
-                        // accumulators 4 r4 .. 4 r4 + 3 are four consecutive rows of one column: the
-                        // tile is stored column-major so that they go out as one 16-byte write
-                        // (and the column scan below comes back as 16-byte reads)
-                        const int row = m * 32 + 8 * r4 + 4 * lh;
-                        const int col = wc * 64 + n * 32 + li;
-                        f32x4 v4;
-                        v4[0] = acc[m][n][4 * r4]; v4[1] = acc[m][n][4 * r4 + 1];
-                        v4[2] = acc[m][n][4 * r4 + 2]; v4[3] = acc[m][n][4 * r4 + 3];
-                        *(f32x4 *)&D[col * LDT + row] = v4;
-                    }
-        }
-        __syncthreads();
-
-        unsigned int mask_c = 0u;
-        {
-            const float nbc = nbQs[x], thc = (roles & ROLE_COLS) ? thQs[x] : -INFINITY;
-            float dv[32];
-#pragma unroll
-            for (int g4 = 0; g4 < 8; ++g4) {
-                const f32x4 d4 = *(const f32x4 *)&D[x * LDT + q * 32 + 4 * g4];
-                dv[4 * g4] = d4[0]; dv[4 * g4 + 1] = d4[1]; dv[4 * g4 + 2] = d4[2]; dv[4 * g4 + 3] = d4[3];
-            }
-            const f32x4 *nbv = (const f32x4 *)&nbPs[h * 64 + q * 32];
-            const f32x4 *thv = (const f32x4 *)&thPs[h * 64 + q * 32];
-#pragma unroll
-            for (int g4 = 0; g4 < 8; ++g4) {
-                const f32x4 nb4 = nbv[g4], th4 = thv[g4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float key = fmaf(m2, dv[4 * g4 + e], nb4[e] + nbc);
-                    mask_c |= (key <= thc) ? (1u << (4 * g4 + e)) : 0u;
-                    const unsigned long long hit = __ballot(key <= th4[e]);      // a compare into a scalar pair
-                    // every lane stores the (uniform) mask to the row's slot: one LDS write, no exec games
-                    rowmask[(q * 32 + 4 * g4 + e) * 2 + (w & 1)] = hit;
-                }
-            }
-            mask_c &= ~run_mask(rgq.x - (I * TB + h * 64 + q * 32), rgq.y - (I * TB + h * 64 + q * 32));
-        }
-        // the column role's reservation flies while the rows are finished
-        int base_c = 0;
-        const int64_t gq = (int64_t)J * TB + x;
-        if (mask_c) base_c = atomicAdd(&g.cnt[gq], __popc(mask_c));
-        __syncthreads();
-        if (roles & ROLE_ROWS) {
-            // four lanes per row (lane = 16 part + row-in-wave): each takes a 32-column quarter of the row's
-            // 128-bit mask; part 0 reserves for all four, the base comes back by a shuffle
-            const int part = lane >> 4;
-            const unsigned long long m64 = rowmask[rl * 2 + (part >> 1)];
-            unsigned int mm = (unsigned int)(m64 >> (32 * (part & 1)));
-            const int2 rg = h ? rgr1 : rgr0;
-            mm &= ~run_mask(rg.x - (J * TB + 32 * part), rg.y - (J * TB + 32 * part));   // the row's own chromosome
-            const int mine = __popc(mm);
-            const int c1 = __shfl(mine, (lane & 15) + 16), c2 = __shfl(mine, (lane & 15) + 32), c3 = __shfl(mine, (lane & 15) + 48);
-            const int r = h * 64 + rl;
-            const int64_t gp = (int64_t)I * TB + r;
-            int base_r = 0;
-            if (part == 0 && mine + c1 + c2 + c3 > 0) base_r = atomicAdd(&g.cnt[gp], mine + c1 + c2 + c3);
-            base_r = __shfl(base_r, lane & 15);
-            const int c0 = __shfl(mine, lane & 15);
-            base_r += (part > 0 ? c0 : 0) + (part > 1 ? c1 : 0) + (part > 2 ? c2 : 0);
-            if (mm) {
-                const float nbr = nbPs[r];
-                unsigned long long *dst = g.list + gp * g.cap;
-                while (mm) {
-                    const int c = 32 * part + (__ffs((int)mm) - 1);
-                    mm &= mm - 1;
-                    const float key = fmaf(m2, D[c * LDT + rl], nbr + nbQs[c]);
-                    if (base_r < g.cap) dst[base_r] = pack_entry(key, J * TB + c);
-                    ++base_r;
-                }
-            }
-        }
-        if (mask_c) {
-            const float nbc = nbQs[x];
-            unsigned long long *dst = g.list + gq * g.cap;
-            while (mask_c) {
-                int rr = __ffs((int)mask_c) - 1;
-                mask_c &= mask_c - 1;
-                int l = q * 32 + rr, r = h * 64 + l;
-                float key = fmaf(m2, D[x * LDT + l], nbPs[r] + nbc);
-                if (base_c < g.cap) dst[base_c] = pack_entry(key, I * TB + r);
-                ++base_c;
-            }
-        }
-    }
+    gram_epilogue(g, sm, D, nbPs, nbQs, thPs, thQs, acc, I, J, roles, m2, tid, lane, w, wr, wc, li, lh);
 }
 
+
+// ------------------------------------------------ LDS-DMA tile kernel (float16) ----
+// The float16 tiles' default kernel (WC_GRAM_STAGE=regs selects the register-staged k_gram<GRAM_F16> instead):
+// the operand slabs are brought in by global_load_lds_dwordx4
+// (global -> LDS directly: no staging registers, no ds_write pass).  A slab is 32 samples = 64 bytes per row;
+// a wave's DMA instruction fills 16 rows x 64 B = 1 KB lane-linearly, so the row padding of the
+// register-staged kernel is not available: the 16-byte chunk g of row r sits in slot g ^ ((r >> 2) & 3)
+// (swizzled on the SOURCE address and again on the fragment read), which keeps the sixteen rows a
+// ds_read_b128 group touches on distinct banks.  Two slabs of LDS (32 KB) + the dot tile's 35 KB aliasing
+// them: four workgroups per CU.  One barrier per slab: the barrier at the top of step s waits for slab s
+// (the compiler drains the DMA there) and tells everybody that slab s - 1's buffer may be refilled, the
+// DMA of slab s + 1 then runs under the MFMAs of slab s.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+constexpr int GL_ROW = 16;            // floats per LDS row (64 bytes = 32 float16)
+constexpr int GL_STAGE = 2 * TB * GL_ROW;   // floats per stage: A rows then B rows
+__global__ __launch_bounds__(256, 4) void k_gram_glds(GramArgs g) {
+    __shared__ __attribute__((aligned(16))) float sm[128 * LDT + 256 + 4 * TB];   // dot tile + row masks + bounds / thresholds
+    float *D = sm;
+    float *nbPs = sm + 128 * LDT + 256;
+    float *nbQs = nbPs + TB;
+    float *thPs = nbQs + TB;
+    float *thQs = thPs + TB;
+    static_assert(2 * GL_STAGE <= 128 * LDT, "the two operand stages alias the dot tile");
+    const int chunk = (g.ntiles + 7) >> 3;
+    const int t_id = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (t_id >= g.ntiles) return;
+    const int4 tile = g.tiles[t_id];
+    const int I = tile.x, J = tile.y, roles = tile.z;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const float m2 = *g.m2;
+    if (tid < TB) {
+        int64_t gp = (int64_t)I * TB + tid;
+        nbPs[tid] = g.nbP[gp];
+        thPs[tid] = g.thr[gp];
+    } else {
+        int c = tid - TB;
+        int64_t gq = (int64_t)J * TB + c;
+        nbQs[c] = g.nbQ[gq];
+        thQs[c] = g.thr[gq];
+    }
+    // DMA sources: wave w fills rows [32 w, 32 w + 32) of A and of B, 16 rows per instruction; lane l
+    // lands in row (l >> 2), slot (l & 3) and therefore fetches chunk (l & 3) ^ ((row >> 2) & 3)
+    const float *srcA[2], *srcB[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = w * 32 + j * 16 + (lane >> 2);
+        const int gch = (lane & 3) ^ ((row >> 2) & 3);
+        srcA[j] = g.P + ((int64_t)I * TB + row) * g.ld + gch * 4;
+        srcB[j] = g.Q + ((int64_t)J * TB + row) * g.ld + gch * 4;
+    }
+    auto dma = [&](int slab, int stage) {
+        float *base = sm + stage * GL_STAGE + (w * 32) * GL_ROW;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(srcA[j] + slab * GL_ROW), (lds_void_t *)(base + j * 16 * GL_ROW), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(srcB[j] + slab * GL_ROW),
+                                             (lds_void_t *)(base + TB * GL_ROW + j * 16 * GL_ROW), 16, 0, 0);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    // fragment read offsets (floats) of this lane: rows li and li + 32 of its wave's 64, chunk 2 t + lh swizzled
+    const int ra0 = wr * 64 + li, ra1 = ra0 + 32, rb0 = wc * 64 + li, rb1 = rb0 + 32;
+    int offA[2][2], offB[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        offA[t][0] = ra0 * GL_ROW + (((2 * t + lh) ^ ((ra0 >> 2) & 3)) << 2);
+        offA[t][1] = ra1 * GL_ROW + (((2 * t + lh) ^ ((ra1 >> 2) & 3)) << 2);
+        offB[t][0] = (TB + rb0) * GL_ROW + (((2 * t + lh) ^ ((rb0 >> 2) & 3)) << 2);
+        offB[t][1] = (TB + rb1) * GL_ROW + (((2 * t + lh) ^ ((rb1 >> 2) & 3)) << 2);
+    }
+    const int nslab = g.nslab32;          // 32-sample slabs
+    dma(0, 0);
+    __builtin_amdgcn_s_setprio(2);
+    for (int slab = 0; slab < nslab; ++slab) {
+        __syncthreads();                  // slab `slab` has landed (vmcnt(0) + barrier); the other stage is free
+        if (slab + 1 < nslab) dma(slab + 1, (slab + 1) & 1);
+        const float *st = sm + (slab & 1) * GL_STAGE;
+        const int nt = slab + 1 < nslab ? 2 : g.last_steps32;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (t >= nt) break;
+            const f16x8 a0 = *(const f16x8 *)&st[offA[t][0]], a1 = *(const f16x8 *)&st[offA[t][1]];
+            const f16x8 b0 = *(const f16x8 *)&st[offB[t][0]], b1 = *(const f16x8 *)&st[offB[t][1]];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    gram_epilogue(g, sm, D, nbPs, nbQs, thPs, thQs, acc, I, J, roles, m2, tid, lane, w, wr, wc, li, lh);
+}
 
 // ---------------------------------------------- threshold-estimate Gram (bf16) ----
 // The admission thresholds only have to put a few hundred candidates per row on the
@@ -2281,6 +2392,8 @@ int wc_newref_collect_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t
         g.last_groups = 4;
         g.last_steps16 = (int)((rem + 15) / 16);
         g.m2 = st.m2.as<float>();
+        g.nslab32 = (int)((st.n_samples + 31) / 32);
+        g.last_steps32 = (int)(((st.n_samples - (int64_t)(g.nslab32 - 1) * 32) + 15) / 16);
     } else {
         g.P = g.Q = st.split ? st.a3.as<float>() : st.a32.as<float>();
         g.ld = st.k_pad;
@@ -2302,7 +2415,10 @@ int wc_newref_collect_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t
     {
         const char *e = getenv("WC_GRAM_DEPTH");
         const bool d1 = e && atoi(e) == 1;
-        if (st.gram_mode == 2) {
+        const char *se = getenv("WC_GRAM_STAGE");              // "regs": the register-staged tile kernel instead of LDS-DMA (float16 tiles)
+        if (st.gram_mode == 2 && !(se && strcmp(se, "regs") == 0)) {
+            hipLaunchKernelGGL(k_gram_glds, dim3(grid), dim3(256), 0, stream, g);
+        } else if (st.gram_mode == 2) {
             if (d1) hipLaunchKernelGGL((k_gram<GRAM_F16, 1>), dim3(grid), dim3(256), 0, stream, g);
             else hipLaunchKernelGGL((k_gram<GRAM_F16, 2>), dim3(grid), dim3(256), 0, stream, g);
         } else if (st.gram_mode == 1) {
@@ -2495,7 +2611,7 @@ int wc_get_reference_dev(wc_ctx *ctx, void *stream_, const double *corrected, in
     if (want) {
         key = {(int64_t)(intptr_t)corrected, n_bins, n_samples, n_chrom, k, sum_order, row_begin, row_end,
                (int64_t)(intptr_t)idx_out, (int64_t)(intptr_t)dist_out, (int64_t)(intptr_t)stream_,
-               env_word("WC_GRAM_MODE"), env_word("WC_GRAM_DEPTH"), env_word("WC_FINISH_ENGINE"),
+               env_word("WC_GRAM_MODE"), env_word("WC_GRAM_DEPTH"), env_word("WC_GRAM_STAGE"), env_word("WC_FINISH_ENGINE"),
                env_word("WC_FINISH_THREADS")};
         for (int c = 0; c < n_chrom; ++c) key.push_back(chrom_bins_host[c]);
     }
