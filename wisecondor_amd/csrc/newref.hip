@@ -46,6 +46,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef double f64x2_u __attribute__((ext_vector_type(2), aligned(8)));   // rows of an odd sample count start 8-byte aligned
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void lds_void_t;          // operands of __builtin_amdgcn_global_load_lds
+typedef __attribute__((address_space(1))) const void glb_void_t;
 
 // ------------------------------------------------------------------ prepare ----
 // Robust per-sample centre from a strided subset of rows: mean -> 8 x mean absolute
@@ -661,8 +663,6 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 3 : 4) void k_gram(GramArgs g) {
 // them: four workgroups per CU.  One barrier per slab: the barrier at the top of step s waits for slab s
 // (the compiler drains the DMA there) and tells everybody that slab s - 1's buffer may be refilled, the
 // DMA of slab s + 1 then runs under the MFMAs of slab s.
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void glb_void_t;
 constexpr int GL_ROW = 16;            // floats per LDS row (64 bytes = 32 float16)
 constexpr int GL_STAGE = 2 * TB * GL_ROW;   // floats per stage: A rows then B rows
 __global__ __launch_bounds__(256, 4) void k_gram_glds(GramArgs g) {
@@ -1640,11 +1640,15 @@ __device__ inline void wave_lds_fence() {
 // Dynamic LDS: [target row: Sp doubles][wave slabs: 8 KB each]; after the sums (one barrier) the
 // slab memory holds dk / jv (distances and candidates as computed) and sd / sj (in order).
 constexpr int SLAB_DOUBLES = 64 * ST_CH;
-template <bool SEQ>
-__global__ __launch_bounds__(PS_MAX, SEQ ? 4 : 3) void k_rescore(PickArgs p, const double *__restrict__ Xp, int Sp) {
+// GLDS: the candidates' chunks arrive by LDS-DMA (global_load_lds_dwordx4) instead of through staging
+// registers + a ds_write pass: the XOR swizzle moves to the source address, the owning lane forms
+// (candidate - target)^2 itself from the raw values (the same two roundings per element), and the next
+// chunk's DMA runs under the sums of this one.
+template <bool SEQ, bool GLDS>
+__global__ __launch_bounds__(PS_MAX, (SEQ && !GLDS) ? 4 : (SEQ ? 5 : 3)) void k_rescore(PickArgs p, const double *__restrict__ Xp, int Sp) {
     const FinishArgs &a = p.f;
     extern __shared__ __attribute__((aligned(16))) double rs_dyn[];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t row = a.row_begin + blockIdx.x;
     // the row's state, its own values and the first trip's pairs are requested together: three
     // dependent round trips were a third of a row's life at 100 samples (the pair slots beyond the
@@ -1681,14 +1685,59 @@ __global__ __launch_bounds__(PS_MAX, SEQ ? 4 : 3) void k_rescore(PickArgs p, con
         int cj = trip == 0 ? cj_first : cjp[lane < nb ? lane : 0];
         if (trip == 0) cj = __shfl(cj, lane < nb ? lane : 0);   // lanes beyond nb take the trip's first candidate; their sums are dropped
         unsigned int src[NP];                            // byte offset of this lane's 16 bytes in chunk 0 of row r0 + 8 q
+        RowSum<SEQ> sum;
+        sum.init(a);
+        if constexpr (GLDS) {
+            // the slab as two halves of 64 rows x 64 B: samples 0-7 and 8-15 of the chunk.  A DMA instruction
+            // covers 16 rows (lane l: row 16 j + (l >> 2), slot l & 3, piece slot ^ ((row >> 2) & 3)); as soon as
+            // a half has been read into registers the same half of the NEXT chunk is requested, so the DMA runs
+            // under this chunk's arithmetic without a second slab (LDS per wave as in the register-staged form)
+            const int l4 = lane & 3, rq = lane >> 2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rw = 16 * j + rq;
+                src[j] = ((unsigned int)__shfl(cj, rw) * (unsigned int)Sp + 2u * (unsigned int)(l4 ^ ((rw >> 2) & 3))) * 8u;
+            }
+            int rd[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rd[q] = lane * 64 + ((q ^ ((lane >> 2) & 3)) << 4);
+            auto dma = [&](int c, int half) {
+                const char *cb = base + (size_t)c * (ST_CH * 8) + half * 64;
+                char *dst = slab + half * 4096;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    __builtin_amdgcn_global_load_lds((glb_void_t *)(cb + src[j]), (lds_void_t *)(dst + j * 1024), 16, 0, 0);
+            };
+            dma(0, 0);
+            dma(0, 1);
+            for (int c = 0; c < nchunk; ++c) {
+                __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0): both halves of chunk c have landed
+                __builtin_amdgcn_wave_barrier();
+                f64x2 t[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) t[q] = *(const f64x2 *)(slab + rd[q]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) t[4 + q] = *(const f64x2 *)(slab + 4096 + rd[q]);
+                __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0) only: the reads are in registers
+                __builtin_amdgcn_wave_barrier();
+                if (c + 1 < nchunk) { dma(c + 1, 0); dma(c + 1, 1); }
+                double v[ST_CH];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const f64x2 x2 = *(const f64x2 *)&xs[c * ST_CH + 2 * q];     // wave-uniform: a broadcast read
+                    const double d0 = t[q].x - x2.x, d1 = t[q].y - x2.y;
+                    v[2 * q] = d0 * d0;
+                    v[2 * q + 1] = d1 * d1;
+                }
+                sum.chunk_regs(a, v, (int64_t)c * ST_CH, (c + 1) * ST_CH <= a.S);
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < NP; ++q)
             src[q] = ((unsigned int)__shfl(cj, r0 + 8 * q) * (unsigned int)Sp + 2u * (unsigned int)l8) * 8u;
         f64x2 pre[NP];
 #pragma unroll
         for (int q = 0; q < NP; ++q) pre[q] = *(const f64x2 *)(base + src[q]);
-        RowSum<SEQ> sum;
-        sum.init(a);
         for (int c = 0; c < nchunk; ++c) {
             const f64x2 x2 = *(const f64x2 *)&xs[c * ST_CH + 2 * l8];
             wave_lds_fence();                            // the previous chunk's reads are done
@@ -1714,6 +1763,7 @@ __global__ __launch_bounds__(PS_MAX, SEQ ? 4 : 3) void k_rescore(PickArgs p, con
                 v[2 * q + 1] = t2.y;
             }
             sum.chunk_regs(a, v, (int64_t)c * ST_CH, (c + 1) * ST_CH <= a.S);
+        }
         }
         const double d = sum.result();
         const bool ok = lane < nb && d < SENTINEL_DISTANCE;  // NaN and >= 1e10 are never admitted (wisetools.py:314)
@@ -2488,13 +2538,23 @@ static int newref_finish_part(wc_ctx *ctx, void *stream_, int64_t row_begin, int
         const unsigned rows = (unsigned)(row_end - row_begin);
         if (which & 5) hipLaunchKernelGGL(k_pick, dim3((rows + 3) / 4), dim3(256), 0, stream, p);
         // wave slabs; after the sums the same memory holds dk / sd / jv / sj of the counting order
+        // chunk staging: LDS-DMA for the pairwise order (measured at 100 samples x 250 kb: 0.099 vs 0.131 ms; no
+        // staging registers -> no spills in that variant), registers for the sequential order (0.076 vs 0.083 ms:
+        // the DMA of the next chunk can only be issued after this chunk's LDS reads have returned);
+        // WC_RESCORE_STAGE=regs|glds forces one
+        const char *rs_env = getenv("WC_RESCORE_STAGE");
+        const bool glds = rs_env && strcmp(rs_env, "glds") == 0 ? true : (rs_env && strcmp(rs_env, "regs") == 0 ? false : !seq);
         const size_t slabs = sizeof(double) * (size_t)(ps / 64) * SLAB_DOUBLES;
         const size_t order = (sizeof(unsigned long long) + sizeof(int)) * (2 * RMAX + 4);
         const size_t dyn = sizeof(double) * st.s_pad + std::max(slabs, order);
         if (!(which & 9)) {
-        } else if (seq) hipLaunchKernelGGL((k_rescore<true>), dim3(rows), dim3(ps), dyn, stream, p,
-                                           (const double *)st.x64.as<double>(), (int)st.s_pad);
-        else hipLaunchKernelGGL((k_rescore<false>), dim3(rows), dim3(ps), dyn, stream, p,
+        } else if (seq && glds) hipLaunchKernelGGL((k_rescore<true, true>), dim3(rows), dim3(ps), dyn, stream, p,
+                                                   (const double *)st.x64.as<double>(), (int)st.s_pad);
+        else if (seq) hipLaunchKernelGGL((k_rescore<true, false>), dim3(rows), dim3(ps), dyn, stream, p,
+                                         (const double *)st.x64.as<double>(), (int)st.s_pad);
+        else if (glds) hipLaunchKernelGGL((k_rescore<false, true>), dim3(rows), dim3(ps), dyn, stream, p,
+                                          (const double *)st.x64.as<double>(), (int)st.s_pad);
+        else hipLaunchKernelGGL((k_rescore<false, false>), dim3(rows), dim3(ps), dyn, stream, p,
                                 (const double *)st.x64.as<double>(), (int)st.s_pad);
     } else if (which & 1) {
         const bool seq = st.sum_order == WC_SUM_SEQUENTIAL || st.n_samples < 8;
@@ -2611,7 +2671,7 @@ int wc_get_reference_dev(wc_ctx *ctx, void *stream_, const double *corrected, in
     if (want) {
         key = {(int64_t)(intptr_t)corrected, n_bins, n_samples, n_chrom, k, sum_order, row_begin, row_end,
                (int64_t)(intptr_t)idx_out, (int64_t)(intptr_t)dist_out, (int64_t)(intptr_t)stream_,
-               env_word("WC_GRAM_MODE"), env_word("WC_GRAM_DEPTH"), env_word("WC_GRAM_STAGE"), env_word("WC_FINISH_ENGINE"),
+               env_word("WC_GRAM_MODE"), env_word("WC_GRAM_DEPTH"), env_word("WC_GRAM_STAGE"), env_word("WC_RESCORE_STAGE"), env_word("WC_FINISH_ENGINE"),
                env_word("WC_FINISH_THREADS")};
         for (int c = 0; c < n_chrom; ++c) key.push_back(chrom_bins_host[c]);
     }
