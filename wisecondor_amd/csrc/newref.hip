@@ -36,6 +36,8 @@ constexpr int MAX_SAMPLE_COLS = 4096;
 constexpr int LIST_CAP = 1024;
 constexpr int K_MAX = 1024;       // largest refsize (the exact path's selection buffers); above LIST_CAP / 4 every row takes the exact path
 constexpr int FB_BLOCKS = 512;
+constexpr int GL_ROW = 16;            // LDS-DMA tile kernels: floats per LDS row (64 bytes = 32 float16)
+constexpr int GL_STAGE = 2 * TB * GL_ROW;   // floats per stage: A rows then B rows
 #define WC_ADMIT_ALL FLT_MAX
 constexpr double SENTINEL_DISTANCE = 1e10;  // wisetools.py:306
 
@@ -663,8 +665,6 @@ __global__ __launch_bounds__(256, DEPTH == 2 ? 3 : 4) void k_gram(GramArgs g) {
 // them: four workgroups per CU.  One barrier per slab: the barrier at the top of step s waits for slab s
 // (the compiler drains the DMA there) and tells everybody that slab s - 1's buffer may be refilled, the
 // DMA of slab s + 1 then runs under the MFMAs of slab s.
-constexpr int GL_ROW = 16;            // floats per LDS row (64 bytes = 32 float16)
-constexpr int GL_STAGE = 2 * TB * GL_ROW;   // floats per stage: A rows then B rows
 __global__ __launch_bounds__(256, 4) void k_gram_glds(GramArgs g) {
     __shared__ __attribute__((aligned(16))) float sm[128 * LDT + 256 + 4 * TB];   // dot tile + row masks + bounds / thresholds
     float *D = sm;
@@ -757,6 +757,63 @@ __global__ __launch_bounds__(256, 4) void k_gram_glds(GramArgs g) {
 // rate, ~0.4 % error on the dot products, i.e. a ~10 % wobble of the candidate count.
 // Same 128x128 tile / 4 waves / LDS byte layout as k_gram; a slab is 64 bf16 (128 B) deep.
 
+// epilogue of the threshold-estimate tiles: dot products -> 16-bit key codes of every (row, sampled column)
+__device__ __forceinline__ void thr_epilogue(float *D, const float *nbPs, const float *nbQs, f32x16 (&acc)[2][2],
+                                             const int2 *__restrict__ rangeQ, unsigned int *__restrict__ keys,
+                                             const int64_t ldo, const int I, const int J, const float m2, const int tid,
+                                             const int wr, const int wc, const int li, const int lh) {
+    const int cp = tid & 63, rq = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float nbc0 = nbQs[2 * cp], nbc1 = nbQs[2 * cp + 1];
+    const int2 rg0 = rangeQ[(int64_t)J * TB + 2 * cp], rg1 = rangeQ[(int64_t)J * TB + 2 * cp + 1];
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+        if (wr == h) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {    // column-major tile, 16-byte writes (see k_gram)
+                        const int row = m * 32 + 8 * r4 + 4 * lh;
+                        const int col = wc * 64 + n * 32 + li;
+                        f32x4 v4;
+                        v4[0] = acc[m][n][4 * r4]; v4[1] = acc[m][n][4 * r4 + 1];
+                        v4[2] = acc[m][n][4 * r4 + 2]; v4[3] = acc[m][n][4 * r4 + 3];
+                        *(f32x4 *)&D[col * LDT + row] = v4;
+                    }
+        }
+        __syncthreads();
+        // thread = column pair (2cp, 2cp+1) x 16 rows: one 32-bit store carries two 16-bit keys, a
+        // wave writes 256 contiguous bytes per row
+        const int base_row = I * TB + h * 64 + rq * 16;
+        float d0[16], d1[16];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 a4 = *(const f32x4 *)&D[(2 * cp) * LDT + rq * 16 + 4 * g4];
+            const f32x4 b4 = *(const f32x4 *)&D[(2 * cp + 1) * LDT + rq * 16 + 4 * g4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { d0[4 * g4 + e] = a4[e]; d1[4 * g4 + e] = b4[e]; }
+        }
+        const f32x4 *nbv = (const f32x4 *)&nbPs[h * 64 + rq * 16];
+        const unsigned int ex0 = run_mask(rg0.x - base_row, rg0.y - base_row);
+        const unsigned int ex1 = run_mask(rg1.x - base_row, rg1.y - base_row);
+        unsigned int *out = keys + (((int64_t)base_row * ldo + (int64_t)J * TB) >> 1) + cp;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 nb4 = nbv[g4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int rr = 4 * g4 + e;
+                unsigned int c0 = key_code16(fmaf(m2, d0[rr], nb4[e] + nbc0));
+                unsigned int c1 = key_code16(fmaf(m2, d1[rr], nb4[e] + nbc1));
+                if ((ex0 >> rr) & 1u) c0 = 0xFFFFu;     // same chromosome: never a candidate
+                if ((ex1 >> rr) & 1u) c1 = 0xFFFFu;
+                out[(int64_t)rr * (ldo >> 1)] = c0 | (c1 << 16);
+            }
+        }
+    }
+}
+
 template <bool F16>   // operands are float16 (scaled by gam, *m2 = -2 / gam^2) instead of bfloat16
 __global__ __launch_bounds__(256, 4) void k_gram_thr16(const unsigned short *__restrict__ P16,
                                                        const unsigned short *__restrict__ Q16, int64_t ld16,
@@ -842,57 +899,7 @@ __global__ __launch_bounds__(256, 4) void k_gram_thr16(const unsigned short *__r
             }
         }
     }
-    const float m2 = F16 ? *m2p : -2.f;
-    const int cp = tid & 63, rq = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const float nbc0 = nbQs[2 * cp], nbc1 = nbQs[2 * cp + 1];
-    const int2 rg0 = rangeQ[(int64_t)J * TB + 2 * cp], rg1 = rangeQ[(int64_t)J * TB + 2 * cp + 1];
-    for (int h = 0; h < 2; ++h) {
-        __syncthreads();
-        if (wr == h) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-#pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) {    // column-major tile, 16-byte writes (see k_gram)
-                        const int row = m * 32 + 8 * r4 + 4 * lh;
-                        const int col = wc * 64 + n * 32 + li;
-                        f32x4 v4;
-                        v4[0] = acc[m][n][4 * r4]; v4[1] = acc[m][n][4 * r4 + 1];
-                        v4[2] = acc[m][n][4 * r4 + 2]; v4[3] = acc[m][n][4 * r4 + 3];
-                        *(f32x4 *)&D[col * LDT + row] = v4;
-                    }
-        }
-        __syncthreads();
-        // thread = column pair (2cp, 2cp+1) x 16 rows: one 32-bit store carries two 16-bit keys, a
-        // wave writes 256 contiguous bytes per row
-        const int base_row = I * TB + h * 64 + rq * 16;
-        float d0[16], d1[16];
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const f32x4 a4 = *(const f32x4 *)&D[(2 * cp) * LDT + rq * 16 + 4 * g4];
-            const f32x4 b4 = *(const f32x4 *)&D[(2 * cp + 1) * LDT + rq * 16 + 4 * g4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { d0[4 * g4 + e] = a4[e]; d1[4 * g4 + e] = b4[e]; }
-        }
-        const f32x4 *nbv = (const f32x4 *)&nbPs[h * 64 + rq * 16];
-        const unsigned int ex0 = run_mask(rg0.x - base_row, rg0.y - base_row);
-        const unsigned int ex1 = run_mask(rg1.x - base_row, rg1.y - base_row);
-        unsigned int *out = keys + (((int64_t)base_row * ldo + (int64_t)J * TB) >> 1) + cp;
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const f32x4 nb4 = nbv[g4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int rr = 4 * g4 + e;
-                unsigned int c0 = key_code16(fmaf(m2, d0[rr], nb4[e] + nbc0));
-                unsigned int c1 = key_code16(fmaf(m2, d1[rr], nb4[e] + nbc1));
-                if ((ex0 >> rr) & 1u) c0 = 0xFFFFu;     // same chromosome: never a candidate
-                if ((ex1 >> rr) & 1u) c1 = 0xFFFFu;
-                out[(int64_t)rr * (ldo >> 1)] = c0 | (c1 << 16);
-            }
-        }
-    }
+    thr_epilogue(D, nbPs, nbQs, acc, rangeQ, keys, ldo, I, J, F16 ? *m2p : -2.f, tid, wr, wc, li, lh);
 }
 
 __device__ inline uint32_t umed3(uint32_t x, uint32_t y, uint32_t z) {   // v_med3_u32
@@ -2325,6 +2332,8 @@ int wc_newref_thresholds_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int6
                        (const float *)st.norm_lo.as<float>(), (const float *)st.s_norm_lo.as<float>(),             \
                        (const int2 *)st.s_range.as<int2>(), (const int4 *)st.tiles0.as<int4>(), ntiles,            \
                        st.keys1.as<unsigned int>(), st.n_sample_cols, (const float *)st.m2.as<float>())
+        // (LDS-DMA staging was tried here too: 0.554 vs 0.518 ms at 600 x 50 kb -- this kernel's time is its
+        // 472 MB of key-code stores, not its operand path)
         if (st.gram_mode == 2) WC_THR16(true);
         else WC_THR16(false);
 #undef WC_THR16

@@ -1121,6 +1121,7 @@ struct SdShared {
     double sh_p[1024];                    // scan of the threads' approximate sums
     long long sh_A[1024];
     int sh_H0[1024], sh_H1[1024], sh_flag[1024], sh_nb[1024], sh_cnt[1024];
+    int sh_e[1024];                       // binade every thread's own walk ENDS in (checked against its successor's start)
     long long b_A[SD_MAX_BOUND + 1];      // map of the segment that ENDS before boundary k (k = n: the tail)
     int b_H0[SD_MAX_BOUND + 1], b_H1[SD_MAX_BOUND + 1], b_e[SD_MAX_BOUND + 1];
     double b_x[SD_MAX_BOUND + 1];
@@ -1239,6 +1240,16 @@ __device__ inline void sd_fast_block(const int64_t i, SdShared *sm, const double
         before = after;
     });
     if (n_bound == 0) head = run;
+    // A thread's walk ends on its own sequentially rounded sum, its successor starts from the scan's value of
+    // the same prefix: different roundings.  If the two sit on opposite sides of a power of two, the junction
+    // is a binade boundary nobody recorded (the maps left and right of it assume different units): the serial
+    // kernel takes the sample.  (Practically unreachable -- the sum would have to sit within an ulp of 2^k.)
+    sm->sh_e[tid] = before > 0.0 ? sd_exponent(before) : -100000;
+    __syncthreads();
+    if (tid > 0) {
+        const double start = sh_p[tid - 1];
+        if ((start > 0.0 ? sd_exponent(start) : -100000) != sm->sh_e[tid - 1]) bad = true;
+    }
     // block-wide segmented scan over the threads: value = (flag: holds a boundary, map: its tail --
     // or its whole fold when it holds none)
     if (bad) s_bad = 1;
