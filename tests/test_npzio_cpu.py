@@ -187,3 +187,39 @@ def test_writer_matches_np_savez(tmp_path):
                 assert zf.testzip() is None
                 assert {m.compress_type for m in zf.infolist() if m.file_size > 64} == \
                     {zipfile.ZIP_DEFLATED if level else zipfile.ZIP_STORED}
+
+
+def test_parallel_savez_reads_back_like_numpys(tmp_path):
+    """wisecondor_amd.npzfast.savez: the .npz container with members deflated chunk-wise in threads
+    (sync-flushed chunks concatenated into one raw deflate stream) must read back through np.load
+    exactly like np.savez_compressed's file -- values, dtypes, shapes, memory order, pickled objects."""
+    from wisecondor_amd import npzfast
+    rng = np.random.RandomState(3)
+    big = rng.standard_normal((1100, 1000))                    # 8.8 MB: three chunks
+    fort = np.asfortranarray(rng.standard_normal((700, 90)))
+    arrays = dict(arguments={"infiles": ["a", "b"], "binsize": None, "refsize": 100}, runtime={"version": b"x"},
+                  binsize=250000.0, indexes=rng.randint(-1, 5000, size=(3000, 100)).astype(np.int32), distances=big,
+                  correctedData=fort, mask=rng.rand(5000) > 0.1, sums=[1, 2, 3], empty=np.zeros((0, 5)),
+                  ragged=np.array([np.arange(3.0), np.arange(5.0)], dtype=object))
+    ref = str(tmp_path / "numpy.npz")
+    np.savez_compressed(ref, **arrays)
+    want = np.load(ref, allow_pickle=True)
+    for level, threads in ((6, 4), (1, 1), (0, 2)):
+        path = npzfast.savez(str(tmp_path / ("fast_%d" % level)), level=level, threads=threads, **arrays)
+        assert path.endswith(".npz")
+        with zipfile.ZipFile(path) as zf:
+            assert zf.testzip() is None
+            assert [m.filename for m in zf.infolist()] == [k + ".npy" for k in arrays]
+        got = np.load(path, allow_pickle=True)
+        assert sorted(got.files) == sorted(want.files)
+        for key in want.files:
+            a, b = want[key], got[key]
+            assert a.dtype == b.dtype and a.shape == b.shape, key
+            assert a.flags["F_CONTIGUOUS"] == b.flags["F_CONTIGUOUS"] and a.flags["C_CONTIGUOUS"] == b.flags["C_CONTIGUOUS"], key
+            if a.dtype == object and a.shape == ():
+                assert a.item() == b.item(), key
+            elif a.dtype == object:
+                assert all(np.array_equal(p, q) for p, q in zip(a, b)), key
+            else:
+                assert np.array_equal(a, b), key
+    assert os.path.getsize(str(tmp_path / "fast_6.npz")) < 1.02 * os.path.getsize(ref)

@@ -30,13 +30,18 @@ _STARTED = datetime.datetime.now()
 
 
 # ------------------------------------------------------------------ provenance ----
+_VERSION_TAG = []
+
+
 def getRuntime():
     """The `runtime` member of every output file: version, datetime, hostname, username
-    (upstream wisetools.py:47-62)."""
-    try:
-        tag = subprocess.check_output(["git", "describe", "--always"], stderr=subprocess.DEVNULL).split()[0]
-    except Exception:
-        tag = 'unknown'
+    (upstream wisetools.py:47-62).  `git describe` runs once per process."""
+    if not _VERSION_TAG:
+        try:
+            _VERSION_TAG.append(subprocess.check_output(["git", "describe", "--always"], stderr=subprocess.DEVNULL).split()[0])
+        except Exception:
+            _VERSION_TAG.append('unknown')
+    tag = _VERSION_TAG[0]
     return {'version': tag, 'datetime': _STARTED, 'hostname': socket.gethostname(),
             'username': getpass.getuser()}
 
@@ -107,15 +112,26 @@ def _rank_count(args):
     return int(want)
 
 
-def save_part(part_base, number, parts, indexes, distances, args):
+def write_npz(path, temporary=False, **arrays):
+    """The .npz files of this tool (np.load reads them like np.savez_compressed's, which the
+    reference uses: wisecondor.py:97-108, 128-132, 160-170).  Once the GPU part takes
+    milliseconds the sub-commands' wall time is zlib (1.7 of 1.8 s of `newref` at 100 x 250 kb),
+    so members are deflated at level 1 in threads (wisecondor_amd/npzfast.py; WC_NPZ_LEVEL=6 for
+    numpy's own level) and the prep / part files `newref` deletes again at its end are stored."""
+    from . import npzfast
+    level = 0 if temporary else int(os.environ.get('WC_NPZ_LEVEL', '1'))
+    npzfast.savez(path, level=level, threads=min(16, os.cpu_count() or 1), **arrays)
+
+
+def save_part(part_base, number, parts, indexes, distances, args, temporary=False):
     """One part file exactly as `newrefpart` writes it (keys of SURVEY.md App. B)."""
     stamped = copy.copy(args)
     stamped.part = [number, parts]
-    np.savez_compressed(BuildFiles.part_name(part_base, number),
-                        arguments=vars(stamped),
-                        runtime=getRuntime(),
-                        indexes=indexes,
-                        distances=distances)
+    write_npz(BuildFiles.part_name(part_base, number), temporary,
+              arguments=vars(stamped),
+              runtime=getRuntime(),
+              indexes=indexes,
+              distances=distances)
 
 
 def select_all_rows(prepfile, refsize, device=0, rank=0, world=1):
@@ -126,8 +142,8 @@ def select_all_rows(prepfile, refsize, device=0, rank=0, world=1):
     import torch
     from . import _lib
     from .distributed import NewrefJob
-    prep = _open_npz(prepfile)
-    corrected = prep['correctedData']
+    prep = prepfile if isinstance(prepfile, dict) else _open_npz(prepfile)
+    corrected = np.asarray(prep['correctedData'])
     bins = np.ascontiguousarray(prep['maskedChromBins'], dtype=np.int64)
     order = wt.sum_order_of(corrected)
     dev = torch.device('cuda', device)
@@ -140,10 +156,12 @@ def select_all_rows(prepfile, refsize, device=0, rank=0, world=1):
 
 
 # --------------------------------------------------------------- newref: tools ----
-def toolNewrefPrep(args):
+def toolNewrefPrep(args, temporary=False):
     """`newrefprep`: sample files -> prep file (normalise, mask all-zero bins, PCA-correct).
 
-    File contract of upstream wisecondor.py:72-108; the arithmetic is wt.prepReference (GPU)."""
+    File contract of upstream wisecondor.py:72-108; the arithmetic is wt.prepReference (GPU).
+    Returns what it wrote (for `newref`, which goes on with the arrays instead of reading the
+    file back)."""
     from . import ingest
     loaded = ingest.load_samples(args.infiles, args.binsize, verbose=True)
     if args.binsize is None and len(loaded.binsizes) > 1:
@@ -157,18 +175,19 @@ def toolNewrefPrep(args):
     print('Zero mask on the GPU: %d bins x %d samples -> %d bins kept, 3 PCA components removed'
           % (len(mask), n_given, masked.shape[0]))
     running = np.cumsum(masked_bins)
-    np.savez_compressed(args.prepfile,
-                        arguments=vars(args),
-                        runtime=getRuntime(),
-                        binsize=binsize,
-                        chromosomeBins=chrom_bins,
-                        maskedData=masked,
-                        mask=mask,
-                        maskedChromBins=masked_bins,
-                        maskedChromBinSums=[int(v) for v in running],
-                        correctedData=corrected,
-                        pca_components=components,
-                        pca_mean=mean)
+    stored = dict(arguments=vars(args),
+                  runtime=getRuntime(),
+                  binsize=binsize,
+                  chromosomeBins=chrom_bins,
+                  maskedData=masked,
+                  mask=mask,
+                  maskedChromBins=masked_bins,
+                  maskedChromBinSums=[int(v) for v in running],
+                  correctedData=corrected,
+                  pca_components=components,
+                  pca_mean=mean)
+    write_npz(args.prepfile, temporary, **stored)
+    return stored
 
 
 def toolNewrefPart(args):
@@ -202,17 +221,17 @@ def toolNewrefPost(args):
     width = max(b.shape[1] for b in idx_blocks if b.ndim == 2) if any(b.ndim == 2 for b in idx_blocks) else 0
     idx_blocks = [b.reshape(-1, width) for b in idx_blocks]
     dst_blocks = [b.reshape(-1, width) for b in dst_blocks]
-    np.savez_compressed(args.outfile,
-                        arguments=vars(args),
-                        runtime=getRuntime(),
-                        binsize=prep['binsize'].item(),
-                        indexes=np.concatenate(idx_blocks, axis=0),
-                        distances=np.concatenate(dst_blocks, axis=0),
-                        chromosome_sizes=prep['chromosomeBins'],
-                        mask=prep['mask'],
-                        masked_sizes=prep['maskedChromBins'],
-                        pca_components=prep['pca_components'],
-                        pca_mean=prep['pca_mean'])
+    write_npz(args.outfile,
+              arguments=vars(args),
+              runtime=getRuntime(),
+              binsize=prep['binsize'].item(),
+              indexes=np.concatenate(idx_blocks, axis=0),
+              distances=np.concatenate(dst_blocks, axis=0),
+              chromosome_sizes=prep['chromosomeBins'],
+              mask=prep['mask'],
+              masked_sizes=prep['maskedChromBins'],
+              pca_components=prep['pca_components'],
+              pca_mean=prep['pca_mean'])
 
 
 def toolNewref(args):
@@ -232,15 +251,16 @@ def toolNewref(args):
                               parts=args.parts, refsize=args.refsize, infiles=list(args.infiles),
                               binsize=args.binsize, arguments=_plain_arguments(args)))
     else:
+        prep = None
         if not os.path.isfile(args.prepfile):
-            toolNewrefPrep(args)
+            prep = toolNewrefPrep(args, temporary=True)        # (the file is for a resumed run; this one keeps the arrays)
         if todo:
             began = time.time()
-            indexes, distances, _ = select_all_rows(args.prepfile, args.refsize)
+            indexes, distances, _ = select_all_rows(prep if prep is not None else args.prepfile, args.refsize)
             print('reference bins for %d rows in %.2f s' % (indexes.shape[0], time.time() - began))
             for number in todo:
                 lo, hi = wt.getPart(number - 1, args.parts, indexes.shape[0])
-                save_part(args.partfile, number, args.parts, indexes[lo:hi], distances[lo:hi], args)
+                save_part(args.partfile, number, args.parts, indexes[lo:hi], distances[lo:hi], args, temporary=True)
     toolNewrefPost(args)
     os.remove(args.prepfile)
     for number in range(1, args.parts + 1):
@@ -268,17 +288,17 @@ def writeTestOutput(outfile, args, binsize, result, z_threshold):
     calls = np.asarray(result['results_calls'])
     if calls.size == 0:
         calls = np.array([])
-    np.savez_compressed(outfile,
-                        arguments=vars(args),
-                        runtime=getRuntime(),
-                        binsize=binsize,
-                        results_r=_as_object_array(result['results_r']),
-                        results_z=_as_object_array(result['results_z']),
-                        results_cwz=result['results_cwz'],
-                        results_calls=calls,
-                        threshold_z=z_threshold,
-                        asdef=result['asdef'],
-                        aasdef=result['asdef'] * z_threshold)
+    write_npz(outfile,
+              arguments=vars(args),
+              runtime=getRuntime(),
+              binsize=binsize,
+              results_r=_as_object_array(result['results_r']),
+              results_z=_as_object_array(result['results_z']),
+              results_cwz=result['results_cwz'],
+              results_calls=calls,
+              threshold_z=z_threshold,
+              asdef=result['asdef'],
+              aasdef=result['asdef'] * z_threshold)
 
 
 def _reference_and_threshold(args, device=0):
