@@ -165,3 +165,57 @@ def test_eight_ranks_on_one_gpu(tmp_path, mode, xcap):
         with np.errstate(all="ignore"):
             wi, wd = wo.get_ref_for_bins(k, int(r), int(r) + 1, F, others)
         assert np.array_equal(idx1[r], wi[0]) and np.array_equal(dst1[r], wd[0]), r
+
+
+def _worker_rccl(rank, world, port, path_in, out_dir):
+    import torch
+    import torch.distributed as dist
+    from wisecondor_amd import _lib
+    from wisecondor_amd.distributed import NewrefJob
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        z = np.load(path_in)
+        X = torch.from_numpy(np.ascontiguousarray(z["data"])).cuda()
+        out = {}
+        for mode in ("tiles", "rows", None):
+            job = NewrefJob(_lib.context(0), X, z["bins"], int(z["k"]), int(z["order"]), rank=rank, world=world, dist=dist,
+                            mode=mode, passes=3, collectives=True)
+            for _ in range(2):
+                idx, dst = job.run()
+            torch.cuda.synchronize()
+            out["idx_%s" % mode] = idx.cpu().numpy()
+            out["dst_%s" % mode] = dst.cpu().numpy()
+            out["mode_%s" % mode] = job.mode
+        np.savez(os.path.join(out_dir, "rccl.npz"), **out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_collectives_in_a_world_of_one(tmp_path):
+    """The RCCL calls themselves (backend "nccl"): the box has one GPU, so the world has one rank, but the job
+    takes the multi-rank route -- threshold all-gather on a float view, the list all-to-all and the in-place
+    result all-gather on BYTE views, the MAX / MIN all-reduces of the calibration on device tensors -- exactly
+    the calls and dtypes the 8-GPU run makes.  Results equal the plain single-rank pass bit for bit."""
+    import torch
+    import torch.multiprocessing as mp
+    from wisecondor_amd import _lib, synth
+    from wisecondor_amd.distributed import NewrefJob
+    data, bins, sums = synth.corrected_matrix(1000000, 40, seed=21)
+    data[7] = data[1500]
+    path_in = str(tmp_path / "in.npz")
+    np.savez(path_in, data=data, bins=bins, k=100, order=1)
+    mp.get_context("spawn")
+    mp.spawn(_worker_rccl, args=(1, _free_port(), path_in, str(tmp_path)), nprocs=1, join=True)
+    got = np.load(str(tmp_path / "rccl.npz"), allow_pickle=True)
+    one = NewrefJob(_lib.context(0), torch.from_numpy(data).cuda(), bins, 100, 1)
+    idx1, dst1 = one.run()
+    torch.cuda.synchronize()
+    idx1, dst1 = idx1.cpu().numpy(), dst1.cpu().numpy()
+    for mode in ("tiles", "rows", "None"):
+        assert np.array_equal(got["idx_%s" % mode], idx1), mode
+        assert np.array_equal(got["dst_%s" % mode].view(np.int64), dst1.view(np.int64)), mode
+    assert str(got["mode_None"]) in ("tiles", "rows")          # the calibration ran over RCCL and decided

@@ -154,18 +154,21 @@ class NewrefJob(object):
     output)."""
 
     def __init__(self, ctx, X, chrom_bins, k, sum_order, rank=0, world=1, stages=None, dist=None, mode=None,
-                 passes=1):
+                 passes=1, collectives=False):
         """`passes`: how many times the caller expects to run() this job.  The shard mode of a
         multi-rank job is measured (calibrate: four extra passes) only from CALIBRATE_FROM_PASSES
         on or with WC_NEWREF_SHARD=measure; a one-shot job (the CLI) takes the symmetric tile shard."""
         import torch
         self.passes = int(passes)
+        # collectives=True: take the multi-rank route (exchange buffers, every collective) even in a world of
+        # one rank -- a one-GPU box can then run the RCCL calls themselves (tests/test_distributed_gpu.py)
+        self.single = int(world) == 1 and not collectives
         self.torch = torch
         self.rank, self.world = int(rank), int(world)
         self.st = stages if stages is not None else HipStages(ctx, X, chrom_bins, k, sum_order)
         self.k = int(k)
         self.n_bins = int(self.st.n_bins)
-        if dist is None and self.world > 1:
+        if dist is None and not self.single:
             import torch.distributed as dist
         self.dist = dist
         self.mode = mode            # None: measured at the first run (calibrate), unless WC_NEWREF_SHARD pins it
@@ -178,7 +181,7 @@ class NewrefJob(object):
         self.max_rows = max(e - b for b, e in self.ranges)
         t = torch
         e = self.st.empty
-        if self.world == 1:
+        if self.single:
             self.idx = e((self.n_bins, self.k), t.int32)
             self.dst = e((self.n_bins, self.k), t.float64)
         else:
@@ -330,13 +333,13 @@ class NewrefJob(object):
 
     def _run(self):
         st = self.st
-        if self.world == 1 and self._marks is None and hasattr(st, "full_pass"):
+        if self.single and self._marks is None and hasattr(st, "full_pass"):
             st.full_pass(self.idx, self.dst)
             return self.idx, self.dst
         self._mark("start")
         self._local(st.prepare)
         self._mark("prepared")
-        if self.world == 1:
+        if self.single:
             st.thresholds(0, self.n_bins)
             self._mark("thresholds")
             st.collect(0, self.n_bins, 0, 1)
