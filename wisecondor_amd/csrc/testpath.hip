@@ -3408,6 +3408,22 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
     return WC_OK;
 }
 
+// Output-only work of a batch (stdDevAvg, the inflated result arrays, the whole-region values) runs on the
+// context's side stream under the segmentation: side_begin makes the side stream wait for what `stream` has
+// enqueued so far, side_end marks the point join_side waits for.
+static int side_begin(wc_ctx *ctx, hipStream_t stream) {
+    int rc;
+    if ((rc = ctx->ensure_side_stream())) return rc;
+    WC_HIP(hipEventRecord(ctx->ev_fork, stream));
+    WC_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+    return WC_OK;
+}
+static int side_end(wc_ctx *ctx) {
+    WC_HIP(hipEventRecord(ctx->ev_join, ctx->side));
+    ctx->side_pending = true;
+    return WC_OK;
+}
+
 // Make `stream` wait for the side-stream work of run_repeat (before sd_avg is consumed).
 int join_side(wc_ctx *ctx, hipStream_t stream) {
     if (ctx->side_pending) {
@@ -3435,6 +3451,7 @@ struct TreeTail {
     const int *gpos;         // genomic position of every kept bin
     double *reg_calls;       // [n_regions, max_calls, 5]
     bool defer_status;       // the caller reads the tree kernel's status words after its own synchronize
+    double *cwz_out;         // where the whole-region values go besides ts.whole (written on the side stream), or NULL
 };
 // Batches whose regions fit the fused set-up kernel (<= TREE_MAXLEN bins, no -mineffectsize mask): cleaning,
 // prefix sums, whole-region values and the root jobs in ONE launch (k_lat_setup<256>) instead of k_clean +
@@ -3567,8 +3584,18 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
                            (const double *)ts.prefix.as<double>(), total, ts.tmin.as<double>(), ts.tmax.as<double>());
     }
     if (!fused) {
-        hipLaunchKernelGGL(k_region_whole, dim3((unsigned)cdiv(n_regions, 4)), dim3(256), 0, stream, z_dev, regions_dev,
-                           n_regions, bits, bit_off, ts.whole.as<double>(), whole_copy);
+        // batch path: the whole-region values are an output only -> side stream (one wave per region walks
+        // the region in numpy's order: 0.1 ms at 50 kb that the search does not have to wait for)
+        hipStream_t ws = stream;
+        double *wcopy = whole_copy;
+        if (tail && tail->cwz_out && !bits) {
+            if ((rc = side_begin(ctx, stream))) return rc;
+            ws = ctx->side;
+            wcopy = tail->cwz_out;
+        }
+        hipLaunchKernelGGL(k_region_whole, dim3((unsigned)cdiv(n_regions, 4)), dim3(256), 0, ws, z_dev, regions_dev,
+                           n_regions, bits, bit_off, ts.whole.as<double>(), wcopy);
+        if (ws != stream && (rc = side_end(ctx))) return rc;
         hipLaunchKernelGGL(k_init_jobs, dim3((unsigned)cdiv(n_regions, 256)), dim3(256), 0, stream, regions_dev, n_regions,
                            ts.jobs_a.as<Job>(), counters);
     }
@@ -4163,8 +4190,15 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
     const bool ride = lat && n_sel > 0 && calls && n_calls && (ride_mask & 2);
     if ((results_z || results_r) && !ride_inf) {
         dim3 g((unsigned)cdiv(ref->Btot, 256), (unsigned)Ns);
-        hipLaunchKernelGGL(k_inflate, g, dim3(256), 0, stream, zsrc, rsrc, nsrc, B, ref->Btot,
+        // a batch: the inflated outputs feed nothing downstream -> side stream, under the segmentation
+        hipStream_t is = stream;
+        if (!lat && Ns > 8) {
+            if ((rc = side_begin(ctx, stream))) return rc;
+            is = ctx->side;
+        }
+        hipLaunchKernelGGL(k_inflate, g, dim3(256), 0, is, zsrc, rsrc, nsrc, B, ref->Btot,
                            (const int *)ref->g2m.as<int>(), (double)min_ref_bins, results_z, results_r, str_i, str_b);
+        if (is != stream && (rc = side_end(ctx))) return rc;
     }
     if (n_sel == 0) {      // nothing to segment: no calls (otherwise k_assemble_calls writes every n_calls)
         if (n_calls) WC_HIP(hipMemsetAsync(n_calls, 0, sizeof(int) * Ns, stream));
@@ -4225,11 +4259,12 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
                 bits_upper += Ns * (n * (n + 1) / 2);
             }
         ts.mark(3, stream);
-        const TreeTail tail{ts.rc.as<double>(), ts.gpos.as<int>(), ts.effect.as<double>(), calls && n_calls && !ts.profile};
+        const TreeTail tail{ts.rc.as<double>(), ts.gpos.as<int>(), ts.effect.as<double>(), calls && n_calls && !ts.profile,
+                            (!fuse && min_effect == 0.0) ? results_cwz : nullptr};
         const FusedSetup fsu{zsrc, rsrc, nsrc, str_i, str_b, B, ref->moff_dev.as<int64_t>(), ref->goff_dev.as<int64_t>(),
                              ref->m2g.as<int>(), ts.sel.as<int>(), n_sel, (double)min_ref_bins, ts.zc.as<double>(),
                              ts.rc.as<double>(), ts.gpos.as<int>(), ts.regions.as<Region>(), results_cwz};
-        cwz_done = fuse && results_cwz;
+        cwz_done = results_cwz && (fuse || (min_effect == 0.0 && calls && n_calls));
         if ((rc = run_stouffer(ctx, ts.zc.as<double>(), ts.regions.as<Region>(), n_regions, Ns * B, max_n, threshold, 3,
                                max_calls, stream, ts.rc.as<double>(), min_effect, bits_upper, 0, nullptr,
                                calls && n_calls ? &tail : nullptr, fuse ? &fsu : nullptr)))
