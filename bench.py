@@ -628,6 +628,28 @@ def main():
                "kernel_source": None if not lat_kernels else lat_kernels.get("source"),
                "frac_of_call_in_launch_floor": float(floor[0]) * 1e-3 / single_ms}
     test_roof = test_roofline(prof, n_refs, windows, args.test_samples, 1e3 * t_test / test_steps)
+    # the north-star's whole `test` job (1000 samples at this bin size) in ONE call on this GPU: the per-batch
+    # fixed costs (a few dozen small launches, one synchronize) spread over eight times the samples
+    whole_job = None
+    if world == 1 and not args.no_extra:
+        try:
+            reps = (1000 + counts_h.shape[0] - 1) // counts_h.shape[0]
+            big = torch.from_numpy(np.tile(counts_h, (reps, 1))[:1000].copy()).to(dev)
+            tbw = distributed.TestBatch(reference, big, thr, max_calls=256)
+            for _ in range(2):
+                tbw.run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                tbw.run()
+            torch.cuda.synchronize()
+            tw = (time.perf_counter() - t0) / 3
+            whole_job = {"what": "1000 samples x %d kb in one wc_test_batch_dev call (the batch's %d samples repeated)"
+                                 % (binsize // 1000, counts_h.shape[0]),
+                         "samples": 1000, "ms_per_call": 1e3 * tw, "samples_per_s": 1000 / tw}
+            del tbw, big
+        except Exception as exc:
+            whole_job = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
     # ------------------------------------------- extra: newref at 600 x 50 kb ----
     # BASELINE.json config 4 (the at-scale shape), kernel-level synthetic matrix; reported
@@ -917,7 +939,8 @@ def main():
                      "ms": inp.get("prep_ms")},
             "test": {"metric": "test samples/sec", "value": samples_per_s, "unit": "samples/s",
                      "ms_per_batch": 1e3 * t_test / test_steps, "samples_per_gpu": args.test_samples,
-                     "single_sample_latency_ms": single_ms, "latency": latency, "roofline": test_roof,
+                     "single_sample_latency_ms": single_ms, "latency": latency, "whole_job_1000_samples": whole_job,
+                     "roofline": test_roof,
                      "calls_found": n_calls},
             "roofline": dominant,
             "roofline_other": other,
