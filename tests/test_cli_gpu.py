@@ -256,6 +256,7 @@ def test_bench_line_is_complete_on_one_gpu():
     test = line["test"]
     assert test["value"] > 0 and 0 < test["roofline"]["frac"] <= 1.0
     assert test["single_sample_latency_ms"] < test["ms_per_batch"]
+    assert test["whole_job_1000_samples"]["samples_per_s"] > test["value"] * 0.8       # the big call amortises the fixed costs
     assert set(line["stages_ms"]) >= {"start->prepared", "prepared->thresholds", "thresholds->collected",
                                       "collected->picked", "picked->rescored", "rescored->finished"}
     assert "error" not in extra.get("ingest", {}), extra.get("ingest")
