@@ -241,9 +241,13 @@ class NewrefJob(object):
 
     def _gather_results(self):
         self._all_gather(self.res_all.view(-1), self.res_all[self.rank])
-        idx = self.torch.cat([self.idx_all[r][:e - b] for r, (b, e) in enumerate(self.ranges)])
-        dst = self.torch.cat([self.dst_all[r][:e - b] for r, (b, e) in enumerate(self.ranges)])
-        return idx, dst
+        # the ranks' slots (padded to the longest row band) into the [bins, k] result, buffers kept across passes
+        if getattr(self, "idx_full", None) is None:
+            self.idx_full = self.st.empty((self.n_bins, self.k), self.torch.int32)
+            self.dst_full = self.st.empty((self.n_bins, self.k), self.torch.float64)
+        self.torch.cat([self.idx_all[r][:e - b] for r, (b, e) in enumerate(self.ranges)], out=self.idx_full)
+        self.torch.cat([self.dst_all[r][:e - b] for r, (b, e) in enumerate(self.ranges)], out=self.dst_full)
+        return self.idx_full, self.dst_full
 
     def calibrate(self):
         """Pick the shard mode by measurement: one warm-up and one timed pass of each mode on
