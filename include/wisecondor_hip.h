@@ -161,6 +161,11 @@ int wc_launch_floor_us(wc_ctx *ctx, void *stream, int n, int reps, double *out);
 #define WC_NPZ_BINSIZE 3       /* the file's bin size cannot be scaled to to_binsize */
 int wc_read_samples(const char *const *paths, int n_files, int n_threads, const int64_t *chrom_sizes, int n_chrom,
                     double to_binsize, int32_t *counts_out, int64_t row_stride, double *binsize_out, int *status);
+/* chromosome lengths of every file at to_binsize (int64 [n_files, n_chrom]) and its own bin size: what
+ * `newref`'s toNumpyArray needs to size the dense matrix (per-chromosome maximum over the samples,
+ * wisetools.py:243-250) before wc_read_samples fills it */
+int wc_read_sample_lengths(const char *const *paths, int n_files, int n_threads, int n_chrom, double to_binsize,
+                           int64_t *lengths_out, double *binsize_out, int *status);
 int wc_write_test_results(int n_files, int n_threads, const char *const *out_paths,
                           const unsigned char *const *args_npy, const int64_t *args_len,
                           const unsigned char *runtime_npy, int64_t runtime_len, double binsize, double threshold_z,

@@ -223,3 +223,28 @@ def test_parallel_savez_reads_back_like_numpys(tmp_path):
             else:
                 assert np.array_equal(a, b), key
     assert os.path.getsize(str(tmp_path / "fast_6.npz")) < 1.02 * os.path.getsize(ref)
+
+
+def test_load_counts_equals_the_python_sample_load(tmp_path):
+    """ingest.load_counts (`newref`'s sample load: native lengths pass + native rows pass) against
+    load_samples + samples_to_counts, ragged chromosome lengths, merged bins, one file the native reader
+    passes on."""
+    sizes = [20 + c for c in range(22)]
+    paths = []
+    for i in range(5):
+        lengths = [5 * n - (i % 3) * (c % 2) for c, n in enumerate(sizes)] + [33, 8]
+        p = str(tmp_path / ("s%d.npz" % i))
+        np.savez_compressed(p, arguments={"binsize": 50000.0}, runtime={}, sample=_sample(40 + i, lengths), quality={})
+        paths.append(p)
+    odd = {k: v.astype(np.float32) for k, v in _sample(99, [5 * n for n in sizes] + [5, 5]).items()}
+    odd["3"] = odd["3"].astype(np.float16)                                       # -> WC_NPZ_UNSUPPORTED -> np.load
+    p = str(tmp_path / "odd.npz")
+    np.savez_compressed(p, arguments={"binsize": 50000.0}, runtime={}, sample=odd, quality={})
+    paths.append(p)
+    for to_binsize in (250000.0, None):
+        loaded = ingest.load_samples(paths, to_binsize, threads=2)
+        chrom_bins = [max(len(s[str(c)]) for s in loaded.samples) for c in range(1, 23)]
+        want = wt.samples_to_counts(loaded.samples, chrom_bins)
+        counts, bins, binsizes = ingest.load_counts(paths, to_binsize, threads=3)
+        assert bins == chrom_bins and binsizes == {50000.0}
+        assert np.array_equal(counts, want)

@@ -395,6 +395,42 @@ int read_one(const char *path, const int64_t *chrom_sizes, int n_chrom, double t
     return WC_OK;
 }
 
+// chromosome lengths of one sample file (what toNumpyArray needs before it can size the dense matrix:
+// the reference takes the per-chromosome maximum over the samples, wisetools.py:243-250)
+int lengths_one(const char *path, int n_chrom, double to_binsize, int64_t *len_out, double *binsize_out) {
+    std::string buf;
+    if (!read_file(path, buf)) return WC_NPZ_IO;
+    std::vector<ZipEntry> dir;
+    if (!zip_directory(buf, dir)) return WC_NPZ_UNSUPPORTED;
+    const ZipEntry *zs = nullptr, *za = nullptr;
+    for (const ZipEntry &z : dir) {
+        if (z.name == "sample.npy") zs = &z;
+        if (z.name == "arguments.npy") za = &z;
+    }
+    if (!zs || !za) return WC_NPZ_UNSUPPORTED;
+    std::string m;
+    VP args, sample;
+    if (!zip_member(buf, *za, m) || !npy_object_dict(m, args)) return WC_NPZ_UNSUPPORTED;
+    if (!zip_member(buf, *zs, m) || !npy_object_dict(m, sample)) return WC_NPZ_UNSUPPORTED;
+    VP bs = dict_get(args, "binsize");
+    if (!bs || (bs->kind != Val::FLOAT && bs->kind != Val::INT)) return WC_NPZ_UNSUPPORTED;
+    const double own = bs->kind == Val::FLOAT ? bs->f : (double)bs->i;
+    *binsize_out = own;
+    int64_t scale = 1;
+    if (to_binsize > 0 && own != to_binsize) {
+        if (own <= 0 || to_binsize < own || std::fmod(to_binsize, own) != 0.0) return WC_NPZ_BINSIZE;
+        scale = (int64_t)(to_binsize / own);
+    }
+    for (int c = 0; c < n_chrom; ++c) {
+        char key[16];
+        snprintf(key, sizeof(key), "%d", c + 1);
+        VP a = dict_get(sample, key);
+        if (!a || a->kind != Val::NDARRAY || a->shape.size() != 1) return WC_NPZ_UNSUPPORTED;
+        len_out[c] = (a->shape[0] + scale - 1) / scale;       // scaleSample: ceil(len / scale) merged bins
+    }
+    return WC_OK;
+}
+
 // --------------------------------------------------------------- writer ----
 void put16(std::string &s, uint16_t v) { s.push_back((char)(v & 0xFF)); s.push_back((char)(v >> 8)); }
 void put32(std::string &s, uint32_t v) { for (int k = 0; k < 4; ++k) s.push_back((char)((v >> (8 * k)) & 0xFF)); }
@@ -562,6 +598,22 @@ int wc_read_samples(const char *const *paths, int n_files, int n_threads, const 
         int rc;
         try {
             rc = read_one(paths[i], chrom_sizes, n_chrom, to_binsize, counts_out + (int64_t)i * row_stride, &binsize_out[i]);
+        } catch (...) {
+            rc = WC_NPZ_UNSUPPORTED;
+        }
+        status[i] = rc;
+    });
+    return WC_OK;
+}
+
+int wc_read_sample_lengths(const char *const *paths, int n_files, int n_threads, int n_chrom, double to_binsize,
+                           int64_t *lengths_out, double *binsize_out, int *status) {
+    if (!paths || n_files < 0 || n_chrom <= 0 || !lengths_out || !binsize_out || !status) return WC_E_ARG;
+    run_pool(n_files, n_threads, [&](int i) {
+        binsize_out[i] = 0.0;
+        int rc;
+        try {
+            rc = lengths_one(paths[i], n_chrom, to_binsize, lengths_out + (int64_t)i * n_chrom, &binsize_out[i]);
         } catch (...) {
             rc = WC_NPZ_UNSUPPORTED;
         }

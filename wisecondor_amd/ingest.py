@@ -82,6 +82,33 @@ def read_counts(paths, chrom_sizes, to_binsize, out_rows, threads=8, fallbacks=N
     return own
 
 
+def load_counts(paths, to_binsize=None, threads=8, verbose=False):
+    """`newref`'s sample load as one dense matrix: (counts int32 [files, sum(chrom_bins)], chrom_bins[22],
+    the set of the files' own bin sizes).  chrom_bins is the per-chromosome maximum over the samples
+    (toNumpyArray, wisetools.py:243-250); two native passes over the files (lengths, then rows), np.load
+    for any file the native reader passes on."""
+    began = time.time()
+    n = len(paths)
+    lens = np.zeros((n, 22), dtype=np.int64)
+    own = np.zeros(n, dtype=np.float64)
+    status = np.zeros(n, dtype=np.int32)
+    if n:
+        _lib.check(_lib.load().wc_read_sample_lengths(_c_strings(paths), n, int(threads), 22, float(to_binsize or 0.0),
+                                                      _lib.ptr(lens), _lib.ptr(own), _lib.ptr(status)))
+    for i in np.nonzero(status)[0]:
+        sample, size = read_sample(paths[i], to_binsize)
+        lens[i] = [len(sample[str(c)]) for c in range(1, 23)]
+        own[i] = size
+    chrom_bins = [int(v) for v in lens.max(axis=0)] if n else [0] * 22
+    counts = np.zeros((n, int(sum(chrom_bins))), dtype=np.int32)
+    read_counts(paths, chrom_bins, to_binsize, counts, threads=threads)
+    if verbose:
+        for path, size in zip(paths, own):
+            print('read %s (binsize %d)' % (path, int(size)))
+        print('%d sample files in %.2f s' % (n, time.time() - began))
+    return counts, chrom_bins, set(float(v) for v in own)
+
+
 def _object_npy(obj):
     """Bytes of the .npy member np.savez writes for a Python object (a 0-d object array)."""
     header = b"{'descr': '|O', 'fortran_order': False, 'shape': (), }"

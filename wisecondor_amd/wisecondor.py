@@ -163,15 +163,17 @@ def toolNewrefPrep(args, temporary=False):
     Returns what it wrote (for `newref`, which goes on with the arrays instead of reading the
     file back)."""
     from . import ingest
-    loaded = ingest.load_samples(args.infiles, args.binsize, verbose=True)
-    if args.binsize is None and len(loaded.binsizes) > 1:
-        print('ERROR: the input samples were binned at different sizes:', sorted(loaded.binsizes))
+    counts, chrom_bins_in, binsizes = ingest.load_counts(args.infiles, args.binsize, threads=min(16, os.cpu_count() or 1),
+                                                         verbose=True)
+    if args.binsize is None and len(binsizes) > 1:
+        print('ERROR: the input samples were binned at different sizes:', sorted(binsizes))
         print('Drop the odd ones or give -binsize to merge them to a common size')
         sys.exit(1)
-    binsize = args.binsize if args.binsize is not None else next(iter(loaded.binsizes))
+    binsize = args.binsize if args.binsize is not None else next(iter(binsizes))
 
-    n_given = len(loaded.samples)
-    masked, chrom_bins, mask, corrected, components, mean, masked_bins = wt.prepReference(loaded.samples)
+    n_given = counts.shape[0]
+    masked, chrom_bins, mask, corrected, components, mean, masked_bins = wt.prepReference(
+        None, counts=counts, chrom_bins=chrom_bins_in)
     print('Zero mask on the GPU: %d bins x %d samples -> %d bins kept, 3 PCA components removed'
           % (len(mask), n_given, masked.shape[0]))
     running = np.cumsum(masked_bins)
