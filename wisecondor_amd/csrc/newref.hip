@@ -17,7 +17,7 @@
 //               the certificate, the candidates with bound <= U as pairs; k_rescore: their exact
 //               float64 distances in numpy's summation order, counting order, output.  Rows whose
 //               certificate fails (and every row beyond refsize 256) take an exact path on the GPU
-//               (k_fallback_fill / k_fallback, k_all_exact).  WC_FINISH_ENGINE=rows: round 1's k_finish.
+//               (k_fallback_all, k_all_exact).  WC_FINISH_ENGINE=rows: round 1's k_finish.
 #include <cstring>
 #include "ctx.h"
 
@@ -1900,7 +1900,7 @@ __device__ inline unsigned long long fb_radix_select(int64_t n, int want, V v, U
 // The k-th smallest key by radix selection; everything below it is taken, of the entries that
 // tie with it the lowest positions (a second selection over the positions when there are more
 // ties than places); the <= 256 chosen entries are ordered by counting.
-__device__ inline void fb_select(const FinishArgs &a, int64_t row, const unsigned long long *__restrict__ sc,
+__device__ inline void fb_select(const FinishArgs &a, int64_t row, const unsigned long long *sc,
                                  unsigned long long *selk, int *selj, unsigned int *hist, int tid) {
     __shared__ unsigned long long s_pref;
     __shared__ int s_int[4];
@@ -1979,10 +1979,23 @@ __device__ inline void fb_select(const FinishArgs &a, int64_t row, const unsigne
 // workgroup per row, as the first version had it, reads the whole matrix -- 277 MB at
 // 57 633 x 600 -- through a single CU: ~100 ms for a single outlier row.)
 constexpr int FB_ROWS_PAR = 8;
-__global__ __launch_bounds__(256) void k_fallback_fill(FinishArgs a, unsigned long long *scratch, int64_t Bpad) {
+// ONE launch for the whole exact path (round 3; two launches before -- a fill kernel and a select kernel that
+// cost ~9 us per pass as no-ops): FB_BLOCKS workgroups fill the distance rows of the first FB_BLOCKS exact rows
+// together (eight rows in flight, 64 workgroups share a row's candidates); a workgroup that finishes its part
+// of a row publishes it (fence, then a ticket on the row's counter) and the LAST one to arrive selects the row --
+// nobody ever waits for anybody, so the launch cannot deadlock however many other kernels share the GPU.  Exact
+// rows beyond FB_BLOCKS (pathological inputs, and every row when refsize > 256) are filled and selected by one
+// workgroup each, in a scratch slot of its own (the second half of the scratch: the first half's slots are still
+// being filled / selected by other workgroups).  `done` = FB_BLOCKS counters, zeroed by the caller's memset.
+__global__ __launch_bounds__(256) void k_fallback_all(FinishArgs a, unsigned long long *scratch, int64_t Bpad, int *done) {
+    __shared__ unsigned long long rk[K_MAX];
+    __shared__ int rj[K_MAX];
+    __shared__ unsigned int hist[256];
     __shared__ double xs[2048];
+    __shared__ int s_last;
     const int tid = threadIdx.x;
     const int nfb = *a.fb_count;
+    if (nfb == 0) return;
     const int nf = nfb < FB_BLOCKS ? nfb : FB_BLOCKS;
     constexpr int SHARE = FB_BLOCKS / FB_ROWS_PAR;
     const int part = blockIdx.x % SHARE, lane_row = blockIdx.x / SHARE;
@@ -1998,21 +2011,22 @@ __global__ __launch_bounds__(256) void k_fallback_fill(FinishArgs a, unsigned lo
         unsigned long long *sc = scratch + (int64_t)f * Bpad;
         for (int64_t c0 = (int64_t)part * 256; c0 < a.B; c0 += (int64_t)SHARE * 256)
             fb_fill(a, row, xi, c0, c0 + 256 < a.B ? c0 + 256 : a.B, sc, tid);
+        // publish this part; the last of the row's SHARE workgroups selects (agent-scope release by one lane after
+        // every wave has drained its stores, ticket, agent-scope acquire by the last arriver: the recipe of the
+        // programming guide's inter-workgroup section)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int old = __hip_atomic_fetch_add(&done[f], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = old == SHARE - 1;
+            if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        if (s_last) fb_select(a, row, sc, rk, rj, hist, tid);
     }
-}
-
-// Selection for the rows whose keys k_fallback_fill left in scratch (one workgroup per row);
-// fallback rows beyond FB_BLOCKS (pathological inputs) run both steps here, one row at a
-// time per workgroup, in the workgroup's own scratch slot.
-__global__ __launch_bounds__(256) void k_fallback(FinishArgs a, unsigned long long *scratch, int64_t Bpad) {
-    __shared__ unsigned long long rk[K_MAX];
-    __shared__ int rj[K_MAX];
-    __shared__ unsigned int hist[256];
-    __shared__ double xs[2048];
-    const int tid = threadIdx.x;
-    const int nfb = *a.fb_count;
-    unsigned long long *sc = scratch + (int64_t)blockIdx.x * Bpad;
-    if ((int)blockIdx.x < nfb) fb_select(a, a.fb_rows[blockIdx.x], sc, rk, rj, hist, tid);
+    unsigned long long *own = scratch + ((int64_t)FB_BLOCKS + blockIdx.x) * Bpad;
     for (int f = FB_BLOCKS + blockIdx.x; f < nfb; f += gridDim.x) {
         const int64_t row = a.fb_rows[f];
         const double *xi = a.X + row * a.S;
@@ -2022,9 +2036,9 @@ __global__ __launch_bounds__(256) void k_fallback(FinishArgs a, unsigned long lo
             xi = xs;
         }
         __syncthreads();
-        fb_fill(a, row, xi, 0, a.B, sc, tid);
+        fb_fill(a, row, xi, 0, a.B, own, tid);
         __syncthreads();
-        fb_select(a, row, sc, rk, rj, hist, tid);
+        fb_select(a, row, own, rk, rj, hist, tid);
     }
 }
 
@@ -2223,7 +2237,7 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
     if ((rc = st.cnt.reserve(sizeof(int) * st.bins_pad))) return rc;
     if ((rc = st.list.reserve(sizeof(uint64_t) * st.bins_pad * st.cap))) return rc;
     if ((rc = st.fb_rows.reserve(sizeof(int) * st.bins_pad))) return rc;
-    if ((rc = st.fb_count.reserve(sizeof(int) * 4))) return rc;
+    if ((rc = st.fb_count.reserve(sizeof(int) * (4 + FB_BLOCKS)))) return rc;
     if ((rc = st.stats.reserve(sizeof(int) * st.bins_pad))) return rc;
 
     {
@@ -2492,7 +2506,7 @@ int wc_newref_collect_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t
 }
 
 // stage D in two halves: `which` bit 0 = the per-row fast path (k_finish), bit 1 = the exact path
-// for the rows it handed over (k_fallback_fill + k_fallback; idle launches when there are none)
+// for the rows it handed over (k_fallback_all; one idle launch when there are none)
 static int newref_finish_part(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t row_end, int32_t *idx_out,
                               double *dist_out, int which) {
     WC_CHECK(ctx && ctx->nr.prepared, WC_E_ARG, "newref: prepare has not run");
@@ -2502,8 +2516,8 @@ static int newref_finish_part(wc_ctx *ctx, void *stream_, int64_t row_begin, int
     if (row_begin == row_end) return WC_OK;
     hipStream_t stream = (hipStream_t)stream_;
     int rc;
-    if ((rc = st.fb_scratch.reserve(sizeof(uint64_t) * FB_BLOCKS * st.bins_pad))) return rc;
-    if (which & 5) WC_HIP(hipMemsetAsync(st.fb_count.p, 0, sizeof(int) * 4, stream));
+    if ((rc = st.fb_scratch.reserve(sizeof(uint64_t) * 2 * FB_BLOCKS * st.bins_pad))) return rc;
+    if (which & 5) WC_HIP(hipMemsetAsync(st.fb_count.p, 0, sizeof(int) * (4 + FB_BLOCKS), stream));   // the counter and the rows' tickets
     FinishArgs a{};
     a.X = st.corrected;
     a.B = st.n_bins;
@@ -2579,12 +2593,9 @@ static int newref_finish_part(wc_ctx *ctx, void *stream_, int64_t row_begin, int
             else hipLaunchKernelGGL((k_finish<false, 256>), grid, dim3(256), dyn, stream, a);
         }
     }
-    if (which & 2) {
-        hipLaunchKernelGGL(k_fallback_fill, dim3(FB_BLOCKS), dim3(256), 0, stream, a,
-                           st.fb_scratch.as<unsigned long long>(), st.bins_pad);
-        hipLaunchKernelGGL(k_fallback, dim3(FB_BLOCKS), dim3(256), 0, stream, a,
-                           st.fb_scratch.as<unsigned long long>(), st.bins_pad);
-    }
+    if (which & 2)
+        hipLaunchKernelGGL(k_fallback_all, dim3(FB_BLOCKS), dim3(256), 0, stream, a,
+                           st.fb_scratch.as<unsigned long long>(), st.bins_pad, st.fb_count.as<int>() + 4);
     WC_HIP(hipGetLastError());
     return WC_OK;
 }
