@@ -185,14 +185,21 @@ int wc_write_test_results(int n_files, int n_threads, const char *const *out_pat
  *   correctedData is its transpose VIEW, i.e. Fortran-ordered [B, n_samples]);
  *   pca_components_out [n_comp, B]; pca_mean_out [B].
  * Call once with the four data outputs NULL to learn B, then again with buffers.
- * wc_newref_prep solves the small eigenproblem with a host Jacobi; callers that own a
- * LAPACK use the two-step form: _gram returns the Gram matrix G [n_samples, n_samples]
- * of the centred data, _finish takes the n_comp leading eigenvectors (rows, unit norm)
- * and eigenvalues of G in descending order.
+ * wc_newref_prep is the one-call form.  The steps are also exported: _gram builds the Gram
+ * matrix G [n_samples, n_samples] of the centred data in HBM (and copies it to gram_out unless
+ * that is NULL), _eig solves its eigenproblem on the GPU for the n_pairs leading pairs
+ * (Householder tridiagonalisation, Sturm multisection, inverse iteration: a direct method,
+ * 3 <= n_samples <= 4096, n_pairs <= 8; eigenvalues descending, unit eigenvectors as rows, host
+ * outputs), _finish takes such pairs -- from _eig or from the caller's own LAPACK on gram_out.
+ * wc_sym_eigh_leading_dev is the same solver on any device-resident symmetric float64 matrix
+ * (left untouched).
  */
 int wc_newref_prep_gram(wc_ctx *ctx, const int32_t *counts, int64_t n_samples, int64_t n_total_bins,
                         const int64_t *chromosome_bins, int n_chrom, uint8_t *mask_out,
                         int64_t *masked_chrom_bins_out, int64_t *n_masked_out, double *gram_out);
+int wc_newref_prep_eig(wc_ctx *ctx, int n_pairs, double *eigvals_out, double *eigvecs_out);
+int wc_sym_eigh_leading_dev(wc_ctx *ctx, const double *matrix_dev, int64_t n, int n_pairs, double *eigvals_out,
+                            double *eigvecs_out);
 int wc_newref_prep_finish(wc_ctx *ctx, int n_comp, const double *eigvecs, const double *eigvals,
                           double *masked_data_out, double *corrected_t_out, double *pca_components_out,
                           double *pca_mean_out);

@@ -1,4 +1,5 @@
-"""Time of the GPU newref prep (wc_newref_prep_gram + host eigh of the leading pairs + wc_newref_prep_finish[_dev]) on random counts.
+"""Time of the GPU newref prep (wc_newref_prep_gram + the eigen-solve of the leading pairs, on the GPU (wc_newref_prep_eig)
+and by LAPACK on the fetched matrix + wc_newref_prep_finish[_dev]) on random counts.
     python3 tools/gpu_prep_time.py [cfg2|cfg4]"""
 import ctypes, sys, time
 import numpy as np
@@ -20,8 +21,14 @@ for it in range(3):
     _lib.check(lib.wc_newref_prep_gram(ctx, _lib.ptr(counts), n_s, n_total, _lib.ptr(sizes), len(sizes),
                                        _lib.ptr(mask), _lib.ptr(mbins), ctypes.byref(n_b), _lib.ptr(gram)))
     t1 = time.perf_counter()
+    gv, gvec = np.empty(3), np.empty((3, n_s))
+    _lib.check(lib.wc_newref_prep_eig(ctx, 3, _lib.ptr(gv), _lib.ptr(gvec)))
+    t1b = time.perf_counter()
+    t_gpu_eig = t1b - t1
+    t1 = t1b
     evals, evecs = wt._leading_eigenpairs(gram, 3)
     t2 = time.perf_counter()
+    diff = max(np.abs(np.sign(np.dot(gvec[j], evecs[j])) * gvec[j] - evecs[j]).max() for j in range(3))
     B = n_b.value
     masked = wt._pinned((B, n_s)); corrected_t = wt._pinned((n_s, B)); comps = np.empty((3, B)); mean = np.empty(B)
     _lib.check(lib.wc_newref_prep_finish(ctx, 3, _lib.ptr(evecs), _lib.ptr(evals), _lib.ptr(masked),
@@ -33,7 +40,7 @@ for it in range(3):
     _lib.check(lib.wc_newref_prep_finish_dev(ctx, 3, _lib.ptr(evecs), _lib.ptr(evals), ctypes.c_void_p(dm.data_ptr()),
                                              ctypes.c_void_p(dc.data_ptr()), _lib.ptr(comps), _lib.ptr(mean)))
     t5 = time.perf_counter()
-    print("%s it %d: gram (incl. H2D of the counts, mask round trip) %.1f ms, eigh (leading 3) %.1f ms, finish to pinned host "
+    print("%s it %d: gram (incl. H2D of the counts, mask round trip) %.1f ms, eigen-solve (leading 3) on the GPU %.2f ms [vectors differ by %.1e] / by LAPACK %.1f ms, finish to pinned host "
           "(D2H of %d MB) %.1f ms, finish device-resident %.1f ms"
-          % (which, it, 1e3 * (t1 - t0), 1e3 * (t2 - t1), (masked.nbytes + corrected_t.nbytes) >> 20, 1e3 * (t3 - t2),
+          % (which, it, 1e3 * (t1 - t0 - t_gpu_eig), 1e3 * t_gpu_eig, diff, 1e3 * (t2 - t1), (masked.nbytes + corrected_t.nbytes) >> 20, 1e3 * (t3 - t2),
              1e3 * (t5 - t4)), flush=True)

@@ -47,6 +47,8 @@ SIGNATURES = {
     "wc_write_test_results": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _i32, _vp, _vp, _i64, _vp,
                                      _i32, _vp, _vp, _i32, _vp, _i32, _vp]),
     "wc_newref_prep_gram": (_i32, [_vp, _vp, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "wc_newref_prep_eig": (_i32, [_vp, _i32, _vp, _vp]),
+    "wc_sym_eigh_leading_dev": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "wc_newref_prep_finish": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "wc_newref_prep_finish_dev": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "wc_newref_prep": (_i32, [_vp, _vp, _i64, _i64, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

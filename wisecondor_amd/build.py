@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwisecondor_hip.so")
-SOURCES = ["ctx.hip", "newref.hip", "testpath.hip", "prep.hip", "npzio.cpp"]   # npzio.cpp: host only (zip / pickle / zlib)
+SOURCES = ["ctx.hip", "newref.hip", "testpath.hip", "prep.hip", "eigh.hip", "npzio.cpp"]   # npzio.cpp: host only (zip / pickle / zlib)
 # -fno-slp-vectorize: the SLP vectoriser pairs float32 operations into v_pk_add_f32 /
 # v_pk_fma_f32; an in-place pair whose low half reads the destination's high half
 # (v_pk_add_f32 v[74:75], v[84:85], v[74:75] op_sel:[0,1]) returned run-to-run different

@@ -89,6 +89,7 @@ struct TestState {
 struct PrepState {
     int64_t S = 0, Btot = 0, B = 0;
     bool ready = false;
+    wc::DevBuf eig_ws;          // eigh.hip: working copy, reflectors, tridiagonal, vectors
 };
 
 struct wc_ctx {
@@ -134,6 +135,12 @@ struct wc_ctx {
                 &ts.sel, &ts.res_z, &ts.res_r, &ts.cwz, &ts.calls, &ts.n_calls, &ts.zs, &ts.rs2, &ts.ns2, &ts.sds, &ts.sub, &ts.tmin, &ts.tmax, &ts.prefix, &ts.reg_abs,
                 &ts.reg_flag, &ts.rs, &ts.jobs_a, &ts.jobs_b, &ts.job_cnt, &ts.partial, &ts.job_res, &ts.hot,
                 &ts.cand, &ts.cand_cnt, &ts.seg, &ts.seg_cnt, &ts.out_val, &ts.out_x, &ts.out_y, &ts.out_n,
-                &ts.whole, &ts.effect, &ts.misc, &ts.misc2, &ts.reduce_tmp, &ts.win_bits, &ts.bit_off, &ts.pairs_a, &ts.pairs_b, &ts.cut_vals, &ts.prof_work, &ts.sd_fail};
+                &ts.whole, &ts.effect, &ts.misc, &ts.misc2, &ts.reduce_tmp, &ts.win_bits, &ts.bit_off, &ts.pairs_a, &ts.pairs_b, &ts.cut_vals, &ts.prof_work, &ts.sd_fail, &prep.eig_ws};
     }
 };
+
+namespace wc {
+// eigh.hip: leading eigenpairs of a device-resident symmetric matrix (host outputs)
+int sym_eigh_leading(wc_ctx *ctx, const double *matrix_dev, int64_t n, int n_pairs, double *eigvals_out,
+                     double *eigvecs_out);
+}  // namespace wc

@@ -1,8 +1,9 @@
 // newref prep on gfx950: toNumpyArray's normalisation and
 // zero mask (wisetools.py:240-264) and trainPCA (wisetools.py:89-101) as an exact,
 // deterministic rank-n PCA: float64 Gram matrix of the centred [samples, bins] data on the
-// GPU, its small [samples, samples] eigenproblem on the host (LAPACK-free Jacobi), the
-// components, projection, reconstruction and the corrected matrix on the GPU.
+// GPU, its small [samples, samples] eigenproblem by the direct solver of eigh.hip (or by the caller:
+// the Gram matrix can be fetched and the pairs handed back), the components, projection,
+// reconstruction and the corrected matrix on the GPU.
 #include "ctx.h"
 
 #include <algorithm>
@@ -298,8 +299,8 @@ extern "C" {
 int wc_newref_prep_gram(wc_ctx *ctx, const int32_t *counts, int64_t n_samples, int64_t n_total_bins,
                         const int64_t *chromosome_bins, int n_chrom, uint8_t *mask_out,
                         int64_t *masked_chrom_bins_out, int64_t *n_masked_out, double *gram_out) {
-    WC_CHECK(ctx && counts && chromosome_bins && mask_out && masked_chrom_bins_out && n_masked_out && gram_out,
-             WC_E_ARG, "prep: NULL argument");
+    WC_CHECK(ctx && counts && chromosome_bins && mask_out && masked_chrom_bins_out && n_masked_out,
+             WC_E_ARG, "prep: NULL argument");           // gram_out may be NULL: the matrix stays in HBM for wc_newref_prep_eig
     WC_CHECK(n_samples > 0 && n_total_bins > 0 && n_chrom > 0 && n_chrom <= WC_MAX_CHROM, WC_E_ARG, "prep: bad shape");
     WC_CHECK(n_samples <= 4096, WC_E_LIMIT, "prep: more than 4096 samples not supported");
     WC_HIP(hipSetDevice(ctx->device));
@@ -372,9 +373,18 @@ int wc_newref_prep_gram(wc_ctx *ctx, const int32_t *counts, int64_t n_samples, i
                            (int)n_slices, S, G);
     }
     WC_HIP(hipDeviceSynchronize());
-    WC_HIP(hipMemcpy(gram_out, G, sizeof(double) * S * S, hipMemcpyDeviceToHost));
+    if (gram_out) WC_HIP(hipMemcpy(gram_out, G, sizeof(double) * S * S, hipMemcpyDeviceToHost));
     g_prep.S = S; g_prep.Btot = Btot; g_prep.B = B; g_prep.ready = true;
     return WC_OK;
+}
+
+// The leading eigenpairs of the Gram matrix wc_newref_prep_gram left in HBM (eigh.hip): eigenvalues
+// descending, unit eigenvectors as rows -- what wc_newref_prep_finish* take.
+int wc_newref_prep_eig(wc_ctx *ctx, int n_pairs, double *eigvals_out, double *eigvecs_out) {
+    WC_CHECK(ctx && eigvals_out && eigvecs_out, WC_E_ARG, "prep: NULL argument");
+    WC_CHECK(ctx->prep.ready, WC_E_ARG, "prep: wc_newref_prep_gram has not run");
+    WC_HIP(hipSetDevice(ctx->device));
+    return wc::sym_eigh_leading(ctx, ctx->ts.z.as<double>(), ctx->prep.S, n_pairs, eigvals_out, eigvecs_out);
 }
 
 // Device part of the finish step: components (sign fixed), projection, corrected_t [S, B] in ts.xc.
@@ -467,8 +477,8 @@ int wc_newref_prep_finish_dev(wc_ctx *ctx, int n_comp, const double *eigvecs, co
     return WC_OK;
 }
 
-// One-call variant for callers without a LAPACK: the [samples, samples] eigenproblem is
-// solved by cyclic Jacobi on the host (fine up to a few hundred samples).
+// One-call variant: the [samples, samples] eigenproblem by eigh.hip (one or two samples: the
+// host Jacobi below, there is nothing to tridiagonalise).
 int wc_newref_prep(wc_ctx *ctx, const int32_t *counts, int64_t n_samples, int64_t n_total_bins,
                    const int64_t *chromosome_bins, int n_chrom, int n_comp, uint8_t *mask_out,
                    int64_t *masked_chrom_bins_out, int64_t *n_masked_out, double *masked_data_out,
@@ -479,7 +489,14 @@ int wc_newref_prep(wc_ctx *ctx, const int32_t *counts, int64_t n_samples, int64_
     if (rc) return rc;
     if (!masked_data_out || !corrected_t_out || !pca_components_out || !pca_mean_out) return WC_OK;  // size query
     std::vector<double> val, vec;
-    jacobi_eigh(gram, (int)n_samples, val, vec);
+    if (n_samples >= 3) {
+        WC_CHECK(n_comp >= 1 && n_comp <= 8 && n_comp <= n_samples, WC_E_ARG, "prep: 1..8 components supported");
+        val.resize(8);
+        vec.resize((size_t)8 * n_samples);
+        if ((rc = wc_newref_prep_eig(ctx, n_comp, val.data(), vec.data()))) return rc;
+    } else {
+        jacobi_eigh(gram, (int)n_samples, val, vec);
+    }
     return wc_newref_prep_finish(ctx, n_comp, vec.data(), val.data(), masked_data_out, corrected_t_out,
                                  pca_components_out, pca_mean_out);
 }

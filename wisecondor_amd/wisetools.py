@@ -6,6 +6,7 @@ runs in the gfx950 HIP library through the C ABI (include/wisecondor_hip.h).
 No numpy fallback exists: without the library or a GPU these functions raise.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -365,7 +366,8 @@ def test_batch(reference, samples, threshold, minrefbins=25, repeats=5, chromoso
 # newref prep (upstream of the hot path)
 # ---------------------------------------------------------------------------
 def _leading_eigenpairs(gram, n):
-    """The n largest eigenvalues (descending) and unit eigenvectors (rows) of the symmetric `gram`."""
+    """The n largest eigenvalues (descending) and unit eigenvectors (rows) of the symmetric `gram`
+    on the host (LAPACK): the route of WC_PREP_EIG=host and of matrices eigh.hip does not take."""
     n_s = gram.shape[0]
     try:
         from scipy.linalg import eigh as _eigh          # LAPACK dsyevr on the wanted pairs only
@@ -374,6 +376,37 @@ def _leading_eigenpairs(gram, n):
         vals, vecs = np.linalg.eigh(gram)
     order = np.argsort(vals)[::-1][:n]
     return np.ascontiguousarray(vals[order]), np.ascontiguousarray(vecs[:, order].T)
+
+
+EIG_ON_GPU_FROM = 256       # samples; below, LAPACK on the fetched Gram matrix is quicker than ~n launches
+
+
+def _eig_on_gpu(n_s, pcacomp):
+    """Where trainPCA's [samples, samples] eigenproblem is solved: WC_PREP_EIG=gpu|host, else by size."""
+    mode = os.environ.get('WC_PREP_EIG', 'auto')
+    if mode not in ('auto', 'gpu', 'host'):
+        raise ValueError("WC_PREP_EIG must be gpu, host or auto, not %r" % mode)
+    possible = 3 <= n_s <= 4096 and 1 <= pcacomp <= 8
+    if mode == 'gpu' and not possible:
+        raise ValueError("WC_PREP_EIG=gpu: the GPU solver takes 3..4096 samples and up to 8 components")
+    return possible and (mode == 'gpu' or (mode == 'auto' and n_s >= EIG_ON_GPU_FROM))
+
+
+def sym_eigh_leading(matrix, n_pairs, device=0):
+    """The n_pairs largest eigenvalues (descending) and unit eigenvectors (rows) of a symmetric
+    float64 matrix by the GPU solver of csrc/eigh.hip.  `matrix`: numpy array or CUDA tensor."""
+    import torch
+    lib = _lib.load()
+    ctx = _lib.context(device)
+    m = matrix if isinstance(matrix, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(matrix, dtype=np.float64))
+    m = m.to(device=torch.device('cuda', device), dtype=torch.float64).contiguous()
+    n = m.shape[0]
+    vals = np.empty(n_pairs)
+    vecs = np.empty((n_pairs, n))
+    torch.cuda.current_stream(device).synchronize()
+    _lib.check(lib.wc_sym_eigh_leading_dev(ctx, ctypes.c_void_p(m.data_ptr()), n, int(n_pairs), _lib.ptr(vals),
+                                           _lib.ptr(vecs)))
+    return vals, vecs
 
 
 def _pinned(shape):
@@ -390,8 +423,10 @@ def prepReference(samples, pcacomp=3, device=0, device_out=False, counts=None, c
     """toNumpyArray + trainPCA (wisetools.py:240-264, 89-101) with the bins-sized work on the GPU.
 
     The Gram matrix of the centred [samples, bins] data comes from the GPU (float64 matrix
-    cores), LAPACK solves its small [samples, samples] eigenproblem for the leading pairs, and
-    the GPU finishes (components, projection, reconstruction, division).  Returns
+    cores); its small [samples, samples] eigenproblem is solved for the leading pairs by the direct
+    solver of csrc/eigh.hip (from EIG_ON_GPU_FROM samples; below that, and under WC_PREP_EIG=host,
+    by LAPACK on the fetched matrix), and the GPU finishes (components, projection,
+    reconstruction, division).  Returns
     (maskedData [B,S], chromosomeBins, mask, correctedData [B,S] Fortran-ordered like the
     reference's, pca_components [n,B], pca_mean [B], maskedChromBins).
 
@@ -416,10 +451,16 @@ def prepReference(samples, pcacomp=3, device=0, device_out=False, counts=None, c
     mask = np.empty(n_total, dtype=np.uint8)
     mbins = np.empty(len(sizes), dtype=np.int64)
     n_b = ctypes.c_int64()
-    gram = np.empty((n_s, n_s))
+    on_gpu = _eig_on_gpu(n_s, pcacomp)
+    gram = None if on_gpu else np.empty((n_s, n_s))
     _lib.check(lib.wc_newref_prep_gram(ctx, _lib.ptr(counts), n_s, n_total, _lib.ptr(sizes), len(sizes),
-                                       _lib.ptr(mask), _lib.ptr(mbins), ctypes.byref(n_b), _lib.ptr(gram)))
-    evals, evecs = _leading_eigenpairs(gram, pcacomp)
+                                       _lib.ptr(mask), _lib.ptr(mbins), ctypes.byref(n_b),
+                                       None if on_gpu else _lib.ptr(gram)))
+    if on_gpu:          # the Gram matrix never leaves HBM
+        evals, evecs = np.empty(pcacomp), np.empty((pcacomp, n_s))
+        _lib.check(lib.wc_newref_prep_eig(ctx, int(pcacomp), _lib.ptr(evals), _lib.ptr(evecs)))
+    else:
+        evals, evecs = _leading_eigenpairs(gram, pcacomp)
     B = n_b.value
     comps = np.empty((pcacomp, B))
     mean = np.empty(B)
