@@ -934,8 +934,10 @@ def main():
                        "world_size": dist.get_world_size() if world > 1 else 1,
                        "shard_mode": job.mode or "single", "shard_calibration_s": job.calibration},
             "stages_ms": stages,
-            "prep": {"what": "newrefprep numerics on the GPU (normalise, mask, float64 MFMA Gram, host LAPACK for the "
-                             "leading eigenpairs, components, correctedData left in HBM), %d samples, dense int32 host counts in" % S,
+            "prep": {"what": "newrefprep numerics on the GPU (normalise, mask, float64 MFMA Gram, the leading eigenpairs by %s, "
+                             "components, correctedData left in HBM), %d samples, dense int32 host counts in"
+                             % ("csrc/eigh.hip (tridiagonalisation + Sturm multisection + inverse iteration)"
+                                if wt._eig_on_gpu(S, 3) else "host LAPACK (fewer than %d samples)" % wt.EIG_ON_GPU_FROM, S),
                      "ms": inp.get("prep_ms")},
             "test": {"metric": "test samples/sec", "value": samples_per_s, "unit": "samples/s",
                      "ms_per_batch": 1e3 * t_test / test_steps, "samples_per_gpu": args.test_samples,
