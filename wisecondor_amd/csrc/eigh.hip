@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -207,6 +208,7 @@ __global__ __launch_bounds__(256) void k_tri_step_reg(double *__restrict__ A, do
         r0[q] = (i0 < n && j < n) ? row0[j] : 0.0;
         r1[q] = (i1 < n && j < n) ? row1[j] : 0.0;
     }
+    __builtin_amdgcn_sched_barrier(0);      // (the loads stay in front of the reductions)
     // previous reflector: w = p - (tau/2 p.v) v
     double acc = 0.0;
 #pragma unroll
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256) void k_tri_step_reg(double *__restrict__ A, do
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int j = tid + 256 * q;
-        double r = j >= k ? rk[q] - (vpk * pj[q] + wpk * vj[q]) : 0.0;
+        double r = j >= k ? fma(-wpk, vj[q], fma(-vpk, pj[q], rk[q])) : 0.0;
         if (j == k && blockIdx.x == 0) d[k] = r;
         r = j > k ? r : 0.0;
         if (j < n) vc[j] = r;
@@ -254,17 +256,23 @@ __global__ __launch_bounds__(256) void k_tri_step_reg(double *__restrict__ A, do
     const double vp0 = i0 < n ? vp[i0] : 0.0, wp0 = i0 < n ? wp[i0] : 0.0;
     const double vp1 = i1 < n ? vp[i1] : 0.0, wp1 = i1 < n ? wp[i1] : 0.0;
     double dot0[4] = {0.0, 0.0, 0.0, 0.0}, dot1[4] = {0.0, 0.0, 0.0, 0.0};
+    // float64 instructions are what this part costs (a wave issues one every ~8 ns here): the
+    // update is two fused multiply-adds per element, and the 64-column groups beyond the end of
+    // the row are skipped by a wave-uniform branch instead of being issued under an empty mask
+    const int nq = (n - k - 1 + 63) >> 6;
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
-        const int j = k + 1 + lane + 64 * q;
-        if (j < n) {
-            const double wj = wp[j], vj2 = vp[j], cj = vc[j];
-            const double a0 = r0[q] - (vp0 * wj + wp0 * vj2);
-            const double a1 = r1[q] - (vp1 * wj + wp1 * vj2);
-            if (i0 < n) row0[j] = a0;
-            if (i1 < n) row1[j] = a1;
-            dot0[q & 3] = fma(a0, cj, dot0[q & 3]);
-            dot1[q & 3] = fma(a1, cj, dot1[q & 3]);
+        if (q < nq) {
+            const int j = k + 1 + lane + 64 * q;
+            if (j < n) {
+                const double wj = wp[j], vj2 = vp[j], cj = vc[j];
+                const double a0 = fma(-wp0, vj2, fma(-vp0, wj, r0[q]));
+                const double a1 = fma(-wp1, vj2, fma(-vp1, wj, r1[q]));
+                if (i0 < n) row0[j] = a0;
+                if (i1 < n) row1[j] = a1;
+                dot0[q & 3] = fma(a0, cj, dot0[q & 3]);
+                dot1[q & 3] = fma(a1, cj, dot1[q & 3]);
+            }
         }
     }
     const double s0 = wave_sum((dot0[0] + dot0[1]) + (dot0[2] + dot0[3]));
@@ -273,6 +281,117 @@ __global__ __launch_bounds__(256) void k_tri_step_reg(double *__restrict__ A, do
         if (i0 < n) Pc[i0] = t * s0;
         if (i1 < n) Pc[i1] = t * s1;
     }
+}
+
+// The last TAIL_MAX columns in ONE workgroup: once the trailing matrix fits into LDS (128 x 128
+// float64 = 132 KB with the padding), a column costs a handful of workgroup barriers (~1.3 us)
+// instead of a launch (5.8 us).  The pending update of the last multi-workgroup column is applied
+// while the block is loaded; from there the block is kept up to date (product, then rank-2 update,
+// both with eight threads per row).  Also writes the reflector rows, d, e, tau of its columns and
+// the final 2 x 2 block.  Matrices of up to TAIL_MAX rows never see another kernel.
+constexpr int TAIL_MAX = 128, TAIL_LD = TAIL_MAX + 1, TAIL_THREADS = 1024;
+
+__device__ inline double block_sum1024(double v, double *red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < TAIL_THREADS / 64; ++w) s += red[w];
+    return s;
+}
+
+__global__ __launch_bounds__(TAIL_THREADS) void k_tri_tail(const double *__restrict__ A, double *__restrict__ V,
+                                                           const double *__restrict__ P, double *__restrict__ d,
+                                                           double *__restrict__ e, double *__restrict__ tau, int n,
+                                                           int k0) {
+    extern __shared__ double lds[];
+    __shared__ double red[TAIL_THREADS / 64];
+    double *M = lds, *v = M + TAIL_MAX * TAIL_LD, *w = v + TAIL_MAX, *pl = w + TAIL_MAX;
+    double *es = pl + TAIL_MAX, *ts = es + TAIL_MAX;
+    const int tid = threadIdx.x;
+    const int mt = n - k0;                       // <= TAIL_MAX
+    // the previous column's reflector and w = p - (tau/2 p.v) v, local indices
+    {
+        double vv = 0.0, pp = 0.0;
+        if (k0 > 0 && tid < mt) {
+            vv = V[(size_t)(k0 - 1) * n + k0 + tid];
+            pp = P[(size_t)((k0 - 1) & 1) * n + k0 + tid];
+        }
+        const double tp = k0 > 0 ? tau[k0 - 1] : 0.0;
+        const double K = 0.5 * tp * block_sum1024(pp * vv, red);
+        if (tid < TAIL_MAX) { v[tid] = vv; w[tid] = pp - K * vv; }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < mt * mt; idx += TAIL_THREADS) {
+        const int r = idx / mt, c = idx - r * mt;
+        M[r * TAIL_LD + c] = A[(size_t)(k0 + r) * n + k0 + c] - (v[r] * w[c] + w[r] * v[c]);
+    }
+    __syncthreads();
+    const int row = tid >> 3, part = tid & 7;    // eight threads per row of the block
+    const int lane = tid & 63;
+    for (int c = 0; c < mt - 2; ++c) {
+        // the column: row c of the block right of the diagonal.  Every wave reduces it for itself
+        // (two elements per lane): no workgroup barrier for a number all of them need
+        const double xa = (lane > c && lane < mt) ? M[c * TAIL_LD + lane] : 0.0;
+        const double xb = (lane + 64 > c && lane + 64 < mt) ? M[c * TAIL_LD + lane + 64] : 0.0;
+        const double ss = wave_sum(xa * xa + xb * xb);
+        const double x0 = M[c * TAIL_LD + c + 1];
+        double alpha = 0.0, t = 0.0, v0 = x0;
+        if (ss > 0.0 && isfinite(ss)) {
+            const double nrm = sqrt(ss);
+            alpha = -copysign(nrm, x0);
+            v0 = x0 - alpha;
+            t = 2.0 / ((ss - x0 * x0) + v0 * v0);
+        }
+        if (tid < 64) {
+            v[lane] = lane == c + 1 ? v0 : xa;
+            v[lane + 64] = lane + 64 == c + 1 ? v0 : xb;
+        }
+        if (tid == 0) { es[c] = alpha; ts[c] = t; }
+        __syncthreads();
+        // the reflector replaces the row it came from (nobody reads row c any more); global memory
+        // sees it after the loop -- a store inside the loop would sit in front of every barrier
+        if (tid > c && tid < mt) M[c * TAIL_LD + tid] = v[tid];
+        // p = t M v, eight threads per row, four partial sums each; columns left of the diagonal
+        // hold zeros of v and are skipped in whole groups of eight
+        const int q0 = (c + 1) >> 3;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        if (row > c && row < mt) {
+#pragma unroll
+            for (int q = 0; q < TAIL_MAX / 8; ++q) {
+                const int j = part + 8 * q;
+                if (q >= q0 && j < mt) acc[q & 3] = fma(M[row * TAIL_LD + j], v[j], acc[q & 3]);
+            }
+        }
+        double s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        s = dpp_add<0x111, 0xF>(s);
+        s = dpp_add<0x112, 0xF>(s);
+        s = dpp_add<0x114, 0xF>(s);               // lane 8 g + 7 holds the sum of its group of eight
+        if (part == 7) pl[row] = (row > c && row < mt) ? t * s : 0.0;
+        __syncthreads();
+        // K = t/2 p.v per wave again; w = p - K v by the first two waves' worth of threads
+        const double K = 0.5 * t * wave_sum(pl[lane] * v[lane] + pl[lane + 64] * v[lane + 64]);
+        if (tid < TAIL_MAX) w[tid] = fma(-K, v[tid], pl[tid]);
+        __syncthreads();
+        if (row > c && row < mt) {
+            const double vi = v[row], wi = w[row];
+#pragma unroll
+            for (int q = 0; q < TAIL_MAX / 8; ++q) {
+                const int j = part + 8 * q;
+                if (q >= q0 && j > c && j < mt)
+                    M[row * TAIL_LD + j] = fma(-wi, v[j], fma(-vi, w[j], M[row * TAIL_LD + j]));
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < mt) d[k0 + tid] = M[tid * TAIL_LD + tid];
+    if (tid < mt - 2) { e[k0 + tid] = es[tid]; tau[k0 + tid] = ts[tid]; }
+    if (tid == 0) e[k0 + mt - 2] = M[(mt - 1) * TAIL_LD + mt - 2];
+    for (int c = 0; c < mt - 2; ++c)
+        for (int j = tid; j < n; j += TAIL_THREADS)
+            V[(size_t)(k0 + c) * n + j] = j > k0 + c ? M[c * TAIL_LD + j - k0] : 0.0;
 }
 
 // The last 2 x 2 block: d[n-2], d[n-1], e[n-2] with the last pending update applied.
@@ -620,7 +739,10 @@ int sym_eigh_leading(wc_ctx *ctx, const double *matrix_dev, int64_t n64, int n_p
     if ((rc = allow_lds(k_tri_step, lds_step))) return rc;
     if ((rc = allow_lds(k_tri_last, lds_step))) return rc;
     if ((rc = allow_lds(k_tri_step_reg, lds_step))) return rc;
-    for (int k = 0; k < n - 2; ++k) {
+    // the last TAIL_MAX rows in one workgroup (WC_EIG_TAIL=0: every column its own launch)
+    static const bool use_tail = [] { const char *s = getenv("WC_EIG_TAIL"); return !(s && s[0] == '0'); }();
+    const int k_split = use_tail ? std::max(0, n - TAIL_MAX) : n - 2;
+    for (int k = 0; k < k_split; ++k) {
         const int m = n - k - 1;
         const unsigned grid = (unsigned)std::min(256, std::max(1, (m + 7) / 8));
         if (n <= 1024)
@@ -628,8 +750,15 @@ int sym_eigh_leading(wc_ctx *ctx, const double *matrix_dev, int64_t n64, int n_p
         else
             hipLaunchKernelGGL(k_tri_step, dim3(grid), dim3(256), lds_step, stream, A, V, P, d, e, tau, n, k);
     }
-    hipLaunchKernelGGL(k_tri_last, dim3(1), dim3(256), lds_step, stream, (const double *)A, (const double *)V,
-                       (const double *)P, d, e, (const double *)tau, n);
+    if (use_tail) {
+        const size_t lds_tail = sizeof(double) * ((size_t)TAIL_MAX * TAIL_LD + 5 * TAIL_MAX);
+        if ((rc = allow_lds(k_tri_tail, lds_tail))) return rc;
+        hipLaunchKernelGGL(k_tri_tail, dim3(1), dim3(TAIL_THREADS), lds_tail, stream, (const double *)A, V,
+                           (const double *)P, d, e, tau, n, k_split);
+    } else {
+        hipLaunchKernelGGL(k_tri_last, dim3(1), dim3(256), lds_step, stream, (const double *)A, (const double *)V,
+                           (const double *)P, d, e, (const double *)tau, n);
+    }
     const size_t lds_vals = sizeof(double) * 2 * (size_t)n;
     if ((rc = allow_lds(k_tri_eigvals, lds_vals))) return rc;
     hipLaunchKernelGGL(k_tri_eigvals, dim3((unsigned)n_pairs), dim3(EV_THREADS), lds_vals, stream, (const double *)d,

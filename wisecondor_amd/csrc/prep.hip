@@ -39,30 +39,61 @@ __global__ void k_prep_mask(const int *__restrict__ counts, int64_t S, int64_t B
     mask[g] = sum > 0.0;
 }
 
-// maskedData[b, s] = counts[s, m2g[b]] / total[s]; tdata[s, b] the same transposed
-__global__ void k_prep_normalize(const int *__restrict__ counts, int64_t S, int64_t Btot, const int *__restrict__ m2g,
-                                 int64_t B, const double *__restrict__ totals, double *__restrict__ masked,
-                                 double *__restrict__ tdata) {
-    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t s = blockIdx.y;
-    if (b >= B) return;
-    double v = (double)counts[s * Btot + m2g[b]] / totals[s];
-    masked[b * S + s] = v;
-    tdata[s * B + b] = v;
-}
-
-// mean over samples: tData is the transposed VIEW of maskedData (wisetools.py:90), so
-// numpy's axis-0 mean runs along the contiguous sample axis of maskedData[b, :], i.e. a
-// pairwise sum per bin; then centre
-__global__ void k_prep_centre(const double *__restrict__ masked, const double *__restrict__ tdata, int64_t S,
-                              int64_t B, double *__restrict__ mean, double *__restrict__ xc) {
-    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    const double *row = masked + b * S;
-    const double sum = wc::pairwise_sum<false>([&](int64_t s) { return row[s]; }, S, 0);
-    const double m = sum / (double)S;
-    mean[b] = m;
-    for (int64_t s = 0; s < S; ++s) xc[s * B + b] = tdata[s * B + b] - m;
+// maskedData[b, s] = counts[s, m2g[b]] / total[s], tdata[s, b] the same transposed, the per-bin mean
+// and the centred matrix xc[s, b], in ONE pass: a workgroup takes NB neighbouring bins for all
+// samples through LDS (row stride S | 1: the transposed reads are conflict free), so every
+// global access is a contiguous run -- whole rows of maskedData, NB x 8 bytes of the three
+// [samples, bins] arrays -- where the two per-element kernels before it wrote one double per
+// 4.8 KB stride (0.97 -> 0.3 ms at 600 x 50 kb).  The mean is numpy's: tData is the transposed
+// VIEW of maskedData (wisetools.py:90), so the axis-0 mean runs along the contiguous sample axis
+// of maskedData[b, :], a pairwise sum per bin -- walked by eight lanes per bin.
+__global__ __launch_bounds__(256, 2) void k_prep_norm_centre(const int *__restrict__ counts, int64_t S, int64_t Btot,
+                                                          const int *__restrict__ m2g, int64_t B,
+                                                          const double *__restrict__ totals, int NB,
+                                                          double *__restrict__ masked, double *__restrict__ tdata,
+                                                          double *__restrict__ mean, double *__restrict__ xc) {
+    extern __shared__ double tile[];
+    __shared__ double sh_mean[32];
+    const int64_t b0 = (int64_t)blockIdx.x * NB;
+    const int nb = (int)(B - b0 < NB ? B - b0 : NB);
+    const int64_t ld = S | 1;
+    const int tid = threadIdx.x;
+    const int i = tid % NB, s0 = tid / NB, sstep = 256 / NB;
+    if (i < nb) {
+        const int64_t g = m2g[b0 + i];
+        int64_t s = s0;
+        for (; s + 3 * sstep < S; s += 4 * sstep) {          // four rows' loads in flight per thread
+            int c[4];
+            double tt[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { c[u] = counts[(s + u * sstep) * Btot + g]; tt[u] = totals[s + u * sstep]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) tile[i * ld + s + u * sstep] = (double)c[u] / tt[u];
+        }
+        for (; s < S; s += sstep) tile[i * ld + s] = (double)counts[s * Btot + g] / totals[s];
+    }
+    __syncthreads();
+    for (int r = 0; r < nb; ++r)
+        for (int64_t s = tid; s < S; s += 256) masked[(b0 + r) * S + s] = tile[r * ld + s];
+    {
+        const int grp = tid >> 3, sub = tid & 7;
+        const int r = grp < nb ? grp : 0;         // (whole waves walk the tree together)
+        const double sum = wc::pairwise_sum<true>([&](int64_t s) { return tile[r * ld + s]; }, S, sub);
+        if (grp < nb && sub == 0) {
+            const double m = sum / (double)S;
+            sh_mean[grp] = m;
+            mean[b0 + grp] = m;
+        }
+    }
+    __syncthreads();
+    if (i < nb) {
+        const double m = sh_mean[i];
+        for (int64_t s = s0; s < S; s += sstep) {
+            const double v = tile[i * ld + s];
+            tdata[s * B + b0 + i] = v;
+            xc[s * B + b0 + i] = v - m;
+        }
+    }
 }
 
 // Gram matrix G[s, t] = sum_b xc[s, b] * xc[t, b] on the float64 matrix cores
@@ -344,13 +375,18 @@ int wc_newref_prep_gram(wc_ctx *ctx, const int32_t *counts, int64_t n_samples, i
     double *G = ts.z.as<double>(), *mean = G + S * S + 8 * S + 8 * B;
     ts.sel_host.clear();      // the test path caches its chromosome selection in this buffer: not valid any more
     WC_HIP(hipMemcpy(ts.sel.p, m2g.data(), sizeof(int) * B, hipMemcpyHostToDevice));
-    dim3 gb((unsigned)cdiv(B, 256), (unsigned)S);
-    hipLaunchKernelGGL(k_prep_normalize, gb, dim3(256), 0, nullptr, (const int *)ts.counts.as<int>(), S, Btot,
-                       (const int *)ts.sel.as<int>(), B, (const double *)ts.totals.as<double>(), ts.raw.as<double>(),
-                       ts.data.as<double>());
-    hipLaunchKernelGGL(k_prep_centre, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, nullptr,
-                       (const double *)ts.raw.as<double>(), (const double *)ts.data.as<double>(), S, B, mean,
-                       ts.xt.as<double>());
+    {
+        int nbins = 32;                             // bins per workgroup: a power of two, tile <= 96 KB of LDS
+        while (nbins > 1 && (int64_t)nbins * (S | 1) * 8 > 96 * 1024) nbins >>= 1;
+        const size_t lds = sizeof(double) * (size_t)nbins * (size_t)(S | 1);
+        if (lds > 48 * 1024)
+            WC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_prep_norm_centre),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_prep_norm_centre, dim3((unsigned)cdiv(B, nbins)), dim3(256), lds, nullptr,
+                           (const int *)ts.counts.as<int>(), S, Btot, (const int *)ts.sel.as<int>(), B,
+                           (const double *)ts.totals.as<double>(), nbins, ts.raw.as<double>(), ts.data.as<double>(), mean,
+                           ts.xt.as<double>());
+    }
     {
         // lower triangle of 64 x 64 tiles x bin slices: about 2 000 workgroups, slices of whole panels
         std::vector<int2> tiles;
