@@ -34,6 +34,26 @@ def test_random_symmetric(n):
     _check(a + a.T, min(3, n), vec_tol=1e-10)
 
 
+def test_largest_order():
+    """4 096 is the limit of the prep step (and of this solver): the 96 KB LDS configuration of the
+    column kernel, the 1 024-thread back-transformation."""
+    rng = np.random.default_rng(4096)
+    a = rng.standard_normal((4096, 4096))
+    _check(a + a.T, 3, vec_tol=1e-9, val_tol=1e-12)
+
+
+def test_random_sizes_and_pair_counts():
+    """Sizes on both sides of every switch (one-workgroup tail at 128, register form up to 1 024,
+    LDS or global work arrays) with 1..8 wanted pairs; WC_SWEEP scales the number of cases."""
+    rng = np.random.default_rng(99)
+    cases = 12 * max(1, int(os.environ.get("WC_SWEEP", "1")))
+    for _ in range(cases):
+        n = int(rng.choice([rng.integers(3, 12), rng.integers(120, 140), rng.integers(3, 700), rng.integers(1000, 1100)]))
+        k = int(rng.integers(1, min(8, n) + 1))
+        a = rng.standard_normal((n, n)) * rng.choice([1e-8, 1.0, 1e6])
+        _check(a + a.T, k, vec_tol=1e-9 if n > 8 else None, val_tol=1e-12)
+
+
 @pytest.mark.parametrize("n,bins", [(100, 4000), (300, 12000), (600, 30000)])
 def test_gram_like_spectrum(n, bins):
     """One systematic component on top of Poisson-like noise: the wanted second and third
