@@ -110,7 +110,11 @@ constexpr int SY_T = 64, SY_KB = 32, SY_LD = SY_KB + 2;
 __global__ __launch_bounds__(256) void k_prep_syrk(const double *__restrict__ xc, int64_t S, int64_t B,
                                                    const int2 *__restrict__ tiles, int64_t bins_per_slice,
                                                    double *__restrict__ partial) {
-    __shared__ __attribute__((aligned(16))) double As[SY_T * SY_LD], Bs[SY_T * SY_LD];
+    // two LDS stages: the next panel's global loads are issued before the current panel's 32 MFMAs
+    // per wave and land in the other stage after them -- one barrier per panel, the memory latency
+    // under the matrix-core time (single-staged: load, barrier, store, barrier, multiply; 0.30 of
+    // the float64 matrix-core time the tiles need)
+    __shared__ __attribute__((aligned(16))) double As[2][SY_T * SY_LD], Bs[2][SY_T * SY_LD];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int2 tile = tiles[blockIdx.x];
     const int64_t s0 = (int64_t)tile.x * SY_T, t0 = (int64_t)tile.y * SY_T;
@@ -126,8 +130,8 @@ __global__ __launch_bounds__(256) void k_prep_syrk(const double *__restrict__ xc
     const int lr = tid >> 2, lc = (tid & 3) * 8;          // this thread's row and first column of a panel
     const bool a_row = s0 + lr < S, b_row = t0 + lr < S;
     const double *ga = xc + (a_row ? s0 + lr : 0) * B, *gb = xc + (b_row ? t0 + lr : 0) * B;
-    for (int64_t b0 = b_lo; b0 < b_hi; b0 += SY_KB) {
-        double va[8], vb[8];
+    double va[8], vb[8];
+    auto fetch = [&](int64_t b0) {
         if (b0 + lc + 8 <= b_hi && (((b0 + lc) & 1) == 0) && ((B & 1) == 0)) {
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {
@@ -143,26 +147,38 @@ __global__ __launch_bounds__(256) void k_prep_syrk(const double *__restrict__ xc
                 vb[e] = in ? gb[b0 + lc + e] : 0.0;
             }
         }
-        __syncthreads();                                  // the previous panel's fragment reads are done
+    };
+    auto stash = [&](int stage) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            As[lr * SY_LD + lc + e] = a_row ? va[e] : 0.0;
-            Bs[lr * SY_LD + lc + e] = b_row ? vb[e] : 0.0;
+            As[stage][lr * SY_LD + lc + e] = a_row ? va[e] : 0.0;
+            Bs[stage][lr * SY_LD + lc + e] = b_row ? vb[e] : 0.0;
         }
-        __syncthreads();
+    };
+    if (b_lo < b_hi) {
+        fetch(b_lo);
+        stash(0);
+    }
+    __syncthreads();
+    int stage = 0;
+    for (int64_t b0 = b_lo; b0 < b_hi; b0 += SY_KB, stage ^= 1) {
+        const bool more = b0 + SY_KB < b_hi;
+        if (more) fetch(b0 + SY_KB);
 #pragma unroll
         for (int kk = 0; kk < SY_KB; kk += 4) {
             double fa[2], fb[2];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) fa[m] = As[(wr + 16 * m + fi) * SY_LD + kk + fk];
+            for (int m = 0; m < 2; ++m) fa[m] = As[stage][(wr + 16 * m + fi) * SY_LD + kk + fk];
 #pragma unroll
-            for (int n = 0; n < 2; ++n) fb[n] = Bs[(wc + 16 * n + fi) * SY_LD + kk + fk];
+            for (int n = 0; n < 2; ++n) fb[n] = Bs[stage][(wc + 16 * n + fi) * SY_LD + kk + fk];
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[m], fb[n], acc[m][n], 0, 0, 0);
         }
+        if (more) stash(stage ^ 1);
+        __syncthreads();
     }
     double *out = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (SY_T * SY_T);
 #pragma unroll
@@ -189,50 +205,99 @@ __global__ __launch_bounds__(256) void k_prep_gram_reduce(const double *__restri
     G[t * S + s] = sum;
 }
 
-// components[c, b] = sum_s w[c, s] * xc[s, b]   (w = eigenvector / singular value)
-__global__ void k_prep_components(const double *__restrict__ xc, int64_t S, int64_t B, const double *__restrict__ w,
-                                  int n_comp, double *__restrict__ comp) {
-    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+// comp[c, b] = sum_s w[c, s] * xc[s, b]: the principal axes from the sample-space eigenvectors
+// (w = eigenvector / sigma).  64 bins x 16 sample groups per workgroup: every group walks a
+// sixteenth of the samples (one read of its part of the column for all components), the sixteen
+// partial sums of a bin are added in group order.  (One thread per bin walking all samples kept
+// 0.9 waves per SIMD busy: 0.32 ms for one pass over 277 MB at 600 x 50 kb; this form 0.06.)
+__global__ __launch_bounds__(1024) void k_prep_components(const double *__restrict__ xc, int64_t S, int64_t B,
+                                                          const double *__restrict__ w, int n_comp,
+                                                          double *__restrict__ comp) {
+    __shared__ double sh[16][64];
+    const int x = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int64_t b = (int64_t)blockIdx.x * 64 + x;
     double acc[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) acc[c] = 0.0;
-    for (int64_t s = 0; s < S; ++s) {                    // one read of the column for all components
-        const double v = xc[s * B + b];
+    if (b < B)
+        for (int64_t s = g; s < S; s += 16) {
+            const double v = xc[s * B + b];
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
-            if (c < n_comp) acc[c] += w[(int64_t)c * S + s] * v;
+            for (int c = 0; c < 8; ++c)
+                if (c < n_comp) acc[c] += w[(int64_t)c * S + s] * v;
+        }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        if (c >= n_comp) break;
+        sh[g][x] = acc[c];
+        __syncthreads();
+        if (g == 0 && b < B) {
+            double sum = 0.0;
+            for (int q = 0; q < 16; ++q) sum += sh[q][x];
+            comp[(int64_t)c * B + b] = sum;
+        }
+        __syncthreads();
     }
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-        if (c < n_comp) comp[(int64_t)c * B + b] = acc[c];
 }
 
-// transformed[s, c] = sum_b xc[s, b] * comp[c, b]  (pca.transform, wisetools.py:94)
-__global__ __launch_bounds__(256) void k_prep_transform(const double *__restrict__ xc, int64_t B,
-                                                        const double *__restrict__ comp, int n_comp,
-                                                        double *__restrict__ tr) {
-    __shared__ double sh[8][256];
+// scikit-learn's svd_flip (v based): the entry of largest magnitude of every component becomes
+// positive (the first one on ties, like numpy's argmax).  One workgroup per component.
+__global__ __launch_bounds__(1024) void k_prep_sign(double *__restrict__ comp, int64_t B) {
+    __shared__ double s_abs[16];
+    __shared__ long long s_idx[16];
+    __shared__ int s_flip;
+    double *row = comp + (int64_t)blockIdx.x * B;
+    double best = -1.0;
+    long long at = 0;
+    for (int64_t b = threadIdx.x; b < B; b += 1024) {
+        const double v = fabs(row[b]);
+        if (v > best) { best = v; at = b; }              // ascending b per thread: the first maximum stays
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o);
+        const long long oa = __shfl_xor(at, o);
+        if (ob > best || (ob == best && oa < at)) { best = ob; at = oa; }
+    }
+    if ((threadIdx.x & 63) == 0) { s_abs[threadIdx.x >> 6] = best; s_idx[threadIdx.x >> 6] = at; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 1; q < 16; ++q)
+            if (s_abs[q] > best || (s_abs[q] == best && s_idx[q] < at)) { best = s_abs[q]; at = s_idx[q]; }
+        s_flip = row[at] < 0.0;
+    }
+    __syncthreads();
+    if (s_flip)
+        for (int64_t b = threadIdx.x; b < B; b += 1024) row[b] = -row[b];
+}
+
+// transformed[s, c] = sum_b xc[s, b] * comp[c, b]  (pca.transform, wisetools.py:94); one workgroup of
+// sixteen waves per sample
+__global__ __launch_bounds__(1024) void k_prep_transform(const double *__restrict__ xc, int64_t B,
+                                                         const double *__restrict__ comp, int n_comp,
+                                                         double *__restrict__ tr) {
+    __shared__ double sh[8][16];
     const double *x = xc + (int64_t)blockIdx.x * B;
     double acc[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) acc[c] = 0.0;
-    for (int64_t b = threadIdx.x; b < B; b += 256) {
+    for (int64_t b = threadIdx.x; b < B; b += 1024) {
         double v = x[b];
 #pragma unroll
         for (int c = 0; c < 8; ++c)
             if (c < n_comp) acc[c] += v * comp[(int64_t)c * B + b];
     }
 #pragma unroll
-    for (int c = 0; c < 8; ++c) sh[c][threadIdx.x] = acc[c];
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o)
-#pragma unroll
-            for (int c = 0; c < 8; ++c) sh[c][threadIdx.x] += sh[c][threadIdx.x + o];
-        __syncthreads();
+    for (int c = 0; c < 8; ++c) {
+        double a = acc[c];
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+        if ((threadIdx.x & 63) == 0) sh[c][threadIdx.x >> 6] = a;
     }
-    if ((int)threadIdx.x < n_comp) tr[(int64_t)blockIdx.x * 8 + threadIdx.x] = sh[threadIdx.x][0];
+    __syncthreads();
+    if ((int)threadIdx.x < n_comp) {
+        double sum = 0.0;
+        for (int q = 0; q < 16; ++q) sum += sh[threadIdx.x][q];
+        tr[(int64_t)blockIdx.x * 8 + threadIdx.x] = sum;
+    }
 }
 
 // corrected_t[s, b] = tdata[s, b] / (transformed[s, :] . comp[:, b] + mean[b])  (wisetools.py:95-96)
@@ -441,22 +506,14 @@ static int prep_finish_body(wc_ctx *ctx, int n_comp, const double *eigvecs, cons
         for (int64_t s = 0; s < S; ++s) hw[(size_t)c * S + s] = eigvecs[(size_t)c * S + s] * inv_sigma;
     }
     WC_HIP(hipMemcpy(w, hw.data(), sizeof(double) * 8 * S, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_prep_components, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, nullptr,
+    hipLaunchKernelGGL(k_prep_components, dim3((unsigned)cdiv(B, 64)), dim3(1024), 0, nullptr,
                        (const double *)ts.xt.as<double>(), S, B, (const double *)w, n_comp, comp);
-    // scikit-learn's svd_flip (v based): the largest |entry| of every component is positive
-    hc.resize((size_t)n_comp * B);
-    WC_HIP(hipMemcpy(hc.data(), comp, sizeof(double) * n_comp * B, hipMemcpyDeviceToHost));
-    for (int c = 0; c < n_comp; ++c) {
-        double *row = hc.data() + (size_t)c * B;
-        int64_t arg = 0;
-        for (int64_t b = 1; b < B; ++b)
-            if (fabs(row[b]) > fabs(row[arg])) arg = b;
-        if (row[arg] < 0.0)
-            for (int64_t b = 0; b < B; ++b) row[b] = -row[b];
-    }
-    WC_HIP(hipMemcpy(comp, hc.data(), sizeof(double) * n_comp * B, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_prep_transform, dim3((unsigned)S), dim3(256), 0, nullptr, (const double *)ts.xt.as<double>(),
+    hipLaunchKernelGGL(k_prep_sign, dim3((unsigned)n_comp), dim3(1024), 0, nullptr, comp, B);
+    hipLaunchKernelGGL(k_prep_transform, dim3((unsigned)S), dim3(1024), 0, nullptr, (const double *)ts.xt.as<double>(),
                        B, (const double *)comp, n_comp, ts.proj.as<double>());
+    // the host copy of the components travels while the rest runs (the callers synchronise)
+    hc.resize((size_t)n_comp * B);
+    WC_HIP(hipMemcpyAsync(hc.data(), comp, sizeof(double) * n_comp * B, hipMemcpyDeviceToHost, nullptr));
     if (want_t) {
         dim3 gb((unsigned)cdiv(B, 256), (unsigned)S);
         hipLaunchKernelGGL(k_prep_correct, gb, dim3(256), 0, nullptr, (const double *)ts.data.as<double>(), B,
@@ -507,9 +564,9 @@ int wc_newref_prep_finish_dev(wc_ctx *ctx, int n_comp, const double *eigvecs, co
     }
     if (masked_dev)
         WC_HIP(hipMemcpyAsync(masked_dev, ts.raw.p, sizeof(double) * B * S, hipMemcpyDeviceToDevice, nullptr));
-    if (pca_components_out) memcpy(pca_components_out, hc.data(), sizeof(double) * n_comp * B);
     if (pca_mean_out) WC_HIP(hipMemcpy(pca_mean_out, mean, sizeof(double) * B, hipMemcpyDeviceToHost));
     WC_HIP(hipDeviceSynchronize());
+    if (pca_components_out) memcpy(pca_components_out, hc.data(), sizeof(double) * n_comp * B);   // (its copy has landed)
     return WC_OK;
 }
 
