@@ -52,6 +52,12 @@ json.dump({"what": "one latency-mode test call (one 250 kb sample) under rocprof
            "span_us_first_start_to_last_end": sum(c[1] for c in same) / len(same)}, open(sys.argv[2], "w"), indent=1)
 print(open(sys.argv[2]).read())
 PY
+# newref prep at 600 x 50 kb (Gram, eigen-solve on the GPU, finish): kernel statistics and the eigen-solver's timings
+( cd /tmp && export TMPDIR=/tmp
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof_${TAG}_prep" -o t -- python3 "$REPO/tools/gpu_prep_time.py" cfg4 > "$OUT/prep_run.log" 2>&1 )
+cp "$(find gpurun_out/prof_${TAG}_prep -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_prep_cfg4_kernel_stats.csv"
+python3 tools/gpu_prep_time.py cfg4 > "$OUT/${TAG}_prep_cfg4_times.txt"
+python3 tools/gpu_eig_time.py 100 300 600 1000 1200 2400 > "$OUT/${TAG}_eig_times.json" 2> /dev/null
 # busy / cache counters of the newref kernels (one pass per counter set)
 bash tools/pmc_run.sh ${TAG}A_cfg2 "SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" tools/gpu_newref_only.py cfg2 10 > "$OUT/pmcA_cfg2.log" 2>&1
 bash tools/pmc_run.sh ${TAG}A_cfg4 "SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" tools/gpu_newref_only.py cfg4 3 > "$OUT/pmcA_cfg4.log" 2>&1
