@@ -27,6 +27,7 @@ struct NewrefState {
     wc::DevBuf sample_rows, sample_slot, s32, s_norm_lo, s_chrom, s_range, a16, s16;
     wc::DevBuf keys1, thr, cnt, list, tiles;
     wc::DevBuf fb_rows, fb_count, fb_scratch, stats, tiles0, pw_prog, pairs, x64, m2;
+    bool fb_dirty = true;       // fb_count holds a finished pass's counts (k_convert zeroes it for the next job)
     int64_t s_pad = 0;      // samples padded to whole 16-sample chunks (x64 row stride)
     bool exact_only = false; // refsize beyond the candidate lists' design size: every row takes the exact path
     bool x64_pad = false;   // the padded float64 image exists (pair engine usable)

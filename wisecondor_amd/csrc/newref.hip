@@ -147,9 +147,14 @@ __global__ __launch_bounds__(256) void k_convert(const double *__restrict__ X, i
                                                  int *__restrict__ s_chrom, int2 *__restrict__ s_range,
                                                  float *__restrict__ thr, int *__restrict__ cnt,
                                                  int *__restrict__ row_stat, unsigned short *__restrict__ A3,
-                                                 double *__restrict__ X64, int64_t Sp, float *__restrict__ m2_out) {
+                                                 double *__restrict__ X64, int64_t Sp, float *__restrict__ m2_out,
+                                                 int *__restrict__ fb_zero, int n_fb_zero) {
     int lane = threadIdx.x & 63;
     int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // the exact path's counter and tickets of the job that starts here (was a memset launch in front of
+    // the pick stage of every pass)
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < n_fb_zero; i += 256) fb_zero[i] = 0;
     if (row >= Bpad) return;
     // float64 image with rows padded to whole 16-sample chunks (128-byte aligned rows, zero
     // padding): the re-score gathers read it with aligned 16-byte loads and no tail cases
@@ -2302,10 +2307,12 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
                        st.s16.as<unsigned short>(), st.s_norm_lo.as<float>(), st.s_chrom.as<int>(),                \
                        st.s_range.as<int2>(), st.thr.as<float>(), st.cnt.as<int>(), st.stats.as<int>(),            \
                        st.gram_mode == 1 ? st.a3.as<unsigned short>() : (unsigned short *)nullptr,                 \
-                       st.x64_pad ? st.x64.as<double>() : (double *)nullptr, st.s_pad, st.m2.as<float>())
+                       st.x64_pad ? st.x64.as<double>() : (double *)nullptr, st.s_pad, st.m2.as<float>(),          \
+                       st.fb_count.as<int>(), 4 + FB_BLOCKS)
     if (st.gram_mode == 2) WC_CONVERT(1);
     else WC_CONVERT(0);
 #undef WC_CONVERT
+    st.fb_dirty = false;
     if (M > n_bins)
         hipLaunchKernelGGL(k_pad_samples, dim3((unsigned)(M - n_bins)), dim3(256), 0, stream, st.k_pad16, n_bins,
                            st.s16.as<unsigned short>(), st.s_norm_lo.as<float>(), st.s_chrom.as<int>(),
@@ -2517,7 +2524,12 @@ static int newref_finish_part(wc_ctx *ctx, void *stream_, int64_t row_begin, int
     hipStream_t stream = (hipStream_t)stream_;
     int rc;
     if ((rc = st.fb_scratch.reserve(sizeof(uint64_t) * 2 * FB_BLOCKS * st.bins_pad))) return rc;
-    if (which & 5) WC_HIP(hipMemsetAsync(st.fb_count.p, 0, sizeof(int) * (4 + FB_BLOCKS), stream));   // the counter and the rows' tickets
+    if (which & 5) {
+        // the counter and the rows' tickets: k_convert zeroed them for the first pick of a prepared job; a second
+        // finish on the same prepared state starts from a memset
+        if (st.fb_dirty) WC_HIP(hipMemsetAsync(st.fb_count.p, 0, sizeof(int) * (4 + FB_BLOCKS), stream));
+        st.fb_dirty = true;
+    }
     FinishArgs a{};
     a.X = st.corrected;
     a.B = st.n_bins;
