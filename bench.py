@@ -42,7 +42,6 @@ PEAK_BF16_MFMA = 2500e12    # v_mfma_f32_32x32x16_bf16 / _f16 dense (no sparsity
 PEAK_HBM = 8.0e12           # bytes/s, spec (6.3e12 achievable by a copy)
 PEAK_L2 = 34.5e12           # bytes/s aggregate over the 8 XCDs
 PEAK_FP64_VALU_OPS = 39.3e12  # float64 vector add / mul / max per second (78.6 TFLOP/s counts an FMA as two)
-SPLIT_PRODUCTS = 3.0        # k_gram<split>: hi.hi + hi.lo + lo.hi per float32 multiply
 PEAK_MALL = 10.0e12         # bytes/s the Infinity Cache sustains towards the L2s (order of magnitude, MI355X_MICROARCH.md)
 ROUND = "r03"
 LATENCY_LAUNCHES = 8        # kernels of one latency-mode `test` call
@@ -367,9 +366,6 @@ GRAM_KERNELS = {
     "f16": ("k_gram_glds (symmetric distance tiles, ONE float16 matrix-core product per multiply, every row's "
             "representation error charged to its norm bounds, operand slabs by LDS-DMA, + candidate filter)", 1.0,
             PEAK_BF16_MFMA),
-    "split": ("k_gram<split> (symmetric distance tiles on the bf16 matrix cores, hi/lo operand pairs: three "
-              "products per multiply, + candidate filter)", SPLIT_PRODUCTS, PEAK_BF16_MFMA),
-    "f32": ("k_gram<f32> (symmetric fp32 MFMA distance tiles + candidate filter)", 1.0, PEAK_FP32_MFMA),
 }
 
 
@@ -544,30 +540,8 @@ def main():
     if finish_ms is None:
         finish_ms = stages.get("collected->rescored", stages.get("exchanged->rescored"))
     stats = wt.newref_stats(local_rank)
-    gram_mode = os.environ.get("WC_GRAM_MODE", "") or "f16"
-    if gram_mode not in ("f16", "split", "f32"):
-        gram_mode = "f16"
+    gram_mode = "f16"
     variants = {}
-    if world == 1:
-        # the same pass with the distance tiles in the other two forms, for the record (kernel time only):
-        # float32 matrix cores (the north-star's wording) and bf16 hi/lo pairs (round 2's default)
-        for other in ("f32", "split", "f16"):
-            if other == gram_mode:
-                continue
-            os.environ["WC_GRAM_MODE"] = other
-            job.run()
-            v_marks = []
-            for _ in range(4):
-                job.run(timing=True)
-                v_marks.append(job.last_marks)
-            torch.cuda.synchronize()
-            variants[other] = mean_stages(job, v_marks)["thresholds->collected"]
-        if gram_mode == "f16":
-            os.environ.pop("WC_GRAM_MODE", None)
-        else:
-            os.environ["WC_GRAM_MODE"] = gram_mode
-        idx, dst = job.run()                      # leave the context in the mode of the timed passes
-        torch.cuda.synchronize()
     ms_per_step = 1e3 * t_newref / args.steps
     value = pairs * args.steps / t_newref
 
@@ -705,22 +679,8 @@ def main():
             extra["k_gram_frac_of_mfma_peak"] = xprod * xflops / (xk_ms * 1e-3) / xpeak
             extra["k_gram_frac_algorithmic_vs_fp32_mfma"] = xflops / (xk_ms * 1e-3) / PEAK_FP32_MFMA
             if world == 1:
-                xvar = {}
-                for other in ("f32", "split", "f16"):
-                    if other == gram_mode:
-                        continue
-                    os.environ["WC_GRAM_MODE"] = other
-                    xjob.run()
-                    xjob.run(timing=True)
-                    torch.cuda.synchronize()
-                    xvar[other] = xjob.stage_ms()["thresholds->collected"]
-                if gram_mode == "f16":
-                    os.environ.pop("WC_GRAM_MODE", None)
-                else:
-                    os.environ["WC_GRAM_MODE"] = gram_mode
                 xidx, _ = xjob.run()
                 torch.cuda.synchronize()
-                extra["k_gram_ms_other_tile_modes"] = xvar
                 if rank == 0 and not args.no_cpu_baseline:
                     # >= 8 target rows x the full candidate set on the host
                     try:
@@ -920,10 +880,8 @@ def main():
             # every delivered index and distance is decided in float64 (numpy's bits); the matrix
             # cores only bound the distances to pick the candidates that get re-scored
             "dtype": "f64",
-            "dtype_detail": {"f16": "f16 MFMA (one product per multiply, f32 accumulate, per-row representation error "
-                                    "in the bounds) distance bounds + f64 exact re-score",
-                             "split": "bf16x3 MFMA (hi/lo pairs, f32 accumulate) distance bounds + f64 exact re-score",
-                             "f32": "f32 MFMA distance bounds + f64 exact re-score"}[gram_mode],
+            "dtype_detail": "f16 MFMA (one product per multiply, f32 accumulate, per-row representation error in the "
+                            "bounds) distance bounds + f64 exact re-score",
             "timing": "value / ms_per_step: %d plain passes between two synchronizes; stages_ms and the roofline "
                       "kernel times: %d further passes with events between the stages" % (args.steps, args.steps),
             "data": "synthetic",

@@ -85,7 +85,7 @@ int wc_get_reference_dev(wc_ctx *ctx, void *stream, const double *corrected, int
 /*
  * Multi-GPU building blocks of the same computation (one process per GPU; the
  * host exchanges `thr` / candidate lists with RCCL between the calls).
- *   stage A  wc_newref_prepare_dev    centre + f32 convert + norms (all rows)
+ *   stage A  wc_newref_prepare_dev    centre + float16 operand image + norm bounds (all rows)
  *   stage B  wc_newref_thresholds_dev per-row admission thresholds for rows
  *            [row_begin,row_end) from a fixed pseudo-random column sample
  *   stage C  wc_newref_collect_dev    symmetric MFMA distance tiles
@@ -132,6 +132,13 @@ int wc_newref_pick_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row
                        int32_t *idx_out, double *dist_out);
 int wc_newref_rescore_pairs_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end,
                                 int32_t *idx_out, double *dist_out);
+/* The exact path for EVERY row of [row_begin, row_end) of a prepared job (wc_newref_prepare_dev): float64
+ * distances to all candidates in numpy's order and the stable selection of wisetools.py:305-321, without
+ * matrix cores, bounds or candidate lists.  It is what a row takes when its certificate fails and what
+ * refsize > 256 runs for every row; exported so that callers (the full-size tests) can hold the fast path
+ * against it row by row. */
+int wc_newref_exact_dev(wc_ctx *ctx, void *stream, int64_t row_begin, int64_t row_end, int32_t *idx_out,
+                        double *dist_out);
 /* measurement helper: microseconds a chain of n dependent empty kernel launches takes on `stream`
  * (mean over reps) -- the launch floor bench.py prices the one-sample `test` latency against */
 int wc_launch_floor_us(wc_ctx *ctx, void *stream, int n, int reps, double *out);
@@ -176,8 +183,10 @@ int wc_write_test_results(int n_files, int n_threads, const char *const *out_pat
 /*
  * newref prep (upstream of the hot path): toNumpyArray's
  * normalisation + all-zero-bin mask (wisetools.py:240-264) and trainPCA
- * (wisetools.py:89-101) as a deterministic exact PCA (float64 Gram matrix on the GPU,
- * its [samples, samples] eigenproblem on the host, everything bins-sized on the GPU).
+ * (wisetools.py:89-101) as a deterministic exact PCA (float64 Gram matrix on the GPU's float64
+ * matrix cores, its [samples, samples] eigenproblem by the direct solver of csrc/eigh.hip on the GPU --
+ * wc_newref_prep_eig; callers may also solve the fetched matrix with their own LAPACK --, everything
+ * bins-sized on the GPU).
  *   counts [n_samples, n_total_bins] int32: per chromosome padded with zeros to
  *          chromosome_bins[c] (the longest sample, wisetools.py:245-250)
  *   mask_out [n_total_bins], masked_chrom_bins_out [n_chrom], *n_masked_out = B

@@ -45,6 +45,56 @@ def test_newref_600x50kb_properties(wt):
         assert np.array_equal(dst[row].view(np.uint64), d[order].view(np.uint64)), row
 
 
+@pytest.mark.parametrize("kind", ["uncorrelated", "pipeline"])
+def test_fast_path_equals_exact_path_on_every_row_600x50kb(wt, kind):
+    """BASELINE config 4 (600 samples x 50 kb, 57 633 / ~55 k masked bins): the float16-bound fast path against
+    the exact GPU path (float64 distances to every candidate in numpy's order, stable selection; pinned on the
+    reference at the sizes the reference can run) for EVERY row -- indexes and distance bits -- on the
+    kernel-level matrix (uncorrelated rows, C order: pairwise sums) and on a matrix made by the prep pipeline
+    from 600 synthetic samples (correlated rows, Fortran order: sequential sums).  wisetools.py:298-325."""
+    import torch
+    from wisecondor_amd import _lib, distributed, synth
+    if kind == "uncorrelated":
+        data, bins, _ = synth.corrected_matrix(50000, 600, seed=0)
+        order = _lib.SUM_PAIRWISE
+    else:
+        profile = synth.bin_profile(50000)
+        samples = [synth.make_sample(profile, seed=i) for i in range(600)]
+        _, _, _, data, _, _, bins = wt.prepReference(samples)
+        order = wt.sum_order_of(data)
+        assert order == _lib.SUM_SEQUENTIAL
+        del samples
+    bins = np.asarray(bins, dtype=np.int64)
+    B = data.shape[0]
+    assert B > 50000 and data.shape[1] == 600
+    X = torch.from_numpy(np.ascontiguousarray(data)).cuda()
+    job = distributed.NewrefJob(_lib.context(0), X, bins, 100, order)
+    idx, dst = job.run()
+    torch.cuda.synchronize()
+    stats = wt.newref_stats(0)
+    assert stats["fast_rows"] == B and stats["fallback_rows"] == 0, stats      # what is compared IS the fast path
+    idx, dst = idx.clone(), dst.clone()
+    ex_i, ex_d = torch.empty_like(idx), torch.empty_like(dst)
+    job.st.exact(0, B, ex_i, ex_d)
+    torch.cuda.synchronize()
+    bad = (idx != ex_i).any(dim=1) | (dst.view(torch.int64) != ex_d.view(torch.int64)).any(dim=1)
+    assert int(bad.sum()) == 0, torch.nonzero(bad)[:10].flatten().tolist()
+    # and the exact path itself against numpy on a few rows (it is pinned on the reference at small sizes)
+    rng = np.random.RandomState(1)
+    chrom = np.repeat(np.arange(len(bins)), bins)
+    starts = np.concatenate([[0], np.cumsum(bins)])
+    host_i, host_d = ex_i.cpu().numpy(), ex_d.cpu().numpy()
+    lay = np.asfortranarray(data) if order == _lib.SUM_SEQUENTIAL else np.ascontiguousarray(data)
+    for row in rng.choice(B, 4, replace=False):
+        c = chrom[row]
+        others = np.concatenate([lay[:starts[c]], lay[starts[c + 1]:]])
+        with np.errstate(all="ignore"):
+            d = np.sum(np.power(others - lay[row], 2), 1)
+        o = np.argsort(d, kind="stable")[:100]
+        assert np.array_equal(host_i[row], o.astype(np.int32)), row
+        assert np.array_equal(host_d[row].view(np.uint64), d[o].view(np.uint64)), row
+
+
 def test_batched_test_50kb_equals_single_samples(wt):
     """cfg5's shape per GPU (here 24 samples x 50 kb): every output of the batch equals the output
     of the same sample tested alone, and a second run of the batch is bit-identical."""

@@ -199,33 +199,13 @@ def test_thresholds_are_reproducible():
     assert np.isfinite(seen[0]).all() and (seen[0] > 0).all()
 
 
-@pytest.mark.parametrize("mode", ["f16", "split", "f32"])
-@pytest.mark.parametrize("kind", ["noise", "wide", "huge", "tiny"])
-def test_listed_keys_are_lower_bounds(mode, kind, monkeypatch):
-    """Every decision of the fast path rests on key <= true distance <= key + slack_i + slack_j.
-    The candidate lists expose the keys and wc_newref_get_bounds_dev the slacks: check both sides
-    on every listed pair, for the one-product float16 tiles (default), the bf16 hi/lo tiles and
-    the float32 tiles, on plain noise, on rows whose magnitudes span four orders (16-bit operands
-    lose the low bits of large values; float16 also clamps and flushes), and on matrices far
-    outside float16's own range (1e6 and 1e-9 times the usual magnitudes: the image is scaled)."""
+def _check_listed_bounds(data, bins, order, step, kind):
+    """Run prepare / thresholds / collect on `data` and check BOTH sides of the interval on every listed pair of
+    every step-th row.  Returns (job, stages, pairs checked, worst relative key gap)."""
     import torch
-    from wisecondor_amd import _lib, distributed, synth
-    if mode == "f16":
-        monkeypatch.delenv("WC_GRAM_MODE", raising=False)
-    else:
-        monkeypatch.setenv("WC_GRAM_MODE", mode)
-    data, bins, _ = synth.corrected_matrix(1000000, 200, seed=8)
-    if kind == "wide":
-        rng = np.random.RandomState(3)
-        data = data * np.exp(rng.uniform(-4.0, 4.0, size=(data.shape[0], 1)))      # per-row scale e^-4 .. e^4
-        data += rng.standard_normal(data.shape) * 1e-3
-    elif kind == "huge":
-        data = data * 1e6
-    elif kind == "tiny":
-        data = data * 1e-9
-    data = np.ascontiguousarray(data)
-    X = torch.from_numpy(data).cuda()
-    job = distributed.NewrefJob(_lib.context(0), X, bins, 100, _lib.SUM_PAIRWISE)
+    from wisecondor_amd import _lib, distributed
+    X = torch.from_numpy(np.ascontiguousarray(data)).cuda()
+    job = distributed.NewrefJob(_lib.context(0), X, bins, 100, order)
     st = job.st
     st.prepare()
     st.thresholds(0, st.n_bins)
@@ -234,38 +214,88 @@ def test_listed_keys_are_lower_bounds(mode, kind, monkeypatch):
     cnt = torch.zeros(st.n_bins, dtype=torch.int32, device="cuda")
     lst = torch.zeros((st.n_bins, cap), dtype=torch.int64, device="cuda")
     st.export(0, st.n_bins, cap, cnt, lst)
-    torch.cuda.synchronize()
     lo_t = torch.zeros(st.n_bins, dtype=torch.float32, device="cuda")
     slack_t = torch.zeros(st.n_bins, dtype=torch.float32, device="cuda")
     st.get_bounds(0, st.n_bins, lo_t, slack_t)
     torch.cuda.synchronize()
     slack = slack_t.cpu().numpy().astype(np.float64)
     cnt = cnt.cpu().numpy()
-    lst = lst.cpu().numpy().view(np.uint64)
-    checked = 0
-    worst = 0.0
-    for i in range(0, st.n_bins, 7):
-        n = min(int(cnt[i]), cap)
-        if n == 0:
-            continue
-        e = lst[i, :n]
-        j = (e & np.uint64(0xFFFFFFFF)).astype(np.int64)
-        u = (e >> np.uint64(32)).astype(np.uint32)
-        bits = np.where(u & np.uint32(0x80000000), u & np.uint32(0x7FFFFFFF), ~u)
-        key = bits.astype(np.uint32).view(np.float32).astype(np.float64)
-        d = ((data[j] - data[i]) ** 2).sum(1)
-        assert (key <= d * (1 + 1e-12) + 1e-300).all(), (mode, kind, i)
-        assert (d <= key + (slack[i] + slack[j]) * (1 + 1e-12) + 1e-300).all(), (mode, kind, i)
-        scale = (data[j] ** 2).sum(1) + (data[i] ** 2).sum()
-        worst = max(worst, float(((d - key) / np.maximum(scale, 1e-300)).max()))
-        checked += n
+    rows = np.arange(0, st.n_bins, step)
+    lst = lst[torch.from_numpy(rows).cuda()].cpu().numpy().view(np.uint64)
+    checked, worst = 0, 0.0
+    with np.errstate(all="ignore"):
+        for at, i in enumerate(rows):
+            n = min(int(cnt[i]), cap)
+            if n == 0:
+                continue
+            e = lst[at, :n]
+            j = (e & np.uint64(0xFFFFFFFF)).astype(np.int64)
+            u = (e >> np.uint64(32)).astype(np.uint32)
+            bits = np.where(u & np.uint32(0x80000000), u & np.uint32(0x7FFFFFFF), ~u)
+            key = bits.astype(np.uint32).view(np.float32).astype(np.float64)
+            d = ((data[j] - data[i]) ** 2).sum(1)
+            ok = np.isfinite(d)                      # a non-finite distance is never admitted, whatever its key says
+            assert (key[ok] <= d[ok] * (1 + 1e-12) + 1e-300).all(), (kind, i)
+            hi = key + (slack[i] + slack[j]) * (1 + 1e-12) + 1e-300
+            assert (d[ok] <= hi[ok]).all(), (kind, i)
+            scale = (data[j] ** 2).sum(1) + (data[i] ** 2).sum()
+            gap = ((d - key) / np.maximum(scale, 1e-300))[ok & np.isfinite(key)]
+            if gap.size:
+                worst = max(worst, float(gap.max()))
+            checked += n
+    return job, st, checked, worst
+
+
+def _spoil(data, kind, seed=3):
+    """The data kinds of the bound tests (in place on a copy)."""
+    rng = np.random.RandomState(seed)
+    data = data.copy()
+    B, S = data.shape
+    if kind == "wide":
+        data = data * np.exp(rng.uniform(-4.0, 4.0, size=(B, 1)))      # per-row scale e^-4 .. e^4
+        data += rng.standard_normal(data.shape) * 1e-3
+    elif kind == "huge":
+        data = data * 1e6
+    elif kind == "tiny":
+        data = data * 1e-9
+    elif kind == "clamped":
+        # values far beyond +-65504 / gam (the float16 image clamps them): single spikes, whole outlier rows
+        # and one outlier SAMPLE column; the rows concerned lose their certificate, their bounds must still hold
+        rows = rng.choice(B, 40, replace=False)
+        data[rows[:20], rng.randint(0, S, 20)] += 1e4 * rng.choice([-1.0, 1.0], 20)
+        data[rows[20:30]] *= 5e4
+        data[rows[30:], :] = 1.0 + 3e5 * rng.standard_normal((10, S))
+        data[:, S // 2] += 50.0 * (rng.rand(B) < 0.01)
+    elif kind == "flushed":
+        # centred values below the float16 subnormal flush (|a| gam < 6.1e-5): rows that are constant up to 1e-7
+        # of the usual spread, and rows that mix such entries with normal ones
+        rows = rng.choice(B, 60, replace=False)
+        data[rows[:30]] = 1.0 + 2e-9 * rng.standard_normal((30, S))
+        mix = rng.rand(30, S) < 0.5
+        data[rows[30:]] = np.where(mix, 1.0 + 2e-9 * rng.standard_normal((30, S)), data[rows[30:]])
+    return data
+
+
+@pytest.mark.parametrize("kind", ["noise", "wide", "huge", "tiny", "clamped", "flushed"])
+def test_listed_keys_are_lower_bounds(kind):
+    """Every decision of the fast path rests on key <= true distance <= key + slack_i + slack_j.
+    The candidate lists expose the keys and wc_newref_get_bounds_dev the slacks: check both sides
+    on every listed pair of the one-product float16 tiles, on plain noise, on rows whose magnitudes
+    span four orders (16-bit operands lose the low bits of large values), on matrices far outside
+    float16's own range (1e6 and 1e-9 times the usual magnitudes: the image is scaled), with values
+    the image clamps (beyond +-65504 / gam) and with values it flushes to zero."""
+    import torch
+    from wisecondor_amd import _lib, synth
+    data, bins, _ = synth.corrected_matrix(1000000, 200, seed=8)
+    data = _spoil(data, kind)
+    job, st, checked, worst = _check_listed_bounds(data, bins, _lib.SUM_PAIRWISE, 7, kind)
     assert checked > 10000
     # the slack relative to |a|^2 + |b|^2 of the raw rows; on plain noise the kernel's centred rows
     # have smaller norms than the raw ones, so this is far inside 3 * beta (the wide case centres
     # rows of very different scale on one common centre: no such yardstick)
     if kind == "noise":
         assert worst < 1e-3
-    if kind != "wide":
+    if kind in ("noise", "huge", "tiny"):
         # the fast path must actually carry these rows: a bound so loose that everything falls back
         # to the exact scan would pass the checks above
         from wisecondor_amd import wisetools as wt
@@ -275,3 +305,41 @@ def test_listed_keys_are_lower_bounds(mode, kind, monkeypatch):
         assert stats["fallback_rows"] == 0 and stats["fast_rows"] == st.n_bins, stats
         assert stats["rescored"] < 1.25 * 100 * st.n_bins, stats       # ~k candidates per row, not the whole list
 
+
+@pytest.mark.parametrize("kind", ["noise", "pipeline", "clamped", "flushed"])
+def test_listed_keys_are_lower_bounds_at_600_samples(kind):
+    """The same interval at the sample count the headline configuration trusts it at (600 samples change
+    beta, the accumulation chain and the clamp statistics), 28 783 bins (100 kb): plain noise, a matrix made by
+    the prep pipeline (correlated rows, Fortran order), clamped and flushed values.  On the clean kinds the whole
+    result is then held against the exact path for every row."""
+    import torch
+    from wisecondor_amd import _lib, synth
+    from wisecondor_amd import wisetools as wt
+    if kind == "pipeline":
+        profile = synth.bin_profile(100000)
+        samples = [synth.make_sample(profile, seed=i) for i in range(600)]
+        _, _, _, data, _, _, bins = wt.prepReference(samples)
+        bins = np.asarray(bins, dtype=np.int64)
+        order = wt.sum_order_of(data)
+        assert order == _lib.SUM_SEQUENTIAL
+        data = np.ascontiguousarray(data)
+    else:
+        data, bins, _ = synth.corrected_matrix(100000, 600, seed=11)
+        data = _spoil(data, kind, seed=5)
+        order = _lib.SUM_PAIRWISE
+    assert data.shape[0] >= 20000 and data.shape[1] == 600
+    job, st, checked, worst = _check_listed_bounds(data, bins, order, 61, kind)
+    assert checked > 100000
+    idx, dst = job.run()
+    torch.cuda.synchronize()
+    stats = wt.newref_stats()
+    if kind in ("noise", "pipeline"):
+        assert stats["fallback_rows"] == 0 and stats["fast_rows"] == st.n_bins, stats
+    else:
+        assert 0 < stats["fallback_rows"] < 2000, stats       # the spoiled rows (and their victims) take the exact path
+    idx, dst = idx.clone(), dst.clone()
+    ex_i, ex_d = torch.empty_like(idx), torch.empty_like(dst)
+    st.exact(0, st.n_bins, ex_i, ex_d)
+    torch.cuda.synchronize()
+    assert torch.equal(idx, ex_i)
+    assert torch.equal(dst.view(torch.int64), ex_d.view(torch.int64))

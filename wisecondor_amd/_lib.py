@@ -41,6 +41,7 @@ SIGNATURES = {
     "wc_newref_fallback_dev": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "wc_newref_pick_dev": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "wc_newref_rescore_pairs_dev": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "wc_newref_exact_dev": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "wc_launch_floor_us": (_i32, [_vp, _vp, _i32, _i32, _vp]),
     "wc_read_samples": (_i32, [_vp, _i32, _i32, _vp, _i32, _dbl, _vp, _i64, _vp, _vp]),
     "wc_read_sample_lengths": (_i32, [_vp, _i32, _i32, _i32, _dbl, _vp, _vp, _vp]),

@@ -8,8 +8,7 @@ struct NewrefState {
     // problem
     int64_t n_bins = 0, n_samples = 0;
     int64_t bins_pad = 0;   // rows padded to the 128-row tile
-    int64_t k_pad = 0;      // samples padded to the 32-wide k-slab
-    int64_t k_pad16 = 0;    // samples padded to the 64-wide bf16 k-slab
+    int64_t k_pad16 = 0;    // samples padded to the 64-wide float16 k-slab of the threshold tiles
     int n_chrom = 0, k = 0, sum_order = 0;
     int64_t chrom_off[WC_MAX_CHROM + 1] = {0};
     const double *corrected = nullptr;  // device, caller owned
@@ -19,11 +18,9 @@ struct NewrefState {
     int64_t expect = 0;             // expected candidates per row under the sampled threshold
     float beta = 0.f;               // relative half-width of the key error interval
     bool prepared = false;
-    bool split = false;             // distance tiles on the bf16 matrix cores with hi/lo operand pairs
-    int gram_mode = 2;              // 0 float32 matrix cores, 1 bf16 hi/lo pairs, 2 one float16 product (default)
-    double tau = 0.0;               // f16 mode: weight of the representation-error split (k_convert)
+    double tau = 0.0;               // weight of the float16 representation-error split (k_convert)
     // device buffers
-    wc::DevBuf a3, col_partial, col_mean, a32, norm_lo, norm_hi, chrom_of_row, chrom_range, chrom_off_dev;
+    wc::DevBuf col_partial, col_mean, norm_lo, norm_hi, chrom_of_row, chrom_range, chrom_off_dev;
     wc::DevBuf sample_rows, sample_slot, s32, s_norm_lo, s_chrom, s_range, a16, s16;
     wc::DevBuf keys1, thr, cnt, list, tiles;
     wc::DevBuf fb_rows, fb_count, fb_scratch, stats, tiles0, pw_prog, pairs, x64, m2;
@@ -36,11 +33,6 @@ struct NewrefState {
     // host-side caches so that repeated calls on the same layout enqueue kernels only
     std::vector<int64_t> sample_key, tiles0_key, tiles1_key, chrom_key;
     int64_t tiles0_n = 0, tiles1_n = 0;
-    // wc_get_reference_dev: the whole pass as one hipGraph once the same call has been seen twice
-    hipGraphExec_t pass_exec = nullptr;
-    std::vector<int64_t> pass_key, pass_fail_key;   // the call the graph (or the warm eager pass) belongs to / one whose capture failed
-    unsigned long long pass_epoch = 0;              // wc::realloc_epoch() when the workspaces were last known to be in place
-    bool pass_warm = false;
 };
 
 // Workspaces of the batched test path (grow-only, reused across calls).
@@ -127,7 +119,7 @@ struct wc_ctx {
     }
 
     std::vector<wc::DevBuf *> all_buffers() {
-        return {&nr.a3, &nr.col_partial, &nr.col_mean, &nr.a32, &nr.norm_lo, &nr.norm_hi, &nr.chrom_of_row, &nr.chrom_range,
+        return {&nr.col_partial, &nr.col_mean, &nr.norm_lo, &nr.norm_hi, &nr.chrom_of_row, &nr.chrom_range,
                 &nr.chrom_off_dev, &nr.sample_rows, &nr.sample_slot, &nr.s32, &nr.s_norm_lo, &nr.s_chrom, &nr.s_range, &nr.keys1,
                 &nr.thr, &nr.cnt, &nr.list, &nr.tiles, &nr.fb_rows, &nr.fb_count, &nr.fb_scratch,
                 &nr.stats, &nr.tiles0, &nr.pw_prog, &nr.pairs, &nr.x64, &nr.m2, &nr.a16, &nr.s16, &tmp_a, &tmp_b, &tmp_c, &tmp_d,

@@ -57,7 +57,6 @@ void wc_destroy(wc_ctx *ctx) {
     if (ctx->lat_stream) (void)hipStreamDestroy(ctx->lat_stream);
     if (ctx->ev_lat_in) (void)hipEventDestroy(ctx->ev_lat_in);
     if (ctx->ev_lat_out) (void)hipEventDestroy(ctx->ev_lat_out);
-    if (ctx->nr.pass_exec) (void)hipGraphExecDestroy(ctx->nr.pass_exec);
     delete ctx;
 }
 

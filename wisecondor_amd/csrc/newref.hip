@@ -5,19 +5,19 @@
 // chromosome, keep the k nearest in stable (distance, position) order.
 //
 // Pipeline:
-//   prepare     robust per-sample centre; float64 -> float32 operand image stored as bfloat16 hi / lo
-//               pairs (float32 with WC_GRAM_MODE=f32), a bfloat16 image for the threshold estimate, a
-//               padded float64 image for the re-score; row norms with a rigorous error interval
-//   thresholds  bf16-MFMA Gram tiles of all rows x M pseudo-random sample rows -> 16-bit key codes ->
+//   prepare     robust per-sample centre; float64 -> ONE float16 operand image (values scaled by a
+//               power of two) for the threshold estimate and the distance tiles, a padded float64
+//               image for the re-score; per-row norm bounds that carry the row's representation error
+//   thresholds  f16-MFMA Gram tiles of all rows x M pseudo-random sample rows -> 16-bit key codes ->
 //               per-row admission threshold from an order statistic
-//   collect     symmetric MFMA Gram tiles over the cross-chromosome triangle (three bf16 products
-//               per multiply, or float32 MFMA); the epilogue turns dot products into LOWER BOUNDS
-//               of the true distance and appends the few that pass the row threshold
+//   collect     symmetric f16-MFMA Gram tiles over the cross-chromosome triangle, operand slabs by
+//               LDS-DMA; the epilogue turns dot products into LOWER BOUNDS of the true distance and
+//               appends the few that pass the row threshold
 //   re-score    k_pick: per row (one wave) a separator for the k-th lower bound, the upper bound U,
 //               the certificate, the candidates with bound <= U as pairs; k_rescore: their exact
 //               float64 distances in numpy's summation order, counting order, output.  Rows whose
-//               certificate fails (and every row beyond refsize 256) take an exact path on the GPU
-//               (k_fallback_all, k_all_exact).  WC_FINISH_ENGINE=rows: round 1's k_finish.
+//               certificate fails (and every row beyond refsize 256) take the exact path on the GPU
+//               (k_exact_tile + k_exact_select).  More than 2048 samples: k_finish, one workgroup per row.
 #include <cstring>
 #include "ctx.h"
 
@@ -35,7 +35,6 @@ constexpr int ROLE_COLS = 2;   // targets are the tile's columns (Q side)
 constexpr int MAX_SAMPLE_COLS = 4096;
 constexpr int LIST_CAP = 1024;
 constexpr int K_MAX = 1024;       // largest refsize (the exact path's selection buffers); above LIST_CAP / 4 every row takes the exact path
-constexpr int FB_BLOCKS = 512;
 constexpr int GL_ROW = 16;            // LDS-DMA tile kernels: floats per LDS row (64 bytes = 32 float16)
 constexpr int GL_STAGE = 2 * TB * GL_ROW;   // floats per stage: A rows then B rows
 #define WC_ADMIT_ALL FLT_MAX
@@ -43,7 +42,6 @@ constexpr double SENTINEL_DISTANCE = 1e10;  // wisetools.py:306
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef double f64x2_u __attribute__((ext_vector_type(2), aligned(8)));   // rows of an odd sample count start 8-byte aligned
@@ -59,12 +57,13 @@ typedef __attribute__((address_space(1))) const void glb_void_t;
 // a few bins are wild outliers.  One block owns 64 samples end to end.
 __global__ __launch_bounds__(1024) void k_col_centre(const double *__restrict__ X, int64_t B, int64_t S,
                                                      int64_t n_rows, int64_t row_step,
-                                                     double *__restrict__ centre) {
+                                                     double *__restrict__ centre, int *__restrict__ bad_norm) {
     __shared__ double sh_s[16][64];
     __shared__ double sh_c[16][64];
     __shared__ double sh_v[64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int64_t s = (int64_t)blockIdx.x * 64 + tx;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *bad_norm = 0x7F800000;   // +inf: no row with a clamped value yet (k_convert)
     // the (at most 128) sampled rows of this sample are read ONCE into registers: the three
     // passes were three dependent memory round trips before (10 us for a kernel that moves 100 KB)
     constexpr int PER = 8;                      // n_rows <= 128 = 16 row phases x 8
@@ -102,19 +101,12 @@ __global__ __launch_bounds__(1024) void k_col_centre(const double *__restrict__ 
     }
 }
 
-// round-to-nearest-even float -> bfloat16 bits (NaN stays NaN, overflow becomes inf)
-__device__ inline unsigned short f32_to_bf16(float f) {
-    unsigned int b = __float_as_uint(f);
-    if ((b & 0x7FFFFFFFu) > 0x7F800000u) return (unsigned short)((b >> 16) | 0x40u);
-    b += 0x7FFFu + ((b >> 16) & 1u);
-    return (unsigned short)(b >> 16);
-}
-
 // float32 -> float16 bits for the one-product tiles: value * gam (a power of two) clamped to the
 // finite float16 range, rounded to nearest even, subnormal results flushed to zero (so that the
 // image is exactly what any matrix-core denormal mode sees).  NaN stays NaN.
-__device__ inline unsigned short f32_to_f16_scaled(float a, double gam, double inv_gam, double &back) {
+__device__ inline unsigned short f32_to_f16_scaled(float a, double gam, double inv_gam, double &back, bool &clamped) {
     double sd = (double)a * gam;
+    clamped = clamped || sd > 65504.0 || sd < -65504.0;
     sd = sd > 65504.0 ? 65504.0 : (sd < -65504.0 ? -65504.0 : sd);
     _Float16 h = (_Float16)(float)sd;           // (float)sd is exact: a has 24 bits, gam is a power of two
     if (fabs((double)(float)h) < 6.103515625e-05) h = (_Float16)0.f;
@@ -124,21 +116,23 @@ __device__ inline unsigned short f32_to_f16_scaled(float a, double gam, double i
     return bits;
 }
 
-// One wave per row: centred operand image(s), norm interval, chromosome id.
-//   MODE16 = 0: float32 image A or bfloat16 hi/lo pairs A3 for the collect tiles, a bfloat16 image
-//               A16 for the admission-threshold estimate;
-//   MODE16 = 1: ONE float16 image (A16; values scaled by the power of two gam) for both.  The row's
-//               representation error e = |a - h| and |h|^2 are accumulated in float64, and the
-//               lower bound loses w = e^2 / tau + tau max(|a|^2, |h|^2) on top of the float32 chain:
-//               2 |a_i.a_j - h_i.h_j| <= 2 (e_i |a_j| + |h_i| e_j) <= w_i + w_j for any tau > 0
-//               ("one product per multiply").
+// One wave per row: centred operand image, norm interval, chromosome id.
+// ONE float16 image (A16; values scaled by the power of two gam) serves the threshold estimate and
+// the distance tiles.  The row's representation error e = |a - h| and |h|^2 are accumulated in
+// float64, and the lower bound loses w = e^2 / tau + tau max(|a|^2, |h|^2) on top of the float32
+// accumulation chain: 2 |a_i.a_j - h_i.h_j| <= 2 (e_i |a_j| + |h_i| e_j) <= w_i + w_j for any tau > 0
+// ("one product per multiply").
 // norm_hi holds the row's SLACK: key <= true distance <= key + slack_i + slack_j.
-template <int MODE16>
+// A row with a CLAMPED value (beyond +-65504 / gam: thousands of times the typical spread) has no usable
+// image: as a listed candidate its huge slack would void the certificate of every row that lists it.  Such a
+// row gets infinite bounds -- never listed, its own row takes the exact path -- and leaves the smallest
+// norm among such rows in *bad_norm; k_pick certifies a row only if (|a_bad| - |a_i|)^2, a lower bound of
+// its distance to any of them, stays above U.
 __global__ __launch_bounds__(256) void k_convert(const double *__restrict__ X, int64_t B, int64_t S,
-                                                 int64_t Bpad, int64_t Kpad,
+                                                 int64_t Bpad,
                                                  const double *__restrict__ mean, double beta, double tau,
                                                  const int64_t *__restrict__ chrom_off, int n_chrom,
-                                                 float *__restrict__ A, unsigned short *__restrict__ A16,
+                                                 unsigned short *__restrict__ A16,
                                                  int64_t Kpad16, float *__restrict__ norm_lo,
                                                  float *__restrict__ norm_hi, int *__restrict__ chrom_of_row,
                                                  int2 *__restrict__ chrom_range,
@@ -146,9 +140,9 @@ __global__ __launch_bounds__(256) void k_convert(const double *__restrict__ X, i
                                                  unsigned short *__restrict__ S16, float *__restrict__ s_norm_lo,
                                                  int *__restrict__ s_chrom, int2 *__restrict__ s_range,
                                                  float *__restrict__ thr, int *__restrict__ cnt,
-                                                 int *__restrict__ row_stat, unsigned short *__restrict__ A3,
+                                                 int *__restrict__ row_stat,
                                                  double *__restrict__ X64, int64_t Sp, float *__restrict__ m2_out,
-                                                 int *__restrict__ fb_zero, int n_fb_zero) {
+                                                 int *__restrict__ bad_norm, int *__restrict__ fb_zero, int n_fb_zero) {
     int lane = threadIdx.x & 63;
     int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     // the exact path's counter and tickets of the job that starts here (was a memset launch in front of
@@ -172,7 +166,7 @@ __global__ __launch_bounds__(256) void k_convert(const double *__restrict__ X, i
         range_w = make_int2((int)(c ? __shfl(endc, c - 1) : 0), (int)__shfl(endc, c));
     }
     double gam = 1.0, inv_gam = 1.0;
-    if (MODE16) {
+    {
         // every wave derives the same scale: typical |a| * gam lands in [4, 8) (float16 keeps
         // 2^13 above that and 2^16 below it in its normal range)
         double t = 0.0, c = 0.0;
@@ -190,49 +184,38 @@ __global__ __launch_bounds__(256) void k_convert(const double *__restrict__ X, i
         if (row == 0 && lane == 0) *m2_out = (float)(-2.0 * inv_gam * inv_gam);
     }
     double acc = 0.0, e2 = 0.0, hn = 0.0;
+    bool clamped = false;
     for (int64_t s = lane; s < Kpad16; s += 64) {
         float a = 0.f;
         if (row < B && s < S) a = (float)(X[row * S + s] - mean[s]);
-        unsigned short h;
-        if (MODE16) {
-            double back;
-            h = f32_to_f16_scaled(a, gam, inv_gam, back);
-            const double err = (double)a - back;
-            e2 += err * err;
-            hn += back * back;
-        } else {
-            if (A && s < Kpad) A[row * Kpad + s] = a;
-            h = f32_to_bf16(a);
-            if (A3 && s < Kpad) {      // split image: per 32-sample slab, 32 hi then 32 lo bfloat16
-                const float hi_f = __uint_as_float((unsigned int)h << 16);
-                const int64_t at = row * (2 * Kpad) + (s >> 5) * 64 + (s & 31);
-                A3[at] = h;
-                A3[at + 32] = f32_to_bf16(a - hi_f);        // a - hi is exact in float32
-            }
-        }
+        double back;
+        const unsigned short h = f32_to_f16_scaled(a, gam, inv_gam, back, clamped);
+        const double err = (double)a - back;
+        e2 += err * err;
+        hn += back * back;
         A16[row * Kpad16 + s] = h;
         if (slot >= 0) S16[(int64_t)slot * Kpad16 + s] = h;
         acc += (double)a * (double)a;
     }
     for (int o = 32; o > 0; o >>= 1) {
         acc += __shfl_xor(acc, o);
-        if (MODE16) { e2 += __shfl_xor(e2, o); hn += __shfl_xor(hn, o); }
+        e2 += __shfl_xor(e2, o);
+        hn += __shfl_xor(hn, o);
     }
+    clamped = __any(clamped);
     if (lane == 0) {
         float lo = INFINITY, hi = INFINITY;
         int ch = -1;
         int2 range = make_int2(0, 0);   // rows of this row's chromosome (padding rows: none)
         if (row < B) {
-            if (isfinite(acc) && acc < 1e37 && (!MODE16 || (isfinite(e2) && isfinite(hn)))) {
+            if (isfinite(acc) && acc < 1e37 && isfinite(e2) && isfinite(hn) && clamped) {
+                // positive floats order like their bit patterns
+                atomicMin(bad_norm, __float_as_int(__double2float_rd(sqrt(acc) * (1.0 - 1e-6))));
+            } else if (isfinite(acc) && acc < 1e37 && isfinite(e2) && isfinite(hn)) {
                 // key = lo_i + lo_j - 2 dot must never exceed the true distance
-                if (MODE16) {
-                    const double m = fmax(acc, hn);
-                    lo = __double2float_rd(acc - (e2 / tau + tau * m) * (1.0 + 1e-9) - beta * m - 1e-37);
-                    hi = __double2float_ru(2.0 * (acc - (double)lo) * (1.0 + 1e-6) + 1e-37);
-                } else {
-                    lo = __double2float_rd(acc * (1.0 - beta) - 1e-37);
-                    hi = __double2float_ru(3.0 * beta * acc * (1.0 + 1e-9) * (1.0 + 1e-6));
-                }
+                const double m = fmax(acc, hn);
+                lo = __double2float_rd(acc - (e2 / tau + tau * m) * (1.0 + 1e-9) - beta * m - 1e-37);
+                hi = __double2float_ru(2.0 * (acc - (double)lo) * (1.0 + 1e-6) + 1e-37);
             }
             ch = ch_w;
             range = range_w;
@@ -270,13 +253,10 @@ __global__ void k_pad_samples(int64_t Kpad16, int64_t first, unsigned short *__r
 
 // --------------------------------------------------------------- Gram tiles ----
 struct GramArgs {
-    const float *P, *Q;          // [rows, ld] float32, rows padded to 128
-    int64_t ld;                  // padded sample count
-    int nslab;                   // ld / 32
-    int last_groups;             // groups of four MFMA steps of the last slab that hold samples (1..4)
-    int last_steps16;            // split / f16 modes: 16-sample MFMA steps of the last slab that hold samples (1..2 / 1..4)
-    const float *m2;             // f16 mode: -2 / gam^2 (the operand image is scaled by gam); NULL: -2
-    int nslab32, last_steps32;   // LDS-DMA kernel: 32-sample slabs, 16-sample steps of the last one that hold samples (1..2)
+    const float *P, *Q;          // [rows, ld] float16 image viewed as 32-bit words, rows padded to 128
+    int64_t ld;                  // row stride in 32-bit words (padded sample count / 2)
+    const float *m2;             // -2 / gam^2 (the operand image is scaled by gam)
+    int nslab32, last_steps32;   // 32-sample slabs, 16-sample MFMA steps of the last one that hold samples (1..2)
     const float *nbP, *nbQ;      // lower norm bounds
     const int2 *range;           // per row: [first, last+1) row of its chromosome (never candidates)
     const int4 *tiles;           // {I, J, roles, 0}
@@ -311,94 +291,11 @@ __device__ inline unsigned long long pack_entry(float key, int j) {
     return ((unsigned long long)wc::f32_ordered(key) << 32) | (unsigned int)j;
 }
 
-// 128x128 output tile per 256-thread workgroup; each wave owns 64x64 as 2x2
-// v_mfma_f32_32x32x2_f32 accumulators.  A/B slabs are staged global->regs->LDS
-// with the next slab's loads in flight during the MFMA phase.  Within a slab
-// lane (i, h) feeds k = 16h + t at MFMA step t, so each lane fetches its 16
-// operands with four conflict-free ds_read_b128.
-//
-// MODE = GRAM_SPLIT runs the same tile on the bf16 matrix cores: every float32 operand is stored as
-// a pair of bfloat16 values (hi = bf16(a), lo = bf16(a - hi); a k-slab row is 32 hi then 32 lo,
-// the same 128 bytes), and a.b is accumulated as hi.hi + hi.lo + lo.hi in float32 -- three
-// v_mfma_f32_32x32x16_bf16 (8 passes for 16 samples each) instead of eight
-// v_mfma_f32_32x32x2_f32 (16 passes for 2 samples each): 5.3x less matrix-core time.  The
-// bf16 keeps 8 significant bits: |a - hi| <= 2^-8 |a|, |a - hi - lo| <= 2^-16 |a|, so the
-// hi+lo representation (2 * 2^-16) and the dropped lo.lo term (2^-16) stay below 3.1 * 2^-16 |a||b|;
-// that goes into beta (NewrefState::beta), i.e. into the lower / upper bounds every decision
-// rests on.
-// MODE = GRAM_F16 (the default) needs ONE product per multiply: the operand image is float16
-// (11 significant bits, scaled by a power of two), a k-slab row is 64 samples in the same 128
-// bytes, and the representation error of every row is known exactly (k_convert) and charged to
-// that row's norm bounds -- half the operand bytes, a third of the matrix-core work of the
-// bf16 pairs, about 2.3x their bound width (a few more candidates per row to re-score).
-constexpr int GRAM_F32 = 0, GRAM_SPLIT = 1, GRAM_F16 = 2;
-
-// the MFMA steps of one staged slab; nt = steps that hold samples (GRAM_F32: groups of four steps)
-template <int MODE>
-__device__ __forceinline__ void gram_steps(const float *As, const float *Bs, f32x16 (&acc)[2][2], int nt, int wr,
-                                           int wc, int li, int lh) {
-    if constexpr (MODE == GRAM_F16) {
-        // MFMA step t covers samples 16 t .. 16 t + 15 of the slab; lane half h supplies 8 consecutive
-        // ones, from the same slots for A and B
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (t >= nt) break;
-            const int off = t * 8 + lh * 4;   // float units: (16 t + 8 h) halfs
-            const f16x8 a0 = *(const f16x8 *)&As[(wr * 64 + li) * LDA + off];
-            const f16x8 a1 = *(const f16x8 *)&As[(wr * 64 + 32 + li) * LDA + off];
-            const f16x8 b0 = *(const f16x8 *)&Bs[(wc * 64 + li) * LDA + off];
-            const f16x8 b1 = *(const f16x8 *)&Bs[(wc * 64 + 32 + li) * LDA + off];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
-        }
-    } else if constexpr (MODE == GRAM_SPLIT) {
-        // slab row = 32 hi | 32 lo bfloat16 (16 + 16 floats).  MFMA step t covers samples
-        // 16 t .. 16 t + 15 of the slab; lane half h supplies 8 consecutive ones, from the same
-        // slots for A and B.  The last slab stops after the steps that hold samples.
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if (t >= nt) break;
-            const int off = t * 8 + lh * 4;       // float units within the hi half; lo half: + 16
-            const float *ar = &As[(wr * 64 + li) * LDA + off], *br = &Bs[(wc * 64 + li) * LDA + off];
-            const bf16x8 a0h = *(const bf16x8 *)ar, a0l = *(const bf16x8 *)(ar + 16);
-            const bf16x8 a1h = *(const bf16x8 *)(ar + 32 * LDA), a1l = *(const bf16x8 *)(ar + 32 * LDA + 16);
-            const bf16x8 b0h = *(const bf16x8 *)br, b0l = *(const bf16x8 *)(br + 16);
-            const bf16x8 b1h = *(const bf16x8 *)(br + 32 * LDA), b1l = *(const bf16x8 *)(br + 32 * LDA + 16);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b0h, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l, b1h, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b0h, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l, b1h, acc[1][1], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0l, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b1l, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0l, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1l, acc[1][1], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b0h, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h, b1h, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b0h, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h, b1h, acc[1][1], 0, 0, 0);
-        }
-    } else {
-        const float *a0 = &As[(wr * 64 + li) * LDA + lh * 16], *a1 = a0 + 32 * LDA;
-        const float *b0 = &Bs[(wc * 64 + li) * LDA + lh * 16], *b1 = b0 + 32 * LDA;
-        // the last slab runs only the step groups that hold samples (lane half h feeds
-        // k = 16h + t; the padding beyond the sample count is zero)
-#pragma unroll
-        for (int tg = 0; tg < 4; ++tg) {
-            if (tg >= nt) break;
-            const f32x4 ca0 = *(const f32x4 *)(a0 + 4 * tg), ca1 = *(const f32x4 *)(a1 + 4 * tg);
-            const f32x4 cb0 = *(const f32x4 *)(b0 + 4 * tg), cb1 = *(const f32x4 *)(b1 + 4 * tg);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca0[e], cb0[e], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca0[e], cb1[e], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca1[e], cb0[e], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca1[e], cb1[e], acc[1][1], 0, 0, 0);
-            }
-        }
-    }
-}
+// Distance tiles: 128 x 128 outputs per 256-thread workgroup, each wave a 64 x 64 block as 2 x 2
+// v_mfma_f32_32x32x16_f16 accumulators.  The operand image is float16 (11 significant bits, values
+// scaled by one power of two), a k-slab row is 32 samples = 64 bytes, and the representation error
+// of every row is known exactly (k_convert) and charged to that row's norm bounds: ONE matrix-core
+// product per multiply, rigorous lower bounds out.
 
 // The tile's epilogue (shared by the register-staged and the LDS-DMA tile kernels): dot products ->
 // lower-bound keys -> the few that pass a target's threshold appended to that target's list.
@@ -521,147 +418,8 @@ __device__ __forceinline__ void gram_epilogue(const GramArgs &g, float *sm, floa
     }
 }
 
-template <int MODE, int DEPTH>   // DEPTH: k-slabs of operand loads in flight (register staged; 2 not with GRAM_F32)
-__global__ __launch_bounds__(256, DEPTH == 2 ? 3 : 4) void k_gram(GramArgs g) {
-    __shared__ __attribute__((aligned(16))) float sm[2 * TB * LDA + 4 * TB];   // dot tile: 128 * LDT <= 2 * TB * LDA
-    float *As = sm;
-    float *Bs = sm + TB * LDA;
-    float *D = sm;
-    float *nbPs = sm + 2 * TB * LDA;
-    float *nbQs = nbPs + TB;
-    float *thPs = nbQs + TB;
-    float *thQs = thPs + TB;
-
-    // XCD-aware order: workgroup b runs on XCD b%8; give each XCD a contiguous run
-    // of the (I-major) tile list so co-resident tiles share operand panels in its L2.
-    const int chunk = (g.ntiles + 7) >> 3;
-    const int t_id = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    if (t_id >= g.ntiles) return;
-    const int4 tile = g.tiles[t_id];
-    const int I = tile.x, J = tile.y, roles = tile.z;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
-    const int li = lane & 31, lh = lane >> 5;
-    const float m2 = MODE == GRAM_F16 ? *g.m2 : -2.f;
-
-    if (tid < TB) {
-        int64_t gp = (int64_t)I * TB + tid;
-        nbPs[tid] = g.nbP[gp];
-        thPs[tid] = g.thr[gp];
-    } else {
-        int c = tid - TB;
-        int64_t gq = (int64_t)J * TB + c;
-        nbQs[c] = g.nbQ[gq];
-        thQs[c] = g.thr[gq];
-    }
-
-    // a slab row is 128 bytes in every mode (32 floats / 32 hi + 32 lo bfloat16 / 64 float16)
-    const int lrow = tid >> 3, lcol = (tid & 7) * 4;
-    const float *Pg = g.P + ((int64_t)I * TB + lrow) * g.ld + lcol;
-    const float *Qg = g.Q + ((int64_t)J * TB + lrow) * g.ld + lcol;
-    f32x4 pa[4], qb[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        pa[p] = *(const f32x4 *)(Pg + (int64_t)p * 32 * g.ld);
-        qb[p] = *(const f32x4 *)(Qg + (int64_t)p * 32 * g.ld);
-    }
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    // steps of a full slab / of the last one
-    const int full = MODE == GRAM_F16 ? 4 : (MODE == GRAM_SPLIT ? 2 : 4);
-    const int last = MODE == GRAM_F32 ? g.last_groups : g.last_steps16;
-
-    if constexpr (DEPTH == 2) {
-        // Two slabs of loads in flight: with the 16-bit tiles one slab's MFMAs (0.4 us) no longer
-        // cover a global round trip (~3 us under load), so the loads of slab s+2 are issued while
-        // slab s is multiplied and slab s+1 is still on its way.  Costs 32 more registers: three
-        // waves per SIMD instead of four.
-        f32x4 pa2[4], qb2[4];
-        {
-            const int64_t ko = (int64_t)(g.nslab > 1 ? 1 : 0) * BK;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                pa2[p] = *(const f32x4 *)(Pg + ko + (int64_t)p * 32 * g.ld);
-                qb2[p] = *(const f32x4 *)(Qg + ko + (int64_t)p * 32 * g.ld);
-            }
-        }
-        __builtin_amdgcn_s_setprio(2);
-        for (int slab = 0; slab < g.nslab; slab += 2) {
-            __syncthreads();
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                *(f32x4 *)&As[(lrow + 32 * p) * LDA + lcol] = pa[p];
-                *(f32x4 *)&Bs[(lrow + 32 * p) * LDA + lcol] = qb[p];
-            }
-            __syncthreads();
-            {   // slab + 2 (clamped to the last slab: a harmless re-read instead of a branch)
-                const int64_t ko = (int64_t)(slab + 2 < g.nslab ? slab + 2 : g.nslab - 1) * BK;
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    pa[p] = *(const f32x4 *)(Pg + ko + (int64_t)p * 32 * g.ld);
-                    qb[p] = *(const f32x4 *)(Qg + ko + (int64_t)p * 32 * g.ld);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            gram_steps<MODE>(As, Bs, acc, slab + 1 < g.nslab ? full : last, wr, wc, li, lh);
-            if (slab + 1 >= g.nslab) break;
-            __syncthreads();
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                *(f32x4 *)&As[(lrow + 32 * p) * LDA + lcol] = pa2[p];
-                *(f32x4 *)&Bs[(lrow + 32 * p) * LDA + lcol] = qb2[p];
-            }
-            __syncthreads();
-            {
-                const int64_t ko = (int64_t)(slab + 3 < g.nslab ? slab + 3 : g.nslab - 1) * BK;
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    pa2[p] = *(const f32x4 *)(Pg + ko + (int64_t)p * 32 * g.ld);
-                    qb2[p] = *(const f32x4 *)(Qg + ko + (int64_t)p * 32 * g.ld);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            gram_steps<MODE>(As, Bs, acc, slab + 2 < g.nslab ? full : last, wr, wc, li, lh);
-        }
-    } else {
-    __builtin_amdgcn_s_setprio(2);   // waves feeding the matrix cores go ahead of waves in their epilogue
-    for (int slab = 0; slab < g.nslab; ++slab) {
-        __syncthreads();
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            *(f32x4 *)&As[(lrow + 32 * p) * LDA + lcol] = pa[p];
-            *(f32x4 *)&Bs[(lrow + 32 * p) * LDA + lcol] = qb[p];
-        }
-        __syncthreads();
-        {   // next slab's loads fly during the MFMA phase (last iteration re-reads its own slab)
-            const int64_t ko = (int64_t)(slab + 1 < g.nslab ? slab + 1 : slab) * BK;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                pa[p] = *(const f32x4 *)(Pg + ko + (int64_t)p * 32 * g.ld);
-                qb[p] = *(const f32x4 *)(Qg + ko + (int64_t)p * 32 * g.ld);
-            }
-        }
-        // keep the prefetch above the MFMA phase: the staging registers stay live, and the
-        // fragments are fetched in four groups of four steps (16 live floats) instead
-        __builtin_amdgcn_sched_barrier(0);
-        gram_steps<MODE>(As, Bs, acc, slab + 1 < g.nslab ? full : last, wr, wc, li, lh);
-    }
-
-    }   // DEPTH
-
-    gram_epilogue(g, sm, D, nbPs, nbQs, thPs, thQs, acc, I, J, roles, m2, tid, lane, w, wr, wc, li, lh);
-}
-
-
 // ------------------------------------------------ LDS-DMA tile kernel (float16) ----
-// The float16 tiles' default kernel (WC_GRAM_STAGE=regs selects the register-staged k_gram<GRAM_F16> instead):
-// the operand slabs are brought in by global_load_lds_dwordx4
+// The operand slabs are brought in by global_load_lds_dwordx4
 // (global -> LDS directly: no staging registers, no ds_write pass).  A slab is 32 samples = 64 bytes per row;
 // a wave's DMA instruction fills 16 rows x 64 B = 1 KB lane-linearly, so the row padding of the
 // register-staged kernel is not available: the 16-byte chunk g of row r sits in slot g ^ ((r >> 2) & 3)
@@ -737,7 +495,10 @@ __global__ __launch_bounds__(256, 4) void k_gram_glds(GramArgs g) {
     dma(0, 0);
     __builtin_amdgcn_s_setprio(2);
     for (int slab = 0; slab < nslab; ++slab) {
-        __syncthreads();                  // slab `slab` has landed (vmcnt(0) + barrier); the other stage is free
+        // the LDS this wave reads below was filled by OTHER waves' DMA: every wave drains its own DMA before the
+        // barrier (explicitly: a barrier alone need not wait for vmcnt)
+        __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
+        __syncthreads();                  // slab `slab` has landed; the other stage is free
         if (slab + 1 < nslab) dma(slab + 1, (slab + 1) & 1);
         const float *st = sm + (slab & 1) * GL_STAGE;
         const int nt = slab + 1 < nslab ? 2 : g.last_steps32;
@@ -752,15 +513,17 @@ __global__ __launch_bounds__(256, 4) void k_gram_glds(GramArgs g) {
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
         }
     }
+    __builtin_amdgcn_s_waitcnt(0x0070);   // nothing of this wave in flight into the LDS the dot tile is about to alias
     gram_epilogue(g, sm, D, nbPs, nbQs, thPs, thQs, acc, I, J, roles, m2, tid, lane, w, wr, wc, li, lh);
 }
 
-// ---------------------------------------------- threshold-estimate Gram (bf16) ----
+// ----------------------------------------------- threshold-estimate Gram (f16) ----
 // The admission thresholds only have to put a few hundred candidates per row on the
 // lists; they decide nothing (every stored index and distance is re-derived exactly).
-// So the distances to the M sampled rows use the bf16 matrix cores: 16x the fp32 MFMA
-// rate, ~0.4 % error on the dot products, i.e. a ~10 % wobble of the candidate count.
-// Same 128x128 tile / 4 waves / LDS byte layout as k_gram; a slab is 64 bf16 (128 B) deep.
+// The distances to the M sampled rows come from the same float16 image as the distance
+// tiles.  128x128 tile / 4 waves, operand slabs staged global -> registers -> LDS (row
+// stride LDA); a slab is 64 float16 (128 B) deep.  (LDS-DMA staging measured slower here:
+// this kernel's time is its key-code stores.)
 
 // epilogue of the threshold-estimate tiles: dot products -> 16-bit key codes of every (row, sampled column)
 __device__ __forceinline__ void thr_epilogue(float *D, const float *nbPs, const float *nbQs, f32x16 (&acc)[2][2],
@@ -819,7 +582,7 @@ __device__ __forceinline__ void thr_epilogue(float *D, const float *nbPs, const 
     }
 }
 
-template <bool F16>   // operands are float16 (scaled by gam, *m2 = -2 / gam^2) instead of bfloat16
+// operands are float16 (scaled by gam, *m2 = -2 / gam^2)
 __global__ __launch_bounds__(256, 4) void k_gram_thr16(const unsigned short *__restrict__ P16,
                                                        const unsigned short *__restrict__ Q16, int64_t ld16,
                                                        int nslab, const float *__restrict__ nbP,
@@ -882,29 +645,18 @@ __global__ __launch_bounds__(256, 4) void k_gram_thr16(const unsigned short *__r
         // A and B use the same slots, so the pairing of k is right whatever the hardware order.
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int off = t * 8 + lh * 4;   // float units: (16 t + 8 h) bf16 = 32 t + 16 h bytes
-            if constexpr (F16) {
-                const f16x8 a0 = *(const f16x8 *)&As[(wr * 64 + li) * LDA + off];
-                const f16x8 a1 = *(const f16x8 *)&As[(wr * 64 + 32 + li) * LDA + off];
-                const f16x8 b0 = *(const f16x8 *)&Bs[(wc * 64 + li) * LDA + off];
-                const f16x8 b1 = *(const f16x8 *)&Bs[(wc * 64 + 32 + li) * LDA + off];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
-            } else {
-                const bf16x8 a0 = *(const bf16x8 *)&As[(wr * 64 + li) * LDA + off];
-                const bf16x8 a1 = *(const bf16x8 *)&As[(wr * 64 + 32 + li) * LDA + off];
-                const bf16x8 b0 = *(const bf16x8 *)&Bs[(wc * 64 + li) * LDA + off];
-                const bf16x8 b1 = *(const bf16x8 *)&Bs[(wc * 64 + 32 + li) * LDA + off];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
-            }
+            const int off = t * 8 + lh * 4;   // float units: (16 t + 8 h) halfs = 32 t + 16 h bytes
+            const f16x8 a0 = *(const f16x8 *)&As[(wr * 64 + li) * LDA + off];
+            const f16x8 a1 = *(const f16x8 *)&As[(wr * 64 + 32 + li) * LDA + off];
+            const f16x8 b0 = *(const f16x8 *)&Bs[(wc * 64 + li) * LDA + off];
+            const f16x8 b1 = *(const f16x8 *)&Bs[(wc * 64 + 32 + li) * LDA + off];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
         }
     }
-    thr_epilogue(D, nbPs, nbQs, acc, rangeQ, keys, ldo, I, J, F16 ? *m2p : -2.f, tid, wr, wc, li, lh);
+    thr_epilogue(D, nbPs, nbQs, acc, rangeQ, keys, ldo, I, J, *m2p, tid, wr, wc, li, lh);
 }
 
 __device__ inline uint32_t umed3(uint32_t x, uint32_t y, uint32_t z) {   // v_med3_u32
@@ -988,7 +740,7 @@ __global__ __launch_bounds__(256) void k_select_thr(const unsigned int *__restri
 struct FinishArgs {
     const double *X;
     int64_t B, S;
-    const float *norm_hi, *thr;
+    const float *norm_lo, *norm_hi, *thr;
     const int *cnt;
     const unsigned long long *list;
     int cap, k;
@@ -999,6 +751,7 @@ struct FinishArgs {
     int32_t *idx_out;
     double *dist_out;
     int *fb_rows, *fb_count;
+    const float *bad_norm;   // smallest norm among the rows without a usable float16 image (+inf: none)
     int *row_stat;
     int sum_order;
     int xs_in_lds;
@@ -1011,55 +764,6 @@ struct FinishArgs {
     // layout of correctedData (found by the seed sweep: 3 bins in 1 + 2, 4 bins in 1 + 2 + 1).
     unsigned long long lone_mask;
 };
-
-// Exact distance of rows j and i with numpy's bits: subtract, square (rounded), sum
-// (wisetools.py:302).  Eight lanes cooperate per candidate.  The summation order
-// numpy uses depends on the memory layout of correctedData:
-//   WC_SUM_PAIRWISE    C-contiguous [bins, samples]: each row is reduced by
-//                      numpy's pairwise_sum;
-//   WC_SUM_SEQUENTIAL  Fortran-contiguous (what np.load returns for the prep
-//                      file, because trainPCA hands back corrected.T,
-//                      wisetools.py:101): the reduction runs sample by sample,
-//                      i.e. a plain left-to-right sum.
-__device__ inline double exact_distance(const double *__restrict__ xj, const double *xi, int64_t S, int sub,
-                                        int sum_order) {
-    if (sum_order == WC_SUM_PAIRWISE) {
-        return wc::pairwise_sum<true>(
-            [&](int64_t s) {
-                double df = xj[s] - xi[s];
-                double sq = df * df;
-                return sq;
-            },
-            S, sub);
-    }
-    // left-to-right sum: the chain is serial per candidate, so keep eight coalesced
-    // loads per lane in flight and feed the chain by 8-lane broadcasts.  Padding
-    // with +0.0 is exact because every partial sum is >= +0 (or NaN).
-    double acc = 0.0;
-    double cur[8], nxt[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        int64_t s = 8 * u + sub;
-        double df = (s < S) ? xj[s] - xi[s] : 0.0;
-        cur[u] = df * df;
-    }
-    for (int64_t s0 = 0; s0 < S; s0 += 64) {
-        // next 64 samples are requested before the serial chain consumes the current ones
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            int64_t s = s0 + 64 + 8 * u + sub;
-            double df = (s < S) ? xj[s] - xi[s] : 0.0;
-            nxt[u] = df * df;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc = acc + __shfl(cur[u], i, 8);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
-    }
-    return acc;
-}
 
 constexpr int RMAX = 512;       // most candidates re-scored on the fast path (more -> exact fallback)
 constexpr int ST_CH = 16;       // samples per staged chunk of the sequential re-score
@@ -1197,6 +901,14 @@ __global__ __launch_bounds__(NT, 4) void k_finish(FinishArgs a) {
             for (int q = 1; q < NT / 64; ++q) U = fmax(U, red[q]);
             // every candidate that was never listed has a lower bound > thr: need thr >= U
             if (!(U == U) || (!admit_all && !(U <= (double)thr_f))) fallback = true;
+        }
+        {
+            // rows with clamped values are never listed: see pick_row
+            const float bad = *a.bad_norm;
+            if (bad < INFINITY) {
+                const double ni = sqrt(fmax((double)a.norm_lo[row] + (double)nhi_f, 0.0));
+                if (!((sqrt(fmax(U, 0.0)) + ni) * (1.0 + 1e-3) < (double)bad * (1.0 - 1e-3))) fallback = true;
+            }
         }
         if (!fallback) {
             // compact the survivors (order is irrelevant: they are sorted exactly below)
@@ -1499,6 +1211,16 @@ __device__ inline int pick_row(const PickArgs &p, int64_t row, int lane, int n, 
         // every candidate that was never listed has a lower bound > thr: need thr >= U
         if (!(U == U) || (!admit_all && !(U <= (double)thr_f))) return -1;
     }
+    {
+        // rows with clamped values are never listed (k_convert): their distance to this row is at least
+        // (|a_bad| - |a_i|)^2, which must stay above U (|a_i|^2 <= lo_i + slack_i); an admit-all row with
+        // fewer than k candidates (U infinite) cannot tell and takes the exact path
+        const float bad = *a.bad_norm;
+        if (bad < INFINITY) {
+            const double ni = sqrt(fmax((double)a.norm_lo[row] + (double)nhi_f, 0.0));
+            if (!((sqrt(fmax(U, 0.0)) + ni) * (1.0 + 1e-3) < (double)bad * (1.0 - 1e-3))) return -1;
+        }
+    }
     int base = 0;
     int *out = p.pairs + row * RMAX;
 #pragma unroll
@@ -1599,6 +1321,18 @@ struct RowSum {
                 for (int e = 0; e < 8; ++e) r[e] = r[e] + v[8 * g + e];
                 leaf_end(a, base);
             }
+        }
+    }
+    // the same for one group of eight samples starting at `base` (cntg of them real), pairwise order
+    __device__ inline void group_regs(const FinishArgs &a, const double (&v)[8], int64_t base, int cntg) {
+        if (in_tail || cntg < 8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (e < cntg) acc = acc + v[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = r[e] + v[e];
+            leaf_end(a, base);
         }
     }
     // after a complete group of eight at `base`: close the leaf when its body ends here
@@ -1845,27 +1579,44 @@ __global__ __launch_bounds__(PS_MAX, (SEQ && !GLDS) ? 4 : (SEQ ? 5 : 3)) void k_
     }
 }
 
-// Exact path for rows whose certificate failed (ties at the boundary, outlier
-// rows, list overflow): every distance in float64, then k rounds of
-// lexicographic (distance, position) minimum selection.
-// -- exact path, two kernels --------------------------------------------------------
-// fb_fill: float64 distance keys of `row` to the candidates [j0, j1) into sc[j] (8 lanes per
-// candidate, 32 candidates per trip); same chromosome / NaN / >= 1e10 -> ~0.
-__device__ inline void fb_fill(const FinishArgs &a, int64_t row, const double *xi, int64_t j0, int64_t j1,
-                               unsigned long long *__restrict__ sc, int tid) {
+// -- exact path: the slow filler and the selection ------------------------------------------
+// fb_fill: float64 distance keys of `row` to the candidates [j0, j1) into sc[j], one thread per
+// candidate (its 128-byte chunks are whole cache lines), numpy's order by RowSum; same chromosome /
+// NaN / >= 1e10 -> ~0.  Only the rows the tiled kernel leaves out come here: rows of a "lone"
+// chromosome (pairwise order whatever the layout) and targets beyond EX_CAP.
+template <bool SEQ>
+__device__ inline void fb_fill_order(const FinishArgs &a, int64_t row, const double *xi, int64_t j0, int64_t j1,
+                                     unsigned long long *__restrict__ sc, int tid) {
     const int ch = a.chrom_of_row[row];
     const int64_t cs = a.chrom_off[ch], ce = a.chrom_off[ch + 1];
-    const int grp = tid >> 3, sub = tid & 7;
-    for (int64_t base = j0; base < j1; base += 32) {
-        int64_t j = base + grp;
-        bool in = j < j1;
-        double d = exact_distance(a.X + (in ? j : row) * a.S, xi, a.S, sub,
-                                  ((a.lone_mask >> ch) & 1ull) ? WC_SUM_PAIRWISE : a.sum_order);
-        if (in && sub == 0) {
-            bool ok = !(j >= cs && j < ce) && d < SENTINEL_DISTANCE;
+    for (int64_t base = j0; base < j1; base += 256) {
+        const int64_t j = base + tid;
+        const bool in = j < j1;
+        const double *xj = a.X + (in ? j : row) * a.S;
+        RowSum<SEQ> sum;
+        sum.init(a);
+        for (int64_t c0 = 0; c0 < a.S; c0 += ST_CH) {
+            double v[ST_CH];
+#pragma unroll
+            for (int e = 0; e < ST_CH; ++e) {
+                const double d = c0 + e < a.S ? xj[c0 + e] - xi[c0 + e] : 0.0;   // zero padding: adds +0.0 to sums >= +0
+                v[e] = d * d;
+            }
+            sum.chunk_regs(a, v, c0, c0 + ST_CH <= a.S);
+        }
+        const double d = sum.result();
+        if (in) {
+            const bool ok = !(j >= cs && j < ce) && d < SENTINEL_DISTANCE;
             sc[j] = ok ? wc::f64_ordered(d) : ~0ull;
         }
     }
+}
+__device__ inline void fb_fill(const FinishArgs &a, int64_t row, const double *xi, int64_t j0, int64_t j1,
+                               unsigned long long *__restrict__ sc, int tid) {
+    const bool lone = (a.lone_mask >> a.chrom_of_row[row]) & 1ull;
+    // fewer than eight samples: numpy's pairwise sum is the plain left-to-right one
+    if (a.S < 8 || (!lone && a.sum_order == WC_SUM_SEQUENTIAL)) fb_fill_order<true>(a, row, xi, j0, j1, sc, tid);
+    else fb_fill_order<false>(a, row, xi, j0, j1, sc, tid);
 }
 
 // Radix selection (8-bit digits, most significant first) of the element of 0-based rank `want`
@@ -1979,61 +1730,170 @@ __device__ inline void fb_select(const FinishArgs &a, int64_t row, const unsigne
     __syncthreads();
 }
 
-// Distances of the first FB_BLOCKS fallback rows, all workgroups together: FB_ROWS_PAR rows are
-// in flight at a time, FB_BLOCKS / FB_ROWS_PAR workgroups share a row's candidates.  (One
-// workgroup per row, as the first version had it, reads the whole matrix -- 277 MB at
-// 57 633 x 600 -- through a single CU: ~100 ms for a single outlier row.)
-constexpr int FB_ROWS_PAR = 8;
-// ONE launch for the whole exact path (round 3; two launches before -- a fill kernel and a select kernel that
-// cost ~9 us per pass as no-ops): FB_BLOCKS workgroups fill the distance rows of the first FB_BLOCKS exact rows
-// together (eight rows in flight, 64 workgroups share a row's candidates); a workgroup that finishes its part
-// of a row publishes it (fence, then a ticket on the row's counter) and the LAST one to arrive selects the row --
-// nobody ever waits for anybody, so the launch cannot deadlock however many other kernels share the GPU.  Exact
-// rows beyond FB_BLOCKS (pathological inputs, and every row when refsize > 256) are filled and selected by one
-// workgroup each, in a scratch slot of its own (the second half of the scratch: the first half's slots are still
-// being filled / selected by other workgroups).  `done` = FB_BLOCKS counters, zeroed by the caller's memset.
-__global__ __launch_bounds__(256) void k_fallback_all(FinishArgs a, unsigned long long *scratch, int64_t Bpad, int *done) {
+// ------------------------------------------------------------ exact path, tiled ----
+// Float64 distances of a SET of target rows to every candidate, in numpy's rounding order, then the
+// k smallest per row.  Who takes it: rows whose certificate failed (ties at the boundary, outlier rows,
+// lost list entries), every row when refsize > 256, and wc_newref_exact_dev -- the entry point the
+// full-size tests use to check the fast path row by row.
+//   k_exact_tile    EX_T x EX_T (target, candidate) pairs per 256-thread workgroup, every thread a
+//                   TR x TR block of pairs: 16-sample chunks of the 2 EX_T rows are staged through LDS
+//                   (sample-major, so a thread's TR targets are 16-byte reads and the candidates of the
+//                   sixteen lanes of a row of threads are consecutive), the next chunk's loads in flight;
+//                   a pair's squared differences are added in numpy's order -- sequential: one
+//                   running sum per pair (4 x 4 pairs per thread, sixteen independent chains);
+//                   pairwise: RowSum<false> per pair (2 x 2 pairs per thread).  Ordered keys of the
+//                   distances go to scratch[target slot][candidate] (~0: same chromosome, NaN, >= 1e10).
+//   k_exact_select  one workgroup per target: radix selection of the k-th key, counting order, output row
+//                   (fb_select).  The launch boundary between the two is the only synchronisation.
+// Up to EX_CAP targets per launch pair; a normal pass does not know the number of certificate failures
+// on the host (no read-back), so the grid is sized for EX_CAP and surplus workgroups leave at once; targets
+// beyond EX_CAP (pathological inputs) are filled and selected by one workgroup each in k_exact_select.
+// Rows of a "lone" chromosome (FinishArgs::lone_mask: pairwise order whatever the layout) are filled by
+// their select workgroup as well.
+constexpr int EX_CAP = 1024;     // targets per launch pair (scratch: 2 EX_CAP rows of Bpad keys)
+constexpr int EX_LD = 130;       // doubles per staged sample: 128 values + 2 (16-byte aligned rows, spread banks)
+
+template <bool SEQ>
+__global__ __launch_bounds__(256) void k_exact_tile(FinishArgs a, const int *__restrict__ rows,
+                                                    const int *__restrict__ n_rows_dev, int n_rows_host, int first,
+                                                    unsigned long long *__restrict__ scratch, int64_t Bpad) {
+    constexpr int TR = SEQ ? 4 : 2;            // pairs per thread: TR targets x TR candidates
+    constexpr int EX_T = 16 * TR;              // targets (and candidates) per tile
+    constexpr int NLD = 2 * EX_T * ST_CH / 256;   // staged values per thread and chunk
+    __shared__ __attribute__((aligned(16))) double buf[ST_CH * EX_LD];
+    __shared__ int s_row[EX_T];
+    __shared__ int2 s_rng[EX_T];
+    const int tid = threadIdx.x;
+    int nf = (n_rows_dev ? *n_rows_dev : n_rows_host) - first;
+    nf = nf > EX_CAP ? EX_CAP : nf;
+    if (nf <= 0) return;
+    const int tr = tid >> 4, tc = tid & 15;
+    const int64_t j0 = (int64_t)blockIdx.x * EX_T;
+    for (int rg = blockIdx.y; rg * EX_T < nf; rg += gridDim.y) {
+        __syncthreads();
+        if (tid < EX_T) {
+            const int f = rg * EX_T + tid;
+            const int row = rows[first + (f < nf ? f : rg * EX_T)];      // slots beyond nf repeat the group's first row
+            s_row[tid] = row;
+            const int ch = a.chrom_of_row[row];
+            const bool lone = (a.lone_mask >> ch) & 1ull;                // filled by k_exact_select instead
+            s_rng[tid] = (f < nf && !lone) ? make_int2((int)a.chrom_off[ch], (int)a.chrom_off[ch + 1]) : make_int2(0, 0x7FFFFFFF);
+        }
+        __syncthreads();
+        // staging: value e = tid + 256 q of a chunk is sample e & 15 of staged row e >> 4 (targets, then candidates)
+        int64_t src[NLD];
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int rr = (tid + 256 * q) >> 4;
+            int64_t row = rr < EX_T ? (int64_t)s_row[rr] : j0 + (rr - EX_T);
+            row = row < a.B ? row : a.B - 1;
+            src[q] = row * a.S + (tid & 15);
+        }
+        double pre[NLD];
+        auto fetch = [&](int64_t c0) {
+            const bool in = c0 + (tid & 15) < a.S;
+#pragma unroll
+            for (int q = 0; q < NLD; ++q) pre[q] = in ? a.X[src[q] + c0] : 0.0;     // zero padding: adds +0.0 to sums >= +0
+        };
+        fetch(0);
+        RowSum<SEQ> sum[TR][TR];
+#pragma unroll
+        for (int i = 0; i < TR; ++i)
+#pragma unroll
+            for (int q = 0; q < TR; ++q) sum[i][q].init(a);
+        for (int64_t c0 = 0; c0 < a.S; c0 += ST_CH) {
+            __syncthreads();                       // the previous chunk's reads are done
+#pragma unroll
+            for (int q = 0; q < NLD; ++q) buf[(tid & 15) * EX_LD + ((tid + 256 * q) >> 4)] = pre[q];
+            __syncthreads();
+            if (c0 + ST_CH < a.S) fetch(c0 + ST_CH);
+            if constexpr (SEQ) {
+#pragma unroll
+                for (int s = 0; s < ST_CH; ++s) {
+                    const f64x2 ra = *(const f64x2 *)&buf[s * EX_LD + 4 * tr], rb = *(const f64x2 *)&buf[s * EX_LD + 4 * tr + 2];
+                    const double xr[4] = {ra.x, ra.y, rb.x, rb.y};
+                    double xc[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xc[q] = buf[s * EX_LD + EX_T + tc + 16 * q];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const double d = xc[q] - xr[i];
+                            const double sq = d * d;
+                            sum[i][q].acc = sum[i][q].acc + sq;
+                        }
+                }
+            } else {
+#pragma unroll 1
+                for (int g = 0; g < 2; ++g) {
+                    const int64_t base = c0 + 8 * g;
+                    if (base >= a.S) break;
+                    double xr[2][8], xc[2][8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const f64x2 r2 = *(const f64x2 *)&buf[(8 * g + e) * EX_LD + 2 * tr];
+                        xr[0][e] = r2.x; xr[1][e] = r2.y;
+                        xc[0][e] = buf[(8 * g + e) * EX_LD + EX_T + tc];
+                        xc[1][e] = buf[(8 * g + e) * EX_LD + EX_T + tc + 16];
+                    }
+                    const int cntg = (a.S - base) < 8 ? (int)(a.S - base) : 8;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            double v[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const double d = xc[q][e] - xr[i][e];
+                                v[e] = d * d;
+                            }
+                            sum[i][q].group_regs(a, v, base, cntg);
+                        }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TR; ++i) {
+            const int rl = TR * tr + i, f = rg * EX_T + rl;
+            if (f >= nf) continue;
+            const int2 rng = s_rng[rl];
+            if (rng.y == 0x7FFFFFFF) continue;      // lone chromosome: filled by k_exact_select
+            unsigned long long *sc = scratch + (int64_t)f * Bpad;
+#pragma unroll
+            for (int q = 0; q < TR; ++q) {
+                const int64_t j = j0 + tc + 16 * q;
+                if (j >= a.B) continue;
+                const double d = sum[i][q].result();
+                const bool ok = !(j >= rng.x && j < rng.y) && d < SENTINEL_DISTANCE;   // NaN and >= 1e10 are never admitted (wisetools.py:314)
+                sc[j] = ok ? wc::f64_ordered(d) : ~0ull;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_exact_select(FinishArgs a, const int *__restrict__ rows,
+                                                      const int *__restrict__ n_rows_dev, int n_rows_host, int first,
+                                                      unsigned long long *__restrict__ scratch, int64_t Bpad) {
     __shared__ unsigned long long rk[K_MAX];
     __shared__ int rj[K_MAX];
     __shared__ unsigned int hist[256];
     __shared__ double xs[2048];
-    __shared__ int s_last;
     const int tid = threadIdx.x;
-    const int nfb = *a.fb_count;
-    if (nfb == 0) return;
-    const int nf = nfb < FB_BLOCKS ? nfb : FB_BLOCKS;
-    constexpr int SHARE = FB_BLOCKS / FB_ROWS_PAR;
-    const int part = blockIdx.x % SHARE, lane_row = blockIdx.x / SHARE;
-    for (int f = lane_row; f < nf; f += FB_ROWS_PAR) {
-        const int64_t row = a.fb_rows[f];
-        const double *xi = a.X + row * a.S;
+    const int count = (n_rows_dev ? *n_rows_dev : n_rows_host) - first;
+    const int nf = count > EX_CAP ? EX_CAP : count;
+    if ((int)blockIdx.x < nf) {
+        const int64_t row = rows[first + blockIdx.x];
+        unsigned long long *sc = scratch + (int64_t)blockIdx.x * Bpad;
+        if ((a.lone_mask >> a.chrom_of_row[row]) & 1ull) fb_fill(a, row, a.X + row * a.S, 0, a.B, sc, tid);
         __syncthreads();
-        if (a.S <= 2048) {
-            for (int64_t s = tid; s < a.S; s += 256) xs[s] = xi[s];
-            xi = xs;
-        }
-        __syncthreads();
-        unsigned long long *sc = scratch + (int64_t)f * Bpad;
-        for (int64_t c0 = (int64_t)part * 256; c0 < a.B; c0 += (int64_t)SHARE * 256)
-            fb_fill(a, row, xi, c0, c0 + 256 < a.B ? c0 + 256 : a.B, sc, tid);
-        // publish this part; the last of the row's SHARE workgroups selects (agent-scope release by one lane after
-        // every wave has drained its stores, ticket, agent-scope acquire by the last arriver: the recipe of the
-        // programming guide's inter-workgroup section)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int old = __hip_atomic_fetch_add(&done[f], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = old == SHARE - 1;
-            if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-        if (s_last) fb_select(a, row, sc, rk, rj, hist, tid);
+        fb_select(a, row, sc, rk, rj, hist, tid);
     }
-    unsigned long long *own = scratch + ((int64_t)FB_BLOCKS + blockIdx.x) * Bpad;
-    for (int f = FB_BLOCKS + blockIdx.x; f < nfb; f += gridDim.x) {
-        const int64_t row = a.fb_rows[f];
+    // targets beyond EX_CAP (only when the host does not know the count: it loops over bands otherwise)
+    if (!n_rows_dev) return;
+    unsigned long long *own = scratch + ((int64_t)EX_CAP + blockIdx.x) * Bpad;
+    for (int f = EX_CAP + blockIdx.x; f < count; f += gridDim.x) {
+        const int64_t row = rows[first + f];
         const double *xi = a.X + row * a.S;
         __syncthreads();
         if (a.S <= 2048) {
@@ -2181,28 +2041,14 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
     WC_CHECK(st.chrom_off[n_chrom] == n_bins, WC_E_ARG, "newref: chromosome sizes sum to %lld, expected %lld",
              (long long)st.chrom_off[n_chrom], (long long)n_bins);
     st.bins_pad = round_up(n_bins, TB);
-    st.k_pad = round_up(n_samples, BK);
     st.k_pad16 = round_up(n_samples, 64);
     st.cap = LIST_CAP;
     st.expect = LIST_CAP * 3 / 8;     // 384: k = 100 is 4 sigma of the sampled order statistic away, the cap 6
-    if (const char *e = getenv("WC_NEWREF_EXPECT")) {      // tuning switch: candidates per row the sampled threshold aims for
-        const int v = atoi(e);
-        if (v >= 2 * k && v <= LIST_CAP / 2) st.expect = v;
-    }
-    {
-        // "f32": float32 matrix cores; "split": bfloat16 hi/lo pairs (three products per multiply);
-        // default "f16": one float16 product per multiply, representation error charged per row
-        const char *e = getenv("WC_GRAM_MODE");
-        st.gram_mode = (e && strcmp(e, "f32") == 0) ? 0 : ((e && strcmp(e, "split") == 0) ? 1 : 2);
-        st.split = st.gram_mode == 1;
-    }
-    // relative half-width of the key error interval: the float32 accumulation chain (doubled in
-    // the 16-bit modes: nothing is assumed about the rounding inside the matrix cores' dot products
-    // beyond 2^-23 per term) plus, in split mode, the hi+lo representation and the dropped lo.lo
-    // term.  The f16 mode charges its representation error per row (k_convert, tau).
+    // relative half-width of the key error interval: the float32 accumulation chain, doubled because
+    // nothing is assumed about the rounding inside the matrix cores' dot products beyond 2^-23 per
+    // term.  The float16 representation error is charged per row (k_convert, tau).
     const double chain = (double)(n_samples + 16) * 5.9604644775390625e-08;
-    st.beta = st.gram_mode == 1 ? (float)((2.0 * chain + 3.1 * 1.52587890625e-05) * 1.001)
-              : st.gram_mode == 2 ? (float)(2.0 * chain * 1.001) : (float)(chain * 1.001);
+    st.beta = (float)(2.0 * chain * 1.001);
     st.tau = 2.44140625e-04;      // 2^-12: round-to-nearest float16 leaves |a - h| ~ 1.9e-4 |a| (rms)
     int64_t M = round_up((n_bins + 13) / 14, TB);
     if (M < 512) M = 512;
@@ -2215,15 +2061,8 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
     // padded float64 image for the pair engine's gathers (32-bit byte offsets: below 4 GB; the
     // target row and two chunk slabs per wave must fit the LDS: up to 2048 samples)
     st.s_pad = round_up(n_samples, 16);
-    {
-        const char *eng = getenv("WC_FINISH_ENGINE");
-        st.x64_pad = !(eng && strcmp(eng, "rows") == 0) && n_samples <= 2048 &&
-                     st.bins_pad * st.s_pad * 8 < (1ll << 32);
-    }
+    st.x64_pad = n_samples <= 2048 && st.bins_pad * st.s_pad * 8 < (1ll << 32);
     if (st.x64_pad && (rc = st.x64.reserve(sizeof(double) * st.bins_pad * st.s_pad))) return rc;
-    // one operand image: float32 for the fp32 matrix cores, hi/lo bfloat16 pairs for the split tiles
-    if (st.gram_mode == 0 && (rc = st.a32.reserve(sizeof(float) * st.bins_pad * st.k_pad))) return rc;
-    if (st.gram_mode == 1 && (rc = st.a3.reserve(sizeof(float) * st.bins_pad * st.k_pad))) return rc;
     if ((rc = st.m2.reserve(sizeof(float) * 4))) return rc;
     if ((rc = st.norm_lo.reserve(sizeof(float) * st.bins_pad))) return rc;
     if ((rc = st.norm_hi.reserve(sizeof(float) * st.bins_pad))) return rc;
@@ -2242,7 +2081,7 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
     if ((rc = st.cnt.reserve(sizeof(int) * st.bins_pad))) return rc;
     if ((rc = st.list.reserve(sizeof(uint64_t) * st.bins_pad * st.cap))) return rc;
     if ((rc = st.fb_rows.reserve(sizeof(int) * st.bins_pad))) return rc;
-    if ((rc = st.fb_count.reserve(sizeof(int) * (4 + FB_BLOCKS)))) return rc;
+    if ((rc = st.fb_count.reserve(sizeof(int) * 4))) return rc;
     if ((rc = st.stats.reserve(sizeof(int) * st.bins_pad))) return rc;
 
     {
@@ -2294,24 +2133,18 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
         int64_t n_rows = std::min<int64_t>(n_bins, 128);
         int64_t row_step = n_bins / n_rows;
         hipLaunchKernelGGL(k_col_centre, dim3((unsigned)((n_samples + 63) / 64)), dim3(1024), 0, stream, corrected,
-                           n_bins, n_samples, n_rows, row_step, mean2);
+                           n_bins, n_samples, n_rows, row_step, mean2, st.m2.as<int>() + 1);
     }
 
-#define WC_CONVERT(M16)                                                                                         \
-    hipLaunchKernelGGL(k_convert<M16>, dim3((unsigned)(st.bins_pad / 4)), dim3(256), 0, stream, corrected, n_bins, \
-                       n_samples, st.bins_pad, st.k_pad, (const double *)mean2, (double)st.beta, st.tau,           \
-                       st.chrom_off_dev.as<int64_t>(), n_chrom,                                                    \
-                       st.gram_mode == 0 ? st.a32.as<float>() : (float *)nullptr, st.a16.as<unsigned short>(),    \
-                       st.k_pad16, st.norm_lo.as<float>(), st.norm_hi.as<float>(), st.chrom_of_row.as<int>(),      \
-                       st.chrom_range.as<int2>(), (const int *)st.sample_slot.as<int>(),                           \
-                       st.s16.as<unsigned short>(), st.s_norm_lo.as<float>(), st.s_chrom.as<int>(),                \
-                       st.s_range.as<int2>(), st.thr.as<float>(), st.cnt.as<int>(), st.stats.as<int>(),            \
-                       st.gram_mode == 1 ? st.a3.as<unsigned short>() : (unsigned short *)nullptr,                 \
-                       st.x64_pad ? st.x64.as<double>() : (double *)nullptr, st.s_pad, st.m2.as<float>(),          \
-                       st.fb_count.as<int>(), 4 + FB_BLOCKS)
-    if (st.gram_mode == 2) WC_CONVERT(1);
-    else WC_CONVERT(0);
-#undef WC_CONVERT
+    hipLaunchKernelGGL(k_convert, dim3((unsigned)(st.bins_pad / 4)), dim3(256), 0, stream, corrected, n_bins,
+                       n_samples, st.bins_pad, (const double *)mean2, (double)st.beta, st.tau,
+                       st.chrom_off_dev.as<int64_t>(), n_chrom, st.a16.as<unsigned short>(),
+                       st.k_pad16, st.norm_lo.as<float>(), st.norm_hi.as<float>(), st.chrom_of_row.as<int>(),
+                       st.chrom_range.as<int2>(), (const int *)st.sample_slot.as<int>(),
+                       st.s16.as<unsigned short>(), st.s_norm_lo.as<float>(), st.s_chrom.as<int>(),
+                       st.s_range.as<int2>(), st.thr.as<float>(), st.cnt.as<int>(), st.stats.as<int>(),
+                       st.x64_pad ? st.x64.as<double>() : (double *)nullptr, st.s_pad, st.m2.as<float>(),
+                       st.m2.as<int>() + 1, st.fb_count.as<int>(), 4);
     st.fb_dirty = false;
     if (M > n_bins)
         hipLaunchKernelGGL(k_pad_samples, dim3((unsigned)(M - n_bins)), dim3(256), 0, stream, st.k_pad16, n_bins,
@@ -2346,18 +2179,14 @@ int wc_newref_thresholds_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int6
     {
         const int ntiles = (int)st.tiles0_n;
         unsigned grid = (unsigned)(((ntiles + 7) / 8) * 8);
-#define WC_THR16(F16)                                                                                           \
-    hipLaunchKernelGGL(k_gram_thr16<F16>, dim3(grid), dim3(256), 0, stream,                                        \
-                       (const unsigned short *)st.a16.as<unsigned short>(),                                        \
-                       (const unsigned short *)st.s16.as<unsigned short>(), st.k_pad16, (int)(st.k_pad16 / 64),    \
-                       (const float *)st.norm_lo.as<float>(), (const float *)st.s_norm_lo.as<float>(),             \
-                       (const int2 *)st.s_range.as<int2>(), (const int4 *)st.tiles0.as<int4>(), ntiles,            \
-                       st.keys1.as<unsigned int>(), st.n_sample_cols, (const float *)st.m2.as<float>())
         // (LDS-DMA staging was tried here too: 0.554 vs 0.518 ms at 600 x 50 kb -- this kernel's time is its
-        // 472 MB of key-code stores, not its operand path)
-        if (st.gram_mode == 2) WC_THR16(true);
-        else WC_THR16(false);
-#undef WC_THR16
+        // 472 MB of key-code stores, not its operand path; EXPERIMENTS.md)
+        hipLaunchKernelGGL(k_gram_thr16, dim3(grid), dim3(256), 0, stream,
+                           (const unsigned short *)st.a16.as<unsigned short>(),
+                           (const unsigned short *)st.s16.as<unsigned short>(), st.k_pad16, (int)(st.k_pad16 / 64),
+                           (const float *)st.norm_lo.as<float>(), (const float *)st.s_norm_lo.as<float>(),
+                           (const int2 *)st.s_range.as<int2>(), (const int4 *)st.tiles0.as<int4>(), ntiles,
+                           st.keys1.as<unsigned int>(), st.n_sample_cols, (const float *)st.m2.as<float>());
     }
     unsigned sg = (unsigned)((row_end - row_begin + 3) / 4);
     {
@@ -2463,26 +2292,12 @@ int wc_newref_collect_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t
     ctx->last_stats[3] = st.n_sample_cols;
     if (st.tiles1_n == 0) return WC_OK;
     GramArgs g{};
-    if (st.gram_mode == 2) {
-        // the float16 image the threshold estimate used: rows of k_pad16 halfs, 64 samples per slab
-        g.P = g.Q = st.a16.as<float>();
-        g.ld = st.k_pad16 / 2;
-        g.nslab = (int)(st.k_pad16 / 64);
-        const int64_t rem = st.n_samples - (int64_t)(g.nslab - 1) * 64;     // samples in the last slab, 1..64
-        g.last_groups = 4;
-        g.last_steps16 = (int)((rem + 15) / 16);
-        g.m2 = st.m2.as<float>();
-        g.nslab32 = (int)((st.n_samples + 31) / 32);
-        g.last_steps32 = (int)(((st.n_samples - (int64_t)(g.nslab32 - 1) * 32) + 15) / 16);
-    } else {
-        g.P = g.Q = st.split ? st.a3.as<float>() : st.a32.as<float>();
-        g.ld = st.k_pad;
-        g.nslab = (int)(st.k_pad / BK);
-        const int64_t rem = st.n_samples - (int64_t)(g.nslab - 1) * BK;     // samples in the last slab, 1..32
-        g.last_groups = (int)((std::min<int64_t>(rem, 16) + 3) / 4);
-        g.last_steps16 = rem > 16 ? 2 : 1;
-        g.m2 = nullptr;
-    }
+    // the float16 image the threshold estimate used: rows of k_pad16 halfs, 32 samples per slab
+    g.P = g.Q = st.a16.as<float>();
+    g.ld = st.k_pad16 / 2;
+    g.m2 = st.m2.as<float>();
+    g.nslab32 = (int)((st.n_samples + 31) / 32);
+    g.last_steps32 = (int)(((st.n_samples - (int64_t)(g.nslab32 - 1) * 32) + 15) / 16);
     g.nbP = g.nbQ = st.norm_lo.as<float>();
     g.range = st.chrom_range.as<int2>();
     g.tiles = st.tiles.as<int4>();
@@ -2491,49 +2306,19 @@ int wc_newref_collect_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t
     g.cnt = st.cnt.as<int>();
     g.list = st.list.as<unsigned long long>();
     g.cap = (int)st.cap;
-    unsigned grid = (unsigned)(((g.ntiles + 7) / 8) * 8);
-    {
-        const char *e = getenv("WC_GRAM_DEPTH");
-        const bool d1 = e && atoi(e) == 1;
-        const char *se = getenv("WC_GRAM_STAGE");              // "regs": the register-staged tile kernel instead of LDS-DMA (float16 tiles)
-        if (st.gram_mode == 2 && !(se && strcmp(se, "regs") == 0)) {
-            hipLaunchKernelGGL(k_gram_glds, dim3(grid), dim3(256), 0, stream, g);
-        } else if (st.gram_mode == 2) {
-            if (d1) hipLaunchKernelGGL((k_gram<GRAM_F16, 1>), dim3(grid), dim3(256), 0, stream, g);
-            else hipLaunchKernelGGL((k_gram<GRAM_F16, 2>), dim3(grid), dim3(256), 0, stream, g);
-        } else if (st.gram_mode == 1) {
-            if (d1) hipLaunchKernelGGL((k_gram<GRAM_SPLIT, 1>), dim3(grid), dim3(256), 0, stream, g);
-            else hipLaunchKernelGGL((k_gram<GRAM_SPLIT, 2>), dim3(grid), dim3(256), 0, stream, g);
-        } else {
-            hipLaunchKernelGGL((k_gram<GRAM_F32, 1>), dim3(grid), dim3(256), 0, stream, g);
-        }
-    }
+    const unsigned grid = (unsigned)(((g.ntiles + 7) / 8) * 8);
+    hipLaunchKernelGGL(k_gram_glds, dim3(grid), dim3(256), 0, stream, g);
     WC_HIP(hipGetLastError());
     return WC_OK;
 }
 
-// stage D in two halves: `which` bit 0 = the per-row fast path (k_finish), bit 1 = the exact path
-// for the rows it handed over (k_fallback_all; one idle launch when there are none)
-static int newref_finish_part(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t row_end, int32_t *idx_out,
-                              double *dist_out, int which) {
-    WC_CHECK(ctx && ctx->nr.prepared, WC_E_ARG, "newref: prepare has not run");
-    NewrefState &st = ctx->nr;
-    WC_CHECK(row_begin >= 0 && row_begin <= row_end && row_end <= st.n_bins, WC_E_ARG, "newref: bad row range");
-    WC_CHECK(idx_out && dist_out, WC_E_ARG, "newref: NULL output");
-    if (row_begin == row_end) return WC_OK;
-    hipStream_t stream = (hipStream_t)stream_;
-    int rc;
-    if ((rc = st.fb_scratch.reserve(sizeof(uint64_t) * 2 * FB_BLOCKS * st.bins_pad))) return rc;
-    if (which & 5) {
-        // the counter and the rows' tickets: k_convert zeroed them for the first pick of a prepared job; a second
-        // finish on the same prepared state starts from a memset
-        if (st.fb_dirty) WC_HIP(hipMemsetAsync(st.fb_count.p, 0, sizeof(int) * (4 + FB_BLOCKS), stream));
-        st.fb_dirty = true;
-    }
-    FinishArgs a{};
+// the arguments every kernel of stage D shares
+static void finish_args(NewrefState &st, int64_t row_begin, int64_t row_end, int32_t *idx_out, double *dist_out,
+                        FinishArgs &a) {
     a.X = st.corrected;
     a.B = st.n_bins;
     a.S = st.n_samples;
+    a.norm_lo = st.norm_lo.as<float>();
     a.norm_hi = st.norm_hi.as<float>();
     a.thr = st.thr.as<float>();
     a.cnt = st.cnt.as<int>();
@@ -2549,6 +2334,7 @@ static int newref_finish_part(wc_ctx *ctx, void *stream_, int64_t row_begin, int
     a.dist_out = dist_out;
     a.fb_rows = st.fb_rows.as<int>();
     a.fb_count = st.fb_count.as<int>();
+    a.bad_norm = st.m2.as<float>() + 1;
     a.row_stat = st.stats.as<int>();
     a.sum_order = st.sum_order;
     a.lone_mask = 0ull;
@@ -2558,56 +2344,114 @@ static int newref_finish_part(wc_ctx *ctx, void *stream_, int64_t row_begin, int
     a.xs_in_lds = st.n_samples <= 2048;
     a.pw_prog = st.pw_prog.as<int2>();
     a.pw_leaves = st.pw_leaves;
-    const char *eng = getenv("WC_FINISH_ENGINE");   // "rows": the one-workgroup-per-row kernel (k_finish) for every row
+}
+
+// The exact path over the rows listed in fb_rows: `n_host` < 0 -- the count is on the device (the rows the fast
+// path handed over; ONE launch pair sized for EX_CAP rows, no read-back); otherwise the host knows it and loops
+// over bands of EX_CAP rows.
+static int launch_exact(NewrefState &st, hipStream_t stream, const FinishArgs &a, int64_t n_host) {
+    int rc;
+    if ((rc = st.fb_scratch.reserve(sizeof(uint64_t) * 2 * EX_CAP * st.bins_pad))) return rc;
+    const bool seq = st.sum_order == WC_SUM_SEQUENTIAL || st.n_samples < 8;
+    const int edge = seq ? 64 : 32;                                  // targets / candidates per tile
+    const unsigned ctiles = (unsigned)((st.n_bins + edge - 1) / edge);
+    unsigned long long *scratch = st.fb_scratch.as<unsigned long long>();
+    const int *rows = st.fb_rows.as<int>();
+    const int *n_dev = n_host < 0 ? (const int *)st.fb_count.as<int>() : nullptr;
+    const int64_t total = n_host < 0 ? 1 : n_host;
+    for (int64_t first = 0; first < total; first += EX_CAP) {
+        const int64_t nf = n_host < 0 ? EX_CAP : std::min<int64_t>(EX_CAP, n_host - first);
+        // row groups in flight: a few when the count is unknown (surplus workgroups leave at once)
+        const unsigned rgroups = n_host < 0 ? 4u : (unsigned)((nf + edge - 1) / edge);
+        const unsigned nsel = n_host < 0 ? (unsigned)EX_CAP : (unsigned)nf;
+        if (seq) hipLaunchKernelGGL((k_exact_tile<true>), dim3(ctiles, rgroups), dim3(256), 0, stream, a, rows, n_dev,
+                                    (int)n_host, (int)first, scratch, st.bins_pad);
+        else hipLaunchKernelGGL((k_exact_tile<false>), dim3(ctiles, rgroups), dim3(256), 0, stream, a, rows, n_dev,
+                                (int)n_host, (int)first, scratch, st.bins_pad);
+        hipLaunchKernelGGL(k_exact_select, dim3(nsel), dim3(256), 0, stream, a, rows, n_dev, (int)n_host, (int)first,
+                           scratch, st.bins_pad);
+    }
+    return WC_OK;
+}
+
+// stage D in parts: `which` bit 0 = the per-row fast path (k_pick + k_rescore; k_finish beyond 2048 samples),
+// bit 1 = the exact path for the rows it handed over (two idle launches when there are none), bit 2 = k_pick
+// alone, bit 3 = k_rescore alone
+static int newref_finish_part(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t row_end, int32_t *idx_out,
+                              double *dist_out, int which) {
+    WC_CHECK(ctx && ctx->nr.prepared, WC_E_ARG, "newref: prepare has not run");
+    NewrefState &st = ctx->nr;
+    WC_CHECK(row_begin >= 0 && row_begin <= row_end && row_end <= st.n_bins, WC_E_ARG, "newref: bad row range");
+    WC_CHECK(idx_out && dist_out, WC_E_ARG, "newref: NULL output");
+    if (row_begin == row_end) return WC_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc;
+    if (which & 5) {
+        // the counter of exact rows: k_convert zeroed it for the first pick of a prepared job; a second
+        // finish on the same prepared state starts from a memset
+        if (st.fb_dirty) WC_HIP(hipMemsetAsync(st.fb_count.p, 0, sizeof(int) * 4, stream));
+        st.fb_dirty = true;
+    }
+    FinishArgs a{};
+    finish_args(st, row_begin, row_end, idx_out, dist_out, a);
     // pair engine: workgroups of k + margin threads (whole waves); refsize beyond PS_MAX - 28 takes several trips
     const int ps = (int)std::max<int64_t>(128, std::min<int64_t>(PS_MAX, round_up(st.k + 28, 64)));
-    const bool pair_engine = st.x64_pad && !(eng && strcmp(eng, "rows") == 0) && !st.exact_only;
+    const bool pair_engine = st.x64_pad && !st.exact_only;
     if ((which & 12) && !pair_engine) which = (which & ~12) | ((which & 4) ? 1 : 0);   // no halves outside the pair engine: all of it in the first call
+    const bool seq = st.sum_order == WC_SUM_SEQUENTIAL || st.n_samples < 8;
+    const unsigned rows = (unsigned)(row_end - row_begin);
     if ((which & 1) && st.exact_only) {
-        const unsigned rows = (unsigned)(row_end - row_begin);
         hipLaunchKernelGGL(k_all_exact, dim3((rows + 255) / 256), dim3(256), 0, stream, a);
     } else if ((which & 13) && pair_engine) {
-        const bool seq = st.sum_order == WC_SUM_SEQUENTIAL || st.n_samples < 8;
         if ((rc = st.pairs.reserve(sizeof(int) * st.bins_pad * RMAX))) return rc;
         PickArgs p{a, st.pairs.as<int>(), ps};
-        const unsigned rows = (unsigned)(row_end - row_begin);
         if (which & 5) hipLaunchKernelGGL(k_pick, dim3((rows + 3) / 4), dim3(256), 0, stream, p);
-        // wave slabs; after the sums the same memory holds dk / sd / jv / sj of the counting order
-        // chunk staging: LDS-DMA for the pairwise order (measured at 100 samples x 250 kb: 0.099 vs 0.131 ms; no
-        // staging registers -> no spills in that variant), registers for the sequential order (0.076 vs 0.083 ms:
-        // the DMA of the next chunk can only be issued after this chunk's LDS reads have returned);
-        // WC_RESCORE_STAGE=regs|glds forces one
-        const char *rs_env = getenv("WC_RESCORE_STAGE");
-        const bool glds = rs_env && strcmp(rs_env, "glds") == 0 ? true : (rs_env && strcmp(rs_env, "regs") == 0 ? false : !seq);
+        // wave slabs; after the sums the same memory holds dk / sd / jv / sj of the counting order.
+        // Chunk staging: LDS-DMA for the pairwise order (100 samples x 250 kb: 0.099 vs 0.131 ms, no staging
+        // registers), registers for the sequential order (0.076 vs 0.083 ms: the DMA of the next chunk can only
+        // be issued after this chunk's LDS reads have returned)
         const size_t slabs = sizeof(double) * (size_t)(ps / 64) * SLAB_DOUBLES;
         const size_t order = (sizeof(unsigned long long) + sizeof(int)) * (2 * RMAX + 4);
         const size_t dyn = sizeof(double) * st.s_pad + std::max(slabs, order);
         if (!(which & 9)) {
-        } else if (seq && glds) hipLaunchKernelGGL((k_rescore<true, true>), dim3(rows), dim3(ps), dyn, stream, p,
-                                                   (const double *)st.x64.as<double>(), (int)st.s_pad);
-        else if (seq) hipLaunchKernelGGL((k_rescore<true, false>), dim3(rows), dim3(ps), dyn, stream, p,
-                                         (const double *)st.x64.as<double>(), (int)st.s_pad);
-        else if (glds) hipLaunchKernelGGL((k_rescore<false, true>), dim3(rows), dim3(ps), dyn, stream, p,
-                                          (const double *)st.x64.as<double>(), (int)st.s_pad);
-        else hipLaunchKernelGGL((k_rescore<false, false>), dim3(rows), dim3(ps), dyn, stream, p,
+        } else if (seq) hipLaunchKernelGGL((k_rescore<true, false>), dim3(rows), dim3(ps), dyn, stream, p,
+                                           (const double *)st.x64.as<double>(), (int)st.s_pad);
+        else hipLaunchKernelGGL((k_rescore<false, true>), dim3(rows), dim3(ps), dyn, stream, p,
                                 (const double *)st.x64.as<double>(), (int)st.s_pad);
     } else if (which & 1) {
-        const bool seq = st.sum_order == WC_SUM_SEQUENTIAL || st.n_samples < 8;
-        const char *e = getenv("WC_FINISH_THREADS");
-        const int nt = e ? atoi(e) : 128;   // 128 threads per row measured faster at every size tried
-        const dim3 grid((unsigned)(row_end - row_begin));
+        // more than 2048 samples (the pair engine's LDS holds the target row and its chunk slabs up to there):
+        // one 128-thread workgroup per row does selection, re-score and order
         const size_t dyn = a.xs_in_lds ? sizeof(double) * st.n_samples : 0;
-        if (nt == 128) {
-            if (seq) hipLaunchKernelGGL((k_finish<true, 128>), grid, dim3(128), dyn, stream, a);
-            else hipLaunchKernelGGL((k_finish<false, 128>), grid, dim3(128), dyn, stream, a);
-        } else {
-            if (seq) hipLaunchKernelGGL((k_finish<true, 256>), grid, dim3(256), dyn, stream, a);
-            else hipLaunchKernelGGL((k_finish<false, 256>), grid, dim3(256), dyn, stream, a);
-        }
+        if (seq) hipLaunchKernelGGL((k_finish<true, 128>), dim3(rows), dim3(128), dyn, stream, a);
+        else hipLaunchKernelGGL((k_finish<false, 128>), dim3(rows), dim3(128), dyn, stream, a);
     }
-    if (which & 2)
-        hipLaunchKernelGGL(k_fallback_all, dim3(FB_BLOCKS), dim3(256), 0, stream, a,
-                           st.fb_scratch.as<unsigned long long>(), st.bins_pad, st.fb_count.as<int>() + 4);
+    if (which & 2) {
+        if (st.exact_only) rc = launch_exact(st, stream, a, (int64_t)rows);
+        else rc = launch_exact(st, stream, a, -1);
+        if (rc) return rc;
+    }
+    WC_HIP(hipGetLastError());
+    return WC_OK;
+}
+
+// The exact path for EVERY row of [row_begin, row_end) on a prepared job (wc_newref_prepare_dev): float64
+// distances to all candidates in numpy's order, stable selection -- no matrix cores, no bounds, no lists.
+// The full-size tests hold the fast path against it row by row; it is also what refsize > 256 runs.
+int wc_newref_exact_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t row_end, int32_t *idx_out,
+                        double *dist_out) {
+    WC_CHECK(ctx && ctx->nr.prepared, WC_E_ARG, "newref: prepare has not run");
+    NewrefState &st = ctx->nr;
+    WC_CHECK(row_begin >= 0 && row_begin <= row_end && row_end <= st.n_bins, WC_E_ARG, "newref: bad row range");
+    WC_CHECK(idx_out && dist_out, WC_E_ARG, "newref: NULL output");
+    if (row_begin == row_end) return WC_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    FinishArgs a{};
+    finish_args(st, row_begin, row_end, idx_out, dist_out, a);
+    const unsigned rows = (unsigned)(row_end - row_begin);
+    hipLaunchKernelGGL(k_all_exact, dim3((rows + 255) / 256), dim3(256), 0, stream, a);
+    st.fb_dirty = true;
+    const int rc = launch_exact(st, stream, a, (int64_t)rows);
+    if (rc) return rc;
     WC_HIP(hipGetLastError());
     return WC_OK;
 }
@@ -2677,100 +2521,12 @@ static int newref_pass(wc_ctx *ctx, void *stream, const double *corrected, int64
     return wc_newref_finish_dev(ctx, stream, row_begin, row_end, idx_out, dist_out);
 }
 
-static int64_t env_word(const char *name) {     // the switches are read per call: a changed one is a different pass
-    const char *e = getenv(name);
-    int64_t h = 1469598103934665603ll;
-    for (; e && *e; ++e) h = (h ^ (unsigned char)*e) * 1099511628211ll;
-    return e ? h : 0;
-}
-
-// WC_NEWREF_GRAPH=1: the whole pass (ten launches) is replayed as ONE hipGraph from the third
-// identical call on: the first call sizes the workspaces and uploads the tables, the second one is
-// captured.  A graph bakes addresses in, so it is keyed on every argument, on the switches and on
-// wc::realloc_epoch(); a capture that fails is remembered and that call stays eager.  Off by
-// default: measured at 100 samples x 250 kb the replay is no faster than the eager launch series
-// (0.221 vs 0.216 ms on a stream of its own, 0.258 vs 0.220 ms behind the NULL stream, where the
-// graph needs a private stream and two event hops) -- the launches are queued ahead of the GPU
-// anyway, and the dispatch gaps between dependent kernels are the same inside a graph.
 int wc_get_reference_dev(wc_ctx *ctx, void *stream_, const double *corrected, int64_t n_bins, int64_t n_samples,
                          const int64_t *chrom_bins_host, int n_chrom, int k, int sum_order,
                          int64_t row_begin, int64_t row_end, int32_t *idx_out, double *dist_out) {
     WC_CHECK(ctx && corrected && chrom_bins_host, WC_E_ARG, "newref: NULL argument");
-    NewrefState &st = ctx->nr;
-    const char *ge = getenv("WC_NEWREF_GRAPH");
-    const bool want = ge && ge[0] == '1' && n_chrom > 0 && n_chrom <= WC_MAX_CHROM && row_end > row_begin;
-    std::vector<int64_t> key;
-    if (want) {
-        key = {(int64_t)(intptr_t)corrected, n_bins, n_samples, n_chrom, k, sum_order, row_begin, row_end,
-               (int64_t)(intptr_t)idx_out, (int64_t)(intptr_t)dist_out, (int64_t)(intptr_t)stream_,
-               env_word("WC_GRAM_MODE"), env_word("WC_GRAM_DEPTH"), env_word("WC_GRAM_STAGE"), env_word("WC_RESCORE_STAGE"), env_word("WC_FINISH_ENGINE"),
-               env_word("WC_FINISH_THREADS")};
-        for (int c = 0; c < n_chrom; ++c) key.push_back(chrom_bins_host[c]);
-    }
-    if (st.pass_exec && (key != st.pass_key || st.pass_epoch != wc::realloc_epoch())) {
-        (void)hipGraphExecDestroy(st.pass_exec);
-        st.pass_exec = nullptr;
-        st.pass_warm = false;
-    }
-    if (!want || key == st.pass_fail_key) {
-        st.pass_key.clear();
-        st.pass_warm = false;
-        return newref_pass(ctx, stream_, corrected, n_bins, n_samples, chrom_bins_host, n_chrom, k, sum_order,
-                           row_begin, row_end, idx_out, dist_out);
-    }
-    if (key != st.pass_key || st.pass_epoch != wc::realloc_epoch()) st.pass_warm = false;
-    if (!st.pass_exec && !st.pass_warm) {
-        // first sight of this call: eager (reserves, uploads); the next one can be captured
-        int rc = newref_pass(ctx, stream_, corrected, n_bins, n_samples, chrom_bins_host, n_chrom, k, sum_order,
-                             row_begin, row_end, idx_out, dist_out);
-        st.pass_key = key;
-        st.pass_warm = rc == WC_OK;
-        st.pass_epoch = wc::realloc_epoch();
-        return rc;
-    }
-    WC_HIP(hipSetDevice(ctx->device));
-    hipStream_t stream = (hipStream_t)stream_;
-    hipStream_t ls = stream;
-    if (stream == nullptr) {        // the NULL stream cannot be captured: the context's own stream, ordered behind it
-        if (!ctx->lat_stream) {
-            WC_HIP(hipStreamCreateWithFlags(&ctx->lat_stream, hipStreamNonBlocking));
-            WC_HIP(hipEventCreateWithFlags(&ctx->ev_lat_in, hipEventDisableTiming));
-            WC_HIP(hipEventCreateWithFlags(&ctx->ev_lat_out, hipEventDisableTiming));
-        }
-        ls = ctx->lat_stream;
-    }
-    if (!st.pass_exec) {
-        hipGraph_t graph = nullptr;
-        bool ok = hipStreamBeginCapture(ls, hipStreamCaptureModeThreadLocal) == hipSuccess;
-        int rc = WC_OK;
-        if (ok) {
-            rc = newref_pass(ctx, ls, corrected, n_bins, n_samples, chrom_bins_host, n_chrom, k, sum_order, row_begin,
-                             row_end, idx_out, dist_out);
-            ok = hipStreamEndCapture(ls, &graph) == hipSuccess && graph && rc == WC_OK &&
-                 st.pass_epoch == wc::realloc_epoch();
-        }
-        if (ok) ok = hipGraphInstantiate(&st.pass_exec, graph, nullptr, nullptr, 0) == hipSuccess;
-        if (graph) (void)hipGraphDestroy(graph);
-        if (!ok) {
-            (void)hipGetLastError();
-            st.pass_exec = nullptr;
-            st.pass_fail_key = key;
-            st.pass_key.clear();
-            st.pass_warm = false;
-            return newref_pass(ctx, stream_, corrected, n_bins, n_samples, chrom_bins_host, n_chrom, k, sum_order,
-                               row_begin, row_end, idx_out, dist_out);
-        }
-    }
-    if (ls != stream) {
-        WC_HIP(hipEventRecord(ctx->ev_lat_in, stream));
-        WC_HIP(hipStreamWaitEvent(ls, ctx->ev_lat_in, 0));
-    }
-    WC_HIP(hipGraphLaunch(st.pass_exec, ls));
-    if (ls != stream) {
-        WC_HIP(hipEventRecord(ctx->ev_lat_out, ls));
-        WC_HIP(hipStreamWaitEvent(stream, ctx->ev_lat_out, 0));
-    }
-    return WC_OK;
+    return newref_pass(ctx, stream_, corrected, n_bins, n_samples, chrom_bins_host, n_chrom, k, sum_order,
+                       row_begin, row_end, idx_out, dist_out);
 }
 
 int wc_get_reference(wc_ctx *ctx, const double *corrected, int64_t n_bins, int64_t n_samples,

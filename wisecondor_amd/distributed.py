@@ -53,8 +53,7 @@ class HipStages(object):
         self.cap = int(self.lib.wc_newref_list_capacity(self.ctx))
 
     def full_pass(self, idx, dst):
-        """All four stages for every row in one C call (wc_get_reference_dev): the library replays
-        the launch series as one hipGraph from the third identical call on."""
+        """All four stages for every row in one C call (wc_get_reference_dev)."""
         _lib.check(self.lib.wc_get_reference_dev(self.ctx, self._stream(), self.X.data_ptr(), self.n_bins,
                                                  self.n_samples, _lib.ptr(self.bins), len(self.bins), self.k,
                                                  self.order, 0, self.n_bins, idx.data_ptr(), dst.data_ptr()))
@@ -99,6 +98,11 @@ class HipStages(object):
 
     def fallback(self, rb, re, idx, dst):
         _lib.check(self.lib.wc_newref_fallback_dev(self.ctx, self._stream(), rb, re, idx.data_ptr(), dst.data_ptr()))
+
+    def exact(self, rb, re, idx, dst):
+        """Every row of [rb, re) by the exact path (float64 distances to all candidates, stable selection) on a
+        prepared job: what the full-size tests hold the fast path against."""
+        _lib.check(self.lib.wc_newref_exact_dev(self.ctx, self._stream(), rb, re, idx.data_ptr(), dst.data_ptr()))
 
     def empty(self, shape, dtype):
         return self.torch.empty(shape, dtype=dtype, device=self.device)
