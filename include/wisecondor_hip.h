@@ -157,7 +157,8 @@ int wc_launch_floor_us(wc_ctx *ctx, void *stream, int n, int reps, double *out);
  *   undefined and the caller reads that file the slow way (np.load), which also words the error.
  * wc_write_test_results: one `test` output file per row (keys / dtypes / shapes of the reference's,
  *   SURVEY.md App. B): arguments (args_npy[i]: the ready-made .npy member bytes, a pickled dict),
- *   runtime (shared bytes), binsize, results_r / results_z (object arrays of n_chrom float64 arrays cut
+ *   runtime (shared bytes), binsize (int64 when binsize_is_int -- the reference stores the Python value it read
+ *   from the reference file unchanged --, else float64), results_r / results_z (object arrays of n_chrom float64 arrays cut
  *   from row i of r / z at chrom_sizes), results_cwz [n_sel], results_calls [n, 5] (shape (0,) when
  *   empty), threshold_z, asdef, aasdef = asdef * threshold_z.  level: zlib level of the members
  *   (0 = stored).  status[i]: WC_OK or WC_NPZ_IO.
@@ -175,7 +176,8 @@ int wc_read_sample_lengths(const char *const *paths, int n_files, int n_threads,
                            int64_t *lengths_out, double *binsize_out, int *status);
 int wc_write_test_results(int n_files, int n_threads, const char *const *out_paths,
                           const unsigned char *const *args_npy, const int64_t *args_len,
-                          const unsigned char *runtime_npy, int64_t runtime_len, double binsize, double threshold_z,
+                          const unsigned char *runtime_npy, int64_t runtime_len, double binsize, int binsize_is_int,
+                          double threshold_z,
                           const int64_t *chrom_sizes, int n_chrom, const double *z, const double *r,
                           int64_t row_stride, const double *cwz, int n_sel, const double *calls,
                           const int32_t *n_calls, int max_calls, const double *asdef, int level, int *status);

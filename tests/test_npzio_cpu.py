@@ -158,15 +158,17 @@ def test_writer_matches_np_savez(tmp_path):
         per_file.append(one)
         outs.append(one.outfile)
     runtime = {"version": "abc", "datetime": "now", "hostname": "h", "username": "u"}
-    for level in (1, 0):
-        ingest.write_results(outs, per_file, runtime, 250000.0, 5.25, sizes, z, r, cwz, calls, n_calls, asdef,
+    # binsize as the reference file holds it: a float (the reference's CLI, type=float) or an int (this CLI's
+    # -binsize): the Python value goes into the file unchanged, so the member's dtype follows it
+    for level, binsize in ((1, 250000.0), (0, 250000)):
+        ingest.write_results(outs, per_file, runtime, binsize, 5.25, sizes, z, r, cwz, calls, n_calls, asdef,
                              threads=3, level=level)
         for i in range(n):
             result = dict(results_z=[z[i, offs[c]:offs[c + 1]] for c in range(22)],
                           results_r=[r[i, offs[c]:offs[c + 1]] for c in range(22)],
                           results_cwz=cwz[i], results_calls=calls[i, :n_calls[i]], asdef=float(asdef[i]))
             ref_path = str(tmp_path / ("python_%d.npz" % i))
-            cli.writeTestOutput(ref_path, per_file[i], 250000.0, result, 5.25)
+            cli.writeTestOutput(ref_path, per_file[i], binsize, result, 5.25)
             a = np.load(ref_path, allow_pickle=True)
             b = np.load(outs[i], allow_pickle=True)
             assert sorted(a.files) == sorted(b.files)
@@ -182,6 +184,7 @@ def test_writer_matches_np_savez(tmp_path):
                     assert all(p.dtype == q.dtype and np.array_equal(p, q) for p, q in zip(x, y)), key
                 else:
                     assert np.array_equal(x, y), key
+            assert b["binsize"].dtype == (np.int64 if isinstance(binsize, int) else np.float64)
             assert b["results_calls"].shape == ((n_calls[i], 5) if n_calls[i] else (0,))
             with zipfile.ZipFile(outs[i]) as zf:
                 assert zf.testzip() is None

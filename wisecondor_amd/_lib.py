@@ -45,7 +45,7 @@ SIGNATURES = {
     "wc_launch_floor_us": (_i32, [_vp, _vp, _i32, _i32, _vp]),
     "wc_read_samples": (_i32, [_vp, _i32, _i32, _vp, _i32, _dbl, _vp, _i64, _vp, _vp]),
     "wc_read_sample_lengths": (_i32, [_vp, _i32, _i32, _i32, _dbl, _vp, _vp, _vp]),
-    "wc_write_test_results": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _i32, _vp, _vp, _i64, _vp,
+    "wc_write_test_results": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _i64, _dbl, _i32, _dbl, _vp, _i32, _vp, _vp, _i64, _vp,
                                      _i32, _vp, _vp, _i32, _vp, _i32, _vp]),
     "wc_newref_prep_gram": (_i32, [_vp, _vp, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _vp]),
     "wc_newref_prep_eig": (_i32, [_vp, _i32, _vp, _vp]),

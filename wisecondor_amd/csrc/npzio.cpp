@@ -58,6 +58,10 @@ bool read_file(const char *path, std::string &out) {
     return got == (size_t)n;
 }
 
+// Largest member this reader inflates: a converted sample is a few MB; anything beyond this is a damaged header
+// (the file is then left to np.load, which words the error).
+constexpr uint64_t MAX_MEMBER_BYTES = 1ull << 30;
+
 bool zip_directory(const std::string &buf, std::vector<ZipEntry> &out) {
     const unsigned char *b = (const unsigned char *)buf.data();
     const size_t n = buf.size();
@@ -69,13 +73,15 @@ bool zip_directory(const std::string &buf, std::vector<ZipEntry> &out) {
     uint64_t count = rd16(b + eocd + 10), cd_off = rd32(b + eocd + 16);
     if ((count == 0xFFFF || cd_off == 0xFFFFFFFFu) && eocd >= 20 && rd32(b + eocd - 20) == 0x07064b50u) {
         const uint64_t z64 = rd64(b + eocd - 20 + 8);        // zip64 end of central directory record
-        if (z64 + 56 > n || rd32(b + z64) != 0x06064b50u) return false;
+        // (every offset and size below comes from the file: compare without additions that could wrap)
+        if (n < 56 || z64 > n - 56 || rd32(b + z64) != 0x06064b50u) return false;
         count = rd64(b + z64 + 32);
         cd_off = rd64(b + z64 + 48);
     }
+    if (cd_off > n || count > n / 46) return false;         // a directory entry takes at least 46 bytes
     size_t at = (size_t)cd_off;
     for (uint64_t e = 0; e < count; ++e) {
-        if (at + 46 > n || rd32(b + at) != 0x02014b50u) return false;
+        if (n - at < 46 || rd32(b + at) != 0x02014b50u) return false;
         ZipEntry z;
         z.method = rd16(b + at + 10);
         z.crc = rd32(b + at + 16);
@@ -83,7 +89,7 @@ bool zip_directory(const std::string &buf, std::vector<ZipEntry> &out) {
         z.usize = rd32(b + at + 24);
         const size_t nl = rd16(b + at + 28), xl = rd16(b + at + 30), cl = rd16(b + at + 32);
         z.local = rd32(b + at + 42);
-        if (at + 46 + nl + xl + cl > n) return false;
+        if (n - at - 46 < nl + xl + cl) return false;
         z.name.assign((const char *)b + at + 46, nl);
         // zip64 extra field: the values that overflowed, in the order usize, csize, local offset
         size_t x = at + 46 + nl;
@@ -98,6 +104,9 @@ bool zip_directory(const std::string &buf, std::vector<ZipEntry> &out) {
             }
             x += 4 + len;
         }
+        // a member cannot be larger than the file that holds it (stored) / a sane multiple of it (deflated), and its
+        // header must lie inside the file
+        if (z.csize > n || z.local > n || z.usize > MAX_MEMBER_BYTES) return false;
         out.push_back(z);
         at += 46 + nl + xl + cl;
     }
@@ -106,9 +115,11 @@ bool zip_directory(const std::string &buf, std::vector<ZipEntry> &out) {
 
 bool zip_member(const std::string &buf, const ZipEntry &z, std::string &out) {
     const unsigned char *b = (const unsigned char *)buf.data();
-    if (z.local + 30 > buf.size() || rd32(b + z.local) != 0x04034b50u) return false;
-    const size_t data = (size_t)z.local + 30 + rd16(b + z.local + 26) + rd16(b + z.local + 28);
-    if (data + z.csize > buf.size()) return false;
+    const size_t n = buf.size();
+    if (n < 30 || z.local > n - 30 || rd32(b + z.local) != 0x04034b50u) return false;
+    const size_t data = (size_t)z.local + 30 + rd16(b + z.local + 26) + rd16(b + z.local + 28);   // <= n + 2 * 65535: no wrap
+    if (data > n || z.csize > n - data) return false;
+    if (z.usize > MAX_MEMBER_BYTES || z.csize > 0xFFFFFFFFull || z.usize > 0xFFFFFFFFull) return false;   // zlib's 32-bit counters
     out.resize((size_t)z.usize);
     if (z.method == 0) {
         if (z.csize != z.usize) return false;
@@ -333,7 +344,7 @@ bool array_values(const VP &a, std::vector<int64_t> &out) {
     size_t w = 0;
     if (c == "i4" || c == "u4") w = 4; else if (c == "i8" || c == "u8") w = 8; else if (c == "i2" || c == "u2") w = 2;
     else if (c == "f8") w = 8; else if (c == "f4") w = 4; else return false;
-    if (n < 0 || a->s.size() != (size_t)n * w) return false;
+    if (n < 0 || (uint64_t)n > a->s.size() / w || a->s.size() != (size_t)n * w) return false;   // (n * w cannot wrap after the first test)
     out.resize((size_t)n);
     const char *p = a->s.data();
     for (int64_t e = 0; e < n; ++e, p += w) {
@@ -624,6 +635,7 @@ int wc_read_sample_lengths(const char *const *paths, int n_files, int n_threads,
 
 int wc_write_test_results(int n_files, int n_threads, const char *const *out_paths, const unsigned char *const *args_npy,
                           const int64_t *args_len, const unsigned char *runtime_npy, int64_t runtime_len, double binsize,
+                          int binsize_is_int,
                           double threshold_z, const int64_t *chrom_sizes, int n_chrom, const double *z, const double *r,
                           int64_t row_stride, const double *cwz, int n_sel, const double *calls, const int32_t *n_calls,
                           int max_calls, const double *asdef, int level, int *status) {
@@ -637,7 +649,15 @@ int wc_write_test_results(int n_files, int n_threads, const char *const *out_pat
             const std::vector<int64_t> none;
             bool ok = zw.add("arguments.npy", std::string((const char *)args_npy[i], (size_t)args_len[i]));
             ok = ok && zw.add("runtime.npy", std::string((const char *)runtime_npy, (size_t)runtime_len));
-            ok = ok && zw.add("binsize.npy", npy_f64(&binsize, none));
+            if (binsize_is_int) {
+                // the reference stores referenceFile['binsize'].item() unchanged: a Python int becomes an int64 array
+                const int64_t bi = (int64_t)binsize;
+                std::string m = npy_header("<i8", "()");
+                m.append((const char *)&bi, 8);
+                ok = ok && zw.add("binsize.npy", m);
+            } else {
+                ok = ok && zw.add("binsize.npy", npy_f64(&binsize, none));
+            }
             ok = ok && zw.add("results_r.npy", npy_object_of_f64(r + (int64_t)i * row_stride, chrom_sizes, n_chrom), true);
             ok = ok && zw.add("results_z.npy", npy_object_of_f64(z + (int64_t)i * row_stride, chrom_sizes, n_chrom), true);
             ok = ok && zw.add("results_cwz.npy", npy_f64(cwz + (int64_t)i * n_sel, {(int64_t)n_sel}));

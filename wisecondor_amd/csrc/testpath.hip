@@ -546,39 +546,63 @@ __device__ inline void zscore_one(const int64_t b, const int64_t i, const int64_
 
 // The same for a wave that holds ONE bin and 64 samples (b wave-uniform) when every lane keeps
 // all of its values, the normal case in the first repeat: the G full groups of eight stay in
-// registers, so the references are gathered once instead of once per pass -- the gathers are
-// what the kernel waits for (about 1 KB per reference row and wave, from L2).  Anything else
-// (a dropped value anywhere in the wave, a list longer than 8 G + 7) takes zscore_one.
+// registers, so the references are gathered once instead of once per pass.
+// The wave's life is a latency chain, so everything it will need is requested at once: the bin's
+// whole index list by 16-index scalar loads (the list is padded with -1 beyond its length and the
+// array by one such load at its end, so no load depends on the length), then every gather -- an
+// index of -1 reads row 0 and is masked afterwards (no branch between a scalar load and its gather:
+// one index at a time, each waited for, was ~100 dependent round trips per wave), the pair's own
+// value with them.  Anything else (a dropped value anywhere in the wave, a list longer than
+// 8 G + 7, a list stride that is not a multiple of four) takes zscore_one.
+typedef int int16v __attribute__((ext_vector_type(16), aligned(16)));   // list rows start 16-byte aligned (k % 4 == 0)
 template <int G>
 __device__ inline void zscore_wave(const int b, const int64_t i, const int64_t gid, const double *__restrict__ XT,
                                    const double *__restrict__ XC, const int *__restrict__ gidx,
                                    const int *__restrict__ nref, int k, int64_t Ns, double *__restrict__ zT,
                                    double *__restrict__ rT, double *__restrict__ nT, double *__restrict__ sdT) {
+    constexpr int NL = (8 * G + 7 + 15) / 16;      // 16-index loads that cover 8 G + 7 list slots
     const int *lst = gidx + (int64_t)b * k;
     const int n = nref[b];
     const int ng = n >> 3;
-    double v[8 * G];
-    bool mine = true;
-    if (ng <= G) {
+    if (ng > G || (k & 3)) {
+        zscore_one(b, i, gid, XT, XC, gidx, nref, k, Ns, zT, rT, nT, sdT);
+        return;
+    }
+    double v[16 * NL];
+    const double x = XT[gid];
+    {
+        const int16v *l16 = reinterpret_cast<const int16v *>(lst);
+        unsigned int absent[NL];                                    // per 16 slots: bit e set = no reference there
+        const unsigned int ioff = (unsigned int)i * 8u;             // scalar row base + this lane's 32-bit byte offset
 #pragma unroll
-        for (int q = 0; q < G; ++q) {
-            if (q < ng) {
+        for (int t = 0; t < NL; ++t) {
+            const int16v g16 = l16[t];
+            unsigned int bits = 0u;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int g = lst[8 * q + e];
-                    v[8 * q + e] = g >= 0 ? XC[(int64_t)g * Ns + i] : -1.0;
-                }
+            for (int e = 0; e < 16; ++e) {
+                const int g = 16 * t + e < k ? g16[e] : -1;        // slots beyond this bin's list belong to the next bin
+                bits |= g < 0 ? (1u << e) : 0u;
+                const char *rowp = reinterpret_cast<const char *>(XC + (int64_t)(g < 0 ? 0 : g) * Ns);
+                v[16 * t + e] = *reinterpret_cast<const double *>(rowp + ioff);
             }
+            absent[t] = bits;
         }
+        __builtin_amdgcn_sched_barrier(0);                          // every gather is requested before the first one is waited for
 #pragma unroll
-        for (int q = 0; q < G; ++q) {
-            if (q < ng) {
+        for (int t = 0; t < NL; ++t)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) mine = mine && (v[8 * q + e] >= 0.0);
-            }
+            for (int e = 0; e < 16; ++e)
+                if ((absent[t] >> e) & 1u) v[16 * t + e] = -1.0;
+    }
+    bool mine = true;
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+        if (q < ng) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mine = mine && (v[8 * q + e] >= 0.0);
         }
     }
-    if (ng > G || !__all(mine)) {
+    if (!__all(mine)) {
         zscore_one(b, i, gid, XT, XC, gidx, nref, k, Ns, zT, rT, nT, sdT);
         return;
     }
@@ -592,12 +616,16 @@ __device__ inline void zscore_wave(const int b, const int64_t i, const int64_t g
         }
     }
     acc.pos = 8 * ng;
+    // the incomplete last group: slots 8 ng .. 8 ng + 6 (beyond the list: -1, dropped)
     double tailv[7];
 #pragma unroll
-    for (int e = 0; e < 7; ++e) {
-        const int r = 8 * ng + e;
-        const int g = r < n ? lst[r] : -1;
-        tailv[e] = g >= 0 ? XC[(int64_t)g * Ns + i] : -1.0;
+    for (int e = 0; e < 7; ++e) tailv[e] = -1.0;
+#pragma unroll
+    for (int q = 0; q <= G; ++q) {
+        if (q == ng) {
+#pragma unroll
+            for (int e = 0; e < 7; ++e) tailv[e] = v[8 * q + e];
+        }
     }
 #pragma unroll
     for (int e = 0; e < 7; ++e)
@@ -626,7 +654,6 @@ __device__ inline void zscore_wave(const int b, const int64_t i, const int64_t g
         }
     const double var = acc.finish() / (double)m;
     const double sd = sqrt(var);
-    const double x = XT[gid];
     zT[gid] = (x - mean) / sd;
     rT[gid] = x / mean;
     nT[gid] = (double)m;
@@ -1964,6 +1991,345 @@ __global__ __launch_bounds__(256) void k_seg_quiet(Job *__restrict__ jobs, int n
     if (job.pad) return;                          // a sibling workgroup already found a window
     if (quiet_body(job, regions, prefix, rs, reg_abs, thr, tmin, tmax, work, blockIdx.x, gridDim.x) && tid == 0)
         jobs[j].pad = 1;
+}
+
+// ------------------------------------------------------------ bound-driven search ----
+// The host-driven rounds (regions beyond the tree kernel, i.e. bin sizes below ~125 kb; every call of
+// wc_stouffer_segments without -mineffectsize) do not evaluate every window of a job that may hold a call.
+// The same per-(row, 32-end block) bounds that certify a quiet job also LOCATE the extremes of a loud one:
+//     ub(x, k) = max(max P over block k - P[x], 0) * rs[min len]  >=  every window value of the pair
+// (subtraction, scaling and rounding are monotone, so the bound covers the values exactly as the search would
+// compute them), the same from below, and for a whole block  max(...) * rs[min len + 32]  is a LOWER bound of
+// the pair's best window (the window that ends on the block's maximum is at most 31 bins longer).
+//   k_seg_bound    per (job, row block): near windows (< 64 bins) by value, far pairs by bound.  Leaves per row
+//                  block a lower bound of its largest window value (values seen, lower bounds of the pairs) and an
+//                  upper bound of it (ChunkBound), the same for the smallest.
+//   k_seg_refine   the job's cut follows from those tables: every pair whose bound reaches
+//                  max(best lower bound, thr - eps) is evaluated window by window, nothing else can hold the
+//                  job's extreme or reach the threshold.  Row blocks whose upper bound stays below the cut are
+//                  not visited.  Afterwards partial[] holds, per row block, extremes that are EXACTLY the full
+//                  search's whenever they can matter (>= thr - eps in magnitude); k_seg_classify reads them.
+//   k_seg_bcollect the windows within 2 eps of the extremes (k_seg_collect's job): again only the pairs whose
+//                  bound reaches the cut, and only for a side that can hold a call.
+// On a 50 kb batch ~3 % of the windows are touched: 1 bound per 32 windows + the pairs around the extremes.
+struct ChunkBound { double ubmax, lbmin; };
+constexpr int BS_QUEUE = 2048;      // (row, end block) pairs a row block can queue for evaluation; more: the block is scanned in full
+
+// One row block of a job by a 256-thread workgroup.  MODE 0: bounds (k_seg_bound); 1: extremes of the
+// qualifying pairs (k_seg_refine); 2: candidates (k_seg_bcollect; emit(v, x, y) with region coordinates).
+// s_tmx / s_tmn: the job's slice of the block tables (table_ok: it fits).  Every thread returns its share
+// of vmax / vmin (values seen or proven), ubmax / lbmin (MODE 0: bounds over the far pairs).
+template <int MODE, class F>
+__device__ inline void bscan_chunk(const Job &job, const int chunk, const long long base, const double *__restrict__ prefix,
+                                   const double *__restrict__ rs, const double cut_hi, const double cut_lo,
+                                   const double *s_tmx, const double *s_tmn, const long long k_base, const long long k_last,
+                                   const bool table_ok, double &vmax, double &vmin, double &ubmax, double &lbmin, F emit,
+                                   unsigned long long *__restrict__ work) {
+    __shared__ double s_pn[2][2 * ROWS_HALF];     // rows of a side and their near ends
+    __shared__ double s_px[2 * ROWS_HALF];        // P[x] of the block's rows (side * 64 + lane)
+    __shared__ long long s_ax[2 * ROWS_HALF];     // their absolute prefix indexes
+    __shared__ int s_work[BS_QUEUE];
+    __shared__ int s_nwork;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int L = job.hi - job.lo, half = (L + 1) / 2;
+    const long long a_hi = base + L;              // absolute index of the last end
+    bool full = !table_ok;
+    int evals = 0;
+    __syncthreads();                              // the previous chunk's shared state is done with
+    if (tid == 0) s_nwork = 0;
+    if (!full) {
+        {   // the 64 rows of each side and the 64 prefix entries after them (clipped to the job)
+            const int side = tid >> 7, t = tid & 127;
+            const int xr_lo = side == 0 ? chunk * ROWS_HALF : L - 1 - (chunk * ROWS_HALF + 63);
+            const long long ai = base + (xr_lo < 0 ? 0 : xr_lo) + t;
+            s_pn[side][t] = ai <= a_hi ? prefix[ai] : 0.0;
+        }
+        __syncthreads();
+        for (int side = 0; side < 2; ++side) {
+            int xr = chunk * ROWS_HALF + lane;
+            bool live;
+            if (side == 0) {
+                live = xr < half;
+            } else {
+                xr = L - 1 - xr;
+                live = xr >= half;
+            }
+            const long long ax = base + (live ? xr : 0);
+            const int xr_lo = side == 0 ? chunk * ROWS_HALF : L - 1 - (chunk * ROWS_HALF + 63);
+            const long long a0 = base + (xr_lo < 0 ? 0 : xr_lo);
+            const int xo = (int)(ax - a0);                              // 0..63 for live lanes
+            const double px = live ? s_pn[side][xo] : 0.0;
+            if (w == 0) { s_px[side * ROWS_HALF + lane] = px; s_ax[side * ROWS_HALF + lane] = ax; }
+            const long long k_far = ax / QB + 2;                        // first end block that starts past ax + 32
+            long long y_near = k_far * QB - 1;
+            if (y_near > a_hi) y_near = a_hi;
+            const int near = live ? (int)(y_near - ax) : 0;             // <= 63
+            if (w == 0 && live) evals += near + (int)(k_last >= k_far ? k_last - k_far + 1 : 0);
+            const int x = job.lo + xr;
+#pragma unroll 4
+            for (int len = 1 + w; len <= 2 * QB; len += 4) {
+                const double r = rs[len];
+                if (len <= near) {
+                    const double v = (s_pn[side][xo + len] - px) * r;
+                    if (MODE == 2) {
+                        if (v >= cut_hi || v <= cut_lo) emit(v, x, x + len - 1);
+                    } else {
+                        vmax = fmax(vmax, v);
+                        vmin = fmin(vmin, v);
+                    }
+                }
+            }
+            const long long k0 = a0 / QB + 2;
+            for (long long k = k0 + w; k <= k_last; k += 4) {
+                const double mx = s_tmx[k - k_base], mn = s_tmn[k - k_base];     // wave-uniform LDS reads
+                if (live && k >= k_far) {
+                    const int minlen = (int)(k * QB - ax);              // >= 33
+                    const double r = rs[minlen];
+                    const double up = mx - px, dn = mn - px;
+                    const double ub = fmax(up, 0.0) * r, lb = fmin(dn, 0.0) * r;
+                    if (MODE == 0) {
+                        ubmax = fmax(ubmax, ub);
+                        lbmin = fmin(lbmin, lb);
+                        // a whole block inside the job: the window that ends on the block's extreme is at most 31
+                        // bins longer than minlen, so its value is at least up * rs[minlen + 32] -- a lower bound of
+                        // the job's maximum that is within a few percent of the pair's upper bound
+                        if (k < k_last && (ub > vmax || lb < vmin)) {
+                            const double r2 = rs[minlen + QB];
+                            if (up > 0.0) vmax = fmax(vmax, up * r2);
+                            if (dn < 0.0) vmin = fmin(vmin, dn * r2);
+                        }
+                    } else if (ub >= cut_hi || lb <= cut_lo) {
+                        const int at = atomicAdd(&s_nwork, 1);
+                        if (at < BS_QUEUE) s_work[at] = ((side * ROWS_HALF + lane) << 24) | (int)(k - k_base);
+                    }
+                }
+            }
+        }
+        if (MODE != 0) {
+            __syncthreads();
+            const int nwork = s_nwork;
+            if (nwork > BS_QUEUE) {
+                full = true;                          // workgroup-uniform: scan the whole block instead
+            } else {
+                for (int wk = tid >> 5; wk < nwork; wk += 8) {      // 32 ends per pair, eight pairs per trip
+                    const int row = s_work[wk] >> 24;
+                    const long long ay = (k_base + (s_work[wk] & 0xFFFFFF)) * QB + (tid & 31);
+                    if (ay <= a_hi) {
+                        const int len = (int)(ay - s_ax[row]);
+                        const double v = (prefix[ay] - s_px[row]) * rs[len];
+                        if (MODE == 2) {
+                            const int x = job.lo + (int)(s_ax[row] - base);
+                            if (v >= cut_hi || v <= cut_lo) emit(v, x, x + len - 1);
+                        } else {
+                            vmax = fmax(vmax, v);
+                            vmin = fmin(vmin, v);
+                        }
+                    }
+                }
+                if (tid == 0) evals += 32 * nwork;
+            }
+        }
+    }
+    if (full) {
+        // every window of the block (jobs longer than the staged tables cover, queue overflow): the plain scan
+        ScanCtx c;
+        c.lo = job.lo; c.hi = job.hi; c.L = L; c.half = half; c.chunk = chunk;
+        c.P = prefix + (base - job.lo);
+        c.wm = WindowMask{nullptr, 0, 0};
+        scan_chunk(c, rs, tid, [&](double v, int x, int y) {
+            if (MODE == 2) {
+                if (v >= cut_hi || v <= cut_lo) emit(v, x, y);
+            } else {
+                vmax = fmax(vmax, v);
+                vmin = fmin(vmin, v);
+            }
+        });
+        if (MODE == 0) { ubmax = INFINITY; lbmin = -INFINITY; }    // stands for "evaluated": the reduce below replaces it
+    }
+    if (work && tid < 64) {
+        for (int o = 32; o > 0; o >>= 1) evals += __shfl_xor(evals, o);
+        if (tid == 0) atomicAdd(work + (MODE == 0 ? 1 : 0), (unsigned long long)evals);
+    }
+}
+
+// workgroup reduction of four doubles (max, min, max, min); every thread gets the results
+__device__ inline void block_minmax4(double &a_max, double &a_min, double &b_max, double &b_min, int tid) {
+    __shared__ double red[4][4];
+    for (int o = 32; o > 0; o >>= 1) {
+        a_max = fmax(a_max, __shfl_xor(a_max, o));
+        a_min = fmin(a_min, __shfl_xor(a_min, o));
+        b_max = fmax(b_max, __shfl_xor(b_max, o));
+        b_min = fmin(b_min, __shfl_xor(b_min, o));
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) { red[0][tid >> 6] = a_max; red[1][tid >> 6] = a_min; red[2][tid >> 6] = b_max; red[3][tid >> 6] = b_min; }
+    __syncthreads();
+    a_max = fmax(fmax(red[0][0], red[0][1]), fmax(red[0][2], red[0][3]));
+    a_min = fmin(fmin(red[1][0], red[1][1]), fmin(red[1][2], red[1][3]));
+    b_max = fmax(fmax(red[2][0], red[2][1]), fmax(red[2][2], red[2][3]));
+    b_min = fmin(fmin(red[3][0], red[3][1]), fmin(red[3][2], red[3][3]));
+}
+
+// the job's slice of the block tables into LDS; false when it does not fit (the job is scanned in full)
+__device__ inline bool stage_block_tables(const long long base, const int L, const double *__restrict__ tmin,
+                                          const double *__restrict__ tmax, double *s_tmx, double *s_tmn,
+                                          long long &k_base, long long &k_last, int tid) {
+    k_last = (base + L) / QB;
+    k_base = base / QB;
+    if (k_last - k_base >= Q_BLOCKS) return false;
+    for (int i = tid; i <= (int)(k_last - k_base); i += 256) {
+        s_tmx[i] = tmax[k_base + i];
+        s_tmn[i] = tmin[k_base + i];
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_seg_bound(const Job *__restrict__ jobs, int n_jobs,
+                                                   const Region *__restrict__ regions,
+                                                   const double *__restrict__ prefix, const double *__restrict__ rs,
+                                                   const int *__restrict__ reg_flag,
+                                                   const double *__restrict__ tmin, const double *__restrict__ tmax,
+                                                   int max_chunks, Extreme *__restrict__ partial,
+                                                   ChunkBound *__restrict__ cbound, int *__restrict__ counters,
+                                                   int *__restrict__ next_count, unsigned long long *__restrict__ work) {
+    __shared__ double s_tmx[Q_BLOCKS], s_tmn[Q_BLOCKS];
+    const int j = blockIdx.y, tid = threadIdx.x;
+    // first kernel of a round: next-jobs / hot / brute counts start at zero (classify runs after)
+    if (j == 0 && blockIdx.x == 0 && tid == 0) { *next_count = 0; counters[2] = 0; counters[3] = 0; }
+    if (j >= n_jobs) return;
+    const Job job = jobs[j];
+    const int L = job.hi - job.lo, half = (L + 1) / 2;
+    if (L <= 0 || (int)blockIdx.x * ROWS_HALF >= half) return;
+    if (!reg_flag[job.region]) return;            // non-finite region: classify sends it to the brute path
+    const long long base = regions[job.region].off + job.region + job.lo;    // absolute index of the job's P[0]
+    long long k_base, k_last;
+    const bool table_ok = stage_block_tables(base, L, tmin, tmax, s_tmx, s_tmn, k_base, k_last, tid);
+    for (int chunk = blockIdx.x; chunk * ROWS_HALF < half; chunk += gridDim.x) {
+        double vmax = -INFINITY, vmin = INFINITY, ubmax = -INFINITY, lbmin = INFINITY;
+        bscan_chunk<0>(job, chunk, base, prefix, rs, 0.0, 0.0, s_tmx, s_tmn, k_base, k_last, table_ok, vmax, vmin, ubmax,
+                       lbmin, [](double, int, int) {}, work);
+        block_minmax4(vmax, vmin, ubmax, lbmin, tid);
+        if (tid == 0) {
+            Extreme e;
+            e.maxv = vmax; e.minv = vmin;
+            e.max_x = e.max_y = e.min_x = e.min_y = -1;
+            partial[(int64_t)j * max_chunks + chunk] = e;
+            // upper bound of every window of the block: the far pairs' bounds and the near windows' values (a block
+            // that was scanned in full reports its values: nothing is left to find there)
+            ChunkBound cb;
+            cb.ubmax = table_ok ? fmax(ubmax, vmax) : vmax;
+            cb.lbmin = table_ok ? fmin(lbmin, vmin) : vmin;
+            cbound[(int64_t)j * max_chunks + chunk] = cb;
+        }
+    }
+}
+
+// the cuts of a job from its row blocks' tables: every thread returns them
+__device__ inline void job_cuts(const Extreme *__restrict__ partial, const ChunkBound *__restrict__ cbound, int nch,
+                                double T, double &cut_hi, double &cut_lo, int tid) {
+    double lbM = -INFINITY, ubm = INFINITY, d0 = -INFINITY, d1 = INFINITY;
+    for (int ch = tid; ch < nch; ch += 256) {
+        lbM = fmax(lbM, partial[ch].maxv);
+        ubm = fmin(ubm, partial[ch].minv);
+    }
+    block_minmax4(lbM, ubm, d0, d1, tid);
+    // nothing below max(best value known, thr - eps) can be the job's maximum AND matter
+    cut_hi = fmax(lbM, T);
+    cut_lo = fmin(ubm, -T);
+}
+
+__global__ __launch_bounds__(256) void k_seg_refine(const Job *__restrict__ jobs, int n_jobs,
+                                                    const Region *__restrict__ regions,
+                                                    const double *__restrict__ prefix, const double *__restrict__ rs,
+                                                    const double *__restrict__ reg_abs, const int *__restrict__ reg_flag,
+                                                    double thr, const double *__restrict__ tmin,
+                                                    const double *__restrict__ tmax, int max_chunks,
+                                                    Extreme *__restrict__ partial, const ChunkBound *__restrict__ cbound,
+                                                    unsigned long long *__restrict__ work) {
+    __shared__ double s_tmx[Q_BLOCKS], s_tmn[Q_BLOCKS];
+    const int j = blockIdx.y, tid = threadIdx.x;
+    if (j >= n_jobs) return;
+    const Job job = jobs[j];
+    const int L = job.hi - job.lo, half = (L + 1) / 2;
+    if (L <= 0 || (int)blockIdx.x * ROWS_HALF >= half) return;
+    if (!reg_flag[job.region]) return;
+    const int nch = (half + ROWS_HALF - 1) / ROWS_HALF;
+    Extreme *pj = partial + (int64_t)j * max_chunks;
+    const ChunkBound *cj = cbound + (int64_t)j * max_chunks;
+    const double eps = window_eps(regions[job.region].n, reg_abs[job.region]);
+    double cut_hi, cut_lo;
+    job_cuts(pj, cj, nch, thr - eps, cut_hi, cut_lo, tid);
+    // the row blocks this workgroup would refine: any at all?
+    int any = 0;
+    for (int chunk = blockIdx.x; chunk < nch; chunk += gridDim.x) any |= (cj[chunk].ubmax >= cut_hi) | (cj[chunk].lbmin <= cut_lo);
+    if (!any) return;
+    const long long base = regions[job.region].off + job.region + job.lo;
+    long long k_base, k_last;
+    const bool table_ok = stage_block_tables(base, L, tmin, tmax, s_tmx, s_tmn, k_base, k_last, tid);
+    if (!table_ok) return;                        // scanned in full by k_seg_bound: its values are the block's extremes
+    for (int chunk = blockIdx.x; chunk < nch; chunk += gridDim.x) {
+        if (!(cj[chunk].ubmax >= cut_hi || cj[chunk].lbmin <= cut_lo)) continue;      // workgroup-uniform
+        double vmax = -INFINITY, vmin = INFINITY, d0 = -INFINITY, d1 = INFINITY;
+        bscan_chunk<1>(job, chunk, base, prefix, rs, cut_hi, cut_lo, s_tmx, s_tmn, k_base, k_last, true, vmax, vmin, d0, d1,
+                       [](double, int, int) {}, work);
+        block_minmax4(vmax, vmin, d0, d1, tid);
+        // every window of the block at or beyond a cut has been evaluated; the lower bounds k_seg_bound left
+        // (<= some window's value, so <= the job's extreme, which IS among the evaluated ones) stay valid
+        if (tid == 0) {
+            pj[chunk].maxv = fmax(pj[chunk].maxv, vmax);
+            pj[chunk].minv = fmin(pj[chunk].minv, vmin);
+        }
+    }
+}
+
+// k_seg_collect's job on the bound tables: the windows within 2 eps of a hot job's extremes, listed for exact
+// scoring -- only for a side that can hold a call (the other side's "extreme" is merely a value below thr - eps:
+// it cannot win against a call, and an empty list is what k_seg_decide needs to see then).
+__global__ __launch_bounds__(256) void k_seg_bcollect(const Job *__restrict__ jobs, const int *__restrict__ hot,
+                                                      const int *__restrict__ counters,
+                                                      const Region *__restrict__ regions,
+                                                      const double *__restrict__ prefix, const double *__restrict__ rs,
+                                                      const double *__restrict__ reg_abs, double thr,
+                                                      const Extreme *__restrict__ job_res,
+                                                      const double *__restrict__ tmin, const double *__restrict__ tmax,
+                                                      int max_chunks, const ChunkBound *__restrict__ cbound,
+                                                      int2 *__restrict__ cand, int *__restrict__ cand_cnt,
+                                                      unsigned long long *__restrict__ work) {
+    __shared__ double s_tmx[Q_BLOCKS], s_tmn[Q_BLOCKS];
+    const int h = blockIdx.y, tid = threadIdx.x;
+    if (h >= counters[2]) return;
+    const int j = hot[h];
+    const Job job = jobs[j];
+    const int L = job.hi - job.lo, half = (L + 1) / 2;
+    if ((int)blockIdx.x * ROWS_HALF >= half) return;
+    const int nch = (half + ROWS_HALF - 1) / ROWS_HALF;
+    const ChunkBound *cj = cbound + (int64_t)j * max_chunks;
+    const double eps = window_eps(regions[job.region].n, reg_abs[job.region]);
+    const Extreme e = job_res[j];
+    const double hi_cut = !(e.maxv + eps < thr) ? e.maxv - 2.0 * eps : INFINITY;
+    const double lo_cut = !(-e.minv + eps < thr) ? e.minv + 2.0 * eps : -INFINITY;
+    int any = 0;
+    for (int chunk = blockIdx.x; chunk < nch; chunk += gridDim.x) any |= (cj[chunk].ubmax >= hi_cut) | (cj[chunk].lbmin <= lo_cut);
+    if (!any) return;
+    const long long base = regions[job.region].off + job.region + job.lo;
+    long long k_base, k_last;
+    const bool table_ok = stage_block_tables(base, L, tmin, tmax, s_tmx, s_tmn, k_base, k_last, tid);
+    for (int chunk = blockIdx.x; chunk < nch; chunk += gridDim.x) {
+        if (!(cj[chunk].ubmax >= hi_cut || cj[chunk].lbmin <= lo_cut)) continue;
+        double d0 = -INFINITY, d1 = INFINITY, d2 = -INFINITY, d3 = INFINITY;
+        bscan_chunk<2>(job, chunk, base, prefix, rs, hi_cut, lo_cut, s_tmx, s_tmn, k_base, k_last, table_ok, d0, d1, d2, d3,
+                       [&](double v, int x, int y) {
+                           if (v >= hi_cut) {
+                               const int at = atomicAdd(&cand_cnt[2 * h], 1);
+                               if (at < CAND_CAP) cand[((int64_t)2 * h) * CAND_CAP + at] = make_int2(x, y);
+                           }
+                           if (v <= lo_cut) {
+                               const int at = atomicAdd(&cand_cnt[2 * h + 1], 1);
+                               if (at < CAND_CAP) cand[((int64_t)2 * h + 1) * CAND_CAP + at] = make_int2(x, y);
+                           }
+                       }, work);
+    }
 }
 
 // v_max_f64 / v_min_f64 on finite values, without the canonicalisation fmax() / fmin() imply
@@ -3602,6 +3968,12 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     Job *cur = ts.jobs_a.as<Job>(), *next = ts.jobs_b.as<Job>();
     int64_t n_jobs = n_regions;
     int guard = 0;
+    // Rounds that the tree kernel does not take over (regions beyond TREE_MAXLEN, callers without call rows) and
+    // that carry no -mineffectsize mask locate the extremes from the block bounds (k_seg_bound / k_seg_refine /
+    // k_seg_bcollect) instead of evaluating every window of every job that may hold a call.
+    const char *tree_env = getenv("WC_TEST_TREE_TAIL");        // "0": host-driven rounds only
+    const bool tree_ok = tail && !bits && max_n <= TREE_MAXLEN && !ts.no_tree && !(tree_env && tree_env[0] == '0');
+    const bool bound_path = !bits && !tree_ok;
     if ((rc = ctx->ensure_pinned(256))) return rc;
     int *h = (int *)ctx->pinned;          // counter read-backs land in pinned memory
     h[4] = 0;
@@ -3615,10 +3987,25 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
         // round counters are reset by the search kernel, candidate counts by classify
         dim3 sg((unsigned)max_chunks, (unsigned)n_jobs);
         ts.mark(10, stream);
+        // about 16 384 workgroups in all: one per job when there are many jobs, every row block of a job in
+        // parallel when there are few
+        const unsigned per_job = (unsigned)std::min<int64_t>(max_chunks, std::max<int64_t>(1, 16384 / n_jobs));
+        if (bound_path) {
+            if ((rc = ts.cbound.reserve(sizeof(ChunkBound) * n_jobs * max_chunks))) return rc;
+            hipLaunchKernelGGL(k_seg_bound, dim3(per_job, (unsigned)n_jobs), dim3(256), 0, stream, (const Job *)cur, (int)n_jobs,
+                               regions_dev, (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
+                               (const int *)ts.reg_flag.as<int>(), (const double *)ts.tmin.as<double>(),
+                               (const double *)ts.tmax.as<double>(), max_chunks, ts.partial.as<Extreme>(),
+                               ts.cbound.as<ChunkBound>(), counters, counters + 1, work);
+            hipLaunchKernelGGL(k_seg_refine, dim3(per_job, (unsigned)n_jobs), dim3(256), 0, stream, (const Job *)cur, (int)n_jobs,
+                               regions_dev, (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
+                               (const double *)ts.reg_abs.as<double>(), (const int *)ts.reg_flag.as<int>(), thr,
+                               (const double *)ts.tmin.as<double>(), (const double *)ts.tmax.as<double>(), max_chunks,
+                               ts.partial.as<Extreme>(), (const ChunkBound *)ts.cbound.as<ChunkBound>(), work);
+        } else {
         if (certify) {
             // about 16 384 workgroups in all: one per job when there are many jobs, every row block
             // of a job in parallel when there are few
-            const unsigned per_job = (unsigned)std::min<int64_t>(max_chunks, std::max<int64_t>(1, 16384 / n_jobs));
             hipLaunchKernelGGL(k_seg_quiet, dim3(per_job, (unsigned)n_jobs), dim3(256), 0, stream, cur, (int)n_jobs, regions_dev,
                                (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
                                (const double *)ts.reg_abs.as<double>(), (const int *)ts.reg_flag.as<int>(), thr,
@@ -3640,11 +4027,12 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
 #undef WC_SEARCH_NW
 #undef WC_SEARCH
         }
+        }   // !bound_path
         ts.mark(11, stream);
         hipLaunchKernelGGL(k_seg_classify, dim3((unsigned)n_jobs), dim3(64), 0, stream, (const Job *)cur, (int)n_jobs,
                            regions_dev, (const double *)ts.reg_abs.as<double>(), (const int *)ts.reg_flag.as<int>(),
                            (const Extreme *)ts.partial.as<Extreme>(), max_chunks, thr, ts.job_res.as<Extreme>(), hot,
-                           brute, counters, ts.cand_cnt.as<int>(), (int)certify, (const int *)nullptr);
+                           brute, counters, ts.cand_cnt.as<int>(), (int)(certify && !bound_path), (const int *)nullptr);
         // The number of hot jobs lives on the device.  Small rounds (latency mode, child
         // ranges) launch the follow-up kernels for the upper bound n_jobs and let surplus
         // workgroups exit, which saves a host round trip; big rounds read the count back.
@@ -3654,8 +4042,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
             WC_HIP(hipStreamSynchronize(stream));
             n_hot = h[2];
         }
-        const char *tree_env = getenv("WC_TEST_TREE_TAIL");        // "0": host-driven rounds only
-        if (guard == 1 && tail && !bits && max_n <= TREE_MAXLEN && n_hot > 0 && !ts.no_tree && !(tree_env && tree_env[0] == '0')) {
+        if (guard == 1 && tree_ok && n_hot > 0) {
             SdRider no_sd{};
             InflateRider no_inf{};
             AssembleRider no_as{};
@@ -3689,7 +4076,15 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
             WC_HIP(hipMemsetAsync(counters + 4, 0, sizeof(int), stream));
             WC_HIP(hipMemsetAsync(counters + 6, 0, sizeof(int), stream));
         }
-        if (n_hot > 0) {
+        if (n_hot > 0 && bound_path) {
+            const unsigned per_hot = (unsigned)std::min<int64_t>(max_chunks, std::max<int64_t>(1, 16384 / n_hot));
+            hipLaunchKernelGGL(k_seg_bcollect, dim3(per_hot, (unsigned)n_hot), dim3(256), 0, stream, (const Job *)cur,
+                               (const int *)hot, (const int *)counters, regions_dev, (const double *)ts.prefix.as<double>(),
+                               (const double *)ts.rs.as<double>(), (const double *)ts.reg_abs.as<double>(), thr,
+                               (const Extreme *)ts.job_res.as<Extreme>(), (const double *)ts.tmin.as<double>(),
+                               (const double *)ts.tmax.as<double>(), max_chunks, (const ChunkBound *)ts.cbound.as<ChunkBound>(),
+                               ts.cand.as<int2>(), ts.cand_cnt.as<int>(), work);
+        } else if (n_hot > 0) {
             // only a few blocks survive the pruning; sixteen waves each keep their scan short
             hipLaunchKernelGGL(k_seg_collect, dim3((unsigned)max_chunks, (unsigned)n_hot), dim3(1024), 0, stream,
                                (const Job *)cur, (const int *)hot, (const int *)counters, regions_dev,
@@ -3698,6 +4093,8 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
                                (const Extreme *)ts.partial.as<Extreme>(), max_chunks,
                                (const double2 *)ts.sub.as<double2>(), bits, bit_off, ts.cand.as<int2>(),
                                ts.cand_cnt.as<int>());
+        }
+        if (n_hot > 0) {
             hipLaunchKernelGGL(k_seg_decide, dim3((unsigned)n_hot), dim3(256), 0, stream, (const Job *)cur,
                                (const int *)hot, counters, regions_dev, z_dev, (const int2 *)ts.cand.as<int2>(),
                                (const int *)ts.cand_cnt.as<int>(), thr, min_search, bits, bit_off, ts.seg.as<Seg>(),
@@ -3881,7 +4278,8 @@ wc_reference *wc_reference_create(wc_ctx *ctx, const int32_t *indexes, const dou
         }
     }
     const int64_t nk = n_bins * k;
-    bool ok = ref->gidx.reserve(sizeof(int) * nk) == 0 && ref->nref.reserve(sizeof(int) * n_bins) == 0 &&
+    // (+ 64 bytes: k_zscore reads a bin's list with 16-index loads, the last bin's beyond its end)
+    bool ok = ref->gidx.reserve(sizeof(int) * nk + 64) == 0 && ref->nref.reserve(sizeof(int) * n_bins) == 0 &&
               ref->pca_mean.reserve(sizeof(double) * n_bins) == 0 &&
               ref->pca_comp.reserve(sizeof(double) * std::max<int64_t>(1, (int64_t)n_comp * n_bins)) == 0 &&
               ref->m2g.reserve(sizeof(int) * n_bins) == 0 && ref->g2m.reserve(sizeof(int) * ref->Btot) == 0 &&

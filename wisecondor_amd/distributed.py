@@ -266,9 +266,16 @@ class NewrefJob(object):
         for mode in ("tiles", "rows"):
             self.mode = mode
             state, err, elapsed = 2, None, 0.0           # 2 ok, 1 the backend lacks an exchange collective, 0 failed
-            self._checked = True
             try:
-                self._run()                              # buffers, tile lists, communicator warm-up
+                # warm-up pass (buffers, tile lists, communicator) with the ranks agreeing on every local step
+                # before the next collective; the TIMED pass runs as a production pass does -- the agreement's
+                # all-reduces and host synchronisations (four per pass in the tile shard, two in the row shard)
+                # would otherwise be part of what is compared
+                self._checked = True
+                try:
+                    self._run()
+                finally:
+                    self._checked = False
                 self._sync()
                 self.dist.barrier()
                 t0 = time.perf_counter()
@@ -278,8 +285,6 @@ class NewrefJob(object):
             except Exception as exc:
                 err = exc
                 state = 1 if (mode == "tiles" and _unsupported(exc)) else 0
-            finally:
-                self._checked = False
             state = self._min_over_ranks(state)
             if state == 0:
                 self.mode = None
@@ -359,6 +364,7 @@ class NewrefJob(object):
         if self.mode is None:
             measure = self.passes >= CALIBRATE_FROM_PASSES or os.environ.get("WC_NEWREF_SHARD") == "measure"
             self.mode = forced_shard_mode() or (self.calibrate() if measure else "tiles")
+            self._untried = not measure and forced_shard_mode() is None       # one-shot job: the tile shard, untested
             st.prepare()
         if self.mode == "rows":
             # row band of this rank against all columns: no exchange, one collective
@@ -397,7 +403,17 @@ class NewrefJob(object):
                 if r != self.rank:
                     st.export(b, e, self.cap_x, self.send_cnt[r], self.send_lst[r])
         self._local(tiles)
-        self._all_to_all(self.recv.view(-1), self.send.view(-1))
+        try:
+            self._all_to_all(self.recv.view(-1), self.send.view(-1))
+        except Exception as exc:
+            # a one-shot job takes the tile shard without having tried it: a backend that does not offer the
+            # exchange collective says so on every rank alike, and the row shard (one all-gather) takes over
+            if not (getattr(self, "_untried", False) and _unsupported(exc)):
+                raise
+            self.mode, self._untried = "rows", False
+            st.prepare()
+            return self._run()
+        self._untried = False
 
         # owners merge what they received and finish their rows; results to everyone
         def own_rows():

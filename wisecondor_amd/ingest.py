@@ -138,7 +138,7 @@ def write_results(out_paths, per_file_args, runtime, binsize, threshold_z, chrom
     assert n_calls.dtype == np.int32 and z.shape[1] == int(sizes.sum())
     _lib.check(_lib.load().wc_write_test_results(
         n, int(threads), _c_strings(out_paths), blob_ptrs, _lib.ptr(lens), rt, len(rt), float(binsize),
-        float(threshold_z), _lib.ptr(sizes), len(sizes), _lib.ptr(z), _lib.ptr(r), z.shape[1], _lib.ptr(cwz),
+        int(isinstance(binsize, (int, np.integer)) and not isinstance(binsize, bool)), float(threshold_z), _lib.ptr(sizes), len(sizes), _lib.ptr(z), _lib.ptr(r), z.shape[1], _lib.ptr(cwz),
         cwz.shape[1], _lib.ptr(calls), _lib.ptr(n_calls), calls.shape[1], _lib.ptr(asdef), int(level), _lib.ptr(status)))
     bad = np.nonzero(status)[0]
     if len(bad):
