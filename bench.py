@@ -43,7 +43,7 @@ PEAK_HBM = 8.0e12           # bytes/s, spec (6.3e12 achievable by a copy)
 PEAK_L2 = 34.5e12           # bytes/s aggregate over the 8 XCDs
 PEAK_FP64_VALU_OPS = 39.3e12  # float64 vector add / mul / max per second (78.6 TFLOP/s counts an FMA as two)
 PEAK_MALL = 10.0e12         # bytes/s the Infinity Cache sustains towards the L2s (order of magnitude, MI355X_MICROARCH.md)
-ROUND = "r03"
+ROUND = "r04"
 LATENCY_LAUNCHES = 8        # kernels of one latency-mode `test` call
 
 
@@ -136,13 +136,14 @@ def build_inputs(binsize, n_ref, n_test, seed0=0, device=0):
 def committed_traffic(workload):
     """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/<round>_traffic.json),
     or {} when no such file is there."""
-    for rnd in (ROUND, "r01"):
+    for rnd in (ROUND, "r03", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_traffic.json" % rnd)
         if os.path.exists(path):
             t = json.load(open(path)).get(workload)
             if t:
                 t = dict(t)
                 t["source"] = "profiles/%s_traffic.json" % rnd
+                t["measured_in_this_run"] = False
                 return t
     return {}
 
@@ -150,11 +151,12 @@ def committed_traffic(workload):
 def committed_latency_trace():
     """Kernel durations of one latency-mode replay from the committed rocprofv3 kernel trace
     (profiles/<round>_latency_trace.json, written by tools/refresh_profiles.sh), or None."""
-    for rnd in (ROUND, "r02"):
+    for rnd in (ROUND, "r03", "r02"):
         path = os.path.join(ROOT, "profiles", "%s_latency_trace.json" % rnd)
         if os.path.exists(path):
             t = json.load(open(path))
             t["source"] = "profiles/%s_latency_trace.json" % rnd
+            t["measured_in_this_run"] = False
             return t
     return None
 
@@ -166,12 +168,34 @@ def hbm_bytes(entry):
     return 1024.0 * (2.0 * entry["fetch_kb_per_launch"] + entry.get("write_kb_per_launch", 0.0))
 
 
+def committed_busy_file():
+    for rnd in (ROUND, "r03"):
+        path = os.path.join(ROOT, "profiles", "%s_pmc_busy.json" % rnd)
+        if os.path.exists(path):
+            return rnd, json.load(open(path))
+    return None, None
+
+
+def committed_l2(workload, kernel_prefix):
+    """L2 hit rate and memory-side read requests of a kernel from the committed TCC counter pass, or None."""
+    rnd, runs = committed_busy_file()
+    for run, kernels in sorted((runs or {}).items()):
+        if run.endswith(workload) and "T_" in run:
+            for name, row in kernels.items():
+                if name.startswith(kernel_prefix) and "l2_hit_rate" in row:
+                    rd = row.get("counters", {}).get("TCC_EA0_RDREQ_sum")
+                    return {"l2_hit_rate": row["l2_hit_rate"], "tcc_ea0_rdreq": rd,
+                            "rdreq_bytes_at_128B": None if rd is None else rd * 128.0,
+                            "source": "profiles/%s_pmc_busy.json (%s, %s)" % (rnd, run, name),
+                            "measured_in_this_run": False}
+    return None
+
+
 def committed_busy(workload):
     """VALU / LDS busy fractions of the re-score kernels from the committed counter passes, or None."""
-    path = os.path.join(ROOT, "profiles", "%s_pmc_busy.json" % ROUND)
-    if not os.path.exists(path):
+    rnd, runs = committed_busy_file()
+    if runs is None:
         return None
-    runs = json.load(open(path))
     for run, kernels in sorted(runs.items()):
         if run.endswith(workload):
             out = {}
@@ -180,7 +204,8 @@ def committed_busy(workload):
                     out[name] = {n: round(row[n], 3) for n in ("valu_busy", "lds_busy", "waves_per_simd", "eff_clock_ghz")
                                  if n in row}
             if out:
-                out["source"] = "profiles/%s_pmc_busy.json (%s)" % (ROUND, run)
+                out["source"] = "profiles/%s_pmc_busy.json (%s)" % (rnd, run)
+                out["measured_in_this_run"] = False
                 return out
     return None
 
@@ -429,6 +454,111 @@ def test_roofline(prof, n_refs, windows, n_samples, ms_per_batch):
     }
 
 
+# ------------------------------------------------ a node's worth of ranks, one after the other ----
+XGMI_LINK = 150.0e9          # bytes/s of one xGMI link as the projection prices it (153 GB/s peak per link)
+COLLECTIVE_LATENCY_S = 25e-6  # assumed start-up cost of one RCCL collective on an 8-GPU node (not measured here)
+
+
+def emulate_world_newref(ctx, X, bins, k, order, world, single_idx, single_dst):
+    """What each rank of a `world`-GPU newref job would do, run serially on THIS GPU with the real HIP stages:
+    per-rank milliseconds of every local stage in both shard modes, the bytes each collective moves, and a
+    PROJECTED step time -- slowest rank + bytes over one xGMI link + collective latencies.  Nothing here is a
+    multi-GPU measurement: RCCL between GPUs first runs in the driver's --gpus N runs."""
+    import numpy as np
+    import torch
+    from wisecondor_amd import distributed
+    st = distributed.HipStages(ctx, X, bins, k, order)
+    B = st.n_bins
+    ranges = [distributed.row_range(r, world, B) for r in range(world)]
+    st.prepare()
+    cap_x = distributed.exchange_capacity(st.cap, world)
+    dev = X.device
+    max_rows = max(e - b for b, e in ranges)
+
+    def timed(fn):
+        a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b_.record()
+        return a, b_
+
+    # what the threshold all-gather delivers: every row's threshold
+    thr_all = torch.empty(B, dtype=torch.float32, device=dev)
+    st.thresholds(0, B)
+    st.get_thr(0, B, thr_all)
+    send_cnt = [[torch.zeros(max_rows, dtype=torch.int32, device=dev) for _ in range(world)] for _ in range(world)]
+    send_lst = [[torch.zeros((max_rows, cap_x), dtype=torch.int64, device=dev) for _ in range(world)] for _ in range(world)]
+    idx = torch.empty((B, k), dtype=torch.int32, device=dev)
+    dst = torch.empty((B, k), dtype=torch.float64, device=dev)
+    ev = {m: [dict() for _ in range(world)] for m in ("tiles", "rows")}
+
+    def tile_share(r, export):
+        rb, re = ranges[r]
+        ev["tiles"][r]["prepare"] = timed(st.prepare)
+        ev["tiles"][r]["thresholds"] = timed(lambda: st.thresholds(rb, re))
+        for q, (b, e) in enumerate(ranges):
+            if q != r:
+                st.set_thr(b, e, thr_all[b:e])
+        ev["tiles"][r]["collect"] = timed(lambda: st.collect(0, B, r, world))
+        if export:
+            def ex():
+                for q, (b, e) in enumerate(ranges):
+                    if q != r:
+                        st.export(b, e, cap_x, send_cnt[r][q], send_lst[r][q])
+            ev["tiles"][r]["export"] = timed(ex)
+
+    for r in range(world):            # every rank's tile share once, to fill the exchange buffers
+        tile_share(r, True)
+    for r in range(world):            # again, now with the other ranks' lists to import, through to the rows' results
+        rb, re = ranges[r]
+        exp = ev["tiles"][r]["export"]
+        tile_share(r, False)
+        ev["tiles"][r]["export"] = exp
+
+        def im():
+            for q in range(world):
+                if q != r:
+                    st.import_(rb, re, cap_x, send_cnt[q][r], send_lst[q][r])
+        ev["tiles"][r]["import"] = timed(im)
+        ev["tiles"][r]["finish"] = timed(lambda: st.finish(rb, re, idx[rb:re], dst[rb:re]))
+    torch.cuda.synchronize()
+    tiles_ok = bool(torch.equal(idx, single_idx) and torch.equal(dst.view(torch.int64), single_dst.view(torch.int64)))
+    idx.zero_()
+    for r in range(world):            # row shard: the rank's band against all columns, no exchange
+        rb, re = ranges[r]
+        ev["rows"][r]["prepare"] = timed(st.prepare)
+        ev["rows"][r]["thresholds"] = timed(lambda: st.thresholds(rb, re))
+        ev["rows"][r]["collect"] = timed(lambda: st.collect(rb, re, 0, 1))
+        ev["rows"][r]["finish"] = timed(lambda: st.finish(rb, re, idx[rb:re], dst[rb:re]))
+    torch.cuda.synchronize()
+    rows_ok = bool(torch.equal(idx, single_idx) and torch.equal(dst.view(torch.int64), single_dst.view(torch.int64)))
+
+    out = {"what": "every rank's share of a %d-GPU newref job run serially on ONE GPU (real HIP stages, events around "
+                   "each); `projected_*` are PROJECTIONS, not measurements: slowest rank + the bytes one rank receives "
+                   "over ONE %.0f GB/s xGMI link + %d collective start-ups of an assumed %.0f us"
+                   % (world, XGMI_LINK / 1e9, 3, COLLECTIVE_LATENCY_S * 1e6),
+           "world": world, "exchange_slots_per_row_and_source": cap_x}
+    bytes_thr = float(B) * 4.0
+    per_rank_recv_lists = [(world - 1) * ((ranges[r][1] - ranges[r][0]) * (4.0 + cap_x * 8.0)) for r in range(world)]
+    bytes_result = float(B) * k * 12.0
+    for mode in ("tiles", "rows"):
+        per = []
+        for r in range(world):
+            ms = {name: a.elapsed_time(b_) for name, (a, b_) in ev[mode][r].items()}
+            ms["total"] = sum(ms.values())
+            per.append(ms)
+        tot = [p_["total"] for p_ in per]
+        coll = ({"threshold_all_gather": bytes_thr, "list_all_to_all": max(per_rank_recv_lists),
+                 "result_all_gather": bytes_result} if mode == "tiles" else {"result_all_gather": bytes_result})
+        comm_s = sum(coll.values()) / XGMI_LINK + len(coll) * COLLECTIVE_LATENCY_S
+        out[mode] = {"per_rank_ms": per, "max_rank_ms": max(tot), "mean_rank_ms": float(np.mean(tot)),
+                     "imbalance_max_over_mean": max(tot) / float(np.mean(tot)),
+                     "bytes_received_per_rank_per_collective": coll,
+                     "projected_comm_ms": 1e3 * comm_s, "projected_step_ms": max(tot) + 1e3 * comm_s,
+                     "results_equal_single_rank": tiles_ok if mode == "tiles" else rows_ok}
+    return out
+
+
 # --------------------------------------------------------------------- main ----
 def main():
     ap = argparse.ArgumentParser()
@@ -539,6 +669,7 @@ def main():
     finish_ms = None if rescore_ms is None else rescore_ms + (pick_ms or 0.0)
     if finish_ms is None:
         finish_ms = stages.get("collected->rescored", stages.get("exchanged->rescored"))
+        rescore_ms = finish_ms
     stats = wt.newref_stats(local_rank)
     gram_mode = "f16"
     variants = {}
@@ -639,8 +770,9 @@ def main():
             XX = torch.from_numpy(xdata).to(dev)
             del xdata
             xjob = distributed.NewrefJob(ctx, XX, xbins, k, _lib.SUM_SEQUENTIAL, rank=rank, world=world, passes=8)
-            xsteps = 3
-            xjob.run()
+            xsteps = 10
+            for _ in range(3):
+                xjob.run()
             sync_all()
             xmarks = []
             t0 = time.perf_counter()
@@ -661,9 +793,7 @@ def main():
                      "k_gram_algorithmic_tflops": xflops / (xk_ms * 1e-3) / 1e12}
             # the re-score stage on this matrix: uncorrelated rows share no candidates, the 295 MB float64
             # image does not fit the 32 MB of L2, and the gathers come from HBM / Infinity Cache
-            xr_ms = xstages.get("collected->rescored")
-            if xr_ms is None and "picked->rescored" in xstages:
-                xr_ms = xstages["picked->rescored"] + xstages.get("collected->picked", xstages.get("exchanged->picked", 0.0))
+            xr_ms = xstages.get("picked->rescored", xstages.get("collected->rescored", xstages.get("exchanged->rescored")))
             if xr_ms:
                 xr_bytes = float(XB) / world * k * xs * 8.0 + float(XB) / world * k * 12.0
                 extra["rescore_ms"] = xr_ms
@@ -671,15 +801,24 @@ def main():
                                              "peak": PEAK_HBM / 1e9, "unit": "GB/s",
                                              "frac": xr_bytes / (xr_ms * 1e-3) / PEAK_HBM,
                                              "algorithmic_bytes_per_launch": xr_bytes,
-                                             "note": "L2 hit rate 15 %%, TCC_EA0_RDREQ 194 M x 128 B = 24.8 GB per launch "
-                                                     "(profiles/%s_pmc_busy.json, r2T_cfg4 / r2D_cfg4)" % ROUND}
+                                             "l2_counters": committed_l2("cfg4", "k_rescore"),
+                                             "note": "k_rescore alone (k_pick's 0.1 ms not included); l2_counters: the committed TCC pass of k_rescore on this "
+                                                     "matrix (uncorrelated rows share no candidates)"}
             _, xprod, xpeak = GRAM_KERNELS[gram_mode]
             extra["k_gram_mode"] = gram_mode
             extra["k_gram_executed_tflops"] = xprod * xflops / (xk_ms * 1e-3) / 1e12
             extra["k_gram_frac_of_mfma_peak"] = xprod * xflops / (xk_ms * 1e-3) / xpeak
             extra["k_gram_frac_algorithmic_vs_fp32_mfma"] = xflops / (xk_ms * 1e-3) / PEAK_FP32_MFMA
             if world == 1:
-                xidx, _ = xjob.run()
+                xidx, xdst = xjob.run()
+                torch.cuda.synchronize()
+                try:
+                    extra["emulated_world_8"] = emulate_world_newref(ctx, XX, xbins, k, _lib.SUM_SEQUENTIAL, 8,
+                                                                     xidx.clone(), xdst.clone())
+                    extra["emulated_world_8"]["single_rank_ms_per_step"] = extra["ms_per_step"]
+                except Exception as exc:
+                    extra["emulated_world_8"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+                xidx, xdst = xjob.run()
                 torch.cuda.synchronize()
                 if rank == 0 and not args.no_cpu_baseline:
                     # >= 8 target rows x the full candidate set on the host
@@ -699,7 +838,8 @@ def main():
         # BASELINE.json config 5, one GPU's share: batched test of 125 samples at 50 kb bins (reference from
         # 100 samples through the GPU prep + newref, untimed)
         try:
-            inp5 = build_inputs(50000, 100, 125, seed0=500, device=local_rank)
+            n5 = 1000 if (world == 1 and rank == 0) else 125          # one GPU: the north-star's whole cohort, in eight shares
+            inp5 = build_inputs(50000, 100, n5, seed0=500, device=local_rank)
             bins5 = np.ascontiguousarray(inp5["masked_bins"])
             X5 = torch.from_numpy(np.ascontiguousarray(inp5["corrected"])).to(dev)
             job5 = distributed.NewrefJob(ctx, X5, bins5, k, wt.sum_order_of(inp5["corrected"]))
@@ -708,8 +848,8 @@ def main():
             ref5 = wt.Reference(idx5.cpu().numpy(), dst5.cpu().numpy(), inp5["chrom_bins"], inp5["masked_bins"],
                                 inp5["mask"], inp5["pca_mean"], inp5["pca_components"], binsize=50000, device=local_rank)
             thr5 = float(zThreshold([int(v) for v in inp5["masked_bins"]], 1000, None))
-            tb5 = distributed.TestBatch(ref5, torch.from_numpy(wt.samples_to_counts(inp5["tests"], inp5["chrom_bins"])).to(dev),
-                                        thr5, max_calls=256)
+            counts5 = torch.from_numpy(wt.samples_to_counts(inp5["tests"], inp5["chrom_bins"])).to(dev)
+            tb5 = distributed.TestBatch(ref5, counts5[:125].contiguous(), thr5, max_calls=256)
             for _ in range(2):
                 tb5.run()
             sync_all()
@@ -731,6 +871,41 @@ def main():
                                   "value": world * 125 / t5, "unit": "samples/s", "ms_per_batch": 1e3 * t5,
                                   "samples_per_gpu": 125, "calls_found": int(tb5.n_calls.sum().item()),
                                   "roofline": test_roofline(prof5, n_refs5, windows5, 125, 1e3 * t5)}
+            if n5 == 1000:
+                # (a) every rank's share of the 8-GPU job (125 of the 1 000 samples, no collective) one after the
+                # other on this GPU; (b) the whole cohort in ONE call on this GPU
+                shares = []
+                for r8 in range(8):
+                    tbr = distributed.TestBatch(ref5, counts5[125 * r8:125 * (r8 + 1)].contiguous(), thr5, max_calls=256)
+                    tbr.run()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        tbr.run()
+                    torch.cuda.synchronize()
+                    shares.append(1e3 * (time.perf_counter() - t0) / 3)
+                    del tbr
+                extra["test_50kb"]["emulated_world_8"] = {
+                    "what": "cfg5 on 8 GPUs = eight independent shares of 125 samples (sample shard, no collective): each "
+                            "share timed on THIS GPU, one after the other; projected_* is a PROJECTION (slowest share), not "
+                            "a multi-GPU measurement",
+                    "per_rank_ms": shares, "max_rank_ms": max(shares), "mean_rank_ms": float(np.mean(shares)),
+                    "imbalance_max_over_mean": max(shares) / float(np.mean(shares)),
+                    "projected_samples_per_s_8_gpus": 1000.0 / (max(shares) * 1e-3)}
+                tbw5 = distributed.TestBatch(ref5, counts5, thr5, max_calls=256)
+                for _ in range(2):
+                    tbw5.run()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    tbw5.run()
+                torch.cuda.synchronize()
+                tw5 = (time.perf_counter() - t0) / 3
+                extra["test_50kb"]["whole_job_1000_samples"] = {
+                    "what": "BASELINE config 5 whole: 1000 distinct samples x 50 kb in ONE wc_test_batch_dev call on one GPU",
+                    "samples": 1000, "ms_per_call": 1e3 * tw5, "samples_per_s": 1000.0 / tw5,
+                    "calls_found": int(tbw5.n_calls.sum().item())}
+                del tbw5
             if rank == 0 and world == 1 and not args.no_cpu_baseline:
                 # one sample x the three longest chromosomes on the host
                 try:
@@ -824,43 +999,51 @@ def main():
         # (rows x k x S x 8 B) + the output it writes.  The rows are gathered, and
         # neighbouring targets share candidates, so L2 / Infinity Cache serve most of the reads:
         # HBM is NOT what binds this kernel (see binding / hbm_counter_frac / l2_model_frac).
-        roof_finish = None
-        if finish_ms:
+        # ---- the float64 re-score: `roofline` candidates are SINGLE kernels; k_rescore is one (kernel_ms = the
+        # event interval around it).
+        # Algorithmic bytes = the candidate rows it must read (rows x k x S x 8 B) + the output.
+        # The rows are gathered, and neighbouring targets share candidates, so L2 / Infinity Cache serve most of
+        # the reads: which roof binds is read from the committed counters.
+        roof_finish, rescore_stage = None, None
+        if rescore_ms:
             rows_here = B / world
             fbytes = rows_here * k * S * 8.0 + rows_here * k * 12.0
-            gathered = float(stats.get("rescored", 0)) * S * 8.0      # what the kernels really pull through L2
-            ft = hbm_bytes(traffic.get("k_finish"))
-            hbm_alg = fbytes / (finish_ms * 1e-3) / PEAK_HBM
-            hbm_cnt = None if ft is None else ft / (finish_ms * 1e-3) / PEAK_HBM
-            l2_frac = gathered / (finish_ms * 1e-3) / PEAK_L2
+            gathered = float(stats.get("rescored", 0)) * S * 8.0      # what the kernel really pulls through L2
+            kt = (traffic.get("k_finish") or {}).get("kernels", {}).get("k_rescore")
+            ft = hbm_bytes(kt)
+            hbm_alg = fbytes / (rescore_ms * 1e-3) / PEAK_HBM
+            hbm_cnt = None if ft is None else ft / (rescore_ms * 1e-3) / PEAK_HBM
+            l2_frac = gathered / (rescore_ms * 1e-3) / PEAK_L2
             busy = committed_busy(args.workload)
-            # which roof binds is read from the counters: when the memory-side counters see less than half
-            # of what the HBM roof would allow (the image is re-read out of L2 / Infinity Cache), the stage
-            # is priced against the L2 gather bandwidth instead, with the issue-side busy fractions beside it
+            # when the memory-side counters see less than half of what the HBM roof would allow (the image is
+            # re-read out of L2 / Infinity Cache), the kernel is priced against the L2 gather bandwidth instead
             hbm_binds = hbm_cnt is not None and hbm_cnt >= 0.5 and hbm_alg <= 1.0
-            common = {"kernel": "float64 re-score stage: k_pick (k-th key, bound, certificate, compaction) + k_rescore "
-                                "(exact distances in numpy's order, counting order); events around each of the two, "
-                                "the exact-path launches come after",
-                      "kernel_ms": finish_ms, "k_pick_ms": pick_ms, "k_rescore_ms": rescore_ms, "algorithmic_bytes_per_launch": fbytes,
+            common = {"kernel": "float64 re-score: k_rescore (exact float64 distances of the picked candidates in numpy's "
+                                "order, counting order, output rows), alone: events around it on the launch stream",
+                      "kernel_ms": rescore_ms, "algorithmic_bytes_per_launch": fbytes,
                       "gathered_bytes_per_launch": gathered, "traffic": ft,
-                      "traffic_unit": "HBM-side bytes per launch (rocprofv3 PMC, %s)" % traffic.get("source"),
+                      "traffic_unit": "HBM-side bytes per launch of k_rescore (rocprofv3 PMC, %s; measured_in_this_run: false)"
+                                      % traffic.get("source"),
                       "hbm_algorithmic_frac": hbm_alg, "hbm_counter_frac": hbm_cnt, "l2_gather_frac": l2_frac,
                       "issue_busy": busy}
             if hbm_binds:
-                roof_finish = dict(common, bound="hbm", achieved=fbytes / (finish_ms * 1e-3) / 1e9, peak=PEAK_HBM / 1e9,
+                roof_finish = dict(common, bound="hbm", achieved=fbytes / (rescore_ms * 1e-3) / 1e9, peak=PEAK_HBM / 1e9,
                                    unit="GB/s", frac=hbm_alg)
             else:
-                roof_finish = dict(common, bound="l2", achieved=gathered / (finish_ms * 1e-3) / 1e9, peak=PEAK_L2 / 1e9,
+                roof_finish = dict(common, bound="l2", achieved=gathered / (rescore_ms * 1e-3) / 1e9, peak=PEAK_L2 / 1e9,
                                    unit="GB/s", frac=l2_frac,
                                    binding="the candidate rows are gathered out of L2 / Infinity Cache (neighbouring "
                                            "targets share candidates), not HBM: hbm_algorithmic_frac prices the "
                                            "SURVEY 8(d) bytes against the HBM peak as the contract words it and may "
                                            "exceed 1; `frac` is the gathered bytes over the aggregate L2 bandwidth; "
-                                           "issue_busy holds the VALU / LDS busy fractions of k_rescore from "
-                                           "profiles/%s_pmc_busy.json -- the stage is issue and gather-latency bound" % ROUND)
-        # `roofline` is the single kernel that takes longest per step (k_gram against k_rescore alone;
-        # the re-score stage keeps its own object either way)
-        if roof_finish and (rescore_ms or finish_ms) > gram_ms:
+                                           "issue_busy holds the committed VALU / LDS busy fractions -- the kernel is "
+                                           "issue and gather-latency bound")
+            rescore_stage = {"what": "k_pick (k-th key, bound, certificate, compaction) + k_rescore; the exact-path "
+                                     "launches come after", "stage_ms": finish_ms, "k_pick_ms": pick_ms,
+                             "k_rescore_ms": rescore_ms,
+                             "l2_gather_frac_of_stage": None if not finish_ms else gathered / (finish_ms * 1e-3) / PEAK_L2}
+        # `roofline` is the single kernel that takes longest per step (k_gram_glds against k_rescore)
+        if roof_finish and rescore_ms > gram_ms:
             dominant, other = roof_finish, roof_gram
         else:
             dominant, other = roof_gram, roof_finish
@@ -904,6 +1087,7 @@ def main():
                      "calls_found": n_calls},
             "roofline": dominant,
             "roofline_other": other,
+            "rescore_stage": rescore_stage,
             "newref_stats": stats,
             "extra": extra,
             "cpu_baseline": cpu,

@@ -260,4 +260,15 @@ def test_bench_line_is_complete_on_one_gpu():
     assert set(line["stages_ms"]) >= {"start->prepared", "prepared->thresholds", "thresholds->collected",
                                       "collected->picked", "picked->rescored", "rescored->finished"}
     assert "error" not in extra.get("ingest", {}), extra.get("ingest")
+    # round 4: the node's worth of ranks one after the other (projections, labelled), the whole 50 kb cohort in one call
+    em = extra["emulated_world_8"]
+    assert "error" not in em, em
+    for mode in ("tiles", "rows"):
+        assert em[mode]["results_equal_single_rank"] is True and len(em[mode]["per_rank_ms"]) == 8
+        assert em[mode]["projected_step_ms"] > em[mode]["max_rank_ms"] > 0
+    assert "PROJECT" in em["what"].upper()
+    t50 = extra["test_50kb"]
+    assert len(t50["emulated_world_8"]["per_rank_ms"]) == 8 and t50["whole_job_1000_samples"]["samples"] == 1000
+    assert t50["whole_job_1000_samples"]["samples_per_s"] > 0.8 * t50["value"]
+    assert line["rescore_stage"]["k_rescore_ms"] > 0 and line["roofline_other"] is not None
     assert extra["ingest"]["files_per_s"] > 100

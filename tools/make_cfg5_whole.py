@@ -116,8 +116,14 @@ def main():
         with mp.get_context("spawn").Pool(args.jobs) as pool:
             for _ in pool.imap_unordered(work, tasks, chunksize=1):
                 pass
-    _, z = reference_arrays()
-    out = dict(threshold=np.float64(z["threshold"]), cutoff=np.float64(z["cutoff"]),
+    ref, z = reference_arrays()
+    # cutoff / threshold as the reference derives them from the reference FILE (getOptimalCutoff,
+    # wisetools.py:328-336, and wisecondor.py:203-204), computed here by the CPU oracle -- not the values the GPU
+    # box happened to store beside the arrays
+    from oracle import wc_oracle as wo
+    cutoff = wo.get_optimal_cutoff(ref["distances"], 3)[0]
+    threshold = wo.z_threshold([int(v) for v in ref["masked_sizes"]], 1000, None)
+    out = dict(threshold=np.float64(threshold), cutoff=np.float64(cutoff),
                masked_sizes=np.asarray(z["masked_sizes"], dtype=np.int64),
                distances_sha256=z["distances_sha256"], stride=np.int64(STRIDE),
                ref_samples=np.array(REF_SAMPLES, dtype=np.int64),

@@ -65,8 +65,10 @@ bash tools/pmc_run.sh ${TAG}T_cfg2 "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" 
 bash tools/pmc_run.sh ${TAG}T_cfg4 "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" tools/gpu_newref_only.py cfg4 3 > "$OUT/pmcT_cfg4.log" 2>&1
 bash tools/pmc_run.sh ${TAG}W_cfg2 "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS" tools/gpu_newref_only.py cfg2 10 > "$OUT/pmcW_cfg2.log" 2>&1
 bash tools/pmc_run.sh ${TAG}W_cfg4 "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS" tools/gpu_newref_only.py cfg4 3 > "$OUT/pmcW_cfg4.log" 2>&1
+# the same three counter sets for the `test` path kernels (128 x 250 kb and 125 x 50 kb batches)
+bash tools/pmc_test_path.sh ${TAG} > "$OUT/pmc_test.log" 2>&1
 python3 tools/busy_summary.py $TAG gpurun_out/${TAG}A_cfg2 gpurun_out/${TAG}A_cfg4 gpurun_out/${TAG}T_cfg2 gpurun_out/${TAG}T_cfg4 gpurun_out/${TAG}W_cfg2 gpurun_out/${TAG}W_cfg4 > "$OUT/busy.log" 2>&1
-cp profiles/${TAG}_pmc_busy.md profiles/${TAG}_pmc_busy.json "$OUT/" 2>/dev/null
+cp profiles/${TAG}_pmc_busy.md profiles/${TAG}_pmc_busy.json profiles/${TAG}_test_pmc_busy.md profiles/${TAG}_test_pmc_busy.json "$OUT/" 2>/dev/null
 python3 - "$OUT" "$TAG" <<'PY'
 import csv, json, sys
 out, tag = sys.argv[1], sys.argv[2]
@@ -89,8 +91,7 @@ for wl in ("cfg2", "cfg4"):
                     best[kern] = (int(row[1]), float(row[2]))
         for kern, (_, v) in best.items():
             vals[kern][c] = v
-    # the float64 re-score stage is k_pick + k_rescore (the pair engine); k_finish only runs under
-    # WC_FINISH_ENGINE=rows
+    # the float64 re-score stage is k_pick + k_rescore (the pair engine); k_finish only runs beyond 2048 samples
     stage = {}
     for c in ("fetch_size", "write_size"):
         parts = [vals[kk].get(c) for kk in ("k_pick", "k_rescore")]

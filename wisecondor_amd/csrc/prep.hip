@@ -489,9 +489,11 @@ int wc_newref_prep_eig(wc_ctx *ctx, int n_pairs, double *eigvals_out, double *ei
 }
 
 // Device part of the finish step: components (sign fixed), projection, corrected_t [S, B] in ts.xc.
-// Leaves maskedData in ts.raw, components / mean in ts.z; returns the host copy of the components.
+// Leaves maskedData in ts.raw, components / mean in ts.z; *hc points at the host copy of the components in the
+// context's pinned block (valid once the caller has synchronised; owned by the context, so an error return
+// between the copy's launch and that synchronisation leaves nothing dangling).
 static int prep_finish_body(wc_ctx *ctx, int n_comp, const double *eigvecs, const double *eigvals,
-                            std::vector<double> &hc, bool want_t) {
+                            const double **hc, bool want_t) {
     PrepState &g_prep = ctx->prep;
     WC_CHECK(g_prep.ready, WC_E_ARG, "prep: wc_newref_prep_gram has not run");
     const int64_t S = g_prep.S, B = g_prep.B;
@@ -511,9 +513,14 @@ static int prep_finish_body(wc_ctx *ctx, int n_comp, const double *eigvecs, cons
     hipLaunchKernelGGL(k_prep_sign, dim3((unsigned)n_comp), dim3(1024), 0, nullptr, comp, B);
     hipLaunchKernelGGL(k_prep_transform, dim3((unsigned)S), dim3(1024), 0, nullptr, (const double *)ts.xt.as<double>(),
                        B, (const double *)comp, n_comp, ts.proj.as<double>());
-    // the host copy of the components travels while the rest runs (the callers synchronise)
-    hc.resize((size_t)n_comp * B);
-    WC_HIP(hipMemcpyAsync(hc.data(), comp, sizeof(double) * n_comp * B, hipMemcpyDeviceToHost, nullptr));
+    // the host copy of the components travels while the rest runs (the callers synchronise): pinned memory, so the
+    // copy really is asynchronous
+    {
+        int rc = ctx->ensure_pinned(sizeof(double) * (size_t)n_comp * B);
+        if (rc) return rc;
+    }
+    *hc = (const double *)ctx->pinned;
+    WC_HIP(hipMemcpyAsync(ctx->pinned, comp, sizeof(double) * n_comp * B, hipMemcpyDeviceToHost, nullptr));
     if (want_t) {
         dim3 gb((unsigned)cdiv(B, 256), (unsigned)S);
         hipLaunchKernelGGL(k_prep_correct, gb, dim3(256), 0, nullptr, (const double *)ts.data.as<double>(), B,
@@ -529,8 +536,8 @@ int wc_newref_prep_finish(wc_ctx *ctx, int n_comp, const double *eigvecs, const 
                           double *pca_mean_out) {
     WC_CHECK(ctx && eigvecs && eigvals && masked_data_out && corrected_t_out && pca_components_out && pca_mean_out,
              WC_E_ARG, "prep: NULL argument");
-    std::vector<double> hc;
-    int rc = prep_finish_body(ctx, n_comp, eigvecs, eigvals, hc, true);
+    const double *hc = nullptr;
+    int rc = prep_finish_body(ctx, n_comp, eigvecs, eigvals, &hc, true);
     if (rc) return rc;
     TestState &ts = ctx->ts;
     const int64_t S = ctx->prep.S, B = ctx->prep.B;
@@ -538,7 +545,7 @@ int wc_newref_prep_finish(wc_ctx *ctx, int n_comp, const double *eigvecs, const 
     WC_HIP(hipDeviceSynchronize());
     WC_HIP(hipMemcpy(masked_data_out, ts.raw.p, sizeof(double) * B * S, hipMemcpyDeviceToHost));
     WC_HIP(hipMemcpy(corrected_t_out, ts.xc.p, sizeof(double) * B * S, hipMemcpyDeviceToHost));
-    memcpy(pca_components_out, hc.data(), sizeof(double) * n_comp * B);
+    memcpy(pca_components_out, hc, sizeof(double) * n_comp * B);
     WC_HIP(hipMemcpy(pca_mean_out, mean, sizeof(double) * B, hipMemcpyDeviceToHost));
     return WC_OK;
 }
@@ -551,8 +558,8 @@ int wc_newref_prep_finish_dev(wc_ctx *ctx, int n_comp, const double *eigvecs, co
                               double *masked_dev, double *corrected_bs_dev, double *pca_components_out,
                               double *pca_mean_out) {
     WC_CHECK(ctx && eigvecs && eigvals, WC_E_ARG, "prep: NULL argument");
-    std::vector<double> hc;
-    int rc = prep_finish_body(ctx, n_comp, eigvecs, eigvals, hc, false);
+    const double *hc = nullptr;
+    int rc = prep_finish_body(ctx, n_comp, eigvecs, eigvals, &hc, false);
     if (rc) return rc;
     TestState &ts = ctx->ts;
     const int64_t S = ctx->prep.S, B = ctx->prep.B;
@@ -566,7 +573,7 @@ int wc_newref_prep_finish_dev(wc_ctx *ctx, int n_comp, const double *eigvecs, co
         WC_HIP(hipMemcpyAsync(masked_dev, ts.raw.p, sizeof(double) * B * S, hipMemcpyDeviceToDevice, nullptr));
     if (pca_mean_out) WC_HIP(hipMemcpy(pca_mean_out, mean, sizeof(double) * B, hipMemcpyDeviceToHost));
     WC_HIP(hipDeviceSynchronize());
-    if (pca_components_out) memcpy(pca_components_out, hc.data(), sizeof(double) * n_comp * B);   // (its copy has landed)
+    if (pca_components_out) memcpy(pca_components_out, hc, sizeof(double) * n_comp * B);   // (its copy has landed)
     return WC_OK;
 }
 

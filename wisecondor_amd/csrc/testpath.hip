@@ -1823,18 +1823,41 @@ __device__ inline double window_eps(int n, double abs_sum) {
 constexpr int QB = 32;              // window ends per end block
 constexpr int Q_WORK = 1024;        // undecided (row, end block) pairs a block can queue (10 KB of LDS in all: 8 blocks per CU)
 constexpr int Q_BLOCKS = 256;       // end blocks of one job held in LDS (jobs up to ~8 k bins)
-__global__ void k_block_minmax(const double *__restrict__ prefix, int64_t total, double *__restrict__ tmin,
-                               double *__restrict__ tmax) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t a = k * QB;
-    if (a >= total) return;
-    const int64_t b = a + QB < total ? a + QB : total;
-    double mn = prefix[a], mx = mn;
-    for (int64_t i = a + 1; i < b; ++i) { mn = fmin(mn, prefix[i]); mx = fmax(mx, prefix[i]); }
-    tmin[k] = mn;
-    tmax[k] = mx;
+// One workgroup = 256 consecutive entries = eight blocks: coalesced reads, a half-wave reduces a block.  tmin2 /
+// tmax2 (optional): the second level, minimum and maximum of every 128-entry block (four first-level blocks), for
+// the bound-driven search's long windows.
+__global__ __launch_bounds__(256) void k_block_minmax(const double *__restrict__ prefix, int64_t total,
+                                                      double *__restrict__ tmin, double *__restrict__ tmax,
+                                                      double *__restrict__ tmin2, double *__restrict__ tmax2) {
+    __shared__ double s_mn[8], s_mx[8];
+    const int tid = threadIdx.x;
+    const int64_t at = (int64_t)blockIdx.x * 256 + tid;
+    double mn = INFINITY, mx = -INFINITY;
+    if (at < total) mn = mx = prefix[at];
+    for (int o = 16; o > 0; o >>= 1) {
+        mn = fmin(mn, __shfl_xor(mn, o));
+        mx = fmax(mx, __shfl_xor(mx, o));
+    }
+    const int64_t k = (int64_t)blockIdx.x * 8 + (tid >> 5);
+    const bool real = k * QB < total;
+    if ((tid & 31) == 0) {
+        if (real) { tmin[k] = mn; tmax[k] = mx; }
+        s_mn[tid >> 5] = mn;
+        s_mx[tid >> 5] = mx;
+    }
+    if (!tmin2) return;
+    __syncthreads();
+    if (tid < 2 && ((int64_t)blockIdx.x * 2 + tid) * (4 * QB) < total) {
+        double a = s_mn[4 * tid], b = s_mx[4 * tid];
+        for (int q = 1; q < 4; ++q) { a = fmin(a, s_mn[4 * tid + q]); b = fmax(b, s_mx[4 * tid + q]); }
+        tmin2[(int64_t)blockIdx.x * 2 + tid] = a;
+        tmax2[(int64_t)blockIdx.x * 2 + tid] = b;
+    }
 }
 
+// (second level: beyond 512 bins a 128-end block loosens the bound by less than a 32-end block does at 64)
+constexpr int QB2 = 4 * QB;         // window ends per second-level block
+constexpr int FAR2 = 512;           // window lengths from here on are bounded per second-level block
 // Quiet-job certificate.  Most jobs (a chromosome of a sample, or a child range) hold no call:
 // every window stays below the threshold.  Proving that needs far fewer evaluations than
 // finding the extremes.  A lane owns a window start x (as in the search); for a 32-entry block
@@ -1999,37 +2022,51 @@ __global__ __launch_bounds__(256) void k_seg_quiet(Job *__restrict__ jobs, int n
 // The same per-(row, 32-end block) bounds that certify a quiet job also LOCATE the extremes of a loud one:
 //     ub(x, k) = max(max P over block k - P[x], 0) * rs[min len]  >=  every window value of the pair
 // (subtraction, scaling and rounding are monotone, so the bound covers the values exactly as the search would
-// compute them), the same from below, and for a whole block  max(...) * rs[min len + 32]  is a LOWER bound of
-// the pair's best window (the window that ends on the block's maximum is at most 31 bins longer).
-//   k_seg_bound    per (job, row block): near windows (< 64 bins) by value, far pairs by bound.  Leaves per row
-//                  block a lower bound of its largest window value (values seen, lower bounds of the pairs) and an
-//                  upper bound of it (ChunkBound), the same for the smallest.
-//   k_seg_refine   the job's cut follows from those tables: every pair whose bound reaches
-//                  max(best lower bound, thr - eps) is evaluated window by window, nothing else can hold the
-//                  job's extreme or reach the threshold.  Row blocks whose upper bound stays below the cut are
-//                  not visited.  Afterwards partial[] holds, per row block, extremes that are EXACTLY the full
-//                  search's whenever they can matter (>= thr - eps in magnitude); k_seg_classify reads them.
-//   k_seg_bcollect the windows within 2 eps of the extremes (k_seg_collect's job): again only the pairs whose
-//                  bound reaches the cut, and only for a side that can hold a call.
-// On a 50 kb batch ~3 % of the windows are touched: 1 bound per 32 windows + the pairs around the extremes.
+// compute them), the same from below, and for a whole block  (max P - P[x]) * rs[min len + 32]  is a LOWER
+// bound of the pair's best window (the window that ends on the block's maximum is at most 31 bins longer).
+//   k_seg_seed     per job, from the block tables alone: the window from the minimum of block a to the maximum
+//                  of block b is worth at least (max_b - min_a) * rs[(b - a + 1) 32]; the best such value (and
+//                  its mirror image) seeds the job's cut max(seed, thr - eps): nothing below it can be the job's
+//                  extreme AND matter.  L^2 / 2048 products per job.
+//   k_seg_bound    per (job, row block): near windows (< 64 bins) by value, far pairs by bound; a pair whose bound
+//                  reaches the cut first raises the cut to its own lower bound, then is queued and evaluated
+//                  window by window after the sweep.  The cut only ever rises (to values of windows that exist),
+//                  so whatever was skipped lies below the job's final extreme or below thr - eps: partial[] ends
+//                  up holding, per row block, extremes that are EXACTLY the full search's whenever they can matter
+//                  (>= thr - eps in magnitude), and k_seg_classify reads them as before.  Per row block it also
+//                  leaves an upper bound of everything it did NOT evaluate (ChunkBound).
+//   k_seg_bcollect the windows within 2 eps of the extremes (k_seg_collect's job): the row blocks whose values or
+//                  residual bounds reach the cut, and in them the pairs whose bound does -- only for a side that
+//                  can hold a call.
+// On a 50 kb batch ~4 % of the windows are touched: 1 bound per 32 windows + the pairs around the extremes and
+// the few that reach thr - eps by chance.
 struct ChunkBound { double ubmax, lbmin; };
+// 1 / sqrt(len) from above and from below for the BOUNDS (the values themselves use the table rs[], as the search
+// does): the hardware's float reciprocal square root (1 ulp) widened by 1e-6 -- no table gather in the sweep, whose
+// iterations would otherwise each wait out a memory round trip
+__device__ inline double rs_above(int len) { return (double)__builtin_amdgcn_rsqf((float)len) * (1.0 + 1e-6); }
+__device__ inline double rs_below(int len) { return (double)__builtin_amdgcn_rsqf((float)len) * (1.0 - 1e-6); }
 constexpr int BS_QUEUE = 2048;      // (row, end block) pairs a row block can queue for evaluation; more: the block is scanned in full
 
-// One row block of a job by a 256-thread workgroup.  MODE 0: bounds (k_seg_bound); 1: extremes of the
-// qualifying pairs (k_seg_refine); 2: candidates (k_seg_bcollect; emit(v, x, y) with region coordinates).
+// One row block of a job by a 256-thread workgroup.  MODE 0: bounds + evaluation of what reaches the running cut
+// (k_seg_bound; cut_hi / cut_lo come in as the job's cuts so far and go out raised); 2: candidates
+// (k_seg_bcollect; fixed cuts, emit(v, x, y) with region coordinates).
 // s_tmx / s_tmn: the job's slice of the block tables (table_ok: it fits).  Every thread returns its share
-// of vmax / vmin (values seen or proven), ubmax / lbmin (MODE 0: bounds over the far pairs).
+// of vmax / vmin (values seen) and, MODE 0, of ubmax / lbmin (bounds of the pairs that were NOT evaluated).
 template <int MODE, class F>
 __device__ inline void bscan_chunk(const Job &job, const int chunk, const long long base, const double *__restrict__ prefix,
-                                   const double *__restrict__ rs, const double cut_hi, const double cut_lo,
+                                   const double *__restrict__ rs, double &cut_hi, double &cut_lo,
                                    const double *s_tmx, const double *s_tmn, const long long k_base, const long long k_last,
+                                   const double *s_tmx2, const double *s_tmn2,
                                    const bool table_ok, double &vmax, double &vmin, double &ubmax, double &lbmin, F emit,
                                    unsigned long long *__restrict__ work) {
     __shared__ double s_pn[2][2 * ROWS_HALF];     // rows of a side and their near ends
     __shared__ double s_px[2 * ROWS_HALF];        // P[x] of the block's rows (side * 64 + lane)
     __shared__ long long s_ax[2 * ROWS_HALF];     // their absolute prefix indexes
+    __shared__ double s_b0x[2][16], s_b0n[2][16]; // maximum / minimum of every 8 entries of s_pn (entries of the job only)
     __shared__ int s_work[BS_QUEUE];
     __shared__ int s_nwork;
+    __shared__ unsigned long long s_cut[2];       // the running cuts, ordered bit patterns: [0] cut_hi, [1] -cut_lo
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int L = job.hi - job.lo, half = (L + 1) / 2;
@@ -2037,13 +2074,28 @@ __device__ inline void bscan_chunk(const Job &job, const int chunk, const long l
     bool full = !table_ok;
     int evals = 0;
     __syncthreads();                              // the previous chunk's shared state is done with
-    if (tid == 0) s_nwork = 0;
+    if (tid == 0) {
+        s_nwork = 0;
+        s_cut[0] = wc::f64_ordered(cut_hi);
+        s_cut[1] = wc::f64_ordered(-cut_lo);
+    }
     if (!full) {
         {   // the 64 rows of each side and the 64 prefix entries after them (clipped to the job)
             const int side = tid >> 7, t = tid & 127;
             const int xr_lo = side == 0 ? chunk * ROWS_HALF : L - 1 - (chunk * ROWS_HALF + 63);
             const long long ai = base + (xr_lo < 0 ? 0 : xr_lo) + t;
             s_pn[side][t] = ai <= a_hi ? prefix[ai] : 0.0;
+        }
+        __syncthreads();
+        if (tid < 32) {      // 8-entry blocks of the staged stretches: the near windows beyond 8..15 bins go by bound too
+            const int side = tid >> 4, b = tid & 15;
+            const int xr_lo = side == 0 ? chunk * ROWS_HALF : L - 1 - (chunk * ROWS_HALF + 63);
+            const long long a0 = base + (xr_lo < 0 ? 0 : xr_lo);
+            double mx = -INFINITY, mn = INFINITY;
+            for (int e = 0; e < 8; ++e)
+                if (a0 + 8 * b + e <= a_hi) { mx = fmax(mx, s_pn[side][8 * b + e]); mn = fmin(mn, s_pn[side][8 * b + e]); }
+            s_b0x[side][b] = mx;
+            s_b0n[side][b] = mn;
         }
         __syncthreads();
         for (int side = 0; side < 2; ++side) {
@@ -2065,14 +2117,121 @@ __device__ inline void bscan_chunk(const Job &job, const int chunk, const long l
             long long y_near = k_far * QB - 1;
             if (y_near > a_hi) y_near = a_hi;
             const int near = live ? (int)(y_near - ax) : 0;             // <= 63
-            if (w == 0 && live) evals += near + (int)(k_last >= k_far ? k_last - k_far + 1 : 0);
             const int x = job.lo + xr;
+            // the cut as the workgroup has raised it so far (MODE 0), re-read now and then: a stale value only costs
+            // evaluations
+            double chi = cut_hi, clo = cut_lo;
+            auto refresh = [&]() {
+                if (MODE == 0) {
+                    chi = wc::f64_from_ordered(__hip_atomic_load(&s_cut[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    clo = -wc::f64_from_ordered(__hip_atomic_load(&s_cut[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                }
+            };
+            refresh();
+            auto window = [&](const double v, const int len) {
+                if (MODE == 2) {
+                    if (v >= cut_hi || v <= cut_lo) emit(v, x, x + len - 1);
+                } else {
+                    vmax = fmax(vmax, v);
+                    vmin = fmin(vmin, v);
+                }
+            };
+            // near ends: the first 8..15 by value (the four waves take every fourth length: uniform per wave, its
+            // 1/sqrt(len) is a scalar load), the rest per 8-entry block of the staged stretch by bound, a block that
+            // reaches the cut window by window on the spot
+            const int fb = (xo + 16) >> 3;                              // first 8-block that starts at least 9 past the row
+            const int n_exact = near < 8 * fb - 1 - xo ? near : 8 * fb - 1 - xo;
 #pragma unroll 4
-            for (int len = 1 + w; len <= 2 * QB; len += 4) {
+            for (int len = 1 + w; len <= 15; len += 4) {
                 const double r = rs[len];
-                if (len <= near) {
-                    const double v = (s_pn[side][xo + len] - px) * r;
+                if (len <= n_exact) window((s_pn[side][xo + len] - px) * r, len);
+            }
+            for (int b = fb + w; b < 16; b += 4) {
+                const int minlen = 8 * b - xo;                          // 9..
+                if (minlen > near) break;
+                const double r = rs_above(minlen);
+                const double ub = fmax(s_b0x[side][b] - px, 0.0) * r, lb = fmin(s_b0n[side][b] - px, 0.0) * r;
+                ++evals;
+                if (ub >= chi || lb <= clo) {
+                    // queued like the far pairs (a wave that evaluated on the spot would walk the eight windows
+                    // whenever ANY of its lanes has such a block)
+                    const int at = atomicAdd(&s_nwork, 1);
+                    if (at < BS_QUEUE) s_work[at] = ((side * ROWS_HALF + lane) << 24) | (1 << 23) | b;
+                } else if (MODE == 0) {
+                    ubmax = fmax(ubmax, ub);
+                    lbmin = fmin(lbmin, lb);
+                }
+            }
+            // far ends, one bound per block: 32-end blocks up to lengths of FAR2, 128-end blocks beyond (the first
+            // second-level block of a row is the first one that starts at least FAR2 past it)
+            // (32-bit indexes relative to the start of the job's first second-level block: the sweep's index
+            // arithmetic stays off the 64-bit vector path)
+            const long long org = (k_base / 4) * QB2;
+            const int rax = (int)(ax - org), ra0 = (int)(a0 - org), rhi = (int)(a_hi - org);
+            const int d1 = (int)(k_base & 3);                           // first-level block rel / 32 is table entry rel / 32 - d1
+            const int r_far = rax / QB + 2, r_last = rhi / QB;
+            const int r0 = ra0 / QB + 2;
+            const int r2_first = (rax + FAR2 + QB2 - 1) / QB2;          // this row's first second-level block
+            const int r1_end = r2_first * 4;                            // ... and the first-level blocks before it
+            const int r2_last = rhi / QB2;
+            const int r1_stop = ((ra0 + 63 + FAR2 + QB2 - 1) / QB2) * 4;     // wave-uniform: beyond every lane's r1_end
+            auto pair = [&](const double mx, const double mn, const int minlen, const int span, const bool whole,
+                            const int first_blk, const int n_blk) {
+                const double r = rs_above(minlen);
+                const double up = mx - px, dn = mn - px;
+                const double ub = fmax(up, 0.0) * r, lb = fmin(dn, 0.0) * r;
+                ++evals;
+                if (ub >= chi || lb <= clo) {
+                    if (MODE == 0 && whole) {
+                        // a whole block inside the job: the window that ends on the block's extreme is less than
+                        // `span` bins longer than minlen, so its value is at least up * rs[minlen + span] -- raise the
+                        // cut to it before anybody queues more of what it rules out
+                        const double r2 = rs_below(minlen + span);
+                        if (ub >= chi && up > 0.0) atomicMax(&s_cut[0], wc::f64_ordered(up * r2));
+                        if (lb <= clo && dn < 0.0) atomicMax(&s_cut[1], wc::f64_ordered(-(dn * r2)));
+                        refresh();
+                    }
+                    const int at = atomicAdd(&s_nwork, n_blk);          // evaluated as n_blk first-level blocks
+                    for (int q = 0; q < n_blk; ++q)
+                        if (at + q < BS_QUEUE) s_work[at + q] = ((side * ROWS_HALF + lane) << 24) | (first_blk + q);
+                } else if (MODE == 0) {
+                    ubmax = fmax(ubmax, ub);
+                    lbmin = fmin(lbmin, lb);
+                }
+            };
+            int since = 0;
+            for (int r1 = r0 + w; r1 <= r_last && r1 < r1_stop; r1 += 4) {
+                const double mx = s_tmx[r1 - d1], mn = s_tmn[r1 - d1];           // wave-uniform LDS reads
+                if (live && r1 >= r_far && r1 < r1_end) pair(mx, mn, r1 * QB - rax, QB, r1 < r_last, r1 - d1, 1);
+                if ((++since & 7) == 0) refresh();
+            }
+            for (int r2 = (ra0 + FAR2) / QB2 + w; r2 <= r2_last; r2 += 4) {
+                const double mx = s_tmx2[r2], mn = s_tmn2[r2];
+                if (live && r2 >= r2_first) pair(mx, mn, r2 * QB2 - rax, QB2, r2 < r2_last, r2 * 4 - d1, 4);
+                if ((++since & 7) == 0) refresh();
+            }
+        }
+        __syncthreads();
+        const int nwork = s_nwork;
+        if (nwork > BS_QUEUE) {
+            full = true;                          // workgroup-uniform: scan the whole block instead
+        } else {
+            for (int wk = tid >> 5; wk < nwork; wk += 8) {      // 32 ends per pair, eight pairs per trip
+                const int row = s_work[wk] >> 24;
+                long long ay = (k_base + (s_work[wk] & 0x7FFFFF)) * QB + (tid & 31);
+                long long last = a_hi;
+                if (s_work[wk] & (1 << 23)) {
+                    // a near block: eight entries of the row's side, up to the row's last near end
+                    const int xr_lo = (row >> 6) == 0 ? chunk * ROWS_HALF : L - 1 - (chunk * ROWS_HALF + 63);
+                    ay = base + (xr_lo < 0 ? 0 : xr_lo) + 8 * (s_work[wk] & 15) + (tid & 31);
+                    const long long y_near = (s_ax[row] / QB + 2) * QB - 1;
+                    last = (tid & 31) < 8 ? (y_near < a_hi ? y_near : a_hi) : -1;
+                }
+                if (ay <= last) {
+                    const int len = (int)(ay - s_ax[row]);
+                    const double v = (prefix[ay] - s_px[row]) * rs[len];
                     if (MODE == 2) {
+                        const int x = job.lo + (int)(s_ax[row] - base);
                         if (v >= cut_hi || v <= cut_lo) emit(v, x, x + len - 1);
                     } else {
                         vmax = fmax(vmax, v);
@@ -2080,55 +2239,7 @@ __device__ inline void bscan_chunk(const Job &job, const int chunk, const long l
                     }
                 }
             }
-            const long long k0 = a0 / QB + 2;
-            for (long long k = k0 + w; k <= k_last; k += 4) {
-                const double mx = s_tmx[k - k_base], mn = s_tmn[k - k_base];     // wave-uniform LDS reads
-                if (live && k >= k_far) {
-                    const int minlen = (int)(k * QB - ax);              // >= 33
-                    const double r = rs[minlen];
-                    const double up = mx - px, dn = mn - px;
-                    const double ub = fmax(up, 0.0) * r, lb = fmin(dn, 0.0) * r;
-                    if (MODE == 0) {
-                        ubmax = fmax(ubmax, ub);
-                        lbmin = fmin(lbmin, lb);
-                        // a whole block inside the job: the window that ends on the block's extreme is at most 31
-                        // bins longer than minlen, so its value is at least up * rs[minlen + 32] -- a lower bound of
-                        // the job's maximum that is within a few percent of the pair's upper bound
-                        if (k < k_last && (ub > vmax || lb < vmin)) {
-                            const double r2 = rs[minlen + QB];
-                            if (up > 0.0) vmax = fmax(vmax, up * r2);
-                            if (dn < 0.0) vmin = fmin(vmin, dn * r2);
-                        }
-                    } else if (ub >= cut_hi || lb <= cut_lo) {
-                        const int at = atomicAdd(&s_nwork, 1);
-                        if (at < BS_QUEUE) s_work[at] = ((side * ROWS_HALF + lane) << 24) | (int)(k - k_base);
-                    }
-                }
-            }
-        }
-        if (MODE != 0) {
-            __syncthreads();
-            const int nwork = s_nwork;
-            if (nwork > BS_QUEUE) {
-                full = true;                          // workgroup-uniform: scan the whole block instead
-            } else {
-                for (int wk = tid >> 5; wk < nwork; wk += 8) {      // 32 ends per pair, eight pairs per trip
-                    const int row = s_work[wk] >> 24;
-                    const long long ay = (k_base + (s_work[wk] & 0xFFFFFF)) * QB + (tid & 31);
-                    if (ay <= a_hi) {
-                        const int len = (int)(ay - s_ax[row]);
-                        const double v = (prefix[ay] - s_px[row]) * rs[len];
-                        if (MODE == 2) {
-                            const int x = job.lo + (int)(s_ax[row] - base);
-                            if (v >= cut_hi || v <= cut_lo) emit(v, x, x + len - 1);
-                        } else {
-                            vmax = fmax(vmax, v);
-                            vmin = fmin(vmin, v);
-                        }
-                    }
-                }
-                if (tid == 0) evals += 32 * nwork;
-            }
+            if (tid == 0) evals += 32 * nwork;
         }
     }
     if (full) {
@@ -2145,11 +2256,16 @@ __device__ inline void bscan_chunk(const Job &job, const int chunk, const long l
                 vmin = fmin(vmin, v);
             }
         });
-        if (MODE == 0) { ubmax = INFINITY; lbmin = -INFINITY; }    // stands for "evaluated": the reduce below replaces it
+        if (MODE == 0) { ubmax = -INFINITY; lbmin = INFINITY; }    // nothing left unevaluated in this block
     }
-    if (work && tid < 64) {
+    if (MODE == 0) {
+        __syncthreads();
+        cut_hi = wc::f64_from_ordered(s_cut[0]);                    // (the values seen join it in the caller's reduce)
+        cut_lo = -wc::f64_from_ordered(s_cut[1]);
+    }
+    if (work) {
         for (int o = 32; o > 0; o >>= 1) evals += __shfl_xor(evals, o);
-        if (tid == 0) atomicAdd(work + (MODE == 0 ? 1 : 0), (unsigned long long)evals);
+        if (lane == 0) atomicAdd(work + 1, (unsigned long long)evals);     // bounds + windows evaluated by value
     }
 }
 
@@ -2174,7 +2290,10 @@ __device__ inline void block_minmax4(double &a_max, double &a_min, double &b_max
 // the job's slice of the block tables into LDS; false when it does not fit (the job is scanned in full)
 __device__ inline bool stage_block_tables(const long long base, const int L, const double *__restrict__ tmin,
                                           const double *__restrict__ tmax, double *s_tmx, double *s_tmn,
-                                          long long &k_base, long long &k_last, int tid) {
+                                          long long &k_base, long long &k_last, int tid,
+                                          const double *__restrict__ tmin2 = nullptr,
+                                          const double *__restrict__ tmax2 = nullptr, double *s_tmx2 = nullptr,
+                                          double *s_tmn2 = nullptr) {
     k_last = (base + L) / QB;
     k_base = base / QB;
     if (k_last - k_base >= Q_BLOCKS) return false;
@@ -2182,7 +2301,59 @@ __device__ inline bool stage_block_tables(const long long base, const int L, con
         s_tmx[i] = tmax[k_base + i];
         s_tmn[i] = tmin[k_base + i];
     }
+    if (tmin2) {      // the second-level blocks that overlap the slice
+        const long long k2_base = k_base / 4, k2_last = (base + L) / QB2;
+        for (int i = tid; i <= (int)(k2_last - k2_base); i += 256) {
+            s_tmx2[i] = tmax2[k2_base + i];
+            s_tmn2[i] = tmin2[k2_base + i];
+        }
+    }
     return true;
+}
+
+// The job's starting cuts from the block tables alone (see the header of this section).  cuts[2 j] = cut_hi,
+// cuts[2 j + 1] = -cut_lo as ordered bit patterns (k_seg_bound raises them with atomicMax).
+__global__ __launch_bounds__(256) void k_seg_seed(const Job *__restrict__ jobs, int n_jobs,
+                                                  const Region *__restrict__ regions, const double *__restrict__ rs,
+                                                  const double *__restrict__ reg_abs, const int *__restrict__ reg_flag,
+                                                  double thr, const double *__restrict__ tmin,
+                                                  const double *__restrict__ tmax,
+                                                  unsigned long long *__restrict__ cuts) {
+    __shared__ double s_tmx[Q_BLOCKS], s_tmn[Q_BLOCKS];
+    const int j = blockIdx.x, tid = threadIdx.x;
+    if (j >= n_jobs) return;
+    const Job job = jobs[j];
+    const int L = job.hi - job.lo;
+    const double eps = window_eps(regions[job.region].n, reg_abs[job.region]);
+    const double T = thr - eps;
+    double hi = T, lo = -T, d0 = -INFINITY, d1 = INFINITY;
+    if (L > 0 && reg_flag[job.region]) {
+        const long long base = regions[job.region].off + job.region + job.lo;
+        long long k_base, k_last;
+        if (stage_block_tables(base, L, tmin, tmax, s_tmx, s_tmn, k_base, k_last, tid)) {
+            __syncthreads();
+            // blocks that lie wholly inside the job's prefix slice [base, base + L]
+            const int b_first = (int)((base + QB - 1) / QB - k_base);
+            const int b_last = (int)((base + L + 1) / QB - 1 - k_base);
+            const int nb = b_last - b_first + 1;
+            if (nb >= 2) {
+                // pair (a, b), a < b: thread t takes the pairs with distance d = b - a = 1 + t, 1 + t + 256, ...
+                for (int d = 1 + tid; d < nb; d += 256) {
+                    const double r = rs[(d + 1) * QB];
+                    for (int a = b_first; a + d <= b_last; ++a) {
+                        const double up = s_tmx[a + d] - s_tmn[a], dn = s_tmn[a + d] - s_tmx[a];
+                        if (up > 0.0) hi = fmax(hi, up * r);
+                        if (dn < 0.0) lo = fmin(lo, dn * r);
+                    }
+                }
+            }
+        }
+    }
+    block_minmax4(hi, lo, d0, d1, tid);
+    if (tid == 0) {
+        cuts[2 * j] = wc::f64_ordered(hi);
+        cuts[2 * j + 1] = wc::f64_ordered(-lo);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_seg_bound(const Job *__restrict__ jobs, int n_jobs,
@@ -2190,12 +2361,17 @@ __global__ __launch_bounds__(256) void k_seg_bound(const Job *__restrict__ jobs,
                                                    const double *__restrict__ prefix, const double *__restrict__ rs,
                                                    const int *__restrict__ reg_flag,
                                                    const double *__restrict__ tmin, const double *__restrict__ tmax,
+                                                   const double *__restrict__ tmin2, const double *__restrict__ tmax2,
                                                    int max_chunks, Extreme *__restrict__ partial,
-                                                   ChunkBound *__restrict__ cbound, int *__restrict__ counters,
-                                                   int *__restrict__ next_count, unsigned long long *__restrict__ work) {
-    __shared__ double s_tmx[Q_BLOCKS], s_tmn[Q_BLOCKS];
+                                                   ChunkBound *__restrict__ cbound, unsigned long long *__restrict__ cuts,
+                                                   int *__restrict__ counters, int *__restrict__ next_count,
+                                                   unsigned long long *__restrict__ work, Job *__restrict__ mark_jobs,
+                                                   const double *__restrict__ reg_abs, double thr) {
+    // mark_jobs (the tree path's certificate role): Job::pad = 1 for every job one of whose windows can reach
+    // the threshold -- the value search and classify then skip the others, as after k_seg_quiet
+    __shared__ double s_tmx[Q_BLOCKS], s_tmn[Q_BLOCKS], s_tmx2[Q_BLOCKS / 4 + 2], s_tmn2[Q_BLOCKS / 4 + 2];
     const int j = blockIdx.y, tid = threadIdx.x;
-    // first kernel of a round: next-jobs / hot / brute counts start at zero (classify runs after)
+    // first kernel of a round that touches the counters: next-jobs / hot / brute counts start at zero
     if (j == 0 && blockIdx.x == 0 && tid == 0) { *next_count = 0; counters[2] = 0; counters[3] = 0; }
     if (j >= n_jobs) return;
     const Job job = jobs[j];
@@ -2204,10 +2380,14 @@ __global__ __launch_bounds__(256) void k_seg_bound(const Job *__restrict__ jobs,
     if (!reg_flag[job.region]) return;            // non-finite region: classify sends it to the brute path
     const long long base = regions[job.region].off + job.region + job.lo;    // absolute index of the job's P[0]
     long long k_base, k_last;
-    const bool table_ok = stage_block_tables(base, L, tmin, tmax, s_tmx, s_tmn, k_base, k_last, tid);
+    const bool table_ok = stage_block_tables(base, L, tmin, tmax, s_tmx, s_tmn, k_base, k_last, tid, tmin2, tmax2, s_tmx2, s_tmn2);
     for (int chunk = blockIdx.x; chunk * ROWS_HALF < half; chunk += gridDim.x) {
+        // the job's cuts as every workgroup has raised them so far (a stale value only costs evaluations)
+        double cut_hi = wc::f64_from_ordered(__hip_atomic_load(&cuts[2 * j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        double cut_lo = -wc::f64_from_ordered(__hip_atomic_load(&cuts[2 * j + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const double in_hi = cut_hi, in_lo = cut_lo;
         double vmax = -INFINITY, vmin = INFINITY, ubmax = -INFINITY, lbmin = INFINITY;
-        bscan_chunk<0>(job, chunk, base, prefix, rs, 0.0, 0.0, s_tmx, s_tmn, k_base, k_last, table_ok, vmax, vmin, ubmax,
+        bscan_chunk<0>(job, chunk, base, prefix, rs, cut_hi, cut_lo, s_tmx, s_tmn, k_base, k_last, s_tmx2, s_tmn2, table_ok, vmax, vmin, ubmax,
                        lbmin, [](double, int, int) {}, work);
         block_minmax4(vmax, vmin, ubmax, lbmin, tid);
         if (tid == 0) {
@@ -2215,70 +2395,20 @@ __global__ __launch_bounds__(256) void k_seg_bound(const Job *__restrict__ jobs,
             e.maxv = vmax; e.minv = vmin;
             e.max_x = e.max_y = e.min_x = e.min_y = -1;
             partial[(int64_t)j * max_chunks + chunk] = e;
-            // upper bound of every window of the block: the far pairs' bounds and the near windows' values (a block
-            // that was scanned in full reports its values: nothing is left to find there)
+            // upper bound of every window of the block: the bounds of what was not evaluated and the values of what was
             ChunkBound cb;
-            cb.ubmax = table_ok ? fmax(ubmax, vmax) : vmax;
-            cb.lbmin = table_ok ? fmin(lbmin, vmin) : vmin;
+            cb.ubmax = fmax(ubmax, vmax);
+            cb.lbmin = fmin(lbmin, vmin);
             cbound[(int64_t)j * max_chunks + chunk] = cb;
-        }
-    }
-}
-
-// the cuts of a job from its row blocks' tables: every thread returns them
-__device__ inline void job_cuts(const Extreme *__restrict__ partial, const ChunkBound *__restrict__ cbound, int nch,
-                                double T, double &cut_hi, double &cut_lo, int tid) {
-    double lbM = -INFINITY, ubm = INFINITY, d0 = -INFINITY, d1 = INFINITY;
-    for (int ch = tid; ch < nch; ch += 256) {
-        lbM = fmax(lbM, partial[ch].maxv);
-        ubm = fmin(ubm, partial[ch].minv);
-    }
-    block_minmax4(lbM, ubm, d0, d1, tid);
-    // nothing below max(best value known, thr - eps) can be the job's maximum AND matter
-    cut_hi = fmax(lbM, T);
-    cut_lo = fmin(ubm, -T);
-}
-
-__global__ __launch_bounds__(256) void k_seg_refine(const Job *__restrict__ jobs, int n_jobs,
-                                                    const Region *__restrict__ regions,
-                                                    const double *__restrict__ prefix, const double *__restrict__ rs,
-                                                    const double *__restrict__ reg_abs, const int *__restrict__ reg_flag,
-                                                    double thr, const double *__restrict__ tmin,
-                                                    const double *__restrict__ tmax, int max_chunks,
-                                                    Extreme *__restrict__ partial, const ChunkBound *__restrict__ cbound,
-                                                    unsigned long long *__restrict__ work) {
-    __shared__ double s_tmx[Q_BLOCKS], s_tmn[Q_BLOCKS];
-    const int j = blockIdx.y, tid = threadIdx.x;
-    if (j >= n_jobs) return;
-    const Job job = jobs[j];
-    const int L = job.hi - job.lo, half = (L + 1) / 2;
-    if (L <= 0 || (int)blockIdx.x * ROWS_HALF >= half) return;
-    if (!reg_flag[job.region]) return;
-    const int nch = (half + ROWS_HALF - 1) / ROWS_HALF;
-    Extreme *pj = partial + (int64_t)j * max_chunks;
-    const ChunkBound *cj = cbound + (int64_t)j * max_chunks;
-    const double eps = window_eps(regions[job.region].n, reg_abs[job.region]);
-    double cut_hi, cut_lo;
-    job_cuts(pj, cj, nch, thr - eps, cut_hi, cut_lo, tid);
-    // the row blocks this workgroup would refine: any at all?
-    int any = 0;
-    for (int chunk = blockIdx.x; chunk < nch; chunk += gridDim.x) any |= (cj[chunk].ubmax >= cut_hi) | (cj[chunk].lbmin <= cut_lo);
-    if (!any) return;
-    const long long base = regions[job.region].off + job.region + job.lo;
-    long long k_base, k_last;
-    const bool table_ok = stage_block_tables(base, L, tmin, tmax, s_tmx, s_tmn, k_base, k_last, tid);
-    if (!table_ok) return;                        // scanned in full by k_seg_bound: its values are the block's extremes
-    for (int chunk = blockIdx.x; chunk < nch; chunk += gridDim.x) {
-        if (!(cj[chunk].ubmax >= cut_hi || cj[chunk].lbmin <= cut_lo)) continue;      // workgroup-uniform
-        double vmax = -INFINITY, vmin = INFINITY, d0 = -INFINITY, d1 = INFINITY;
-        bscan_chunk<1>(job, chunk, base, prefix, rs, cut_hi, cut_lo, s_tmx, s_tmn, k_base, k_last, true, vmax, vmin, d0, d1,
-                       [](double, int, int) {}, work);
-        block_minmax4(vmax, vmin, d0, d1, tid);
-        // every window of the block at or beyond a cut has been evaluated; the lower bounds k_seg_bound left
-        // (<= some window's value, so <= the job's extreme, which IS among the evaluated ones) stay valid
-        if (tid == 0) {
-            pj[chunk].maxv = fmax(pj[chunk].maxv, vmax);
-            pj[chunk].minv = fmin(pj[chunk].minv, vmin);
+            // values of windows that exist (and lower bounds of such) raise the job's cuts for everybody
+            cut_hi = fmax(cut_hi, vmax);
+            cut_lo = fmin(cut_lo, vmin);
+            if (cut_hi > in_hi) atomicMax(&cuts[2 * j], wc::f64_ordered(cut_hi));
+            if (cut_lo < in_lo) atomicMax(&cuts[2 * j + 1], wc::f64_ordered(-cut_lo));
+            if (mark_jobs) {
+                const double eps = window_eps(regions[job.region].n, reg_abs[job.region]);
+                if (!(fmax(fabs(vmax), fabs(vmin)) + eps < thr)) mark_jobs[j].pad = 1;
+            }
         }
     }
 }
@@ -2293,10 +2423,11 @@ __global__ __launch_bounds__(256) void k_seg_bcollect(const Job *__restrict__ jo
                                                       const double *__restrict__ reg_abs, double thr,
                                                       const Extreme *__restrict__ job_res,
                                                       const double *__restrict__ tmin, const double *__restrict__ tmax,
+                                                      const double *__restrict__ tmin2, const double *__restrict__ tmax2,
                                                       int max_chunks, const ChunkBound *__restrict__ cbound,
                                                       int2 *__restrict__ cand, int *__restrict__ cand_cnt,
                                                       unsigned long long *__restrict__ work) {
-    __shared__ double s_tmx[Q_BLOCKS], s_tmn[Q_BLOCKS];
+    __shared__ double s_tmx[Q_BLOCKS], s_tmn[Q_BLOCKS], s_tmx2[Q_BLOCKS / 4 + 2], s_tmn2[Q_BLOCKS / 4 + 2];
     const int h = blockIdx.y, tid = threadIdx.x;
     if (h >= counters[2]) return;
     const int j = hot[h];
@@ -2307,18 +2438,18 @@ __global__ __launch_bounds__(256) void k_seg_bcollect(const Job *__restrict__ jo
     const ChunkBound *cj = cbound + (int64_t)j * max_chunks;
     const double eps = window_eps(regions[job.region].n, reg_abs[job.region]);
     const Extreme e = job_res[j];
-    const double hi_cut = !(e.maxv + eps < thr) ? e.maxv - 2.0 * eps : INFINITY;
-    const double lo_cut = !(-e.minv + eps < thr) ? e.minv + 2.0 * eps : -INFINITY;
+    double hi_cut = !(e.maxv + eps < thr) ? e.maxv - 2.0 * eps : INFINITY;
+    double lo_cut = !(-e.minv + eps < thr) ? e.minv + 2.0 * eps : -INFINITY;
     int any = 0;
     for (int chunk = blockIdx.x; chunk < nch; chunk += gridDim.x) any |= (cj[chunk].ubmax >= hi_cut) | (cj[chunk].lbmin <= lo_cut);
     if (!any) return;
     const long long base = regions[job.region].off + job.region + job.lo;
     long long k_base, k_last;
-    const bool table_ok = stage_block_tables(base, L, tmin, tmax, s_tmx, s_tmn, k_base, k_last, tid);
+    const bool table_ok = stage_block_tables(base, L, tmin, tmax, s_tmx, s_tmn, k_base, k_last, tid, tmin2, tmax2, s_tmx2, s_tmn2);
     for (int chunk = blockIdx.x; chunk < nch; chunk += gridDim.x) {
         if (!(cj[chunk].ubmax >= hi_cut || cj[chunk].lbmin <= lo_cut)) continue;
         double d0 = -INFINITY, d1 = INFINITY, d2 = -INFINITY, d3 = INFINITY;
-        bscan_chunk<2>(job, chunk, base, prefix, rs, hi_cut, lo_cut, s_tmx, s_tmn, k_base, k_last, table_ok, d0, d1, d2, d3,
+        bscan_chunk<2>(job, chunk, base, prefix, rs, hi_cut, lo_cut, s_tmx, s_tmn, k_base, k_last, s_tmx2, s_tmn2, table_ok, d0, d1, d2, d3,
                        [&](double v, int x, int y) {
                            if (v >= hi_cut) {
                                const int at = atomicAdd(&cand_cnt[2 * h], 1);
@@ -3851,7 +3982,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     if ((rc = ts.prefix.reserve(sizeof(double) * (total_len + n_regions + 8)))) return rc;
     if ((rc = ts.reg_abs.reserve(sizeof(double) * n_regions))) return rc;
     if ((rc = ts.reg_flag.reserve(sizeof(int) * n_regions))) return rc;
-    const int64_t rs_need = std::max<int64_t>(max_n + 80, 2 * QB + 80);   // the search reads four lengths at a time (the candidate scan one trip ahead)
+    const int64_t rs_need = std::max<int64_t>(max_n + 80 + QB2, 2 * QB + 80 + QB2);   // the search reads four lengths at a time (the candidate scan one trip ahead); the bound scan min len + 128
                                                                         // past the longest window, the certificate 1..64
     if (ts.rs_len < rs_need) {
         if ((rc = ts.rs.reserve(sizeof(double) * rs_need))) return rc;
@@ -3946,8 +4077,12 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
         const int64_t total = total_len + n_regions, nblk = cdiv(total, QB);
         if ((rc = ts.tmin.reserve(sizeof(double) * nblk))) return rc;
         if ((rc = ts.tmax.reserve(sizeof(double) * nblk))) return rc;
-        hipLaunchKernelGGL(k_block_minmax, dim3((unsigned)cdiv(nblk, 256)), dim3(256), 0, stream,
-                           (const double *)ts.prefix.as<double>(), total, ts.tmin.as<double>(), ts.tmax.as<double>());
+        const int64_t nblk2 = cdiv(nblk, 4);
+        if ((rc = ts.tmin2.reserve(sizeof(double) * nblk2))) return rc;
+        if ((rc = ts.tmax2.reserve(sizeof(double) * nblk2))) return rc;
+        hipLaunchKernelGGL(k_block_minmax, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream,
+                           (const double *)ts.prefix.as<double>(), total, ts.tmin.as<double>(), ts.tmax.as<double>(),
+                           ts.tmin2.as<double>(), ts.tmax2.as<double>());
     }
     if (!fused) {
         // batch path: the whole-region values are an output only -> side stream (one wave per region walks
@@ -3992,20 +4127,39 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
         const unsigned per_job = (unsigned)std::min<int64_t>(max_chunks, std::max<int64_t>(1, 16384 / n_jobs));
         if (bound_path) {
             if ((rc = ts.cbound.reserve(sizeof(ChunkBound) * n_jobs * max_chunks))) return rc;
+            if ((rc = ts.cuts.reserve(sizeof(unsigned long long) * 2 * n_jobs))) return rc;
+            hipLaunchKernelGGL(k_seg_seed, dim3((unsigned)n_jobs), dim3(256), 0, stream, (const Job *)cur, (int)n_jobs,
+                               regions_dev, (const double *)ts.rs.as<double>(), (const double *)ts.reg_abs.as<double>(),
+                               (const int *)ts.reg_flag.as<int>(), thr, (const double *)ts.tmin.as<double>(),
+                               (const double *)ts.tmax.as<double>(), ts.cuts.as<unsigned long long>());
             hipLaunchKernelGGL(k_seg_bound, dim3(per_job, (unsigned)n_jobs), dim3(256), 0, stream, (const Job *)cur, (int)n_jobs,
                                regions_dev, (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
                                (const int *)ts.reg_flag.as<int>(), (const double *)ts.tmin.as<double>(),
-                               (const double *)ts.tmax.as<double>(), max_chunks, ts.partial.as<Extreme>(),
-                               ts.cbound.as<ChunkBound>(), counters, counters + 1, work);
-            hipLaunchKernelGGL(k_seg_refine, dim3(per_job, (unsigned)n_jobs), dim3(256), 0, stream, (const Job *)cur, (int)n_jobs,
-                               regions_dev, (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
-                               (const double *)ts.reg_abs.as<double>(), (const int *)ts.reg_flag.as<int>(), thr,
-                               (const double *)ts.tmin.as<double>(), (const double *)ts.tmax.as<double>(), max_chunks,
-                               ts.partial.as<Extreme>(), (const ChunkBound *)ts.cbound.as<ChunkBound>(), work);
+                               (const double *)ts.tmax.as<double>(), (const double *)ts.tmin2.as<double>(),
+                               (const double *)ts.tmax2.as<double>(), max_chunks, ts.partial.as<Extreme>(),
+                               ts.cbound.as<ChunkBound>(), ts.cuts.as<unsigned long long>(), counters, counters + 1, work,
+                               (Job *)nullptr, (const double *)nullptr, thr);
         } else {
         if (certify) {
             // about 16 384 workgroups in all: one per job when there are many jobs, every row block
             // of a job in parallel when there are few
+            if (!bits) {
+                // the certificate by the bound sweep (its extremes are not used on this path: the tree kernel starts
+                // from the value search's per-slice partials, so the search still runs for the jobs marked here)
+                if ((rc = ts.cbound.reserve(sizeof(ChunkBound) * n_jobs * max_chunks))) return rc;
+                if ((rc = ts.cuts.reserve(sizeof(unsigned long long) * 2 * n_jobs))) return rc;
+                hipLaunchKernelGGL(k_seg_seed, dim3((unsigned)n_jobs), dim3(256), 0, stream, (const Job *)cur, (int)n_jobs,
+                                   regions_dev, (const double *)ts.rs.as<double>(), (const double *)ts.reg_abs.as<double>(),
+                                   (const int *)ts.reg_flag.as<int>(), thr, (const double *)ts.tmin.as<double>(),
+                                   (const double *)ts.tmax.as<double>(), ts.cuts.as<unsigned long long>());
+                hipLaunchKernelGGL(k_seg_bound, dim3(per_job, (unsigned)n_jobs), dim3(256), 0, stream, (const Job *)cur,
+                                   (int)n_jobs, regions_dev, (const double *)ts.prefix.as<double>(),
+                                   (const double *)ts.rs.as<double>(), (const int *)ts.reg_flag.as<int>(),
+                                   (const double *)ts.tmin.as<double>(), (const double *)ts.tmax.as<double>(),
+                                   (const double *)ts.tmin2.as<double>(), (const double *)ts.tmax2.as<double>(), max_chunks,
+                                   ts.partial.as<Extreme>(), ts.cbound.as<ChunkBound>(), ts.cuts.as<unsigned long long>(),
+                                   counters, counters + 1, work, cur, (const double *)ts.reg_abs.as<double>(), thr);
+            } else
             hipLaunchKernelGGL(k_seg_quiet, dim3(per_job, (unsigned)n_jobs), dim3(256), 0, stream, cur, (int)n_jobs, regions_dev,
                                (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
                                (const double *)ts.reg_abs.as<double>(), (const int *)ts.reg_flag.as<int>(), thr,
@@ -4082,7 +4236,8 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
                                (const int *)hot, (const int *)counters, regions_dev, (const double *)ts.prefix.as<double>(),
                                (const double *)ts.rs.as<double>(), (const double *)ts.reg_abs.as<double>(), thr,
                                (const Extreme *)ts.job_res.as<Extreme>(), (const double *)ts.tmin.as<double>(),
-                               (const double *)ts.tmax.as<double>(), max_chunks, (const ChunkBound *)ts.cbound.as<ChunkBound>(),
+                               (const double *)ts.tmax.as<double>(), (const double *)ts.tmin2.as<double>(),
+                               (const double *)ts.tmax2.as<double>(), max_chunks, (const ChunkBound *)ts.cbound.as<ChunkBound>(),
                                ts.cand.as<int2>(), ts.cand_cnt.as<int>(), work);
         } else if (n_hot > 0) {
             // only a few blocks survive the pruning; sixteen waves each keep their scan short
