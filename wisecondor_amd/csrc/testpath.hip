@@ -2365,10 +2365,7 @@ __global__ __launch_bounds__(256) void k_seg_bound(const Job *__restrict__ jobs,
                                                    int max_chunks, Extreme *__restrict__ partial,
                                                    ChunkBound *__restrict__ cbound, unsigned long long *__restrict__ cuts,
                                                    int *__restrict__ counters, int *__restrict__ next_count,
-                                                   unsigned long long *__restrict__ work, Job *__restrict__ mark_jobs,
-                                                   const double *__restrict__ reg_abs, double thr) {
-    // mark_jobs (the tree path's certificate role): Job::pad = 1 for every job one of whose windows can reach
-    // the threshold -- the value search and classify then skip the others, as after k_seg_quiet
+                                                   unsigned long long *__restrict__ work) {
     __shared__ double s_tmx[Q_BLOCKS], s_tmn[Q_BLOCKS], s_tmx2[Q_BLOCKS / 4 + 2], s_tmn2[Q_BLOCKS / 4 + 2];
     const int j = blockIdx.y, tid = threadIdx.x;
     // first kernel of a round that touches the counters: next-jobs / hot / brute counts start at zero
@@ -2405,10 +2402,6 @@ __global__ __launch_bounds__(256) void k_seg_bound(const Job *__restrict__ jobs,
             cut_lo = fmin(cut_lo, vmin);
             if (cut_hi > in_hi) atomicMax(&cuts[2 * j], wc::f64_ordered(cut_hi));
             if (cut_lo < in_lo) atomicMax(&cuts[2 * j + 1], wc::f64_ordered(-cut_lo));
-            if (mark_jobs) {
-                const double eps = window_eps(regions[job.region].n, reg_abs[job.region]);
-                if (!(fmax(fabs(vmax), fabs(vmin)) + eps < thr)) mark_jobs[j].pad = 1;
-            }
         }
     }
 }
@@ -4137,29 +4130,11 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
                                (const int *)ts.reg_flag.as<int>(), (const double *)ts.tmin.as<double>(),
                                (const double *)ts.tmax.as<double>(), (const double *)ts.tmin2.as<double>(),
                                (const double *)ts.tmax2.as<double>(), max_chunks, ts.partial.as<Extreme>(),
-                               ts.cbound.as<ChunkBound>(), ts.cuts.as<unsigned long long>(), counters, counters + 1, work,
-                               (Job *)nullptr, (const double *)nullptr, thr);
+                               ts.cbound.as<ChunkBound>(), ts.cuts.as<unsigned long long>(), counters, counters + 1, work);
         } else {
         if (certify) {
             // about 16 384 workgroups in all: one per job when there are many jobs, every row block
             // of a job in parallel when there are few
-            if (!bits) {
-                // the certificate by the bound sweep (its extremes are not used on this path: the tree kernel starts
-                // from the value search's per-slice partials, so the search still runs for the jobs marked here)
-                if ((rc = ts.cbound.reserve(sizeof(ChunkBound) * n_jobs * max_chunks))) return rc;
-                if ((rc = ts.cuts.reserve(sizeof(unsigned long long) * 2 * n_jobs))) return rc;
-                hipLaunchKernelGGL(k_seg_seed, dim3((unsigned)n_jobs), dim3(256), 0, stream, (const Job *)cur, (int)n_jobs,
-                                   regions_dev, (const double *)ts.rs.as<double>(), (const double *)ts.reg_abs.as<double>(),
-                                   (const int *)ts.reg_flag.as<int>(), thr, (const double *)ts.tmin.as<double>(),
-                                   (const double *)ts.tmax.as<double>(), ts.cuts.as<unsigned long long>());
-                hipLaunchKernelGGL(k_seg_bound, dim3(per_job, (unsigned)n_jobs), dim3(256), 0, stream, (const Job *)cur,
-                                   (int)n_jobs, regions_dev, (const double *)ts.prefix.as<double>(),
-                                   (const double *)ts.rs.as<double>(), (const int *)ts.reg_flag.as<int>(),
-                                   (const double *)ts.tmin.as<double>(), (const double *)ts.tmax.as<double>(),
-                                   (const double *)ts.tmin2.as<double>(), (const double *)ts.tmax2.as<double>(), max_chunks,
-                                   ts.partial.as<Extreme>(), ts.cbound.as<ChunkBound>(), ts.cuts.as<unsigned long long>(),
-                                   counters, counters + 1, work, cur, (const double *)ts.reg_abs.as<double>(), thr);
-            } else
             hipLaunchKernelGGL(k_seg_quiet, dim3(per_job, (unsigned)n_jobs), dim3(256), 0, stream, cur, (int)n_jobs, regions_dev,
                                (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
                                (const double *)ts.reg_abs.as<double>(), (const int *)ts.reg_flag.as<int>(), thr,
