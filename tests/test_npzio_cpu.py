@@ -137,6 +137,87 @@ def test_reader_falls_back_and_reports(tmp_path):
         ingest.read_counts([str(tmp_path / "missing.npz")], sizes, 1e6, got)
 
 
+def test_reader_rejects_damaged_zip_headers_without_reading_past_the_file(tmp_path):
+    """Sizes and offsets of a zip member come from the file.  Damaged ones -- values that would wrap a size_t in
+    `offset + size` checks, a zip64 extra field claiming 2^63 bytes, a local header beyond the end, a member that
+    claims to inflate to a terabyte -- must make the native reader pass the file on (status != 0) instead of reading
+    past the buffer or allocating what the header says; np.load then words the error."""
+    import struct
+    from wisecondor_amd import _lib
+    sizes = [10] * 22
+    good = str(tmp_path / "good.npz")
+    np.savez_compressed(good, arguments={"binsize": 1e6}, runtime={}, sample=_sample(3, [10] * 24), quality={})
+    raw = bytearray(open(good, "rb").read())
+    eocd = raw.rfind(b"PK\x05\x06")
+    cd_off = struct.unpack_from("<I", raw, eocd + 16)[0]
+    n_entries = struct.unpack_from("<H", raw, eocd + 10)[0]
+    # central directory entry of sample.npy
+    at, entry = cd_off, None
+    for _ in range(n_entries):
+        nl, xl, cl = struct.unpack_from("<HHH", raw, at + 28)
+        if bytes(raw[at + 46:at + 46 + nl]) == b"sample.npy":
+            entry = at
+        at += 46 + nl + xl + cl
+    assert entry is not None
+
+    def variant(name, edit):
+        data = bytearray(raw)
+        edit(data)
+        path = str(tmp_path / name)
+        open(path, "wb").write(bytes(data))
+        return path
+
+    def huge_usize(d):       # inflates to 2^40 bytes, says the header
+        struct.pack_into("<I", d, entry + 24, 0xFFFFFFFE)
+
+    def huge_csize(d):       # compressed size beyond the file: offset + size wraps in a careless check
+        struct.pack_into("<I", d, entry + 20, 0xFFFFFFF0)
+
+    def far_local(d):        # local header offset beyond the end of the file
+        struct.pack_into("<I", d, entry + 42, 0xFFFFFF00)
+
+    def far_directory(d):    # central directory offset beyond the end of the file
+        struct.pack_into("<I", d, eocd + 16, 0xFFFFFF00)
+
+    def many_entries(d):     # more directory entries than the file could hold
+        struct.pack_into("<H", d, eocd + 10, 0xFFFE)
+        struct.pack_into("<H", d, eocd + 8, 0xFFFE)
+
+    paths = [variant("v%d.npz" % i, e) for i, e in enumerate((huge_usize, huge_csize, far_local, far_directory, many_entries))]
+    # zip64 extra field with 2^63-sized members, appended to the directory entry of a copy
+    data = bytearray(raw)
+    nl, xl, cl = struct.unpack_from("<HHH", data, entry + 28)
+    extra = struct.pack("<HHQQ", 1, 16, 1 << 63, 1 << 63)
+    struct.pack_into("<I", data, entry + 20, 0xFFFFFFFF)
+    struct.pack_into("<I", data, entry + 24, 0xFFFFFFFF)
+    struct.pack_into("<H", data, entry + 30, xl + len(extra))
+    data[entry + 46 + nl + xl:entry + 46 + nl + xl] = extra
+    new_eocd = eocd + len(extra)
+    struct.pack_into("<I", data, new_eocd + 12, struct.unpack_from("<I", data, new_eocd + 12)[0] + len(extra))
+    p64 = str(tmp_path / "zip64.npz")
+    open(p64, "wb").write(bytes(data))
+    paths.append(p64)
+    paths.append(good)
+    n = len(paths)
+    rows = np.zeros((n, 220), dtype=np.int32)
+    own = np.zeros(n)
+    status = np.zeros(n, dtype=np.int32)
+    csz = np.ascontiguousarray(sizes, dtype=np.int64)
+    _lib.check(_lib.load().wc_read_samples(ingest._c_strings(paths), n, 2, _lib.ptr(csz), 22, 1e6, _lib.ptr(rows), 220,
+                                           _lib.ptr(own), _lib.ptr(status)))
+    assert status[-1] == 0 and rows[-1].sum() > 0           # the untouched file reads fine
+    assert (status[:-1] != 0).all(), status                  # every damaged one is passed on, nothing crashed
+    # the np.load path either words an error or -- where Python's zipfile trusts a different copy of the damaged
+    # field -- still delivers the file's true content; never something else
+    for path in paths[:-1]:
+        got = np.zeros((1, 220), dtype=np.int32)
+        try:
+            ingest.read_counts([path], sizes, 1e6, got)
+        except Exception:
+            continue
+        assert np.array_equal(got[0], rows[-1]), path
+
+
 def test_writer_matches_np_savez(tmp_path):
     from wisecondor_amd import wisecondor as cli
     rng = np.random.RandomState(5)
