@@ -434,7 +434,10 @@ def test_roofline(prof, n_refs, windows, n_samples, ms_per_batch):
         "bound": "fp64-valu" if byte_frac > 1.0 else "hbm",
         "frac": valu_frac if byte_frac > 1.0 else byte_frac,
         "fp64_valu_frac": valu_frac,
-        "fp64_valu_detail": {"kernels": "k_seg_quiet + k_seg_search, all rounds of one batch (events on the launch stream)",
+        "fp64_valu_detail": {"kernels": "the window-search kernels of all rounds of one batch (k_seg_seed + k_seg_bound on the "
+                                        "host-driven rounds, k_seg_quiet + k_seg_search on the tree path; events on the launch "
+                                        "stream): windows evaluated by value x 4 + bounds x 6 float64 operations, counted by "
+                                        "the kernels",
                              "ms": search_ms, "windows_evaluated": float(prof[6]),
                              "certificate_evaluations": float(prof[7]), "fp64_ops": search_ops,
                              "peak_ops_per_s": PEAK_FP64_VALU_OPS},
@@ -491,6 +494,7 @@ def emulate_world_newref(ctx, X, bins, k, order, world, single_idx, single_dst):
     idx = torch.empty((B, k), dtype=torch.int32, device=dev)
     dst = torch.empty((B, k), dtype=torch.float64, device=dev)
     ev = {m: [dict() for _ in range(world)] for m in ("tiles", "rows")}
+    exact_rows = []          # tile shard: rows of each rank that took the exact path (exchange-slot overflow included)
 
     def tile_share(r, export):
         rb, re = ranges[r]
@@ -521,6 +525,8 @@ def emulate_world_newref(ctx, X, bins, k, order, world, single_idx, single_dst):
                     st.import_(rb, re, cap_x, send_cnt[q][r], send_lst[q][r])
         ev["tiles"][r]["import"] = timed(im)
         ev["tiles"][r]["finish"] = timed(lambda: st.finish(rb, re, idx[rb:re], dst[rb:re]))
+        from wisecondor_amd import wisetools as _wt
+        exact_rows.append(int(_wt.newref_stats(dev.index or 0)["fallback_rows"]))     # (synchronises: the events are recorded)
     torch.cuda.synchronize()
     tiles_ok = bool(torch.equal(idx, single_idx) and torch.equal(dst.view(torch.int64), single_dst.view(torch.int64)))
     idx.zero_()
@@ -556,6 +562,8 @@ def emulate_world_newref(ctx, X, bins, k, order, world, single_idx, single_dst):
                      "bytes_received_per_rank_per_collective": coll,
                      "projected_comm_ms": 1e3 * comm_s, "projected_step_ms": max(tot) + 1e3 * comm_s,
                      "results_equal_single_rank": tiles_ok if mode == "tiles" else rows_ok}
+        if mode == "tiles":
+            out[mode]["exact_path_rows_per_rank"] = exact_rows
     return out
 
 

@@ -739,9 +739,9 @@ int sym_eigh_leading(wc_ctx *ctx, const double *matrix_dev, int64_t n64, int n_p
     if ((rc = allow_lds(k_tri_step, lds_step))) return rc;
     if ((rc = allow_lds(k_tri_last, lds_step))) return rc;
     if ((rc = allow_lds(k_tri_step_reg, lds_step))) return rc;
-    // the last TAIL_MAX rows in one workgroup (WC_EIG_TAIL=0: every column its own launch)
-    static const bool use_tail = [] { const char *s = getenv("WC_EIG_TAIL"); return !(s && s[0] == '0'); }();
-    const int k_split = use_tail ? std::max(0, n - TAIL_MAX) : n - 2;
+    // the last TAIL_MAX rows in one workgroup
+    const bool use_tail = true;
+    const int k_split = std::max(0, n - TAIL_MAX);
     for (int k = 0; k < k_split; ++k) {
         const int m = n - k - 1;
         const unsigned grid = (unsigned)std::min(256, std::max(1, (m + 7) / 8));

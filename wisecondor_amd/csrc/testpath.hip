@@ -2072,7 +2072,7 @@ __device__ inline void bscan_chunk(const Job &job, const int chunk, const long l
     const int L = job.hi - job.lo, half = (L + 1) / 2;
     const long long a_hi = base + L;              // absolute index of the last end
     bool full = !table_ok;
-    int evals = 0;
+    int evals = 0, wins = 0;                      // profiling only: bounds / windows by value of this thread
     __syncthreads();                              // the previous chunk's shared state is done with
     if (tid == 0) {
         s_nwork = 0;
@@ -2129,6 +2129,7 @@ __device__ inline void bscan_chunk(const Job &job, const int chunk, const long l
             };
             refresh();
             auto window = [&](const double v, const int len) {
+                ++wins;
                 if (MODE == 2) {
                     if (v >= cut_hi || v <= cut_lo) emit(v, x, x + len - 1);
                 } else {
@@ -2228,6 +2229,7 @@ __device__ inline void bscan_chunk(const Job &job, const int chunk, const long l
                     last = (tid & 31) < 8 ? (y_near < a_hi ? y_near : a_hi) : -1;
                 }
                 if (ay <= last) {
+                    ++wins;
                     const int len = (int)(ay - s_ax[row]);
                     const double v = (prefix[ay] - s_px[row]) * rs[len];
                     if (MODE == 2) {
@@ -2239,7 +2241,6 @@ __device__ inline void bscan_chunk(const Job &job, const int chunk, const long l
                     }
                 }
             }
-            if (tid == 0) evals += 32 * nwork;
         }
     }
     if (full) {
@@ -2249,6 +2250,7 @@ __device__ inline void bscan_chunk(const Job &job, const int chunk, const long l
         c.P = prefix + (base - job.lo);
         c.wm = WindowMask{nullptr, 0, 0};
         scan_chunk(c, rs, tid, [&](double v, int x, int y) {
+            ++wins;
             if (MODE == 2) {
                 if (v >= cut_hi || v <= cut_lo) emit(v, x, y);
             } else {
@@ -2264,8 +2266,14 @@ __device__ inline void bscan_chunk(const Job &job, const int chunk, const long l
         cut_lo = -wc::f64_from_ordered(s_cut[1]);
     }
     if (work) {
-        for (int o = 32; o > 0; o >>= 1) evals += __shfl_xor(evals, o);
-        if (lane == 0) atomicAdd(work + 1, (unsigned long long)evals);     // bounds + windows evaluated by value
+        // spread over 64 counter pairs (wc_test_profile_read adds them up): one address for every wave of the grid
+        // would serialise the launch
+        for (int o = 32; o > 0; o >>= 1) { evals += __shfl_xor(evals, o); wins += __shfl_xor(wins, o); }
+        const int slot = (int)((blockIdx.x * 7u + blockIdx.y * 13u + (unsigned)w) & 63u);
+        if (lane == 0) {
+            atomicAdd(work + 2 * slot, (unsigned long long)wins);
+            atomicAdd(work + 2 * slot + 1, (unsigned long long)evals);
+        }
     }
 }
 
@@ -3593,14 +3601,6 @@ struct InflateRider {
     double minref;
     double *res_z, *res_r;
 };
-struct AssembleRider {
-    int on, n_sel, max_calls;
-    int64_t Ns;
-    double *calls;
-    int *n_calls, *overflow, *host_status;
-    const int *rep_overflow, *sd_fail;
-    const double *reg_calls;
-};
 __global__ __launch_bounds__(1024) void k_seg_tree(int *__restrict__ counters, const Region *__restrict__ regions,
                                                    int64_t n_regions, const int *__restrict__ reg_flag,
                                                    const double *__restrict__ prefix, const double *__restrict__ rs,
@@ -3610,7 +3610,7 @@ __global__ __launch_bounds__(1024) void k_seg_tree(int *__restrict__ counters, c
                                                    double *__restrict__ reg_calls, int *__restrict__ out_n,
                                                    const Extreme *__restrict__ partial,
                                                    const double2 *__restrict__ sub, int max_chunks, SdRider sd,
-                                                   InflateRider inf, AssembleRider as,
+                                                   InflateRider inf,
                                                    const int *__restrict__ hot_list, const int *__restrict__ hot_count) {
     const int blk = (int)blockIdx.x;
     if (blk < sd.blocks) {
@@ -3641,59 +3641,6 @@ __global__ __launch_bounds__(1024) void k_seg_tree(int *__restrict__ counters, c
         seg_tree_region(region, counters, regions, n_regions, reg_flag, prefix, rs, reg_abs, z, ratio,
                         gpos, thr, min_search, max_calls, reg_calls, out_n, partial, sub, max_chunks);
     }
-    if (!as.on) return;
-    __shared__ int s_last;
-    __threadfence();                                   // this workgroup's results, before its arrival is counted
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&counters[7], 1) == (int)gridDim.x - 1;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    const int t = threadIdx.x;
-    {
-        // k_assemble_calls' job with the loads in parallel: the other workgroups' results come from
-        // memory (other XCDs' L2s), a chain of dependent reads per sample would cost a round trip each.
-        // Thread (i, c) = (t >> 6, t & 63) reads the call count of region c of sample i; a serial scan per
-        // sample over <= WC_MAX_CHROM counts in LDS; then every thread copies its region's rows.
-        __shared__ int a_n[8][64], a_off[8][65];
-        const int i = t >> 6, c = t & 63;
-        const bool mine = t < 512 && i < as.Ns && c < as.n_sel;
-        int n = 0;
-        if (mine) {
-            n = ((volatile const int *)out_n)[i * as.n_sel + c];
-            if (n > as.max_calls) { *as.overflow = 1; n = as.max_calls; }
-        }
-        if (t < 512) a_n[i][c] = n;
-        __syncthreads();
-        if (t < 8 && t < as.Ns) {
-            int total = 0;
-            for (int q = 0; q < as.n_sel; ++q) { a_off[t][q] = total; total += a_n[t][q]; }
-            if (total > as.max_calls) *as.overflow = 1;
-            as.n_calls[t] = total < as.max_calls ? total : as.max_calls;
-        }
-        __syncthreads();
-        if (mine) {
-            const int64_t r = (int64_t)i * as.n_sel + c;
-            for (int q = 0; q < n; ++q) {
-                const int at = a_off[i][c] + q;
-                if (at >= as.max_calls) break;
-                for (int f = 0; f < 5; ++f)
-                    as.calls[((int64_t)i * as.max_calls + at) * 5 + f] =
-                        ((volatile const double *)as.reg_calls)[(r * as.max_calls + q) * 5 + f];
-            }
-        }
-    }
-    __threadfence();
-    __syncthreads();
-    if (t == 0) as.host_status[16] = ((volatile int *)as.overflow)[0];
-    if (t < 8) as.host_status[24 + t] = ((volatile int *)counters)[t];
-    if (t == 8) as.host_status[32] = as.rep_overflow[0];
-    if (t == 9) {
-        int f = 0;
-        for (int64_t q = 0; q < as.Ns; ++q) f |= ((volatile const int *)as.sd_fail)[q];
-        as.host_status[33] = f;
-    }
-    __threadfence_system();
 }
 
 // ------------------------------------------------------------ host drivers ----
@@ -3843,9 +3790,8 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
     // stdDevAvg only feeds the asdef output: it runs on the context's side stream under the
     // segmentation work (latency mode: on the launch stream -- the parallel form takes a few
     // microseconds, a second stream in the captured graph costs more -- straight into `asdef_out`).
-    const char *sd_env0 = getenv("WC_SD_AVG");
     ts.lat_ride = false;
-    if (lat && !(sd_env0 && strcmp(sd_env0, "serial") == 0) && ref->B <= 65536) {
+    if (lat && ref->B <= 65536) {
         // latency mode: the parallel form rides in k_seg_tree's grid (run_seg_lat) -- no second stream,
         // whose fork and join cost more than the kernel; a sample it gives up on raises status word 33
         if ((rc = ts.sd_fail.reserve(sizeof(int) * Ns))) return rc;
@@ -3861,10 +3807,9 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
         sds = ctx->side;
     }
     // the parallel form first (exact, see k_sd_fast); the serial chain only for samples it gave up on
-    const char *sd_env = getenv("WC_SD_AVG");                   // "serial": the chain for every sample
     const int *only = nullptr;
     double *out2 = lat ? asdef_out : nullptr;
-    if (!(sd_env && strcmp(sd_env, "serial") == 0) && ref->B <= 65536) {
+    if (ref->B <= 65536) {
         if ((rc = ts.sd_fail.reserve(sizeof(int) * Ns))) return rc;
         if (Ns > 8) {
             // a batch: the sums run over a sample-major copy (a sample's standard deviations contiguous): in
@@ -4043,8 +3988,8 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     }
     unsigned long long *work = nullptr;     // profiling: evaluation counters of the search kernels
     if (ts.profile) {
-        if ((rc = ts.prof_work.reserve(sizeof(unsigned long long) * 2))) return rc;
-        WC_HIP(hipMemsetAsync(ts.prof_work.p, 0, sizeof(unsigned long long) * 2, stream));
+        if ((rc = ts.prof_work.reserve(sizeof(unsigned long long) * 128))) return rc;      // 64 pairs {windows, bounds}
+        WC_HIP(hipMemsetAsync(ts.prof_work.p, 0, sizeof(unsigned long long) * 128, stream));
         work = ts.prof_work.as<unsigned long long>();
     }
     int *counters = ts.job_cnt.as<int>();  // [1] next jobs [2] hot [3] brute [4] segments
@@ -4174,13 +4119,12 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
         if (guard == 1 && tree_ok && n_hot > 0) {
             SdRider no_sd{};
             InflateRider no_inf{};
-            AssembleRider no_as{};
             hipLaunchKernelGGL(k_seg_tree, dim3((unsigned)n_hot), dim3(1024), sizeof(double) * (2 * max_n + 2), stream,
                                counters, regions_dev, n_regions, (const int *)ts.reg_flag.as<int>(),
                                (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
                                (const double *)ts.reg_abs.as<double>(), z_dev, tail->ratio, tail->gpos, thr, min_search,
                                max_calls, tail->reg_calls, ts.out_n.as<int>(), (const Extreme *)ts.partial.as<Extreme>(),
-                               (const double2 *)ts.sub.as<double2>(), max_chunks, no_sd, no_inf, no_as,
+                               (const double2 *)ts.sub.as<double2>(), max_chunks, no_sd, no_inf,
                                (const int *)hot, (const int *)(counters + 2));
             WC_HIP(hipMemcpyAsync(h, counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
             if (tail->defer_status) {
@@ -4257,7 +4201,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
 // left in ts.effect / ts.out_n, the whole-chromosome values in ts.whole.
 int run_seg_lat(wc_ctx *ctx, const wc_reference *ref, const double *zsrc, const double *rsrc, const double *nsrc,
                 int64_t str_i, int64_t str_b, int64_t Ns, int n_sel, int64_t max_n, double thr, int min_ref_bins,
-                int max_calls, hipStream_t stream, double *whole_copy, InflateRider inf, AssembleRider as) {
+                int max_calls, hipStream_t stream, double *whole_copy, InflateRider inf) {
     TestState &ts = ctx->ts;
     const int64_t B = ref->B, n_regions = Ns * n_sel, total_len = Ns * B;
     int rc;
@@ -4321,8 +4265,6 @@ int run_seg_lat(wc_ctx *ctx, const wc_reference *ref, const double *zsrc, const 
         rider.sb = Ns;
         rider.si = 1;
     }
-    as.reg_calls = ts.effect.as<double>();
-    as.sd_fail = ts.sd_fail.as<int>();
     const size_t tree_lds = std::max<size_t>(sizeof(double) * (2 * max_n + 2), rider.blocks ? sizeof(SdShared) : 0);
     hipLaunchKernelGGL(k_seg_tree, dim3((unsigned)(n_regions + rider.blocks + inf.blocks)), dim3(1024), tree_lds, stream, counters,
                        (const Region *)ts.regions.as<Region>(), n_regions, (const int *)ts.reg_flag.as<int>(),
@@ -4330,7 +4272,7 @@ int run_seg_lat(wc_ctx *ctx, const wc_reference *ref, const double *zsrc, const 
                        (const double *)ts.reg_abs.as<double>(), (const double *)ts.zc.as<double>(),
                        (const double *)ts.rc.as<double>(), (const int *)ts.gpos.as<int>(), thr, 3, max_calls,
                        ts.effect.as<double>(), ts.out_n.as<int>(), (const Extreme *)ts.partial.as<Extreme>(),
-                       (const double2 *)ts.sub.as<double2>(), max_chunks, rider, inf, as, (const int *)nullptr,
+                       (const double2 *)ts.sub.as<double2>(), max_chunks, rider, inf, (const int *)nullptr,
                        (const int *)nullptr);
     ts.last_segs = 0;                     // the calls are already in ts.effect / ts.out_n
     WC_HIP(hipGetLastError());
@@ -4712,10 +4654,8 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
     }
     // latency mode with something to segment: results_z / results_r are written by rider workgroups of the
     // last launch (k_seg_tree) instead of a launch of their own on the critical path
-    const char *ride_env = getenv("WC_LAT_RIDERS");            // bit 0: inflate rider (default), bit 1: assemble rider
-    const int ride_mask = ride_env ? atoi(ride_env) : 1;      // the assemble rider measured 8 us slower than its own launch (device-scope fences)
-    const bool ride_inf = lat && n_sel > 0 && calls && n_calls && (ride_mask & 1);
-    const bool ride = lat && n_sel > 0 && calls && n_calls && (ride_mask & 2);
+    // (k_assemble_calls as a rider too measured 8 us slower than its own launch: device-scope fences; EXPERIMENTS.md)
+    const bool ride_inf = lat && n_sel > 0 && calls && n_calls;
     if ((results_z || results_r) && !ride_inf) {
         dim3 g((unsigned)cdiv(ref->Btot, 256), (unsigned)Ns);
         // a batch: the inflated outputs feed nothing downstream -> side stream, under the segmentation
@@ -4743,7 +4683,6 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
     if (lat) {
         if ((rc = ctx->ensure_pinned(256))) return rc;
         InflateRider inf{};
-        AssembleRider as{};
         if (ride_inf && (results_z || results_r)) {
             {
                 inf.blocks = (int)std::min<int64_t>(16, cdiv(ref->Btot * Ns, 1024));
@@ -4754,25 +4693,11 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
                 inf.res_z = results_z; inf.res_r = results_r;
             }
         }
-        if (ride) {
-            as.on = 1; as.n_sel = n_sel; as.max_calls = max_calls; as.Ns = Ns;
-            as.calls = calls; as.n_calls = n_calls; as.overflow = ts.misc.as<int>();
-            as.host_status = (int *)ctx->pinned;
-            as.rep_overflow = ts.misc2.as<int>() + repeats + 1;
-        }
-        if (ride && (rc = join_side(ctx, stream))) return rc;     // WC_SD_AVG=serial: the flags come from the side stream
         if ((rc = run_seg_lat(ctx, ref, zsrc, rsrc, nsrc, str_i, str_b, Ns, n_sel, max_n, threshold, min_ref_bins,
-                              max_calls, stream, results_cwz, inf, as)))
+                              max_calls, stream, results_cwz, inf)))
             return rc;
-        if (ride) {
-            ts.mark(4, stream);
-            ts.mark(5, stream);
-            WC_HIP(hipGetLastError());
-            return WC_OK;
-        }
     } else {
-        const char *fs_env = getenv("WC_TEST_FUSED_SETUP");        // "0": the separate set-up kernels
-        const bool fuse = min_effect == 0.0 && max_n <= TREE_MAXLEN && !(fs_env && fs_env[0] == '0');
+        const bool fuse = min_effect == 0.0 && max_n <= TREE_MAXLEN;       // regions that fit the fused set-up kernel
         if (!fuse)
         hipLaunchKernelGGL(k_clean, dim3((unsigned)n_sel, (unsigned)Ns),
                            dim3((unsigned)std::min<int64_t>(1024, std::max<int64_t>(64, cdiv(max_n, 256) * 64))), 0, stream, zsrc, rsrc, nsrc, B, Ns,
@@ -5013,10 +4938,10 @@ int wc_test_profile_read(wc_ctx *ctx, double out[8]) {
         }
     }
     if (ts.prof_work.p) {
-        unsigned long long w[2] = {0, 0};
+        unsigned long long w[128];
         WC_HIP(hipMemcpy(w, ts.prof_work.p, sizeof(w), hipMemcpyDeviceToHost));
-        out[6] = (double)w[0];
-        out[7] = (double)w[1];
+        out[6] = out[7] = 0.0;
+        for (int q = 0; q < 64; ++q) { out[6] += (double)w[2 * q]; out[7] += (double)w[2 * q + 1]; }
     }
     return WC_OK;
 }

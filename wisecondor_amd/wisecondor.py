@@ -343,11 +343,7 @@ def toolTestBatch(args):
     reference, cut = _reference_and_threshold(args, device=device)
     lo, hi = shard_samples(len(args.infiles), rank, world_env)
     os.makedirs(args.outdir, exist_ok=True)
-    py_writer = None
-    if os.environ.get('WC_INGEST_PYTHON_WRITER'):      # the pre-native writer (np.savez_compressed per file), for comparison
-        py_writer = lambda path, one, res: writeTestOutput(path, one, reference.binsize, res, cut)   # noqa: E731
-    stats = ingest.run_testbatch(reference, args.infiles[lo:hi], args.outdir, cut, args, writer=py_writer,
-                                 runtime=getRuntime())
+    stats = ingest.run_testbatch(reference, args.infiles[lo:hi], args.outdir, cut, args, runtime=getRuntime())
     print('rank %d: %d samples in %.2f s (%.1f files/s end to end; GPU batches %.3f s)'
           % (rank, stats['files'], stats['wall_s'], stats['files_per_s'], stats['gpu_s']))
     reference.close()
