@@ -4097,7 +4097,11 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
 #define WC_SEARCH_NW(M, P_) do { if (wide) WC_SEARCH(M, P_, 16); else WC_SEARCH(M, P_, 4); } while (0)
             const bool wide = n_jobs * max_chunks <= 2048;     // few blocks: sixteen waves each
             if (bits) { if (plds) WC_SEARCH_NW(true, true); else WC_SEARCH_NW(true, false); }
-            else { if (plds) WC_SEARCH_NW(false, true); else WC_SEARCH_NW(false, false); }
+            else {
+                // unmasked rounds get here only on the tree path (regions <= TREE_MAXLEN): the slice always fits
+                WC_CHECK(plds, WC_E_INTERNAL, "stouffer: unmasked value search beyond the LDS-staged sizes");
+                WC_SEARCH_NW(false, true);
+            }
 #undef WC_SEARCH_NW
 #undef WC_SEARCH
         }
