@@ -158,6 +158,7 @@ def test_newref_on_two_ranks_equals_one(tmp_path, golden, monkeypatch):
     one = str(tmp_path / "one.npz")
     cli.main(["newref"] + infiles + [one, "-refsize", "100", "-parts", "3"])
     monkeypatch.setenv("WC_RANKS_BACKEND", "gloo")
+    monkeypatch.chdir(tmp_path)          # the rank processes must find the package from any working directory
     two = str(tmp_path / "two.npz")
     cli.main(["newref"] + infiles + [two, "-refsize", "100", "-cpus", "3", "-gpus", "2"])
     assert not os.path.exists(str(tmp_path / "two_prep.npz")) and not os.path.exists(str(tmp_path / "two_part_2.npz"))

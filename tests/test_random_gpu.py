@@ -193,7 +193,7 @@ def test_mineffectsize_counting_equals_sorted_insert_on_long_regions(wt, monkeyp
     itself pinned on the reference's goldens)."""
     rng = np.random.RandomState(77)
     zs, rs = [], []
-    for n in (3000, 5000, 1237):
+    for n in (3000, 5000, 1237, 6500):        # (6 500: beyond the LDS-staged prefix slice of the masked value search)
         z = rng.standard_normal(n)
         r = np.round(1.0 + 0.03 * rng.standard_normal(n), 3)
         a = n // 3
@@ -211,6 +211,38 @@ def test_mineffectsize_counting_equals_sorted_insert_on_long_regions(wt, monkeyp
         assert [(x, y) for _, (x, y) in sa] == [(x, y) for _, (x, y) in sb]
         assert same_bits([v for v, _ in sa], [v for v, _ in sb])
     assert same_bits(whole_a, whole_b)
+
+
+def test_mineffectsize_on_many_regions(wt, monkeypatch):
+    """A round with many jobs (the four-wave forms of the masked value search, with and without the prefix slice in
+    LDS): 180 regions of ~1 500 bins and one of 6 500 with the median filter on, counting kernel against the sorted-insert kernel, and the short regions among them against
+    the oracle's fillTriMin."""
+    rng = np.random.RandomState(78)
+    zs, rs = [], []
+    for i in range(180):
+        n = 6500 if i == 1 else (1500 if i % 30 else 90)        # one region beyond the LDS-staged prefix slice
+        z = rng.standard_normal(n)
+        r = np.round(1.0 + 0.03 * rng.standard_normal(n), 3)
+        if i % 3 == 0:
+            a = n // 4
+            z[a:a + n // 8] += 1.0
+            r[a:a + n // 8] += 0.05
+        zs.append(z)
+        rs.append(r)
+    monkeypatch.delenv("WC_MINEFFECT", raising=False)
+    whole_a, segs_a = wt.stouffer_segments(zs, 4.5, 3, ratios=rs, mineffectsize=0.02)
+    monkeypatch.setenv("WC_MINEFFECT", "sorted")
+    whole_b, segs_b = wt.stouffer_segments(zs, 4.5, 3, ratios=rs, mineffectsize=0.02)
+    assert sum(len(s) for s in segs_a) >= 50
+    for sa, sb in zip(segs_a, segs_b):
+        assert [(x, y) for _, (x, y) in sa] == [(x, y) for _, (x, y) in sb]
+        assert same_bits([v for v, _ in sa], [v for v, _ in sb])
+    assert same_bits(whole_a, whole_b)
+    for i in range(0, 180, 30):
+        tri = wo.fill_tri_min(zs[i], rs[i], 0.02)
+        want = wo.segment_tri(tri, len(zs[i]), 4.5, 3)
+        assert [(x, y) for _, (x, y) in segs_a[i]] == [(x, y) for _, (x, y) in want], i
+        assert same_bits([v for v, _ in segs_a[i]], [v for v, _ in want]), i
 
 
 def test_degenerate_samples(wt):

@@ -296,7 +296,7 @@ def test_std_dev_avg_parallel_form_is_exact(wt):
     huge and tiny terms; and it must really be the parallel form that answered."""
     rng = np.random.RandomState(11)
     rows = []
-    for n in (1, 2, 7, 63, 64, 65, 1000, 1024, 1025, 11087, 57633):
+    for n in (1, 2, 7, 63, 64, 65, 1000, 1024, 1025, 11087, 20011, 57633):      # (20 011: the 13..24 values-per-thread form)
         rows.append((n, np.abs(0.03 + 0.01 * rng.standard_normal(n))))
         v = np.abs(rng.standard_normal(n)) * 10.0 ** rng.uniform(-6, 6, size=n)       # many binade crossings
         rows.append((n, v))

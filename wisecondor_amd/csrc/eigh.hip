@@ -394,21 +394,6 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tri_tail(const double *__restr
             V[(size_t)(k0 + c) * n + j] = j > k0 + c ? M[c * TAIL_LD + j - k0] : 0.0;
 }
 
-// The last 2 x 2 block: d[n-2], d[n-1], e[n-2] with the last pending update applied.
-__global__ __launch_bounds__(256) void k_tri_last(const double *__restrict__ A, const double *__restrict__ V,
-                                                  const double *__restrict__ P, double *__restrict__ d,
-                                                  double *__restrict__ e, const double *__restrict__ tau, int n) {
-    extern __shared__ double lds[];
-    __shared__ double red[4];
-    double *vp = lds, *wp = lds + n;
-    previous_reflector(V, P, tau, n, n - 2, vp, wp, red);
-    if (threadIdx.x == 0) {
-        const int a = n - 2, b = n - 1;
-        d[a] = A[(size_t)a * n + a] - (vp[a] * wp[a] + wp[a] * vp[a]);
-        d[b] = A[(size_t)b * n + b] - (vp[b] * wp[b] + wp[b] * vp[b]);
-        e[a] = A[(size_t)b * n + a] - (vp[b] * wp[a] + wp[b] * vp[a]);
-    }
-}
 
 // Eigenvalue number (n-1-blockIdx.x) in ascending order -- the blockIdx.x-th largest -- of the
 // symmetric tridiagonal (d, e): multisection on the Sturm count (number of eigenvalues below x; the
@@ -737,10 +722,8 @@ int sym_eigh_leading(wc_ctx *ctx, const double *matrix_dev, int64_t n64, int n_p
     }
     const size_t lds_step = sizeof(double) * 3 * (size_t)n;
     if ((rc = allow_lds(k_tri_step, lds_step))) return rc;
-    if ((rc = allow_lds(k_tri_last, lds_step))) return rc;
     if ((rc = allow_lds(k_tri_step_reg, lds_step))) return rc;
     // the last TAIL_MAX rows in one workgroup
-    const bool use_tail = true;
     const int k_split = std::max(0, n - TAIL_MAX);
     for (int k = 0; k < k_split; ++k) {
         const int m = n - k - 1;
@@ -750,14 +733,11 @@ int sym_eigh_leading(wc_ctx *ctx, const double *matrix_dev, int64_t n64, int n_p
         else
             hipLaunchKernelGGL(k_tri_step, dim3(grid), dim3(256), lds_step, stream, A, V, P, d, e, tau, n, k);
     }
-    if (use_tail) {
+    {
         const size_t lds_tail = sizeof(double) * ((size_t)TAIL_MAX * TAIL_LD + 5 * TAIL_MAX);
         if ((rc = allow_lds(k_tri_tail, lds_tail))) return rc;
         hipLaunchKernelGGL(k_tri_tail, dim3(1), dim3(TAIL_THREADS), lds_tail, stream, (const double *)A, V,
                            (const double *)P, d, e, tau, n, k_split);
-    } else {
-        hipLaunchKernelGGL(k_tri_last, dim3(1), dim3(256), lds_step, stream, (const double *)A, (const double *)V,
-                           (const double *)P, d, e, (const double *)tau, n);
     }
     const size_t lds_vals = sizeof(double) * 2 * (size_t)n;
     if ((rc = allow_lds(k_tri_eigvals, lds_vals))) return rc;

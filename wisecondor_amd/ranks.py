@@ -38,9 +38,12 @@ def launch(n_ranks, spec, backend=None, extra_env=None):
         json.dump(spec, f)
         spec_path = f.name
     procs = []
+    # the children import this package the way this process did, whatever the working directory is
+    pkg_parent = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     try:
         for rank in range(n_ranks):
             env = dict(os.environ)
+            env['PYTHONPATH'] = os.pathsep.join([pkg_parent] + [p for p in env.get('PYTHONPATH', '').split(os.pathsep) if p])
             env.update({'RANK': str(rank), 'LOCAL_RANK': str(rank), 'WORLD_SIZE': str(n_ranks),
                         'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port),
                         'HSA_ENABLE_IPC_MODE_LEGACY': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0')})
