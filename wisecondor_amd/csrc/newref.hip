@@ -101,6 +101,14 @@ __global__ __launch_bounds__(1024) void k_col_centre(const double *__restrict__ 
     }
 }
 
+// Layout of the float16 image A16 (bins_pad rows x Kpad16 samples): the 128 rows of a tile panel and the 32
+// samples of a k-slab form one contiguous 8 KB block (row-major inside, 64 bytes per row), blocks ordered by
+// (panel, slab).  A tile's operand slab is then ONE contiguous stretch: every 128-byte line the LDS-DMA touches is
+// used whole (rows of Kpad16 halfs put a slab on half a line of each of 128 rows: measured 16 % slower tile loop).
+__device__ __host__ inline int64_t a16_index(int64_t row, int64_t s, int64_t Kpad16) {
+    return (((row >> 7) * (Kpad16 >> 5) + (s >> 5)) << 12) + ((row & 127) << 5) + (s & 31);
+}
+
 // float32 -> float16 bits for the one-product tiles: value * gam (a power of two) clamped to the
 // finite float16 range, rounded to nearest even, subnormal results flushed to zero (so that the
 // image is exactly what any matrix-core denormal mode sees).  NaN stays NaN.
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(256) void k_convert(const double *__restrict__ X, i
         const double err = (double)a - back;
         e2 += err * err;
         hn += back * back;
-        A16[row * Kpad16 + s] = h;
+        A16[a16_index(row, s, Kpad16)] = h;
         if (slot >= 0) S16[(int64_t)slot * Kpad16 + s] = h;
         acc += (double)a * (double)a;
     }
@@ -253,7 +261,7 @@ __global__ void k_pad_samples(int64_t Kpad16, int64_t first, unsigned short *__r
 
 // --------------------------------------------------------------- Gram tiles ----
 struct GramArgs {
-    const float *P, *Q;          // [rows, ld] float16 image viewed as 32-bit words, rows padded to 128
+    const float *P, *Q;          // blocked float16 image (a16_index) viewed as 32-bit words, rows padded to 128
     int64_t ld;                  // row stride in 32-bit words (padded sample count / 2)
     const float *m2;             // -2 / gam^2 (the operand image is scaled by gam)
     int nslab32, last_steps32;   // 32-sample slabs, 16-sample MFMA steps of the last one that hold samples (1..2)
@@ -374,45 +382,62 @@ __device__ __forceinline__ void gram_epilogue(const GramArgs &g, float *sm, floa
         const int64_t gq = (int64_t)J * TB + x;
         if (mask_c) base_c = atomicAdd(&g.cnt[gq], __popc(mask_c));
         __syncthreads();
+        // Row role, first half: four lanes per row (lane = 16 part + row-in-wave), each takes a 32-column quarter of
+        // the row's 128-bit mask; part 0 reserves for all four.  The reservation's round trip is covered by the
+        // column role's appends; the row's own appends follow them.
+        const int part = lane >> 4;
+        unsigned int mm = 0u;
+        int base_r = 0, mine = 0, c1 = 0, c2 = 0, c3 = 0;
+        const int r_row = h * 64 + rl;
+        const int64_t gp = (int64_t)I * TB + r_row;
         if (roles & ROLE_ROWS) {
-            // four lanes per row (lane = 16 part + row-in-wave): each takes a 32-column quarter of the row's
-            // 128-bit mask; part 0 reserves for all four, the base comes back by a shuffle
-            const int part = lane >> 4;
             const unsigned long long m64 = rowmask[rl * 2 + (part >> 1)];
-            unsigned int mm = (unsigned int)(m64 >> (32 * (part & 1)));
+            mm = (unsigned int)(m64 >> (32 * (part & 1)));
             const int2 rg = h ? rgr1 : rgr0;
             mm &= ~run_mask(rg.x - (J * TB + 32 * part), rg.y - (J * TB + 32 * part));   // the row's own chromosome
-            const int mine = __popc(mm);
-            const int c1 = __shfl(mine, (lane & 15) + 16), c2 = __shfl(mine, (lane & 15) + 32), c3 = __shfl(mine, (lane & 15) + 48);
-            const int r = h * 64 + rl;
-            const int64_t gp = (int64_t)I * TB + r;
-            int base_r = 0;
+            mine = __popc(mm);
+            c1 = __shfl(mine, (lane & 15) + 16); c2 = __shfl(mine, (lane & 15) + 32); c3 = __shfl(mine, (lane & 15) + 48);
             if (part == 0 && mine + c1 + c2 + c3 > 0) base_r = atomicAdd(&g.cnt[gp], mine + c1 + c2 + c3);
-            base_r = __shfl(base_r, lane & 15);
-            const int c0 = __shfl(mine, lane & 15);
-            base_r += (part > 0 ? c0 : 0) + (part > 1 ? c1 : 0) + (part > 2 ? c2 : 0);
-            if (mm) {
-                const float nbr = nbPs[r];
-                unsigned long long *dst = g.list + gp * g.cap;
-                while (mm) {
-                    const int c = 32 * part + (__ffs((int)mm) - 1);
-                    mm &= mm - 1;
-                    const float key = fmaf(m2, D[c * LDT + rl], nbr + nbQs[c]);
-                    if (base_r < g.cap) dst[base_r] = pack_entry(key, J * TB + c);
-                    ++base_r;
-                }
-            }
         }
+        // Appends, two entries per trip (their LDS reads fly together)
         if (mask_c) {
             const float nbc = nbQs[x];
             unsigned long long *dst = g.list + gq * g.cap;
             while (mask_c) {
-                int rr = __ffs((int)mask_c) - 1;
+                const int rr0 = __ffs((int)mask_c) - 1;
                 mask_c &= mask_c - 1;
-                int l = q * 32 + rr, r = h * 64 + l;
-                float key = fmaf(m2, D[x * LDT + l], nbPs[r] + nbc);
-                if (base_c < g.cap) dst[base_c] = pack_entry(key, I * TB + r);
-                ++base_c;
+                const bool two = mask_c != 0u;
+                const int rr1 = two ? __ffs((int)mask_c) - 1 : rr0;
+                mask_c &= mask_c - 1;                                   // (0 stays 0)
+                const int l0 = q * 32 + rr0, l1 = q * 32 + rr1;
+                const float d0 = D[x * LDT + l0], d1 = D[x * LDT + l1];
+                const float n0 = nbPs[h * 64 + l0], n1 = nbPs[h * 64 + l1];
+                const float key0 = fmaf(m2, d0, n0 + nbc), key1 = fmaf(m2, d1, n1 + nbc);
+                if (base_c < g.cap) dst[base_c] = pack_entry(key0, I * TB + h * 64 + l0);
+                if (two && base_c + 1 < g.cap) dst[base_c + 1] = pack_entry(key1, I * TB + h * 64 + l1);
+                base_c += 2;
+            }
+        }
+        if (roles & ROLE_ROWS) {
+            base_r = __shfl(base_r, lane & 15);
+            const int c0 = __shfl(mine, lane & 15);
+            base_r += (part > 0 ? c0 : 0) + (part > 1 ? c1 : 0) + (part > 2 ? c2 : 0);
+            if (mm) {
+                const float nbr = nbPs[r_row];
+                unsigned long long *dst = g.list + gp * g.cap;
+                while (mm) {
+                    const int ca = 32 * part + (__ffs((int)mm) - 1);
+                    mm &= mm - 1;
+                    const bool two = mm != 0u;
+                    const int cb = two ? 32 * part + (__ffs((int)mm) - 1) : ca;
+                    mm &= mm - 1;
+                    const float d0 = D[ca * LDT + rl], d1 = D[cb * LDT + rl];
+                    const float n0 = nbQs[ca], n1 = nbQs[cb];
+                    const float key0 = fmaf(m2, d0, nbr + n0), key1 = fmaf(m2, d1, nbr + n1);
+                    if (base_r < g.cap) dst[base_r] = pack_entry(key0, J * TB + ca);
+                    if (two && base_r + 1 < g.cap) dst[base_r + 1] = pack_entry(key1, J * TB + cb);
+                    base_r += 2;
+                }
             }
         }
     }
@@ -425,9 +450,11 @@ __device__ __forceinline__ void gram_epilogue(const GramArgs &g, float *sm, floa
 // register-staged kernel is not available: the 16-byte chunk g of row r sits in slot g ^ ((r >> 2) & 3)
 // (swizzled on the SOURCE address and again on the fragment read), which keeps the sixteen rows a
 // ds_read_b128 group touches on distinct banks.  Two slabs of LDS (32 KB) + the dot tile's 35 KB aliasing
-// them: four workgroups per CU.  One barrier per slab: the barrier at the top of step s waits for slab s
-// (the compiler drains the DMA there) and tells everybody that slab s - 1's buffer may be refilled, the
-// DMA of slab s + 1 then runs under the MFMAs of slab s.
+// them: four workgroups per CU.  The loop is software pipelined: the fragments of k-step t + 1 are read from LDS
+// while the matrix cores work on step t (two fragment sets), across the slab boundary as well; the ONE barrier per
+// slab sits between the two k-steps of a slab -- there every wave has its reads of the slab back and its DMA of the
+// next slab landed (waited for explicitly: a bare s_barrier, __syncthreads()'s fence would add nothing), after it
+// the freed stage is refilled with the slab after next.
 __global__ __launch_bounds__(256, 4) void k_gram_glds(GramArgs g) {
     __shared__ __attribute__((aligned(16))) float sm[128 * LDT + 256 + 4 * TB];   // dot tile + row masks + bounds / thresholds
     float *D = sm;
@@ -445,16 +472,6 @@ __global__ __launch_bounds__(256, 4) void k_gram_glds(GramArgs g) {
     const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
     const int li = lane & 31, lh = lane >> 5;
     const float m2 = *g.m2;
-    if (tid < TB) {
-        int64_t gp = (int64_t)I * TB + tid;
-        nbPs[tid] = g.nbP[gp];
-        thPs[tid] = g.thr[gp];
-    } else {
-        int c = tid - TB;
-        int64_t gq = (int64_t)J * TB + c;
-        nbQs[c] = g.nbQ[gq];
-        thQs[c] = g.thr[gq];
-    }
     // DMA sources: wave w fills rows [32 w, 32 w + 32) of A and of B, 16 rows per instruction; lane l
     // lands in row (l >> 2), slot (l & 3) and therefore fetches chunk (l & 3) ^ ((row >> 2) & 3)
     const float *srcA[2], *srcB[2];
@@ -462,15 +479,17 @@ __global__ __launch_bounds__(256, 4) void k_gram_glds(GramArgs g) {
     for (int j = 0; j < 2; ++j) {
         const int row = w * 32 + j * 16 + (lane >> 2);
         const int gch = (lane & 3) ^ ((row >> 2) & 3);
-        srcA[j] = g.P + ((int64_t)I * TB + row) * g.ld + gch * 4;
-        srcB[j] = g.Q + ((int64_t)J * TB + row) * g.ld + gch * 4;
+        // (the panel's block of slab 0: a16_index in 32-bit words)
+        srcA[j] = g.P + (int64_t)I * TB * g.ld + row * GL_ROW + gch * 4;
+        srcB[j] = g.Q + (int64_t)J * TB * g.ld + row * GL_ROW + gch * 4;
     }
+    constexpr int slab_stride = TB * GL_ROW;      // the next slab's block
     auto dma = [&](int slab, int stage) {
         float *base = sm + stage * GL_STAGE + (w * 32) * GL_ROW;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            __builtin_amdgcn_global_load_lds((glb_void_t *)(srcA[j] + slab * GL_ROW), (lds_void_t *)(base + j * 16 * GL_ROW), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_void_t *)(srcB[j] + slab * GL_ROW),
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(srcA[j] + slab * slab_stride), (lds_void_t *)(base + j * 16 * GL_ROW), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(srcB[j] + slab * slab_stride),
                                              (lds_void_t *)(base + TB * GL_ROW + j * 16 * GL_ROW), 16, 0, 0);
         }
     };
@@ -492,27 +511,51 @@ __global__ __launch_bounds__(256, 4) void k_gram_glds(GramArgs g) {
         offB[t][1] = (TB + rb1) * GL_ROW + (((2 * t + lh) ^ ((rb1 >> 2) & 3)) << 2);
     }
     const int nslab = g.nslab32;          // 32-sample slabs
+    f16x8 fa[2][2], fb[2][2];
+    auto rd = [&](const float *st, int t) {
+        fa[t][0] = *(const f16x8 *)&st[offA[t][0]]; fa[t][1] = *(const f16x8 *)&st[offA[t][1]];
+        fb[t][0] = *(const f16x8 *)&st[offB[t][0]]; fb[t][1] = *(const f16x8 *)&st[offB[t][1]];
+    };
+    auto mm = [&](int t) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[t][0], fb[t][0], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[t][0], fb[t][1], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[t][1], fb[t][0], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[t][1], fb[t][1], acc[1][1], 0, 0, 0);
+    };
     dma(0, 0);
-    __builtin_amdgcn_s_setprio(2);
-    for (int slab = 0; slab < nslab; ++slab) {
-        // the LDS this wave reads below was filled by OTHER waves' DMA: every wave drains its own DMA before the
-        // barrier (explicitly: a barrier alone need not wait for vmcnt)
-        __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
-        __syncthreads();                  // slab `slab` has landed; the other stage is free
-        if (slab + 1 < nslab) dma(slab + 1, (slab + 1) & 1);
-        const float *st = sm + (slab & 1) * GL_STAGE;
-        const int nt = slab + 1 < nslab ? 2 : g.last_steps32;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if (t >= nt) break;
-            const f16x8 a0 = *(const f16x8 *)&st[offA[t][0]], a1 = *(const f16x8 *)&st[offA[t][1]];
-            const f16x8 b0 = *(const f16x8 *)&st[offB[t][0]], b1 = *(const f16x8 *)&st[offB[t][1]];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
-        }
+    // (the bounds and thresholds of the tile's rows and columns: their loads fly with the first slab)
+    if (tid < TB) {
+        int64_t gp = (int64_t)I * TB + tid;
+        nbPs[tid] = g.nbP[gp];
+        thPs[tid] = g.thr[gp];
+    } else {
+        int c = tid - TB;
+        int64_t gq = (int64_t)J * TB + c;
+        nbQs[c] = g.nbQ[gq];
+        thQs[c] = g.thr[gq];
     }
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    if (nslab > 1) dma(1, 1);
+    rd(sm, 0);
+    rd(sm, 1);
+    __builtin_amdgcn_s_setprio(2);
+    for (int slab = 0; slab + 1 < nslab; ++slab) {
+        mm(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0070);   // my reads of slab `slab` are back, my DMA of slab + 1 has landed
+        __builtin_amdgcn_s_barrier();
+        if (slab + 2 < nslab) dma(slab + 2, slab & 1);
+        const float *st = sm + ((slab + 1) & 1) * GL_STAGE;
+        rd(st, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(1);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(st, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    mm(0);
+    if (g.last_steps32 > 1) mm(1);
     __builtin_amdgcn_s_waitcnt(0x0070);   // nothing of this wave in flight into the LDS the dot tile is about to alias
     gram_epilogue(g, sm, D, nbPs, nbQs, thPs, thQs, acc, I, J, roles, m2, tid, lane, w, wr, wc, li, lh);
 }
@@ -609,12 +652,14 @@ __global__ __launch_bounds__(256, 4) void k_gram_thr16(const unsigned short *__r
     if (tid < TB) nbPs[tid] = nbP[(int64_t)I * TB + tid];
     else nbQs[tid - TB] = nbQ[(int64_t)J * TB + tid - TB];
     const int lrow = tid >> 3, lcol = (tid & 7) * 8;   // 8 bf16 = 16 bytes per thread and row
-    const unsigned short *Pg = P16 + ((int64_t)I * TB + lrow) * ld16 + lcol;
+    // P is the blocked image (a16_index: a 64-sample slab here is two of its 32-sample blocks), Q the sampled rows
+    // as plain rows of ld16 halfs
+    const unsigned short *Pg = P16 + a16_index((int64_t)I * TB + lrow, lcol, ld16);
     const unsigned short *Qg = Q16 + ((int64_t)J * TB + lrow) * ld16 + lcol;
     f32x4 pa[4], qb[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        pa[p] = *(const f32x4 *)(Pg + (int64_t)p * 32 * ld16);
+        pa[p] = *(const f32x4 *)(Pg + p * 32 * 32);
         qb[p] = *(const f32x4 *)(Qg + (int64_t)p * 32 * ld16);
     }
     f32x16 acc[2][2];
@@ -637,7 +682,7 @@ __global__ __launch_bounds__(256, 4) void k_gram_thr16(const unsigned short *__r
             const int64_t ko = (int64_t)(slab + 1 < nslab ? slab + 1 : slab) * 64;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                pa[p] = *(const f32x4 *)(Pg + ko + (int64_t)p * 32 * ld16);
+                pa[p] = *(const f32x4 *)(Pg + ko * TB + p * 32 * 32);      // 64 samples on = two blocks of TB x 32
                 qb[p] = *(const f32x4 *)(Qg + ko + (int64_t)p * 32 * ld16);
             }
         }
@@ -2292,7 +2337,7 @@ int wc_newref_collect_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int64_t
     ctx->last_stats[3] = st.n_sample_cols;
     if (st.tiles1_n == 0) return WC_OK;
     GramArgs g{};
-    // the float16 image the threshold estimate used: rows of k_pad16 halfs, 32 samples per slab
+    // the float16 image the threshold estimate used (blocked: a16_index), 32 samples per slab
     g.P = g.Q = st.a16.as<float>();
     g.ld = st.k_pad16 / 2;
     g.m2 = st.m2.as<float>();
