@@ -257,6 +257,10 @@ def test_bench_line_is_complete_on_one_gpu():
     test = line["test"]
     assert test["value"] > 0 and 0 < test["roofline"]["frac"] <= 1.0
     assert test["single_sample_latency_ms"] < test["ms_per_batch"]
+    for leg in (test, extra["test_50kb"]):          # one batch in flight and several, the better one on top
+        one, two = leg["one_batch_in_flight"], leg["pipelined"]
+        assert one["ms_per_batch"] > 0 and two["ms_per_batch"] > 0 and two["batches_timed"] >= 8
+        assert leg["ms_per_batch"] == min(one["ms_per_batch"], two["ms_per_batch"])
     assert test["whole_job_1000_samples"]["samples_per_s"] > test["value"] * 0.8       # the big call amortises the fixed costs
     assert set(line["stages_ms"]) >= {"start->prepared", "prepared->thresholds", "thresholds->collected",
                                       "collected->picked", "picked->rescored", "rescored->finished"}

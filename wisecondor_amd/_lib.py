@@ -165,6 +165,21 @@ def ptr(arr):
 _contexts = {}
 
 
+def new_context(device=0):
+    """A further wc_ctx on `device` with its own scratch, streams and error state (distributed.TestPipeline keeps
+    several batches in flight with one each); the caller destroys it with destroy_context."""
+    lib = load()
+    h = lib.wc_create(device)
+    if not h:
+        raise WisecondorHipError("wc_create(%d) failed: %s" % (device, lib.wc_last_error().decode()))
+    return h
+
+
+def destroy_context(handle):
+    if handle:
+        load().wc_destroy(handle)
+
+
 def context(device=0):
     """One wc_ctx per device, created lazily; fails loudly without a GPU."""
     if device not in _contexts:

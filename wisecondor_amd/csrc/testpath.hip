@@ -4320,7 +4320,7 @@ wc_reference *wc_reference_create(wc_ctx *ctx, const int32_t *indexes, const dou
         return nullptr;
     }
     wc_reference *ref = new wc_reference();
-    static unsigned long long next_serial = 0;
+    static std::atomic<unsigned long long> next_serial{0};
     ref->serial = ++next_serial;
     ref->ctx = ctx;
     ref->B = n_bins;

@@ -122,10 +122,10 @@ class Reference(object):
     """
 
     def __init__(self, indexes, distances, chromosome_sizes, masked_sizes, mask, pca_mean,
-                 pca_components, binsize=None, cutoff=None, device=0):
+                 pca_components, binsize=None, cutoff=None, device=0, ctx=None):
         lib = _lib.load()
         self.device = device
-        self.ctx = _lib.context(device)
+        self.ctx = ctx if ctx is not None else _lib.context(device)     # ctx: a context of _lib.new_context
         self.binsize = binsize
         self.indexes = np.ascontiguousarray(indexes, dtype=np.int32)
         self.distances = np.ascontiguousarray(distances, dtype=np.float64)
@@ -154,6 +154,12 @@ class Reference(object):
         binsize = npz['binsize'].item() if hasattr(npz['binsize'], 'item') else npz['binsize']
         return cls(npz['indexes'], npz['distances'], npz['chromosome_sizes'], npz['masked_sizes'],
                    npz['mask'], npz['pca_mean'], npz['pca_components'], binsize=binsize, device=device)
+
+    def clone(self, ctx):
+        """The same reference in another context of the same device (its own device copy and user lists)."""
+        return Reference(self.indexes, self.distances, self.chromosome_sizes, self.masked_sizes, self.mask,
+                         self.pca_mean, self.pca_components, binsize=self.binsize, cutoff=self.cutoff,
+                         device=self.device, ctx=ctx)
 
     def close(self):
         if getattr(self, "handle", None):
