@@ -1152,6 +1152,12 @@ struct SdShared {
     long long b_A[SD_MAX_BOUND + 1];      // map of the segment that ENDS before boundary k (k = n: the tail)
     int b_H0[SD_MAX_BOUND + 1], b_H1[SD_MAX_BOUND + 1], b_e[SD_MAX_BOUND + 1];
     double b_x[SD_MAX_BOUND + 1];
+    // boundaries as the threads meet them (unordered): owner thread, its how-manieth, the map of the thread's own
+    // terms since its previous boundary (or its start), the boundary term, the binade after it
+    long long r_A[SD_MAX_BOUND];
+    int r_H0[SD_MAX_BOUND], r_H1[SD_MAX_BOUND], r_e[SD_MAX_BOUND], r_tid[SD_MAX_BOUND], r_j[SD_MAX_BOUND];
+    double r_x[SD_MAX_BOUND];
+    int s_nrec;
     int s_bad;
     double sh_wp[16];
     int sh_wc[16];
@@ -1178,7 +1184,7 @@ __device__ inline void sd_fast_block(const int64_t i, SdShared *sm, const double
     const int tid = threadIdx.x;
     const int per = (int)((B + 1023) / 1024);
     if (per > PER_MAX) { if (tid == 0) fail[i] = 1; return; }
-    if (tid == 0) s_bad = 0;
+    if (tid == 0) { s_bad = 0; sm->s_nrec = 0; }
     const int64_t lo = (int64_t)tid * per, hi = lo + per < B ? lo + per : B;
     constexpr int NREG = REG > 0 ? REG : 1;
     double xr[NREG];
@@ -1244,7 +1250,6 @@ __device__ inline void sd_fast_block(const int64_t i, SdShared *sm, const double
     // thread's first boundary, `tail` = composition after its last boundary
     SdMap ident; ident.A = 0; ident.H0 = 0; ident.H1 = 0;
     SdMap run = ident;
-    SdMap head = ident;
     int n_bound = 0;
     for_each([&](double raw_v) {
         const double xv = raw_v != raw_v ? 0.0 : raw_v;      // NaN: not part of the sum
@@ -1260,13 +1265,20 @@ __device__ inline void sd_fast_block(const int64_t i, SdShared *sm, const double
             }
         }
         if (boundary) {
-            if (n_bound == 0) head = run;
+            // recorded once, here: its place among all boundaries is known after the scan below (a second walk
+            // that published them in order cost as much as this one)
+            const int slot = atomicAdd(&sm->s_nrec, 1);
+            if (slot < SD_MAX_BOUND) {
+                sm->r_tid[slot] = tid; sm->r_j[slot] = n_bound;
+                sm->r_A[slot] = run.A; sm->r_H0[slot] = run.H0; sm->r_H1[slot] = run.H1;
+                sm->r_x[slot] = xv;
+                sm->r_e[slot] = sd_exponent(after);       // the exponent the following segment assumes
+            }
             ++n_bound;
             run = ident;
         }
         before = after;
     });
-    if (n_bound == 0) head = run;
     // A thread's walk ends on its own sequentially rounded sum, its successor starts from the scan's value of
     // the same prefix: different roundings.  If the two sit on opposite sides of a power of two, the junction
     // is a binade boundary nobody recorded (the maps left and right of it assume different units): the serial
@@ -1316,67 +1328,85 @@ __device__ inline void sd_fast_block(const int64_t i, SdShared *sm, const double
     }
     const int n_total_bound = sh_nb[1023];
     if (n_total_bound > SD_MAX_BOUND) { if (tid == 0) fail[i] = 1; return; }
-    // carry-in of this thread: the open segment's composition over all earlier threads
-    SdMap carry = ident;
-    int k0 = 0;                                     // boundaries before this thread
-    if (tid > 0) { carry.A = sh_A[tid - 1]; carry.H0 = sh_H0[tid - 1]; carry.H1 = sh_H1[tid - 1]; k0 = sh_nb[tid - 1]; }
-    // second walk: at every boundary, publish the map of the segment that ends just before it
-    {
-        SdMap seg = carry;
-        double bef = tid > 0 ? sh_p[tid - 1] : 0.0;
-        int k = k0;
-        for_each([&](double raw_v) {
-            const double xv = raw_v != raw_v ? 0.0 : raw_v;
-            const double after = bef + xv;
-            bool boundary = false;
-            if (xv > 0.0) {
-                if (bef <= 0.0) boundary = true;
-                else {
-                    const int eb = sd_exponent(bef), ea = sd_exponent(after);
-                    if (eb != ea) boundary = true;
-                    else if (!(eb < -900 || eb > 50)) seg = sd_compose(seg, sd_element_map(xv, eb));
-                }
+    // every recorded boundary to its place: boundary j of thread t is number (boundaries before t) + j; the map of
+    // the segment that ends just before it is the thread's own terms since its previous boundary, for its first
+    // one behind the open segment of all earlier threads (the scan's value at t - 1)
+    if (tid < n_total_bound) {
+        const int t = sm->r_tid[tid], j = sm->r_j[tid];
+        SdMap m; m.A = sm->r_A[tid]; m.H0 = sm->r_H0[tid]; m.H1 = sm->r_H1[tid];
+        int k = j;
+        if (t > 0) {
+            k += sh_nb[t - 1];
+            if (j == 0) {
+                SdMap carry; carry.A = sh_A[t - 1]; carry.H0 = sh_H0[t - 1]; carry.H1 = sh_H1[t - 1];
+                m = sd_compose(carry, m);
             }
-            if (boundary) {
-                b_A[k] = seg.A; b_H0[k] = seg.H0; b_H1[k] = seg.H1;
-                b_x[k] = xv;
-                b_e[k] = sd_exponent(after);          // the exponent the following segment assumes
-                ++k;
-                seg = ident;
-            }
-            bef = after;
-        });
-        if (tid == 1023) { b_A[n_total_bound] = seg.A; b_H0[n_total_bound] = seg.H0; b_H1[n_total_bound] = seg.H1; }
+        }
+        b_A[k] = m.A; b_H0[k] = m.H0; b_H1[k] = m.H1;
+        b_x[k] = sm->r_x[tid];
+        b_e[k] = sm->r_e[tid];
     }
+    // the tail: the open segment through the last thread
+    if (tid == 1023) { b_A[n_total_bound] = sh_A[1023]; b_H0[n_total_bound] = sh_H0[1023]; b_H1[n_total_bound] = sh_H1[1023]; }
     __syncthreads();
-    if (tid == 0) {
+    // The fold over the boundaries is a dependent chain of ~n_total_bound steps: the first wave runs it with every
+    // lane computing the same values (no divergence), the records of the boundaries in REGISTERS -- lane l holds
+    // record l, a step reads it with v_readlane -- instead of five dependent LDS reads per step (records beyond 63
+    // are read from LDS)
+    if (tid < 64) {
+        const int lane = tid;
+        const bool mine = lane <= n_total_bound;
+        const long long rA = mine ? b_A[lane] : 0;
+        const int rH0 = mine ? b_H0[lane] : 0, rH1 = mine ? b_H1[lane] : 0;
+        const double rx = lane < n_total_bound ? b_x[lane] : 0.0;
+        const int re = lane < n_total_bound ? b_e[lane] : 0;
+        auto rl = [](int v, int src) { return __builtin_amdgcn_readlane(v, src); };
         bool ok = !s_bad;
         double sum = 0.0;
         int e_cur = 0;
         for (int k = 0; k <= n_total_bound && ok; ++k) {
+            long long A;
+            int H0, H1, eb = 0;
+            double xb = 0.0;
+            if (k < 64) {
+                const unsigned int alo = (unsigned int)rl((int)(unsigned int)(rA & 0xFFFFFFFFll), k);
+                const int ahi = rl((int)(rA >> 32), k);
+                A = ((long long)ahi << 32) | (long long)alo;
+                H0 = rl(rH0, k); H1 = rl(rH1, k);
+                const long long xbits = __double_as_longlong(rx);
+                const unsigned int xlo = (unsigned int)rl((int)(unsigned int)(xbits & 0xFFFFFFFFll), k);
+                const int xhi = rl((int)(xbits >> 32), k);
+                xb = __longlong_as_double(((long long)xhi << 32) | (long long)xlo);
+                eb = rl(re, k);
+            } else {
+                A = b_A[k]; H0 = b_H0[k]; H1 = b_H1[k];
+                if (k < n_total_bound) { xb = b_x[k]; eb = b_e[k]; }
+            }
             // the segment before boundary k (k = 0: before the first positive term, the identity)
             if (k > 0 || n_total_bound == 0) {
-                const long long A = b_A[k];
-                if (A != 0 || b_H0[k] != 0 || b_H1[k] != 0) {
+                if (A != 0 || H0 != 0 || H1 != 0) {
                     if (!(sum > 0.0) || sd_exponent(sum) != e_cur) { ok = false; break; }
-                    const double u = ldexp(1.0, e_cur - 52);
-                    const long long S = (long long)(sum / u);            // exact: sum is a multiple of u below 2^53 u
-                    const long long S2 = S + A + ((S & 1) ? b_H1[k] : b_H0[k]);
-                    if (S2 >= (1ll << 53)) { ok = false; break; }
-                    sum = (double)S2 * u;
+                    // in units of u = 2^(e_cur - 52) the sum IS its 53-bit significand (it is a normal number of
+                    // that binade): integer arithmetic on the bits, no scaling and no conversions on this chain
+                    const long long S = (__double_as_longlong(sum) & 0xFFFFFFFFFFFFFll) | (1ll << 52);
+                    const long long S2 = S + A + ((S & 1) ? H1 : H0);
+                    if (A < 0 || A >= (1ll << 53) || S2 >= (1ll << 53)) { ok = false; break; }
+                    sum = __longlong_as_double(((long long)(e_cur + 1023) << 52) | (S2 & 0xFFFFFFFFFFFFFll));
                 }
             }
             if (k < n_total_bound) {
-                sum = sum + b_x[k];                                     // the boundary term: a plain float64 add
-                if (!(sum > 0.0) || sd_exponent(sum) != b_e[k]) { ok = false; break; }
-                e_cur = b_e[k];
+                sum = sum + xb;                                         // the boundary term: a plain float64 add
+                if (!(sum > 0.0) || sd_exponent(sum) != eb) { ok = false; break; }
+                e_cur = eb;
             }
         }
-        if (ok) {
-            out[i] = sum / (double)total_cnt;
-            if (out2) out2[i] = sum / (double)total_cnt;
+        if (tid == 0) {
+            if (ok) {
+                out[i] = sum / (double)total_cnt;
+                if (out2) out2[i] = sum / (double)total_cnt;
+            }
+            fail[i] = ok ? 0 : 1;                  // 1: the serial kernel computes this sample
         }
-        fail[i] = ok ? 0 : 1;                      // 1: the serial kernel computes this sample
     }
 }
 
