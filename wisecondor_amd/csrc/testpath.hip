@@ -1902,8 +1902,8 @@ constexpr int FAR2 = 512;           // window lengths from here on are bounded p
 // first_chunk, first_chunk + chunk_stride, ...; returns (to every thread) 0 when every window of
 // those rows stays below the threshold, 1 when some window could reach it or the job is too long
 // for the staged block table.
-__device__ inline int quiet_body(const Job job, const Region *__restrict__ regions, const double *__restrict__ prefix,
-                                 const double *__restrict__ rs, const double *__restrict__ reg_abs, double thr,
+__device__ inline int quiet_body(const Job job, const Region rg, const double abs_sum, const double *__restrict__ prefix,
+                                 const double *__restrict__ rs, double thr,
                                  const double *__restrict__ tmin, const double *__restrict__ tmax,
                                  unsigned long long *__restrict__ work, int first_chunk, int chunk_stride,
                                  long long tab_k0 = 0) {     // tmin / tmax start at end block tab_k0 (a region-local table)
@@ -1913,12 +1913,13 @@ __device__ inline int quiet_body(const Job job, const Region *__restrict__ regio
     __shared__ int s_work[Q_WORK];                // undecided (row, end block) pairs
     __shared__ double s_tmx[Q_BLOCKS], s_tmn[Q_BLOCKS];   // block maxima / minima the job touches
     __shared__ double s_pn[2][2 * ROWS_HALF];             // rows of a side and their near ends
+    __shared__ double s_b8x[2][16], s_b8n[2][16];         // maxima / minima of every eight of them
     const int tid = threadIdx.x;
     const bool on = tid < 256;                    // larger workgroups: the first 256 threads work, all keep the barriers
     const int L = job.hi - job.lo, half = (L + 1) / 2;
-    const double eps = window_eps(regions[job.region].n, reg_abs[job.region]);
+    const double eps = window_eps(rg.n, abs_sum);
     const double T = thr - eps, T2c = T * T * (1.0 - 3e-6);   // a window below T in magnitude cannot reach thr
-    const long long base = regions[job.region].off + job.region + job.lo;    // absolute index of the job's P[0]
+    const long long base = rg.off + job.region + job.lo;                      // absolute index of the job's P[0]
     const long long a_hi = base + L;                                          // absolute index of the last end
     const long long k_last = a_hi / QB;
     const long long k_base = base / QB;
@@ -1940,7 +1941,16 @@ __device__ inline int quiet_body(const Job job, const Region *__restrict__ regio
             const int side = tid >> 7, t = tid & 127;
             const int xr_lo = side == 0 ? chunk * ROWS_HALF : L - 1 - (chunk * ROWS_HALF + 63);
             const long long ai = base + (xr_lo < 0 ? 0 : xr_lo) + t;
-            s_pn[side][t] = ai <= a_hi ? prefix[ai] : 0.0;
+            const bool valid = ai <= a_hi;
+            const double pv = valid ? prefix[ai] : 0.0;
+            s_pn[side][t] = pv;
+            // minimum and maximum of every eight staged entries (entries past the job's end take no part)
+            double mx8 = valid ? pv : -INFINITY, mn8 = valid ? pv : INFINITY;
+            for (int o = 1; o < 8; o <<= 1) {
+                mx8 = fmax(mx8, __shfl_xor(mx8, o));
+                mn8 = fmin(mn8, __shfl_xor(mn8, o));
+            }
+            if ((t & 7) == 0) { s_b8x[side][t >> 3] = mx8; s_b8n[side][t >> 3] = mn8; }
         }
         __syncthreads();
         bool found = false;
@@ -1967,13 +1977,38 @@ __device__ inline int quiet_body(const Job job, const Region *__restrict__ regio
             long long y_near = k_far * QB - 1;
             if (y_near > a_hi) y_near = a_hi;
             const int near = live ? (int)(y_near - ax) : 0;            // <= 63
-            if (w == 0 && live) evals += near + (int)(k_last >= k_far ? k_last - k_far + 1 : 0);
-#pragma unroll 4
-            for (int len = 1 + w; len <= 2 * QB; len += 4) {
+            // ... the ends in the row's own eight-entry block and the next one (8-15 window lengths) by value,
+            // the eight-entry blocks after them up to y_near by the same bound as the far blocks (a block may reach
+            // past y_near: a superset, still a bound); a block the bound does not settle is evaluated on the spot
+            // -- rare at these lengths, the bound is within a factor ~1.5 of the values
+            const int b_own = xo >> 3;
+            const int exact = 8 * (b_own + 2) - 1 - xo;                  // 8..15
+            const int n_exact = near < exact ? near : exact;
+            if (w == 0 && live) evals += n_exact + (near > exact ? (near - exact + 7) / 8 : 0) +
+                                         (int)(k_last >= k_far ? k_last - k_far + 1 : 0);
+#pragma unroll
+            for (int len = 1 + w; len <= 15; len += 4) {
                 const double r = rs[len];
-                if (len <= near) {
+                if (len <= n_exact) {
                     const double v = (s_pn[side][xo + len] - px) * r;
                     if (!(fabs(v) + eps < thr)) found = true;
+                }
+            }
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) {
+                const int bi = b_own + 2 + w + 4 * jb;                   // ends 8 bi .. 8 bi + 7 of the staged stretch
+                if (live && 8 * bi <= xo + near) {
+                    const double t2 = T2c * (double)(8 * bi - xo);       // the shortest window of the pair
+                    const double up = s_b8x[side][bi] - px, dn = s_b8n[side][bi] - px;
+                    if ((up > 0.0 && up * up >= t2) || (dn < 0.0 && dn * dn >= t2)) {
+                        for (int e = 0; e < 8; ++e) {
+                            const int len = 8 * bi + e - xo;
+                            if (len <= near) {
+                                const double v = (s_pn[side][xo + len] - px) * rs[len];
+                                if (!(fabs(v) + eps < thr)) found = true;
+                            }
+                        }
+                    }
                 }
             }
             // far ends, one bound per block; the four waves take every fourth block.  The bound
@@ -2030,19 +2065,30 @@ __global__ __launch_bounds__(256) void k_seg_quiet(Job *__restrict__ jobs, int n
                                                    const double *__restrict__ tmin,
                                                    const double *__restrict__ tmax,
                                                    unsigned long long *__restrict__ work,
-                                                   const int *__restrict__ n_jobs_dev) {
+                                                   const int *__restrict__ n_jobs_dev, int n_regions) {
     // gridDim.x workgroups share a job: each takes the row blocks blockIdx.x, + gridDim.x, ...
     // (many jobs: one workgroup per job, the block table is staged once; few jobs: all row
     // blocks in parallel)
     const int j = blockIdx.y, tid = threadIdx.x;
     if (n_jobs_dev) n_jobs = *n_jobs_dev < n_jobs ? *n_jobs_dev : n_jobs;   // device-side round loop: n_jobs is the grid's bound
     if (j >= n_jobs) return;
+    // In a first round job j IS region j: the region's words are requested together with the job instead of after
+    // it (a workgroup lives ~7 us here, a dependent load is more than one of them)
+    const bool guess = j < n_regions;
+    Region rg = guess ? regions[j] : Region{0, 0, 0};
+    double abs_sum = guess ? reg_abs[j] : 0.0;
+    int flag = guess ? reg_flag[j] : 0;
     const Job job = jobs[j];
     const int L = job.hi - job.lo, half = (L + 1) / 2;
     if (L <= 0 || (int)blockIdx.x * ROWS_HALF >= half) return;
-    if (!reg_flag[job.region]) return;            // non-finite region: classify sends it to the brute path
+    if (!guess || job.region != j) {
+        rg = regions[job.region];
+        abs_sum = reg_abs[job.region];
+        flag = reg_flag[job.region];
+    }
+    if (!flag) return;                            // non-finite region: classify sends it to the brute path
     if (job.pad) return;                          // a sibling workgroup already found a window
-    if (quiet_body(job, regions, prefix, rs, reg_abs, thr, tmin, tmax, work, blockIdx.x, gridDim.x) && tid == 0)
+    if (quiet_body(job, rg, abs_sum, prefix, rs, thr, tmin, tmax, work, blockIdx.x, gridDim.x) && tid == 0)
         jobs[j].pad = 1;
 }
 
@@ -2626,8 +2672,8 @@ __global__ __launch_bounds__(64 * NW) void k_seg_search(const Job *__restrict__ 
     const Job job = jobs[j];
     const int L = job.hi - job.lo, half = (L + 1) / 2;
     if (L <= 0 || chunk * ROWS_HALF >= half) return;
+    if (certified && !job.pad) return;  // certified quiet by k_seg_quiet (most workgroups of a batch: before the next load)
     if (!reg_flag[job.region]) return;  // non-finite region: exact brute-force path
-    if (certified && !job.pad) return;  // certified quiet by k_seg_quiet
     const double *Pg = prefix + regions[job.region].off + job.region + job.lo;   // Pg[0..L]
     const double *P = Pg;
     if (PLDS) {
@@ -4093,6 +4139,9 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
         // about 16 384 workgroups in all: one per job when there are many jobs, every row block of a job in
         // parallel when there are few
         const unsigned per_job = (unsigned)std::min<int64_t>(max_chunks, std::max<int64_t>(1, 16384 / n_jobs));
+        // (the certificate stages a job's block table per workgroup: half as many, each with two row blocks, measured
+        // 75 -> 61 us at 128 x 250 kb; the bound sweep loses with fewer)
+        const unsigned per_job_quiet = (unsigned)std::min<int64_t>(max_chunks, std::max<int64_t>(1, 8192 / n_jobs));
         if (bound_path) {
             if ((rc = ts.cbound.reserve(sizeof(ChunkBound) * n_jobs * max_chunks))) return rc;
             if ((rc = ts.cuts.reserve(sizeof(unsigned long long) * 2 * n_jobs))) return rc;
@@ -4110,11 +4159,11 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
         if (certify) {
             // about 16 384 workgroups in all: one per job when there are many jobs, every row block
             // of a job in parallel when there are few
-            hipLaunchKernelGGL(k_seg_quiet, dim3(per_job, (unsigned)n_jobs), dim3(256), 0, stream, cur, (int)n_jobs, regions_dev,
+            hipLaunchKernelGGL(k_seg_quiet, dim3(per_job_quiet, (unsigned)n_jobs), dim3(256), 0, stream, cur, (int)n_jobs, regions_dev,
                                (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
                                (const double *)ts.reg_abs.as<double>(), (const int *)ts.reg_flag.as<int>(), thr,
                                (const double *)ts.tmin.as<double>(), (const double *)ts.tmax.as<double>(), work,
-                               (const int *)nullptr);
+                               (const int *)nullptr, (int)n_regions);
         }
         {
             const bool plds = max_n + 1 <= 6144;      // the longest region's prefix slice fits 48 KB of LDS
