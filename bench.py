@@ -692,11 +692,11 @@ def main():
     thr = float(zThreshold([int(v) for v in inp["masked_bins"]], 1000, None))
     counts_h = wt.samples_to_counts(inp["tests"], inp["chrom_bins"])
     tb = distributed.TestBatch(reference, torch.from_numpy(counts_h).to(dev), thr, max_calls=256)
-    for _ in range(max(1, args.warmup // 2)):
+    for _ in range(max(3, args.warmup // 2)):
         tb.run()
     sync_all()
     t0 = time.perf_counter()
-    test_steps = max(1, args.steps // 4)
+    test_steps = max(10, args.steps // 2)
     for _ in range(test_steps):
         tb.run()
     sync_all()
@@ -873,14 +873,14 @@ def main():
             thr5 = float(zThreshold([int(v) for v in inp5["masked_bins"]], 1000, None))
             counts5 = torch.from_numpy(wt.samples_to_counts(inp5["tests"], inp5["chrom_bins"])).to(dev)
             tb5 = distributed.TestBatch(ref5, counts5[:125].contiguous(), thr5, max_calls=256)
-            for _ in range(2):
+            for _ in range(3):
                 tb5.run()
             sync_all()
             t0 = time.perf_counter()
-            for _ in range(5):
+            for _ in range(10):
                 tb5.run()
             sync_all()
-            t5 = max_over_ranks(time.perf_counter() - t0) / 5
+            t5 = max_over_ranks(time.perf_counter() - t0) / 10
             pipe5 = distributed.TestPipeline(ref5, thr5, depth=PIPE_DEPTH, max_calls=256)
             b5 = [tb5.counts] * (6 * PIPE_DEPTH)
             pipe5.run(b5[:PIPE_DEPTH])

@@ -219,3 +219,31 @@ def test_rccl_collectives_in_a_world_of_one(tmp_path):
         assert np.array_equal(got["idx_%s" % mode], idx1), mode
         assert np.array_equal(got["dst_%s" % mode].view(np.int64), dst1.view(np.int64)), mode
     assert str(got["mode_None"]) in ("tiles", "rows")          # the calibration ran over RCCL and decided
+
+
+def test_world_of_three_emulated_in_this_process():
+    """Every rank's share of a three-rank job run one after the other in THIS process (bench.py's
+    emulate_world_newref: thresholds of the band, the tile deal, export of the lists for foreign rows, import at
+    the owner, finish of the band; and the row-band mode): both modes must reproduce the single-rank pass -- the
+    same exchange kernels as the multi-process tests above, visible to a profiler of this process -- and the launch
+    floor measurement the latency object of the bench line uses."""
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    from wisecondor_amd import _lib, synth, distributed
+    data, bins, sums = synth.corrected_matrix(1000000, 16, seed=3)
+    X = torch.from_numpy(data).cuda()
+    ctx = _lib.context(0)
+    job = distributed.NewrefJob(ctx, X, bins, 100, _lib.SUM_PAIRWISE)
+    idx, dst = job.run()
+    torch.cuda.synchronize()
+    em = bench.emulate_world_newref(ctx, X, bins, 100, _lib.SUM_PAIRWISE, 3, idx, dst)
+    for mode in ("tiles", "rows"):
+        assert em[mode]["results_equal_single_rank"] is True, mode
+        assert len(em[mode]["per_rank_ms"]) == 3
+    floor = np.zeros(2)
+    _lib.check(_lib.load().wc_launch_floor_us(ctx, torch.cuda.current_stream().cuda_stream, 8, 10, _lib.ptr(floor)))
+    assert 0.0 < floor[0] < 1e4

@@ -213,14 +213,15 @@ def test_mineffectsize_counting_equals_sorted_insert_on_long_regions(wt, monkeyp
     assert same_bits(whole_a, whole_b)
 
 
-def test_mineffectsize_on_many_regions(wt, monkeypatch):
+@pytest.mark.parametrize("longest", [1500, 6500])
+def test_mineffectsize_on_many_regions(wt, monkeypatch, longest):
     """A round with many jobs (the four-wave forms of the masked value search, with and without the prefix slice in
     LDS): 180 regions of ~1 500 bins and one of 6 500 with the median filter on, counting kernel against the sorted-insert kernel, and the short regions among them against
     the oracle's fillTriMin."""
     rng = np.random.RandomState(78)
     zs, rs = [], []
     for i in range(180):
-        n = 6500 if i == 1 else (1500 if i % 30 else 90)        # one region beyond the LDS-staged prefix slice
+        n = longest if i == 1 else (1500 if i % 30 else 90)    # 6 500: one region beyond the LDS-staged prefix slice
         z = rng.standard_normal(n)
         r = np.round(1.0 + 0.03 * rng.standard_normal(n), 3)
         if i % 3 == 0:
