@@ -124,7 +124,7 @@ __device__ inline unsigned short f32_to_f16_scaled(float a, double gam, double i
     return bits;
 }
 
-// One wave per row: centred operand image, norm interval, chromosome id.
+// Half a wave per row: centred operand image, norm interval, chromosome id.
 // ONE float16 image (A16; values scaled by the power of two gam) serves the threshold estimate and
 // the distance tiles.  The row's representation error e = |a - h| and |h|^2 are accumulated in
 // float64, and the lower bound loses w = e^2 / tau + tau max(|a|^2, |h|^2) on top of the float32
@@ -151,49 +151,63 @@ __global__ __launch_bounds__(256) void k_convert(const double *__restrict__ X, i
                                                  int *__restrict__ row_stat,
                                                  double *__restrict__ X64, int64_t Sp, float *__restrict__ m2_out,
                                                  int *__restrict__ bad_norm, int *__restrict__ fb_zero, int n_fb_zero) {
-    int lane = threadIdx.x & 63;
-    int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // Half a wave per row (lane hl of 32, `half` picks the row): a row's life here is a few dependent round trips,
+    // and with a wave per row the 11 087 rows of a 250 kb problem were 1.35 rounds of what fits the chip -- two rounds
+    // of ~5 us.  Two rows per wave make it one.
+    const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
+    const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + half;
     // the exact path's counter and tickets of the job that starts here (was a memset launch in front of
     // the pick stage of every pass)
     if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < n_fb_zero; i += 256) fb_zero[i] = 0;
-    if (row >= Bpad) return;
+    if (row >= Bpad) return;                   // (Bpad is a multiple of 128: whole waves)
     // float64 image with rows padded to whole 16-sample chunks (128-byte aligned rows, zero
     // padding): the re-score gathers read it with aligned 16-byte loads and no tail cases
     if (X64 && row < B)
-        for (int64_t s = lane; s < Sp; s += 64) X64[row * Sp + s] = s < S ? X[row * S + s] : 0.0;
+        for (int64_t s = hl; s < Sp; s += 32) X64[row * Sp + s] = s < S ? X[row * S + s] : 0.0;
     const int slot = row < B ? sample_slot[row] : -1;   // >= 0: this row is one of the sampled rows
-    // chromosome of the row: lane c holds the end of chromosome c, the row's chromosome is the
-    // number of ends at or below it (the serial search was up to 22 dependent loads on lane 0)
+    // chromosome of the row: lane c of the half holds the end of chromosome c (at most 32 of them), the row's
+    // chromosome is the number of ends at or below it (the serial search was up to 22 dependent loads on lane 0)
     int ch_w = -1;
     int2 range_w = make_int2(0, 0);
-    if (row < B) {
-        const int64_t endc = lane < n_chrom ? chrom_off[lane + 1] : (int64_t)0x7FFFFFFFFFFFFFFFll;
-        int c = __popcll(__ballot(lane < n_chrom - 1 && row >= endc));
-        ch_w = c;
-        range_w = make_int2((int)(c ? __shfl(endc, c - 1) : 0), (int)__shfl(endc, c));
+    {
+        // (up to WC_MAX_CHROM = 64 chromosomes: two ends per lane of the half)
+        const int64_t none = (int64_t)0x7FFFFFFFFFFFFFFFll;
+        const int64_t end0 = hl < n_chrom ? chrom_off[hl + 1] : none, end1 = hl + 32 < n_chrom ? chrom_off[hl + 33] : none;
+        const unsigned long long b0 = __ballot(row < B && hl < n_chrom - 1 && row >= end0);
+        const unsigned long long b1 = __ballot(row < B && hl + 32 < n_chrom - 1 && row >= end1);
+        const int c = __popc((unsigned int)(b0 >> (32 * half))) + __popc((unsigned int)(b1 >> (32 * half)));
+        auto end_of = [&](int i) {             // end of chromosome i, from whichever lane of this half holds it
+            const int64_t a0 = __shfl(end0, (lane & 32) + (i & 31)), a1 = __shfl(end1, (lane & 32) + (i & 31));
+            return i < 32 ? a0 : a1;
+        };
+        const int64_t e_lo = end_of(c ? c - 1 : 0), e_hi = end_of(c);
+        if (row < B) {
+            ch_w = c;
+            range_w = make_int2((int)(c ? e_lo : 0), (int)e_hi);
+        }
     }
     double gam = 1.0, inv_gam = 1.0;
     {
-        // every wave derives the same scale: typical |a| * gam lands in [4, 8) (float16 keeps
+        // every half wave derives the same scale: typical |a| * gam lands in [4, 8) (float16 keeps
         // 2^13 above that and 2^16 below it in its normal range)
         double t = 0.0, c = 0.0;
-        for (int64_t s = lane; s < S; s += 64) {
+        for (int64_t s = hl; s < S; s += 32) {
             const double m = mean[S + s];
             if (isfinite(m) && m > 0.0) { t += m; c += 1.0; }
         }
-        for (int o = 32; o > 0; o >>= 1) { t += __shfl_xor(t, o); c += __shfl_xor(c, o); }
+        for (int o = 16; o > 0; o >>= 1) { t += __shfl_xor(t, o); c += __shfl_xor(c, o); }
         if (c > 0.0 && isfinite(t)) {
             int e = ilogb(t / c);
             e = e < -60 ? -60 : (e > 60 ? 60 : e);
             gam = ldexp(1.0, 2 - e);
             inv_gam = ldexp(1.0, e - 2);
         }
-        if (row == 0 && lane == 0) *m2_out = (float)(-2.0 * inv_gam * inv_gam);
+        if (row == 0 && hl == 0) *m2_out = (float)(-2.0 * inv_gam * inv_gam);
     }
     double acc = 0.0, e2 = 0.0, hn = 0.0;
     bool clamped = false;
-    for (int64_t s = lane; s < Kpad16; s += 64) {
+    for (int64_t s = hl; s < Kpad16; s += 32) {
         float a = 0.f;
         if (row < B && s < S) a = (float)(X[row * S + s] - mean[s]);
         double back;
@@ -205,13 +219,13 @@ __global__ __launch_bounds__(256) void k_convert(const double *__restrict__ X, i
         if (slot >= 0) S16[(int64_t)slot * Kpad16 + s] = h;
         acc += (double)a * (double)a;
     }
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = 16; o > 0; o >>= 1) {
         acc += __shfl_xor(acc, o);
         e2 += __shfl_xor(e2, o);
         hn += __shfl_xor(hn, o);
     }
-    clamped = __any(clamped);
-    if (lane == 0) {
+    clamped = ((unsigned int)(__ballot(clamped) >> (32 * half))) != 0u;
+    if (hl == 0) {
         float lo = INFINITY, hi = INFINITY;
         int ch = -1;
         int2 range = make_int2(0, 0);   // rows of this row's chromosome (padding rows: none)
@@ -2181,7 +2195,7 @@ int wc_newref_prepare_dev(wc_ctx *ctx, void *stream_, const double *corrected, i
                            n_bins, n_samples, n_rows, row_step, mean2, st.m2.as<int>() + 1);
     }
 
-    hipLaunchKernelGGL(k_convert, dim3((unsigned)(st.bins_pad / 4)), dim3(256), 0, stream, corrected, n_bins,
+    hipLaunchKernelGGL(k_convert, dim3((unsigned)(st.bins_pad / 8)), dim3(256), 0, stream, corrected, n_bins,
                        n_samples, st.bins_pad, (const double *)mean2, (double)st.beta, st.tau,
                        st.chrom_off_dev.as<int64_t>(), n_chrom, st.a16.as<unsigned short>(),
                        st.k_pad16, st.norm_lo.as<float>(), st.norm_hi.as<float>(), st.chrom_of_row.as<int>(),
