@@ -557,10 +557,24 @@ class TestPipeline(object):
             raise errors[0]
 
     def close(self):
+        """Frees the extra slots' references and contexts (slot 0 is the caller's reference)."""
         for slot in self.slots[1:]:
             slot["ref"].close()
             _lib.destroy_context(slot["ctx"])
         self.slots = self.slots[:1]
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown: the library may already be gone
+            pass
 
 
 def shard_samples(n_samples, rank, world):
