@@ -253,6 +253,11 @@ double wc_reference_cutoff(const wc_reference *ref);
 
 /* getOptimalCutoff alone, wisetools.py:328-336 (host pointers). */
 int wc_optimal_cutoff(wc_ctx *ctx, const double *distances, int64_t count, int repeats, double *cutoff);
+/* ... with the function's second return value (wisetools.py:332, :336): mask [count] uint8 =
+ * `distances < cutoff of the iteration before the last` (all finite values when repeats == 1).
+ * repeats >= 1; the reference's repeats == 0 case (an all-zero float array) is host marshalling. */
+int wc_optimal_cutoff_mask(wc_ctx *ctx, const double *distances, int64_t count, int repeats, double *cutoff,
+                           uint8_t *mask);
 
 /* applyPCA alone, wisetools.py:104-113, for a batch of already normalised and
  * masked vectors: samples/out [n_samples, n_bins] float64 (host pointers).    */

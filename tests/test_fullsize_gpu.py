@@ -95,6 +95,39 @@ def test_fast_path_equals_exact_path_on_every_row_600x50kb(wt, kind):
         assert np.array_equal(host_d[row].view(np.uint64), d[o].view(np.uint64)), row
 
 
+@pytest.mark.parametrize("tag", ["c", "f"])
+def test_fast_path_equals_the_reference_on_the_cfg4_slice(wt, golden, tag):
+    """BASELINE config 4 pinned on the reference ITSELF: cfg4slice.npz holds the real getReference's output
+    (tools/make_goldens.py --only cfg4slice; wisetools.py:298-325, 364-398) for 64 target rows of the
+    600 x 50 kb kernel-level matrix against all candidates -- first / last bins of chromosomes, chr1, chr21 / 22 --
+    in C order (numpy's pairwise row sums) and Fortran order (sequential).  The float16-bound FAST path (the
+    statistics prove no row left it) must deliver those indexes and distance bits."""
+    import torch
+    from wisecondor_amd import _lib, distributed, synth
+    g = golden("cfg4slice.npz")
+    data, bins, _ = synth.corrected_matrix(50000, 600, seed=0)
+    rows = g["rows"]
+    assert tuple(g["shape"]) == data.shape and np.array_equal(data[rows[:4], :3], g["data_probe"])
+    order = _lib.SUM_PAIRWISE if tag == "c" else _lib.SUM_SEQUENTIAL
+    B = data.shape[0]
+    X = torch.from_numpy(data).cuda()
+    del data
+    job = distributed.NewrefJob(_lib.context(0), X, np.asarray(bins, dtype=np.int64), 100, order)
+    idx, dst = job.run()
+    torch.cuda.synchronize()
+    stats = wt.newref_stats(0)
+    assert stats["fast_rows"] == B and stats["fallback_rows"] == 0, stats
+    sel = torch.from_numpy(rows).cuda()
+    got_i, got_d = idx[sel].cpu().numpy(), dst[sel].cpu().numpy()
+    assert np.array_equal(got_i, g["idx_" + tag])
+    assert np.array_equal(got_d.view(np.uint64), g["dst_" + tag].view(np.uint64))
+    # the function seam on the same rows (getReference picks the order from the array's strides): part = row + 1 of B
+    lay = np.ascontiguousarray(X.cpu().numpy()) if tag == "c" else np.asfortranarray(X.cpu().numpy())
+    for n in (0, 33, 63):
+        i1, d1 = wt.getReference(lay, bins, np.cumsum(bins), 100, int(rows[n]) + 1, B)
+        assert np.array_equal(i1[0], g["idx_" + tag][n]) and np.array_equal(d1[0].view(np.uint64), g["dst_" + tag][n].view(np.uint64))
+
+
 def test_batched_test_50kb_equals_single_samples(wt):
     """cfg5's shape per GPU (here 24 samples x 50 kb): every output of the batch equals the output
     of the same sample tested alone, and a second run of the batch is bit-identical."""

@@ -328,3 +328,36 @@ def test_cfg5_whole_samples_oracle_equals_reference(golden):
         assert np.allclose(a[:, 3:], b[:, 3:], rtol=1e-9, atol=1e-12), i
         assert np.allclose(g["ref%d_results_cwz" % i], g["oracle%d_results_cwz" % i], rtol=1e-9, atol=1e-12), i
         assert np.isclose(float(g["ref%d_asdef" % i]), float(g["oracle%d_asdef" % i]), rtol=1e-12), i
+
+
+def test_cutoff_and_mask_of_the_reference(golden):
+    """Both return values of getOptimalCutoff (wisetools.py:328-336), repeats 0..3."""
+    g = golden("cutoff_mask.npz")
+    d1 = golden("cfg1_pipeline.npz")["ref_distances"]
+    for name, arr in (("cfg1", d1), ("small", g["small"])):
+        for repeats in (0, 1, 2, 3):
+            with np.errstate(all="ignore"):
+                cut, mask = wo.get_optimal_cutoff(arr, repeats)
+            assert same_bits(cut, g["%s_cutoff_%d" % (name, repeats)])
+            want = np.unpackbits(g["%s_mask_%d" % (name, repeats)])[:arr.size].astype(bool).reshape(arr.shape)
+            assert np.array_equal(np.asarray(mask).astype(bool), want)
+            assert str(np.asarray(mask).dtype) == str(g["%s_maskdtype_%d" % (name, repeats)])
+
+
+@pytest.mark.parametrize("tag", ["c", "f"])
+def test_cfg4_slice_oracle_equals_reference(golden, tag):
+    """BASELINE config 4 (600 samples x 50 kb): four of the 64 reference-made rows of cfg4slice.npz through
+    the oracle, C order (pairwise sums) and Fortran order (sequential)."""
+    from wisecondor_amd import synth
+    g = golden("cfg4slice.npz")
+    data, bins, sums = synth.corrected_matrix(50000, 600, seed=0)
+    assert tuple(g["shape"]) == data.shape and np.array_equal(data[g["rows"][:4], :3], g["data_probe"])
+    lay = np.ascontiguousarray(data) if tag == "c" else np.asfortranarray(data)
+    del data
+    B = int(sums[-1])
+    for n in (0, 21, 40, 63):
+        row = int(g["rows"][n])
+        with np.errstate(all="ignore"):
+            idx, dst = wo.get_reference(lay, bins, sums, 100, row + 1, B, fast=True)
+        assert np.array_equal(np.asarray(idx).reshape(-1), g["idx_" + tag][n])
+        assert same_bits(np.asarray(dst).reshape(-1), g["dst_" + tag][n])

@@ -6,6 +6,7 @@ ratios and effect sizes within 1e-9 relative (float64 everywhere; the only
 non-bit-exact step is the PCA projection, whose BLAS summation order is not
 reproducible), stated next to each assertion.
 """
+import os
 import warnings
 
 import numpy as np
@@ -56,18 +57,33 @@ def test_cutoff(wt, cfg1, reference):
     # the moments are taken in numpy's order (row-major compaction, pairwise within 8192-element
     # pieces, pieces left to right): the cutoff is the reference's double
     assert reference.cutoff == float(cfg1["cutoff"])
-    cut, _ = wt.getOptimalCutoff(cfg1["ref_distances"], 3)
+    cut, mask = wt.getOptimalCutoff(cfg1["ref_distances"], 3)
     assert cut == float(cfg1["cutoff"])
+    _, want_mask = wo.get_optimal_cutoff(cfg1["ref_distances"], 3)
+    assert mask.dtype == np.bool_ and mask.shape == want_mask.shape and np.array_equal(mask, want_mask)
+    assert not mask.all() and mask.any()                    # the second iteration's cutoff does clip here
+    c0, m0 = wt.getOptimalCutoff(cfg1["ref_distances"], 0)  # the loop never runs (wisetools.py:329-330)
+    w0, wm0 = wo.get_optimal_cutoff(cfg1["ref_distances"], 0)
+    assert c0 == w0 == float("inf") and m0.dtype == wm0.dtype and np.array_equal(m0, wm0)
+    # both return values against the real reference's (tools/make_goldens.py --only cutoffmask)
+    gm = np.load(os.path.join(os.path.dirname(__file__), "golden", "cutoff_mask.npz"), allow_pickle=False)
+    for name, arr in (("cfg1", cfg1["ref_distances"]), ("small", gm["small"])):
+        for repeats in (0, 1, 2, 3):
+            got, got_mask = wt.getOptimalCutoff(arr, repeats)
+            assert got == float(gm["%s_cutoff_%d" % (name, repeats)])
+            want = np.unpackbits(gm["%s_mask_%d" % (name, repeats)])[:arr.size].astype(bool).reshape(arr.shape)
+            assert np.array_equal(got_mask.astype(bool), want) and str(got_mask.dtype) == str(gm["%s_maskdtype_%d" % (name, repeats)])
     rng = np.random.RandomState(2)
     for shape in [(1, 1), (3, 7), (90, 100), (700, 100), (8192, 1), (8193, 1), (3000, 37)]:
         d = np.sort(rng.gamma(3.0, 0.1, size=shape), axis=1)
         d[rng.rand(*shape) < 0.01] = 1e10                 # padding entries of short lists
         for repeats in (1, 3):
-            got, _ = wt.getOptimalCutoff(d, repeats)
+            got, got_mask = wt.getOptimalCutoff(d, repeats)
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")        # a one-element set clips itself away: numpy warns
-                want, _ = wo.get_optimal_cutoff(d, repeats)
+                want, want_mask = wo.get_optimal_cutoff(d, repeats)
             assert (np.isnan(got) and np.isnan(want)) or got == want, (shape, repeats)
+            assert got_mask.shape == want_mask.shape and np.array_equal(got_mask, want_mask), (shape, repeats)
 
 
 @pytest.mark.parametrize("name", NAMES)

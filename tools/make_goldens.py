@@ -554,9 +554,75 @@ def scale_cases(wt):
     return out
 
 
+# ------------------------------------------------- cfg4 slice (600 x 50 kb) --
+def cfg4slice_rows(bins):
+    """64 target rows of the 600 x 50 kb matrix: first / last bin of several chromosomes, bins inside
+    chr1, chr21 and chr22, and a seeded handful anywhere."""
+    bins = np.asarray(bins, dtype=np.int64)
+    ends = np.cumsum(bins)
+    starts = ends - bins
+    rows = []
+    for c in (0, 1, 6, 11, 17, 20, 21):
+        rows += [int(starts[c]), int(ends[c] - 1)]
+    rows += [int(starts[0] + v) for v in (1, 2, 777, 2492, 4000)]
+    rows += [int(starts[20] + v) for v in (1, 100, 481, 900)]
+    rows += [int(starts[21] + v) for v in (1, 313, 1000)]
+    rng = np.random.RandomState(4)
+    while len(rows) < 64:
+        r = int(rng.randint(0, int(ends[-1])))
+        if r not in rows:
+            rows.append(r)
+    return np.array(sorted(rows), dtype=np.int64)
+
+
+def cfg4slice_cases(wt):
+    """BASELINE config 4 (600 samples x 50 kb, 57 633 bins): the REAL reference's getReference
+    (wisetools.py:364-398, getRefForBins :298-325) for 64 target rows against ALL candidates, on the
+    kernel-level matrix in C order (numpy sums each row pairwise) and in Fortran order (the prep file's
+    layout: sample by sample).  `part = row + 1 of B parts` makes getPart return exactly [row, row + 1)
+    (B / float(B) is 1.0).  Only the rows, indexes and distances are stored; the matrix is
+    synth.corrected_matrix(50000, 600, seed=0)."""
+    data, bins, sums = synth.corrected_matrix(50000, 600, seed=0)
+    B = int(sums[-1])
+    rows = cfg4slice_rows(bins)
+    out = {"rows": rows, "shape": np.array(data.shape, dtype=np.int64), "k": np.int64(100),
+           "data_probe": data[rows[:4], :3].copy()}
+    for tag, lay in (("c", np.ascontiguousarray(data)), ("f", np.asfortranarray(data))):
+        idx = np.empty((len(rows), 100), dtype=np.int32)
+        dst = np.empty((len(rows), 100), dtype=np.float64)
+        for n, row in enumerate(rows):
+            with quiet(), np.errstate(all="ignore"):
+                i_, d_ = wt.getReference(lay, list(bins), list(sums), 100, int(row) + 1, B)
+            i_ = np.asarray(i_); d_ = np.asarray(d_)
+            assert i_.shape == (1, 100), i_.shape
+            idx[n], dst[n] = i_[0], d_[0]
+        out["idx_" + tag], out["dst_" + tag] = idx, dst
+        del lay
+    return out
+
+
+def cutoff_mask_cases(wt):
+    """getOptimalCutoff's BOTH return values (wisetools.py:328-336) from the real reference, on the
+    cfg1 reference's distances (read from the committed cfg1 fixture) and on a tiny hand-made array."""
+    g = np.load(os.path.join(GOLD, "cfg1_pipeline.npz"), allow_pickle=False)
+    d = np.asarray(g["ref_distances"], dtype=np.float64)
+    small = np.sort(np.random.RandomState(8).gamma(3.0, 0.1, size=(40, 9)), axis=1)
+    small[::7, -2:] = 1e10
+    out = {"small": small}
+    for name, arr in (("cfg1", d), ("small", small)):
+        for repeats in (0, 1, 2, 3):
+            with quiet(), np.errstate(all="ignore"):
+                cut, mask = wt.getOptimalCutoff(arr, repeats)
+            out["%s_cutoff_%d" % (name, repeats)] = np.float64(cut)
+            out["%s_mask_%d" % (name, repeats)] = np.packbits(np.asarray(mask).astype(bool).ravel())
+            out["%s_maskdtype_%d" % (name, repeats)] = np.array(str(np.asarray(mask).dtype))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default=None, help="regenerate one file only: layout | cfg3 | cfg5 | refsize300")
+    ap.add_argument("--only", default=None,
+                    help="regenerate one file only: layout | cfg3 | cfg5 | refsize300 | cfg4slice | cutoffmask")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     wt, wc, _tri = ref_loader.load(full_svd=True)
@@ -567,6 +633,10 @@ def main():
         save(os.path.join(GOLD, "cfg3_250kb.npz"), **cfg3_cases(wt, wc))
     if args.only == "refsize300":
         save(os.path.join(GOLD, "refsize300.npz"), **refsize300_cases(wt, wc))
+    if args.only == "cutoffmask":
+        save(os.path.join(GOLD, "cutoff_mask.npz"), **cutoff_mask_cases(wt))
+    if args.only == "cfg4slice":
+        save(os.path.join(GOLD, "cfg4slice.npz"), **cfg4slice_cases(wt))
     if args.only == "cfg5":
         save(os.path.join(GOLD, "cfg5_50kb.npz"), **cfg5_cases(wt))
     if args.only is not None:

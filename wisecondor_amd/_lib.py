@@ -58,6 +58,7 @@ SIGNATURES = {
     "wc_reference_destroy": (None, [_vp]),
     "wc_reference_cutoff": (_dbl, [_vp]),
     "wc_optimal_cutoff": (_i32, [_vp, _vp, _i64, _i32, _vp]),
+    "wc_optimal_cutoff_mask": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "wc_prepare_samples": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "wc_repeat_test": (_i32, [_vp, _vp, _vp, _i64, _dbl, _i32, _vp, _vp, _vp, _vp]),
     "wc_std_dev_avg": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),

@@ -122,8 +122,14 @@ __global__ void k_cut_fold(const double *__restrict__ piece, const long long *__
     out[1] = (double)n;
 }
 
+// the mask getOptimalCutoff hands back (wisetools.py:332): distances < the cutoff of the iteration before
+__global__ void k_cut_mask(const double *__restrict__ d, int64_t count, double cutoff, uint8_t *__restrict__ mask) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) mask[i] = d[i] < cutoff ? 1 : 0;
+}
+
 int device_cutoff(wc_ctx *ctx, const double *d_dev, int64_t count, int repeats, hipStream_t stream, double *out,
-                  int k = 1) {
+                  int k = 1, double *previous = nullptr) {
     int rc;
     WC_CHECK(k > 0 && count % k == 0, WC_E_ARG, "cutoff: distances are not [rows, k]");
     const int64_t rows = count / k;
@@ -140,6 +146,7 @@ int device_cutoff(wc_ctx *ctx, const double *d_dev, int64_t count, int repeats, 
     const unsigned gr = (unsigned)cdiv(rows, 256);
     for (int it = 0; it < repeats; ++it) {
         double h[2];
+        if (previous) *previous = cutoff;
         hipLaunchKernelGGL(k_cut_count, dim3(gr), dim3(256), 0, stream, d_dev, rows, k, cutoff, cnt);
         hipLaunchKernelGGL(k_cut_scan, dim3(1), dim3(1024), 0, stream, (const int *)cnt, rows, off);
         hipLaunchKernelGGL(k_cut_compact, dim3(gr), dim3(256), 0, stream, d_dev, rows, k, cutoff,
@@ -4373,6 +4380,24 @@ int wc_optimal_cutoff(wc_ctx *ctx, const double *distances, int64_t count, int r
     if ((rc = ctx->tmp_a.reserve(sizeof(double) * count))) return rc;
     WC_HIP(hipMemcpy(ctx->tmp_a.p, distances, sizeof(double) * count, hipMemcpyHostToDevice));
     return device_cutoff(ctx, ctx->tmp_a.as<double>(), count, repeats, nullptr, cutoff);
+}
+
+int wc_optimal_cutoff_mask(wc_ctx *ctx, const double *distances, int64_t count, int repeats, double *cutoff,
+                           uint8_t *mask) {
+    WC_CHECK(ctx && distances && cutoff && mask && count > 0 && repeats > 0, WC_E_ARG,
+             "getOptimalCutoff: bad argument");
+    WC_HIP(hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ctx->tmp_a.reserve(sizeof(double) * count))) return rc;
+    if ((rc = ctx->tmp_b.reserve(count))) return rc;
+    WC_HIP(hipMemcpy(ctx->tmp_a.p, distances, sizeof(double) * count, hipMemcpyHostToDevice));
+    double previous = INFINITY;
+    if ((rc = device_cutoff(ctx, ctx->tmp_a.as<double>(), count, repeats, nullptr, cutoff, 1, &previous))) return rc;
+    hipLaunchKernelGGL(k_cut_mask, dim3((unsigned)cdiv(count, 256)), dim3(256), 0, nullptr,
+                       (const double *)ctx->tmp_a.as<double>(), count, previous, ctx->tmp_b.as<uint8_t>());
+    WC_HIP(hipGetLastError());
+    WC_HIP(hipMemcpy(mask, ctx->tmp_b.p, count, hipMemcpyDeviceToHost));
+    return WC_OK;
 }
 
 wc_reference *wc_reference_create(wc_ctx *ctx, const int32_t *indexes, const double *distances, int64_t n_bins,

@@ -205,12 +205,14 @@ def applyPCA(sampleData, mean, components, device=0):
 def getOptimalCutoff(reference, repeats, device=0):
     """Iterated mean + 3 sd clip of the reference distances (wisetools.py:328-336)."""
     d = np.ascontiguousarray(reference, dtype=np.float64)
+    if int(repeats) <= 0:       # the loop body never runs: +inf and the float zeros of wisetools.py:330
+        return float("inf"), np.zeros(np.shape(reference))
     cutoff = ctypes.c_double()
-    _lib.check(_lib.load().wc_optimal_cutoff(_lib.context(device), _lib.ptr(d), d.size, int(repeats),
-                                             ctypes.byref(cutoff)))
-    # the mask the reference returns is the one of the LAST iteration, i.e. against the
-    # previous cutoff; toolTest never uses it (wisecondor.py:201), so it is not rebuilt here
-    return cutoff.value, None
+    # the mask is the LAST iteration's, i.e. against the cutoff of the iteration before (wisetools.py:332)
+    mask = np.empty(d.shape, dtype=np.uint8)
+    _lib.check(_lib.load().wc_optimal_cutoff_mask(_lib.context(device), _lib.ptr(d), d.size, int(repeats),
+                                                  ctypes.byref(cutoff), _lib.ptr(mask)))
+    return cutoff.value, mask.view(np.bool_).reshape(np.shape(reference))
 
 
 def repeatTest(testData, indexes, distances, chromosomeBins, chromosomeBinSums, cutoff, threshold,
