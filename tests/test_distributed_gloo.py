@@ -118,13 +118,14 @@ class FailingStages(NumpyStages):
         return NumpyStages.collect(self, rb, re, rank, ranks)
 
 
-def _worker(rank, world, port, X, bins, k, out_dir, mode, passes=1, fail_rank=-1):
+def _worker(rank, world, port, X, bins, k, out_dir, mode, passes=1, fail_rank=-1, bands=None, gather=True):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         st = (FailingStages if rank == fail_rank else NumpyStages)(X, bins, k)
-        job = NewrefJob(None, None, bins, k, 0, rank=rank, world=world, stages=st, dist=dist, mode=mode, passes=passes)
+        job = NewrefJob(None, None, bins, k, 0, rank=rank, world=world, stages=st, dist=dist, mode=mode, passes=passes,
+                        bands=bands, gather=gather)
         try:
             for _ in range(2):          # second run reuses the exchange buffers
                 idx, dst = job.run()
@@ -134,7 +135,7 @@ def _worker(rank, world, port, X, bins, k, out_dir, mode, passes=1, fail_rank=-1
             np.savez(os.path.join(out_dir, "rank%d.npz" % rank), error=type(exc).__name__)
             return
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), idx=idx.numpy(), dst=dst.numpy(), mode=job.mode,
-                 measured=sorted((job.calibration or {}).keys()))
+                 measured=sorted((job.calibration or {}).keys()), n_bands=job.n_bands)
     finally:
         dist.destroy_process_group()
 
@@ -183,3 +184,40 @@ def test_multi_rank_equals_single_rank_and_oracle(tmp_path, world, mode):
         if mode is None:        # the shard mode was measured (both modes timed), not assumed
             assert list(got["measured"]) == ["rows", "tiles"]
     assert len(modes) == 1 and modes <= {"tiles", "rows"}      # every rank reached the same decision
+
+
+@pytest.mark.parametrize("world,mode,bands", [(2, "tiles", 1), (3, "tiles", 3), (3, "rows", 2), (8, "tiles", 7), (2, "rows", 64)])
+def test_band_pipeline_any_band_count(tmp_path, world, mode, bands):
+    """The multi-rank step is a pipeline over row bands with the collectives in flight (async_op): any band
+    count -- one (a single exchange and gather), more bands than a rank has rows, bands that leave the shorter
+    ranks' last band empty -- gives the single-rank result."""
+    rng = np.random.RandomState(15)
+    bins = np.array([9, 14, 7, 12, 11], dtype=np.int64)
+    X = 1.0 + 0.05 * rng.standard_normal((int(bins.sum()), 6))
+    k = 10
+    mp.spawn(_worker, args=(world, _free_port(), X, bins, k, str(tmp_path), mode, 1, -1, bands), nprocs=world, join=True)
+    want_i, want_d = wo.get_reference(X, bins, np.cumsum(bins), k, 1, 1, fast=True)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        assert np.array_equal(got["idx"], want_i) and np.array_equal(got["dst"], want_d), r
+        assert 1 <= int(got["n_bands"]) <= bands
+
+
+@pytest.mark.parametrize("world,mode", [(2, "tiles"), (3, "rows"), (8, "tiles")])
+def test_owners_keep_their_rows_without_the_result_gather(tmp_path, world, mode):
+    """gather=False (the command line tool: a rank writes the part files of the rows it owns, the reference's
+    workers exchange nothing but files, wisecondor.py:47-56): run() returns the rank's own rows, which stacked in
+    rank order are the whole result."""
+    from wisecondor_amd.distributed import row_range
+    rng = np.random.RandomState(25)
+    bins = np.array([9, 14, 7, 12, 11], dtype=np.int64)
+    X = 1.0 + 0.05 * rng.standard_normal((int(bins.sum()), 6))
+    k = 10
+    mp.spawn(_worker, args=(world, _free_port(), X, bins, k, str(tmp_path), mode, 1, -1, None, False), nprocs=world, join=True)
+    want_i, want_d = wo.get_reference(X, bins, np.cumsum(bins), k, 1, 1, fast=True)
+    got = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    for r in range(world):
+        b, e = row_range(r, world, X.shape[0])
+        assert got[r]["idx"].shape == (e - b, k)
+    assert np.array_equal(np.concatenate([g["idx"] for g in got]), want_i)
+    assert np.array_equal(np.concatenate([g["dst"] for g in got]), want_d)

@@ -113,7 +113,7 @@ def _worker8(rank, world, port, path_in, out_dir, mode, xcap):
         idx, dst = idx.cpu().numpy(), dst.cpu().numpy()
         over = 0
         if mode == "tiles":
-            over = int(sum(int((job.recv_cnt[r] > job.cap_x).sum()) for r in range(world) if r != rank))
+            over = int(sum(int((job.recv_cnt[i][r] > job.cap_x).sum()) for i in range(job.n_bands) for r in range(world) if r != rank))
         out = dict(sha=hashlib.sha256(idx.tobytes() + dst.tobytes()).hexdigest(), overflow=over, cap_x=getattr(job, "cap_x", 0),
                    fallback=wt.newref_stats()["fallback_rows"])
         if rank == 0:

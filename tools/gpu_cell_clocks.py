@@ -1,0 +1,38 @@
+"""Phase clocks of k_seg_job over one batch (WC_LIB_PATH=wisecondor_amd/ab/lib_cellclk.so, tools/cell_clocks_variant.py)."""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+from wisecondor_amd import _lib, distributed, wisetools as wt
+from wisecondor_amd.wisecondor import zThreshold
+ns = int(sys.argv[1]) if len(sys.argv) > 1 else 125
+binsize = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
+inp = bench.build_inputs(binsize, 100, ns)
+corrected = inp["corrected"]; bins = np.ascontiguousarray(inp["masked_bins"])
+X = torch.from_numpy(np.ascontiguousarray(corrected)).cuda()
+job = distributed.NewrefJob(_lib.context(0), X, bins, 100, wt.sum_order_of(corrected))
+idx, dst = job.run(); torch.cuda.synchronize()
+ref = wt.Reference(idx.cpu().numpy(), dst.cpu().numpy(), inp["chrom_bins"], inp["masked_bins"], inp["mask"],
+                   inp["pca_mean"], inp["pca_components"], binsize=binsize)
+thr = float(zThreshold([int(v) for v in inp["masked_bins"]], 1000, None))
+counts = torch.from_numpy(wt.samples_to_counts(inp["tests"], inp["chrom_bins"])).cuda()
+tb = distributed.TestBatch(ref, counts, thr, max_calls=256)
+lib, ctx = _lib.load(), _lib.context(0)
+for _ in range(3):
+    tb.run()
+a = np.zeros(64, dtype=np.uint64); b = np.zeros(64, dtype=np.uint64)
+_lib.check(lib.wc_debug_times(ctx, 0, _lib.ptr(a)))
+tb.run()
+_lib.check(lib.wc_debug_times(ctx, 0, _lib.ptr(b)))
+d = (b - a).astype(np.float64)
+jobs, hot = d[16], d[17]
+print("jobs %d, hot %d, longest workgroup %.0f ticks (all-time max)" % (jobs, hot, float(b[48])))
+names = {1: "tables + seed", 2: "search: near sweep", 3: "search: cell sweeps", 4: "search: refine", 10: "collect: near sweep",
+         11: "collect: cell sweeps", 12: "collect: refine", 15: "classify + write"}
+tot = sum(d[k] for k in names)
+for k, n in names.items():
+    per = hot if k in (10, 11, 12) else jobs
+    print("%-22s %10.0f kticks %5.1f %%  %8.0f ticks per %s" % (n, d[k] / 1e3, 100 * d[k] / tot, d[k] / max(per, 1), "hot job" if per is hot else "job"))
+print("loud cells per job: search %.1f, collect %.1f per hot job; queue overflows: search %d, collect %d"
+      % (d[5] / jobs, d[13] / max(hot, 1), d[6], d[14]))

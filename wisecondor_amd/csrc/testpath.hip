@@ -1865,13 +1865,21 @@ constexpr int Q_BLOCKS = 256;       // end blocks of one job held in LDS (jobs u
 // the bound-driven search's long windows.
 __global__ __launch_bounds__(256) void k_block_minmax(const double *__restrict__ prefix, int64_t total,
                                                       double *__restrict__ tmin, double *__restrict__ tmax,
-                                                      double *__restrict__ tmin2, double *__restrict__ tmax2) {
+                                                      double *__restrict__ tmin2, double *__restrict__ tmax2,
+                                                      double *__restrict__ t8min = nullptr,
+                                                      double *__restrict__ t8max = nullptr) {
     __shared__ double s_mn[8], s_mx[8];
     const int tid = threadIdx.x;
     const int64_t at = (int64_t)blockIdx.x * 256 + tid;
     double mn = INFINITY, mx = -INFINITY;
     if (at < total) mn = mx = prefix[at];
-    for (int o = 16; o > 0; o >>= 1) {
+    for (int o = 1; o < 8; o <<= 1) {
+        mn = fmin(mn, __shfl_xor(mn, o));
+        mx = fmax(mx, __shfl_xor(mx, o));
+    }
+    // (optional) the level below: minimum and maximum of every 8 entries, for the cell-driven search's near windows
+    if (t8min && (tid & 7) == 0 && at < total) { t8min[at >> 3] = mn; t8max[at >> 3] = mx; }
+    for (int o = 8; o < 32; o <<= 1) {
         mn = fmin(mn, __shfl_xor(mn, o));
         mx = fmax(mx, __shfl_xor(mx, o));
     }
@@ -2544,6 +2552,427 @@ __global__ __launch_bounds__(256) void k_seg_bcollect(const Job *__restrict__ jo
                                if (at < CAND_CAP) cand[((int64_t)2 * h + 1) * CAND_CAP + at] = make_int2(x, y);
                            }
                        }, work);
+    }
+}
+
+// ------------------------------------------------------------ cell-driven search ----
+// The bound-driven search above gives every block of 64 + 64 rows to a workgroup and sweeps, per ROW, one bound
+// per end block: ~60 evaluations per row and, per row block, a chain of staging, sweep, queue pass and reduction
+// (phase clocks of round 5: 21 k ticks per row block, no phase above a quarter).  The same bounds hold for whole
+// CELLS -- a block of rows against a block of ends, both read from the block tables:
+//     ub(A, K) = max(max P over K - min P over A, 0) * rs_above(shortest window of the cell)  >=  every window of it
+// -- so one workgroup per JOB decides 128 x 128 and 32 x 32 windows at a time and only descends into the cells that
+// reach the cut: cell -> rows (one bound each) -> windows.  A job's windows are tiled exactly once by
+//   * the row's first 8..15 window lengths (ends inside its own and the next 8-entry block)        by value,
+//   * the 8-entry blocks after them up to the end of the row's next 32-block (lengths below 64)   by bound,
+//   * 32 x 32 cells (A, K), K >= A + 2, whose 128-blocks are the same or adjacent (below 256)     by bound,
+//   * 128 x 128 cells (A2, K2), K2 >= A2 + 2                                                       by bound,
+// blocks aligned to the concatenated prefix array like the tables (a block that straddles the job's ends bounds a
+// superset).  MODE 0 finds the extremes with rising cuts exactly as bscan_chunk does (the cut only ever takes the
+// value of a window that exists or a lower bound of one, so whatever is skipped lies below the job's final extreme
+// or below thr - eps); MODE 2 lists the windows at or beyond fixed cuts (k_seg_bcollect's job).
+constexpr int CJ_MAXLEN = 8192;                 // longest job of this path (level-1 table 259 entries)
+constexpr int CJ_T1 = CJ_MAXLEN / QB + 3;
+constexpr int CJ_T2 = CJ_MAXLEN / QB2 + 3;
+constexpr int CJ_CELLQ = 1024;                  // loud 32 x 32 cells waiting for their rows; more: every cell is refined in turn
+constexpr int CJ_ITEMQ = 2048;                  // loud (row, 8-entry block) pairs; more: the row evaluates its block itself
+constexpr int CJ_RPT = 4;                       // rows per thread and near-sweep trip
+constexpr int CJ_TRIP = 256 * CJ_RPT;           // rows per trip
+constexpr int CJ_PN = CJ_TRIP + 64;             // the trip's rows and the 64 entries after them
+constexpr int CJ_NB8 = CJ_PN / 8 + 2;           // 8-entry blocks that overlap them
+constexpr int CJ_LOADS = (CJ_PN + 255) / 256;
+// Development aid (tools/cell_clocks_variant.py defines WC_CELL_CLOCKS): thread 0 of every k_seg_job workgroup books the
+// clock ticks of its phases in LDS and adds them to g_dbg[phase] when it leaves.
+// WC_CELL_CLOCKS_SWITCH
+#ifdef WC_CELL_CLOCKS
+#define CJ_CLK(n) do { if (tid == 0) { const unsigned long long t_ = clock64(); sh.clk[n] += t_ - sh.t_prev; sh.t_prev = t_; } } while (0)
+#else
+#define CJ_CLK(n) do { } while (0)
+#endif
+struct CellShared {
+#ifdef WC_CELL_CLOCKS
+    unsigned long long clk[32], t_prev;
+#endif
+    double tmx[CJ_T1], tmn[CJ_T1], tmx2[CJ_T2], tmn2[CJ_T2];
+    double pn[CJ_PN];
+    double b8x[CJ_NB8], b8n[CJ_NB8];            // maximum / minimum of the staged entries per (absolute) 8-entry block
+    double rsn[64];                             // rs[0 .. 63]
+    unsigned long long cut[2];                  // ordered bit patterns: [0] cut_hi, [1] -cut_lo
+    unsigned int cellq[CJ_CELLQ], itemq[CJ_ITEMQ];
+    int n_cells, n_items, n_hi, n_lo, overflow, slot;
+    int2 c_hi[CAND_CAP], c_lo[CAND_CAP];
+};
+
+// the job's slices of both table levels (and the first 64 table factors) into LDS
+__device__ inline void cell_stage_tables(CellShared &sh, const long long base, const long long a_hi,
+                                         const double *__restrict__ tmin, const double *__restrict__ tmax,
+                                         const double *__restrict__ tmin2, const double *__restrict__ tmax2,
+                                         const double *__restrict__ rs, int tid) {
+    const long long k1 = base >> 5, n1 = (a_hi >> 5) - k1 + 1;
+    for (int i = tid; i < (int)n1; i += 256) { sh.tmx[i] = tmax[k1 + i]; sh.tmn[i] = tmin[k1 + i]; }
+    const long long k2 = base >> 7, n2 = (a_hi >> 7) - k2 + 1;
+    for (int i = tid; i < (int)n2; i += 256) { sh.tmx2[i] = tmax2[k2 + i]; sh.tmn2[i] = tmin2[k2 + i]; }
+    if (tid < 64) sh.rsn[tid] = rs[tid];
+}
+
+template <int MODE>
+__device__ inline void cell_search(CellShared &sh, const long long base, const int L, const int job_lo,
+                                   const double *__restrict__ prefix, const double *__restrict__ rs,
+                                   const double hi_cut, const double lo_cut, double &vmax, double &vmin,
+                                   int &wins, int &evals, const int tid) {
+    const long long a_hi = base + L;                        // the job's last prefix entry (rows: base .. a_hi - 1)
+    const long long A1f = base >> 5, A1l = (a_hi - 1) >> 5, K1l = a_hi >> 5;
+    const long long A2f = base >> 7, A2l = (a_hi - 1) >> 7, K2l = a_hi >> 7;
+    const int lane = tid & 63, w = tid >> 6;
+    double chi = hi_cut, clo = lo_cut;
+    auto cuts = [&]() {
+        if (MODE == 0) {
+            chi = wc::f64_from_ordered(__hip_atomic_load(&sh.cut[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            clo = -wc::f64_from_ordered(__hip_atomic_load(&sh.cut[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        }
+    };
+    // a window's value: prefix entries ax (row) and ay (end), ay - ax bins
+    auto see = [&](const double v, const long long ax, const long long ay) {
+        ++wins;
+        if (MODE == 0) {
+            vmax = fmax(vmax, v);
+            vmin = fmin(vmin, v);
+            if (v > chi) { atomicMax(&sh.cut[0], wc::f64_ordered(v)); chi = v; }
+            if (v < clo) { atomicMax(&sh.cut[1], wc::f64_ordered(-v)); clo = v; }
+        } else {
+            const int x = job_lo + (int)(ax - base), y = x + (int)(ay - ax) - 1;
+            if (v >= hi_cut) {
+                const int at = atomicAdd(&sh.n_hi, 1);
+                if (at < CAND_CAP) sh.c_hi[at] = make_int2(x, y);
+            }
+            if (v <= lo_cut) {
+                const int at = atomicAdd(&sh.n_lo, 1);
+                if (at < CAND_CAP) sh.c_lo[at] = make_int2(x, y);
+            }
+        }
+    };
+    // ---- near windows (ends before the row's first 32 x 32 cell, i.e. fewer than 64 bins): CJ_TRIP rows per trip,
+    // everything of a trip in LDS, the next trip's entries requested while this one is worked on.  Nothing is
+    // evaluated by default: an 8-row block against an 8-end block two or more blocks on is ONE bound from the
+    // 8-entry block extremes, a row against its own and the next 8-block one bound each; what reaches the cut is
+    // queued as (row, 8-block) pairs and evaluated by eight lanes each.
+    double nxt[CJ_LOADS];
+    auto request = [&](const int r0) {
+#pragma unroll
+        for (int u = 0; u < CJ_LOADS; ++u) {
+            const int i = tid + 256 * u;
+            const long long a = base + r0 + i;
+            nxt[u] = (i < CJ_PN && a <= a_hi) ? prefix[a] : 0.0;
+        }
+    };
+    request(0);
+    for (int r0 = 0; r0 < L; r0 += CJ_TRIP) {
+        const long long a0 = base + r0;
+        __syncthreads();                                    // the previous trip's rows and queue are done with
+#pragma unroll
+        for (int u = 0; u < CJ_LOADS; ++u)
+            if (tid + 256 * u < CJ_PN) sh.pn[tid + 256 * u] = nxt[u];
+        if (tid == 0) sh.n_items = 0;
+        __syncthreads();
+        if (r0 + CJ_TRIP < L) request(r0 + CJ_TRIP);
+        // maximum / minimum of the staged entries per absolute 8-entry block (entries past the job's end take no part)
+        const long long k8_0 = a0 >> 3;
+        if (tid < CJ_NB8) {
+            double mx = -INFINITY, mn = INFINITY;
+            const int i0 = (int)(((k8_0 + tid) << 3) - a0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int i = i0 + e;
+                if (i >= 0 && i < CJ_PN && a0 + i <= a_hi) { mx = fmax(mx, sh.pn[i]); mn = fmin(mn, sh.pn[i]); }
+            }
+            sh.b8x[tid] = mx;
+            sh.b8n[tid] = mn;
+        }
+        __syncthreads();
+        cuts();
+        const int rows_here = L - r0 < CJ_TRIP ? L - r0 : CJ_TRIP;           // rows t = 0 .. rows_here - 1 of this trip
+        auto push = [&](const int t, const int j8) {        // (row t of the trip, staged 8-block j8)
+            const int at = atomicAdd(&sh.n_items, 1);
+            if (at < CJ_ITEMQ) {
+                sh.itemq[at] = ((unsigned int)t << 8) | (unsigned int)j8;
+            } else {                                         // queue full: the pusher walks the block itself
+                const long long ax = a0 + t;
+                long long y_near = (((ax >> 5) + 2) << 5) - 1;
+                if (y_near > a_hi) y_near = a_hi;
+                for (int e = 0; e < 8; ++e) {
+                    const long long ay = ((k8_0 + j8) << 3) + e;
+                    if (ay > ax && ay <= y_near) see((sh.pn[(int)(ay - a0)] - sh.pn[t]) * sh.rsn[(int)(ay - ax)], ax, ay);
+                }
+            }
+        };
+        // 8 x 8 cells: a thread per 8-row block of the trip, its end blocks two or more on
+        for (int jb = tid; jb < CJ_NB8; jb += 256) {
+            const long long A8 = k8_0 + jb;
+            int t_lo = (int)((A8 << 3) - a0), t_hi = t_lo + 7;       // the block's rows within the trip
+            if (t_lo < 0) t_lo = 0;
+            if (t_hi >= rows_here) t_hi = rows_here - 1;
+            if (t_lo > t_hi) continue;
+            long long y_near = (((A8 >> 2) + 2) << 5) - 1;            // the same for the eight rows
+            if (y_near > a_hi) y_near = a_hi;
+            // (the block's extremes as staged: rows of the neighbouring trip that share it only widen the bound)
+            const double rmx = sh.b8x[jb], rmn = sh.b8n[jb];
+            for (int j8 = jb + 2; ((k8_0 + j8) << 3) <= y_near; ++j8) {
+                const int minlen = ((j8 - jb - 1) << 3) + 1;
+                const double r = rs_above(minlen);
+                const double ub = fmax(sh.b8x[j8] - rmn, 0.0) * r, lb = fmin(sh.b8n[j8] - rmx, 0.0) * r;
+                ++evals;
+                if (ub >= chi || lb <= clo)
+                    for (int t = t_lo; t <= t_hi; ++t) push(t, j8);
+            }
+        }
+        // a row against its own 8-block (the entries after it) and the next one
+#pragma unroll
+        for (int q = 0; q < CJ_RPT; ++q) {
+            const int t = tid + 256 * q;
+            if (t >= rows_here) continue;
+            const long long ax = a0 + t;
+            const double px = sh.pn[t];
+            const int kb = (int)((ax >> 3) - k8_0);
+            long long y_near = (((ax >> 5) + 2) << 5) - 1;
+            if (y_near > a_hi) y_near = a_hi;
+            // own block: windows from 1 bin on (the block's extremes include the entries up to the row: a superset)
+            {
+                const double ub = fmax(sh.b8x[kb] - px, 0.0), lb = fmin(sh.b8n[kb] - px, 0.0);
+                ++evals;
+                if ((ax & 7) != 7 && (ub >= chi || lb <= clo)) push(t, kb);
+            }
+            if (((k8_0 + kb + 1) << 3) <= y_near) {
+                const int minlen = (int)(((k8_0 + kb + 1) << 3) - ax);       // 1..8
+                const double r = sh.rsn[minlen];
+                const double ub = fmax(sh.b8x[kb + 1] - px, 0.0) * r, lb = fmin(sh.b8n[kb + 1] - px, 0.0) * r;
+                ++evals;
+                if (ub >= chi || lb <= clo) push(t, kb + 1);
+            }
+        }
+        __syncthreads();
+        // queued (row, 8-block) pairs: eight lanes per pair
+        const int n_items = sh.n_items < CJ_ITEMQ ? sh.n_items : CJ_ITEMQ;
+        for (int i = tid >> 3; i < n_items; i += 32) {
+            const unsigned int it = sh.itemq[i];
+            const int t = (int)(it >> 8);
+            const long long ax = a0 + t, ay = ((k8_0 + (it & 255u)) << 3) + (tid & 7);
+            long long y_near = (((ax >> 5) + 2) << 5) - 1;
+            if (y_near > a_hi) y_near = a_hi;
+            if (ay > ax && ay <= y_near) see((sh.pn[(int)(ay - a0)] - sh.pn[t]) * sh.rsn[(int)(ay - ax)], ax, ay);
+        }
+    }
+    __syncthreads();
+    CJ_CLK(MODE * 4 + 2);
+    if (tid == 0) { sh.n_cells = 0; sh.overflow = 0; }
+    __syncthreads();
+    cuts();
+    // ---- far windows: cells.  A 32 x 32 cell that reaches the cut is queued for its rows.
+    auto cell1 = [&](const long long A, const long long K) {
+        const int minlen = (int)(((K - A - 1) << 5) + 1);
+        const double r = rs_above(minlen);
+        const double ub = fmax(sh.tmx[K - A1f] - sh.tmn[A - A1f], 0.0) * r;
+        const double lb = fmin(sh.tmn[K - A1f] - sh.tmx[A - A1f], 0.0) * r;
+        ++evals;
+        if (ub >= chi || lb <= clo) {
+            const int at = atomicAdd(&sh.n_cells, 1);
+            if (at < CJ_CELLQ) sh.cellq[at] = ((unsigned int)(A - A1f) << 16) | (unsigned int)(K - A1f);
+            else sh.overflow = 1;
+        }
+    };
+    // 128 x 128 cells: a wave per row block, a lane per end block; a loud one is taken apart on the spot
+    for (long long A2 = A2f + w; A2 <= A2l; A2 += 4)
+        for (long long K2 = A2 + 2 + lane; K2 <= K2l; K2 += 64) {
+            const int minlen = (int)(((K2 - A2 - 1) << 7) + 1);
+            const double r = rs_above(minlen);
+            const double ub = fmax(sh.tmx2[K2 - A2f] - sh.tmn2[A2 - A2f], 0.0) * r;
+            const double lb = fmin(sh.tmn2[K2 - A2f] - sh.tmx2[A2 - A2f], 0.0) * r;
+            ++evals;
+            if (ub >= chi || lb <= clo)
+                for (int q = 0; q < 16; ++q) {
+                    const long long A = (A2 << 2) + (q >> 2), K = (K2 << 2) + (q & 3);
+                    if (A >= A1f && A <= A1l && K <= K1l) cell1(A, K);
+                }
+        }
+    // 32 x 32 cells between the near windows and the 128 x 128 cells: a thread per row block
+    for (long long A = A1f + tid; A <= A1l; A += 256) {
+        long long k_end = (((A >> 2) + 2) << 2) - 1;
+        if (k_end > K1l) k_end = K1l;
+        for (long long K = A + 2; K <= k_end; ++K) cell1(A, K);
+    }
+    __syncthreads();
+    CJ_CLK(MODE * 4 + 3);
+    // ---- the rows of the loud cells: half a wave per cell, a lane per row; a loud row's 32 windows by the same lanes.
+    // Everything a cell needs from memory -- its 32 rows, its 32 ends and the 63 table factors of its window lengths
+    // -- is requested up front, one cell ahead of the one being worked on; the row loop itself only shuffles.
+    const int hl = tid & 31, half = tid & 32;
+    struct CellLoad { long long A, K; double px, py, r_lo, r_hi; };
+    auto fetch = [&](const long long A, const long long K) {
+        CellLoad c;
+        c.A = A; c.K = K;
+        const long long ax = (A << 5) + hl, ay = (K << 5) + hl;
+        c.px = (ax >= base && ax < a_hi) ? prefix[ax] : 0.0;
+        c.py = ay <= a_hi ? prefix[ay] : 0.0;
+        const int len0 = (int)((K - A) << 5) - 31;           // the cell's shortest window; lengths len0 .. len0 + 62
+        c.r_lo = rs[len0 + hl];
+        c.r_hi = rs[len0 + 32 + hl];
+        return c;
+    };
+    auto refine = [&](const CellLoad &c) {
+        const long long A = c.A, K = c.K;
+        const long long ax = (A << 5) + hl, ay = (K << 5) + hl;
+        const bool valid = ax >= base && ax < a_hi;
+        const double px = c.px;
+        const double mx = sh.tmx[K - A1f], mn = sh.tmn[K - A1f];
+        const int minlen = (int)((K << 5) - ax);             // >= 33
+        const double r = rs_above(minlen);
+        const double up = mx - px, dn = mn - px;
+        const double ub = fmax(up, 0.0) * r, lb = fmin(dn, 0.0) * r;
+        ++evals;
+        cuts();
+        const bool loud = valid && (ub >= chi || lb <= clo);
+        if (MODE == 0 && loud && (K << 5) + 31 <= a_hi) {
+            // the end block lies wholly inside the job: the window that ends on its extreme is at most 31 bins
+            // longer than the shortest one -- a lower bound of this row's best window, i.e. a value the cut may take
+            const double r2 = rs_below(minlen + 31);
+            if (ub >= chi && up > 0.0 && up * r2 > chi) atomicMax(&sh.cut[0], wc::f64_ordered(up * r2));
+            if (lb <= clo && dn < 0.0 && dn * r2 < clo) atomicMax(&sh.cut[1], wc::f64_ordered(-(dn * r2)));
+        }
+        unsigned int m = (unsigned int)(__ballot(loud) >> half);
+        while (__any(m != 0u)) {                             // (both halves of the wave stay in step)
+            const bool act = m != 0u;
+            const int rr = act ? __ffs(m) - 1 : 0;
+            m &= m - 1u;
+            const double pxr = __shfl(px, half + rr);
+            // the window from row rr to end hl has length len0 + 31 + hl - rr: factor number 31 + hl - rr of the 63
+            const int fi = 31 + hl - rr;
+            const double f_lo = __shfl(c.r_lo, half + (fi & 31)), f_hi = __shfl(c.r_hi, half + (fi & 31));
+            if (act && ay <= a_hi) see((c.py - pxr) * (fi < 32 ? f_lo : f_hi), (A << 5) + rr, ay);
+        }
+    };
+    if (!sh.overflow) {
+        const int nc = sh.n_cells;
+        int c = tid >> 5;
+        CellLoad cur{}, nxt_c{};
+        if (c < nc) cur = fetch(A1f + (sh.cellq[c] >> 16), A1f + (sh.cellq[c] & 0xFFFFu));
+        for (; c < nc; c += 8) {
+            const bool more = c + 8 < nc;
+            if (more) nxt_c = fetch(A1f + (sh.cellq[c + 8] >> 16), A1f + (sh.cellq[c + 8] & 0xFFFFu));
+            refine(cur);
+            cur = nxt_c;
+        }
+    } else {
+        // more loud cells than the queue holds (a job that is one long aberration): every far cell in turn
+        for (long long A = A1f + (tid >> 5); A <= A1l; A += 8)
+            for (long long K = A + 2; K <= K1l; ++K) refine(fetch(A, K));
+    }
+#ifdef WC_CELL_CLOCKS
+    __syncthreads();
+    CJ_CLK(MODE * 4 + 4);
+    if (tid == 0) { sh.clk[MODE * 4 + 5] += (unsigned long long)sh.n_cells; sh.clk[MODE * 4 + 6] += (unsigned long long)sh.overflow; }
+#endif
+}
+
+// One workgroup per job: seed, search, classification and -- for a job that may hold a call -- the candidate list,
+// i.e. k_seg_seed + k_seg_bound + k_seg_classify + k_seg_bcollect of the bound-driven rounds in one launch.
+// hot / cand / cand_cnt leave it in the form k_seg_decide reads.  counters[2] / [3] / next_count are zeroed by the
+// host before the launch.
+__global__ __launch_bounds__(256) void k_seg_job(const Job *__restrict__ jobs, int n_jobs,
+                                                 const Region *__restrict__ regions,
+                                                 const double *__restrict__ prefix, const double *__restrict__ rs,
+                                                 const double *__restrict__ reg_abs, const int *__restrict__ reg_flag,
+                                                 double thr, const double *__restrict__ tmin,
+                                                 const double *__restrict__ tmax, const double *__restrict__ tmin2,
+                                                 const double *__restrict__ tmax2, int *__restrict__ hot,
+                                                 int *__restrict__ brute, int *__restrict__ counters,
+                                                 int2 *__restrict__ cand, int *__restrict__ cand_cnt,
+                                                 unsigned long long *__restrict__ work) {
+    __shared__ CellShared sh;
+    const int j = blockIdx.x, tid = threadIdx.x;
+    if (j >= n_jobs) return;
+    const Job job = jobs[j];
+    const int L = job.hi - job.lo;
+    if (L <= 0) return;
+    if (!reg_flag[job.region]) {                  // non-finite region: the exact scan
+        if (tid == 0) brute[atomicAdd(&counters[3], 1)] = j;
+        return;
+    }
+    const Region rg = regions[job.region];
+    const double eps = window_eps(rg.n, reg_abs[job.region]);
+    const double T = thr - eps;
+    const long long base = rg.off + job.region + job.lo, a_hi = base + L;
+#ifdef WC_CELL_CLOCKS
+    if (tid < 32) sh.clk[tid] = 0ull;
+    if (tid == 0) sh.t_prev = clock64();
+    const unsigned long long t_begin = clock64();
+    __syncthreads();
+#endif
+    cell_stage_tables(sh, base, a_hi, tmin, tmax, tmin2, tmax2, rs, tid);
+    if (tid == 0) { sh.n_hi = 0; sh.n_lo = 0; }
+    __syncthreads();
+    // the starting cuts (k_seg_seed): the window from the minimum of block a to the maximum of block b, both wholly
+    // inside the job, is worth at least (max_b - min_a) * rs[(b - a + 1) 32]
+    {
+        double hi = T, lo = -T, d0 = -INFINITY, d1 = INFINITY;
+        const long long k1 = base >> 5;
+        const int b_first = (int)((base + QB - 1) / QB - k1), b_last = (int)((a_hi + 1) / QB - 1 - k1);
+        // a wave per start block, a lane per end block
+        for (int a = b_first + (tid >> 6); a < b_last; a += 4) {
+            const double mn_a = sh.tmn[a], mx_a = sh.tmx[a];
+            for (int b = a + 1 + (tid & 63); b <= b_last; b += 64) {
+                const double r = rs_below((b - a + 1) * QB);
+                const double up = sh.tmx[b] - mn_a, dn = sh.tmn[b] - mx_a;
+                if (up > 0.0) hi = fmax(hi, up * r);
+                if (dn < 0.0) lo = fmin(lo, dn * r);
+            }
+        }
+        block_minmax4(hi, lo, d0, d1, tid);
+        if (tid == 0) { sh.cut[0] = wc::f64_ordered(hi); sh.cut[1] = wc::f64_ordered(-lo); }
+    }
+    __syncthreads();
+    CJ_CLK(1);
+    double vmax = -INFINITY, vmin = INFINITY, d2 = -INFINITY, d3 = INFINITY;
+    int wins = 0, evals = 0;
+    cell_search<0>(sh, base, L, job.lo, prefix, rs, INFINITY, -INFINITY, vmax, vmin, wins, evals, tid);
+    block_minmax4(vmax, vmin, d2, d3, tid);
+    const bool is_hot = !(fmax(fabs(vmax), fabs(vmin)) + eps < thr);        // k_seg_classify's test
+    if (is_hot) {
+        // the windows within 2 eps of the extremes, only for a side that can hold a call
+        const double hi_cut = !(vmax + eps < thr) ? vmax - 2.0 * eps : INFINITY;
+        const double lo_cut = !(-vmin + eps < thr) ? vmin + 2.0 * eps : -INFINITY;
+        double e0 = -INFINITY, e1 = INFINITY;
+        cell_search<2>(sh, base, L, job.lo, prefix, rs, hi_cut, lo_cut, e0, e1, wins, evals, tid);
+        __syncthreads();
+        if (tid == 0) {
+            const int h = atomicAdd(&counters[2], 1);
+            hot[h] = j;
+            cand_cnt[2 * h] = sh.n_hi;
+            cand_cnt[2 * h + 1] = sh.n_lo;
+            sh.slot = h;
+        }
+        __syncthreads();
+        const int h = sh.slot;
+        const int n_hi = sh.n_hi < CAND_CAP ? sh.n_hi : CAND_CAP, n_lo = sh.n_lo < CAND_CAP ? sh.n_lo : CAND_CAP;
+        for (int i = tid; i < n_hi; i += 256) cand[((int64_t)2 * h) * CAND_CAP + i] = sh.c_hi[i];
+        for (int i = tid; i < n_lo; i += 256) cand[((int64_t)2 * h + 1) * CAND_CAP + i] = sh.c_lo[i];
+    }
+#ifdef WC_CELL_CLOCKS
+    __syncthreads();
+    CJ_CLK(15);
+    if (tid == 0) {
+        sh.clk[16] = 1ull;
+        sh.clk[17] = is_hot ? 1ull : 0ull;
+        atomicMax(&g_dbg[48], clock64() - t_begin);          // the longest-lived workgroup
+    }
+    __syncthreads();
+    if (tid < 32) atomicAdd(&g_dbg[tid], sh.clk[tid]);
+#endif
+    if (work) {
+        for (int o = 32; o > 0; o >>= 1) { evals += __shfl_xor(evals, o); wins += __shfl_xor(wins, o); }
+        const int slot = (int)((blockIdx.x * 7u + (unsigned)(tid >> 6)) & 63u);
+        if ((tid & 63) == 0) {
+            atomicAdd(work + 2 * slot, (unsigned long long)wins);
+            atomicAdd(work + 2 * slot + 1, (unsigned long long)evals);
+        }
     }
 }
 
@@ -4130,6 +4559,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     const char *tree_env = getenv("WC_TEST_TREE_TAIL");        // "0": host-driven rounds only
     const bool tree_ok = tail && !bits && max_n <= TREE_MAXLEN && !ts.no_tree && !(tree_env && tree_env[0] == '0');
     const bool bound_path = !bits && !tree_ok;
+    const char *cells_env = getenv("WC_TEST_CELLS");
     if ((rc = ctx->ensure_pinned(256))) return rc;
     int *h = (int *)ctx->pinned;          // counter read-backs land in pinned memory
     h[4] = 0;
@@ -4149,6 +4579,33 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
         // (the certificate stages a job's block table per workgroup: half as many, each with two row blocks, measured
         // 75 -> 61 us at 128 x 250 kb; the bound sweep loses with fewer)
         const unsigned per_job_quiet = (unsigned)std::min<int64_t>(max_chunks, std::max<int64_t>(1, 8192 / n_jobs));
+        // jobs up to CJ_MAXLEN bins: one workgroup per job finds the extremes from cell bounds and lists the candidates
+        // (k_seg_job); WC_TEST_CELLS=0 keeps the row-block kernels (k_seg_seed / k_seg_bound / k_seg_bcollect)
+        const bool cell_path = bound_path && max_n <= CJ_MAXLEN && !(cells_env && cells_env[0] == '0');
+        if (cell_path) {
+            WC_HIP(hipMemsetAsync(counters + 1, 0, sizeof(int) * 3, stream));      // next jobs, hot, brute
+            hipLaunchKernelGGL(k_seg_job, dim3((unsigned)n_jobs), dim3(256), 0, stream, (const Job *)cur, (int)n_jobs,
+                               regions_dev, (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
+                               (const double *)ts.reg_abs.as<double>(), (const int *)ts.reg_flag.as<int>(), thr,
+                               (const double *)ts.tmin.as<double>(), (const double *)ts.tmax.as<double>(),
+                               (const double *)ts.tmin2.as<double>(), (const double *)ts.tmax2.as<double>(),
+                               hot, brute, counters, ts.cand.as<int2>(), ts.cand_cnt.as<int>(), work);
+            ts.mark(11, stream);
+            hipLaunchKernelGGL(k_seg_decide, dim3((unsigned)n_jobs), dim3(256), 0, stream, (const Job *)cur,
+                               (const int *)hot, counters, regions_dev, z_dev, (const int2 *)ts.cand.as<int2>(),
+                               (const int *)ts.cand_cnt.as<int>(), thr, min_search, bits, bit_off, ts.seg.as<Seg>(),
+                               (int)seg_cap, next, (int)job_cap, brute, counters + 1);
+            hipLaunchKernelGGL(k_seg_brute, dim3((unsigned)n_jobs), dim3(256), 0, stream, (const Job *)cur,
+                               (const int *)brute, counters, regions_dev, z_dev, thr, min_search, bits, bit_off,
+                               ts.seg.as<Seg>(), (int)seg_cap, next, (int)job_cap, counters + 1);
+            WC_HIP(hipMemcpyAsync(h, counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
+            WC_HIP(hipStreamSynchronize(stream));
+            WC_CHECK(h[1] <= job_cap, WC_E_INTERNAL, "stouffer: job list overflow");
+            WC_CHECK(h[4] <= seg_cap, WC_E_LIMIT, "stouffer: more than max_calls=%d segments per region", max_calls);
+            n_jobs = h[1];
+            std::swap(cur, next);
+            continue;
+        }
         if (bound_path) {
             if ((rc = ts.cbound.reserve(sizeof(ChunkBound) * n_jobs * max_chunks))) return rc;
             if ((rc = ts.cuts.reserve(sizeof(unsigned long long) * 2 * n_jobs))) return rc;

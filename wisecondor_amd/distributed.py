@@ -148,17 +148,51 @@ def _align(n, a):
     return (n + a - 1) // a * a
 
 
-class NewrefJob(object):
-    """getReference for all rows, on `world` ranks; every rank ends with the full result.
+class _Pending(object):
+    """A collective in flight.  RCCL: the work runs on the communicator's stream, ordered after what the launch
+    stream held when it was issued; wait() makes the launch stream wait for it (the host does not block).
+    gloo with device tensors (CPU tests, ranks sharing a GPU): the tensors were staged to the host before the
+    collective started; wait() blocks the host and copies the result back."""
 
-    Collectives per run: tiles mode 3 (thresholds all-gather, one all-to-all carrying counts
-    and lists, one all-gather carrying indexes and distances), rows mode 1 (the all-gather).
-    Counts+lists and indexes+distances share one byte buffer each so that they travel in
-    one collective; the result all-gather is in place (the rank's own slot is its finish
-    output)."""
+    def __init__(self, work, after=None):
+        self.work, self.after = work, after
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+        if self.after is not None:
+            self.after()
+        self.work = self.after = None
+
+
+def band_count(default=4):
+    """Row bands per rank of the multi-rank pipeline (WC_NEWREF_BANDS; 1 = one exchange, one gather)."""
+    try:
+        return max(1, int(os.environ.get("WC_NEWREF_BANDS", default)))
+    except ValueError:
+        return default
+
+
+class NewrefJob(object):
+    """getReference for all rows, on `world` ranks.
+
+    A rank's rows (the reference's getPart) are cut into `bands` row bands and the multi-rank step is a
+    software pipeline over them, every collective issued with async_op=True so that it runs on the
+    communicator's stream beside the launch stream's kernels:
+
+      tiles  thresholds all-gather (small, blocking); the rank's share of the symmetric tile space; then per
+             band: export of the band's foreign lists -> all-to-all (async) -- and, one band behind, import ->
+             re-score of the band's own rows -> all-gather of the band's results (async).  The exchange of
+             band i + 1 and the result gather of band i - 1 travel while band i is re-scored.
+      rows   the rank's row band against all columns; per band: re-score -> all-gather (async).
+
+    Counts + lists and indexes + distances share one byte buffer per band so that they travel in one
+    collective.  gather=False (the command line tool: every rank writes the part files of the rows it owns,
+    wisecondor.py:47-56 -- the reference's workers exchange nothing but files) skips the result gathers and
+    run() returns the rank's own rows."""
 
     def __init__(self, ctx, X, chrom_bins, k, sum_order, rank=0, world=1, stages=None, dist=None, mode=None,
-                 passes=1, collectives=False):
+                 passes=1, collectives=False, bands=None, gather=True):
         """`passes`: how many times the caller expects to run() this job.  The shard mode of a
         multi-rank job is measured (calibrate: four extra passes) only from CALIBRATE_FROM_PASSES
         on or with WC_NEWREF_SHARD=measure; a one-shot job (the CLI) takes the symmetric tile shard."""
@@ -176,10 +210,12 @@ class NewrefJob(object):
             import torch.distributed as dist
         self.dist = dist
         self.mode = mode            # None: measured at the first run (calibrate), unless WC_NEWREF_SHARD pins it
+        self.gather = bool(gather)
         self.calibration = None
-        self._checked = False       # calibration passes: ranks agree on every local step's outcome (_local)
+        self._checked = False       # calibration warm-up passes: ranks agree on every local step's outcome (_local)
         self._marks = None
         self.last_marks = None
+        self.comm_log = None        # run(timing=True): one entry per collective {name, bytes, ms (blocking)}
         self.chrom_bins = np.asarray(chrom_bins, dtype=np.int64)
         self.ranges = [row_range(r, self.world, self.n_bins) for r in range(self.world)]
         self.max_rows = max(e - b for b, e in self.ranges)
@@ -188,69 +224,115 @@ class NewrefJob(object):
         if self.single:
             self.idx = e((self.n_bins, self.k), t.int32)
             self.dst = e((self.n_bins, self.k), t.float64)
-        else:
-            # result slots [world, dst f64 | idx i32], one all-gather for both
-            n = self.max_rows * self.k
-            self.res_bytes = _align(n * 12, 16)
-            self.res_all = e((self.world, self.res_bytes), t.uint8)
-            self.dst_all = [self.res_all[r, :n * 8].view(t.float64).view(self.max_rows, self.k)
-                            for r in range(self.world)]
-            self.idx_all = [self.res_all[r, n * 8:n * 12].view(t.int32).view(self.max_rows, self.k)
-                            for r in range(self.world)]
-            self.thr_all = e((self.world, self.max_rows), t.float32)
-            self.buffers_ready = False
+            return
+        # row bands: band i of rank r = rows [b_r + i * band_rows, ...) clipped to the rank's range (the same band
+        # length on every rank: equal blocks per collective; a rank with one row less has a shorter last band)
+        want = band_count() if bands is None else max(1, int(bands))
+        self.band_rows = max(1, -(-self.max_rows // want))
+        self.n_bands = -(-self.max_rows // self.band_rows)
+        n = self.band_rows * self.k
+        # result slots per band: [dst f64 | idx i32] of band_rows rows -- `own` is what finish writes and the
+        # all-gather sends, `res` [band, rank, bytes] what it delivers
+        self.res_bytes = _align(n * 12, 16)
+        self.own = e((self.n_bands, self.res_bytes), t.uint8)
+        self.own_dst = [self.own[i, :n * 8].view(t.float64).view(self.band_rows, self.k) for i in range(self.n_bands)]
+        self.own_idx = [self.own[i, n * 8:n * 12].view(t.int32).view(self.band_rows, self.k) for i in range(self.n_bands)]
+        if self.gather:
+            self.res = e((self.n_bands, self.world, self.res_bytes), t.uint8)
+            self.res_dst = self.res[:, :, :n * 8].view(t.float64).view(self.n_bands, self.world, self.band_rows, self.k)
+            self.res_idx = self.res[:, :, n * 8:n * 12].view(t.int32).view(self.n_bands, self.world, self.band_rows, self.k)
+            # where row g of the [bins, k] result sits in `res`: (band, rank, row of the band)
+            owner = np.zeros(self.n_bins, dtype=np.int64)
+            local = np.zeros(self.n_bins, dtype=np.int64)
+            for r, (b, en) in enumerate(self.ranges):
+                owner[b:en] = r
+                local[b:en] = np.arange(en - b)
+            dev = self.own.device
+            self._map = tuple(t.from_numpy(np.ascontiguousarray(a)).to(dev)
+                              for a in (local // self.band_rows, owner, local % self.band_rows))
+        self.thr_all = e((self.world, self.max_rows), t.float32)
+        self.buffers_ready = False
+
+    def band(self, r, i):
+        """Global row range of band i of rank r (empty when the rank's range ends before it)."""
+        b, e = self.ranges[r]
+        lo = min(e, b + i * self.band_rows)
+        return lo, min(e, lo + self.band_rows)
 
     # Collectives: RCCL moves device tensors directly; under gloo (CPU tests, or two ranks
     # sharing one GPU in tests) device tensors are staged through host memory.
     def _needs_staging(self, t):
         return self.dist.get_backend() == "gloo" and t.device.type != "cpu"
 
-    def _all_gather(self, out, own):
-        """In-place all-gather: `own` is this rank's slot of `out`."""
-        if self._needs_staging(out):
-            o = out.cpu()
-            self.dist.all_gather_into_tensor(o, own.cpu())
-            out.copy_(o)
-        else:
-            # `own` aliases a slot of `out`: RCCL and gloo both accept a separate send buffer for certain,
-            # and the copy is a few microseconds next to the collective
-            self.dist.all_gather_into_tensor(out, own.clone())
+    def _timed_collective(self, name, nbytes, issue):
+        """Issue a collective; in a timing run (run(timing=True)) it is waited for on the spot between two events
+        on the launch stream, so that its own duration (with the wait for the slowest peer) is on record."""
+        if self.comm_log is None or self._marks is None:
+            return issue()
+        ev = self.torch.cuda.Event
+        cuda = getattr(self.st, "device", None) is not None and self.st.device.type == "cuda"
+        a, b = (ev(enable_timing=True), ev(enable_timing=True)) if cuda else (None, None)
+        import time
+        t0 = time.perf_counter()
+        if cuda:
+            a.record()
+        pending = issue()
+        pending.wait()
+        if cuda:
+            b.record()
+        self.comm_log.append({"name": name, "bytes": int(nbytes), "events": (a, b),
+                              "host_ms": 1e3 * (time.perf_counter() - t0)})
+        return _Pending(None)
 
-    def _all_to_all(self, out, inp):
-        if self._needs_staging(inp):
-            o = out.cpu()
-            self.dist.all_to_all_single(o, inp.cpu())
-            out.copy_(o)
-        else:
-            self.dist.all_to_all_single(out, inp)
+    def _all_gather(self, out, own, name="all_gather"):
+        """All-gather of `own` (every rank's block) into `out`, in flight when this returns."""
+        def issue():
+            if self._needs_staging(out):
+                o = out.cpu()
+                work = self.dist.all_gather_into_tensor(o, own.cpu(), async_op=True)
+                return _Pending(work, lambda: out.copy_(o))
+            return _Pending(self.dist.all_gather_into_tensor(out, own, async_op=True))
+        return self._timed_collective(name, out.numel() * out.element_size(), issue)
+
+    def _all_to_all(self, out, inp, name="all_to_all"):
+        def issue():
+            if self._needs_staging(inp):
+                o = out.cpu()
+                work = self.dist.all_to_all_single(o, inp.cpu(), async_op=True)
+                return _Pending(work, lambda: out.copy_(o))
+            return _Pending(self.dist.all_to_all_single(out, inp, async_op=True))
+        return self._timed_collective(name, out.numel() * out.element_size(), issue)
 
     def _alloc_exchange(self):
         t = self.torch
         e = self.st.empty
         self.cap_x = exchange_capacity(self.st.cap, self.world)
-        # per destination rank: [counts i32 x max_rows | lists i64 x max_rows x cap_x]
-        off = _align(self.max_rows * 4, 16)
-        self.x_bytes = off + self.max_rows * self.cap_x * 8
-        self.send = e((self.world, self.x_bytes), t.uint8)
-        self.recv = e((self.world, self.x_bytes), t.uint8)
+        # per band and destination rank: [counts i32 x band_rows | lists i64 x band_rows x cap_x]
+        off = _align(self.band_rows * 4, 16)
+        self.x_bytes = off + self.band_rows * self.cap_x * 8
+        self.send = e((self.n_bands, self.world, self.x_bytes), t.uint8)
+        self.recv = e((self.n_bands, self.world, self.x_bytes), t.uint8)
 
         def views(buf):
-            cnt = [buf[r, :self.max_rows * 4].view(t.int32) for r in range(self.world)]
-            lst = [buf[r, off:].view(t.int64).view(self.max_rows, self.cap_x) for r in range(self.world)]
+            cnt = [[buf[i, r, :self.band_rows * 4].view(t.int32) for r in range(self.world)] for i in range(self.n_bands)]
+            lst = [[buf[i, r, off:].view(t.int64).view(self.band_rows, self.cap_x) for r in range(self.world)]
+                   for i in range(self.n_bands)]
             return cnt, lst
         self.send_cnt, self.send_lst = views(self.send)
         self.recv_cnt, self.recv_lst = views(self.recv)
-        self.send_cnt_all = self.send[:, :off]
+        self.send_cnt_all = self.send[:, :, :off]
         self.buffers_ready = True
 
-    def _gather_results(self):
-        self._all_gather(self.res_all.view(-1), self.res_all[self.rank])
-        # the ranks' slots (padded to the longest row band) into the [bins, k] result, buffers kept across passes
-        if getattr(self, "idx_full", None) is None:
-            self.idx_full = self.st.empty((self.n_bins, self.k), self.torch.int32)
-            self.dst_full = self.st.empty((self.n_bins, self.k), self.torch.float64)
-        self.torch.cat([self.idx_all[r][:e - b] for r, (b, e) in enumerate(self.ranges)], out=self.idx_full)
-        self.torch.cat([self.dst_all[r][:e - b] for r, (b, e) in enumerate(self.ranges)], out=self.dst_full)
+    def _assemble(self):
+        """The bands' slots into the [bins, k] result (one gather per array; buffers kept across passes)."""
+        if not self.gather:
+            rows = self.ranges[self.rank][1] - self.ranges[self.rank][0]
+            idx = self.torch.cat(self.own_idx)[:rows]
+            dst = self.torch.cat(self.own_dst)[:rows]
+            return idx, dst
+        bi, ri, ti = self._map
+        self.idx_full = self.res_idx[bi, ri, ti]
+        self.dst_full = self.res_dst[bi, ri, ti]
         return self.idx_full, self.dst_full
 
     def calibrate(self):
@@ -268,20 +350,13 @@ class NewrefJob(object):
             state, err, elapsed = 2, None, 0.0           # 2 ok, 1 the backend lacks an exchange collective, 0 failed
             try:
                 # warm-up pass (buffers, tile lists, communicator) with the ranks agreeing on every local step
-                # before the next collective; the TIMED pass runs as a production pass does -- the agreement's
-                # all-reduces and host synchronisations (four per pass in the tile shard, two in the row shard)
-                # would otherwise be part of what is compared
+                # before the next collective: whatever can fail on one rank alone (memory, a kernel fault) fails here
                 self._checked = True
                 try:
                     self._run()
                 finally:
                     self._checked = False
                 self._sync()
-                self.dist.barrier()
-                t0 = time.perf_counter()
-                self._run()
-                self._sync()
-                elapsed = time.perf_counter() - t0
             except Exception as exc:
                 err = exc
                 state = 1 if (mode == "tiles" and _unsupported(exc)) else 0
@@ -295,8 +370,18 @@ class NewrefJob(object):
             if state == 1:
                 times[mode] = None
                 times["tiles_error"] = "%s: %s" % (type(err).__name__, err) if err is not None else "on another rank"
-            else:
-                times[mode] = self._max_over_ranks(elapsed)
+                continue
+            # the TIMED pass runs as a production pass does (collectives in flight beside the kernels; the
+            # agreement's all-reduces and host synchronisations would be what is compared otherwise).  The same
+            # buffers, lists and communicator have just worked; should this pass still fail on one rank, that rank
+            # must NOT enter the agreement below while its peers sit in the pass's collectives: the error leaves
+            # calibrate() at once, the process ends non-zero and the launcher (ranks.launch, torchrun) stops the peers
+            self.dist.barrier()
+            t0 = time.perf_counter()
+            self._run()
+            self._sync()
+            elapsed = time.perf_counter() - t0
+            times[mode] = self._max_over_ranks(elapsed)
         self.mode = None
         self._marks = marks
         self.calibration = times
@@ -321,28 +406,49 @@ class NewrefJob(object):
         return float(t.item())
 
     def _mark(self, name):
-        """Record a timing event on the launch stream (only while `timing` is on)."""
+        """Record a timing event on the launch stream (only while `timing` is on): the time since the previous
+        mark is booked under `name`."""
         if self._marks is not None:
             ev = self.torch.cuda.Event(enable_timing=True)
             ev.record()
-            self._marks[name] = ev
+            self._marks.append((name, ev))
+
+    STAGES = ("prepared", "thresholds", "collected", "exported", "exchanged", "picked", "rescored", "finished", "gathered")
 
     def stage_ms(self):
-        """Milliseconds between the marks of the last timed run (call after a synchronize)."""
-        m = self.last_marks or {}
-        order = ["start", "prepared", "thresholds", "collected", "exchanged", "picked", "rescored", "finished", "gathered"]
-        have = [n for n in order if n in m]
-        return {"%s->%s" % (a, b): m[a].elapsed_time(m[b]) for a, b in zip(have, have[1:])}
+        """Milliseconds of the last timed run's stages (call after a synchronize): every interval between two
+        marks is booked under the later mark's name and the bands' intervals add up -- prepared, thresholds,
+        collected (the tile kernel), [exported, exchanged (import)], picked, rescored, finished (exact path),
+        [gathered (assembly)]; `comm` = the collectives, each waited for on the spot in a timing run."""
+        m = self.last_marks or []
+        out = {}
+        for (_, a), (name, b) in zip(m, m[1:]):
+            out[name] = out.get(name, 0.0) + a.elapsed_time(b)
+        return out
+
+    def collective_ms(self):
+        """The collectives of the last run(timing=True), each waited for on the spot (its own duration incl. the
+        wait for the slowest peer): [{name, bytes, ms}] (call after a synchronize)."""
+        out = []
+        for c in self.last_comm or []:
+            a, b = c["events"]
+            out.append({"name": c["name"], "bytes": c["bytes"],
+                        "ms": a.elapsed_time(b) if a is not None else c["host_ms"]})
+        return out
+
+    last_comm = None
 
     def run(self, timing=False):
-        """One pass.  timing=True records torch events between the stages on the launch stream
-        (read them with stage_ms() after a synchronize): prepared, thresholds, collected,
-        [exchanged], rescored (k_finish fast path alone), finished (+ exact path), [gathered]."""
-        self._marks = {} if timing else None
+        """One pass.  timing=True records torch events between the stages on the launch stream (stage_ms() after
+        a synchronize) and, on several ranks, waits for every collective where it is issued (collective_ms()):
+        a diagnostic pass -- the production pass keeps the collectives in flight beside the kernels."""
+        self._marks = [] if timing else None
+        self.comm_log = [] if timing else None
         try:
             return self._run()
         finally:
             self.last_marks, self._marks = self._marks, None
+            self.last_comm, self.comm_log = self.comm_log, None
 
     def _run(self):
         st = self.st
@@ -366,18 +472,40 @@ class NewrefJob(object):
             self.mode = forced_shard_mode() or (self.calibrate() if measure else "tiles")
             self._untried = not measure and forced_shard_mode() is None       # one-shot job: the tile shard, untested
             st.prepare()
+        bands = range(self.n_bands)
+        gathers = []
+
+        def finish_rows(i):
+            b, e = self.band(self.rank, i)
+            if e > b:
+                self._finish(b, e, self.own_idx[i], self.own_dst[i])
+
+        def gather_band(i):
+            # (a collective is never issued inside _local: a rank whose local step failed must not have entered it)
+            if self.gather:
+                gathers.append(self._all_gather(self.res[i].view(-1), self.own[i], "result_all_gather[%d]" % i))
+                self._mark("comm")
+
+        def finish_all():
+            for g in gathers:
+                g.wait()
+            out = self._assemble()
+            self._mark("gathered")
+            return out
+
         if self.mode == "rows":
-            # row band of this rank against all columns: no exchange, one collective
-            def band():
+            # row band of this rank against all columns: no exchange; the result gather of band i travels while
+            # band i + 1 is re-scored
+            def head():
                 st.thresholds(rb, re)
                 self._mark("thresholds")
                 st.collect(rb, re, 0, 1)
                 self._mark("collected")
-                self._finish(rb, re, self.idx_all[self.rank], self.dst_all[self.rank])
-            self._local(band)
-            out = self._gather_results()
-            self._mark("gathered")
-            return out
+            self._local(head)
+            for i in bands:
+                self._local(lambda i=i: finish_rows(i))
+                gather_band(i)
+            return finish_all()
 
         # thresholds: owner computes, everyone needs them for the tiles it was dealt
         def own_thresholds():
@@ -387,10 +515,11 @@ class NewrefJob(object):
             self.thr_all[self.rank].zero_()
             st.get_thr(rb, re, self.thr_all[self.rank])
         self._local(own_thresholds)
-        self._all_gather(self.thr_all.view(-1), self.thr_all[self.rank])
+        self._mark("thresholds")
+        self._all_gather(self.thr_all.view(-1), self.thr_all[self.rank].clone(), "threshold_all_gather").wait()
+        self._mark("comm")
 
-        # this rank's share of the symmetric tile space, candidates for all rows; the lists of
-        # foreign rows are packed for their owners
+        # this rank's share of the symmetric tile space, candidates for all rows
         def tiles():
             for r, (b, e) in enumerate(self.ranges):
                 if r != self.rank:
@@ -399,15 +528,27 @@ class NewrefJob(object):
             st.collect(0, self.n_bins, self.rank, self.world)
             self._mark("collected")
             self.send_cnt_all.zero_()
-            for r, (b, e) in enumerate(self.ranges):
-                if r != self.rank:
-                    st.export(b, e, self.cap_x, self.send_cnt[r], self.send_lst[r])
         self._local(tiles)
+
+        # the lists of foreign rows travel to their owners band by band
+        def export_band(i):
+            for r in range(self.world):
+                b, e = self.band(r, i)
+                if r != self.rank and e > b:
+                    st.export(b, e, self.cap_x, self.send_cnt[i][r], self.send_lst[i][r])
+            self._mark("exported")
+
+        exchanges = []
         try:
-            self._all_to_all(self.recv.view(-1), self.send.view(-1))
+            for i in bands:
+                self._local(lambda i=i: export_band(i))
+                exchanges.append(self._all_to_all(self.recv[i].view(-1), self.send[i].view(-1), "list_all_to_all[%d]" % i))
+                self._mark("comm")
+                if i == 0 and getattr(self, "_untried", False):
+                    exchanges[0].wait()          # a backend without the collective says so here at the latest
         except Exception as exc:
             # a one-shot job takes the tile shard without having tried it: a backend that does not offer the
-            # exchange collective says so on every rank alike, and the row shard (one all-gather) takes over
+            # exchange collective says so on every rank alike, and the row shard (all-gathers only) takes over
             if not (getattr(self, "_untried", False) and _unsupported(exc)):
                 raise
             self.mode, self._untried = "rows", False
@@ -415,20 +556,23 @@ class NewrefJob(object):
             return self._run()
         self._untried = False
 
-        # owners merge what they received and finish their rows; results to everyone
-        def own_rows():
-            for r in range(self.world):
-                if r != self.rank:
-                    st.import_(rb, re, self.cap_x, self.recv_cnt[r], self.recv_lst[r])
+        # owners merge what they received and finish their rows, one band behind the exchange
+        def own_band(i):
+            b, e = self.band(self.rank, i)
+            if e > b:
+                for r in range(self.world):
+                    if r != self.rank:
+                        st.import_(b, e, self.cap_x, self.recv_cnt[i][r], self.recv_lst[i][r])
             self._mark("exchanged")
-            self._finish(rb, re, self.idx_all[self.rank], self.dst_all[self.rank])
-        self._local(own_rows)
-        out = self._gather_results()
-        self._mark("gathered")
-        return out
+            finish_rows(i)
+        for i in bands:
+            exchanges[i].wait()
+            self._local(lambda i=i: own_band(i))
+            gather_band(i)
+        return finish_all()
 
     def _local(self, work):
-        """This rank's work between two collectives.  During the calibration passes (`_checked`) the
+        """This rank's work between two collectives.  During the calibration warm-up passes (`_checked`) the
         ranks agree on its outcome before any of them enters the next collective: a rank that failed
         would otherwise leave its peers waiting there."""
         if not self._checked:
