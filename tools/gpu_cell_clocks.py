@@ -26,13 +26,11 @@ _lib.check(lib.wc_debug_times(ctx, 0, _lib.ptr(a)))
 tb.run()
 _lib.check(lib.wc_debug_times(ctx, 0, _lib.ptr(b)))
 d = (b - a).astype(np.float64)
-jobs, hot = d[16], d[17]
-print("jobs %d, hot %d, longest workgroup %.0f ticks (all-time max)" % (jobs, hot, float(b[48])))
-names = {1: "tables + seed", 2: "search: near sweep", 3: "search: cell sweeps", 4: "search: refine", 10: "collect: near sweep",
-         11: "collect: cell sweeps", 12: "collect: refine", 15: "classify + write"}
+wgs = d[16]
+print("workgroups (job parts) %d, longest-lived %.0f ticks (all-time max)" % (wgs, float(b[48])))
+names = {1: "tables + seed", 2: "search: near sweep", 3: "search: cell sweeps", 4: "search: rows + windows", 10: "2nd pass: near sweep",
+         11: "2nd pass: cell sweeps", 12: "2nd pass: rows + windows", 15: "merge + classify + write"}
 tot = sum(d[k] for k in names)
 for k, n in names.items():
-    per = hot if k in (10, 11, 12) else jobs
-    print("%-22s %10.0f kticks %5.1f %%  %8.0f ticks per %s" % (n, d[k] / 1e3, 100 * d[k] / tot, d[k] / max(per, 1), "hot job" if per is hot else "job"))
-print("loud cells per job: search %.1f, collect %.1f per hot job; queue overflows: search %d, collect %d"
-      % (d[5] / jobs, d[13] / max(hot, 1), d[6], d[14]))
+    print("%-26s %10.0f kticks %5.1f %%  %8.0f ticks per workgroup" % (n, d[k] / 1e3, 100 * d[k] / tot, d[k] / max(wgs, 1)))
+print("loud cells per workgroup: 128 x 128 %.1f, 32 x 32 band %.1f; second passes: %d / %d" % (d[5] / wgs, d[6] / wgs, d[13], d[14]))

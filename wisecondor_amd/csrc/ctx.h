@@ -42,7 +42,7 @@ struct TestState {
     wc::DevBuf zc, rc, gpos, clean_n, regions, sel;
     wc::DevBuf res_z, res_r, cwz, calls, n_calls;
     // Stouffer search
-    wc::DevBuf zs, rs2, ns2, sds, sub, tmin, tmax, tmin2, tmax2, t8min, t8max, prefix, reg_abs, reg_flag, rs, jobs_a, jobs_b, job_cnt, partial, cbound, cuts, job_res, hot, cand, cand_cnt;
+    wc::DevBuf zs, rs2, ns2, sds, sub, tmin, tmax, tmin2, tmax2, cell_state, cell_rec, prefix, reg_abs, reg_flag, rs, jobs_a, jobs_b, job_cnt, partial, cbound, cuts, job_res, hot, cand, cand_cnt;
     wc::DevBuf seg, seg_cnt, out_val, out_x, out_y, out_n, whole, effect, misc, misc2, reduce_tmp, win_bits, bit_off, pairs_a, pairs_b, cut_vals;
     int64_t rs_len = 0;
     int64_t last_segs = 0;       // segments of the last segmentation call; negative: -(bound), the count is on the device
@@ -125,7 +125,7 @@ struct wc_ctx {
                 &nr.stats, &nr.tiles0, &nr.pw_prog, &nr.pairs, &nr.x64, &nr.m2, &nr.a16, &nr.s16, &tmp_a, &tmp_b, &tmp_c, &tmp_d,
                 &ts.counts, &ts.totals, &ts.raw, &ts.proj, &ts.data, &ts.xt, &ts.xc, &ts.zt, &ts.rt, &ts.nt,
                 &ts.sdt, &ts.z, &ts.r, &ts.n, &ts.sd_avg, &ts.zc, &ts.rc, &ts.gpos, &ts.clean_n, &ts.regions,
-                &ts.sel, &ts.res_z, &ts.res_r, &ts.cwz, &ts.calls, &ts.n_calls, &ts.zs, &ts.rs2, &ts.ns2, &ts.sds, &ts.sub, &ts.tmin, &ts.tmax, &ts.tmin2, &ts.tmax2, &ts.t8min, &ts.t8max, &ts.prefix, &ts.reg_abs,
+                &ts.sel, &ts.res_z, &ts.res_r, &ts.cwz, &ts.calls, &ts.n_calls, &ts.zs, &ts.rs2, &ts.ns2, &ts.sds, &ts.sub, &ts.tmin, &ts.tmax, &ts.tmin2, &ts.tmax2, &ts.cell_state, &ts.cell_rec, &ts.prefix, &ts.reg_abs,
                 &ts.reg_flag, &ts.rs, &ts.jobs_a, &ts.jobs_b, &ts.job_cnt, &ts.partial, &ts.cbound, &ts.cuts, &ts.job_res, &ts.hot,
                 &ts.cand, &ts.cand_cnt, &ts.seg, &ts.seg_cnt, &ts.out_val, &ts.out_x, &ts.out_y, &ts.out_n,
                 &ts.whole, &ts.effect, &ts.misc, &ts.misc2, &ts.reduce_tmp, &ts.win_bits, &ts.bit_off, &ts.pairs_a, &ts.pairs_b, &ts.cut_vals, &ts.prof_work, &ts.sd_fail, &prep.eig_ws};

@@ -2559,28 +2559,50 @@ __global__ __launch_bounds__(256) void k_seg_bcollect(const Job *__restrict__ jo
 // The bound-driven search above gives every block of 64 + 64 rows to a workgroup and sweeps, per ROW, one bound
 // per end block: ~60 evaluations per row and, per row block, a chain of staging, sweep, queue pass and reduction
 // (phase clocks of round 5: 21 k ticks per row block, no phase above a quarter).  The same bounds hold for whole
-// CELLS -- a block of rows against a block of ends, both read from the block tables:
+// CELLS -- a block of rows against a block of ends, both read from block tables:
 //     ub(A, K) = max(max P over K - min P over A, 0) * rs_above(shortest window of the cell)  >=  every window of it
-// -- so one workgroup per JOB decides 128 x 128 and 32 x 32 windows at a time and only descends into the cells that
-// reach the cut: cell -> rows (one bound each) -> windows.  A job's windows are tiled exactly once by
-//   * the row's first 8..15 window lengths (ends inside its own and the next 8-entry block)        by value,
-//   * the 8-entry blocks after them up to the end of the row's next 32-block (lengths below 64)   by bound,
-//   * 32 x 32 cells (A, K), K >= A + 2, whose 128-blocks are the same or adjacent (below 256)     by bound,
-//   * 128 x 128 cells (A2, K2), K2 >= A2 + 2                                                       by bound,
+// -- so 128 x 128, 32 x 32 and 8 x 8 windows are decided at a time and only the cells that reach the cut are
+// taken apart: cell -> rows (one bound each) -> windows.  A job's windows are tiled exactly once by
+//   * a row against its own 8-entry block (the entries after it) and against the next one          one bound each,
+//   * 8 x 8 cells two or more 8-blocks on, up to the end of the row's next 32-block (below 64 bins),
+//   * 32 x 32 cells (A, K), K >= A + 2, whose 128-blocks are the same or adjacent (below 256 bins),
+//   * 128 x 128 cells (A2, K2), K2 >= A2 + 2,
 // blocks aligned to the concatenated prefix array like the tables (a block that straddles the job's ends bounds a
-// superset).  MODE 0 finds the extremes with rising cuts exactly as bscan_chunk does (the cut only ever takes the
-// value of a window that exists or a lower bound of one, so whatever is skipped lies below the job's final extreme
-// or below thr - eps); MODE 2 lists the windows at or beyond fixed cuts (k_seg_bcollect's job).
-constexpr int CJ_MAXLEN = 8192;                 // longest job of this path (level-1 table 259 entries)
-constexpr int CJ_T1 = CJ_MAXLEN / QB + 3;
-constexpr int CJ_T2 = CJ_MAXLEN / QB2 + 3;
-constexpr int CJ_CELLQ = 1024;                  // loud 32 x 32 cells waiting for their rows; more: every cell is refined in turn
-constexpr int CJ_ITEMQ = 2048;                  // loud (row, 8-entry block) pairs; more: the row evaluates its block itself
+// superset).  The cuts rise exactly as in bscan_chunk -- only to values of windows that exist or lower bounds of
+// such, so whatever is skipped lies below the job's final extreme or below thr - eps -- and every test keeps a
+// margin of 2 eps: a window within 2 eps of the FINAL extreme is therefore always evaluated, and it is recorded
+// when it is (it lies within 2 eps of the cut of that moment), so the candidate list of a job that may hold a call
+// (k_seg_bcollect's product) falls out of the same pass; a second pass with fixed cuts (MODE 2) only runs when
+// that record overflows.
+// A job is worked on by parts(L) workgroups (one per 1024 rows): part p takes the near windows of trip p and every
+// parts-th row block of the cell sweeps; the parts share the job's cuts through global atomics, leave their
+// extremes and records in the job's state and the last one to arrive (a ticket) classifies the job and writes the
+// list.  All indexes inside a job are 32-bit, relative to the start of its first 128-block.
+constexpr int CJ_MAXLEN = 8192;                 // longest job of this path
+constexpr int CJ_T1 = (CJ_MAXLEN + 128) / QB + 2;
+constexpr int CJ_T2 = (CJ_MAXLEN + 128) / QB2 + 2;
+constexpr int CJ_Q2 = 512;                      // loud 128 x 128 cells of a part (a part owns at most ~300)
+constexpr int CJ_Q1 = 320;                      // loud 32 x 32 cells of a part's band next to the near windows (at most ~260)
+constexpr int CJ_ITEMQ = 1024;                  // loud (row, block) pairs: near sweep (more: the pusher evaluates the block itself),
+                                                // and the rows of 32 cells at a time
 constexpr int CJ_RPT = 4;                       // rows per thread and near-sweep trip
-constexpr int CJ_TRIP = 256 * CJ_RPT;           // rows per trip
+constexpr int CJ_TRIP = 256 * CJ_RPT;           // rows per trip = rows per part
+constexpr int CJ_MAXPARTS = CJ_MAXLEN / CJ_TRIP;
 constexpr int CJ_PN = CJ_TRIP + 64;             // the trip's rows and the 64 entries after them
 constexpr int CJ_NB8 = CJ_PN / 8 + 2;           // 8-entry blocks that overlap them
 constexpr int CJ_LOADS = (CJ_PN + 255) / 256;
+constexpr int CJ_REC = 64;                      // near-extreme windows a part records per side
+constexpr int CJ_GREC = 128;                    // ... and a job keeps per side (more: the second pass)
+__host__ __device__ inline int cell_parts(int L) {
+    const int p = (L + CJ_TRIP - 1) / CJ_TRIP;
+    return p < 1 ? 1 : (p > CJ_MAXPARTS ? CJ_MAXPARTS : p);
+}
+struct CellRec { int x, y; double v; };
+struct CellJobState {                           // per job and round, zeroed by the host before the launch
+    unsigned long long cut[2];                  // ordered bit patterns: [0] cut_hi, [1] -cut_lo (0 = below everything)
+    unsigned long long ext[2];                  // ... of the largest value seen, of minus the smallest
+    int ticket, n_rec[2], overflow;
+};
 // Development aid (tools/cell_clocks_variant.py defines WC_CELL_CLOCKS): thread 0 of every k_seg_job workgroup books the
 // clock ticks of its phases in LDS and adds them to g_dbg[phase] when it leaves.
 // WC_CELL_CLOCKS_SWITCH
@@ -2595,95 +2617,110 @@ struct CellShared {
 #endif
     double tmx[CJ_T1], tmn[CJ_T1], tmx2[CJ_T2], tmn2[CJ_T2];
     double pn[CJ_PN];
-    double b8x[CJ_NB8], b8n[CJ_NB8];            // maximum / minimum of the staged entries per (absolute) 8-entry block
+    double b8x[CJ_NB8], b8n[CJ_NB8];            // maximum / minimum of the staged entries per 8-entry block
     double rsn[64];                             // rs[0 .. 63]
-    unsigned long long cut[2];                  // ordered bit patterns: [0] cut_hi, [1] -cut_lo
-    unsigned int cellq[CJ_CELLQ], itemq[CJ_ITEMQ];
-    int n_cells, n_items, n_hi, n_lo, overflow, slot;
-    int2 c_hi[CAND_CAP], c_lo[CAND_CAP];
+    unsigned long long cut[2];                  // this workgroup's view of the job's cuts
+    unsigned int q2[CJ_Q2], q1[CJ_Q1], l1[256], itemq[CJ_ITEMQ];
+    CellRec rec[2][CJ_REC];
+    int n_rec[2];
+    int n_q2, n_q1, n_l1, n_items, slot, last;
 };
 
-// the job's slices of both table levels (and the first 64 table factors) into LDS
-__device__ inline void cell_stage_tables(CellShared &sh, const long long base, const long long a_hi,
-                                         const double *__restrict__ tmin, const double *__restrict__ tmax,
-                                         const double *__restrict__ tmin2, const double *__restrict__ tmax2,
-                                         const double *__restrict__ rs, int tid) {
-    const long long k1 = base >> 5, n1 = (a_hi >> 5) - k1 + 1;
-    for (int i = tid; i < (int)n1; i += 256) { sh.tmx[i] = tmax[k1 + i]; sh.tmn[i] = tmin[k1 + i]; }
-    const long long k2 = base >> 7, n2 = (a_hi >> 7) - k2 + 1;
-    for (int i = tid; i < (int)n2; i += 256) { sh.tmx2[i] = tmax2[k2 + i]; sh.tmn2[i] = tmin2[k2 + i]; }
-    if (tid < 64) sh.rsn[tid] = rs[tid];
-}
+// the job's geometry in relative indexes (origin: the start of the 128-block that holds the job's first prefix entry)
+struct CellGeom {
+    const double *P;        // prefix + origin
+    int rb, rhi;            // the job's first and last prefix entry (rows: rb .. rhi - 1)
+    int job_lo;             // region coordinate of row rb
+};
 
+// MODE 0: extremes with rising cuts, near-extreme windows recorded; MODE 2: windows at or beyond fixed cuts
+// recorded (the whole job by the calling workgroup).  part / parts: this workgroup's share (MODE 0).
 template <int MODE>
-__device__ inline void cell_search(CellShared &sh, const long long base, const int L, const int job_lo,
-                                   const double *__restrict__ prefix, const double *__restrict__ rs,
-                                   const double hi_cut, const double lo_cut, double &vmax, double &vmin,
-                                   int &wins, int &evals, const int tid) {
-    const long long a_hi = base + L;                        // the job's last prefix entry (rows: base .. a_hi - 1)
-    const long long A1f = base >> 5, A1l = (a_hi - 1) >> 5, K1l = a_hi >> 5;
-    const long long A2f = base >> 7, A2l = (a_hi - 1) >> 7, K2l = a_hi >> 7;
+__device__ inline void cell_search(CellShared &sh, const CellGeom g, const double *__restrict__ rs, const double eps2,
+                                   const double hi_cut, const double lo_cut, unsigned long long *__restrict__ gcut,
+                                   const int part, const int parts, double &vmax, double &vmin, int &wins, int &evals,
+                                   const int tid) {
+    const double *__restrict__ P = g.P;
+    const int rb = g.rb, rhi = g.rhi;
+    const int A1f = rb >> 5, A1l = (rhi - 1) >> 5, K1l = rhi >> 5;
+    const int A2l = (rhi - 1) >> 7, K2l = rhi >> 7;          // (the first 128-block is block 0)
     const int lane = tid & 63, w = tid >> 6;
-    double chi = hi_cut, clo = lo_cut;
+    double chi = hi_cut, clo = lo_cut;                       // the cuts less / plus the 2 eps margin
     auto cuts = [&]() {
         if (MODE == 0) {
-            chi = wc::f64_from_ordered(__hip_atomic_load(&sh.cut[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-            clo = -wc::f64_from_ordered(__hip_atomic_load(&sh.cut[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            chi = wc::f64_from_ordered(__hip_atomic_load(&sh.cut[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) - eps2;
+            clo = -wc::f64_from_ordered(__hip_atomic_load(&sh.cut[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) + eps2;
+        }
+    };
+    // the job's cuts as the other parts have raised them (thread 0, between barriers)
+    auto share_cuts = [&]() {
+        if (MODE == 0 && parts > 1 && tid == 0) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const unsigned long long mine = sh.cut[q];
+                const unsigned long long theirs = __hip_atomic_load(&gcut[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (theirs > mine) sh.cut[q] = theirs;
+                else if (mine > theirs) atomicMax(&gcut[q], mine);
+            }
+        }
+    };
+    auto record = [&](const int side, const double v, const int ax, const int ay) {
+        const int at = atomicAdd(&sh.n_rec[side], 1);
+        if (at < CJ_REC) {
+            CellRec r;
+            r.x = g.job_lo + (ax - rb);
+            r.y = r.x + (ay - ax) - 1;
+            r.v = v;
+            sh.rec[side][at] = r;
         }
     };
     // a window's value: prefix entries ax (row) and ay (end), ay - ax bins
-    auto see = [&](const double v, const long long ax, const long long ay) {
+    auto see = [&](const double v, const int ax, const int ay) {
         ++wins;
         if (MODE == 0) {
             vmax = fmax(vmax, v);
             vmin = fmin(vmin, v);
-            if (v > chi) { atomicMax(&sh.cut[0], wc::f64_ordered(v)); chi = v; }
-            if (v < clo) { atomicMax(&sh.cut[1], wc::f64_ordered(-v)); clo = v; }
+            if (v >= chi || v <= clo) {
+                cuts();                                      // (rare: against the cuts as they stand now)
+                if (v >= chi) {
+                    record(0, v, ax, ay);
+                    if (v - eps2 > chi) { atomicMax(&sh.cut[0], wc::f64_ordered(v)); chi = v - eps2; }
+                }
+                if (v <= clo) {
+                    record(1, v, ax, ay);
+                    if (v + eps2 < clo) { atomicMax(&sh.cut[1], wc::f64_ordered(-v)); clo = v + eps2; }
+                }
+            }
         } else {
-            const int x = job_lo + (int)(ax - base), y = x + (int)(ay - ax) - 1;
-            if (v >= hi_cut) {
-                const int at = atomicAdd(&sh.n_hi, 1);
-                if (at < CAND_CAP) sh.c_hi[at] = make_int2(x, y);
-            }
-            if (v <= lo_cut) {
-                const int at = atomicAdd(&sh.n_lo, 1);
-                if (at < CAND_CAP) sh.c_lo[at] = make_int2(x, y);
-            }
+            if (v >= hi_cut) record(0, v, ax, ay);
+            if (v <= lo_cut) record(1, v, ax, ay);
         }
     };
     // ---- near windows (ends before the row's first 32 x 32 cell, i.e. fewer than 64 bins): CJ_TRIP rows per trip,
-    // everything of a trip in LDS, the next trip's entries requested while this one is worked on.  Nothing is
-    // evaluated by default: an 8-row block against an 8-end block two or more blocks on is ONE bound from the
-    // 8-entry block extremes, a row against its own and the next 8-block one bound each; what reaches the cut is
-    // queued as (row, 8-block) pairs and evaluated by eight lanes each.
-    double nxt[CJ_LOADS];
-    auto request = [&](const int r0) {
+    // everything of a trip in LDS.  Nothing is evaluated by default: an 8-row block against an 8-end block two or
+    // more blocks on is ONE bound from the 8-entry block extremes, a row against its own and the next 8-block one
+    // bound each; what reaches the cut is queued as (row, 8-block) pairs and evaluated by eight lanes each.
+    const int L = rhi - rb;
+    for (int r0 = (MODE == 0 ? part : 0) * CJ_TRIP; r0 < L; r0 += (MODE == 0 ? parts : 1) * CJ_TRIP) {
+        const int a0 = rb + r0;                              // the trip's first row
+        __syncthreads();                                    // the previous trip's rows and queue are done with
 #pragma unroll
         for (int u = 0; u < CJ_LOADS; ++u) {
             const int i = tid + 256 * u;
-            const long long a = base + r0 + i;
-            nxt[u] = (i < CJ_PN && a <= a_hi) ? prefix[a] : 0.0;
+            if (i < CJ_PN) sh.pn[i] = a0 + i <= rhi ? P[a0 + i] : 0.0;
         }
-    };
-    request(0);
-    for (int r0 = 0; r0 < L; r0 += CJ_TRIP) {
-        const long long a0 = base + r0;
-        __syncthreads();                                    // the previous trip's rows and queue are done with
-#pragma unroll
-        for (int u = 0; u < CJ_LOADS; ++u)
-            if (tid + 256 * u < CJ_PN) sh.pn[tid + 256 * u] = nxt[u];
         if (tid == 0) sh.n_items = 0;
+        share_cuts();
         __syncthreads();
-        if (r0 + CJ_TRIP < L) request(r0 + CJ_TRIP);
-        // maximum / minimum of the staged entries per absolute 8-entry block (entries past the job's end take no part)
-        const long long k8_0 = a0 >> 3;
+        // maximum / minimum of the staged entries per 8-entry block (entries past the job's end take no part)
+        const int k8_0 = a0 >> 3;
         if (tid < CJ_NB8) {
             double mx = -INFINITY, mn = INFINITY;
-            const int i0 = (int)(((k8_0 + tid) << 3) - a0);
+            const int i0 = ((k8_0 + tid) << 3) - a0;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int i = i0 + e;
-                if (i >= 0 && i < CJ_PN && a0 + i <= a_hi) { mx = fmax(mx, sh.pn[i]); mn = fmin(mn, sh.pn[i]); }
+                if (i >= 0 && i < CJ_PN && a0 + i <= rhi) { mx = fmax(mx, sh.pn[i]); mn = fmin(mn, sh.pn[i]); }
             }
             sh.b8x[tid] = mx;
             sh.b8n[tid] = mn;
@@ -2691,29 +2728,30 @@ __device__ inline void cell_search(CellShared &sh, const long long base, const i
         __syncthreads();
         cuts();
         const int rows_here = L - r0 < CJ_TRIP ? L - r0 : CJ_TRIP;           // rows t = 0 .. rows_here - 1 of this trip
+        auto y_near_of = [&](const int ax) {                 // the last end before the row's first 32 x 32 cell
+            const int y = (((ax >> 5) + 2) << 5) - 1;
+            return y > rhi ? rhi : y;
+        };
         auto push = [&](const int t, const int j8) {        // (row t of the trip, staged 8-block j8)
             const int at = atomicAdd(&sh.n_items, 1);
             if (at < CJ_ITEMQ) {
                 sh.itemq[at] = ((unsigned int)t << 8) | (unsigned int)j8;
             } else {                                         // queue full: the pusher walks the block itself
-                const long long ax = a0 + t;
-                long long y_near = (((ax >> 5) + 2) << 5) - 1;
-                if (y_near > a_hi) y_near = a_hi;
+                const int ax = a0 + t, y_near = y_near_of(ax);
                 for (int e = 0; e < 8; ++e) {
-                    const long long ay = ((k8_0 + j8) << 3) + e;
-                    if (ay > ax && ay <= y_near) see((sh.pn[(int)(ay - a0)] - sh.pn[t]) * sh.rsn[(int)(ay - ax)], ax, ay);
+                    const int ay = ((k8_0 + j8) << 3) + e;
+                    if (ay > ax && ay <= y_near) see((sh.pn[ay - a0] - sh.pn[t]) * sh.rsn[ay - ax], ax, ay);
                 }
             }
         };
         // 8 x 8 cells: a thread per 8-row block of the trip, its end blocks two or more on
         for (int jb = tid; jb < CJ_NB8; jb += 256) {
-            const long long A8 = k8_0 + jb;
-            int t_lo = (int)((A8 << 3) - a0), t_hi = t_lo + 7;       // the block's rows within the trip
+            const int A8 = k8_0 + jb;
+            int t_lo = (A8 << 3) - a0, t_hi = t_lo + 7;       // the block's rows within the trip
             if (t_lo < 0) t_lo = 0;
             if (t_hi >= rows_here) t_hi = rows_here - 1;
             if (t_lo > t_hi) continue;
-            long long y_near = (((A8 >> 2) + 2) << 5) - 1;            // the same for the eight rows
-            if (y_near > a_hi) y_near = a_hi;
+            const int y_near = y_near_of(A8 << 3);            // the same for the eight rows
             // (the block's extremes as staged: rows of the neighbouring trip that share it only widen the bound)
             const double rmx = sh.b8x[jb], rmn = sh.b8n[jb];
             for (int j8 = jb + 2; ((k8_0 + j8) << 3) <= y_near; ++j8) {
@@ -2730,11 +2768,10 @@ __device__ inline void cell_search(CellShared &sh, const long long base, const i
         for (int q = 0; q < CJ_RPT; ++q) {
             const int t = tid + 256 * q;
             if (t >= rows_here) continue;
-            const long long ax = a0 + t;
+            const int ax = a0 + t;
             const double px = sh.pn[t];
-            const int kb = (int)((ax >> 3) - k8_0);
-            long long y_near = (((ax >> 5) + 2) << 5) - 1;
-            if (y_near > a_hi) y_near = a_hi;
+            const int kb = (ax >> 3) - k8_0;
+            const int y_near = y_near_of(ax);
             // own block: windows from 1 bin on (the block's extremes include the entries up to the row: a superset)
             {
                 const double ub = fmax(sh.b8x[kb] - px, 0.0), lb = fmin(sh.b8n[kb] - px, 0.0);
@@ -2742,7 +2779,7 @@ __device__ inline void cell_search(CellShared &sh, const long long base, const i
                 if ((ax & 7) != 7 && (ub >= chi || lb <= clo)) push(t, kb);
             }
             if (((k8_0 + kb + 1) << 3) <= y_near) {
-                const int minlen = (int)(((k8_0 + kb + 1) << 3) - ax);       // 1..8
+                const int minlen = ((k8_0 + kb + 1) << 3) - ax;              // 1..8
                 const double r = sh.rsn[minlen];
                 const double ub = fmax(sh.b8x[kb + 1] - px, 0.0) * r, lb = fmin(sh.b8n[kb + 1] - px, 0.0) * r;
                 ++evals;
@@ -2755,172 +2792,221 @@ __device__ inline void cell_search(CellShared &sh, const long long base, const i
         for (int i = tid >> 3; i < n_items; i += 32) {
             const unsigned int it = sh.itemq[i];
             const int t = (int)(it >> 8);
-            const long long ax = a0 + t, ay = ((k8_0 + (it & 255u)) << 3) + (tid & 7);
-            long long y_near = (((ax >> 5) + 2) << 5) - 1;
-            if (y_near > a_hi) y_near = a_hi;
-            if (ay > ax && ay <= y_near) see((sh.pn[(int)(ay - a0)] - sh.pn[t]) * sh.rsn[(int)(ay - ax)], ax, ay);
+            const int ax = a0 + t, ay = ((k8_0 + (int)(it & 255u)) << 3) + (tid & 7);
+            if (ay > ax && ay <= y_near_of(ax)) see((sh.pn[ay - a0] - sh.pn[t]) * sh.rsn[ay - ax], ax, ay);
         }
     }
     __syncthreads();
     CJ_CLK(MODE * 4 + 2);
-    if (tid == 0) { sh.n_cells = 0; sh.overflow = 0; }
+    if (tid == 0) { sh.n_q2 = 0; sh.n_q1 = 0; sh.n_items = 0; }
+    share_cuts();
     __syncthreads();
     cuts();
-    // ---- far windows: cells.  A 32 x 32 cell that reaches the cut is queued for its rows.
-    auto cell1 = [&](const long long A, const long long K) {
-        const int minlen = (int)(((K - A - 1) << 5) + 1);
+    // ---- far windows: cells.  What reaches the cut is queued: 128 x 128 cells and the 32 x 32 cells of the band
+    // between them and the near windows (a part owns a few hundred of each at most: the queues cannot overflow).
+    auto loud1 = [&](const int A, const int K) {
+        const int minlen = ((K - A - 1) << 5) + 1;
         const double r = rs_above(minlen);
-        const double ub = fmax(sh.tmx[K - A1f] - sh.tmn[A - A1f], 0.0) * r;
-        const double lb = fmin(sh.tmn[K - A1f] - sh.tmx[A - A1f], 0.0) * r;
+        const double ub = fmax(sh.tmx[K] - sh.tmn[A], 0.0) * r;
+        const double lb = fmin(sh.tmn[K] - sh.tmx[A], 0.0) * r;
         ++evals;
-        if (ub >= chi || lb <= clo) {
-            const int at = atomicAdd(&sh.n_cells, 1);
-            if (at < CJ_CELLQ) sh.cellq[at] = ((unsigned int)(A - A1f) << 16) | (unsigned int)(K - A1f);
-            else sh.overflow = 1;
-        }
+        return ub >= chi || lb <= clo;
     };
-    // 128 x 128 cells: a wave per row block, a lane per end block; a loud one is taken apart on the spot
-    for (long long A2 = A2f + w; A2 <= A2l; A2 += 4)
-        for (long long K2 = A2 + 2 + lane; K2 <= K2l; K2 += 64) {
-            const int minlen = (int)(((K2 - A2 - 1) << 7) + 1);
+    const int stride = MODE == 0 ? parts : 1, first = MODE == 0 ? part : 0;
+    // 128 x 128 cells: a wave per row block, a lane per end block
+    for (int A2 = first + stride * w; A2 <= A2l; A2 += 4 * stride)
+        for (int K2 = A2 + 2 + lane; K2 <= K2l; K2 += 64) {
+            const int minlen = ((K2 - A2 - 1) << 7) + 1;
             const double r = rs_above(minlen);
-            const double ub = fmax(sh.tmx2[K2 - A2f] - sh.tmn2[A2 - A2f], 0.0) * r;
-            const double lb = fmin(sh.tmn2[K2 - A2f] - sh.tmx2[A2 - A2f], 0.0) * r;
+            const double ub = fmax(sh.tmx2[K2] - sh.tmn2[A2], 0.0) * r;
+            const double lb = fmin(sh.tmn2[K2] - sh.tmx2[A2], 0.0) * r;
             ++evals;
-            if (ub >= chi || lb <= clo)
-                for (int q = 0; q < 16; ++q) {
-                    const long long A = (A2 << 2) + (q >> 2), K = (K2 << 2) + (q & 3);
-                    if (A >= A1f && A <= A1l && K <= K1l) cell1(A, K);
-                }
+            if (ub >= chi || lb <= clo) {
+                const int at = atomicAdd(&sh.n_q2, 1);
+                if (at < CJ_Q2) sh.q2[at] = ((unsigned int)A2 << 16) | (unsigned int)K2;
+            }
         }
     // 32 x 32 cells between the near windows and the 128 x 128 cells: a thread per row block
-    for (long long A = A1f + tid; A <= A1l; A += 256) {
-        long long k_end = (((A >> 2) + 2) << 2) - 1;
+    for (int A = A1f + first + stride * tid; A <= A1l; A += 256 * stride) {
+        int k_end = (((A >> 2) + 2) << 2) - 1;
         if (k_end > K1l) k_end = K1l;
-        for (long long K = A + 2; K <= k_end; ++K) cell1(A, K);
+        for (int K = A + 2; K <= k_end; ++K)
+            if (loud1(A, K)) {
+                const int at = atomicAdd(&sh.n_q1, 1);
+                if (at < CJ_Q1) sh.q1[at] = ((unsigned int)A << 16) | (unsigned int)K;
+            }
     }
     __syncthreads();
     CJ_CLK(MODE * 4 + 3);
-    // ---- the rows of the loud cells: half a wave per cell, a lane per row; a loud row's 32 windows by the same lanes.
-    // Everything a cell needs from memory -- its 32 rows, its 32 ends and the 63 table factors of its window lengths
-    // -- is requested up front, one cell ahead of the one being worked on; the row loop itself only shuffles.
-    const int hl = tid & 31, half = tid & 32;
-    struct CellLoad { long long A, K; double px, py, r_lo, r_hi; };
-    auto fetch = [&](const long long A, const long long K) {
-        CellLoad c;
-        c.A = A; c.K = K;
-        const long long ax = (A << 5) + hl, ay = (K << 5) + hl;
-        c.px = (ax >= base && ax < a_hi) ? prefix[ax] : 0.0;
-        c.py = ay <= a_hi ? prefix[ay] : 0.0;
-        const int len0 = (int)((K - A) << 5) - 31;           // the cell's shortest window; lengths len0 .. len0 + 62
-        c.r_lo = rs[len0 + hl];
-        c.r_hi = rs[len0 + 32 + hl];
-        return c;
-    };
-    auto refine = [&](const CellLoad &c) {
-        const long long A = c.A, K = c.K;
-        const long long ax = (A << 5) + hl, ay = (K << 5) + hl;
-        const bool valid = ax >= base && ax < a_hi;
-        const double px = c.px;
-        const double mx = sh.tmx[K - A1f], mn = sh.tmn[K - A1f];
-        const int minlen = (int)((K << 5) - ax);             // >= 33
-        const double r = rs_above(minlen);
-        const double up = mx - px, dn = mn - px;
-        const double ub = fmax(up, 0.0) * r, lb = fmin(dn, 0.0) * r;
-        ++evals;
-        cuts();
-        const bool loud = valid && (ub >= chi || lb <= clo);
-        if (MODE == 0 && loud && (K << 5) + 31 <= a_hi) {
-            // the end block lies wholly inside the job: the window that ends on its extreme is at most 31 bins
-            // longer than the shortest one -- a lower bound of this row's best window, i.e. a value the cut may take
-            const double r2 = rs_below(minlen + 31);
-            if (ub >= chi && up > 0.0 && up * r2 > chi) atomicMax(&sh.cut[0], wc::f64_ordered(up * r2));
-            if (lb <= clo && dn < 0.0 && dn * r2 < clo) atomicMax(&sh.cut[1], wc::f64_ordered(-(dn * r2)));
-        }
-        unsigned int m = (unsigned int)(__ballot(loud) >> half);
-        while (__any(m != 0u)) {                             // (both halves of the wave stay in step)
-            const bool act = m != 0u;
-            const int rr = act ? __ffs(m) - 1 : 0;
-            m &= m - 1u;
-            const double pxr = __shfl(px, half + rr);
-            // the window from row rr to end hl has length len0 + 31 + hl - rr: factor number 31 + hl - rr of the 63
-            const int fi = 31 + hl - rr;
-            const double f_lo = __shfl(c.r_lo, half + (fi & 31)), f_hi = __shfl(c.r_hi, half + (fi & 31));
-            if (act && ay <= a_hi) see((c.py - pxr) * (fi < 32 ? f_lo : f_hi), (A << 5) + rr, ay);
+    // ---- the loud cells, in bounded steps (a job that is one long aberration ends up evaluating everything, but
+    // nothing overflows): sixteen 128 x 128 cells -> their 256 32 x 32 cells, a thread each; 32 x 32 cells 32 at a
+    // time -> their 1024 rows, four per thread, one bound each; the rows that reach the cut are queued with their
+    // end block and evaluated by half a wave each.
+    const int hl = tid & 31;
+    auto rows_of = [&](const unsigned int *list, const int n) {        // n <= 256 cells of `list` (LDS)
+        for (int c0 = 0; c0 < n; c0 += 32) {
+            __syncthreads();                                          // the previous chunk's queue is drained
+            if (tid == 0) sh.n_items = 0;
+            share_cuts();
+            __syncthreads();
+            cuts();
+            const int nc = n - c0 < 32 ? n - c0 : 32;
+            for (int i = tid; i < nc * 32; i += 256) {
+                const unsigned int e = list[c0 + (i >> 5)];
+                const int K = (int)(e & 0xFFFFu), ax = ((int)(e >> 16) << 5) + (i & 31);
+                if (ax < rb || ax >= rhi) continue;
+                const double px = P[ax];
+                const int minlen = (K << 5) - ax;                    // >= 33
+                const double r = rs_above(minlen);
+                const double up = sh.tmx[K] - px, dn = sh.tmn[K] - px;
+                const double ub = fmax(up, 0.0) * r, lb = fmin(dn, 0.0) * r;
+                ++evals;
+                if (ub >= chi || lb <= clo) {
+                    if (MODE == 0 && (K << 5) + 31 <= rhi) {
+                        // the end block lies wholly inside the job: the window that ends on its extreme is at most 31
+                        // bins longer than the shortest one -- a lower bound of this row's best window, i.e. a value
+                        // the cut may take
+                        const double r2 = rs_below(minlen + 31);
+                        if (ub >= chi && up > 0.0 && up * r2 - eps2 > chi) atomicMax(&sh.cut[0], wc::f64_ordered(up * r2));
+                        if (lb <= clo && dn < 0.0 && dn * r2 + eps2 < clo) atomicMax(&sh.cut[1], wc::f64_ordered(-(dn * r2)));
+                    }
+                    sh.itemq[atomicAdd(&sh.n_items, 1)] = ((unsigned int)ax << 12) | (unsigned int)K;   // (at most 1024)
+                }
+            }
+            __syncthreads();
+            const int n_items = sh.n_items;
+            for (int i = tid >> 5; i < n_items; i += 8) {
+                const unsigned int it = sh.itemq[i];
+                const int ax = (int)(it >> 12), ay = ((int)(it & 4095u) << 5) + hl;
+                if (ay <= rhi) see((P[ay] - P[ax]) * rs[ay - ax], ax, ay);
+            }
         }
     };
-    if (!sh.overflow) {
-        const int nc = sh.n_cells;
-        int c = tid >> 5;
-        CellLoad cur{}, nxt_c{};
-        if (c < nc) cur = fetch(A1f + (sh.cellq[c] >> 16), A1f + (sh.cellq[c] & 0xFFFFu));
-        for (; c < nc; c += 8) {
-            const bool more = c + 8 < nc;
-            if (more) nxt_c = fetch(A1f + (sh.cellq[c + 8] >> 16), A1f + (sh.cellq[c + 8] & 0xFFFFu));
-            refine(cur);
-            cur = nxt_c;
+    {
+        // (the second pass walks the whole job in one workgroup: should a queue overflow there -- only under massive
+        // ties -- the record is marked overflowing, which sends the job to the exact scan)
+        if (MODE == 2 && tid == 0 && (sh.n_q2 > CJ_Q2 || sh.n_q1 > CJ_Q1)) sh.n_rec[0] = CJ_REC + 1;
+        const int n2 = sh.n_q2 < CJ_Q2 ? sh.n_q2 : CJ_Q2, n1 = sh.n_q1 < CJ_Q1 ? sh.n_q1 : CJ_Q1;
+        for (int c2 = 0; c2 < n2; c2 += 16) {
+            __syncthreads();
+            if (tid == 0) sh.n_l1 = 0;
+            __syncthreads();
+            cuts();
+            if (c2 + (tid >> 4) < n2) {
+                const unsigned int e = sh.q2[c2 + (tid >> 4)];
+                const int A = ((int)(e >> 16) << 2) + ((tid >> 2) & 3), K = ((int)(e & 0xFFFFu) << 2) + (tid & 3);
+                if (A >= A1f && A <= A1l && K <= K1l && loud1(A, K))
+                    sh.l1[atomicAdd(&sh.n_l1, 1)] = ((unsigned int)A << 16) | (unsigned int)K;
+            }
+            __syncthreads();
+            rows_of(sh.l1, sh.n_l1);
         }
-    } else {
-        // more loud cells than the queue holds (a job that is one long aberration): every far cell in turn
-        for (long long A = A1f + (tid >> 5); A <= A1l; A += 8)
-            for (long long K = A + 2; K <= K1l; ++K) refine(fetch(A, K));
+        for (int c1 = 0; c1 < n1; c1 += 256) rows_of(sh.q1 + c1, n1 - c1 < 256 ? n1 - c1 : 256);
     }
 #ifdef WC_CELL_CLOCKS
     __syncthreads();
     CJ_CLK(MODE * 4 + 4);
-    if (tid == 0) { sh.clk[MODE * 4 + 5] += (unsigned long long)sh.n_cells; sh.clk[MODE * 4 + 6] += (unsigned long long)sh.overflow; }
+    if (tid == 0) { sh.clk[MODE * 4 + 5] += (unsigned long long)sh.n_q2; sh.clk[MODE * 4 + 6] += (unsigned long long)sh.n_q1; }
 #endif
 }
 
-// One workgroup per job: seed, search, classification and -- for a job that may hold a call -- the candidate list,
-// i.e. k_seg_seed + k_seg_bound + k_seg_classify + k_seg_bcollect of the bound-driven rounds in one launch.
-// hot / cand / cand_cnt leave it in the form k_seg_decide reads.  counters[2] / [3] / next_count are zeroed by the
-// host before the launch.
+// What both kernels of a job need first: geometry, both table levels of the job in LDS (block 0 = the origin's) with
+// exact edge blocks, the first 64 table factors, empty records.  Ends with a barrier.
+__device__ inline CellGeom cell_setup(CellShared &sh, const Job job, const Region rg, const int region,
+                                      const double *__restrict__ prefix, const double *__restrict__ rs,
+                                      const double *__restrict__ tmin, const double *__restrict__ tmax,
+                                      const double *__restrict__ tmin2, const double *__restrict__ tmax2, const int tid) {
+    const long long base = rg.off + region + job.lo;         // absolute index of the job's first prefix entry
+    const long long org = (base >> 7) << 7;
+    CellGeom g;
+    g.P = prefix + org;
+    g.rb = (int)(base - org);
+    g.rhi = g.rb + (job.hi - job.lo);
+    g.job_lo = job.lo;
+    const int n1 = (g.rhi >> 5) + 1, n2 = (g.rhi >> 7) + 1;
+    const long long k1 = org >> 5, k2 = org >> 7;
+    for (int i = tid; i < n1; i += 256) { sh.tmx[i] = tmax[k1 + i]; sh.tmn[i] = tmin[k1 + i]; }
+    for (int i = tid; i < n2; i += 256) { sh.tmx2[i] = tmax2[k2 + i]; sh.tmn2[i] = tmin2[k2 + i]; }
+    if (tid < 64) sh.rsn[tid] = rs[tid];
+    if (tid == 0) { sh.n_rec[0] = 0; sh.n_rec[1] = 0; }
+    __syncthreads();
+    // The tables are aligned to the concatenated array: the job's first and last block of either level also cover
+    // entries of its neighbours (another region's prefix sums: a jump).  Their extremes over the job's own
+    // entries, a wave each -- otherwise every cell on the job's edges reaches the cut.
+    {
+        const int w = tid >> 6, lane = tid & 63;
+        const int lvl = w >> 1, last = w & 1;                // waves 0 / 1: 32-blocks, 2 / 3: 128-blocks; first / last block
+        const int shift = lvl ? 7 : 5;
+        const int blk = last ? g.rhi >> shift : g.rb >> shift;
+        double mx = -INFINITY, mn = INFINITY;
+        for (int e = lane; e < (1 << shift); e += 64) {
+            const int a = (blk << shift) + e;
+            if (a >= g.rb && a <= g.rhi) { const double v = g.P[a]; mx = fmax(mx, v); mn = fmin(mn, v); }
+        }
+        for (int o = 32; o > 0; o >>= 1) { mx = fmax(mx, __shfl_xor(mx, o)); mn = fmin(mn, __shfl_xor(mn, o)); }
+        if (lane == 0) {
+            if (lvl) { sh.tmx2[blk] = mx; sh.tmn2[blk] = mn; }
+            else { sh.tmx[blk] = mx; sh.tmn[blk] = mn; }
+        }
+    }
+    __syncthreads();
+    return g;
+}
+
+// The search of one job by parts(L) workgroups (k_seg_seed + k_seg_bound of the bound-driven rounds).  A part leaves
+// its extremes and its record of near-extreme windows in the job's state -- relaxed atomics and plain stores, no
+// fence: k_seg_merge reads them after the kernel boundary (an agent-scope fence per workgroup writes back and
+// invalidates the XCD's L2: measured 1.6 ms instead of 0.15 for round 1 of a 125 x 50 kb batch).  The cuts the parts
+// share while they run are hints only.  state[] is zeroed by the host before the launch.
 __global__ __launch_bounds__(256) void k_seg_job(const Job *__restrict__ jobs, int n_jobs,
                                                  const Region *__restrict__ regions,
                                                  const double *__restrict__ prefix, const double *__restrict__ rs,
                                                  const double *__restrict__ reg_abs, const int *__restrict__ reg_flag,
                                                  double thr, const double *__restrict__ tmin,
                                                  const double *__restrict__ tmax, const double *__restrict__ tmin2,
-                                                 const double *__restrict__ tmax2, int *__restrict__ hot,
-                                                 int *__restrict__ brute, int *__restrict__ counters,
-                                                 int2 *__restrict__ cand, int *__restrict__ cand_cnt,
-                                                 unsigned long long *__restrict__ work) {
+                                                 const double *__restrict__ tmax2, CellJobState *__restrict__ state,
+                                                 CellRec *__restrict__ grec, unsigned long long *__restrict__ work) {
     __shared__ CellShared sh;
-    const int j = blockIdx.x, tid = threadIdx.x;
+    const int j = blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
     if (j >= n_jobs) return;
     const Job job = jobs[j];
     const int L = job.hi - job.lo;
     if (L <= 0) return;
-    if (!reg_flag[job.region]) {                  // non-finite region: the exact scan
-        if (tid == 0) brute[atomicAdd(&counters[3], 1)] = j;
-        return;
-    }
+    const int parts = cell_parts(L) < (int)gridDim.x ? cell_parts(L) : (int)gridDim.x;
+    if (part >= parts) return;
+    if (!reg_flag[job.region]) return;            // non-finite region: k_seg_merge hands it to the exact scan
     const Region rg = regions[job.region];
     const double eps = window_eps(rg.n, reg_abs[job.region]);
-    const double T = thr - eps;
-    const long long base = rg.off + job.region + job.lo, a_hi = base + L;
+    const double eps2 = 2.0 * eps, T = thr - eps;
+    CellJobState *js = state + j;
 #ifdef WC_CELL_CLOCKS
     if (tid < 32) sh.clk[tid] = 0ull;
     if (tid == 0) sh.t_prev = clock64();
     const unsigned long long t_begin = clock64();
     __syncthreads();
 #endif
-    cell_stage_tables(sh, base, a_hi, tmin, tmax, tmin2, tmax2, rs, tid);
-    if (tid == 0) { sh.n_hi = 0; sh.n_lo = 0; }
-    __syncthreads();
-    // the starting cuts (k_seg_seed): the window from the minimum of block a to the maximum of block b, both wholly
-    // inside the job, is worth at least (max_b - min_a) * rs[(b - a + 1) 32]
+    const CellGeom g = cell_setup(sh, job, rg, job.region, prefix, rs, tmin, tmax, tmin2, tmax2, tid);
+    // the starting cuts (k_seg_seed's idea): the window from the minimum of block a to the maximum of block b, both
+    // wholly inside the job, is worth at least (max_b - min_a) * rs[(b - a + 1) blocks] -- 32-blocks up to eight
+    // apart (short aberrations), 128-blocks at any distance (long ones)
     {
         double hi = T, lo = -T, d0 = -INFINITY, d1 = INFINITY;
-        const long long k1 = base >> 5;
-        const int b_first = (int)((base + QB - 1) / QB - k1), b_last = (int)((a_hi + 1) / QB - 1 - k1);
-        // a wave per start block, a lane per end block
-        for (int a = b_first + (tid >> 6); a < b_last; a += 4) {
-            const double mn_a = sh.tmn[a], mx_a = sh.tmx[a];
-            for (int b = a + 1 + (tid & 63); b <= b_last; b += 64) {
+        const int b_first = (g.rb + QB - 1) >> 5, b_last = ((g.rhi + 1) >> 5) - 1;
+        for (int i = tid; i < (b_last - b_first) * 8; i += 256) {
+            const int a = b_first + (i >> 3), b = a + 1 + (i & 7);
+            if (b <= b_last) {
                 const double r = rs_below((b - a + 1) * QB);
-                const double up = sh.tmx[b] - mn_a, dn = sh.tmn[b] - mx_a;
+                const double up = sh.tmx[b] - sh.tmn[a], dn = sh.tmn[b] - sh.tmx[a];
+                if (up > 0.0) hi = fmax(hi, up * r);
+                if (dn < 0.0) lo = fmin(lo, dn * r);
+            }
+        }
+        const int c_first = (g.rb + QB2 - 1) >> 7, c_last = ((g.rhi + 1) >> 7) - 1;
+        for (int a = c_first + (tid >> 6); a < c_last; a += 4) {
+            const double mn_a = sh.tmn2[a], mx_a = sh.tmx2[a];
+            for (int b = a + 1 + (tid & 63); b <= c_last; b += 64) {
+                const double r = rs_below((b - a + 1) * QB2);
+                const double up = sh.tmx2[b] - mn_a, dn = sh.tmn2[b] - mx_a;
                 if (up > 0.0) hi = fmax(hi, up * r);
                 if (dn < 0.0) lo = fmin(lo, dn * r);
             }
@@ -2932,35 +3018,32 @@ __global__ __launch_bounds__(256) void k_seg_job(const Job *__restrict__ jobs, i
     CJ_CLK(1);
     double vmax = -INFINITY, vmin = INFINITY, d2 = -INFINITY, d3 = INFINITY;
     int wins = 0, evals = 0;
-    cell_search<0>(sh, base, L, job.lo, prefix, rs, INFINITY, -INFINITY, vmax, vmin, wins, evals, tid);
+    cell_search<0>(sh, g, rs, eps2, INFINITY, -INFINITY, js->cut, part, parts, vmax, vmin, wins, evals, tid);
     block_minmax4(vmax, vmin, d2, d3, tid);
-    const bool is_hot = !(fmax(fabs(vmax), fabs(vmin)) + eps < thr);        // k_seg_classify's test
-    if (is_hot) {
-        // the windows within 2 eps of the extremes, only for a side that can hold a call
-        const double hi_cut = !(vmax + eps < thr) ? vmax - 2.0 * eps : INFINITY;
-        const double lo_cut = !(-vmin + eps < thr) ? vmin + 2.0 * eps : -INFINITY;
-        double e0 = -INFINITY, e1 = INFINITY;
-        cell_search<2>(sh, base, L, job.lo, prefix, rs, hi_cut, lo_cut, e0, e1, wins, evals, tid);
-        __syncthreads();
-        if (tid == 0) {
-            const int h = atomicAdd(&counters[2], 1);
-            hot[h] = j;
-            cand_cnt[2 * h] = sh.n_hi;
-            cand_cnt[2 * h + 1] = sh.n_lo;
-            sh.slot = h;
+    // this part's extremes and record into the job's state
+    CellRec *jrec = grec + (int64_t)j * 2 * CJ_GREC;
+    if (tid == 0) {
+        atomicMax(&js->ext[0], wc::f64_ordered(vmax));
+        atomicMax(&js->ext[1], wc::f64_ordered(-vmin));
+        if (sh.n_rec[0] > CJ_REC || sh.n_rec[1] > CJ_REC) atomicOr(&js->overflow, 1);
+    }
+    for (int side = 0; side < 2; ++side) {
+        const int n = sh.n_rec[side] < CJ_REC ? sh.n_rec[side] : CJ_REC;
+        // (a record that is no longer near this part's cut cannot be near the job's)
+        const double cut = side == 0 ? wc::f64_from_ordered(sh.cut[0]) - eps2 : -wc::f64_from_ordered(sh.cut[1]) + eps2;
+        for (int i = tid; i < n; i += 256) {
+            const CellRec r = sh.rec[side][i];
+            if (side == 0 ? r.v >= cut : r.v <= cut) {
+                const int at = atomicAdd(&js->n_rec[side], 1);
+                if (at < CJ_GREC) jrec[side * CJ_GREC + at] = r;
+            }
         }
-        __syncthreads();
-        const int h = sh.slot;
-        const int n_hi = sh.n_hi < CAND_CAP ? sh.n_hi : CAND_CAP, n_lo = sh.n_lo < CAND_CAP ? sh.n_lo : CAND_CAP;
-        for (int i = tid; i < n_hi; i += 256) cand[((int64_t)2 * h) * CAND_CAP + i] = sh.c_hi[i];
-        for (int i = tid; i < n_lo; i += 256) cand[((int64_t)2 * h + 1) * CAND_CAP + i] = sh.c_lo[i];
     }
 #ifdef WC_CELL_CLOCKS
     __syncthreads();
     CJ_CLK(15);
     if (tid == 0) {
         sh.clk[16] = 1ull;
-        sh.clk[17] = is_hot ? 1ull : 0ull;
         atomicMax(&g_dbg[48], clock64() - t_begin);          // the longest-lived workgroup
     }
     __syncthreads();
@@ -2968,10 +3051,84 @@ __global__ __launch_bounds__(256) void k_seg_job(const Job *__restrict__ jobs, i
 #endif
     if (work) {
         for (int o = 32; o > 0; o >>= 1) { evals += __shfl_xor(evals, o); wins += __shfl_xor(wins, o); }
-        const int slot = (int)((blockIdx.x * 7u + (unsigned)(tid >> 6)) & 63u);
+        const int slot = (int)((blockIdx.y * 7u + blockIdx.x * 3u + (unsigned)(tid >> 6)) & 63u);
         if ((tid & 63) == 0) {
             atomicAdd(work + 2 * slot, (unsigned long long)wins);
             atomicAdd(work + 2 * slot + 1, (unsigned long long)evals);
+        }
+    }
+}
+
+// After the search: classification (k_seg_classify's test on the job's extremes) and, for a job that may hold a
+// call, the candidate list from the parts' records (k_seg_bcollect's product), in the form k_seg_decide reads.  A job
+// whose records overflowed (ties) is walked once more with the final cuts (MODE 2).  One workgroup per job, most
+// leave at once.  counters[2] / [3] and next_count are zeroed by the host before the launch.
+__global__ __launch_bounds__(256) void k_seg_merge(const Job *__restrict__ jobs, int n_jobs,
+                                                   const Region *__restrict__ regions,
+                                                   const double *__restrict__ prefix, const double *__restrict__ rs,
+                                                   const double *__restrict__ reg_abs, const int *__restrict__ reg_flag,
+                                                   double thr, const double *__restrict__ tmin,
+                                                   const double *__restrict__ tmax, const double *__restrict__ tmin2,
+                                                   const double *__restrict__ tmax2,
+                                                   const CellJobState *__restrict__ state,
+                                                   const CellRec *__restrict__ grec, int *__restrict__ hot,
+                                                   int *__restrict__ brute, int *__restrict__ counters,
+                                                   int2 *__restrict__ cand, int *__restrict__ cand_cnt,
+                                                   unsigned long long *__restrict__ work) {
+    __shared__ CellShared sh;
+    const int j = blockIdx.x, tid = threadIdx.x;
+    if (j >= n_jobs) return;
+    const Job job = jobs[j];
+    const int L = job.hi - job.lo;
+    if (L <= 0) return;
+    if (!reg_flag[job.region]) {                  // non-finite region: the exact scan
+        if (tid == 0) brute[atomicAdd(&counters[3], 1)] = j;
+        return;
+    }
+    const CellJobState js = state[j];
+    const double vmax = wc::f64_from_ordered(js.ext[0]), vmin = -wc::f64_from_ordered(js.ext[1]);
+    const Region rg = regions[job.region];
+    const double eps = window_eps(rg.n, reg_abs[job.region]);
+    if (fmax(fabs(vmax), fabs(vmin)) + eps < thr) return;                    // no call in this job
+    // the windows within 2 eps of the extremes, only for a side that can hold a call
+    const double eps2 = 2.0 * eps;
+    const double hi_cut = !(vmax + eps < thr) ? vmax - eps2 : INFINITY;
+    const double lo_cut = !(-vmin + eps < thr) ? vmin + eps2 : -INFINITY;
+    const CellRec *jrec = grec + (int64_t)j * 2 * CJ_GREC;
+    int wins = 0, evals = 0;
+    if (tid == 0) { sh.n_rec[0] = 0; sh.n_rec[1] = 0; }
+    __syncthreads();
+    if (js.overflow || js.n_rec[0] > CJ_GREC || js.n_rec[1] > CJ_GREC) {
+        // more near-extreme windows than the records hold (ties): the whole job once more with the final cuts
+        const CellGeom g = cell_setup(sh, job, rg, job.region, prefix, rs, tmin, tmax, tmin2, tmax2, tid);
+        double e0 = -INFINITY, e1 = INFINITY;
+        cell_search<2>(sh, g, rs, eps2, hi_cut, lo_cut, nullptr, 0, 1, e0, e1, wins, evals, tid);
+    } else {
+        for (int i = tid; i < js.n_rec[0]; i += 256) {
+            const CellRec r = jrec[i];
+            if (r.v >= hi_cut) { const int at = atomicAdd(&sh.n_rec[0], 1); if (at < CJ_REC) sh.rec[0][at] = r; }
+        }
+        for (int i = tid; i < js.n_rec[1]; i += 256) {
+            const CellRec r = jrec[CJ_GREC + i];
+            if (r.v <= lo_cut) { const int at = atomicAdd(&sh.n_rec[1], 1); if (at < CJ_REC) sh.rec[1][at] = r; }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) sh.slot = atomicAdd(&counters[2], 1);
+    __syncthreads();
+    const int h = sh.slot;
+    if (tid < 2) {
+        const int side = tid, n = sh.n_rec[side];
+        // (a list beyond CAND_CAP makes k_seg_decide send the job to the exact scan)
+        for (int i = 0; i < n && i < CAND_CAP; ++i) cand[((int64_t)2 * h + side) * CAND_CAP + i] = make_int2(sh.rec[side][i].x, sh.rec[side][i].y);
+        cand_cnt[2 * h + side] = n > CJ_REC ? CAND_CAP + 1 : n;
+    }
+    if (tid == 0) hot[h] = j;
+    if (work && (wins | evals)) {
+        for (int o = 32; o > 0; o >>= 1) { evals += __shfl_xor(evals, o); wins += __shfl_xor(wins, o); }
+        if ((tid & 63) == 0) {
+            atomicAdd(work + 2 * (tid >> 6), (unsigned long long)wins);
+            atomicAdd(work + 2 * (tid >> 6) + 1, (unsigned long long)evals);
         }
     }
 }
@@ -4584,12 +4741,28 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
         const bool cell_path = bound_path && max_n <= CJ_MAXLEN && !(cells_env && cells_env[0] == '0');
         if (cell_path) {
             WC_HIP(hipMemsetAsync(counters + 1, 0, sizeof(int) * 3, stream));      // next jobs, hot, brute
-            hipLaunchKernelGGL(k_seg_job, dim3((unsigned)n_jobs), dim3(256), 0, stream, (const Job *)cur, (int)n_jobs,
+            if ((rc = ts.cell_state.reserve(sizeof(CellJobState) * n_jobs))) return rc;
+            if ((rc = ts.cell_rec.reserve(sizeof(CellRec) * 2 * CJ_GREC * n_jobs))) return rc;
+            WC_HIP(hipMemsetAsync(ts.cell_state.p, 0, sizeof(CellJobState) * n_jobs, stream));
+            // a round of many jobs fills the chip with one workgroup per job (parts repeat the set-up and the seed);
+            // a round of few jobs -- the later rounds -- is as long as its longest job: several workgroups per job
+            const char *parts_env = getenv("WC_CELL_PARTS");               // experiments: at most this many workgroups per job
+            const int max_parts = std::max(1, std::min(cell_parts((int)max_n), parts_env ? atoi(parts_env) : (n_jobs >= 2048 ? 1 : CJ_MAXPARTS)));
+            hipLaunchKernelGGL(k_seg_job, dim3((unsigned)max_parts, (unsigned)n_jobs), dim3(256), 0, stream,
+                               (const Job *)cur, (int)n_jobs,
                                regions_dev, (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
                                (const double *)ts.reg_abs.as<double>(), (const int *)ts.reg_flag.as<int>(), thr,
                                (const double *)ts.tmin.as<double>(), (const double *)ts.tmax.as<double>(),
                                (const double *)ts.tmin2.as<double>(), (const double *)ts.tmax2.as<double>(),
-                               hot, brute, counters, ts.cand.as<int2>(), ts.cand_cnt.as<int>(), work);
+                               ts.cell_state.as<CellJobState>(), ts.cell_rec.as<CellRec>(), work);
+            hipLaunchKernelGGL(k_seg_merge, dim3((unsigned)n_jobs), dim3(256), 0, stream, (const Job *)cur, (int)n_jobs,
+                               regions_dev, (const double *)ts.prefix.as<double>(), (const double *)ts.rs.as<double>(),
+                               (const double *)ts.reg_abs.as<double>(), (const int *)ts.reg_flag.as<int>(), thr,
+                               (const double *)ts.tmin.as<double>(), (const double *)ts.tmax.as<double>(),
+                               (const double *)ts.tmin2.as<double>(), (const double *)ts.tmax2.as<double>(),
+                               (const CellJobState *)ts.cell_state.as<CellJobState>(),
+                               (const CellRec *)ts.cell_rec.as<CellRec>(), hot, brute, counters, ts.cand.as<int2>(),
+                               ts.cand_cnt.as<int>(), work);
             ts.mark(11, stream);
             hipLaunchKernelGGL(k_seg_decide, dim3((unsigned)n_jobs), dim3(256), 0, stream, (const Job *)cur,
                                (const int *)hot, counters, regions_dev, z_dev, (const int2 *)ts.cand.as<int2>(),
