@@ -435,10 +435,14 @@ def test_roofline(prof, n_refs, windows, n_samples, ms_per_batch):
         "bound": "fp64-valu" if byte_frac > 1.0 else "hbm",
         "frac": valu_frac if byte_frac > 1.0 else byte_frac,
         "fp64_valu_frac": valu_frac,
-        "fp64_valu_detail": {"kernels": "the window-search kernels of all rounds of one batch (k_seg_seed + k_seg_bound on the "
-                                        "host-driven rounds, k_seg_quiet + k_seg_search on the tree path; events on the launch "
-                                        "stream): windows evaluated by value x 4 + bounds x 6 float64 operations, counted by "
-                                        "the kernels",
+        # every window of the (never materialised) triangle x 4 float64 operations against the vector peak: what a
+        # search that evaluated them all would have to sustain -- over the whole batch and over the search stage alone
+        "algorithmic_fp64_frac": n_samples * windows * 4.0 / (ms_per_batch * 1e-3) / PEAK_FP64_VALU_OPS,
+        "algorithmic_fp64_frac_of_search_stage": (n_samples * windows * 4.0 / (search_ms * 1e-3) / PEAK_FP64_VALU_OPS)
+                                                 if search_ms > 0 else None,
+        "fp64_valu_detail": {"kernels": "the window-search kernels of one batch (the cell search: k_seg_walk, or k_seg_job + "
+                                        "k_seg_merge per recursion level; events on the launch stream): windows evaluated by "
+                                        "value x 4 + bounds x 6 float64 operations, counted by the kernels",
                              "ms": search_ms, "windows_evaluated": float(prof[6]),
                              "certificate_evaluations": float(prof[7]), "fp64_ops": search_ops,
                              "peak_ops_per_s": PEAK_FP64_VALU_OPS},
@@ -548,6 +552,32 @@ def emulate_world_newref(ctx, X, bins, k, order, world, single_idx, single_dst):
     bytes_thr = float(B) * 4.0
     per_rank_recv_lists = [(world - 1) * ((ranges[r][1] - ranges[r][0]) * (4.0 + cap_x * 8.0)) for r in range(world)]
     bytes_result = float(B) * k * 12.0
+    n_bands = distributed.band_count()
+
+    def overlapped(ms, coll, mode):
+        """The step as NewrefJob runs it: row bands, every collective on the communicator's stream beside the launch
+        stream's kernels (two cursors; a collective starts when it is issued AND the previous one is done, and is
+        priced like the serial projection: bytes over one link + a start-up each; a band's share of a stage = 1 / bands)."""
+        comm_ms = lambda nbytes: 1e3 * (nbytes / XGMI_LINK + COLLECTIVE_LATENCY_S)
+        t = ms["prepare"] + ms["thresholds"]
+        c = 0.0                                                   # the communicator's stream is free from here
+        x_done = []
+        if mode == "tiles":
+            t = c = t + comm_ms(coll["threshold_all_gather"])     # blocking: the tiles need every threshold
+            t += ms["collect"]
+            for i in range(n_bands):
+                t += ms["export"] / n_bands
+                c = max(c, t) + comm_ms(coll["list_all_to_all"] / n_bands)
+                x_done.append(c)
+        else:
+            t += ms["collect"]
+        for i in range(n_bands):
+            if mode == "tiles":
+                t = max(t, x_done[i]) + ms["import"] / n_bands
+            t += ms["finish"] / n_bands
+            c = max(c, t) + comm_ms(coll["result_all_gather"] / n_bands)
+        return max(t, c)
+
     for mode in ("tiles", "rows"):
         per = []
         for r in range(world):
@@ -562,9 +592,13 @@ def emulate_world_newref(ctx, X, bins, k, order, world, single_idx, single_dst):
                      "imbalance_max_over_mean": max(tot) / float(np.mean(tot)),
                      "bytes_received_per_rank_per_collective": coll,
                      "projected_comm_ms": 1e3 * comm_s, "projected_step_ms": max(tot) + 1e3 * comm_s,
+                     "projected_step_ms_overlapped": max(overlapped(p_, coll, mode) for p_ in per),
+                     "row_bands": n_bands,
                      "results_equal_single_rank": tiles_ok if mode == "tiles" else rows_ok}
         if mode == "tiles":
             out[mode]["exact_path_rows_per_rank"] = exact_rows
+    out["what"] += ("; projected_step_ms_overlapped: the same prices with the schedule NewrefJob runs -- %d row bands per "
+                    "rank, every collective in flight beside the kernels (still a PROJECTION)" % n_bands)
     return out
 
 
@@ -653,7 +687,18 @@ def main():
         for m in mark_sets:
             a_job.last_marks = m
             runs.append(a_job.stage_ms())
-        return {key: float(np.mean([r[key] for r in runs])) for key in runs[0]}
+        return {key: float(np.mean([r.get(key, 0.0) for r in runs])) for key in runs[0]}
+
+    def mean_collectives(a_job, comm_sets):
+        """Per collective of a multi-rank pass (issued blocking in the timing passes): name, bytes, mean ms."""
+        runs = []
+        for c in comm_sets:
+            a_job.last_comm = c
+            runs.append(a_job.collective_ms())
+        if not runs or not runs[0]:
+            return []
+        return [{"name": runs[0][i]["name"], "bytes": runs[0][i]["bytes"],
+                 "ms": float(np.mean([r[i]["ms"] for r in runs if i < len(r)]))} for i in range(len(runs[0]))]
 
     # ------------------------------------------------------------ newref ----
     for _ in range(max(1, args.warmup)):
@@ -666,19 +711,23 @@ def main():
     t_newref = max_over_ranks(time.perf_counter() - t0)
     # the same K passes again with events between the stages (on the launch stream): kernel times
     # for the roofline objects; the events cost ~15 % of a 0.2 ms pass, so they stay out of `value`
-    marks = []
+    marks, comms = [], []
     for s in range(args.steps):
         idx, dst = job.run(timing=True)
         marks.append(job.last_marks)
+        comms.append(job.last_comm)
     sync_all()
-    stages = mean_stages(job, marks)
-    gram_ms = stages.get("thresholds->collected")
-    pick_ms = stages.get("collected->picked", stages.get("exchanged->picked"))
-    rescore_ms = stages.get("picked->rescored")
+    stages = mean_stages(job, marks)             # every interval booked under the stage that ended it (bands add up)
+    collectives = mean_collectives(job, comms)
+    gram_ms = stages.get("collected")
+    pick_ms = stages.get("picked")
+    rescore_ms = stages.get("rescored")
     finish_ms = None if rescore_ms is None else rescore_ms + (pick_ms or 0.0)
-    if finish_ms is None:
-        finish_ms = stages.get("collected->rescored", stages.get("exchanged->rescored"))
-        rescore_ms = finish_ms
+    per_rank = None
+    if world > 1:
+        # every rank's stage times and collectives on the one line: a scaling run is diagnosable from it
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "stages_ms": stages, "collectives": collectives})
     stats = wt.newref_stats(local_rank)
     gram_mode = "f16"
     variants = {}
@@ -805,7 +854,7 @@ def main():
             sync_all()
             xt = max_over_ranks(time.perf_counter() - t0)
             xstages = mean_stages(xjob, xmarks)
-            xk_ms = xstages["thresholds->collected"]
+            xk_ms = xstages["collected"]
             # tiles mode: every unordered pair once on the node; rows mode: every ordered pair
             xflops = (xpairs if xjob.mode == "rows" else xpairs / 2.0) * 2.0 * xs / world
             extra = {"workload": "cfg4: newref %d samples x %d kb bins (%d bins), kernel-level synthetic matrix"
@@ -816,7 +865,7 @@ def main():
                      "k_gram_algorithmic_tflops": xflops / (xk_ms * 1e-3) / 1e12}
             # the re-score stage on this matrix: uncorrelated rows share no candidates, the 295 MB float64
             # image does not fit the 32 MB of L2, and the gathers come from HBM / Infinity Cache
-            xr_ms = xstages.get("picked->rescored", xstages.get("collected->rescored", xstages.get("exchanged->rescored")))
+            xr_ms = xstages.get("rescored")
             if xr_ms:
                 xr_bytes = float(XB) / world * k * xs * 8.0 + float(XB) / world * k * 12.0
                 extra["rescore_ms"] = xr_ms
@@ -900,7 +949,8 @@ def main():
             extra = dict(extra or {})
             extra["test_50kb"] = {"workload": "cfg5, one GPU's share: batched test of 125 samples x 50 kb bins (%d masked bins)"
                                               % int(bins5.sum()),
-                                  "value": world * 125 / min(t5, t5p), "unit": "samples/s", "ms_per_batch": 1e3 * min(t5, t5p),
+                                  "value": world * 125 / t5, "unit": "samples/s", "ms_per_batch": 1e3 * t5,
+                                  "what": "value / ms_per_batch: ONE batch in flight; `pipelined` beside it",
                                   "one_batch_in_flight": {"ms_per_batch": 1e3 * t5, "value": world * 125 / t5},
                                   "pipelined": {"ms_per_batch": 1e3 * t5p, "value": world * 125 / t5p,
                                                 "batches_in_flight": PIPE_DEPTH, "batches_timed": len(b5)},
@@ -1110,15 +1160,21 @@ def main():
                        "world_size": dist.get_world_size() if world > 1 else 1,
                        "shard_mode": job.mode or "single", "shard_calibration_s": job.calibration},
             "stages_ms": stages,
+            "multi_rank": None if world == 1 else {
+                "what": "diagnostic passes of the same job with events between the stages and every collective waited for "
+                        "where it is issued (its own duration incl. the wait for the slowest peer); the timed passes "
+                        "behind `value` keep the collectives in flight beside the kernels (row bands, async_op)",
+                "row_bands_per_rank": getattr(job, "n_bands", None), "per_rank": per_rank},
             "prep": {"what": "newrefprep numerics on the GPU (normalise, mask, float64 MFMA Gram, the leading eigenpairs by %s, "
                              "components, correctedData left in HBM), %d samples, dense int32 host counts in"
                              % ("csrc/eigh.hip (tridiagonalisation + Sturm multisection + inverse iteration)"
                                 if wt._eig_on_gpu(S, 3) else "host LAPACK (fewer than %d samples)" % wt.EIG_ON_GPU_FROM, S),
                      "ms": inp.get("prep_ms")},
-            "test": {"metric": "test samples/sec", "value": max(samples_per_s, pipelined["value"]), "unit": "samples/s",
-                     "ms_per_batch": min(one_in_flight["ms_per_batch"], pipelined["ms_per_batch"]),
-                     "what": "value / ms_per_batch: the better of one batch in flight and several (TestPipeline); both "
-                             "forms below; the roofline and stage times are those of a lone batch",
+            "test": {"metric": "test samples/sec", "value": one_in_flight["value"], "unit": "samples/s",
+                     "ms_per_batch": one_in_flight["ms_per_batch"],
+                     "what": "value / ms_per_batch: ONE batch in flight (a lone wc_test_batch_dev call after the other); "
+                             "`pipelined` beside it: several batches in flight (TestPipeline); the roofline and stage "
+                             "times are those of a lone batch",
                      "one_batch_in_flight": one_in_flight, "pipelined": pipelined,
                      "samples_per_gpu": args.test_samples,
                      "single_sample_latency_ms": single_ms, "latency": latency, "whole_job_1000_samples": whole_job,

@@ -225,3 +225,24 @@ def test_prep_eigen_route_selection(monkeypatch):
     monkeypatch.setenv("WC_PREP_EIG", "maybe")
     with pytest.raises(ValueError):
         wt._eig_on_gpu(100, 3)
+
+
+def test_part_files_go_to_the_rank_that_owns_their_rows():
+    """`newref -gpus N`: part m is written by the rank whose row range (getPart for N parts, wisetools.py:358-361)
+    holds the part's rows, so that no result all-gather is needed; a part count that is no multiple of the rank
+    count leaves parts that straddle two ranges, and then every rank gathers all rows."""
+    from wisecondor_amd import wisecondor as cli
+    from wisecondor_amd import wisetools as wt
+    from wisecondor_amd.distributed import row_range
+    for parts, world, n_bins in [(8, 8, 57633), (16, 8, 57633), (2, 2, 2897), (4, 2, 11087), (24, 8, 55337), (6, 3, 1001)]:
+        owners = cli.part_owners(parts, list(range(1, parts + 1)), n_bins, world)
+        assert owners is not None, (parts, world, n_bins)
+        covered = 0
+        for m, r in owners.items():
+            lo, hi = wt.getPart(m - 1, parts, n_bins)
+            b, e = row_range(r, world, n_bins)
+            assert b <= lo and hi <= e
+            covered += hi - lo
+        assert covered == n_bins
+    assert cli.part_owners(3, [1, 2, 3], 11087, 2) is None            # part 2 straddles the two ranks' ranges
+    assert cli.part_owners(3, [1, 3], 11087, 2) == {1: 0, 3: 1}       # ... but a resumed run that lacks 1 and 3 only does not

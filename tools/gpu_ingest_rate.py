@@ -47,8 +47,7 @@ import contextlib
 import io
 for label, threads, extra_argv, env in (("native_io_16_warmup", 16, [], {}), ("native_io_1", 1, [], {}), ("native_io_4", 4, [], {}), ("native_io_16", 16, [], {}),
                                         ("native_io_16_stored", 16, ["-ziplevel", "0"], {}),
-                                        ("native_io_16_level6", 16, ["-ziplevel", "6"], {}),
-                                        ("python_writer_io_16", 16, [], {"WC_INGEST_PYTHON_WRITER": "1"})):
+                                        ("native_io_16_level6", 16, ["-ziplevel", "6"], {})):
     outdir = os.path.join(tmp, "out_%s" % label)
     argv = ["testbatch"] + paths + [outdir, refpath, "-batch", str(a.batch), "-io", str(threads)] + extra_argv
     os.environ.update(env)

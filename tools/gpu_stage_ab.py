@@ -1,6 +1,6 @@
 """A/B stage times of the device-resident newref pass under environment switches.
 
-    python tools/gpu_stage_ab.py cfg2,cfg4 "" "WC_FINISH_ENGINE=rows" ...
+    python tools/gpu_stage_ab.py cfg2,cfg4 "" "WC_NEWREF_SHARD=rows" ...
 
 Every variant (a space-separated list of NAME=value settings, "" = defaults) runs the same job;
 prints the mean milliseconds between the stage marks and checks that all variants deliver the

@@ -1809,13 +1809,14 @@ __device__ inline void fb_select(const FinishArgs &a, int64_t row, const unsigne
 // beyond EX_CAP (pathological inputs) are filled and selected by one workgroup each in k_exact_select.
 // Rows of a "lone" chromosome (FinishArgs::lone_mask: pairwise order whatever the layout) are filled by
 // their select workgroup as well.
-constexpr int EX_CAP = 1024;     // targets per launch pair (scratch: 2 EX_CAP rows of Bpad keys)
+constexpr int EX_CAP = 1024;     // targets per launch pair when the host knows their number (scratch: EX_CAP rows of Bpad keys)
+constexpr int EX_DEV_CAP = 256;  // ... when only the device does (the normal pass: scratch 2 EX_DEV_CAP rows)
 constexpr int EX_LD = 130;       // doubles per staged sample: 128 values + 2 (16-byte aligned rows, spread banks)
 
 template <bool SEQ>
 __global__ __launch_bounds__(256) void k_exact_tile(FinishArgs a, const int *__restrict__ rows,
                                                     const int *__restrict__ n_rows_dev, int n_rows_host, int first,
-                                                    unsigned long long *__restrict__ scratch, int64_t Bpad) {
+                                                    unsigned long long *__restrict__ scratch, int64_t Bpad, int cap) {
     constexpr int TR = SEQ ? 4 : 2;            // pairs per thread: TR targets x TR candidates
     constexpr int EX_T = 16 * TR;              // targets (and candidates) per tile
     constexpr int NLD = 2 * EX_T * ST_CH / 256;   // staged values per thread and chunk
@@ -1824,7 +1825,7 @@ __global__ __launch_bounds__(256) void k_exact_tile(FinishArgs a, const int *__r
     __shared__ int2 s_rng[EX_T];
     const int tid = threadIdx.x;
     int nf = (n_rows_dev ? *n_rows_dev : n_rows_host) - first;
-    nf = nf > EX_CAP ? EX_CAP : nf;
+    nf = nf > cap ? cap : nf;
     if (nf <= 0) return;
     const int tr = tid >> 4, tc = tid & 15;
     const int64_t j0 = (int64_t)blockIdx.x * EX_T;
@@ -1933,14 +1934,14 @@ __global__ __launch_bounds__(256) void k_exact_tile(FinishArgs a, const int *__r
 
 __global__ __launch_bounds__(256) void k_exact_select(FinishArgs a, const int *__restrict__ rows,
                                                       const int *__restrict__ n_rows_dev, int n_rows_host, int first,
-                                                      unsigned long long *__restrict__ scratch, int64_t Bpad) {
+                                                      unsigned long long *__restrict__ scratch, int64_t Bpad, int cap) {
     __shared__ unsigned long long rk[K_MAX];
     __shared__ int rj[K_MAX];
     __shared__ unsigned int hist[256];
     __shared__ double xs[2048];
     const int tid = threadIdx.x;
     const int count = (n_rows_dev ? *n_rows_dev : n_rows_host) - first;
-    const int nf = count > EX_CAP ? EX_CAP : count;
+    const int nf = count > cap ? cap : count;
     if ((int)blockIdx.x < nf) {
         const int64_t row = rows[first + blockIdx.x];
         unsigned long long *sc = scratch + (int64_t)blockIdx.x * Bpad;
@@ -1948,10 +1949,10 @@ __global__ __launch_bounds__(256) void k_exact_select(FinishArgs a, const int *_
         __syncthreads();
         fb_select(a, row, sc, rk, rj, hist, tid);
     }
-    // targets beyond EX_CAP (only when the host does not know the count: it loops over bands otherwise)
+    // targets beyond the cap (only when the host does not know the count: it loops over bands otherwise)
     if (!n_rows_dev) return;
-    unsigned long long *own = scratch + ((int64_t)EX_CAP + blockIdx.x) * Bpad;
-    for (int f = EX_CAP + blockIdx.x; f < count; f += gridDim.x) {
+    unsigned long long *own = scratch + ((int64_t)cap + blockIdx.x) * Bpad;
+    for (int f = cap + blockIdx.x; f < count; f += gridDim.x) {
         const int64_t row = rows[first + f];
         const double *xi = a.X + row * a.S;
         __syncthreads();
@@ -2410,7 +2411,11 @@ static void finish_args(NewrefState &st, int64_t row_begin, int64_t row_end, int
 // over bands of EX_CAP rows.
 static int launch_exact(NewrefState &st, hipStream_t stream, const FinishArgs &a, int64_t n_host) {
     int rc;
-    if ((rc = st.fb_scratch.reserve(sizeof(uint64_t) * 2 * EX_CAP * st.bins_pad))) return rc;
+    // scratch: one row of keys per target of a launch pair.  Count on the device (the normal pass, usually no row at
+    // all): a launch pair for EX_DEV_CAP targets plus one row per select workgroup for the rows beyond (16 KB per bin
+    // in all: 0.23 GB at 50 kb bins); count on the host: EX_CAP targets per pair, no second half.
+    const int cap = n_host < 0 ? EX_DEV_CAP : EX_CAP;
+    if ((rc = st.fb_scratch.reserve(sizeof(uint64_t) * (n_host < 0 ? 2 : 1) * cap * st.bins_pad))) return rc;
     const bool seq = st.sum_order == WC_SUM_SEQUENTIAL || st.n_samples < 8;
     const int edge = seq ? 64 : 32;                                  // targets / candidates per tile
     const unsigned ctiles = (unsigned)((st.n_bins + edge - 1) / edge);
@@ -2418,17 +2423,17 @@ static int launch_exact(NewrefState &st, hipStream_t stream, const FinishArgs &a
     const int *rows = st.fb_rows.as<int>();
     const int *n_dev = n_host < 0 ? (const int *)st.fb_count.as<int>() : nullptr;
     const int64_t total = n_host < 0 ? 1 : n_host;
-    for (int64_t first = 0; first < total; first += EX_CAP) {
-        const int64_t nf = n_host < 0 ? EX_CAP : std::min<int64_t>(EX_CAP, n_host - first);
+    for (int64_t first = 0; first < total; first += cap) {
+        const int64_t nf = n_host < 0 ? cap : std::min<int64_t>(cap, n_host - first);
         // row groups in flight: a few when the count is unknown (surplus workgroups leave at once)
         const unsigned rgroups = n_host < 0 ? 4u : (unsigned)((nf + edge - 1) / edge);
-        const unsigned nsel = n_host < 0 ? (unsigned)EX_CAP : (unsigned)nf;
+        const unsigned nsel = n_host < 0 ? (unsigned)cap : (unsigned)nf;
         if (seq) hipLaunchKernelGGL((k_exact_tile<true>), dim3(ctiles, rgroups), dim3(256), 0, stream, a, rows, n_dev,
-                                    (int)n_host, (int)first, scratch, st.bins_pad);
+                                    (int)n_host, (int)first, scratch, st.bins_pad, cap);
         else hipLaunchKernelGGL((k_exact_tile<false>), dim3(ctiles, rgroups), dim3(256), 0, stream, a, rows, n_dev,
-                                (int)n_host, (int)first, scratch, st.bins_pad);
+                                (int)n_host, (int)first, scratch, st.bins_pad, cap);
         hipLaunchKernelGGL(k_exact_select, dim3(nsel), dim3(256), 0, stream, a, rows, n_dev, (int)n_host, (int)first,
-                           scratch, st.bins_pad);
+                           scratch, st.bins_pad, cap);
     }
     return WC_OK;
 }

@@ -2618,9 +2618,10 @@ struct CellShared {
     double tmx[CJ_T1], tmn[CJ_T1], tmx2[CJ_T2], tmn2[CJ_T2];
     double pn[CJ_PN];
     double b8x[CJ_NB8], b8n[CJ_NB8];            // maximum / minimum of the staged entries per 8-entry block
+    unsigned int q2[CJ_Q2], q1[CJ_Q1], l1[256], itemq[CJ_ITEMQ];
+    // (k_seg_walk's exact evaluation of the candidates reuses pn .. itemq as its four waves' scratch)
     double rsn[64];                             // rs[0 .. 63]
     unsigned long long cut[2];                  // this workgroup's view of the job's cuts
-    unsigned int q2[CJ_Q2], q1[CJ_Q1], l1[256], itemq[CJ_ITEMQ];
     CellRec rec[2][CJ_REC];
     int n_rec[2];
     int n_q2, n_q1, n_l1, n_items, slot, last;
@@ -2953,6 +2954,35 @@ __device__ inline CellGeom cell_setup(CellShared &sh, const Job job, const Regio
     return g;
 }
 
+// The starting cuts (k_seg_seed's idea): the window from the minimum of block a to the maximum of block b, both wholly
+// inside the job, is worth at least (max_b - min_a) * rs[(b - a + 1) blocks] -- 32-blocks up to eight apart (short
+// aberrations), 128-blocks at any distance (long ones).  Needs a barrier before the cuts are read.
+__device__ inline void cell_seed(CellShared &sh, const CellGeom g, const double T, const int tid) {
+    double hi = T, lo = -T, d0 = -INFINITY, d1 = INFINITY;
+    const int b_first = (g.rb + QB - 1) >> 5, b_last = ((g.rhi + 1) >> 5) - 1;
+    for (int i = tid; i < (b_last - b_first) * 8; i += 256) {
+        const int a = b_first + (i >> 3), b = a + 1 + (i & 7);
+        if (b <= b_last) {
+            const double r = rs_below((b - a + 1) * QB);
+            const double up = sh.tmx[b] - sh.tmn[a], dn = sh.tmn[b] - sh.tmx[a];
+            if (up > 0.0) hi = fmax(hi, up * r);
+            if (dn < 0.0) lo = fmin(lo, dn * r);
+        }
+    }
+    const int c_first = (g.rb + QB2 - 1) >> 7, c_last = ((g.rhi + 1) >> 7) - 1;
+    for (int a = c_first + (tid >> 6); a < c_last; a += 4) {
+        const double mn_a = sh.tmn2[a], mx_a = sh.tmx2[a];
+        for (int b = a + 1 + (tid & 63); b <= c_last; b += 64) {
+            const double r = rs_below((b - a + 1) * QB2);
+            const double up = sh.tmx2[b] - mn_a, dn = sh.tmn2[b] - mx_a;
+            if (up > 0.0) hi = fmax(hi, up * r);
+            if (dn < 0.0) lo = fmin(lo, dn * r);
+        }
+    }
+    block_minmax4(hi, lo, d0, d1, tid);
+    if (tid == 0) { sh.cut[0] = wc::f64_ordered(hi); sh.cut[1] = wc::f64_ordered(-lo); }
+}
+
 // The search of one job by parts(L) workgroups (k_seg_seed + k_seg_bound of the bound-driven rounds).  A part leaves
 // its extremes and its record of near-extreme windows in the job's state -- relaxed atomics and plain stores, no
 // fence: k_seg_merge reads them after the kernel boundary (an agent-scope fence per workgroup writes back and
@@ -2986,34 +3016,7 @@ __global__ __launch_bounds__(256) void k_seg_job(const Job *__restrict__ jobs, i
     __syncthreads();
 #endif
     const CellGeom g = cell_setup(sh, job, rg, job.region, prefix, rs, tmin, tmax, tmin2, tmax2, tid);
-    // the starting cuts (k_seg_seed's idea): the window from the minimum of block a to the maximum of block b, both
-    // wholly inside the job, is worth at least (max_b - min_a) * rs[(b - a + 1) blocks] -- 32-blocks up to eight
-    // apart (short aberrations), 128-blocks at any distance (long ones)
-    {
-        double hi = T, lo = -T, d0 = -INFINITY, d1 = INFINITY;
-        const int b_first = (g.rb + QB - 1) >> 5, b_last = ((g.rhi + 1) >> 5) - 1;
-        for (int i = tid; i < (b_last - b_first) * 8; i += 256) {
-            const int a = b_first + (i >> 3), b = a + 1 + (i & 7);
-            if (b <= b_last) {
-                const double r = rs_below((b - a + 1) * QB);
-                const double up = sh.tmx[b] - sh.tmn[a], dn = sh.tmn[b] - sh.tmx[a];
-                if (up > 0.0) hi = fmax(hi, up * r);
-                if (dn < 0.0) lo = fmin(lo, dn * r);
-            }
-        }
-        const int c_first = (g.rb + QB2 - 1) >> 7, c_last = ((g.rhi + 1) >> 7) - 1;
-        for (int a = c_first + (tid >> 6); a < c_last; a += 4) {
-            const double mn_a = sh.tmn2[a], mx_a = sh.tmx2[a];
-            for (int b = a + 1 + (tid & 63); b <= c_last; b += 64) {
-                const double r = rs_below((b - a + 1) * QB2);
-                const double up = sh.tmx2[b] - mn_a, dn = sh.tmn2[b] - mx_a;
-                if (up > 0.0) hi = fmax(hi, up * r);
-                if (dn < 0.0) lo = fmin(lo, dn * r);
-            }
-        }
-        block_minmax4(hi, lo, d0, d1, tid);
-        if (tid == 0) { sh.cut[0] = wc::f64_ordered(hi); sh.cut[1] = wc::f64_ordered(-lo); }
-    }
+    cell_seed(sh, g, T, tid);
     __syncthreads();
     CJ_CLK(1);
     double vmax = -INFINITY, vmin = INFINITY, d2 = -INFINITY, d3 = INFINITY;
@@ -4312,6 +4315,146 @@ __global__ __launch_bounds__(1024) void k_seg_tree(int *__restrict__ counters, c
     }
 }
 
+// The whole recursion of TriArr.segmentTri (triarray.py:59-84) for one region by one workgroup, every range -- the
+// region itself and every child -- searched with the cell bounds (cell_search): root search, classification,
+// candidate list, exact decision, children, in ONE launch for the whole batch and without a host round trip
+// (k_seg_job / k_seg_merge / k_seg_decide once per recursion level, and k_seg_quiet / k_seg_search / k_seg_classify /
+// k_seg_tree of the 250 kb batches, are what it replaces).  Segments go to segs[] (k_call_post turns them into call
+// rows), their number per region to out_n.  What it is not built for -- non-finite values, more than CAND_CAP tied
+// candidates, a recursion deeper than the stack -- sets counters[6] and the caller repeats the call with the
+// host-driven rounds.
+constexpr int WALK_STACK = 64;
+__global__ __launch_bounds__(256) void k_seg_walk(int *__restrict__ counters, const Region *__restrict__ regions,
+                                                  int n_regions, const int *__restrict__ reg_flag,
+                                                  const double *__restrict__ prefix, const double *__restrict__ rs,
+                                                  const double *__restrict__ reg_abs, const double *__restrict__ z,
+                                                  double thr, int min_search, const double *__restrict__ tmin,
+                                                  const double *__restrict__ tmax, const double *__restrict__ tmin2,
+                                                  const double *__restrict__ tmax2, Seg *__restrict__ segs, int seg_cap,
+                                                  int *__restrict__ out_n, unsigned long long *__restrict__ work) {
+    __shared__ CellShared sh;
+    __shared__ Job stack[WALK_STACK];
+    __shared__ int s_sp, s_nseg, s_stop;
+    __shared__ BestPair s_best[4];
+    const int region = blockIdx.x, tid = threadIdx.x;
+    if (region >= n_regions) return;
+    const Region rg = regions[region];
+    if (rg.n <= 0) return;                         // (out_n was zeroed by the set-up kernel)
+    if (rg.n > CJ_MAXLEN || !reg_flag[region]) {
+        if (tid == 0) counters[6] = 1;
+        return;
+    }
+    const double eps = window_eps(rg.n, reg_abs[region]);
+    const double eps2 = 2.0 * eps, T = thr - eps;
+    const double *zz = z + rg.off;
+    const WindowMask wm{nullptr, 0, rg.n};
+    wc::PwWaveScratch *sc = reinterpret_cast<wc::PwWaveScratch *>(sh.pn);      // four of them fit pn .. itemq
+    static_assert(4 * sizeof(wc::PwWaveScratch) <= sizeof(sh.pn) + sizeof(sh.b8x) + sizeof(sh.b8n) + sizeof(sh.q2) +
+                                                       sizeof(sh.q1) + sizeof(sh.l1) + sizeof(sh.itemq),
+                  "the exact evaluation's scratch does not fit the search's staging area");
+    const int lane = tid & 63, w = tid >> 6;
+    int wins = 0, evals = 0;
+    if (tid == 0) {
+        Job root;
+        root.region = region; root.lo = 0; root.hi = rg.n; root.pad = 0;
+        stack[0] = root;
+        s_sp = 1; s_nseg = 0; s_stop = 0;
+    }
+    while (true) {
+        __syncthreads();
+        if (s_sp == 0 || s_stop) break;
+        const Job job = stack[s_sp - 1];
+        __syncthreads();
+        if (tid == 0) --s_sp;
+        if (job.hi - job.lo <= 0) continue;
+        const CellGeom g = cell_setup(sh, job, rg, region, prefix, rs, tmin, tmax, tmin2, tmax2, tid);
+        cell_seed(sh, g, T, tid);
+        __syncthreads();
+        double vmax = -INFINITY, vmin = INFINITY, d2 = -INFINITY, d3 = INFINITY;
+        cell_search<0>(sh, g, rs, eps2, INFINITY, -INFINITY, nullptr, 0, 1, vmax, vmin, wins, evals, tid);
+        block_minmax4(vmax, vmin, d2, d3, tid);
+        if (fmax(fabs(vmax), fabs(vmin)) + eps < thr) continue;              // no call in this range (k_seg_classify's test)
+        // the windows within 2 eps of the extremes, only for a side that can hold a call
+        const double hi_cut = !(vmax + eps < thr) ? vmax - eps2 : INFINITY;
+        const double lo_cut = !(-vmin + eps < thr) ? vmin + eps2 : -INFINITY;
+        if (sh.n_rec[0] > CJ_REC || sh.n_rec[1] > CJ_REC) {
+            // more near-extreme windows than the record holds (ties): the range once more with the final cuts
+            __syncthreads();
+            if (tid == 0) { sh.n_rec[0] = 0; sh.n_rec[1] = 0; }
+            double e0 = -INFINITY, e1 = INFINITY;
+            cell_search<2>(sh, g, rs, eps2, hi_cut, lo_cut, nullptr, 0, 1, e0, e1, wins, evals, tid);
+            __syncthreads();
+            if (sh.n_rec[0] > CJ_REC || sh.n_rec[1] > CJ_REC) {       // massive ties: the general path evaluates everything exactly
+                if (tid == 0) { counters[6] = 1; s_stop = 1; }
+                continue;
+            }
+        }
+        __syncthreads();                            // the search is done with its staging area: the waves' scratch now
+        // exact values of the candidates (numpy pairwise sum / sqrt): waves 0-1 the candidates for the maximum,
+        // 2-3 for the minimum (the record also holds windows that were near an earlier cut: the final cuts select)
+        {
+            BestPair b;
+            b.maxv = 0.0; b.minv = 0.0; b.mx = b.my = b.nx = b.ny = -1;
+            const int which = w >> 1, slot = w & 1;
+            const int n_mine = sh.n_rec[which];
+            int taken = 0;
+            for (int t = 0; t < n_mine; ++t) {
+                const CellRec r = sh.rec[which][t];
+                if (which == 0 ? !(r.v >= hi_cut) : !(r.v <= lo_cut)) continue;
+                if ((taken++ & 1) != slot) continue;
+                const double v = window_exact_wave(zz, r.x, r.y, lane, wm, sc[w]);
+                if (which == 0) {
+                    if (better_max(v, r.x, r.y, b.maxv, b.mx, b.my)) { b.maxv = v; b.mx = r.x; b.my = r.y; }
+                } else {
+                    if (better_min(v, r.x, r.y, b.minv, b.nx, b.ny)) { b.minv = v; b.nx = r.x; b.ny = r.y; }
+                }
+            }
+            if (lane == 0) s_best[w] = b;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            BestPair b = s_best[0];
+            if (s_best[1].mx >= 0 && better_max(s_best[1].maxv, s_best[1].mx, s_best[1].my, b.maxv, b.mx, b.my)) {
+                b.maxv = s_best[1].maxv; b.mx = s_best[1].mx; b.my = s_best[1].my;
+            }
+            b.minv = s_best[2].minv; b.nx = s_best[2].nx; b.ny = s_best[2].ny;
+            if (s_best[3].nx >= 0 && better_min(s_best[3].minv, s_best[3].nx, s_best[3].ny, b.minv, b.nx, b.ny)) {
+                b.minv = s_best[3].minv; b.nx = s_best[3].nx; b.ny = s_best[3].ny;
+            }
+            double champ = b.maxv;
+            int cx = b.mx, cy = b.my;
+            if (fabs(b.minv) > champ) { champ = b.minv; cx = b.nx; cy = b.ny; }
+            if (!(fabs(champ) < thr)) {
+                const int at = atomicAdd(&counters[4], 1);
+                if (at < seg_cap) {
+                    Seg sgm;
+                    sgm.val = champ; sgm.region = region; sgm.x = cx; sgm.y = cy; sgm.pad = 0;
+                    segs[at] = sgm;
+                }
+                ++s_nseg;
+                const int xr = cx - job.lo, yr = cy - job.lo, edge = job.hi - job.lo;
+                const bool left = xr > min_search, right = yr + 1 < edge - min_search;
+                if (s_sp + (left ? 1 : 0) + (right ? 1 : 0) > WALK_STACK) {
+                    counters[6] = 1;
+                    s_stop = 1;
+                } else {
+                    if (right) { Job n; n.region = region; n.lo = cy + 1; n.hi = job.hi; n.pad = 0; stack[s_sp++] = n; }
+                    if (left) { Job n; n.region = region; n.lo = job.lo; n.hi = cx; n.pad = 0; stack[s_sp++] = n; }
+                }
+            }
+        }
+    }
+    if (tid == 0) out_n[region] = s_nseg;
+    if (work) {
+        for (int o = 32; o > 0; o >>= 1) { evals += __shfl_xor(evals, o); wins += __shfl_xor(wins, o); }
+        const int slot = (int)((blockIdx.x * 7u + (unsigned)w) & 63u);
+        if (lane == 0) {
+            atomicAdd(work + 2 * slot, (unsigned long long)wins);
+            atomicAdd(work + 2 * slot + 1, (unsigned long long)evals);
+        }
+    }
+}
+
 // ------------------------------------------------------------ host drivers ----
 int run_prepare(wc_ctx *ctx, const wc_reference *ref, const int *counts_dev, int64_t Ns, hipStream_t stream) {
     TestState &ts = ctx->ts;
@@ -4582,6 +4725,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     ts.last_segs = 0;
     ts.tree_done = false;
     ts.tree_pending = false;
+    ts.walk_bound = 0;
     if (n_regions == 0) return WC_OK;
     const int64_t job_cap = n_regions + total_len / 4 + 64;
     const int64_t seg_cap = n_regions * (int64_t)max_calls + 64;
@@ -4714,12 +4858,52 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     // that carry no -mineffectsize mask locate the extremes from the block bounds (k_seg_bound / k_seg_refine /
     // k_seg_bcollect) instead of evaluating every window of every job that may hold a call.
     const char *tree_env = getenv("WC_TEST_TREE_TAIL");        // "0": host-driven rounds only
-    const bool tree_ok = tail && !bits && max_n <= TREE_MAXLEN && !ts.no_tree && !(tree_env && tree_env[0] == '0');
-    const bool bound_path = !bits && !tree_ok;
+    const bool tree_ok0 = tail && !bits && max_n <= TREE_MAXLEN && !ts.no_tree && !(tree_env && tree_env[0] == '0');
     const char *cells_env = getenv("WC_TEST_CELLS");
     if ((rc = ctx->ensure_pinned(256))) return rc;
     int *h = (int *)ctx->pinned;          // counter read-backs land in pinned memory
     h[4] = 0;
+    // Callers with call rows, regions up to CJ_MAXLEN bins, no -mineffectsize mask: the whole recursion of every region
+    // in ONE launch (k_seg_walk), no host round trip; k_call_post then takes the segment count from the device.
+    // WC_TEST_WALK=0: the paths it replaces (tree kernel up to TREE_MAXLEN, host-driven rounds beyond).
+    const char *walk_env = getenv("WC_TEST_WALK");
+    if (tail && !bits && max_n <= CJ_MAXLEN && !ts.no_tree && !(walk_env && walk_env[0] == '0')) {
+        ts.mark(10, stream);
+        hipLaunchKernelGGL(k_seg_walk, dim3((unsigned)n_regions), dim3(256), 0, stream, counters, regions_dev,
+                           (int)n_regions, (const int *)ts.reg_flag.as<int>(), (const double *)ts.prefix.as<double>(),
+                           (const double *)ts.rs.as<double>(), (const double *)ts.reg_abs.as<double>(), z_dev, thr,
+                           min_search, (const double *)ts.tmin.as<double>(), (const double *)ts.tmax.as<double>(),
+                           (const double *)ts.tmin2.as<double>(), (const double *)ts.tmax2.as<double>(), ts.seg.as<Seg>(),
+                           (int)seg_cap, ts.out_n.as<int>(), work);
+        ts.mark(11, stream);
+        const int64_t bound = std::min<int64_t>(seg_cap, std::max<int64_t>(2048, 2 * n_regions));
+        WC_HIP(hipMemcpyAsync(h, counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
+        if (tail->defer_status) {
+            // the caller looks at the counters after ITS synchronize: h[6] non-zero = the walk gave up on some
+            // region, h[4] beyond the bound = more segments than k_call_post's grid covers; it then repeats the
+            // batch with the host-driven rounds
+            ts.tree_done = true;
+            ts.tree_pending = true;
+            ts.tree_seg_cap = bound;
+            ts.walk_bound = bound;
+            WC_HIP(hipGetLastError());
+            return WC_OK;
+        }
+        WC_HIP(hipStreamSynchronize(stream));
+        if (h[6] == 0 && h[4] <= bound) {
+            ts.tree_done = true;
+            ts.walk_bound = bound;
+            WC_HIP(hipGetLastError());
+            return WC_OK;
+        }
+        // rare: again on the host-driven path
+        WC_HIP(hipMemsetAsync(ts.out_n.p, 0, sizeof(int) * n_regions, stream));
+        WC_HIP(hipMemsetAsync(counters + 4, 0, sizeof(int), stream));
+        WC_HIP(hipMemsetAsync(counters + 6, 0, sizeof(int), stream));
+        h[4] = 0;
+    }
+    const bool tree_ok = tree_ok0 && (walk_env && walk_env[0] == '0');
+    const bool bound_path = !bits && !tree_ok;
     while (n_jobs > 0) {
         WC_CHECK(++guard < 100000, WC_E_INTERNAL, "stouffer: recursion did not terminate");
         // per-round scratch is sized by the jobs of this round, not by the worst case
@@ -4994,6 +5178,7 @@ int run_seg_lat(wc_ctx *ctx, const wc_reference *ref, const double *zsrc, const 
                        ts.effect.as<double>(), ts.out_n.as<int>(), (const Extreme *)ts.partial.as<Extreme>(),
                        (const double2 *)ts.sub.as<double2>(), max_chunks, rider, inf, (const int *)nullptr,
                        (const int *)nullptr);
+    ts.walk_bound = 0;
     ts.last_segs = 0;                     // the calls are already in ts.effect / ts.out_n
     WC_HIP(hipGetLastError());
     return WC_OK;
@@ -5088,8 +5273,10 @@ wc_reference *wc_reference_create(wc_ctx *ctx, const int32_t *indexes, const dou
         }
     }
     const int64_t nk = n_bins * k;
-    // (+ 64 bytes: k_zscore reads a bin's list with 16-index loads, the last bin's beyond its end)
-    bool ok = ref->gidx.reserve(sizeof(int) * nk + 64) == 0 && ref->nref.reserve(sizeof(int) * n_bins) == 0 &&
+    // (+ 448 bytes: k_zscore reads a bin's list by seven unconditional 16-index loads -- 112 indexes from the list's
+    // start whatever refsize is; only their USE is guarded -- so the last bin's loads reach up to 112 - k indexes
+    // beyond the array)
+    bool ok = ref->gidx.reserve(sizeof(int) * nk + 448) == 0 && ref->nref.reserve(sizeof(int) * n_bins) == 0 &&
               ref->pca_mean.reserve(sizeof(double) * n_bins) == 0 &&
               ref->pca_comp.reserve(sizeof(double) * std::max<int64_t>(1, (int64_t)n_comp * n_bins)) == 0 &&
               ref->m2g.reserve(sizeof(int) * n_bins) == 0 && ref->g2m.reserve(sizeof(int) * ref->Btot) == 0 &&
@@ -5472,6 +5659,12 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
                                (const Seg *)ts.seg.as<Seg>(), (int)ts.last_segs,
                                (const Region *)ts.regions.as<Region>(), (const double *)ts.rc.as<double>(),
                                (const int *)ts.gpos.as<int>(), max_calls, ts.effect.as<double>(), (const int *)nullptr);
+        else if (ts.walk_bound > 0)        // k_seg_walk left the segments on the device: a grid for the bound, the count read there
+            hipLaunchKernelGGL(k_call_post, dim3((unsigned)ts.walk_bound), dim3(CP_THREADS), 0, stream,
+                               (const Seg *)ts.seg.as<Seg>(), (int)ts.walk_bound,
+                               (const Region *)ts.regions.as<Region>(), (const double *)ts.rc.as<double>(),
+                               (const int *)ts.gpos.as<int>(), max_calls, ts.effect.as<double>(),
+                               (const int *)(ts.job_cnt.as<int>() + 4));
         if (lat && (rc = join_side(ctx, stream))) return rc;      // the status words read k_sd_fast's flags
         hipLaunchKernelGGL(k_assemble_calls, dim3((unsigned)cdiv(Ns, 64)), dim3(64), 0, stream,   // latency mode: Ns <= 8, one workgroup
                            (const double *)ts.effect.as<double>(), (const int *)ts.out_n.as<int>(), n_sel, max_calls, Ns,
@@ -5486,7 +5679,7 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
                 // the tree kernel's status words arrived with this synchronize (run_stouffer queued the copy)
                 ts.tree_pending = false;
                 const int *h = (const int *)ctx->pinned;
-                if (h[3] != 0 || h[6] != 0) {
+                if (h[3] != 0 || h[6] != 0 || (ts.walk_bound > 0 && h[4] > ts.walk_bound)) {
                     // rare (non-finite region, tie overflow, deep recursion): the whole batch again with
                     // host-driven rounds -- the same results by construction, one batch time lost
                     ts.no_tree = true;

@@ -6,9 +6,10 @@ Python processes -- before the calling process has touched the GPU -- each bound
 
 newref     every rank loads the prep file (rank 0 writes it first if it is missing), the
            ranks share one NewrefJob pass (symmetric tile shard + candidate exchange, or row
-           bands; wisecondor_amd.distributed), every rank ends with all rows and writes the
-           part files it is dealt (part m goes to rank m mod N), so the merge step of the
-           parent finds exactly the files the upstream tool would have left.
+           bands; wisecondor_amd.distributed) and every rank writes the part files whose rows it
+           owns -- no result all-gather -- so the merge step of the parent finds exactly the
+           files the upstream tool would have left (parts that straddle two ranks' row ranges:
+           every rank gathers all rows, part m goes to rank m mod N).
 testbatch  the sample list is cut into N contiguous shards, no collective.
 
 A worker that fails makes launch() raise: the upstream pool never collects its futures, so
@@ -104,15 +105,26 @@ def _newref(spec, dist, rank, world, device):
     dist.barrier()                       # every rank has listed the missing parts before any is written
     if not todo:
         return
+    # Part m goes to the rank that owns its rows (with `parts` a multiple of the rank count every part lies inside one
+    # rank's row range): the ranks then keep their own rows and the result all-gather is skipped -- the reference's
+    # workers exchange nothing but files either (wisecondor.py:47-56).  Parts that straddle two ranks' ranges: every
+    # rank gathers all rows and part m goes to rank m mod N.
+    import numpy as np
+    from .distributed import row_range
+    n_bins = int(np.sum(np.asarray(np.load(spec['prepfile'], allow_pickle=True)['maskedChromBins'])))
+    owners = cli.part_owners(spec['parts'], todo, n_bins, world)
     indexes, distances, job = cli.select_all_rows(spec['prepfile'], spec['refsize'], device=device,
-                                                  rank=rank, world=world)
+                                                  rank=rank, world=world, gather=owners is None)
     if rank == 0:
-        print('reference bins for %d rows on %d GPUs (%s shard)' % (indexes.shape[0], world, job.mode))
+        print('reference bins for %d rows on %d GPUs (%s shard, %s)'
+              % (n_bins, world, job.mode, 'parts written by the owners of their rows' if owners is not None
+                 else 'every rank gathers all rows'))
+    first = 0 if owners is None else row_range(rank, world, n_bins)[0]
     for m in todo:
-        if m % world != rank:
+        if (m % world if owners is None else owners[m]) != rank:
             continue
-        lo, hi = wt.getPart(m - 1, spec['parts'], indexes.shape[0])
-        cli.save_part(spec['partfile'], m, spec['parts'], indexes[lo:hi], distances[lo:hi], args)
+        lo, hi = wt.getPart(m - 1, spec['parts'], n_bins)
+        cli.save_part(spec['partfile'], m, spec['parts'], indexes[lo - first:hi - first], distances[lo - first:hi - first], args)
     dist.barrier()
 
 

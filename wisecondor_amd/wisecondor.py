@@ -134,11 +134,30 @@ def save_part(part_base, number, parts, indexes, distances, args, temporary=Fals
               distances=distances)
 
 
-def select_all_rows(prepfile, refsize, device=0, rank=0, world=1):
+def part_owners(parts, numbers, n_bins, world):
+    """Which rank owns each of the part files `numbers` (1-based) of `parts`: the rank whose row range
+    (distributed.row_range = the reference's getPart for `world` parts) holds the part's rows; None when
+    some part straddles two ranks' ranges (then every rank needs all rows)."""
+    from .distributed import row_range
+    ranges = [row_range(r, world, n_bins) for r in range(world)]
+    owners = {}
+    for m in numbers:
+        lo, hi = wt.getPart(m - 1, parts, n_bins)
+        own = [r for r, (b, e) in enumerate(ranges) if b <= lo and hi <= e]
+        if hi <= lo:
+            own = [r for r, (b, e) in enumerate(ranges) if b <= lo <= e] or [0]
+        if not own:
+            return None
+        owners[m] = own[0]
+    return owners
+
+
+def select_all_rows(prepfile, refsize, device=0, rank=0, world=1, gather=True):
     """indexes / distances of every bin from a prep file, matrix resident on `device`.
 
     One NewrefJob pass (wisecondor_amd.distributed); with world > 1 the ranks share the work
-    and each ends with the full result."""
+    and each ends with the full result -- or, gather=False, with the rows it owns only (no result
+    all-gather: the reference's workers exchange nothing but files, wisecondor.py:47-56)."""
     import torch
     from . import _lib
     from .distributed import NewrefJob
@@ -149,7 +168,7 @@ def select_all_rows(prepfile, refsize, device=0, rank=0, world=1):
     dev = torch.device('cuda', device)
     torch.cuda.set_device(dev)
     X = torch.from_numpy(np.ascontiguousarray(corrected, dtype=np.float64)).to(dev)
-    job = NewrefJob(_lib.context(device), X, bins, int(refsize), order, rank=rank, world=world)
+    job = NewrefJob(_lib.context(device), X, bins, int(refsize), order, rank=rank, world=world, gather=gather)
     idx, dst = job.run()
     torch.cuda.synchronize()
     return idx.cpu().numpy(), dst.cpu().numpy(), job
