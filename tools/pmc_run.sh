@@ -3,7 +3,7 @@
 TAG=$1; CTRS=$2; shift 2
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $R/gpurun_out/$TAG -o pmc -- python3 "$R/$1" "${@:2}" > $R/gpurun_out/$TAG.log 2>&1
+timeout ${PMC_TIMEOUT:-240} rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $R/gpurun_out/$TAG -o pmc -- python3 "$R/$1" "${@:2}" > $R/gpurun_out/$TAG.log 2>&1
 cd $R
 python3 - <<PY
 import csv

@@ -63,7 +63,6 @@ struct TestState {
     bool tree_pending = false;          // ... but its status words are still on their way to pinned memory (deferred check)
     bool no_tree = false;               // repeat of a batch the tree kernel passed on: host-driven rounds only
     int64_t tree_seg_cap = 0;
-    int64_t walk_bound = 0;             // k_seg_walk ran: k_call_post's grid bound (the segment count is on the device)
     bool lat_ride = false;              // latency mode: stdDevAvg rides in k_seg_tree's grid (run_repeat -> run_seg_lat)
     double *lat_ride_out2 = nullptr;
     wc::DevBuf prof_work;               // u64[2]: windows evaluated by k_seg_search, evaluations by k_seg_quiet

@@ -4092,8 +4092,9 @@ __global__ __launch_bounds__(256) void k_seg_gather(const Seg *__restrict__ segs
 constexpr int CP_THREADS = 1024;     // threads of a k_call_post workgroup (one per segment)
 // k-th smallest (0-based) of v[0..L) by radix selection on the ordered 64-bit image;
 // all CP_THREADS threads of the workgroup take part.
+template <int NT = CP_THREADS>      // NT >= 256 threads
 __device__ inline double block_select(const double *__restrict__ v, int L, int k, int tid) {
-    // CP_THREADS threads; the 256 digit buckets are scanned by the first four waves
+    // NT threads; the 256 digit buckets are scanned by the first four waves
     __shared__ unsigned int hist[256];
     __shared__ unsigned int s_wsum[4];
     __shared__ unsigned long long s_prefix;
@@ -4102,7 +4103,7 @@ __device__ inline double block_select(const double *__restrict__ v, int L, int k
     for (int shift = 56; shift >= 0; shift -= 8) {
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
-        for (int e = tid; e < L; e += CP_THREADS) {
+        for (int e = tid; e < L; e += NT) {
             unsigned long long key = wc::f64_ordered(v[e]);
             if ((key & mask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
         }
@@ -4319,8 +4320,8 @@ __global__ __launch_bounds__(1024) void k_seg_tree(int *__restrict__ counters, c
 // region itself and every child -- searched with the cell bounds (cell_search): root search, classification,
 // candidate list, exact decision, children, in ONE launch for the whole batch and without a host round trip
 // (k_seg_job / k_seg_merge / k_seg_decide once per recursion level, and k_seg_quiet / k_seg_search / k_seg_classify /
-// k_seg_tree of the 250 kb batches, are what it replaces).  Segments go to segs[] (k_call_post turns them into call
-// rows), their number per region to out_n.  What it is not built for -- non-finite values, more than CAND_CAP tied
+// k_seg_tree of the 250 kb batches, are what it replaces); the region's call rows -- position order, genomic bounds,
+// effect size -- at the end of the same workgroup's life (k_seg_gather + k_call_post).  What it is not built for -- non-finite values, more than CAND_CAP tied
 // candidates, a recursion deeper than the stack -- sets counters[6] and the caller repeats the call with the
 // host-driven rounds.
 constexpr int WALK_STACK = 64;
@@ -4330,12 +4331,16 @@ __global__ __launch_bounds__(256) void k_seg_walk(int *__restrict__ counters, co
                                                   const double *__restrict__ reg_abs, const double *__restrict__ z,
                                                   double thr, int min_search, const double *__restrict__ tmin,
                                                   const double *__restrict__ tmax, const double *__restrict__ tmin2,
-                                                  const double *__restrict__ tmax2, Seg *__restrict__ segs, int seg_cap,
-                                                  int *__restrict__ out_n, unsigned long long *__restrict__ work) {
+                                                  const double *__restrict__ tmax2, const double *__restrict__ ratio,
+                                                  const int *__restrict__ gpos, int max_calls,
+                                                  double *__restrict__ reg_calls, int *__restrict__ out_n,
+                                                  unsigned long long *__restrict__ work) {
     __shared__ CellShared sh;
     __shared__ Job stack[WALK_STACK];
-    __shared__ int s_sp, s_nseg, s_stop;
+    __shared__ int s_sp, s_nseg, s_stop, s_nan;
     __shared__ BestPair s_best[4];
+    __shared__ double seg_val[TREE_SEGS];
+    __shared__ int seg_x[TREE_SEGS], seg_y[TREE_SEGS];
     const int region = blockIdx.x, tid = threadIdx.x;
     if (region >= n_regions) return;
     const Region rg = regions[region];
@@ -4425,13 +4430,8 @@ __global__ __launch_bounds__(256) void k_seg_walk(int *__restrict__ counters, co
             int cx = b.mx, cy = b.my;
             if (fabs(b.minv) > champ) { champ = b.minv; cx = b.nx; cy = b.ny; }
             if (!(fabs(champ) < thr)) {
-                const int at = atomicAdd(&counters[4], 1);
-                if (at < seg_cap) {
-                    Seg sgm;
-                    sgm.val = champ; sgm.region = region; sgm.x = cx; sgm.y = cy; sgm.pad = 0;
-                    segs[at] = sgm;
-                }
-                ++s_nseg;
+                if (s_nseg < TREE_SEGS) { seg_val[s_nseg] = champ; seg_x[s_nseg] = cx; seg_y[s_nseg] = cy; ++s_nseg; }
+                else { counters[6] = 1; s_stop = 1; }
                 const int xr = cx - job.lo, yr = cy - job.lo, edge = job.hi - job.lo;
                 const bool left = xr > min_search, right = yr + 1 < edge - min_search;
                 if (s_sp + (left ? 1 : 0) + (right ? 1 : 0) > WALK_STACK) {
@@ -4444,7 +4444,55 @@ __global__ __launch_bounds__(256) void k_seg_walk(int *__restrict__ counters, co
             }
         }
     }
-    if (tid == 0) out_n[region] = s_nseg;
+    // ---- the region's calls in position order (k_seg_gather + k_call_post of the general path): genomic start / end,
+    // value, effect = median of the segment's ratios - 1 (np.median by radix selection; wisecondor.py:233-257)
+    __syncthreads();
+    const int nseg = s_nseg;
+    if (tid == 0) {
+        out_n[region] = nseg;
+        atomicAdd(&counters[4], nseg);
+    }
+    double *sv = sh.pn;                            // a segment's ratios (up to 2048 of them; longer ones are read in place)
+    static_assert(2048 * sizeof(double) <= sizeof(sh.pn) + sizeof(sh.b8x) + sizeof(sh.b8n) + sizeof(sh.q2) + sizeof(sh.q1) +
+                                               sizeof(sh.l1) + sizeof(sh.itemq), "the staged segment does not fit the search's staging area");
+    for (int sidx = 0; sidx < nseg; ++sidx) {
+        const int x = seg_x[sidx], y = seg_y[sidx], Ls = y - x + 1;
+        int rank = 0;
+        for (int u = 0; u < nseg; ++u) rank += seg_x[u] < x;
+        if (rank >= max_calls) continue;                   // k_assemble_calls reports the overflow from out_n
+        __syncthreads();
+        if (tid == 0) s_nan = 0;
+        __syncthreads();
+        const double *rr = ratio + rg.off + x;
+        const bool staged = Ls <= 2048;
+        for (int e = tid; e < Ls; e += 256) {
+            const double v = rr[e];
+            if (staged) sv[e] = v;
+            if (v != v) s_nan = 1;
+        }
+        __syncthreads();
+        const bool has_nan = s_nan != 0;
+        double lo = 0.0, hi = 0.0;
+        if (!has_nan) {
+            const double *src = staged ? sv : rr;
+            lo = block_select<256>(src, Ls, (Ls - 1) / 2, tid);
+            hi = (Ls & 1) ? lo : block_select<256>(src, Ls, Ls / 2, tid);
+        }
+        if (tid == 0) {
+            double med = (Ls & 1) ? lo : (lo + hi) / 2.0;  // np.median: mean of the middle pair
+            if (has_nan) med = NAN;
+            // the end walk of the reference restarts at `start` and re-counts it:
+            // end = position(survivor y-1) + 1, or start itself when y == x
+            const int start = gpos[rg.off + x];
+            const int end = (y > x) ? gpos[rg.off + y - 1] + 1 : start;
+            double *o = reg_calls + ((int64_t)region * max_calls + rank) * 5;
+            o[0] = (double)(rg.pad + 1);
+            o[1] = (double)start;
+            o[2] = (double)end;
+            o[3] = seg_val[sidx];
+            o[4] = med - 1.0;
+        }
+    }
     if (work) {
         for (int o = 32; o > 0; o >>= 1) { evals += __shfl_xor(evals, o); wins += __shfl_xor(wins, o); }
         const int slot = (int)((blockIdx.x * 7u + (unsigned)w) & 63u);
@@ -4725,7 +4773,6 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     ts.last_segs = 0;
     ts.tree_done = false;
     ts.tree_pending = false;
-    ts.walk_bound = 0;
     if (n_regions == 0) return WC_OK;
     const int64_t job_cap = n_regions + total_len / 4 + 64;
     const int64_t seg_cap = n_regions * (int64_t)max_calls + 64;
@@ -4873,10 +4920,10 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
                            (int)n_regions, (const int *)ts.reg_flag.as<int>(), (const double *)ts.prefix.as<double>(),
                            (const double *)ts.rs.as<double>(), (const double *)ts.reg_abs.as<double>(), z_dev, thr,
                            min_search, (const double *)ts.tmin.as<double>(), (const double *)ts.tmax.as<double>(),
-                           (const double *)ts.tmin2.as<double>(), (const double *)ts.tmax2.as<double>(), ts.seg.as<Seg>(),
-                           (int)seg_cap, ts.out_n.as<int>(), work);
+                           (const double *)ts.tmin2.as<double>(), (const double *)ts.tmax2.as<double>(), tail->ratio,
+                           tail->gpos, max_calls, tail->reg_calls, ts.out_n.as<int>(), work);
         ts.mark(11, stream);
-        const int64_t bound = std::min<int64_t>(seg_cap, std::max<int64_t>(2048, 2 * n_regions));
+        const int64_t bound = seg_cap;
         WC_HIP(hipMemcpyAsync(h, counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
         if (tail->defer_status) {
             // the caller looks at the counters after ITS synchronize: h[6] non-zero = the walk gave up on some
@@ -4885,14 +4932,12 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
             ts.tree_done = true;
             ts.tree_pending = true;
             ts.tree_seg_cap = bound;
-            ts.walk_bound = bound;
             WC_HIP(hipGetLastError());
             return WC_OK;
         }
         WC_HIP(hipStreamSynchronize(stream));
         if (h[6] == 0 && h[4] <= bound) {
             ts.tree_done = true;
-            ts.walk_bound = bound;
             WC_HIP(hipGetLastError());
             return WC_OK;
         }
@@ -5178,7 +5223,6 @@ int run_seg_lat(wc_ctx *ctx, const wc_reference *ref, const double *zsrc, const 
                        ts.effect.as<double>(), ts.out_n.as<int>(), (const Extreme *)ts.partial.as<Extreme>(),
                        (const double2 *)ts.sub.as<double2>(), max_chunks, rider, inf, (const int *)nullptr,
                        (const int *)nullptr);
-    ts.walk_bound = 0;
     ts.last_segs = 0;                     // the calls are already in ts.effect / ts.out_n
     WC_HIP(hipGetLastError());
     return WC_OK;
@@ -5659,12 +5703,6 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
                                (const Seg *)ts.seg.as<Seg>(), (int)ts.last_segs,
                                (const Region *)ts.regions.as<Region>(), (const double *)ts.rc.as<double>(),
                                (const int *)ts.gpos.as<int>(), max_calls, ts.effect.as<double>(), (const int *)nullptr);
-        else if (ts.walk_bound > 0)        // k_seg_walk left the segments on the device: a grid for the bound, the count read there
-            hipLaunchKernelGGL(k_call_post, dim3((unsigned)ts.walk_bound), dim3(CP_THREADS), 0, stream,
-                               (const Seg *)ts.seg.as<Seg>(), (int)ts.walk_bound,
-                               (const Region *)ts.regions.as<Region>(), (const double *)ts.rc.as<double>(),
-                               (const int *)ts.gpos.as<int>(), max_calls, ts.effect.as<double>(),
-                               (const int *)(ts.job_cnt.as<int>() + 4));
         if (lat && (rc = join_side(ctx, stream))) return rc;      // the status words read k_sd_fast's flags
         hipLaunchKernelGGL(k_assemble_calls, dim3((unsigned)cdiv(Ns, 64)), dim3(64), 0, stream,   // latency mode: Ns <= 8, one workgroup
                            (const double *)ts.effect.as<double>(), (const int *)ts.out_n.as<int>(), n_sel, max_calls, Ns,
@@ -5679,7 +5717,7 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
                 // the tree kernel's status words arrived with this synchronize (run_stouffer queued the copy)
                 ts.tree_pending = false;
                 const int *h = (const int *)ctx->pinned;
-                if (h[3] != 0 || h[6] != 0 || (ts.walk_bound > 0 && h[4] > ts.walk_bound)) {
+                if (h[3] != 0 || h[6] != 0) {
                     // rare (non-finite region, tie overflow, deep recursion): the whole batch again with
                     // host-driven rounds -- the same results by construction, one batch time lost
                     ts.no_tree = true;
