@@ -795,20 +795,18 @@ __device__ inline void zscore_pair8(const unsigned int gid, const int sub, const
         GroupSum acc;
         acc.init();
 #pragma unroll
-        for (int t8 = 0; t8 < 16; ++t8) {
-            if (8 * t8 >= n) break;
-            acc.trip(v[t8], v[t8] >= 0.0, sub, gbase);   // flagged (-1), negative and NaN values are dropped (wisetools.py:425)
-        }
+        for (int t8 = 0; t8 < 16; ++t8)      // (a predicate, not a break: the loop unrolls and v[] stays in registers)
+            if (8 * t8 < n) acc.trip(v[t8], v[t8] >= 0.0, sub, gbase);   // flagged (-1), negative and NaN values are dropped (wisetools.py:425)
         m = acc.pos;
         mean = acc.finish(sub, gbase) / (double)m;
         acc.init();
 #pragma unroll
-        for (int t8 = 0; t8 < 16; ++t8) {
-            if (8 * t8 >= n) break;
-            const double dv = v[t8] - mean;
-            const double sq = dv * dv;
-            acc.trip(sq, v[t8] >= 0.0, sub, gbase);
-        }
+        for (int t8 = 0; t8 < 16; ++t8)
+            if (8 * t8 < n) {
+                const double dv = v[t8] - mean;
+                const double sq = dv * dv;
+                acc.trip(sq, v[t8] >= 0.0, sub, gbase);
+            }
         var = acc.finish(sub, gbase) / (double)m;
     }
     if (sub == 0) {
@@ -1206,10 +1204,8 @@ __device__ inline void sd_fast_block(const int64_t i, SdShared *sm, const double
     auto for_each = [&](auto f) {
         if (REG > 0) {
 #pragma unroll
-            for (int e = 0; e < NREG; ++e) {
-                if (e >= n_mine) break;
-                f(xr[e]);
-            }
+            for (int e = 0; e < NREG; ++e)           // (a predicate, not a break: the loop unrolls, xr[] stays in registers)
+                if (e < n_mine) f(xr[e]);
         } else {
             for (int e0 = 0; e0 < n_mine; e0 += 8) {
                 double b8[8];
@@ -1459,10 +1455,12 @@ __global__ __launch_bounds__(1024) void k_clean(const double *__restrict__ zT, c
                                                 double minref, double *__restrict__ zc, double *__restrict__ rc,
                                                 int *__restrict__ gpos, Region *__restrict__ regions,
                                                 int64_t str_i, int64_t str_b) {
-    // one 1 024-thread workgroup per (sample, chromosome): 1 024 bins per trip, the kept ones compacted in
-    // order (ballot within a wave, the sixteen wave counts through LDS).  One wave per region walked a 50 kb
-    // chromosome in 74 dependent trips (0.22 ms per 125-sample batch).
-    __shared__ int s_cnt[2][16];
+    // one workgroup (up to 1 024 threads) per (sample, chromosome): CL_U x blockDim bins per trip -- every load of a
+    // trip requested before the first is used -- the kept ones compacted in order (ballot within a wave, the
+    // wave counts of the trip's CL_U slices through LDS: one barrier per trip).  One wave per region walked a 50 kb
+    // chromosome in 74 dependent trips (0.22 ms per 125-sample batch), 1 024 bins per trip in five (0.13 ms).
+    constexpr int CL_U = 4;
+    __shared__ int s_cnt[2][CL_U][16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t i = blockIdx.y;
     const int si = blockIdx.x;
@@ -1470,35 +1468,50 @@ __global__ __launch_bounds__(1024) void k_clean(const double *__restrict__ zT, c
     const int64_t cs = moff[c], ce = moff[c + 1];
     int count = 0, trip = 0;
     const int nt = (int)blockDim.x, nwaves = nt >> 6;      // 64 .. 1 024 threads: the launch sizes the workgroup to the regions
-    for (int64_t base = cs; base < ce; base += nt, trip ^= 1) {
-        const int64_t b = base + tid;
-        bool keep = false;
-        double zv = 0.0, rv = 0.0;
-        int gp = 0;
-        if (b < ce) {
-            keep = nT[i * str_i + b * str_b] >= minref;
-            zv = zT[i * str_i + b * str_b];
-            rv = rT[i * str_i + b * str_b];
-            gp = (int)(m2g[b] - goff[c]);
-        }
-        const unsigned long long mask = __ballot(keep);
-        if (lane == 0) s_cnt[trip][w] = __popcll(mask);
-        if (tid < 16 && tid >= nwaves) s_cnt[trip][tid] = 0;       // waves this workgroup does not have
-        __syncthreads();                     // (the other buffer is written in the next trip: one barrier per trip)
-        int before = 0, total = 0;
+    const int goff_c = (int)goff[c];
+    for (int64_t base = cs; base < ce; base += (int64_t)CL_U * nt, trip ^= 1) {
+        bool keep[CL_U];
+        double zv[CL_U], rv[CL_U], nv[CL_U];
+        int gp[CL_U];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int n = s_cnt[trip][q];
-            before += q < w ? n : 0;
-            total += n;
+        for (int u = 0; u < CL_U; ++u) {
+            const int64_t b = base + (int64_t)u * nt + tid;
+            const bool in = b < ce;
+            const int64_t at = i * str_i + (in ? b : cs) * str_b;
+            nv[u] = nT[at];
+            zv[u] = zT[at];
+            rv[u] = rT[at];
+            gp[u] = m2g[in ? b : cs] - goff_c;
+            keep[u] = in;
         }
-        if (keep) {
-            const int at = count + before + __popcll(mask & ((1ull << lane) - 1ull));
-            zc[i * B + cs + at] = zv;
-            rc[i * B + cs + at] = rv;
-            gpos[i * B + cs + at] = gp;
+        unsigned long long mask[CL_U];
+#pragma unroll
+        for (int u = 0; u < CL_U; ++u) {
+            keep[u] = keep[u] && nv[u] >= minref;
+            mask[u] = __ballot(keep[u]);
+            if (lane == 0) s_cnt[trip][u][w] = __popcll(mask[u]);
+            if (tid < 16 && tid >= nwaves) s_cnt[trip][u][tid] = 0;  // waves this workgroup does not have
         }
-        count += total;
+        __syncthreads();                     // (the other buffer is written in the next trip: one barrier per trip)
+        int before = count;
+#pragma unroll
+        for (int u = 0; u < CL_U; ++u) {
+            int mine = 0, total = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int n = s_cnt[trip][u][q];
+                mine += q < w ? n : 0;
+                total += n;
+            }
+            if (keep[u]) {
+                const int at = before + mine + __popcll(mask[u] & ((1ull << lane) - 1ull));
+                zc[i * B + cs + at] = zv[u];
+                rc[i * B + cs + at] = rv[u];
+                gpos[i * B + cs + at] = gp[u];
+            }
+            before += total;
+        }
+        count = before;
     }
     if (tid == 0) {
         Region rg;
@@ -4325,7 +4338,7 @@ __global__ __launch_bounds__(1024) void k_seg_tree(int *__restrict__ counters, c
 // candidates, a recursion deeper than the stack -- sets counters[6] and the caller repeats the call with the
 // host-driven rounds.
 constexpr int WALK_STACK = 64;
-__global__ __launch_bounds__(256) void k_seg_walk(int *__restrict__ counters, const Region *__restrict__ regions,
+__global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters, const Region *__restrict__ regions,
                                                   int n_regions, const int *__restrict__ reg_flag,
                                                   const double *__restrict__ prefix, const double *__restrict__ rs,
                                                   const double *__restrict__ reg_abs, const double *__restrict__ z,
@@ -5669,7 +5682,7 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
         const bool fuse = min_effect == 0.0 && max_n <= TREE_MAXLEN;       // regions that fit the fused set-up kernel
         if (!fuse)
         hipLaunchKernelGGL(k_clean, dim3((unsigned)n_sel, (unsigned)Ns),
-                           dim3((unsigned)std::min<int64_t>(1024, std::max<int64_t>(64, cdiv(max_n, 256) * 64))), 0, stream, zsrc, rsrc, nsrc, B, Ns,
+                           dim3((unsigned)std::min<int64_t>(1024, std::max<int64_t>(64, cdiv(max_n, 1024) * 256))), 0, stream, zsrc, rsrc, nsrc, B, Ns,
                            (const int64_t *)ref->moff_dev.as<int64_t>(), (const int64_t *)ref->goff_dev.as<int64_t>(),
                            (const int *)ref->m2g.as<int>(), (const int *)ts.sel.as<int>(), n_sel, (double)min_ref_bins,
                            ts.zc.as<double>(), ts.rc.as<double>(), ts.gpos.as<int>(), ts.regions.as<Region>(), str_i,

@@ -386,7 +386,9 @@ def _leading_eigenpairs(gram, n):
     return np.ascontiguousarray(vals[order]), np.ascontiguousarray(vecs[:, order].T)
 
 
-EIG_ON_GPU_FROM = 256       # samples; below, LAPACK on the fetched Gram matrix is quicker than ~n launches
+EIG_ON_GPU_FROM = 3         # samples: every size the solver takes stays on the GPU (up to 128 samples the whole
+                            # tridiagonalisation is ONE workgroup with the matrix in LDS; LAPACK on the fetched Gram
+                            # matrix is ~0.25 ms quicker at 100 samples: WC_PREP_EIG=host)
 
 
 def _eig_on_gpu(n_s, pcacomp):
