@@ -211,10 +211,12 @@ def test_newref_file_names_and_rank_count(monkeypatch):
 
 def test_prep_eigen_route_selection(monkeypatch):
     """Where prepReference solves trainPCA's eigenproblem (wisetools.py:89-101): csrc/eigh.hip from
-    EIG_ON_GPU_FROM samples, LAPACK on the fetched Gram matrix below; WC_PREP_EIG forces either."""
+    EIG_ON_GPU_FROM samples on (every size it takes), LAPACK on the fetched Gram matrix otherwise; WC_PREP_EIG forces either."""
     from wisecondor_amd import wisetools as wt
     monkeypatch.delenv("WC_PREP_EIG", raising=False)
-    assert not wt._eig_on_gpu(100, 3) and wt._eig_on_gpu(wt.EIG_ON_GPU_FROM, 3) and wt._eig_on_gpu(600, 3)
+    assert wt.EIG_ON_GPU_FROM == 3           # round 5: every size the solver takes stays on the GPU
+    assert wt._eig_on_gpu(100, 3) and wt._eig_on_gpu(wt.EIG_ON_GPU_FROM, 3) and wt._eig_on_gpu(600, 3)
+    assert not wt._eig_on_gpu(2, 1)
     assert not wt._eig_on_gpu(5000, 3) and not wt._eig_on_gpu(600, 9)      # beyond the solver: the host route
     monkeypatch.setenv("WC_PREP_EIG", "host")
     assert not wt._eig_on_gpu(600, 3)

@@ -22,12 +22,21 @@ for WL in cfg2 cfg4; do
     python3 tools/pmc_summary.py "$(find $P/pmc_$C -name '*counter_collection.csv' | head -1)" > "$OUT/${TAG}_${WL}_pmc_${lc}.csv"
   done
 done
-python3 bench.py 2> "$OUT/bench_stderr.log" | tail -1 > "$OUT/${TAG}_bench_cfg2_unprofiled.json"
+timeout 1200 python3 bench.py 2> "$OUT/bench_stderr.log" | tail -1 > "$OUT/${TAG}_bench_cfg2_unprofiled.json"
 # batched `test` at 50 kb (config 5's per-GPU share) and one sample per call (config 3): kernel statistics
 ( cd /tmp && export TMPDIR=/tmp
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof_${TAG}_cfg5" -o t -- python3 "$REPO/tools/gpu_test_scale.py" 125 50000 10 > "$OUT/cfg5_run.log" 2>&1
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof_${TAG}_test250" -o t -- python3 "$REPO/tools/gpu_test_scale.py" 128 250000 20 > "$OUT/test250_run.log" 2>&1
-  rocprofv3 --kernel-trace --output-format csv -d "$REPO/gpurun_out/prof_${TAG}_lat" -o t -- python3 "$REPO/tools/gpu_lat_trace.py" 40 > "$OUT/lat_run.log" 2>&1 )
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof_${TAG}_cfg5" -o t -- python3 "$REPO/tools/gpu_test_scale.py" 125 50000 10 > "$OUT/cfg5_run.log" 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof_${TAG}_test250" -o t -- python3 "$REPO/tools/gpu_test_scale.py" 128 250000 20 > "$OUT/test250_run.log" 2>&1
+  # the north-star's calls: 1 000 samples in one wc_test_batch_dev call at both bin sizes
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof_${TAG}_cfg5_1000" -o t -- python3 "$REPO/tools/gpu_test_scale.py" 1000 50000 6 > "$OUT/cfg5_1000_run.log" 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof_${TAG}_test250_1000" -o t -- python3 "$REPO/tools/gpu_test_scale.py" 1000 250000 10 > "$OUT/test250_1000_run.log" 2>&1
+  timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$REPO/gpurun_out/prof_${TAG}_lat" -o t -- python3 "$REPO/tools/gpu_lat_trace.py" 40 > "$OUT/lat_run.log" 2>&1 )
+cp "$(find gpurun_out/prof_${TAG}_cfg5_1000 -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_cfg5_1000_samples_kernel_stats.csv"
+cp "$(find gpurun_out/prof_${TAG}_test250_1000 -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_test250_1000_samples_kernel_stats.csv"
+grep "batch of" "$OUT/cfg5_run.log" "$OUT/test250_run.log" "$OUT/cfg5_1000_run.log" "$OUT/test250_1000_run.log" > "$OUT/${TAG}_test_batch_times_under_rocprof.txt"
+# the gather roof of the z-score stage: micro-benchmark by matrix size and access width, and k_zscore's TA / TCP / TLB counters
+( for n in 3000 11087 55337; do timeout 120 python3 tools/micro/gather_rate.py $n 2>&1 | grep "^bins" | head -4; done ) > "$OUT/${TAG}_gather_roof.txt"
+( echo "== 125 x 50 kb"; PMC_TIMEOUT=120 bash tools/pmc_zscore.sh ${TAG} 125 50000; echo "== 128 x 250 kb"; PMC_TIMEOUT=120 bash tools/pmc_zscore.sh ${TAG}q 128 250000 ) > "$OUT/${TAG}_zscore_ta_tcp.txt" 2>&1
 cp "$(find gpurun_out/prof_${TAG}_cfg5 -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_cfg5_test_kernel_stats.csv"
 cp "$(find gpurun_out/prof_${TAG}_test250 -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_test250_kernel_stats.csv"
 python3 - "$(find gpurun_out/prof_${TAG}_lat -name '*kernel_trace.csv' | head -1)" "$OUT/${TAG}_latency_trace.json" <<'PY'
@@ -54,7 +63,7 @@ print(open(sys.argv[2]).read())
 PY
 # newref prep at 600 x 50 kb (Gram, eigen-solve on the GPU, finish): kernel statistics and the eigen-solver's timings
 ( cd /tmp && export TMPDIR=/tmp
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof_${TAG}_prep" -o t -- python3 "$REPO/tools/gpu_prep_time.py" cfg4 > "$OUT/prep_run.log" 2>&1 )
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof_${TAG}_prep" -o t -- python3 "$REPO/tools/gpu_prep_time.py" cfg4 > "$OUT/prep_run.log" 2>&1 )
 cp "$(find gpurun_out/prof_${TAG}_prep -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_prep_cfg4_kernel_stats.csv"
 python3 tools/gpu_prep_time.py cfg4 > "$OUT/${TAG}_prep_cfg4_times.txt"
 python3 tools/gpu_eig_time.py 100 300 600 1000 1200 2400 > "$OUT/${TAG}_eig_times.json" 2> /dev/null
