@@ -43,7 +43,7 @@ PEAK_HBM = 8.0e12           # bytes/s, spec (6.3e12 achievable by a copy)
 PEAK_L2 = 34.5e12           # bytes/s aggregate over the 8 XCDs
 PEAK_FP64_VALU_OPS = 39.3e12  # float64 vector add / mul / max per second (78.6 TFLOP/s counts an FMA as two)
 PEAK_MALL = 10.0e12         # bytes/s the Infinity Cache sustains towards the L2s (order of magnitude, MI355X_MICROARCH.md)
-ROUND = "r04"
+ROUND = "r05"
 PIPE_DEPTH = 4        # batches of the batched test in flight (distributed.TestPipeline)
 LATENCY_LAUNCHES = 8        # kernels of one latency-mode `test` call
 

@@ -256,18 +256,29 @@ __global__ void k_normalize(const int *__restrict__ counts, int64_t Btot, const 
 // Projection on the components: PROJ_SPLIT workgroups per sample, each over a contiguous
 // slice of the bins; k_pca_apply adds the slice sums in slice order (deterministic).
 constexpr int PROJ_SPLIT = 8;
+// raw != NULL: the normalised vectors as k_normalize wrote them; raw == NULL (batches): the same values taken from
+// the counts on the fly (one IEEE division per element, the expression of k_normalize)
 __global__ __launch_bounds__(256) void k_pca_project(const double *__restrict__ raw, int64_t B,
                                                      const double *__restrict__ mean, const double *__restrict__ comp,
-                                                     int n_comp, double *__restrict__ proj) {
+                                                     int n_comp, double *__restrict__ proj,
+                                                     const int *__restrict__ counts = nullptr, int64_t Btot = 0,
+                                                     const int *__restrict__ m2g = nullptr,
+                                                     const long long *__restrict__ partial = nullptr) {
     __shared__ double sh[MAX_COMP][256];
-    const double *x = raw + (int64_t)blockIdx.x * B;
+    const double *x = raw ? raw + (int64_t)blockIdx.x * B : nullptr;
+    const int *cnt = counts ? counts + (int64_t)blockIdx.x * Btot : nullptr;
+    long long tot = 0;
+    if (!raw)
+#pragma unroll
+        for (int q = 0; q < TOT_SPLIT; ++q) tot += partial[(int64_t)blockIdx.x * TOT_SPLIT + q];
     const int64_t per = (B + PROJ_SPLIT - 1) / PROJ_SPLIT;
     const int64_t b_lo = (int64_t)blockIdx.y * per, b_hi = b_lo + per < B ? b_lo + per : B;
     double acc[MAX_COMP];
 #pragma unroll
     for (int c = 0; c < MAX_COMP; ++c) acc[c] = 0.0;
     for (int64_t b = b_lo + threadIdx.x; b < b_hi; b += 256) {
-        double d = x[b] - mean[b];
+        const double xv = raw ? x[b] : (double)cnt[m2g[b]] / (double)tot;
+        double d = xv - mean[b];
 #pragma unroll
         for (int c = 0; c < MAX_COMP; ++c)
             if (c < n_comp) acc[c] += d * comp[(int64_t)c * B + b];
@@ -299,6 +310,68 @@ __global__ void k_pca_apply(const double *__restrict__ raw, int64_t B, const dou
     }
     rec += mean[b];
     out[i * B + b] = raw[i * B + b] / rec;
+}
+
+// Batches: normalisation (k_normalize's division), x / reconstruction (k_pca_apply's arithmetic, term by term) and the
+// transpose into the repeats' bin-major arrays (k_transpose with its two outputs and the cleared flag words) in ONE
+// launch: 32 bins x 32 samples per workgroup through LDS -- the sample-major intermediates (raw, data: 2 x 55 MB per
+// 125 x 50 kb batch, written and read again) are never made.
+__global__ void k_pca_apply_t(const int *__restrict__ counts, int64_t Btot, const int *__restrict__ m2g, int64_t B,
+                              int64_t Ns, const long long *__restrict__ partial, const double *__restrict__ mean,
+                              const double *__restrict__ comp, int n_comp, const double *__restrict__ proj,
+                              double *__restrict__ xt, double *__restrict__ xc, int *__restrict__ zero,
+                              int64_t n_zero) {
+    __shared__ double tile[32][33];
+    __shared__ double s_t[32][MAX_COMP], s_tot[32];
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 32 + tx;
+    if (zero) {
+        const int64_t nthreads = (int64_t)gridDim.x * gridDim.y * 256;
+        const int64_t me = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid;
+        for (int64_t t = me; t < n_zero; t += nthreads) zero[t] = 0;
+    }
+    const int64_t b0 = (int64_t)blockIdx.x * 32, i0 = (int64_t)blockIdx.y * 32;
+    if (tid < 32) {
+        long long t = 0;
+        if (i0 + tid < Ns)
+#pragma unroll
+            for (int q = 0; q < TOT_SPLIT; ++q) t += partial[(i0 + tid) * TOT_SPLIT + q];
+        s_tot[tid] = (double)t;
+    }
+    {
+        const int sm = tid >> 3, c = tid & 7;                 // MAX_COMP == 8
+        double t = 0.0;
+        if (c < n_comp && i0 + sm < Ns)
+            for (int q = 0; q < PROJ_SPLIT; ++q) t += proj[((i0 + sm) * PROJ_SPLIT + q) * MAX_COMP + c];
+        s_t[sm][c] = t;
+    }
+    __syncthreads();
+    const int64_t b = b0 + tx;
+    const double mean_b = b < B ? mean[b] : 0.0;
+    const int g = b < B ? m2g[b] : 0;
+    double cb[MAX_COMP];
+#pragma unroll
+    for (int c = 0; c < MAX_COMP; ++c) cb[c] = (c < n_comp && b < B) ? comp[(int64_t)c * B + b] : 0.0;
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t i = i0 + j;
+        if (i < Ns && b < B) {
+            const double raw = (double)counts[i * Btot + g] / s_tot[j];
+            double rec = 0.0;
+#pragma unroll
+            for (int c = 0; c < MAX_COMP; ++c)
+                if (c < n_comp) rec += s_t[j][c] * cb[c];
+            rec += mean_b;
+            tile[j][tx] = raw / rec;
+        }
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t bb = b0 + j, i = i0 + tx;
+        if (bb < B && i < Ns) {
+            const double v = tile[tx][j];
+            xt[bb * Ns + i] = v;
+            xc[bb * Ns + i] = v;
+        }
+    }
 }
 
 // Latency mode (a few samples per call): the four preparation launches as two.
@@ -4568,7 +4641,7 @@ void launch_transpose(const double *in, int64_t R, int64_t C, double *out, hipSt
 // lat: latency mode -- k_lat_prepare has already written xt / xc and cleared the counters; the first
 // repeat runs as usual, repeats 2.. in one launch (k_lat_repeats; its overflow flag is pair_counts[repeats + 1])
 int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int64_t Ns, double thr, int repeats,
-               hipStream_t stream, bool lat = false, double *asdef_out = nullptr) {
+               hipStream_t stream, bool lat = false, double *asdef_out = nullptr, bool xt_ready = false) {
     TestState &ts = ctx->ts;
     const int64_t n = ref->B * Ns;
     int rc;
@@ -4585,7 +4658,7 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
             if ((rc = b->reserve(sizeof(unsigned int) * n))) return rc;
     int *pair_counts = ts.misc2.as<int>();                       // [repeats + 2]: pairs queued for repeat it
     unsigned int *dirty = (unsigned int *)(pair_counts + repeats + 2);
-    if (!lat)
+    if (!lat && !xt_ready)       // (xt_ready: the caller's prepare kernel wrote xt / xc and cleared the words)
         launch_transpose(data_dev, Ns, ref->B, ts.xt.as<double>(), stream, ts.xc.as<double>(), pair_counts,
                          repeats > 0 ? repeats + 2 + n_words : 0);
     const unsigned g = (unsigned)cdiv(n, 256);
@@ -5603,11 +5676,29 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
                            (const double *)ref->pca_mean.as<double>(), (const double *)ref->pca_comp.as<double>(),
                            ref->n_comp, (const double *)ts.proj.as<double>(), ts.data.as<double>(), ts.xt.as<double>(),
                            ts.xc.as<double>(), ts.misc2.as<int>(), repeats + 2 + n_words);
-    } else if ((rc = run_prepare(ctx, ref, counts, Ns, stream))) {
-        return rc;
+    } else {
+        // totals -> projection partial sums (normalised values on the fly) -> corrected values straight into the
+        // repeats' bin-major arrays: three launches, no sample-major intermediate
+        const int64_t n = B * Ns, n_words = cdiv(n, 32);
+        if ((rc = ts.totals.reserve(sizeof(long long) * Ns * TOT_SPLIT))) return rc;
+        if ((rc = ts.proj.reserve(sizeof(double) * Ns * MAX_COMP * PROJ_SPLIT))) return rc;
+        if ((rc = ts.xt.reserve(sizeof(double) * n))) return rc;
+        if ((rc = ts.xc.reserve(sizeof(double) * n))) return rc;
+        if ((rc = ts.misc2.reserve(sizeof(int) * (repeats + 2 + n_words)))) return rc;
+        hipLaunchKernelGGL(k_sample_totals, dim3((unsigned)Ns, TOT_SPLIT), dim3(256), 0, stream, counts, ref->Btot,
+                           ts.totals.as<long long>());
+        hipLaunchKernelGGL(k_pca_project, dim3((unsigned)Ns, PROJ_SPLIT), dim3(256), 0, stream, (const double *)nullptr, B,
+                           (const double *)ref->pca_mean.as<double>(), (const double *)ref->pca_comp.as<double>(),
+                           ref->n_comp, ts.proj.as<double>(), counts, ref->Btot, (const int *)ref->m2g.as<int>(),
+                           (const long long *)ts.totals.as<long long>());
+        hipLaunchKernelGGL(k_pca_apply_t, dim3((unsigned)cdiv(B, 32), (unsigned)cdiv(Ns, 32)), dim3(32, 8), 0, stream, counts,
+                           ref->Btot, (const int *)ref->m2g.as<int>(), B, Ns, (const long long *)ts.totals.as<long long>(),
+                           (const double *)ref->pca_mean.as<double>(), (const double *)ref->pca_comp.as<double>(),
+                           ref->n_comp, (const double *)ts.proj.as<double>(), ts.xt.as<double>(), ts.xc.as<double>(),
+                           ts.misc2.as<int>(), repeats > 0 ? repeats + 2 + n_words : 0);
     }
     ts.mark(1, stream);
-    if ((rc = run_repeat(ctx, ref, ts.data.as<double>(), Ns, threshold, repeats, stream, lat, asdef))) return rc;
+    if ((rc = run_repeat(ctx, ref, ts.data.as<double>(), Ns, threshold, repeats, stream, lat, asdef, !lat))) return rc;
     ts.mark(2, stream);
     struct Joiner {   // asdef is copied out once the side stream's sum is done, on every exit path
         wc_ctx *c; hipStream_t s; double *dst; int64_t n; bool on;
