@@ -11,7 +11,7 @@ rng = np.random.RandomState(0)
 for n_bins in (n_rows, 2 * n_rows):
     idx = torch.from_numpy(rng.randint(0, n_rows, size=(n_bins, n_ref)).astype(np.int32)).cuda()
     out = torch.zeros((n_bins, 64), dtype=torch.float64, device="cuda")
-    for mode, row_bytes, useful in ((0, 1000, 512), (0, 1024, 512), (1, 1024, 1024), (2, 1024, 1024)):
+    for mode, row_bytes, useful in ((0, 1000, 512), (0, 1024, 512), (1, 1024, 1024), (2, 1024, 1024), (3, 1024, 1024)):
         X = torch.rand((n_rows, row_bytes // 8), dtype=torch.float64, device="cuda")
         s = torch.cuda.current_stream().cuda_stream
         for _ in range(3):
