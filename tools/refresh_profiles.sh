@@ -23,6 +23,7 @@ for WL in cfg2 cfg4; do
   done
 done
 timeout 1200 python3 bench.py 2> "$OUT/bench_stderr.log" | tail -1 > "$OUT/${TAG}_bench_cfg2_unprofiled.json"
+timeout 600 python3 bench.py --workload cfg4 --steps 10 --warmup 2 --no-extra --no-cpu-baseline 2> "$OUT/bench_cfg4_stderr.log" | tail -1 > "$OUT/${TAG}_bench_cfg4_unprofiled.json"
 # batched `test` at 50 kb (config 5's per-GPU share) and one sample per call (config 3): kernel statistics
 ( cd /tmp && export TMPDIR=/tmp
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/prof_${TAG}_cfg5" -o t -- python3 "$REPO/tools/gpu_test_scale.py" 125 50000 10 > "$OUT/cfg5_run.log" 2>&1
