@@ -22,6 +22,7 @@ wisecondor_amd/synth.py.
 import argparse
 import json
 import os
+import re
 import subprocess
 import sys
 import tempfile
@@ -160,6 +161,29 @@ def committed_latency_trace():
             t["measured_in_this_run"] = False
             return t
     return None
+
+
+def committed_gather_roof(n_rows):
+    """What a kernel that does nothing but gather whole rows of an [n_rows, 1 KB] matrix reaches on this chip
+    (tools/micro/gather_rate.*, 8 B per lane, every XCD gathering from the whole matrix; committed by
+    tools/refresh_profiles.sh as profiles/<round>_gather_roof.txt): the figure of the nearest matrix size, or None."""
+    import numpy as np
+    path = os.path.join(ROOT, "profiles", "%s_gather_roof.txt" % ROUND)
+    if not os.path.exists(path):
+        return None
+    best = None
+    for line in open(path):
+        m = re.match(r"bins\s+(\d+) mode 0 row 1024 B: [\d.]+ ms, ([\d.]+) TB/s", line)
+        if m:
+            rows, rate = int(m.group(1)), float(m.group(2))
+            if best is None or abs(np.log(rows / float(n_rows))) < abs(np.log(best[0] / float(n_rows))):
+                best = (rows, rate)
+    if best is None:
+        return None
+    return {"matrix_rows": best[0], "TBps": best[1], "source": "profiles/%s_gather_roof.txt" % ROUND,
+            "measured_in_this_run": False,
+            "what": "random whole-row gathers of a matrix of this many 1 KB rows by a kernel that does nothing else "
+                    "(the matrix misses the 4 MB L2 of an XCD; the guide's 34.5 TB/s is for L2-resident data)"}
 
 
 def hbm_bytes(entry):
@@ -419,7 +443,7 @@ def gram_roofline(mode, flops, gram_ms, variants, traffic):
     return roof
 
 
-def test_roofline(prof, n_refs, windows, n_samples, ms_per_batch):
+def test_roofline(prof, n_refs, windows, n_samples, ms_per_batch, n_bins=0):
     """`test` has no single binding roof: per-stage times of one batch (events on the launch stream inside
     the library), the z-score stage's gathered bytes against the L2 bandwidth (the sample matrix sits in
     L2 / Infinity Cache, not HBM), the window search's own float64 rate against the vector peak, and the
@@ -431,6 +455,7 @@ def test_roofline(prof, n_refs, windows, n_samples, ms_per_batch):
     byte_frac = n_samples * test_bytes / (ms_per_batch * 1e-3) / PEAK_HBM
     z_ms = float(prof[1])
     z_bytes = n_samples * n_refs * 8.0                          # first repeat: every reference value once
+    gather_roof = committed_gather_roof(n_bins) if n_bins else None
     return {
         "bound": "fp64-valu" if byte_frac > 1.0 else "hbm",
         "frac": valu_frac if byte_frac > 1.0 else byte_frac,
@@ -450,7 +475,10 @@ def test_roofline(prof, n_refs, windows, n_samples, ms_per_batch):
                           "gathered_bytes_per_batch": z_bytes,
                           "achieved_GBps": (z_bytes / (z_ms * 1e-3) / 1e9) if z_ms > 0 else None,
                           "l2_peak_GBps": PEAK_L2 / 1e9,
-                          "l2_frac": (z_bytes / (z_ms * 1e-3) / PEAK_L2) if z_ms > 0 else None},
+                          "l2_frac": (z_bytes / (z_ms * 1e-3) / PEAK_L2) if z_ms > 0 else None,
+                          "measured_gather_roof": gather_roof,
+                          "frac_of_measured_gather_roof": (z_bytes / (z_ms * 1e-3) / (gather_roof["TBps"] * 1e12))
+                                                          if (z_ms > 0 and gather_roof) else None},
         "hbm_byte_model": {"model": "5 repeats x gathered refs x 12 B + 8 B per Stouffer window (SURVEY.md 8d); "
                                     "triangle never materialised", "bytes_per_sample": test_bytes,
                            "achieved_GBps": n_samples * test_bytes / (ms_per_batch * 1e-3) / 1e9,
@@ -804,7 +832,7 @@ def main():
                "kernel_us": None if not lat_kernels else lat_kernels.get("kernels"),
                "kernel_source": None if not lat_kernels else lat_kernels.get("source"),
                "frac_of_call_in_launch_floor": float(floor[0]) * 1e-3 / single_ms}
-    test_roof = test_roofline(prof, n_refs, windows, args.test_samples, 1e3 * t_test / test_steps)
+    test_roof = test_roofline(prof, n_refs, windows, args.test_samples, 1e3 * t_test / test_steps, n_bins=B)
     # the north-star's whole `test` job (1000 samples at this bin size) in ONE call on this GPU: the per-batch
     # fixed costs (a few dozen small launches, one synchronize) spread over eight times the samples
     whole_job = None
@@ -955,7 +983,7 @@ def main():
                                   "pipelined": {"ms_per_batch": 1e3 * t5p, "value": world * 125 / t5p,
                                                 "batches_in_flight": PIPE_DEPTH, "batches_timed": len(b5)},
                                   "samples_per_gpu": 125, "calls_found": int(tb5.n_calls.sum().item()),
-                                  "roofline": test_roofline(prof5, n_refs5, windows5, 125, 1e3 * t5)}
+                                  "roofline": test_roofline(prof5, n_refs5, windows5, 125, 1e3 * t5, n_bins=int(bins5.sum()))}
             if n5 == 1000:
                 # (a) every rank's share of the 8-GPU job (125 of the 1 000 samples, no collective) one after the
                 # other on this GPU; (b) the whole cohort in ONE call on this GPU
@@ -1099,6 +1127,7 @@ def main():
             hbm_alg = fbytes / (rescore_ms * 1e-3) / PEAK_HBM
             hbm_cnt = None if ft is None else ft / (rescore_ms * 1e-3) / PEAK_HBM
             l2_frac = gathered / (rescore_ms * 1e-3) / PEAK_L2
+            groof = committed_gather_roof(B)
             busy = committed_busy(args.workload)
             # when the memory-side counters see less than half of what the HBM roof would allow (the image is
             # re-read out of L2 / Infinity Cache), the kernel is priced against the L2 gather bandwidth instead
@@ -1110,6 +1139,8 @@ def main():
                       "traffic_unit": "HBM-side bytes per launch of k_rescore (rocprofv3 PMC, %s; measured_in_this_run: false)"
                                       % traffic.get("source"),
                       "hbm_algorithmic_frac": hbm_alg, "hbm_counter_frac": hbm_cnt, "l2_gather_frac": l2_frac,
+                      "measured_gather_roof": groof,
+                      "frac_of_measured_gather_roof": None if not groof else gathered / (rescore_ms * 1e-3) / (groof["TBps"] * 1e12),
                       "issue_busy": busy}
             if hbm_binds:
                 roof_finish = dict(common, bound="hbm", achieved=fbytes / (rescore_ms * 1e-3) / 1e9, peak=PEAK_HBM / 1e9,

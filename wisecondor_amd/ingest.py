@@ -209,7 +209,8 @@ def run_testbatch(reference, paths, outdir, threshold, args, writer=None, max_ca
     tb = new_batch(dev_counts, max_calls)
     helpers = concurrent.futures.ThreadPoolExecutor(max_workers=2)
     py_writers = concurrent.futures.ThreadPoolExecutor(max_workers=io_threads) if writer else None
-    gpu_s = 0.0
+    gpu_s = wait_s = run_s = d2h_s = 0.0      # the GPU section and its parts: waiting for the result writers' buffers,
+                                              # H2D + wc_test_batch_dev, D2H of the results
     pending = []
 
     def start_decode(at, slot):
@@ -256,6 +257,8 @@ def run_testbatch(reference, paths, outdir, threshold, args, writer=None, max_ca
             if st.write_done is not None:
                 st.write_done.result()                  # the writer of two batches ago is done with these buffers
                 st.write_done = None
+            wait_s += time.time() - t0
+            t1 = time.time()
             while True:
                 dev_counts[:ns].copy_(st.counts[:ns], non_blocking=True)
                 run = tb if ns == batch else new_batch(dev_counts[:ns], tb.max_calls)
@@ -276,6 +279,9 @@ def run_testbatch(reference, paths, outdir, threshold, args, writer=None, max_ca
                         continue
                     raise
                 break
+            torch.cuda.synchronize()
+            run_s += time.time() - t1
+            t2 = time.time()
             st.z[:ns].copy_(run.results_z, non_blocking=True)
             st.r[:ns].copy_(run.results_r, non_blocking=True)
             st.cwz[:ns].copy_(run.cwz, non_blocking=True)
@@ -283,6 +289,7 @@ def run_testbatch(reference, paths, outdir, threshold, args, writer=None, max_ca
             st.n_calls[:ns].copy_(run.n_calls, non_blocking=True)
             st.asdef[:ns].copy_(run.asdef, non_blocking=True)
             torch.cuda.synchronize()
+            d2h_s += time.time() - t2
             gpu_s += time.time() - t0
             emit(at, names, slot, ns)
         for f in pending:
@@ -292,4 +299,5 @@ def run_testbatch(reference, paths, outdir, threshold, args, writer=None, max_ca
         if py_writers:
             py_writers.shutdown(wait=True)
     wall = time.time() - began
-    return dict(files=n, wall_s=wall, files_per_s=n / wall if wall > 0 else 0.0, gpu_s=gpu_s)
+    return dict(files=n, wall_s=wall, files_per_s=n / wall if wall > 0 else 0.0, gpu_s=gpu_s,
+                wait_writers_s=wait_s, h2d_and_kernels_s=run_s, d2h_s=d2h_s)

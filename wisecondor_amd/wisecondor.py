@@ -363,8 +363,10 @@ def toolTestBatch(args):
     lo, hi = shard_samples(len(args.infiles), rank, world_env)
     os.makedirs(args.outdir, exist_ok=True)
     stats = ingest.run_testbatch(reference, args.infiles[lo:hi], args.outdir, cut, args, runtime=getRuntime())
-    print('rank %d: %d samples in %.2f s (%.1f files/s end to end; GPU batches %.3f s)'
-          % (rank, stats['files'], stats['wall_s'], stats['files_per_s'], stats['gpu_s']))
+    print('rank %d: %d samples in %.2f s (%.1f files/s end to end; GPU batches %.3f s = %.3f waiting for the result '
+          'writers + %.3f copy in and kernels + %.3f results out)'
+          % (rank, stats['files'], stats['wall_s'], stats['files_per_s'], stats['gpu_s'],
+             stats.get('wait_writers_s', 0.0), stats.get('h2d_and_kernels_s', 0.0), stats.get('d2h_s', 0.0)))
     reference.close()
 
 
