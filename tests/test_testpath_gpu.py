@@ -345,3 +345,61 @@ def test_std_dev_avg_parallel_form_is_exact(wt):
     v[100] = np.inf
     got, serial = wt.stdDevAvg(v, return_serial_count=True)
     assert got == _seq_mean(v) and serial == 1
+
+
+@pytest.mark.parametrize("env", [{"WC_TEST_WALK": "0"}, {"WC_TEST_WALK": "0", "WC_TEST_TREE_TAIL": "0"},
+                                 {"WC_TEST_WALK": "0", "WC_TEST_TREE_TAIL": "0", "WC_TEST_CELLS": "0"},
+                                 {"WC_TEST_WALK": "0", "WC_TEST_TREE_TAIL": "0", "WC_CELL_PARTS": "1"}])
+def test_every_segmentation_path_gives_the_walkers_outputs(wt, cfg1, reference, monkeypatch, env):
+    """The batched `test` through the paths k_seg_walk replaced (the switches are read per call): the tree kernel
+    after k_seg_quiet / k_seg_search / k_seg_classify, the host-driven levels with the cell search (k_seg_job /
+    k_seg_merge; one workgroup per range or several), and those levels with the row-block kernels -- bit-identical
+    calls, z, ratios and chromosome-wide values for a batch of 40 samples (the five cfg1 samples repeated)."""
+    g = cfg1
+    thr = float(g["t_mild18_threshold_z"])
+    samples = [_split(g["t_%s_sample" % n], g["sample_chrom_lengths"]) for n in NAMES] * 8
+    want = wt.test_batch(reference, samples, thr)
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    got = wt.test_batch(reference, samples, thr)
+    for a, b in zip(want, got):
+        assert np.array_equal(a["results_calls"], b["results_calls"])
+        assert np.array_equal(np.asarray(a["results_cwz"]).view(np.uint64), np.asarray(b["results_cwz"]).view(np.uint64))
+        assert np.array_equal(np.concatenate(a["results_z"]).view(np.uint64), np.concatenate(b["results_z"]).view(np.uint64))
+        assert np.array_equal(np.concatenate(a["results_r"]).view(np.uint64), np.concatenate(b["results_r"]).view(np.uint64))
+
+
+def test_long_regions_through_the_host_driven_levels(wt, monkeypatch):
+    """wc_stouffer_segments on regions of 3 000 - 8 000 bins: the cell search with several workgroups per range (the
+    default for few ranges), with one workgroup per range, and the row-block kernels give the same segments, bit for
+    bit; every segment's value is its exact window value (the oracle's triangle is out of reach at this size)."""
+    rng = np.random.RandomState(31)
+    regions = []
+    for n in (3000, 5000, 8000):
+        z = rng.standard_normal(n)
+        a = rng.randint(0, n - 700)
+        z[a:a + 600] += 0.35
+        z[n // 2:n // 2 + 25] -= 1.4
+        regions.append(z)
+    thr = 5.2
+    whole, segs = wt.stouffer_segments(regions, thr, 3)
+    found = 0
+    for z, s in zip(regions, segs):
+        found += len(s)
+        xs = [x for _, (x, y) in s]
+        assert xs == sorted(xs)
+        for v, (x, y) in s:
+            assert v == np.sum(z[x:y + 1]) / np.sqrt(y - x + 1) and abs(v) >= thr
+        for (v0, (x0, y0)), (v1, (x1, y1)) in zip(s, s[1:]):
+            assert y0 < x1
+    assert found >= 3
+    for env in ({"WC_CELL_PARTS": "1"}, {"WC_TEST_CELLS": "0"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        whole2, segs2 = wt.stouffer_segments(regions, thr, 3)
+        for k_ in env:
+            monkeypatch.delenv(k_)
+        assert same_bits(whole, whole2)
+        for s, s2 in zip(segs, segs2):
+            assert [(x, y) for _, (x, y) in s] == [(x, y) for _, (x, y) in s2]
+            assert same_bits([v for v, _ in s], [v for v, _ in s2])
