@@ -317,7 +317,7 @@ __global__ void k_pca_apply(const double *__restrict__ raw, int64_t B, const dou
 // launch: 32 bins x 32 samples per workgroup through LDS -- the sample-major intermediates (raw, data: 2 x 55 MB per
 // 125 x 50 kb batch, written and read again) are never made.
 __global__ void k_pca_apply_t(const int *__restrict__ counts, int64_t Btot, const int *__restrict__ m2g, int64_t B,
-                              int64_t Ns, const long long *__restrict__ partial, const double *__restrict__ mean,
+                              int64_t Ns_real, int64_t Ns, const long long *__restrict__ partial, const double *__restrict__ mean,
                               const double *__restrict__ comp, int n_comp, const double *__restrict__ proj,
                               double *__restrict__ xt, double *__restrict__ xc, int *__restrict__ zero,
                               int64_t n_zero) {
@@ -330,18 +330,20 @@ __global__ void k_pca_apply_t(const int *__restrict__ counts, int64_t Btot, cons
         for (int64_t t = me; t < n_zero; t += nthreads) zero[t] = 0;
     }
     const int64_t b0 = (int64_t)blockIdx.x * 32, i0 = (int64_t)blockIdx.y * 32;
+    // (samples Ns_real .. Ns - 1 are the padding of the bin-major rows to whole 128-byte lines: copies of sample 0)
+    auto src = [&](const int64_t i) { return i < Ns_real ? i : 0; };
     if (tid < 32) {
         long long t = 0;
         if (i0 + tid < Ns)
 #pragma unroll
-            for (int q = 0; q < TOT_SPLIT; ++q) t += partial[(i0 + tid) * TOT_SPLIT + q];
+            for (int q = 0; q < TOT_SPLIT; ++q) t += partial[src(i0 + tid) * TOT_SPLIT + q];
         s_tot[tid] = (double)t;
     }
     {
         const int sm = tid >> 3, c = tid & 7;                 // MAX_COMP == 8
         double t = 0.0;
         if (c < n_comp && i0 + sm < Ns)
-            for (int q = 0; q < PROJ_SPLIT; ++q) t += proj[((i0 + sm) * PROJ_SPLIT + q) * MAX_COMP + c];
+            for (int q = 0; q < PROJ_SPLIT; ++q) t += proj[(src(i0 + sm) * PROJ_SPLIT + q) * MAX_COMP + c];
         s_t[sm][c] = t;
     }
     __syncthreads();
@@ -354,7 +356,7 @@ __global__ void k_pca_apply_t(const int *__restrict__ counts, int64_t Btot, cons
     for (int j = ty; j < 32; j += 8) {
         const int64_t i = i0 + j;
         if (i < Ns && b < B) {
-            const double raw = (double)counts[i * Btot + g] / s_tot[j];
+            const double raw = (double)counts[src(i) * Btot + g] / s_tot[j];
             double rec = 0.0;
 #pragma unroll
             for (int c = 0; c < MAX_COMP; ++c)
@@ -756,6 +758,144 @@ __global__ __launch_bounds__(256, 2) void k_zscore(const double *__restrict__ XT
     const int64_t i = (wave - (int64_t)wb * n_sg) * 64 + (threadIdx.x & 63);
     if (i >= Ns) return;
     zscore_wave<12>(wb, i, (int64_t)wb * Ns + i, XT, XC, gidx, nref, k, Ns, zT, rT, nT, sdT);
+}
+
+// The first repeat with SAMPLE TILES DEALT TO XCDs (round 5).  k_zscore above lets every XCD gather rows of the whole
+// [bins, samples] matrix -- 55 MB at 125 x 50 kb against 4 MB of L2 per XCD -- and a gather micro-benchmark
+// (tools/micro/gather_rate.*) tops out at 8.7 TB/s for that whatever the access width; it reaches 24-26 TB/s when a
+// workgroup only ever touches the 128-byte column (16 samples) blockIdx % 8 of every row: workgroups go to the XCDs
+// round robin, so each XCD's L2 then holds one column of the matrix.  A wave here = FOUR bins x the 16 samples of one
+// tile, one lane per pair (64 pairs per wave like k_zscore: the forms with fewer lost to the per-bin work, see
+// EXPERIMENTS.md): the bin and its list are per lane (16-byte index loads, a 64-bit address per gather) instead of
+// wave-uniform, everything else is zscore_wave.  Needs the sample stride to be a multiple of 16 (whole 128-byte
+// columns; the caller pads).
+typedef int int4v __attribute__((ext_vector_type(4), aligned(16)));
+__global__ void k_fill(double *__restrict__ p, int64_t n, double value) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = value;
+}
+// x of lane `from` of the caller's row of 16 lanes (DPP row_newbcast; `from` a constant after unrolling)
+__device__ inline int row_lane(const int x, const int from) {
+#define WC_ROW_LANE(N) case N: return __builtin_amdgcn_mov_dpp(x, 0x150 + N, 0xf, 0xf, true);
+    switch (from) {
+        WC_ROW_LANE(0) WC_ROW_LANE(1) WC_ROW_LANE(2) WC_ROW_LANE(3) WC_ROW_LANE(4) WC_ROW_LANE(5) WC_ROW_LANE(6) WC_ROW_LANE(7)
+        WC_ROW_LANE(8) WC_ROW_LANE(9) WC_ROW_LANE(10) WC_ROW_LANE(11) WC_ROW_LANE(12) WC_ROW_LANE(13) WC_ROW_LANE(14)
+    default: return __builtin_amdgcn_mov_dpp(x, 0x15f, 0xf, 0xf, true);
+    }
+#undef WC_ROW_LANE
+}
+template <int G>
+__global__ __launch_bounds__(256, 2) void k_zscore_tiled(const double *__restrict__ XT, const double *__restrict__ XC,
+                                                         const int *__restrict__ gidx, const int *__restrict__ nref, int k,
+                                                         int B, int Ns, double *__restrict__ zT, double *__restrict__ rT,
+                                                         double *__restrict__ nT, double *__restrict__ sdT) {
+    constexpr int NL = (8 * G + 7 + 3) / 4;        // 4-index loads that cover 8 G + 7 list slots
+    const int n_tiles = Ns >> 4;
+    const int groups = (B + 15) >> 4;              // a workgroup: 4 waves x 4 bins
+    const int xcd = (int)(blockIdx.x & 7u);
+    const int j = (int)(blockIdx.x >> 3);
+    const int tile = xcd + 8 * (j / groups);
+    if (tile >= n_tiles) return;
+    const int lane = threadIdx.x & 63;
+    const int b0 = ((j % groups) * 4 + (threadIdx.x >> 6)) * 4;
+    if (b0 >= B) return;
+    const int q2 = lane >> 4, sm = lane & 15;
+    const bool live = b0 + q2 < B;
+    const int b = live ? b0 + q2 : B - 1;
+    const int64_t i = (int64_t)tile * 16 + sm, gid = (int64_t)b * Ns + i;
+    const int n = nref[b];
+    const int ng = n >> 3;
+    if (!__all(ng <= G) || (k & 3)) {
+        if (live) zscore_one(b, i, gid, XT, XC, gidx, nref, k, Ns, zT, rT, nT, sdT);
+        return;
+    }
+    double v[4 * NL];
+    const double x = XT[gid];
+    {
+        // the 16 lanes of a bin share its list: lane sm holds slots 8 sm .. 8 sm + 7 (two 16-byte loads), a gather
+        // fetches its index from its owner by a row broadcast (DPP) -- 8 index registers per lane instead of 8 G + 8.
+        // An index of -1 (the list's padding; a reference numpy would reject) reads ROW B of XC, which the caller has
+        // filled with -1.0: the value is then dropped like a flagged one, no masks to keep.
+        const int4v *l4 = reinterpret_cast<const int4v *>(gidx + (int64_t)b * k) + 2 * sm;
+        const int4v ga = l4[0], gb = l4[1];
+        const char *base = reinterpret_cast<const char *>(XC);      // scalar base + a 32-bit byte offset per gather (the caller checks the size)
+        const unsigned int ioff = (unsigned int)i * 8u, row_bytes = (unsigned int)Ns * 8u;
+        int own[8] = {ga[0], ga[1], ga[2], ga[3], gb[0], gb[1], gb[2], gb[3]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {                               // the owner turns its indexes into rows' byte offsets once
+            const unsigned int g = (unsigned int)own[e];
+            own[e] = (int)__umul24(g < (unsigned int)B ? g : (unsigned int)B, row_bytes);   // (both below 2^24: the caller checks)
+        }
+#pragma unroll
+        for (int r = 0; r < 4 * NL; ++r) {
+            v[r] = *reinterpret_cast<const double *>(base + ((unsigned int)row_lane(own[r & 7], r >> 3) + ioff));   // from lane r >> 3 of the row
+            __builtin_amdgcn_sched_barrier(0);                      // (offsets computed ahead of their gathers end up in scratch)
+        }
+    }
+    // flagged (-1), negative, NaN: dropped (wisetools.py:425) -- the general form does that; told by the high words:
+    // a non-negative finite value's is below 0x7ff00000 as an unsigned number (infinities go the general way too)
+    unsigned int top = 0u;
+#pragma unroll
+    for (int q = 0; q < G; ++q)
+        if (q < ng) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) top = max(top, (unsigned int)__double2hiint(v[8 * q + e]));
+        }
+    if (!__all(top < 0x7ff00000u || !live)) {
+        if (live) zscore_one(b, i, gid, XT, XC, gidx, nref, k, Ns, zT, rT, nT, sdT);
+        return;
+    }
+    StreamSum acc;
+    acc.init();
+#pragma unroll
+    for (int q = 0; q < G; ++q)
+        if (q < ng) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc.r[e] = acc.r[e] + v[8 * q + e];   // first group: 0 + v == v exactly (v >= 0)
+        }
+    acc.pos = 8 * ng;
+    // the incomplete last group: slots 8 ng .. 8 ng + 6 (beyond the list: -1, dropped)
+    double tailv[7];
+#pragma unroll
+    for (int e = 0; e < 7; ++e) tailv[e] = -1.0;
+#pragma unroll
+    for (int q = 0; q <= G; ++q)
+        if (q == ng) {
+#pragma unroll
+            for (int e = 0; e < 7; ++e) tailv[e] = e < (n & 7) ? v[8 * q + e] : -1.0;
+        }
+#pragma unroll
+    for (int e = 0; e < 7; ++e)
+        if (tailv[e] >= 0.0) acc.push(tailv[e]);  // flagged (-1), negative and NaN values are dropped (wisetools.py:425)
+    const int m = acc.pos;
+    const double mean = acc.finish() / (double)m;
+    acc.init();
+#pragma unroll
+    for (int q = 0; q < G; ++q)
+        if (q < ng) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const double dv = v[8 * q + e] - mean;
+                const double sq = dv * dv;
+                acc.r[e] = acc.r[e] + sq;
+            }
+        }
+    acc.pos = 8 * ng;
+#pragma unroll
+    for (int e = 0; e < 7; ++e)
+        if (tailv[e] >= 0.0) {
+            const double dv = tailv[e] - mean;
+            const double sq = dv * dv;
+            acc.push(sq);
+        }
+    const double var = acc.finish() / (double)m;
+    if (live) {
+        const double sd = sqrt(var);
+        zT[gid] = (x - mean) / sd;
+        rT[gid] = x / mean;
+        nT[gid] = (double)m;
+        sdT[gid] = sd;
+    }
 }
 
 // numpy's pairwise sum of a stream of kept values by an aligned group of eight lanes: lane s
@@ -4646,7 +4786,7 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
     const int64_t n = ref->B * Ns;
     int rc;
     for (wc::DevBuf *b : {&ts.xt, &ts.xc, &ts.zt, &ts.rt, &ts.nt, &ts.sdt})
-        if ((rc = b->reserve(sizeof(double) * n))) return rc;
+        if ((rc = b->reserve(sizeof(double) * (n + Ns)))) return rc;       // (+ one row: xc's row B, see k_zscore_tiled)
     if ((rc = ts.sd_avg.reserve(sizeof(double) * Ns))) return rc;
     WC_CHECK(n < (1ll << 32), WC_E_LIMIT, "repeatTest: more than 2^32 (bin, sample) pairs per call");
     // xt = data^T, xc = its working copy (flags go in there); in the same launch the repeats'
@@ -4705,7 +4845,19 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
                                    (const double *)ts.zt.as<double>(), thr, Ns, ts.xc.as<double>(), uoff, ulst, dirty,
                                    next, pair_counts + it + 1);
         } else if (it == 0) {
-            if (Ns >= 32) {
+            const char *tiled_env = getenv("WC_ZSCORE_TILED");       // "0": the untiled kernel (a wave = one bin x 64 samples)
+            if (Ns >= 32 && (Ns & 15) == 0 && (ref->B + 1) * Ns * 8 < ((int64_t)1 << 32) && ref->B < (1 << 24) &&
+                Ns * 8 < (1 << 24) && !(tiled_env && tiled_env[0] == '0')) {
+                constexpr int ZT_G = 12;
+                const int64_t n_wg = 8 * cdiv(Ns / 16, 8) * cdiv(ref->B, 16);
+                hipLaunchKernelGGL(k_fill, dim3((unsigned)cdiv(Ns, 256)), dim3(256), 0, stream, ts.xc.as<double>() + ref->B * Ns,
+                                   Ns, -1.0);                       // row B of xc: what an index of -1 reads
+                hipLaunchKernelGGL(k_zscore_tiled<ZT_G>, dim3((unsigned)n_wg), dim3(256), 0, stream,
+                                   (const double *)ts.xt.as<double>(), (const double *)ts.xc.as<double>(),
+                                   (const int *)ref->gidx.as<int>(), (const int *)ref->nref.as<int>(), ref->k,
+                                   (int)ref->B, (int)Ns, ts.zt.as<double>(), ts.rt.as<double>(), ts.nt.as<double>(),
+                                   ts.sdt.as<double>());
+            } else if (Ns >= 32) {
                 const unsigned n_uni = (unsigned)cdiv(ref->B * cdiv(Ns, 64), 4);
                 hipLaunchKernelGGL(k_zscore, dim3(n_uni), dim3(256), 0, stream,
                                    (const double *)ts.xt.as<double>(), (const double *)ts.xc.as<double>(),
@@ -5406,7 +5558,7 @@ wc_reference *wc_reference_create(wc_ctx *ctx, const int32_t *indexes, const dou
     // (+ 448 bytes: k_zscore reads a bin's list by seven unconditional 16-index loads -- 112 indexes from the list's
     // start whatever refsize is; only their USE is guarded -- so the last bin's loads reach up to 112 - k indexes
     // beyond the array)
-    bool ok = ref->gidx.reserve(sizeof(int) * nk + 448) == 0 && ref->nref.reserve(sizeof(int) * n_bins) == 0 &&
+    bool ok = ref->gidx.reserve(sizeof(int) * nk + 512) == 0 && ref->nref.reserve(sizeof(int) * n_bins) == 0 &&
               ref->pca_mean.reserve(sizeof(double) * n_bins) == 0 &&
               ref->pca_comp.reserve(sizeof(double) * std::max<int64_t>(1, (int64_t)n_comp * n_bins)) == 0 &&
               ref->m2g.reserve(sizeof(int) * n_bins) == 0 && ref->g2m.reserve(sizeof(int) * ref->Btot) == 0 &&
@@ -5657,6 +5809,10 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
     ts.prof_tag.clear();
     ts.mark(0, stream);
     const bool lat = lat_rounds > 0;
+    // The z-score stage of a batch works on bin-major arrays [bins, Np], Np = the sample count padded to a multiple of
+    // 16: a reference bin's row then starts on a 128-byte line and the tiled z-score kernel's 16-sample columns are
+    // whole lines; the extra samples are copies of sample 0 whose results nobody reads.
+    const int64_t Np = (!lat && Ns >= 32) ? ((Ns + 15) & ~(int64_t)15) : Ns;
     if (lat) {
         // totals, normalisation, PCA and the repeats' working arrays in one launch
         const int64_t n = B * Ns, n_words = cdiv(n, 32);
@@ -5664,7 +5820,7 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
         if ((rc = ts.raw.reserve(sizeof(double) * n))) return rc;
         if ((rc = ts.data.reserve(sizeof(double) * n))) return rc;
         if ((rc = ts.xt.reserve(sizeof(double) * n))) return rc;
-        if ((rc = ts.xc.reserve(sizeof(double) * n))) return rc;
+        if ((rc = ts.xc.reserve(sizeof(double) * (n + Np)))) return rc;
         if ((rc = ts.misc2.reserve(sizeof(int) * (repeats + 2 + n_words)))) return rc;
         if ((rc = ts.proj.reserve(sizeof(double) * Ns * MAX_COMP * PROJ_SPLIT))) return rc;
         hipLaunchKernelGGL(k_lat_project, dim3((unsigned)Ns, PROJ_SPLIT), dim3(256), 0, stream, counts, ref->Btot,
@@ -5679,11 +5835,11 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
     } else {
         // totals -> projection partial sums (normalised values on the fly) -> corrected values straight into the
         // repeats' bin-major arrays: three launches, no sample-major intermediate
-        const int64_t n = B * Ns, n_words = cdiv(n, 32);
+        const int64_t n = B * Np, n_words = cdiv(n, 32);
         if ((rc = ts.totals.reserve(sizeof(long long) * Ns * TOT_SPLIT))) return rc;
         if ((rc = ts.proj.reserve(sizeof(double) * Ns * MAX_COMP * PROJ_SPLIT))) return rc;
         if ((rc = ts.xt.reserve(sizeof(double) * n))) return rc;
-        if ((rc = ts.xc.reserve(sizeof(double) * n))) return rc;
+        if ((rc = ts.xc.reserve(sizeof(double) * (n + Np)))) return rc;
         if ((rc = ts.misc2.reserve(sizeof(int) * (repeats + 2 + n_words)))) return rc;
         hipLaunchKernelGGL(k_sample_totals, dim3((unsigned)Ns, TOT_SPLIT), dim3(256), 0, stream, counts, ref->Btot,
                            ts.totals.as<long long>());
@@ -5691,14 +5847,14 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
                            (const double *)ref->pca_mean.as<double>(), (const double *)ref->pca_comp.as<double>(),
                            ref->n_comp, ts.proj.as<double>(), counts, ref->Btot, (const int *)ref->m2g.as<int>(),
                            (const long long *)ts.totals.as<long long>());
-        hipLaunchKernelGGL(k_pca_apply_t, dim3((unsigned)cdiv(B, 32), (unsigned)cdiv(Ns, 32)), dim3(32, 8), 0, stream, counts,
-                           ref->Btot, (const int *)ref->m2g.as<int>(), B, Ns, (const long long *)ts.totals.as<long long>(),
+        hipLaunchKernelGGL(k_pca_apply_t, dim3((unsigned)cdiv(B, 32), (unsigned)cdiv(Np, 32)), dim3(32, 8), 0, stream, counts,
+                           ref->Btot, (const int *)ref->m2g.as<int>(), B, Ns, Np, (const long long *)ts.totals.as<long long>(),
                            (const double *)ref->pca_mean.as<double>(), (const double *)ref->pca_comp.as<double>(),
                            ref->n_comp, (const double *)ts.proj.as<double>(), ts.xt.as<double>(), ts.xc.as<double>(),
                            ts.misc2.as<int>(), repeats > 0 ? repeats + 2 + n_words : 0);
     }
     ts.mark(1, stream);
-    if ((rc = run_repeat(ctx, ref, ts.data.as<double>(), Ns, threshold, repeats, stream, lat, asdef, !lat))) return rc;
+    if ((rc = run_repeat(ctx, ref, ts.data.as<double>(), Np, threshold, repeats, stream, lat, asdef, !lat))) return rc;
     ts.mark(2, stream);
     struct Joiner {   // asdef is copied out once the side stream's sum is done, on every exit path
         wc_ctx *c; hipStream_t s; double *dst; int64_t n; bool on;
@@ -5717,10 +5873,10 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
     int64_t str_i = 1, str_b = Ns;
     if (!lat) {
         for (wc::DevBuf *b : {&ts.zs, &ts.rs2, &ts.ns2})
-            if ((rc = b->reserve(sizeof(double) * Ns * B))) return rc;
-        dim3 g3((unsigned)cdiv(Ns, 32), (unsigned)cdiv(B, 32), 3);
+            if ((rc = b->reserve(sizeof(double) * Np * B))) return rc;
+        dim3 g3((unsigned)cdiv(Np, 32), (unsigned)cdiv(B, 32), 3);
         hipLaunchKernelGGL(k_transpose3, g3, dim3(32, 8), 0, stream, (const double *)ts.zt.as<double>(),
-                           (const double *)ts.rt.as<double>(), (const double *)ts.nt.as<double>(), B, Ns,
+                           (const double *)ts.rt.as<double>(), (const double *)ts.nt.as<double>(), B, Np,
                            ts.zs.as<double>(), ts.rs2.as<double>(), ts.ns2.as<double>());
         zsrc = ts.zs.as<double>(); rsrc = ts.rs2.as<double>(); nsrc = ts.ns2.as<double>();
         str_i = B; str_b = 1;
