@@ -287,10 +287,13 @@ def test_degenerate_samples(wt):
     reference.close()
 
 
-_FLAG_SHAPES = [(3, 40), (40, 40), (40, 128), (70, 24), (40, 10), (5, 9)]
+# (128 samples and more: the first repeat by k_zscore_tiled -- eight whole tiles; nine, the ninth dealt to all XCDs;
+#  a list stride that is not a multiple of four; lists longer than the 103 references its registers hold)
+_FLAG_SHAPES = [(3, 40), (40, 40), (40, 128), (70, 24), (40, 10), (5, 9), (128, 100), (144, 40), (128, 103), (160, 128)]
 
 
-@pytest.mark.parametrize("n_samples,k,seed", [_FLAG_SHAPES[i % 6] + (i,) for i in range(6 * SWEEP)])
+@pytest.mark.parametrize("n_samples,k,seed", [_FLAG_SHAPES[i % len(_FLAG_SHAPES)] + (i,)
+                                              for i in range(len(_FLAG_SHAPES) * SWEEP)])
 def test_repeats_heavy_flagging(wt, n_samples, k, seed):
     """A low threshold on noisy samples: every repeat adds flags, so later repeats recompute many
     (bin, sample) pairs with dropped references (cooperative pair kernel; full 128-entry lists

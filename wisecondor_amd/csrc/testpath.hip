@@ -790,25 +790,35 @@ __global__ __launch_bounds__(256, 2) void k_zscore_tiled(const double *__restric
                                                          int B, int Ns, double *__restrict__ zT, double *__restrict__ rT,
                                                          double *__restrict__ nT, double *__restrict__ sdT) {
     constexpr int NL = (8 * G + 7 + 3) / 4;        // 4-index loads that cover 8 G + 7 list slots
+    // tiles 0 .. 8 F - 1: tile t belongs to XCD t % 8; the R = n_tiles % 8 tiles left over are dealt to all XCDs by
+    // (tile, workgroup) items, so that no XCD gets a whole extra tile
     const int n_tiles = Ns >> 4;
     const int groups = (B + 15) >> 4;              // a workgroup: 4 waves x 4 bins
     const int xcd = (int)(blockIdx.x & 7u);
     const int j = (int)(blockIdx.x >> 3);
-    const int tile = xcd + 8 * (j / groups);
-    if (tile >= n_tiles) return;
+    const int full = (n_tiles >> 3) * groups, R = n_tiles & 7;
+    int tile, grp;
+    if (j < full) {
+        tile = xcd + 8 * (j / groups);
+        grp = j % groups;
+    } else {
+        const int m = (j - full) * 8 + xcd;
+        if (m >= R * groups) return;
+        tile = (n_tiles & ~7) + m % R;
+        grp = m / R;
+    }
     const int lane = threadIdx.x & 63;
-    const int b0 = ((j % groups) * 4 + (threadIdx.x >> 6)) * 4;
+    const int b0 = (grp * 4 + (threadIdx.x >> 6)) * 4;
     if (b0 >= B) return;
     const int q2 = lane >> 4, sm = lane & 15;
     const bool live = b0 + q2 < B;
     const int b = live ? b0 + q2 : B - 1;
     const int64_t i = (int64_t)tile * 16 + sm, gid = (int64_t)b * Ns + i;
-    const int n = nref[b];
-    const int ng = n >> 3;
-    if (!__all(ng <= G) || (k & 3)) {
+    if (k & 3) {
         if (live) zscore_one(b, i, gid, XT, XC, gidx, nref, k, Ns, zT, rT, nT, sdT);
         return;
     }
+    const int n = nref[b];                         // (not needed before the sums: the list is read whatever its length)
     double v[4 * NL];
     const double x = XT[gid];
     {
@@ -834,7 +844,8 @@ __global__ __launch_bounds__(256, 2) void k_zscore_tiled(const double *__restric
     }
     // flagged (-1), negative, NaN: dropped (wisetools.py:425) -- the general form does that; told by the high words:
     // a non-negative finite value's is below 0x7ff00000 as an unsigned number (infinities go the general way too)
-    unsigned int top = 0u;
+    const int ng = n >> 3;
+    unsigned int top = ng <= G ? 0u : ~0u;         // (a longer list: the general form)
 #pragma unroll
     for (int q = 0; q < G; ++q)
         if (q < ng) {
@@ -4846,10 +4857,12 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
                                    next, pair_counts + it + 1);
         } else if (it == 0) {
             const char *tiled_env = getenv("WC_ZSCORE_TILED");       // "0": the untiled kernel (a wave = one bin x 64 samples)
-            if (Ns >= 32 && (Ns & 15) == 0 && (ref->B + 1) * Ns * 8 < ((int64_t)1 << 32) && ref->B < (1 << 24) &&
+            // (fewer than eight tiles would leave XCDs idle or without a column of their own: the untiled kernel)
+            if (Ns >= 128 && (Ns & 15) == 0 && (ref->B + 1) * Ns * 8 < ((int64_t)1 << 32) && ref->B < (1 << 24) &&
                 Ns * 8 < (1 << 24) && !(tiled_env && tiled_env[0] == '0')) {
                 constexpr int ZT_G = 12;
-                const int64_t n_wg = 8 * cdiv(Ns / 16, 8) * cdiv(ref->B, 16);
+                const int64_t zgroups = cdiv(ref->B, 16), ztiles = Ns / 16;
+                const int64_t n_wg = 8 * ((ztiles / 8) * zgroups + cdiv((ztiles % 8) * zgroups, 8));
                 hipLaunchKernelGGL(k_fill, dim3((unsigned)cdiv(Ns, 256)), dim3(256), 0, stream, ts.xc.as<double>() + ref->B * Ns,
                                    Ns, -1.0);                       // row B of xc: what an index of -1 reads
                 hipLaunchKernelGGL(k_zscore_tiled<ZT_G>, dim3((unsigned)n_wg), dim3(256), 0, stream,
