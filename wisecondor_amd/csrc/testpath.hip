@@ -784,8 +784,8 @@ __device__ inline int row_lane(const int x, const int from) {
     }
 #undef WC_ROW_LANE
 }
-template <int G>
-__global__ __launch_bounds__(256, 2) void k_zscore_tiled(const double *__restrict__ XT, const double *__restrict__ XC,
+template <int G, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void k_zscore_tiled(const double *__restrict__ XT, const double *__restrict__ XC,
                                                          const int *__restrict__ gidx, const int *__restrict__ nref, int k,
                                                          int B, int Ns, double *__restrict__ zT, double *__restrict__ rT,
                                                          double *__restrict__ nT, double *__restrict__ sdT) {
@@ -793,7 +793,7 @@ __global__ __launch_bounds__(256, 2) void k_zscore_tiled(const double *__restric
     // tiles 0 .. 8 F - 1: tile t belongs to XCD t % 8; the R = n_tiles % 8 tiles left over are dealt to all XCDs by
     // (tile, workgroup) items, so that no XCD gets a whole extra tile
     const int n_tiles = Ns >> 4;
-    const int groups = (B + 15) >> 4;              // a workgroup: 4 waves x 4 bins
+    const int groups = (B + 4 * WAVES - 1) / (4 * WAVES);     // a workgroup: WAVES waves x 4 bins
     const int xcd = (int)(blockIdx.x & 7u);
     const int j = (int)(blockIdx.x >> 3);
     const int full = (n_tiles >> 3) * groups, R = n_tiles & 7;
@@ -808,7 +808,7 @@ __global__ __launch_bounds__(256, 2) void k_zscore_tiled(const double *__restric
         grp = m / R;
     }
     const int lane = threadIdx.x & 63;
-    const int b0 = (grp * 4 + (threadIdx.x >> 6)) * 4;
+    const int b0 = (grp * WAVES + (threadIdx.x >> 6)) * 4;
     if (b0 >= B) return;
     const int q2 = lane >> 4, sm = lane & 15;
     const bool live = b0 + q2 < B;
@@ -856,16 +856,18 @@ __global__ __launch_bounds__(256, 2) void k_zscore_tiled(const double *__restric
         if (live) zscore_one(b, i, gid, XT, XC, gidx, nref, k, Ns, zT, rT, nT, sdT);
         return;
     }
-    StreamSum acc;
-    acc.init();
+    // numpy's pairwise sum of m = 8 ng + (kept tail values) numbers: eight strided accumulators over the whole groups,
+    // combined as a tree, then the tail's values one after the other (StreamSum with nothing dropped in the groups)
+    double r8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r8[e] = 0.0;
 #pragma unroll
     for (int q = 0; q < G; ++q)
         if (q < ng) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc.r[e] = acc.r[e] + v[8 * q + e];   // first group: 0 + v == v exactly (v >= 0)
+            for (int e = 0; e < 8; ++e) r8[e] = r8[e] + v[8 * q + e];   // first group: 0 + v == v exactly (v >= 0)
         }
-    acc.pos = 8 * ng;
-    // the incomplete last group: slots 8 ng .. 8 ng + 6 (beyond the list: -1, dropped)
+    // the incomplete last group: slots 8 ng .. n - 1
     double tailv[7];
 #pragma unroll
     for (int e = 0; e < 7; ++e) tailv[e] = -1.0;
@@ -875,12 +877,17 @@ __global__ __launch_bounds__(256, 2) void k_zscore_tiled(const double *__restric
 #pragma unroll
             for (int e = 0; e < 7; ++e) tailv[e] = e < (n & 7) ? v[8 * q + e] : -1.0;
         }
+    int m = 8 * ng;
+    double sum = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
 #pragma unroll
     for (int e = 0; e < 7; ++e)
-        if (tailv[e] >= 0.0) acc.push(tailv[e]);  // flagged (-1), negative and NaN values are dropped (wisetools.py:425)
-    const int m = acc.pos;
-    const double mean = acc.finish() / (double)m;
-    acc.init();
+        if (tailv[e] >= 0.0) {                    // flagged (-1), negative and NaN values are dropped (wisetools.py:425)
+            sum = sum + tailv[e];
+            ++m;
+        }
+    const double mean = sum / (double)m;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r8[e] = 0.0;
 #pragma unroll
     for (int q = 0; q < G; ++q)
         if (q < ng) {
@@ -888,18 +895,18 @@ __global__ __launch_bounds__(256, 2) void k_zscore_tiled(const double *__restric
             for (int e = 0; e < 8; ++e) {
                 const double dv = v[8 * q + e] - mean;
                 const double sq = dv * dv;
-                acc.r[e] = acc.r[e] + sq;
+                r8[e] = r8[e] + sq;
             }
         }
-    acc.pos = 8 * ng;
+    sum = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
 #pragma unroll
     for (int e = 0; e < 7; ++e)
         if (tailv[e] >= 0.0) {
             const double dv = tailv[e] - mean;
             const double sq = dv * dv;
-            acc.push(sq);
+            sum = sum + sq;
         }
-    const double var = acc.finish() / (double)m;
+    const double var = sum / (double)m;
     if (live) {
         const double sd = sqrt(var);
         zT[gid] = (x - mean) / sd;
@@ -4861,11 +4868,12 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
             if (Ns >= 128 && (Ns & 15) == 0 && (ref->B + 1) * Ns * 8 < ((int64_t)1 << 32) && ref->B < (1 << 24) &&
                 Ns * 8 < (1 << 24) && !(tiled_env && tiled_env[0] == '0')) {
                 constexpr int ZT_G = 12;
-                const int64_t zgroups = cdiv(ref->B, 16), ztiles = Ns / 16;
+                constexpr int zwaves = 1;                           // (one wave per workgroup: a slot is refilled as soon as it frees; 2 and 4 measured 1-2 % slower)
+                const int64_t zgroups = cdiv(ref->B, 4 * zwaves), ztiles = Ns / 16;
                 const int64_t n_wg = 8 * ((ztiles / 8) * zgroups + cdiv((ztiles % 8) * zgroups, 8));
                 hipLaunchKernelGGL(k_fill, dim3((unsigned)cdiv(Ns, 256)), dim3(256), 0, stream, ts.xc.as<double>() + ref->B * Ns,
                                    Ns, -1.0);                       // row B of xc: what an index of -1 reads
-                hipLaunchKernelGGL(k_zscore_tiled<ZT_G>, dim3((unsigned)n_wg), dim3(256), 0, stream,
+                hipLaunchKernelGGL((k_zscore_tiled<ZT_G, zwaves>), dim3((unsigned)n_wg), dim3(64 * zwaves), 0, stream,
                                    (const double *)ts.xt.as<double>(), (const double *)ts.xc.as<double>(),
                                    (const int *)ref->gidx.as<int>(), (const int *)ref->nref.as<int>(), ref->k,
                                    (int)ref->B, (int)Ns, ts.zt.as<double>(), ts.rt.as<double>(), ts.nt.as<double>(),
