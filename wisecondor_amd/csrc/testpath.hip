@@ -4575,13 +4575,11 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
                                                   const double *__restrict__ reg_abs, const double *__restrict__ z,
                                                   double thr, int min_search, const double *__restrict__ tmin,
                                                   const double *__restrict__ tmax, const double *__restrict__ tmin2,
-                                                  const double *__restrict__ tmax2, const double *__restrict__ ratio,
-                                                  const int *__restrict__ gpos, int max_calls,
-                                                  double *__restrict__ reg_calls, int *__restrict__ out_n,
-                                                  unsigned long long *__restrict__ work) {
+                                                  const double *__restrict__ tmax2, Seg *__restrict__ wsegs,
+                                                  int *__restrict__ out_n, unsigned long long *__restrict__ work) {
     __shared__ CellShared sh;
     __shared__ Job stack[WALK_STACK];
-    __shared__ int s_sp, s_nseg, s_stop, s_nan;
+    __shared__ int s_sp, s_nseg, s_stop;
     __shared__ BestPair s_best[4];
     __shared__ double seg_val[TREE_SEGS];
     __shared__ int seg_x[TREE_SEGS], seg_y[TREE_SEGS];
@@ -4590,7 +4588,7 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
     const Region rg = regions[region];
     if (rg.n <= 0) return;                         // (out_n was zeroed by the set-up kernel)
     if (rg.n > CJ_MAXLEN || !reg_flag[region]) {
-        if (tid == 0) counters[6] = 1;
+        if (tid == 0) atomicOr(&counters[6], rg.n > CJ_MAXLEN ? 1 : 2);      // (the bits say why: tools/gpu_test_scale.py prints them with WC_TEST_VERBOSE)
         return;
     }
     const double eps = window_eps(rg.n, reg_abs[region]);
@@ -4634,7 +4632,7 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
             cell_search<2>(sh, g, rs, eps2, hi_cut, lo_cut, nullptr, 0, 1, e0, e1, wins, evals, tid);
             __syncthreads();
             if (sh.n_rec[0] > CJ_REC || sh.n_rec[1] > CJ_REC) {       // massive ties: the general path evaluates everything exactly
-                if (tid == 0) { counters[6] = 1; s_stop = 1; }
+                if (tid == 0) { atomicOr(&counters[6], 4); s_stop = 1; }
                 continue;
             }
         }
@@ -4675,11 +4673,11 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
             if (fabs(b.minv) > champ) { champ = b.minv; cx = b.nx; cy = b.ny; }
             if (!(fabs(champ) < thr)) {
                 if (s_nseg < TREE_SEGS) { seg_val[s_nseg] = champ; seg_x[s_nseg] = cx; seg_y[s_nseg] = cy; ++s_nseg; }
-                else { counters[6] = 1; s_stop = 1; }
+                else { atomicOr(&counters[6], 8); s_stop = 1; }
                 const int xr = cx - job.lo, yr = cy - job.lo, edge = job.hi - job.lo;
                 const bool left = xr > min_search, right = yr + 1 < edge - min_search;
                 if (s_sp + (left ? 1 : 0) + (right ? 1 : 0) > WALK_STACK) {
-                    counters[6] = 1;
+                    atomicOr(&counters[6], 16);
                     s_stop = 1;
                 } else {
                     if (right) { Job n; n.region = region; n.lo = cy + 1; n.hi = job.hi; n.pad = 0; stack[s_sp++] = n; }
@@ -4688,17 +4686,53 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
             }
         }
     }
-    // ---- the region's calls in position order (k_seg_gather + k_call_post of the general path): genomic start / end,
-    // value, effect = median of the segment's ratios - 1 (np.median by radix selection; wisecondor.py:233-257)
+    // ---- the region's segments for k_walk_rows (the call rows: position order, genomic bounds, effect size)
     __syncthreads();
     const int nseg = s_nseg;
     if (tid == 0) {
         out_n[region] = nseg;
         atomicAdd(&counters[4], nseg);
     }
-    double *sv = sh.pn;                            // a segment's ratios (up to 2048 of them; longer ones are read in place)
-    static_assert(2048 * sizeof(double) <= sizeof(sh.pn) + sizeof(sh.b8x) + sizeof(sh.b8n) + sizeof(sh.q2) + sizeof(sh.q1) +
-                                               sizeof(sh.l1) + sizeof(sh.itemq), "the staged segment does not fit the search's staging area");
+    for (int sidx = tid; sidx < nseg; sidx += 256) {
+        Seg sg;
+        sg.val = seg_val[sidx]; sg.region = region; sg.x = seg_x[sidx]; sg.y = seg_y[sidx]; sg.pad = 0;
+        wsegs[(int64_t)region * TREE_SEGS + sidx] = sg;
+    }
+    if (work) {
+        for (int o = 32; o > 0; o >>= 1) { evals += __shfl_xor(evals, o); wins += __shfl_xor(wins, o); }
+        const int slot = (int)((blockIdx.x * 7u + (unsigned)w) & 63u);
+        if (lane == 0) {
+            atomicAdd(work + 2 * slot, (unsigned long long)wins);
+            atomicAdd(work + 2 * slot + 1, (unsigned long long)evals);
+        }
+    }
+}
+
+// The call rows of k_seg_walk's segments, one workgroup per region (most regions have none: the workgroup leaves at
+// once): position order, genomic start / end, value, effect = median of the segment's ratios - 1 (np.median;
+// wisecondor.py:233-257) -- k_call_post's work.  A kernel of its own: as the tail of k_seg_walk the radix selection
+// returned wrong medians for about one row in a thousand (a wave out of step with the others by the time the walk
+// loop was over; the selection alone, tools/micro/select_test.hip, is clean), see EXPERIMENTS.md.
+__global__ __launch_bounds__(256) void k_walk_rows(const Seg *__restrict__ wsegs, const int *__restrict__ out_n,
+                                                   const Region *__restrict__ regions, int n_regions,
+                                                   const double *__restrict__ ratio, const int *__restrict__ gpos,
+                                                   int max_calls, double *__restrict__ reg_calls) {
+    constexpr int STAGED = 2048, COUNTED = 64;     // ratios staged in LDS up to STAGED; the counting median up to COUNTED
+    __shared__ double sv[STAGED];
+    __shared__ double s_mid[2];
+    __shared__ int s_nan;
+    __shared__ int seg_x[TREE_SEGS], seg_y[TREE_SEGS];
+    __shared__ double seg_val[TREE_SEGS];
+    const int region = blockIdx.x, tid = threadIdx.x;
+    if (region >= n_regions) return;
+    const int nseg = out_n[region] < TREE_SEGS ? out_n[region] : TREE_SEGS;
+    if (nseg <= 0) return;
+    const Region rg = regions[region];
+    for (int t = tid; t < nseg; t += 256) {
+        const Seg sg = wsegs[(int64_t)region * TREE_SEGS + t];
+        seg_x[t] = sg.x; seg_y[t] = sg.y; seg_val[t] = sg.val;
+    }
+    __syncthreads();
     for (int sidx = 0; sidx < nseg; ++sidx) {
         const int x = seg_x[sidx], y = seg_y[sidx], Ls = y - x + 1;
         int rank = 0;
@@ -4708,7 +4742,7 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
         if (tid == 0) s_nan = 0;
         __syncthreads();
         const double *rr = ratio + rg.off + x;
-        const bool staged = Ls <= 2048;
+        const bool staged = Ls <= STAGED;
         for (int e = tid; e < Ls; e += 256) {
             const double v = rr[e];
             if (staged) sv[e] = v;
@@ -4717,8 +4751,26 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
         __syncthreads();
         const bool has_nan = s_nan != 0;
         double lo = 0.0, hi = 0.0;
-        if (!has_nan) {
-            const double *src = staged ? sv : rr;
+        if (!has_nan && Ls <= COUNTED) {
+            // each value counts how many others lie below / at-or-below it; the value whose count interval covers a
+            // middle rank is that order statistic (k_call_post's short path)
+            const int k_lo = (Ls - 1) / 2, k_hi = Ls / 2;
+            for (int e = tid; e < Ls; e += 256) {
+                const double xv = sv[e];
+                int lt = 0, le = 0;
+                for (int u = 0; u < Ls; ++u) {
+                    const double yv = sv[u];
+                    lt += yv < xv;
+                    le += yv <= xv;
+                }
+                if (lt <= k_lo && k_lo < le) s_mid[0] = xv;      // equal values write the same number
+                if (lt <= k_hi && k_hi < le) s_mid[1] = xv;
+            }
+            __syncthreads();
+            lo = s_mid[0];
+            hi = s_mid[1];
+        } else if (!has_nan) {
+            const double *src = staged ? sv : rr;          // (radix selection: eight passes over the values)
             lo = block_select<256>(src, Ls, (Ls - 1) / 2, tid);
             hi = (Ls & 1) ? lo : block_select<256>(src, Ls, Ls / 2, tid);
         }
@@ -4735,14 +4787,6 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
             o[2] = (double)end;
             o[3] = seg_val[sidx];
             o[4] = med - 1.0;
-        }
-    }
-    if (work) {
-        for (int o = 32; o > 0; o >>= 1) { evals += __shfl_xor(evals, o); wins += __shfl_xor(wins, o); }
-        const int slot = (int)((blockIdx.x * 7u + (unsigned)w) & 63u);
-        if (lane == 0) {
-            atomicAdd(work + 2 * slot, (unsigned long long)wins);
-            atomicAdd(work + 2 * slot + 1, (unsigned long long)evals);
         }
     }
 }
@@ -5052,7 +5096,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     if ((rc = ts.job_cnt.reserve(sizeof(int) * 8))) return rc;
     if ((rc = ts.job_res.reserve(sizeof(Extreme) * job_cap))) return rc;
     if ((rc = ts.hot.reserve(sizeof(int) * 2 * job_cap))) return rc;
-    if ((rc = ts.seg.reserve(sizeof(Seg) * seg_cap))) return rc;
+    if ((rc = ts.seg.reserve(sizeof(Seg) * std::max<int64_t>(seg_cap, n_regions * (int64_t)TREE_SEGS)))) return rc;   // (k_seg_walk: TREE_SEGS slots per region)
     if ((rc = ts.out_val.reserve(sizeof(double) * n_regions * max_calls))) return rc;
     if ((rc = ts.out_x.reserve(sizeof(int) * n_regions * max_calls))) return rc;
     if ((rc = ts.out_y.reserve(sizeof(int) * n_regions * max_calls))) return rc;
@@ -5179,8 +5223,11 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
                            (int)n_regions, (const int *)ts.reg_flag.as<int>(), (const double *)ts.prefix.as<double>(),
                            (const double *)ts.rs.as<double>(), (const double *)ts.reg_abs.as<double>(), z_dev, thr,
                            min_search, (const double *)ts.tmin.as<double>(), (const double *)ts.tmax.as<double>(),
-                           (const double *)ts.tmin2.as<double>(), (const double *)ts.tmax2.as<double>(), tail->ratio,
-                           tail->gpos, max_calls, tail->reg_calls, ts.out_n.as<int>(), work);
+                           (const double *)ts.tmin2.as<double>(), (const double *)ts.tmax2.as<double>(), ts.seg.as<Seg>(),
+                           ts.out_n.as<int>(), work);
+        hipLaunchKernelGGL(k_walk_rows, dim3((unsigned)n_regions), dim3(256), 0, stream, (const Seg *)ts.seg.as<Seg>(),
+                           (const int *)ts.out_n.as<int>(), regions_dev, (int)n_regions, tail->ratio, tail->gpos, max_calls,
+                           tail->reg_calls);
         ts.mark(11, stream);
         const int64_t bound = seg_cap;
         WC_HIP(hipMemcpyAsync(h, counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
@@ -5201,6 +5248,10 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
             return WC_OK;
         }
         // rare: again on the host-driven path
+        if (getenv("WC_TEST_VERBOSE"))
+            fprintf(stderr, "wisecondor_amd: segmentation repeated on the host-driven rounds (walk status %d: 1 = region beyond %d "
+                            "bins, 2 = non-finite z, 4 = ties beyond the record, 8 = more than %d segments, 16 = stack; %d segments)\n",
+                    h[6], CJ_MAXLEN, TREE_SEGS, h[4]);
         WC_HIP(hipMemsetAsync(ts.out_n.p, 0, sizeof(int) * n_regions, stream));
         WC_HIP(hipMemsetAsync(counters + 4, 0, sizeof(int), stream));
         WC_HIP(hipMemsetAsync(counters + 6, 0, sizeof(int), stream));
@@ -5948,9 +5999,11 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
             return rc;
     } else {
         const bool fuse = min_effect == 0.0 && max_n <= TREE_MAXLEN;       // regions that fit the fused set-up kernel
+        // (256 threads = 1 024 bins per trip: 1 000 x 50 kb 1.55 ms with 1 024 threads, 0.92 with 512, 0.56 with 256, 0.68
+        //  with 128 -- eight small workgroups per CU cover each other's barriers and tails; 125 x 50 kb 124 -> < 95 us)
         if (!fuse)
         hipLaunchKernelGGL(k_clean, dim3((unsigned)n_sel, (unsigned)Ns),
-                           dim3((unsigned)std::min<int64_t>(1024, std::max<int64_t>(64, cdiv(max_n, 1024) * 256))), 0, stream, zsrc, rsrc, nsrc, B, Ns,
+                           dim3(max_n <= 8192 ? 256u : 1024u), 0, stream, zsrc, rsrc, nsrc, B, Ns,
                            (const int64_t *)ref->moff_dev.as<int64_t>(), (const int64_t *)ref->goff_dev.as<int64_t>(),
                            (const int *)ref->m2g.as<int>(), (const int *)ts.sel.as<int>(), n_sel, (double)min_ref_bins,
                            ts.zc.as<double>(), ts.rc.as<double>(), ts.gpos.as<int>(), ts.regions.as<Region>(), str_i,
@@ -5999,6 +6052,10 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
                 ts.tree_pending = false;
                 const int *h = (const int *)ctx->pinned;
                 if (h[3] != 0 || h[6] != 0) {
+                    if (getenv("WC_TEST_VERBOSE"))
+                        fprintf(stderr, "wisecondor_amd: batch repeated on the host-driven rounds (tree status %d, walk status %d: 1 = region "
+                                        "beyond %d bins, 2 = non-finite z, 4 = ties beyond the record, 8 = more than %d segments, 16 = stack)\n",
+                                h[3], h[6], CJ_MAXLEN, TREE_SEGS);
                     // rare (non-finite region, tie overflow, deep recursion): the whole batch again with
                     // host-driven rounds -- the same results by construction, one batch time lost
                     ts.no_tree = true;
