@@ -179,3 +179,22 @@ def test_whole_samples_against_the_reference_and_the_oracle(wt, gw, case):
             assert np.allclose(r[::stride], rs, rtol=rtol, atol=1e-12 if same_ref else 1e-9), i
             assert float(gw["ref%d_threshold_z" % i]) == thr
     assert n_calls >= 50
+
+
+def test_the_walker_gives_the_same_calls_on_every_call(wt, case, monkeypatch):
+    """k_seg_walk + k_walk_rows on the 125 x 50 kb batch, 40 calls against ONE run of the host-driven levels: every
+    call row and chromosome-wide value bit for bit, every time.  Round 5 found the call rows' medians wrong in about
+    one region of 14 000 -- one call in five at this size -- while they were computed at the end of k_seg_walk's
+    workgroup: a run-to-run difference that no single comparison shows (tools/gpu_repeatability.py is the same
+    check at up to 1 000 samples)."""
+    thr = case["threshold"]
+    monkeypatch.setenv("WC_TEST_WALK", "0")
+    want = wt.test_batch(case["reference"], case["tests"], thr)
+    monkeypatch.delenv("WC_TEST_WALK")
+    for _ in range(40):
+        got = wt.test_batch(case["reference"], case["tests"], thr)
+        for i, (a, b) in enumerate(zip(want, got)):
+            ca = np.asarray(a["results_calls"], dtype=np.float64).reshape(-1, 5)
+            cb = np.asarray(b["results_calls"], dtype=np.float64).reshape(-1, 5)
+            assert ca.shape == cb.shape and same_bits(ca, cb), i
+            assert same_bits(a["results_cwz"], b["results_cwz"]), i

@@ -369,26 +369,6 @@ def test_every_segmentation_path_gives_the_walkers_outputs(wt, cfg1, reference, 
         assert np.array_equal(np.concatenate(a["results_r"]).view(np.uint64), np.concatenate(b["results_r"]).view(np.uint64))
 
 
-def test_the_walker_gives_the_same_bits_on_every_call(wt, cfg1, reference, monkeypatch):
-    """k_seg_walk + k_walk_rows, 120 calls of a 40-sample batch against ONE run of the host-driven levels: every call
-    row, z, ratio and chromosome-wide value bit for bit, every time.  (Round 5 found the call rows' medians wrong in
-    about one region of 14 000 while they were computed at the end of k_seg_walk's workgroup -- a run-to-run
-    difference no single comparison shows; tools/gpu_repeatability.py is the same check at 125 - 1 000 samples.)"""
-    g = cfg1
-    thr = float(g["t_mild18_threshold_z"])
-    samples = [_split(g["t_%s_sample" % n], g["sample_chrom_lengths"]) for n in NAMES] * 8
-    monkeypatch.setenv("WC_TEST_WALK", "0")
-    want = wt.test_batch(reference, samples, thr)
-    monkeypatch.delenv("WC_TEST_WALK")
-    for _ in range(120):
-        got = wt.test_batch(reference, samples, thr)
-        for a, b in zip(want, got):
-            assert np.array_equal(np.asarray(a["results_calls"], dtype=np.float64).view(np.uint64),
-                                  np.asarray(b["results_calls"], dtype=np.float64).view(np.uint64))
-            assert np.array_equal(np.asarray(a["results_cwz"]).view(np.uint64), np.asarray(b["results_cwz"]).view(np.uint64))
-        assert np.array_equal(np.concatenate(want[3]["results_z"]).view(np.uint64), np.concatenate(got[3]["results_z"]).view(np.uint64))
-
-
 def test_long_regions_through_the_host_driven_levels(wt, monkeypatch):
     """wc_stouffer_segments on regions of 3 000 - 8 000 bins: the cell search with several workgroups per range (the
     default for few ranges), with one workgroup per range, and the row-block kernels give the same segments, bit for
