@@ -163,7 +163,7 @@ def committed_latency_trace():
     return None
 
 
-def committed_gather_roof(n_rows):
+def committed_gather_roof(n_rows, mode=0):
     """What a kernel that does nothing but gather whole rows of an [n_rows, 1 KB] matrix reaches on this chip
     (tools/micro/gather_rate.*, 8 B per lane, every XCD gathering from the whole matrix; committed by
     tools/refresh_profiles.sh as profiles/<round>_gather_roof.txt): the figure of the nearest matrix size, or None."""
@@ -173,7 +173,7 @@ def committed_gather_roof(n_rows):
         return None
     best = None
     for line in open(path):
-        m = re.match(r"bins\s+(\d+) mode 0 row 1024 B: [\d.]+ ms, ([\d.]+) TB/s", line)
+        m = re.match(r"bins\s+(\d+) mode %d row 1024 B: [\d.]+ ms, ([\d.]+) TB/s" % mode, line)
         if m:
             rows, rate = int(m.group(1)), float(m.group(2))
             if best is None or abs(np.log(rows / float(n_rows))) < abs(np.log(best[0] / float(n_rows))):
@@ -182,8 +182,10 @@ def committed_gather_roof(n_rows):
         return None
     return {"matrix_rows": best[0], "TBps": best[1], "source": "profiles/%s_gather_roof.txt" % ROUND,
             "measured_in_this_run": False,
-            "what": "random whole-row gathers of a matrix of this many 1 KB rows by a kernel that does nothing else "
-                    "(the matrix misses the 4 MB L2 of an XCD; the guide's 34.5 TB/s is for L2-resident data)"}
+            "what": ("random whole-row gathers of a matrix of this many 1 KB rows by a kernel that does nothing else "
+                     "(the matrix misses the 4 MB L2 of an XCD; the guide's 34.5 TB/s is for L2-resident data)") if mode == 0 else
+                    ("the same gathers with the 128-byte sample columns dealt to the XCDs (workgroup w only touches column "
+                     "w % 8 of every row, a wave = 4 bins x 16 samples: k_zscore_tiled's access pattern, nothing but the loads)")}
 
 
 def hbm_bytes(entry):
@@ -455,7 +457,9 @@ def test_roofline(prof, n_refs, windows, n_samples, ms_per_batch, n_bins=0):
     byte_frac = n_samples * test_bytes / (ms_per_batch * 1e-3) / PEAK_HBM
     z_ms = float(prof[1])
     z_bytes = n_samples * n_refs * 8.0                          # first repeat: every reference value once
-    gather_roof = committed_gather_roof(n_bins) if n_bins else None
+    tiled = n_samples >= 113                                    # (padded to 128 samples and more: k_zscore_tiled)
+    gather_roof = committed_gather_roof(n_bins, 3 if tiled else 0) if n_bins else None
+    untiled_roof = committed_gather_roof(n_bins, 0) if (n_bins and tiled) else None
     return {
         "bound": "fp64-valu" if byte_frac > 1.0 else "hbm",
         "frac": valu_frac if byte_frac > 1.0 else byte_frac,
@@ -471,12 +475,13 @@ def test_roofline(prof, n_refs, windows, n_samples, ms_per_batch, n_bins=0):
                              "ms": search_ms, "windows_evaluated": float(prof[6]),
                              "certificate_evaluations": float(prof[7]), "fp64_ops": search_ops,
                              "peak_ops_per_s": PEAK_FP64_VALU_OPS},
-        "zscore_gather": {"kernels": "k_zscore + the later repeats' pair kernels", "ms": z_ms,
+        "zscore_gather": {"kernels": "%s + the later repeats' pair kernels" % ("k_zscore_tiled" if tiled else "k_zscore"), "ms": z_ms,
                           "gathered_bytes_per_batch": z_bytes,
                           "achieved_GBps": (z_bytes / (z_ms * 1e-3) / 1e9) if z_ms > 0 else None,
                           "l2_peak_GBps": PEAK_L2 / 1e9,
                           "l2_frac": (z_bytes / (z_ms * 1e-3) / PEAK_L2) if z_ms > 0 else None,
                           "measured_gather_roof": gather_roof,
+                          "measured_gather_roof_untiled": untiled_roof,
                           "frac_of_measured_gather_roof": (z_bytes / (z_ms * 1e-3) / (gather_roof["TBps"] * 1e12))
                                                           if (z_ms > 0 and gather_roof) else None},
         "hbm_byte_model": {"model": "5 repeats x gathered refs x 12 B + 8 B per Stouffer window (SURVEY.md 8d); "

@@ -15,5 +15,5 @@ for C in "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum" \
          "TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" \
          "TD_TD_BUSY_sum TD_TC_STALL_sum"; do
   i=$((i+1))
-  bash tools/pmc_run.sh ${TAG}z${i} "$C" tools/gpu_test_scale.py $NS $BS 3 2>&1 | grep "k_zscore(" | head -1
+  bash tools/pmc_run.sh ${TAG}z${i} "$C" tools/gpu_test_scale.py $NS $BS 3 2>&1 | grep "k_zscore" | grep -v pairs | head -1
 done

@@ -36,7 +36,7 @@ cp "$(find gpurun_out/prof_${TAG}_cfg5_1000 -name '*kernel_stats.csv' | head -1)
 cp "$(find gpurun_out/prof_${TAG}_test250_1000 -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_test250_1000_samples_kernel_stats.csv"
 grep "batch of" "$OUT/cfg5_run.log" "$OUT/test250_run.log" "$OUT/cfg5_1000_run.log" "$OUT/test250_1000_run.log" > "$OUT/${TAG}_test_batch_times_under_rocprof.txt"
 # the gather roof of the z-score stage: micro-benchmark by matrix size and access width, and k_zscore's TA / TCP / TLB counters
-( for n in 3000 11087 55337; do timeout 120 python3 tools/micro/gather_rate.py $n 2>&1 | grep "^bins" | head -4; done ) > "$OUT/${TAG}_gather_roof.txt"
+( for n in 3000 11087 55337; do timeout 120 python3 tools/micro/gather_rate.py $n 2>&1 | grep "^bins" | head -5; done ) > "$OUT/${TAG}_gather_roof.txt"
 ( echo "== 125 x 50 kb"; PMC_TIMEOUT=120 bash tools/pmc_zscore.sh ${TAG} 125 50000; echo "== 128 x 250 kb"; PMC_TIMEOUT=120 bash tools/pmc_zscore.sh ${TAG}q 128 250000 ) > "$OUT/${TAG}_zscore_ta_tcp.txt" 2>&1
 cp "$(find gpurun_out/prof_${TAG}_cfg5 -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_cfg5_test_kernel_stats.csv"
 cp "$(find gpurun_out/prof_${TAG}_test250 -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_test250_kernel_stats.csv"
