@@ -327,6 +327,30 @@ def test_repeats_heavy_flagging(wt, n_samples, k, seed):
         assert same_bits([sd[s_]], [wsd]), (s_,)
 
 
+def test_tiled_and_untiled_first_repeat_agree(wt, monkeypatch):
+    """k_zscore_tiled (sample tiles dealt to XCDs, four bins per wave) against k_zscore (WC_ZSCORE_TILED=0: a bin per
+    wave) on 176 samples -- eleven tiles, three of them dealt to all XCDs -- with negative and NaN values: same bits."""
+    rng = np.random.RandomState(9)
+    bins = np.array([300, 250, 1, 410, 77], dtype=np.int64)
+    B, k = int(bins.sum()), 100
+    idx = np.empty((B, k), dtype=np.int32)
+    b = 0
+    for c in range(len(bins)):
+        others = np.setdiff1d(np.arange(B), np.arange(int(bins[:c].sum()), int(bins[:c + 1].sum())))
+        for _ in range(int(bins[c])):
+            idx[b] = rng.choice(others, size=k, replace=False)
+            b += 1
+    dst = np.sort(rng.rand(B, k), axis=1)
+    data = 1.0 + 0.05 * rng.standard_normal((176, B))
+    data[rng.rand(176, B) < 0.002] = -0.5
+    data[rng.rand(176, B) < 0.001] = np.nan
+    got = wt.repeatTest(data, idx, dst, bins, np.cumsum(bins), 0.9, 2.0, 3)
+    monkeypatch.setenv("WC_ZSCORE_TILED", "0")
+    want = wt.repeatTest(data, idx, dst, bins, np.cumsum(bins), 0.9, 2.0, 3)
+    for a, b_ in zip(got, want):
+        assert same_bits(a, b_)
+
+
 @pytest.mark.parametrize("seed", range(4 * SWEEP))
 def test_segments_random(wt, seed):
     """Stouffer segmentation of random regions against the oracle's triangle walk: lengths around

@@ -4336,8 +4336,8 @@ __global__ __launch_bounds__(256) void k_seg_gather(const Seg *__restrict__ segs
 constexpr int CP_THREADS = 1024;     // threads of a k_call_post workgroup (one per segment)
 // k-th smallest (0-based) of v[0..L) by radix selection on the ordered 64-bit image;
 // all CP_THREADS threads of the workgroup take part.
-template <int NT = CP_THREADS>      // NT >= 256 threads
-__device__ inline double block_select(const double *__restrict__ v, int L, int k, int tid) {
+template <int NT, class F>          // NT >= 256 threads; at(e): the e-th value (a lambda over an LDS array reads it as LDS)
+__device__ inline double block_select_of(F at, int L, int k, int tid) {
     // NT threads; the 256 digit buckets are scanned by the first four waves
     __shared__ unsigned int hist[256];
     __shared__ unsigned int s_wsum[4];
@@ -4347,9 +4347,15 @@ __device__ inline double block_select(const double *__restrict__ v, int L, int k
     for (int shift = 56; shift >= 0; shift -= 8) {
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
-        for (int e = tid; e < L; e += NT) {
-            unsigned long long key = wc::f64_ordered(v[e]);
-            if ((key & mask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+        for (int e0 = tid; e0 < L; e0 += 4 * NT) {            // four values per trip: their loads are in flight together
+            double x4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x4[u] = e0 + u * NT < L ? at(e0 + u * NT) : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned long long key = wc::f64_ordered(x4[u]);
+                if (e0 + u * NT < L && (key & mask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+            }
         }
         __syncthreads();
         unsigned int h = 0, incl = 0;
@@ -4381,6 +4387,40 @@ __device__ inline double block_select(const double *__restrict__ v, int L, int k
         __syncthreads();
     }
     return wc::f64_from_ordered(prefix);
+}
+template <int NT = CP_THREADS>
+__device__ inline double block_select(const double *__restrict__ v, int L, int k, int tid) {
+    return block_select_of<NT>([&](int e) { return v[e]; }, L, k, tid);
+}
+// The two middle order statistics np.median needs, ranks k and k2 (k2 == k or k + 1): the radix selection once, then
+// ONE pass for the successor -- the smallest value above the k-th unless the k-th value occurs often enough to hold
+// rank k2 as well -- instead of a second selection.
+template <int NT, class F>
+__device__ inline void block_select_pair(F at, int L, int k, int k2, int tid, double &lo, double &hi) {
+    __shared__ unsigned long long s_next;
+    __shared__ int s_le;
+    lo = block_select_of<NT>(at, L, k, tid);
+    hi = lo;
+    if (k2 == k) return;
+    const unsigned long long klo = wc::f64_ordered(lo);
+    if (tid == 0) { s_next = ~0ull; s_le = 0; }
+    __syncthreads();
+    unsigned long long mine = ~0ull;
+    int le = 0;
+    for (int e = tid; e < L; e += NT) {
+        const unsigned long long key = wc::f64_ordered(at(e));
+        if (key <= klo) ++le;
+        else if (key < mine) mine = key;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        le += __shfl_xor(le, o);
+        const unsigned long long other = (unsigned long long)__shfl_xor((long long)mine, o);
+        mine = other < mine ? other : mine;
+    }
+    if ((tid & 63) == 0) { atomicAdd(&s_le, le); atomicMin(&s_next, mine); }
+    __syncthreads();
+    if (s_le <= k2) hi = wc::f64_from_ordered(s_next);     // (ranks 0 .. s_le - 1 hold values <= lo)
+    __syncthreads();
 }
 __global__ __launch_bounds__(CP_THREADS) void k_call_post(const Seg *__restrict__ segs, int n_segs,
                                                    const Region *__restrict__ regions, const double *__restrict__ rc,
@@ -4576,7 +4616,8 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
                                                   double thr, int min_search, const double *__restrict__ tmin,
                                                   const double *__restrict__ tmax, const double *__restrict__ tmin2,
                                                   const double *__restrict__ tmax2, Seg *__restrict__ wsegs,
-                                                  int *__restrict__ out_n, unsigned long long *__restrict__ work) {
+                                                  int seg_cap, int *__restrict__ out_n,
+                                                  unsigned long long *__restrict__ work) {
     __shared__ CellShared sh;
     __shared__ Job stack[WALK_STACK];
     __shared__ int s_sp, s_nseg, s_stop;
@@ -4686,17 +4727,20 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
             }
         }
     }
-    // ---- the region's segments for k_walk_rows (the call rows: position order, genomic bounds, effect size)
+    // ---- the region's segments, appended to the batch's list for k_walk_rows (the call rows: position order, genomic
+    // bounds, effect size); pad = the segment's number within the region | the region's count << 16
     __syncthreads();
     const int nseg = s_nseg;
     if (tid == 0) {
         out_n[region] = nseg;
-        atomicAdd(&counters[4], nseg);
+        s_sp = nseg ? atomicAdd(&counters[4], nseg) : 0;     // (the stack pointer's slot: the walk is over)
     }
+    __syncthreads();
+    const int base = s_sp;
     for (int sidx = tid; sidx < nseg; sidx += 256) {
         Seg sg;
-        sg.val = seg_val[sidx]; sg.region = region; sg.x = seg_x[sidx]; sg.y = seg_y[sidx]; sg.pad = 0;
-        wsegs[(int64_t)region * TREE_SEGS + sidx] = sg;
+        sg.val = seg_val[sidx]; sg.region = region; sg.x = seg_x[sidx]; sg.y = seg_y[sidx]; sg.pad = sidx | (nseg << 16);
+        if (base + sidx < seg_cap) wsegs[base + sidx] = sg;   // (beyond: the caller sees counters[4] > seg_cap)
     }
     if (work) {
         for (int o = 32; o > 0; o >>= 1) { evals += __shfl_xor(evals, o); wins += __shfl_xor(wins, o); }
@@ -4708,47 +4752,53 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
     }
 }
 
-// The call rows of k_seg_walk's segments, one workgroup per region (most regions have none: the workgroup leaves at
-// once): position order, genomic start / end, value, effect = median of the segment's ratios - 1 (np.median;
-// wisecondor.py:233-257) -- k_call_post's work.  A kernel of its own: as the tail of k_seg_walk the radix selection
-// returned wrong medians for about one row in a thousand (a wave out of step with the others by the time the walk
-// loop was over; the selection alone, tools/micro/select_test.hip, is clean), see EXPERIMENTS.md.
-__global__ __launch_bounds__(256) void k_walk_rows(const Seg *__restrict__ wsegs, const int *__restrict__ out_n,
-                                                   const Region *__restrict__ regions, int n_regions,
-                                                   const double *__restrict__ ratio, const int *__restrict__ gpos,
-                                                   int max_calls, double *__restrict__ reg_calls) {
-    constexpr int STAGED = 2048, COUNTED = 64;     // ratios staged in LDS up to STAGED; the counting median up to COUNTED
+// The call rows of k_seg_walk's segments: position order, genomic start / end, value, effect = median of the
+// segment's ratios - 1 (np.median; wisecondor.py:233-257) -- k_call_post's work.  A few hundred resident workgroups
+// take the segments of the batch's list one after the other through a cursor (counters[7]; a workgroup per region or
+// per possible segment would mostly be workgroups with nothing to do, and each of them still has to be given its LDS).
+// A kernel of its own: as the tail of k_seg_walk the radix selection returned wrong medians for about one row in a
+// thousand, differently from run to run (the selection alone, tools/micro/select_test.hip, is clean), see
+// EXPERIMENTS.md.
+__global__ __launch_bounds__(256) void k_walk_rows(const Seg *__restrict__ wsegs, const int *__restrict__ n_segs_dev,
+                                                   int *__restrict__ cursor, int seg_cap,
+                                                   const Region *__restrict__ regions, const double *__restrict__ ratio,
+                                                   const int *__restrict__ gpos, int max_calls,
+                                                   double *__restrict__ reg_calls) {
+    // ratios staged in LDS up to STAGED values (40 KB: three workgroups per CU); the counting median up to COUNTED (beyond
+    // that its L x L / 256 dependent LDS reads per thread lose to the selection's eight passes).  An item costs ~20 us of
+    // dependent round trips and barriers whatever its length: 2 304 workgroups with 16 KB each were slower (75 / 38 us)
+    constexpr int STAGED = 5120, COUNTED = 64;
     __shared__ double sv[STAGED];
     __shared__ double s_mid[2];
-    __shared__ int s_nan;
-    __shared__ int seg_x[TREE_SEGS], seg_y[TREE_SEGS];
-    __shared__ double seg_val[TREE_SEGS];
-    const int region = blockIdx.x, tid = threadIdx.x;
-    if (region >= n_regions) return;
-    const int nseg = out_n[region] < TREE_SEGS ? out_n[region] : TREE_SEGS;
-    if (nseg <= 0) return;
-    const Region rg = regions[region];
-    for (int t = tid; t < nseg; t += 256) {
-        const Seg sg = wsegs[(int64_t)region * TREE_SEGS + t];
-        seg_x[t] = sg.x; seg_y[t] = sg.y; seg_val[t] = sg.val;
-    }
-    __syncthreads();
-    for (int sidx = 0; sidx < nseg; ++sidx) {
-        const int x = seg_x[sidx], y = seg_y[sidx], Ls = y - x + 1;
-        int rank = 0;
-        for (int u = 0; u < nseg; ++u) rank += seg_x[u] < x;
-        if (rank >= max_calls) continue;                   // k_assemble_calls reports the overflow from out_n
+    __shared__ int s_nan, s_item, s_rank;
+    const int tid = threadIdx.x;
+    const int total = *n_segs_dev < seg_cap ? *n_segs_dev : seg_cap;
+    while (true) {
         __syncthreads();
-        if (tid == 0) s_nan = 0;
+        if (tid == 0) { s_item = atomicAdd(cursor, 1); s_nan = 0; s_rank = 0; }
         __syncthreads();
+        const int item = s_item;
+        if (item >= total) break;
+        const Seg me = wsegs[item];
+        const int region = me.region, nseg = me.pad >> 16, first = item - (me.pad & 0xFFFF);
+        const Region rg = regions[region];
+        const int x = me.x, y = me.y, Ls = y - x + 1;
+        if (tid < nseg && wsegs[first + tid].x < x) atomicAdd(&s_rank, 1);       // (nseg <= TREE_SEGS = 128)
         const double *rr = ratio + rg.off + x;
         const bool staged = Ls <= STAGED;
-        for (int e = tid; e < Ls; e += 256) {
-            const double v = rr[e];
-            if (staged) sv[e] = v;
-            if (v != v) s_nan = 1;
+        for (int e0 = tid; e0 < Ls; e0 += 8 * 256) {           // eight loads in flight per thread and trip
+            double t8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t8[u] = e0 + u * 256 < Ls ? rr[e0 + u * 256] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (staged && e0 + u * 256 < Ls) sv[e0 + u * 256] = t8[u];
+                if (t8[u] != t8[u]) s_nan = 1;
+            }
         }
         __syncthreads();
+        const int rank = s_rank;
+        if (rank >= max_calls) continue;                   // k_assemble_calls reports the overflow from out_n
         const bool has_nan = s_nan != 0;
         double lo = 0.0, hi = 0.0;
         if (!has_nan && Ls <= COUNTED) {
@@ -4770,9 +4820,9 @@ __global__ __launch_bounds__(256) void k_walk_rows(const Seg *__restrict__ wsegs
             lo = s_mid[0];
             hi = s_mid[1];
         } else if (!has_nan) {
-            const double *src = staged ? sv : rr;          // (radix selection: eight passes over the values)
-            lo = block_select<256>(src, Ls, (Ls - 1) / 2, tid);
-            hi = (Ls & 1) ? lo : block_select<256>(src, Ls, Ls / 2, tid);
+            // (radix selection: eight passes over the values)
+            if (staged) block_select_pair<256>([&](int e) { return sv[e]; }, Ls, (Ls - 1) / 2, Ls / 2, tid, lo, hi);
+            else block_select_pair<256>([&](int e) { return rr[e]; }, Ls, (Ls - 1) / 2, Ls / 2, tid, lo, hi);
         }
         if (tid == 0) {
             double med = (Ls & 1) ? lo : (lo + hi) / 2.0;  // np.median: mean of the middle pair
@@ -4785,7 +4835,7 @@ __global__ __launch_bounds__(256) void k_walk_rows(const Seg *__restrict__ wsegs
             o[0] = (double)(rg.pad + 1);
             o[1] = (double)start;
             o[2] = (double)end;
-            o[3] = seg_val[sidx];
+            o[3] = me.val;
             o[4] = med - 1.0;
         }
     }
@@ -5096,7 +5146,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     if ((rc = ts.job_cnt.reserve(sizeof(int) * 8))) return rc;
     if ((rc = ts.job_res.reserve(sizeof(Extreme) * job_cap))) return rc;
     if ((rc = ts.hot.reserve(sizeof(int) * 2 * job_cap))) return rc;
-    if ((rc = ts.seg.reserve(sizeof(Seg) * std::max<int64_t>(seg_cap, n_regions * (int64_t)TREE_SEGS)))) return rc;   // (k_seg_walk: TREE_SEGS slots per region)
+    if ((rc = ts.seg.reserve(sizeof(Seg) * seg_cap))) return rc;
     if ((rc = ts.out_val.reserve(sizeof(double) * n_regions * max_calls))) return rc;
     if ((rc = ts.out_x.reserve(sizeof(int) * n_regions * max_calls))) return rc;
     if ((rc = ts.out_y.reserve(sizeof(int) * n_regions * max_calls))) return rc;
@@ -5224,10 +5274,10 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
                            (const double *)ts.rs.as<double>(), (const double *)ts.reg_abs.as<double>(), z_dev, thr,
                            min_search, (const double *)ts.tmin.as<double>(), (const double *)ts.tmax.as<double>(),
                            (const double *)ts.tmin2.as<double>(), (const double *)ts.tmax2.as<double>(), ts.seg.as<Seg>(),
-                           ts.out_n.as<int>(), work);
-        hipLaunchKernelGGL(k_walk_rows, dim3((unsigned)n_regions), dim3(256), 0, stream, (const Seg *)ts.seg.as<Seg>(),
-                           (const int *)ts.out_n.as<int>(), regions_dev, (int)n_regions, tail->ratio, tail->gpos, max_calls,
-                           tail->reg_calls);
+                           (int)seg_cap, ts.out_n.as<int>(), work);
+        hipLaunchKernelGGL(k_walk_rows, dim3(768), dim3(256), 0, stream, (const Seg *)ts.seg.as<Seg>(),
+                           (const int *)(counters + 4), counters + 7, (int)seg_cap, regions_dev, tail->ratio, tail->gpos,
+                           max_calls, tail->reg_calls);
         ts.mark(11, stream);
         const int64_t bound = seg_cap;
         WC_HIP(hipMemcpyAsync(h, counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
