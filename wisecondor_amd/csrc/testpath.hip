@@ -784,12 +784,11 @@ __device__ inline int row_lane(const int x, const int from) {
     }
 #undef WC_ROW_LANE
 }
-template <int G, int WAVES>
+template <int G, int WAVES, int NL>        // NL: 4-slot groups of the list held in registers (list stride k <= 4 NL <= 8 G + 8)
 __global__ __launch_bounds__(64 * WAVES, 2) void k_zscore_tiled(const double *__restrict__ XT, const double *__restrict__ XC,
                                                          const int *__restrict__ gidx, const int *__restrict__ nref, int k,
                                                          int B, int Ns, double *__restrict__ zT, double *__restrict__ rT,
                                                          double *__restrict__ nT, double *__restrict__ sdT) {
-    constexpr int NL = (8 * G + 7 + 3) / 4;        // 4-index loads that cover 8 G + 7 list slots
     // tiles 0 .. 8 F - 1: tile t belongs to XCD t % 8; the R = n_tiles % 8 tiles left over are dealt to all XCDs by
     // (tile, workgroup) items, so that no XCD gets a whole extra tile
     const int n_tiles = Ns >> 4;
@@ -875,7 +874,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_zscore_tiled(const double *__
     for (int q = 0; q <= G; ++q)
         if (q == ng) {
 #pragma unroll
-            for (int e = 0; e < 7; ++e) tailv[e] = e < (n & 7) ? v[8 * q + e] : -1.0;
+            for (int e = 0; e < 7; ++e) tailv[e] = (e < (n & 7) && 8 * q + e < 4 * NL) ? v[8 * q + e < 4 * NL ? 8 * q + e : 0] : -1.0;
         }
     int m = 8 * ng;
     double sum = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
@@ -4972,7 +4971,8 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
                 const int64_t n_wg = 8 * ((ztiles / 8) * zgroups + cdiv((ztiles % 8) * zgroups, 8));
                 hipLaunchKernelGGL(k_fill, dim3((unsigned)cdiv(Ns, 256)), dim3(256), 0, stream, ts.xc.as<double>() + ref->B * Ns,
                                    Ns, -1.0);                       // row B of xc: what an index of -1 reads
-                hipLaunchKernelGGL((k_zscore_tiled<ZT_G, zwaves>), dim3((unsigned)n_wg), dim3(64 * zwaves), 0, stream,
+                // (a list stride of up to 100 -- refsize 100 -- needs 100 value slots, not the 104 of 8 G + 8)
+                hipLaunchKernelGGL((ref->k <= 100 ? k_zscore_tiled<ZT_G, zwaves, 25> : k_zscore_tiled<ZT_G, zwaves, 26>), dim3((unsigned)n_wg), dim3(64 * zwaves), 0, stream,
                                    (const double *)ts.xt.as<double>(), (const double *)ts.xc.as<double>(),
                                    (const int *)ref->gidx.as<int>(), (const int *)ref->nref.as<int>(), ref->k,
                                    (int)ref->B, (int)Ns, ts.zt.as<double>(), ts.rt.as<double>(), ts.nt.as<double>(),
