@@ -327,6 +327,50 @@ def test_repeats_heavy_flagging(wt, n_samples, k, seed):
         assert same_bits([sd[s_]], [wsd]), (s_,)
 
 
+def test_calls_longer_than_the_staging_buffer(wt, monkeypatch):
+    """A chromosome of 7 000 bins with gains over 5 600 and 6 900 of them: call rows whose ratios do not fit k_walk_rows'
+    LDS staging (5 120 values: the radix selection then reads global memory) and ones that do, next to short ones --
+    the walker's rows against the host-driven levels + k_call_post, bit for bit, and the effect sizes against
+    np.median of the same bins."""
+    rng = np.random.RandomState(4)
+    sizes = np.array([7000] + [45] * 21, dtype=np.int64)
+    total = int(sizes.sum())
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    mask = np.ones(total, dtype=bool)
+    B, S = total, 24
+    corrected = 1.0 + 0.02 * rng.standard_normal((B, S))
+    idx, dst = wt.getReference(np.asfortranarray(corrected), sizes, np.cumsum(sizes), 60, 1, 1)
+    comps = np.linalg.qr(rng.standard_normal((B, 3)))[0].T
+    mean = np.full(B, 1.0 / B) * (1 + 0.01 * rng.standard_normal(B))
+    reference = wt.Reference(idx, dst, sizes, sizes, mask, mean, comps, binsize=1e6)
+    samples = []
+    for span in ((100, 5700), (50, 6950), (3000, 3040), (10, 2100)):
+        lam = np.full(total, 3000.0) * (1 + 0.02 * rng.standard_normal(total)).clip(0.5)
+        lam[span[0]:span[1]] *= 1.05
+        counts = rng.poisson(lam).astype(np.int32)
+        samples.append({str(c + 1): counts[offs[c]:offs[c + 1]] for c in range(22)})
+    samples = samples * 10                                  # 40 samples: the batch path
+    thr = 4.5
+    got = wt.test_batch(reference, samples, thr)
+    monkeypatch.setenv("WC_TEST_WALK", "0")
+    want = wt.test_batch(reference, samples, thr)
+    longest = 0
+    for a, b in zip(got, want):
+        ca = np.asarray(a["results_calls"], dtype=np.float64).reshape(-1, 5)
+        cb = np.asarray(b["results_calls"], dtype=np.float64).reshape(-1, 5)
+        assert ca.shape == cb.shape and same_bits(ca, cb)
+        r1 = np.asarray(a["results_r"][0])                  # chromosome 1: ratio - 1 per genomic bin (nothing masked)
+        for row in ca[ca[:, 0] == 1]:
+            x, y = int(row[1]), int(row[2])
+            longest = max(longest, y - x)
+            # (every bin is kept here, so positions are bin numbers and the call covers [start, end] -- the reference's end
+            #  is the position of its last-but-one survivor + 1; bins dropped for their reference count would read 0)
+            if y > x and not np.any(r1[x:y + 1] == 0.0):
+                assert np.isclose(row[4], np.median(r1[x:y + 1] + 1.0) - 1.0, rtol=0, atol=1e-12)
+    assert longest > 5200
+    reference.close()
+
+
 def test_tiled_and_untiled_first_repeat_agree(wt, monkeypatch):
     """k_zscore_tiled (sample tiles dealt to XCDs, four bins per wave) against k_zscore (WC_ZSCORE_TILED=0: a bin per
     wave) on 176 samples -- eleven tiles, three of them dealt to all XCDs -- with negative and NaN values: same bits."""
