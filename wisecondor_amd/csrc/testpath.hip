@@ -4563,6 +4563,38 @@ __global__ void k_assemble_calls(const double *__restrict__ reg_calls, const int
 }
 
 
+// The same for a batch: one wave per sample, lane s = the sample's s-th region (n_sel <= 64): the regions' call
+// counts become offsets by a wave scan and every lane copies its own region's rows (one thread per sample walked
+// 22 regions x their rows one after the other: two workgroups, 22 us per 125-sample batch).
+__global__ __launch_bounds__(64) void k_assemble_batch(const double *__restrict__ reg_calls, const int *__restrict__ out_n,
+                                                       int n_sel, int max_calls, int64_t Ns, double *__restrict__ calls,
+                                                       int *__restrict__ n_calls, int *__restrict__ overflow) {
+    const int64_t i = blockIdx.x;
+    const int s = threadIdx.x;
+    if (i >= Ns) return;
+    const int64_t r = i * n_sel + s;
+    int n = s < n_sel ? out_n[r] : 0;
+    bool over = n > max_calls;
+    if (over) n = max_calls;
+    int incl = n;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (s >= o) incl += up;
+    }
+    const int first = incl - n, total = __shfl(incl, 63);
+    for (int c = 0; c < n; ++c) {
+        if (first + c < max_calls) {
+#pragma unroll
+            for (int f = 0; f < 5; ++f)
+                calls[(i * max_calls + first + c) * 5 + f] = reg_calls[(r * max_calls + c) * 5 + f];
+        } else {
+            over = true;
+        }
+    }
+    if (over) *overflow = 1;
+    if (s == 0) n_calls[i] = total < max_calls ? total : max_calls;
+}
+
 // Latency mode's last launch.  One 1024-thread workgroup per region walks the region's recursion
 // (seg_tree_region); the same grid carries three riders that would otherwise be launches (or a
 // forked graph branch) of their own:
@@ -6118,6 +6150,10 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
                                (const Region *)ts.regions.as<Region>(), (const double *)ts.rc.as<double>(),
                                (const int *)ts.gpos.as<int>(), max_calls, ts.effect.as<double>(), (const int *)nullptr);
         if (lat && (rc = join_side(ctx, stream))) return rc;      // the status words read k_sd_fast's flags
+        if (!lat && n_sel <= 64)
+            hipLaunchKernelGGL(k_assemble_batch, dim3((unsigned)Ns), dim3(64), 0, stream, (const double *)ts.effect.as<double>(),
+                               (const int *)ts.out_n.as<int>(), n_sel, max_calls, Ns, calls, n_calls, ts.misc.as<int>());
+        else
         hipLaunchKernelGGL(k_assemble_calls, dim3((unsigned)cdiv(Ns, 64)), dim3(64), 0, stream,   // latency mode: Ns <= 8, one workgroup
                            (const double *)ts.effect.as<double>(), (const int *)ts.out_n.as<int>(), n_sel, max_calls, Ns,
                            calls, n_calls, ts.misc.as<int>(), lat ? (int *)ctx->pinned : (int *)nullptr,
