@@ -296,6 +296,28 @@ def test_cfg1_options(wt, cfg1, reference):
     assert np.isclose(out["asdef"], float(g["opts_asdef"]), rtol=1e-11)
 
 
+@pytest.mark.parametrize("opts", [dict(mineffectsize=0.02), dict(minrefbins=40, repeats=2, chromosomes=[2, 5, 18]),
+                                  dict(repeats=1)])
+def test_options_in_a_padded_batch(wt, cfg1, reference, opts):
+    """45 samples in one call -- the z-score stage then runs on 48 sample columns (three of padding) -- with
+    -mineffectsize, with a chromosome selection / minrefbins / two repeats, and with one repeat: every output equals
+    the one-sample calls' (a different kernel path: no padding, the latency kernels), bit for bit."""
+    g = cfg1
+    thr = float(g["t_mild18_threshold_z"])
+    six = [_split(g["t_%s_sample" % n], g["sample_chrom_lengths"]) for n in NAMES]
+    samples = (six * 8)[:45]
+    got = wt.test_batch(reference, samples, thr, **opts)
+    want = [wt.test_batch(reference, [sm], thr, **opts)[0] for sm in six]
+    for i, out in enumerate(got):
+        w = want[i % len(six)]
+        assert np.array_equal(np.asarray(out["results_calls"], dtype=np.float64).view(np.uint64),
+                              np.asarray(w["results_calls"], dtype=np.float64).view(np.uint64)), (i, opts)
+        assert same_bits(np.concatenate(out["results_z"]), np.concatenate(w["results_z"])), (i, opts)
+        assert same_bits(np.concatenate(out["results_r"]), np.concatenate(w["results_r"])), (i, opts)
+        assert same_bits(out["results_cwz"], w["results_cwz"]), (i, opts)
+        assert same_bits([out["asdef"]], [w["asdef"]]), (i, opts)
+
+
 def _seq_mean(v):
     """trySample's stdDevAvg: Python-style sequential float64 sum of the non-NaN terms / their count."""
     s, n = 0.0, 0
