@@ -376,7 +376,7 @@ def test_every_segmentation_path_gives_the_walkers_outputs(wt, cfg1, reference, 
     """The batched `test` through the paths k_seg_walk replaced (the switches are read per call): the tree kernel
     after k_seg_quiet / k_seg_search / k_seg_classify, the host-driven levels with the cell search (k_seg_job /
     k_seg_merge; one workgroup per range or several), and those levels with the row-block kernels -- bit-identical
-    calls, z, ratios and chromosome-wide values for a batch of 40 samples (the six cfg1 samples repeated)."""
+    calls, z, ratios and chromosome-wide values for a batch of 48 samples (the six cfg1 samples repeated)."""
     g = cfg1
     thr = float(g["t_mild18_threshold_z"])
     samples = [_split(g["t_%s_sample" % n], g["sample_chrom_lengths"]) for n in NAMES] * 8
