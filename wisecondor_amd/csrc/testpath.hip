@@ -4818,7 +4818,7 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
 // thousand, differently from run to run (the selection alone, tools/micro/select_test.hip, is clean), see
 // EXPERIMENTS.md.
 __global__ __launch_bounds__(256) void k_walk_rows(const Seg *__restrict__ wsegs, const int *__restrict__ n_segs_dev,
-                                                   int *__restrict__ cursor, int seg_cap,
+                                                   int seg_cap,
                                                    const Region *__restrict__ regions, const double *__restrict__ ratio,
                                                    const int *__restrict__ gpos, int max_calls,
                                                    double *__restrict__ reg_calls) {
@@ -4828,15 +4828,15 @@ __global__ __launch_bounds__(256) void k_walk_rows(const Seg *__restrict__ wsegs
     constexpr int STAGED = 5120, COUNTED = 64;
     __shared__ double sv[STAGED];
     __shared__ double s_mid[2];
-    __shared__ int s_nan, s_item, s_rank;
+    __shared__ int s_nan, s_rank;
     const int tid = threadIdx.x;
     const int total = *n_segs_dev < seg_cap ? *n_segs_dev : seg_cap;
-    while (true) {
+    // (workgroup w takes items w, w + gridDim.x, ...: they cost about the same, and a cursor would put one more global
+    //  round trip in front of every item)
+    for (int item = blockIdx.x; item < total; item += gridDim.x) {
         __syncthreads();
-        if (tid == 0) { s_item = atomicAdd(cursor, 1); s_nan = 0; s_rank = 0; }
+        if (tid == 0) { s_nan = 0; s_rank = 0; }
         __syncthreads();
-        const int item = s_item;
-        if (item >= total) break;
         const Seg me = wsegs[item];
         const int region = me.region, nseg = me.pad >> 16, first = item - (me.pad & 0xFFFF);
         const Region rg = regions[region];
@@ -5338,7 +5338,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
                            (int)seg_cap, ts.out_n.as<int>(), work,
                            (tail->per_sample > 1 && n_regions % tail->per_sample == 0) ? tail->per_sample : 0);   // (125 x 50 kb: 287 -> 255 us)
         hipLaunchKernelGGL(k_walk_rows, dim3(768), dim3(256), 0, stream, (const Seg *)ts.seg.as<Seg>(),
-                           (const int *)(counters + 4), counters + 7, (int)seg_cap, regions_dev, tail->ratio, tail->gpos,
+                           (const int *)(counters + 4), (int)seg_cap, regions_dev, tail->ratio, tail->gpos,
                            max_calls, tail->reg_calls);
         ts.mark(11, stream);
         const int64_t bound = seg_cap;
