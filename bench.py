@@ -44,7 +44,8 @@ PEAK_HBM = 8.0e12           # bytes/s, spec (6.3e12 achievable by a copy)
 PEAK_L2 = 34.5e12           # bytes/s aggregate over the 8 XCDs
 PEAK_FP64_VALU_OPS = 39.3e12  # float64 vector add / mul / max per second (78.6 TFLOP/s counts an FMA as two)
 PEAK_MALL = 10.0e12         # bytes/s the Infinity Cache sustains towards the L2s (order of magnitude, MI355X_MICROARCH.md)
-ROUND = "r05"
+ROUND = "r06"
+ROUNDS = ("r06", "r05", "r04", "r03", "r02", "r01")   # committed profile files: the newest that exists
 PIPE_DEPTH = 4        # batches of the batched test in flight (distributed.TestPipeline)
 LATENCY_LAUNCHES = 8        # kernels of one latency-mode `test` call
 
@@ -120,25 +121,34 @@ def build_inputs(binsize, n_ref, n_test, seed0=0, device=0):
     _torch.cuda.synchronize()
     prep_ms = 1e3 * (_time.perf_counter() - _t0)
     masked_bins = np.asarray(masked_bins, dtype=np.int64)
+    tests = make_tests(profile, n_test)
+    return dict(corrected=corrected, chrom_bins=np.asarray(chrom_bins, dtype=np.int64), mask=mask,
+                masked_bins=masked_bins, pca_mean=mean, pca_components=comps, tests=tests, prep_ms=prep_ms)
+
+
+def make_tests(profile, n_test):
+    """n_test converted test samples (seeds 1000 ...); SURVEY.md 8(d): 5 % of them carry a 1-5 % gain / loss.
+    The first m samples of make_tests(profile, n) are make_tests(profile, m)."""
+    import numpy as np
+    from wisecondor_amd import synth
     rng = np.random.RandomState(4242)
     tests = []
     for i in range(n_test):
         events = []
-        if rng.rand() < 0.05:  # 5 % of the test samples carry a 1-5 % gain/loss
+        if rng.rand() < 0.05:
             c = int(rng.randint(1, 23))
             n = len(profile[c - 1])
             a = int(rng.randint(0, max(1, n - n // 4)))
             f = 1.0 + rng.choice([-1, 1]) * rng.uniform(0.01, 0.05)
             events.append((str(c), a, a + n // 4, f))
         tests.append(synth.make_sample(profile, seed=1000 + i, events=events))
-    return dict(corrected=corrected, chrom_bins=np.asarray(chrom_bins, dtype=np.int64), mask=mask,
-                masked_bins=masked_bins, pca_mean=mean, pca_components=comps, tests=tests, prep_ms=prep_ms)
+    return tests
 
 
 def committed_traffic(workload):
     """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/<round>_traffic.json),
     or {} when no such file is there."""
-    for rnd in (ROUND, "r03", "r01"):
+    for rnd in ROUNDS:
         path = os.path.join(ROOT, "profiles", "%s_traffic.json" % rnd)
         if os.path.exists(path):
             t = json.load(open(path)).get(workload)
@@ -153,7 +163,7 @@ def committed_traffic(workload):
 def committed_latency_trace():
     """Kernel durations of one latency-mode replay from the committed rocprofv3 kernel trace
     (profiles/<round>_latency_trace.json, written by tools/refresh_profiles.sh), or None."""
-    for rnd in (ROUND, "r03", "r02"):
+    for rnd in ROUNDS:
         path = os.path.join(ROOT, "profiles", "%s_latency_trace.json" % rnd)
         if os.path.exists(path):
             t = json.load(open(path))
@@ -168,8 +178,13 @@ def committed_gather_roof(n_rows, mode=0):
     (tools/micro/gather_rate.*, 8 B per lane, every XCD gathering from the whole matrix; committed by
     tools/refresh_profiles.sh as profiles/<round>_gather_roof.txt): the figure of the nearest matrix size, or None."""
     import numpy as np
-    path = os.path.join(ROOT, "profiles", "%s_gather_roof.txt" % ROUND)
-    if not os.path.exists(path):
+    path, rnd_found = None, None
+    for rnd in ROUNDS:
+        cand = os.path.join(ROOT, "profiles", "%s_gather_roof.txt" % rnd)
+        if os.path.exists(cand):
+            path, rnd_found = cand, rnd
+            break
+    if path is None:
         return None
     best = None
     for line in open(path):
@@ -180,7 +195,7 @@ def committed_gather_roof(n_rows, mode=0):
                 best = (rows, rate)
     if best is None:
         return None
-    return {"matrix_rows": best[0], "TBps": best[1], "source": "profiles/%s_gather_roof.txt" % ROUND,
+    return {"matrix_rows": best[0], "TBps": best[1], "source": "profiles/%s_gather_roof.txt" % rnd_found,
             "measured_in_this_run": False,
             "what": ("random whole-row gathers of a matrix of this many 1 KB rows by a kernel that does nothing else "
                      "(the matrix misses the 4 MB L2 of an XCD; the guide's 34.5 TB/s is for L2-resident data)") if mode == 0 else
@@ -196,7 +211,7 @@ def hbm_bytes(entry):
 
 
 def committed_busy_file():
-    for rnd in (ROUND, "r03"):
+    for rnd in ROUNDS:
         path = os.path.join(ROOT, "profiles", "%s_pmc_busy.json" % rnd)
         if os.path.exists(path):
             return rnd, json.load(open(path))
@@ -405,7 +420,7 @@ def run_cpu_baseline(inp, binsize, k, idx_gpu, reference_arrays, tb_calls, budge
     rows = int(max(8, min(B, budget_s * 1.0e9 / (float(B) * S))))
     out = cpu_newref_leg(corrected, inp["masked_bins"], k, binsize, idx_gpu, rows)
     out["test"] = cpu_test_leg(inp, binsize, k, reference_arrays, tb_calls)
-    for rnd in (ROUND, "r02"):
+    for rnd in ROUNDS:
         ratio_path = os.path.join(ROOT, "profiles", "%s_oracle_vs_reference.json" % rnd)
         if os.path.exists(ratio_path):      # measured in the development container, where the reference can run
             out["port_vs_reference"] = json.load(open(ratio_path))
@@ -635,6 +650,125 @@ def emulate_world_newref(ctx, X, bins, k, order, world, single_idx, single_dst):
     return out
 
 
+# ------------------------------------------------------------- the one line ----
+LINE_LIMIT = 6000       # bytes: the driver's parser lost a 21 KB line in round 5
+
+
+def _pick(d, *keys):
+    return None if not isinstance(d, dict) else {k_: d.get(k_) for k_ in keys if k_ in d}
+
+
+def _num(x, digits=6):
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None                         # no NaN / Infinity tokens on the line
+        return float("%.*g" % (digits, x))
+    if isinstance(x, dict):
+        return {k_: _num(v, digits) for k_, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_num(v, digits) for v in x]
+    return x
+
+
+def compact_line(d):
+    """The line the driver parses: the contract's keys, `roofline` and `cpu_baseline` as flat objects of scalars,
+    a handful of the other legs' headline scalars.  Everything else stays in the detail record."""
+    roof = dict(d.get("roofline") or {})
+    name = str(roof.get("kernel", ""))
+    short = "k_rescore" if name.startswith("float64 re-score") else (name.split(" ")[0] if name else None)
+    r = {"kernel": short}
+    for k_ in ("kernel_ms", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+               "algorithmic_flop_per_launch", "gathered_bytes_per_launch", "frac_of_measured_gather_roof",
+               "frac_algorithmic_vs_fp32_mfma"):
+        if k_ in roof:
+            r[k_] = roof[k_]
+    other = d.get("roofline_other") or {}
+    oname = str(other.get("kernel", ""))
+    r["other"] = {"kernel": "k_rescore" if oname.startswith("float64 re-score") else (oname.split(" ")[0] or None),
+                  "kernel_ms": other.get("kernel_ms"), "bound": other.get("bound"), "frac": other.get("frac")} if other else None
+    cpu = d.get("cpu_baseline")
+    c = None
+    if isinstance(cpu, dict):
+        c = _pick(cpu, "value", "unit", "cores", "cpu_model", "kind", "sample", "matches_gpu_indices", "error")
+        if isinstance(cpu.get("all_cores"), dict):
+            c["all_cores"] = _pick(cpu["all_cores"], "value", "cores")
+        if isinstance(cpu.get("test"), dict):
+            c["test"] = _pick(cpu["test"], "value", "unit", "cores", "matches_gpu_calls")
+    t = d.get("test") or {}
+    wj = t.get("whole_job_1000_samples") or {}
+    test = {"value": t.get("value"), "unit": "samples/s", "ms_per_batch": t.get("ms_per_batch"),
+            "samples_per_gpu": t.get("samples_per_gpu"), "pipelined_value": (t.get("pipelined") or {}).get("value"),
+            "latency_ms_per_call": t.get("single_sample_latency_ms"),
+            "whole_job_1000_samples": _pick(wj, "ms_per_call", "samples_per_s", "distinct_samples", "error"),
+            "roofline_frac": (t.get("roofline") or {}).get("frac"), "roofline_bound": (t.get("roofline") or {}).get("bound"),
+            "calls_found": t.get("calls_found")}
+    ex = d.get("extra")
+    extra = None
+    if isinstance(ex, dict):
+        extra = _pick(ex, "ms_per_step", "value", "shard_mode", "k_gram_ms", "k_gram_frac_of_mfma_peak", "rescore_ms", "error")
+        rr = ex.get("rescore_roofline")
+        if isinstance(rr, dict):
+            extra["rescore_frac_of_hbm"] = rr.get("frac")
+        em = ex.get("emulated_world_8")
+        if isinstance(em, dict) and "error" not in em:
+            extra["emulated_world_8_projection"] = {m: _pick(em.get(m) or {}, "max_rank_ms", "imbalance_max_over_mean",
+                                                             "projected_step_ms_overlapped", "results_equal_single_rank")
+                                                    for m in ("tiles", "rows") if m in em}
+        t5 = ex.get("test_50kb")
+        if isinstance(t5, dict):
+            w5 = t5.get("whole_job_1000_samples") or {}
+            extra["test_50kb"] = {"ms_per_batch": t5.get("ms_per_batch"), "value": t5.get("value"),
+                                  "pipelined_value": (t5.get("pipelined") or {}).get("value"),
+                                  "whole_job_1000_samples": _pick(w5, "ms_per_call", "samples_per_s"),
+                                  "cpu_baseline_value": (t5.get("cpu_baseline") or {}).get("value"),
+                                  "error": t5.get("error")}
+        if isinstance(ex.get("cpu_baseline"), dict):
+            extra["cpu_baseline"] = _pick(ex["cpu_baseline"], "value", "cores", "matches_gpu_indices", "error")
+        if isinstance(ex.get("ingest"), dict):
+            extra["ingest_files_per_s"] = ex["ingest"].get("files_per_s")
+    mr = d.get("multi_rank")
+    multi = None
+    if isinstance(mr, dict) and mr.get("per_rank"):
+        multi = {"row_bands_per_rank": mr.get("row_bands_per_rank"),
+                 "stage_ms_sum_per_rank": [sum((e or {}).get("stages_ms", {}).values()) for e in mr["per_rank"]],
+                 "collective_ms_sum_per_rank": [sum(c_["ms"] for c_ in (e or {}).get("collectives", [])) for e in mr["per_rank"]],
+                 "collective_bytes_rank0": [[c_["name"], c_["bytes"]] for c_ in (mr["per_rank"][0] or {}).get("collectives", [])][:8]}
+    cfg = d.get("config") or {}
+    line = {k_: d.get(k_) for k_ in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                      "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = _pick(cfg, "workload", "parallelism", "world_size", "shard_mode")
+    line["roofline"] = r
+    line["cpu_baseline"] = c
+    line["test"] = test
+    line["extra"] = extra
+    line["stages_ms"] = d.get("stages_ms")
+    line["multi_rank"] = multi
+    line["prep_ms"] = (d.get("prep") or {}).get("ms")
+    line["detail"] = d.get("detail_file")
+    return _num(line)
+
+
+def emit(detail, path):
+    """Write the full record to `path` (when it can be written), print the compact line LAST."""
+    try:
+        with open(path, "w") as fh:
+            json.dump(detail, fh, indent=1)
+        detail["detail_file"] = os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+    except Exception as exc:
+        detail["detail_file"] = "not written: %s" % exc
+    line = json.dumps(compact_line(detail), allow_nan=False, separators=(",", ":"))
+    if len(line) > LINE_LIMIT:          # never again an unparseable line: drop the optional objects, largest first
+        slim = compact_line(detail)
+        for k_ in ("multi_rank", "stages_ms", "extra", "test"):
+            slim[k_] = None
+            line = json.dumps(slim, allow_nan=False, separators=(",", ":"))
+            if len(line) <= LINE_LIMIT:
+                break
+    sys.stdout.flush()
+    print(line)
+    sys.stdout.flush()
+
+
 # --------------------------------------------------------------------- main ----
 def main():
     ap = argparse.ArgumentParser()
@@ -648,6 +782,9 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the extra 600 x 50 kb newref measurement")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
                     "functional tests of the multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="where the full measurement record goes (stage tables, per-rank lists, emulated world, "
+                         "every roofline object); the LAST stdout line is a compact summary of it")
     ap.add_argument("--launch-check", action="store_true",
                     help="only start the ranks, rendezvous (gloo) and report the world size: no GPU work")
     args = ap.parse_args()
@@ -843,8 +980,10 @@ def main():
     whole_job = None
     if world == 1 and not args.no_extra:
         try:
-            reps = (1000 + counts_h.shape[0] - 1) // counts_h.shape[0]
-            big = torch.from_numpy(np.tile(counts_h, (reps, 1))[:1000].copy()).to(dev)
+            from wisecondor_amd import synth as _synth
+            big_h = wt.samples_to_counts(make_tests(_synth.bin_profile(binsize), 1000), inp["chrom_bins"])
+            assert np.array_equal(big_h[:counts_h.shape[0]], counts_h)       # the batch's samples lead the cohort
+            big = torch.from_numpy(big_h).to(dev)
             tbw = distributed.TestBatch(reference, big, thr, max_calls=256)
             for _ in range(2):
                 tbw.run()
@@ -854,9 +993,9 @@ def main():
                 tbw.run()
             torch.cuda.synchronize()
             tw = (time.perf_counter() - t0) / 3
-            whole_job = {"what": "1000 samples x %d kb in one wc_test_batch_dev call (the batch's %d samples repeated)"
-                                 % (binsize // 1000, counts_h.shape[0]),
-                         "samples": 1000, "ms_per_call": 1e3 * tw, "samples_per_s": 1000 / tw}
+            whole_job = {"what": "1000 DISTINCT samples x %d kb in one wc_test_batch_dev call" % (binsize // 1000),
+                         "samples": 1000, "distinct_samples": True, "ms_per_call": 1e3 * tw, "samples_per_s": 1000 / tw,
+                         "calls_found": int(tbw.n_calls.sum().item())}
             del tbw, big
         except Exception as exc:
             whole_job = {"error": "%s: %s" % (type(exc).__name__, exc)}
@@ -1223,7 +1362,7 @@ def main():
             "extra": extra,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        emit(out, args.detail)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

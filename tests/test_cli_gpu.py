@@ -188,61 +188,89 @@ def test_newref_on_two_ranks_equals_one(tmp_path, golden, monkeypatch):
         assert np.array_equal(np.asarray(y["results_calls"]).reshape(-1, 5)[:, :3], want[:, :3])
 
 
-def test_bench_two_ranks_on_one_gpu():
-    """bench.py --gpus 2 starts two ranks itself; with the gloo backend they share the one GPU.
-    The JSON line must carry the world size it really ran with and the measured shard mode."""
+def _strict_json(text):
+    """json.loads that refuses the NaN / Infinity tokens Python's encoder would happily write."""
+    import json
+
+    def refuse(token):
+        raise ValueError("non-standard JSON token %s" % token)
+    return json.loads(text, parse_constant=refuse)
+
+
+def _run_bench(tmp_path, argv, timeout):
+    """bench.py as the driver runs it: the LAST stdout line is the record the driver parses (compact: it lost a
+    21 KB line in round 5), the full record goes to the --detail file.  Returns (line, detail)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--no-extra", "--workload",
-                        "cfg1", "--steps", "2", "--warmup", "1", "--test-samples", "32", "--no-cpu-baseline"],
-                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    detail_path = os.path.join(str(tmp_path), "bench_detail.json")
+    p = subprocess.run([sys.executable, "bench.py"] + argv + ["--detail", detail_path], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, p.stderr[-2000:]
-    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    last = p.stdout.rstrip("\n").splitlines()[-1]
+    assert last.startswith("{") and len(last) < 8000, (len(last), last[:200])
+    line = _strict_json(last)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert set(line["config"]) >= {"workload", "parallelism", "world_size", "shard_mode"}
+    assert set(line["roofline"]) >= {"kernel", "kernel_ms", "bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert line["detail"] and "not written" not in line["detail"]
+    detail = json.load(open(detail_path))
+    assert detail["value"] == pytest.approx(line["value"], rel=1e-4) and detail["ms_per_step"] == pytest.approx(line["ms_per_step"], rel=1e-4)
+    return line, detail
+
+
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """bench.py --gpus 2 starts two ranks itself; with the gloo backend they share the one GPU.
+    The JSON line must carry the world size it really ran with and the measured shard mode; every rank's
+    stage times and collectives are in the detail record, their sums on the line."""
+    line, detail = _run_bench(tmp_path, ["--gpus", "2", "--backend", "gloo", "--no-extra", "--workload", "cfg1", "--steps",
+                                         "2", "--warmup", "1", "--test-samples", "32", "--no-cpu-baseline"], 900)
     assert line["n_gpus"] == 2 and line["config"]["world_size"] == 2
     assert line["config"]["shard_mode"] in ("tiles", "rows")
-    mr = line["multi_rank"]                         # every rank's stage times and collectives on the one line
+    assert len(line["multi_rank"]["stage_ms_sum_per_rank"]) == 2 and len(line["multi_rank"]["collective_ms_sum_per_rank"]) == 2
+    assert all(v > 0 for v in line["multi_rank"]["stage_ms_sum_per_rank"])
+    assert len(line["multi_rank"]["collective_bytes_rank0"]) >= 1
+    mr = detail["multi_rank"]
     assert len(mr["per_rank"]) == 2 and mr["row_bands_per_rank"] >= 1
     for entry in mr["per_rank"]:
         assert entry["stages_ms"]["collected"] > 0 and len(entry["collectives"]) >= 1
         assert all(c["bytes"] > 0 and c["ms"] >= 0 for c in entry["collectives"])
-    assert set(line["config"]["shard_calibration_s"]) == {"tiles", "rows"}
+    assert set(detail["config"]["shard_calibration_s"]) == {"tiles", "rows"}
     assert line["value"] > 0 and line["test"]["value"] > 0
 
 
-def test_bench_eight_ranks_on_one_gpu():
+def test_bench_eight_ranks_on_one_gpu(tmp_path):
     """bench.py --gpus 8 (the driver's scaling run) with the ranks sharing the one GPU over gloo: the launcher
     starts eight ranks, the shard mode is measured on them, and the line says so."""
-    import json
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    p = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--backend", "gloo", "--no-extra", "--workload",
-                        "cfg1", "--steps", "2", "--warmup", "1", "--test-samples", "32", "--no-cpu-baseline"],
-                       cwd=root, env=env, capture_output=True, text=True, timeout=1500)
-    assert p.returncode == 0, p.stderr[-2000:]
-    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    line, detail = _run_bench(tmp_path, ["--gpus", "8", "--backend", "gloo", "--no-extra", "--workload", "cfg1", "--steps",
+                                         "2", "--warmup", "1", "--test-samples", "32", "--no-cpu-baseline"], 1500)
     assert line["n_gpus"] == 8 and line["config"]["world_size"] == 8
     assert line["config"]["shard_mode"] in ("tiles", "rows")
-    assert set(line["config"]["shard_calibration_s"]) == {"tiles", "rows"}
+    assert len(line["multi_rank"]["stage_ms_sum_per_rank"]) == 8
+    assert set(detail["config"]["shard_calibration_s"]) == {"tiles", "rows"}
     assert line["value"] > 0 and line["test"]["value"] > 0
 
 
-def test_bench_line_is_complete_on_one_gpu():
-    """The default bench command in a short form (cfg2, the 600 x 50 kb extra, no CPU leg): one JSON line
-    with every object the measurement contract names, every fraction at most 1, no swallowed error."""
-    import json
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    p = subprocess.run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--test-samples", "32",
-                        "--no-cpu-baseline"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0, p.stderr[-2000:]
-    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+def test_bench_line_is_complete_on_one_gpu(tmp_path):
+    """The default bench command in a short form (cfg2, the 600 x 50 kb extra, no CPU leg): ONE compact last
+    line (< 8 000 bytes, strict JSON) with the contract's keys, and a detail record with every object the
+    measurement contract names, every fraction at most 1, no swallowed error."""
+    short, line = _run_bench(tmp_path, ["--steps", "4", "--warmup", "1", "--test-samples", "32", "--no-cpu-baseline"], 900)
+    assert short["n_gpus"] == 1 and short["steps"] == 4 and short["warmup"] == 1
+    assert short["metric"] == "newref bin-pair distances/sec" and short["value"] > 1e10
+    assert short["roofline"]["kernel"] in ("k_rescore", "k_gram_glds") and 0 < short["roofline"]["frac"] <= 1.0
+    assert short["roofline"]["kernel_ms"] > 0 and short["roofline"]["bound"] in ("hbm", "mfma", "l2")
+    assert short["test"]["value"] > 0 and short["test"]["ms_per_batch"] > 0 and short["test"]["latency_ms_per_call"] > 0
+    assert short["test"]["whole_job_1000_samples"]["ms_per_call"] > 0
+    assert short["test"]["whole_job_1000_samples"]["distinct_samples"] is True
+    assert short["extra"]["ms_per_step"] > 0 and short["extra"]["test_50kb"]["ms_per_batch"] > 0
+    assert short["extra"]["test_50kb"]["whole_job_1000_samples"]["ms_per_call"] > 0
+    assert short["extra"]["emulated_world_8_projection"]["tiles"]["results_equal_single_rank"] is True
+    assert short["cpu_baseline"] is None                        # --no-cpu-baseline
     assert line["n_gpus"] == 1 and line["steps"] == 4 and line["warmup"] == 1
     assert line["metric"] == "newref bin-pair distances/sec" and line["value"] > 1e10
     for roof in (line["roofline"], line["roofline_other"]):

@@ -21,15 +21,37 @@ def _free_port():
     return port
 
 
-def _spawn(fn, args_of_port, nprocs):
-    """mp.spawn with ONE more try on a fresh port when the process group does not come up (eight
-    interpreters importing torch on a busy box, or the port taken between the probe and the rendezvous:
-    seen once in ~40 runs of the suite); what the workers compute is asserted by the caller either way."""
+RENDEZVOUS_FAILED = "RENDEZVOUS_FAILED"
+
+
+def _init_group(dist, rank, world, port):
+    """The gloo process group of a worker.  ONLY a failure in here (the store's port taken between the probe and the
+    bind, a peer that did not connect in time on a busy box) is marked as retryable: the marker is what _spawn looks for."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    except Exception as exc:
+        raise RuntimeError("%s rank %d of %d on port %d: %s: %s" % (RENDEZVOUS_FAILED, rank, world, port,
+                                                                     type(exc).__name__, exc)) from exc
+
+
+def _spawn(fn, args_of_port, nprocs, log_dir=None):
+    """mp.spawn; ONE more try on a fresh port if -- and only if -- the process group did not come up (the marker of
+    _init_group in the failure text).  Anything a worker raises after the rendezvous (an assertion, a HIP error, a
+    collective that fails) fails the test at once.  The first failure's full text is printed and kept in log_dir."""
     import torch.multiprocessing as mp
     try:
         mp.spawn(fn, args=args_of_port(_free_port()), nprocs=nprocs, join=True)
-    except Exception as exc:                      # noqa: BLE001 -- any worker failure: once more, then it counts
-        print("spawn failed once (%s: %s); retrying" % (type(exc).__name__, str(exc)[:300]))
+    except Exception as exc:
+        text = "%s: %s" % (type(exc).__name__, exc)
+        print("spawn failed:\n" + text)
+        if log_dir is not None:
+            with open(os.path.join(str(log_dir), "first_spawn_failure.txt"), "w") as fh:
+                fh.write(text)
+        if RENDEZVOUS_FAILED not in text:
+            raise
+        print("the process group did not come up; one retry on a fresh port")
         mp.spawn(fn, args=args_of_port(_free_port()), nprocs=nprocs, join=True)
 
 
@@ -38,9 +60,7 @@ def _worker(rank, world, port, path_in, out_dir, mode):
     import torch.distributed as dist
     from wisecondor_amd import _lib
     from wisecondor_amd.distributed import NewrefJob
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _init_group(dist, rank, world, port)
     try:
         z = np.load(path_in)
         X = torch.from_numpy(np.ascontiguousarray(z["data"])).cuda()
@@ -68,7 +88,7 @@ def test_hip_multi_rank_on_one_gpu(tmp_path, world, order, mode):
     path_in = str(tmp_path / "in.npz")
     np.savez(path_in, data=data, bins=bins, k=k, order=order)
     mp.get_context("spawn")
-    _spawn(_worker, lambda port: (world, port, path_in, str(tmp_path), mode), world)
+    _spawn(_worker, lambda port: (world, port, path_in, str(tmp_path), mode), world, tmp_path)
     src = data if order == 0 else np.asfortranarray(data)
     with np.errstate(all="ignore"):
         want_i, want_d = wo.get_reference(src, bins, sums, k, 1, 1, fast=True)
@@ -93,7 +113,7 @@ def test_hip_multi_rank_ragged_layout(tmp_path, world, mode):
     path_in = str(tmp_path / "in.npz")
     np.savez(path_in, data=data, bins=bins, k=k, order=1)
     mp.get_context("spawn")
-    _spawn(_worker, lambda port: (world, port, path_in, str(tmp_path), mode), world)
+    _spawn(_worker, lambda port: (world, port, path_in, str(tmp_path), mode), world, tmp_path)
     with np.errstate(all="ignore"):
         want_i, want_d = wo.get_reference(np.asfortranarray(data), bins, np.cumsum(bins), k, 1, 1, fast=True)
     for r in range(world):
@@ -109,11 +129,9 @@ def _worker8(rank, world, port, path_in, out_dir, mode, xcap):
     from wisecondor_amd import _lib
     from wisecondor_amd import wisetools as wt
     from wisecondor_amd.distributed import NewrefJob
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
     if xcap:
         os.environ["WC_EXCHANGE_CAP"] = str(xcap)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _init_group(dist, rank, world, port)
     try:
         z = np.load(path_in)
         X = torch.from_numpy(np.ascontiguousarray(z["data"])).cuda()
@@ -156,7 +174,7 @@ def test_eight_ranks_on_one_gpu(tmp_path, mode, xcap):
     path_in = str(tmp_path / "in.npz")
     np.savez(path_in, data=data, bins=bins, k=k, order=order)
     mp.get_context("spawn")
-    _spawn(_worker8, lambda port: (8, port, path_in, str(tmp_path), mode, xcap), 8)
+    _spawn(_worker8, lambda port: (8, port, path_in, str(tmp_path), mode, xcap), 8, tmp_path)
     one = NewrefJob(_lib.context(0), torch.from_numpy(data).cuda(), bins, k, order)
     idx1, dst1 = one.run()
     torch.cuda.synchronize()

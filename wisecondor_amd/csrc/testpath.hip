@@ -2890,6 +2890,8 @@ struct CellShared {
     CellRec rec[2][CJ_REC];
     int n_rec[2];
     int n_q2, n_q1, n_l1, n_items, slot, last;
+    int lost;                                   // MODE 0: a cell queue overflowed, loud cells were dropped: the extremes are NOT
+                                                // proven -- k_seg_job / k_seg_walk hand the job to a path that needs no bound
 };
 
 // the job's geometry in relative indexes (origin: the start of the 128-block that holds the job's first prefix entry)
@@ -3069,7 +3071,9 @@ __device__ inline void cell_search(CellShared &sh, const CellGeom g, const doubl
     __syncthreads();
     cuts();
     // ---- far windows: cells.  What reaches the cut is queued: 128 x 128 cells and the 32 x 32 cells of the band
-    // between them and the near windows (a part owns a few hundred of each at most: the queues cannot overflow).
+    // between them and the near windows.  A part of cell_parts(L) owns a few hundred of each at most; ONE workgroup with
+    // a whole CJ_MAXLEN job (k_seg_walk, k_seg_job with max_parts = 1) owns ~2 000 and ~1 150: a queue that overflows
+    // sets sh.lost and the caller drops the result of this search.
     auto loud1 = [&](const int A, const int K) {
         const int minlen = ((K - A - 1) << 5) + 1;
         const double r = rs_above(minlen);
@@ -3152,6 +3156,7 @@ __device__ inline void cell_search(CellShared &sh, const CellGeom g, const doubl
         // (the second pass walks the whole job in one workgroup: should a queue overflow there -- only under massive
         // ties -- the record is marked overflowing, which sends the job to the exact scan)
         if (MODE == 2 && tid == 0 && (sh.n_q2 > CJ_Q2 || sh.n_q1 > CJ_Q1)) sh.n_rec[0] = CJ_REC + 1;
+        if (MODE == 0 && tid == 0 && (sh.n_q2 > CJ_Q2 || sh.n_q1 > CJ_Q1)) sh.lost = 1;     // (read after the next barrier)
         const int n2 = sh.n_q2 < CJ_Q2 ? sh.n_q2 : CJ_Q2, n1 = sh.n_q1 < CJ_Q1 ? sh.n_q1 : CJ_Q1;
         for (int c2 = 0; c2 < n2; c2 += 16) {
             __syncthreads();
@@ -3194,7 +3199,7 @@ __device__ inline CellGeom cell_setup(CellShared &sh, const Job job, const Regio
     for (int i = tid; i < n1; i += 256) { sh.tmx[i] = tmax[k1 + i]; sh.tmn[i] = tmin[k1 + i]; }
     for (int i = tid; i < n2; i += 256) { sh.tmx2[i] = tmax2[k2 + i]; sh.tmn2[i] = tmin2[k2 + i]; }
     if (tid < 64) sh.rsn[tid] = rs[tid];
-    if (tid == 0) { sh.n_rec[0] = 0; sh.n_rec[1] = 0; }
+    if (tid == 0) { sh.n_rec[0] = 0; sh.n_rec[1] = 0; sh.lost = 0; }
     __syncthreads();
     // The tables are aligned to the concatenated array: the job's first and last block of either level also cover
     // entries of its neighbours (another region's prefix sums: a jump).  Their extremes over the job's own
@@ -3294,6 +3299,7 @@ __global__ __launch_bounds__(256) void k_seg_job(const Job *__restrict__ jobs, i
         atomicMax(&js->ext[0], wc::f64_ordered(vmax));
         atomicMax(&js->ext[1], wc::f64_ordered(-vmin));
         if (sh.n_rec[0] > CJ_REC || sh.n_rec[1] > CJ_REC) atomicOr(&js->overflow, 1);
+        if (sh.lost) atomicOr(&js->overflow, 2);             // dropped cells: k_seg_merge sends the job to the exact scan
     }
     for (int side = 0; side < 2; ++side) {
         const int n = sh.n_rec[side] < CJ_REC ? sh.n_rec[side] : CJ_REC;
@@ -3354,6 +3360,10 @@ __global__ __launch_bounds__(256) void k_seg_merge(const Job *__restrict__ jobs,
         return;
     }
     const CellJobState js = state[j];
+    if (js.overflow & 2) {                        // a part dropped loud cells: its extremes prove nothing -- the exact scan
+        if (tid == 0) brute[atomicAdd(&counters[3], 1)] = j;
+        return;
+    }
     const double vmax = wc::f64_from_ordered(js.ext[0]), vmin = -wc::f64_from_ordered(js.ext[1]);
     const Region rg = regions[job.region];
     const double eps = window_eps(rg.n, reg_abs[job.region]);
@@ -4719,6 +4729,10 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
         double vmax = -INFINITY, vmin = INFINITY, d2 = -INFINITY, d3 = INFINITY;
         cell_search<0>(sh, g, rs, eps2, INFINITY, -INFINITY, nullptr, 0, 1, vmax, vmin, wins, evals, tid);
         block_minmax4(vmax, vmin, d2, d3, tid);
+        if (sh.lost) {                              // a cell queue overflowed: the general path (its overflow leads to the exact scan)
+            if (tid == 0) { atomicOr(&counters[6], 32); s_stop = 1; }
+            continue;
+        }
         if (fmax(fabs(vmax), fabs(vmin)) + eps < thr) continue;              // no call in this range (k_seg_classify's test)
         // the windows within 2 eps of the extremes, only for a side that can hold a call
         const double hi_cut = !(vmax + eps < thr) ? vmax - eps2 : INFINITY;
@@ -4812,8 +4826,8 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
 
 // The call rows of k_seg_walk's segments: position order, genomic start / end, value, effect = median of the
 // segment's ratios - 1 (np.median; wisecondor.py:233-257) -- k_call_post's work.  A few hundred resident workgroups
-// take the segments of the batch's list one after the other through a cursor (counters[7]; a workgroup per region or
-// per possible segment would mostly be workgroups with nothing to do, and each of them still has to be given its LDS).
+// take the segments of the batch's list with a static stride (workgroup w: items w, w + gridDim.x, ...; a workgroup per
+// region or per possible segment would mostly be workgroups with nothing to do, and each still has to be given its LDS).
 // A kernel of its own: as the tail of k_seg_walk the radix selection returned wrong medians for about one row in a
 // thousand, differently from run to run (the selection alone, tools/micro/select_test.hip, is clean), see
 // EXPERIMENTS.md.
@@ -4841,7 +4855,9 @@ __global__ __launch_bounds__(256) void k_walk_rows(const Seg *__restrict__ wsegs
         const int region = me.region, nseg = me.pad >> 16, first = item - (me.pad & 0xFFFF);
         const Region rg = regions[region];
         const int x = me.x, y = me.y, Ls = y - x + 1;
-        if (tid < nseg && wsegs[first + tid].x < x) atomicAdd(&s_rank, 1);       // (nseg <= TREE_SEGS = 128)
+        // (nseg <= TREE_SEGS = 128; a region whose segments were cut off by seg_cap is not read past the stored ones:
+        //  the caller sees counters[4] > seg_cap and repeats the batch with a larger list)
+        if (tid < nseg && first + tid < total && wsegs[first + tid].x < x) atomicAdd(&s_rank, 1);
         const double *rr = ratio + rg.off + x;
         const bool staged = Ls <= STAGED;
         for (int e0 = tid; e0 < Ls; e0 += 8 * 256) {           // eight loads in flight per thread and trip
@@ -4947,6 +4963,15 @@ void launch_transpose(const double *in, int64_t R, int64_t C, double *out, hipSt
     hipLaunchKernelGGL(k_transpose, g, dim3(32, 8), 0, stream, in, R, C, out, out2, zero, n_zero);
 }
 
+// The bin-major working arrays of the repeats, [B, Ns] + one more row (xc's row B holds -1.0, see k_zscore_tiled).  ONE
+// place sizes them: the batch body calls this BEFORE its prepare kernels write xt / xc, run_repeat again (a no-op then).
+static int reserve_repeat_arrays(TestState &ts, int64_t n, int64_t Ns) {
+    int rc;
+    for (wc::DevBuf *b : {&ts.xt, &ts.xc, &ts.zt, &ts.rt, &ts.nt, &ts.sdt})
+        if ((rc = b->reserve(sizeof(double) * (n + Ns)))) return rc;
+    return ts.sd_avg.reserve(sizeof(double) * Ns);
+}
+
 // repeatTest on device data [Ns, B]; leaves zt/rt/nt/sdt as [B, Ns] and sd_avg[Ns]
 // lat: latency mode -- k_lat_prepare has already written xt / xc and cleared the counters; the first
 // repeat runs as usual, repeats 2.. in one launch (k_lat_repeats; its overflow flag is pair_counts[repeats + 1])
@@ -4955,9 +4980,12 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
     TestState &ts = ctx->ts;
     const int64_t n = ref->B * Ns;
     int rc;
-    for (wc::DevBuf *b : {&ts.xt, &ts.xc, &ts.zt, &ts.rt, &ts.nt, &ts.sdt})
-        if ((rc = b->reserve(sizeof(double) * (n + Ns)))) return rc;       // (+ one row: xc's row B, see k_zscore_tiled)
-    if ((rc = ts.sd_avg.reserve(sizeof(double) * Ns))) return rc;
+    // a caller whose prepare kernel has ALREADY written xt / xc must have sized them with reserve_repeat_arrays: a
+    // reserve that grows a buffer frees it (DevBuf keeps no contents) and the z-scores would read fresh memory
+    if (lat || xt_ready)
+        WC_CHECK(ts.xt.bytes >= sizeof(double) * (size_t)(n + Ns) && ts.xc.bytes >= sizeof(double) * (size_t)(n + Ns),
+                 WC_E_INTERNAL, "repeatTest: the prepared arrays are smaller than the repeats need");
+    if ((rc = reserve_repeat_arrays(ts, n, Ns))) return rc;
     WC_CHECK(n < (1ll << 32), WC_E_LIMIT, "repeatTest: more than 2^32 (bin, sample) pairs per call");
     // xt = data^T, xc = its working copy (flags go in there); in the same launch the repeats'
     // pair counts and the `dirty` bitmap (one bit per pair: queued for the next repeat) are cleared
@@ -6003,8 +6031,7 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
         if ((rc = ts.totals.reserve(sizeof(double) * Ns))) return rc;
         if ((rc = ts.raw.reserve(sizeof(double) * n))) return rc;
         if ((rc = ts.data.reserve(sizeof(double) * n))) return rc;
-        if ((rc = ts.xt.reserve(sizeof(double) * n))) return rc;
-        if ((rc = ts.xc.reserve(sizeof(double) * (n + Np)))) return rc;
+        if ((rc = reserve_repeat_arrays(ts, n, Np))) return rc;
         if ((rc = ts.misc2.reserve(sizeof(int) * (repeats + 2 + n_words)))) return rc;
         if ((rc = ts.proj.reserve(sizeof(double) * Ns * MAX_COMP * PROJ_SPLIT))) return rc;
         hipLaunchKernelGGL(k_lat_project, dim3((unsigned)Ns, PROJ_SPLIT), dim3(256), 0, stream, counts, ref->Btot,
@@ -6022,8 +6049,7 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
         const int64_t n = B * Np, n_words = cdiv(n, 32);
         if ((rc = ts.totals.reserve(sizeof(long long) * Ns * TOT_SPLIT))) return rc;
         if ((rc = ts.proj.reserve(sizeof(double) * Ns * MAX_COMP * PROJ_SPLIT))) return rc;
-        if ((rc = ts.xt.reserve(sizeof(double) * n))) return rc;
-        if ((rc = ts.xc.reserve(sizeof(double) * (n + Np)))) return rc;
+        if ((rc = reserve_repeat_arrays(ts, n, Np))) return rc;
         if ((rc = ts.misc2.reserve(sizeof(int) * (repeats + 2 + n_words)))) return rc;
         hipLaunchKernelGGL(k_sample_totals, dim3((unsigned)Ns, TOT_SPLIT), dim3(256), 0, stream, counts, ref->Btot,
                            ts.totals.as<long long>());
