@@ -12,6 +12,26 @@
 
 #include "../../include/wisecondor_hip.h"
 
+// The workgroup barrier of every kernel here: __syncthreads() with the wait of its release half spelled out.
+// A barrier only orders LDS traffic if every wave's own DS operations have COMPLETED when it arrives (s_waitcnt
+// lgkmcnt(0) in front of s_barrier); the compiler normally derives that wait from the fence inside __syncthreads(),
+// but at the head of k_seg_walk's loop (ROCm 7.2, -O1 and -O3 alike) the listing shows a bare `s_barrier` behind back
+// edges that carry thread 0's ds_write of the stack pointer: the other waves could read the OLD pointer after the
+// barrier, take a different job and fall out of step with the workgroup's barriers for the rest of the kernel --
+// round 5's "wrong medians in one region of 14 000, differently from run to run" (EXPERIMENTS.md, round 6;
+// tools/barrier_scan.py checks every listing, tests/test_isa_cpu.py runs it).  The explicit wait costs one issue slot
+// where the counter is already zero.  0xC07F = vmcnt(63) expcnt(7) lgkmcnt(0): global loads stay in flight across it.
+#if defined(__HIPCC__)
+__device__ __forceinline__ void wc_sync() {
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __syncthreads();
+}
+__device__ __forceinline__ int wc_sync_or(int predicate) {
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    return __syncthreads_or(predicate);
+}
+#endif
+
 namespace wc {
 
 void set_error(const char *fmt, ...);

@@ -50,9 +50,9 @@ __device__ inline double wave_sum(double v) {
 // Sum over the 256 threads of a workgroup, the same order everywhere.  `red` holds 4 doubles.
 __device__ inline double block_sum256(double v, double *red) {
     v = wave_sum(v);
-    __syncthreads();
+    wc_sync();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
+    wc_sync();
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void k_eig_absmax(const double *__restrict__ M
         m = (other > m || other != other) ? other : m;
     }
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
+    wc_sync();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; ++w) m = (red[w] > m || red[w] != red[w]) ? red[w] : m;
         part[blockIdx.x] = m;
@@ -98,7 +98,7 @@ __device__ inline void previous_reflector(const double *__restrict__ V, const do
     const int tid = threadIdx.x;
     if (k == 0) {
         for (int j = tid; j < n; j += 256) { vp[j] = 0.0; wp[j] = 0.0; }
-        __syncthreads();
+        wc_sync();
         return;
     }
     const double tp = tau[k - 1];
@@ -114,7 +114,7 @@ __device__ inline void previous_reflector(const double *__restrict__ V, const do
     }
     const double K = 0.5 * tp * block_sum256(acc, red);
     for (int j = tid; j < n; j += 256) wp[j] = wp[j] - K * vp[j];
-    __syncthreads();
+    wc_sync();
 }
 
 // One column of the tridiagonalisation.  A is the full symmetric matrix (row k serves as column k),
@@ -148,9 +148,9 @@ __global__ __launch_bounds__(256) void k_tri_step(double *__restrict__ A, double
         v0 = x0 - alpha;
         t = 2.0 / ((ss - x0 * x0) + v0 * v0);
     }
-    __syncthreads();
+    wc_sync();
     if (tid == 0) vc[k + 1] = v0;
-    __syncthreads();
+    wc_sync();
     if (blockIdx.x == 0) {
         double *vrow = V + (size_t)k * n;
         for (int j = tid; j < n; j += 256) vrow[j] = vc[j];
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void k_tri_step_reg(double *__restrict__ A, do
         pj[q] = pj[q] - K * vj[q];          // now w
         if (j < n) { vp[j] = vj[q]; wp[j] = pj[q]; }
     }
-    __syncthreads();
+    wc_sync();
     // row k with the pending update applied: the new column
     const double vpk = vp[k], wpk = wp[k];
     double ss = 0.0;
@@ -242,9 +242,9 @@ __global__ __launch_bounds__(256) void k_tri_step_reg(double *__restrict__ A, do
         v0 = x0 - alpha;
         t = 2.0 / ((ss - x0 * x0) + v0 * v0);
     }
-    __syncthreads();
+    wc_sync();
     if (tid == 0) vc[k + 1] = v0;
-    __syncthreads();
+    wc_sync();
     if (blockIdx.x == 0) {
         double *vrow = V + (size_t)k * n;
         for (int j = tid; j < n; j += 256) vrow[j] = vc[j];
@@ -293,9 +293,9 @@ constexpr int TAIL_MAX = 128, TAIL_LD = TAIL_MAX + 1, TAIL_THREADS = 1024;
 
 __device__ inline double block_sum1024(double v, double *red) {
     v = wave_sum(v);
-    __syncthreads();
+    wc_sync();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
+    wc_sync();
     double s = 0.0;
 #pragma unroll
     for (int w = 0; w < TAIL_THREADS / 64; ++w) s += red[w];
@@ -322,13 +322,13 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tri_tail(const double *__restr
         const double tp = k0 > 0 ? tau[k0 - 1] : 0.0;
         const double K = 0.5 * tp * block_sum1024(pp * vv, red);
         if (tid < TAIL_MAX) { v[tid] = vv; w[tid] = pp - K * vv; }
-        __syncthreads();
+        wc_sync();
     }
     for (int idx = tid; idx < mt * mt; idx += TAIL_THREADS) {
         const int r = idx / mt, c = idx - r * mt;
         M[r * TAIL_LD + c] = A[(size_t)(k0 + r) * n + k0 + c] - (v[r] * w[c] + w[r] * v[c]);
     }
-    __syncthreads();
+    wc_sync();
     const int row = tid >> 3, part = tid & 7;    // eight threads per row of the block
     const int lane = tid & 63;
     for (int c = 0; c < mt - 2; ++c) {
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tri_tail(const double *__restr
             v[lane + 64] = lane + 64 == c + 1 ? v0 : xb;
         }
         if (tid == 0) { es[c] = alpha; ts[c] = t; }
-        __syncthreads();
+        wc_sync();
         // the reflector replaces the row it came from (nobody reads row c any more); global memory
         // sees it after the loop -- a store inside the loop would sit in front of every barrier
         if (tid > c && tid < mt) M[c * TAIL_LD + tid] = v[tid];
@@ -370,11 +370,11 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tri_tail(const double *__restr
         s = dpp_add<0x112, 0xF>(s);
         s = dpp_add<0x114, 0xF>(s);               // lane 8 g + 7 holds the sum of its group of eight
         if (part == 7) pl[row] = (row > c && row < mt) ? t * s : 0.0;
-        __syncthreads();
+        wc_sync();
         // K = t/2 p.v per wave again; w = p - K v by the first two waves' worth of threads
         const double K = 0.5 * t * wave_sum(pl[lane] * v[lane] + pl[lane + 64] * v[lane + 64]);
         if (tid < TAIL_MAX) w[tid] = fma(-K, v[tid], pl[tid]);
-        __syncthreads();
+        wc_sync();
         if (row > c && row < mt) {
             const double vi = v[row], wi = w[row];
 #pragma unroll
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tri_tail(const double *__restr
                     M[row * TAIL_LD + j] = fma(-wi, v[j], fma(-vi, w[j], M[row * TAIL_LD + j]));
             }
         }
-        __syncthreads();
+        wc_sync();
     }
     if (tid < mt) d[k0 + tid] = M[tid * TAIL_LD + tid];
     if (tid < mt - 2) { e[k0 + tid] = es[tid]; tau[k0 + tid] = ts[tid]; }
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(EV_THREADS) void k_tri_eigvals(const double *__rest
         emax = fmax(emax, __shfl_xor(emax, o));
     }
     if ((tid & 63) == 0) { red[tid >> 6] = gl; red2[tid >> 6] = gu; red3[tid >> 6] = emax; }
-    __syncthreads();
+    wc_sync();
     for (int w = 0; w < EV_THREADS / 64; ++w) {
         gl = fmin(gl, red[w]);
         gu = fmax(gu, red2[w]);
@@ -466,9 +466,9 @@ __global__ __launch_bounds__(EV_THREADS) void k_tri_eigvals(const double *__rest
         // the last point whose count does not exceed the target: the eigenvalue is at or above it
         int mine = cb <= target ? 2 * tid + 1 : (ca <= target ? 2 * tid : -1);
         for (int o = 32; o > 0; o >>= 1) mine = max(mine, __shfl_xor(mine, o));
-        __syncthreads();
+        wc_sync();
         if ((tid & 63) == 0) best[tid >> 6] = mine;
-        __syncthreads();
+        wc_sync();
         int a = -1;
         for (int w = 0; w < EV_THREADS / 64; ++w) a = max(a, best[w]);
         const double nlo = a >= 0 ? lo + width * ((double)(a + 1) / (double)(EV_POINTS + 1)) : lo;
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(512) void k_tri_eigvecs(const double *__restrict__ 
         h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
         y[i] = (double)h * (2.0 / 4294967296.0) - 1.0;
     }
-    __syncthreads();
+    wc_sync();
     if (lane == 0) tri_factor(dd, ee, n, lam, tiny, u0, u1, u2, l, sw);
     for (int it = 0; it < 3; ++it) {
         if (lane == 0) {
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(512) void k_tri_eigvecs(const double *__restrict__ 
         }
         // Gram-Schmidt in the order of the eigenvalues, then unit length
         for (int j = 0; j < ncomp; ++j) {
-            __syncthreads();
+            wc_sync();
             if (c != j) continue;
             for (int p = 0; p < j; ++p) {
                 const double *zp = base + (size_t)p * 7 * n + 5 * (size_t)n;
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(512) void k_tri_eigvecs(const double *__restrict__ 
             const double inv = nn > 0.0 ? sc / sqrt(nn) : 0.0;
             for (int i = lane; i < n; i += 64) z[i] *= inv;
         }
-        __syncthreads();
+        wc_sync();
     }
     for (int i = lane; i < n; i += 64) Y[(size_t)c * n + i] = z[i];
 }
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(NT) void k_tri_back(const double *__restrict__ V, c
         for (int m = 0; m < PER; ++m) s = fma(v[m], z[m], s);
         s = wave_sum(s);
         if ((tid & 63) == 0) part[k & 1][tid >> 6] = s;
-        __syncthreads();
+        wc_sync();
         double tot = 0.0;
 #pragma unroll
         for (int w = 0; w < NT / 64; ++w) tot += part[k & 1][w];

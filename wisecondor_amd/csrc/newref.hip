@@ -85,19 +85,19 @@ __global__ __launch_bounds__(1024) void k_col_centre(const double *__restrict__ 
         }
         sh_s[ty][tx] = sum;
         sh_c[ty][tx] = cnt;
-        __syncthreads();
+        wc_sync();
         if (ty == 0) {
             double a = 0.0, b = 0.0;
             for (int r = 0; r < 16; ++r) { a += sh_s[r][tx]; b += sh_c[r][tx]; }
             sh_v[tx] = b > 0.0 ? a / b : 0.0;
         }
-        __syncthreads();
+        wc_sync();
         if (pass == 0) c = sh_v[tx];
         else if (pass == 1) {
             rad = 8.0 * sh_v[tx];
             if (ty == 0 && s < S) centre[S + s] = sh_v[tx];   // mean absolute deviation: the f16 image's scale comes from it
         } else if (ty == 0 && s < S) centre[s] = sh_v[tx];
-        __syncthreads();
+        wc_sync();
     }
 }
 
@@ -345,7 +345,7 @@ __device__ __forceinline__ void gram_epilogue(const GramArgs &g, float *sm, floa
     const int rl = w * 16 + (lane & 15);                                   // the row this lane helps to finish (four lanes per row)
     const int2 rgr0 = g.range[(int64_t)I * TB + rl], rgr1 = g.range[(int64_t)I * TB + 64 + rl];
     for (int h = 0; h < 2; ++h) {
-        __syncthreads();
+        wc_sync();
         if (wr == h) {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
@@ -364,7 +364,7 @@ __device__ __forceinline__ void gram_epilogue(const GramArgs &g, float *sm, floa
                         *(f32x4 *)&D[col * LDT + row] = v4;
                     }
         }
-        __syncthreads();
+        wc_sync();
 
         unsigned int mask_c = 0u;
         {
@@ -395,7 +395,7 @@ __device__ __forceinline__ void gram_epilogue(const GramArgs &g, float *sm, floa
         int base_c = 0;
         const int64_t gq = (int64_t)J * TB + x;
         if (mask_c) base_c = atomicAdd(&g.cnt[gq], __popc(mask_c));
-        __syncthreads();
+        wc_sync();
         // Row role, first half: four lanes per row (lane = 16 part + row-in-wave), each takes a 32-column quarter of
         // the row's 128-bit mask; part 0 reserves for all four.  The reservation's round trip is covered by the
         // column role's appends; the row's own appends follow them.
@@ -591,7 +591,7 @@ __device__ __forceinline__ void thr_epilogue(float *D, const float *nbPs, const 
     const float nbc0 = nbQs[2 * cp], nbc1 = nbQs[2 * cp + 1];
     const int2 rg0 = rangeQ[(int64_t)J * TB + 2 * cp], rg1 = rangeQ[(int64_t)J * TB + 2 * cp + 1];
     for (int h = 0; h < 2; ++h) {
-        __syncthreads();
+        wc_sync();
         if (wr == h) {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
@@ -607,7 +607,7 @@ __device__ __forceinline__ void thr_epilogue(float *D, const float *nbPs, const 
                         *(f32x4 *)&D[col * LDT + row] = v4;
                     }
         }
-        __syncthreads();
+        wc_sync();
         // thread = column pair (2cp, 2cp+1) x 16 rows: one 32-bit store carries two 16-bit keys, a
         // wave writes 256 contiguous bytes per row
         const int base_row = I * TB + h * 64 + rq * 16;
@@ -685,13 +685,13 @@ __global__ __launch_bounds__(256, 4) void k_gram_thr16(const unsigned short *__r
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     const int lcolf = (tid & 7) * 4;   // the same 16 bytes, in float units of the LDS row
     for (int slab = 0; slab < nslab; ++slab) {
-        __syncthreads();
+        wc_sync();
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             *(f32x4 *)&As[(lrow + 32 * p) * LDA + lcolf] = pa[p];
             *(f32x4 *)&Bs[(lrow + 32 * p) * LDA + lcolf] = qb[p];
         }
-        __syncthreads();
+        wc_sync();
         {
             const int64_t ko = (int64_t)(slab + 1 < nslab ? slab + 1 : slab) * 64;
 #pragma unroll
@@ -870,9 +870,9 @@ __device__ inline uint32_t select_key(const unsigned long long *ent, int n, int 
         res |= 0xFFFu;
         if (tid == 0) s_tmp[0] = (int)res;
     }
-    __syncthreads();
+    wc_sync();
     const uint32_t out = (uint32_t)s_tmp[0];
-    __syncthreads();
+    wc_sync();
     return out;
 }
 
@@ -929,7 +929,7 @@ __global__ __launch_bounds__(NT, 4) void k_finish(FinishArgs a) {
         xi = xs_dyn;
     }
     if (tid == 0) s_tmp[2] = 0;
-    __syncthreads();
+    wc_sync();
 
     int R = 0;
     if (!fallback) {
@@ -955,7 +955,7 @@ __global__ __launch_bounds__(NT, 4) void k_finish(FinishArgs a) {
             }
             for (int o = 32; o > 0; o >>= 1) my = fmax(my, __shfl_xor(my, o));
             if (lane == 0) red[tid >> 6] = my;
-            __syncthreads();
+            wc_sync();
             U = red[0];
             for (int q = 1; q < NT / 64; ++q) U = fmax(U, red[q]);
             // every candidate that was never listed has a lower bound > thr: need thr >= U
@@ -986,7 +986,7 @@ __global__ __launch_bounds__(NT, 4) void k_finish(FinishArgs a) {
                 int at = base + __popcll(m & ((1ull << lane) - 1ull));
                 if (keep && at < RMAX) cj[at] = j;
             }
-            __syncthreads();
+            wc_sync();
             R = s_tmp[2];
             if (R > RMAX) fallback = true;
         }
@@ -1043,7 +1043,7 @@ __global__ __launch_bounds__(NT, 4) void k_finish(FinishArgs a) {
             bool in_tail = false;
             int2 lf = seq ? make_int2(0, 0) : a.pw_prog[0];   // {leaf end, adds after the leaf}
             for (int64_t c0 = 0; c0 < a.S; c0 += ST_CH) {
-                __syncthreads();
+                wc_sync();
                 {
                     // the staging lanes subtract and square (every lane busy, the target's two
                     // samples read once per chunk); the candidate lanes below only add
@@ -1064,7 +1064,7 @@ __global__ __launch_bounds__(NT, 4) void k_finish(FinishArgs a) {
                         *(f64x2 *)&stage[(r0 + RP * p) * ST_LD + 2 * l8] = sq2;
                     }
                 }
-                __syncthreads();
+                wc_sync();
                 if (c0 + ST_CH < a.S) fetch((unsigned int)(c0 + ST_CH));
                 if (SEQ && tid < CB && c0 + ST_CH <= a.S && a.xs_in_lds) {
                     // full chunk, left-to-right sum: 16-byte LDS reads, no per-element control flow
@@ -1140,13 +1140,13 @@ __global__ __launch_bounds__(NT, 4) void k_finish(FinishArgs a) {
     }
     const int64_t cs = a.chrom_off[ch], ce = a.chrom_off[ch + 1];
     const int64_t orow = row - a.row_begin;
-    __syncthreads();
+    wc_sync();
     {
         // Order by counting: element t goes to slot #{u : (d_u, j_u) < (d_t, j_t)}.  Every thread
         // streams the same (broadcast) LDS pairs, no round-to-round dependencies; the few
         // hundred comparisons per element beat the 28 dependent rounds of a bitonic network.
         if (tid == 0 && (R & 1)) { dk[R] = ~0ull; jv[R] = 0x7FFFFFFF; }
-        __syncthreads();
+        wc_sync();
         for (int t = tid; t < R; t += NT) {
             const unsigned long long mine = dk[t];
             const int myj = jv[t];
@@ -1467,7 +1467,7 @@ __global__ __launch_bounds__(PS_MAX, (SEQ && !GLDS) ? 4 : (SEQ ? 5 : 3)) void k_
         for (int s = tid; s < Sp; s += p.ps) xs[s] = xi[s];
     }
     if (R < 0) return;                                   // exact path (workgroup-uniform)
-    __syncthreads();
+    wc_sync();
     const int l8 = lane & 7, r0 = lane >> 3;
     constexpr int NP = 8;                                // 8 rows per pass x 8 passes = the wave's 64 candidates
     constexpr int TRIPS = RMAX / 128;                    // a wave's trips with the smallest workgroup (two waves)
@@ -1578,7 +1578,7 @@ __global__ __launch_bounds__(PS_MAX, (SEQ && !GLDS) ? 4 : (SEQ ? 5 : 3)) void k_
         for (int t = 0; t < TRIPS; ++t)
             if (t == trip) { my_d[t] = dd; my_j[t] = jj; }
     }
-    __syncthreads();                                     // every wave is through with its slab
+    wc_sync();                                     // every wave is through with its slab
     unsigned long long *dk = reinterpret_cast<unsigned long long *>(rs_dyn + Sp);
     unsigned long long *sd = dk + RMAX + 2;
     int *jv = reinterpret_cast<int *>(sd + RMAX);
@@ -1596,7 +1596,7 @@ __global__ __launch_bounds__(PS_MAX, (SEQ && !GLDS) ? 4 : (SEQ ? 5 : 3)) void k_
     // index as tie-break (stable (distance, position) order, wisetools.py:313-321).
     if (tid == 0 && (R & 1)) dk[R] = ~0ull;
     for (int t = tid; t < R; t += p.ps) sj[t] = -1;
-    __syncthreads();
+    wc_sync();
     for (int t = tid; t < R; t += p.ps) {
         const unsigned long long mine = dk[t];
         int rank = 0;
@@ -1608,10 +1608,10 @@ __global__ __launch_bounds__(PS_MAX, (SEQ && !GLDS) ? 4 : (SEQ ? 5 : 3)) void k_
         sd[rank] = mine;
         sj[rank] = jv[t];
     }
-    __syncthreads();
+    wc_sync();
     int hole = 0;
     for (int t = tid; t < R; t += p.ps) hole |= sj[t] == -1;
-    if (__syncthreads_or(hole)) {
+    if (wc_sync_or(hole)) {
         for (int t = tid; t < R; t += p.ps) {
             const unsigned long long mine = dk[t];
             const int myj = jv[t];
@@ -1620,7 +1620,7 @@ __global__ __launch_bounds__(PS_MAX, (SEQ && !GLDS) ? 4 : (SEQ ? 5 : 3)) void k_
             sd[rank] = mine;
             sj[rank] = myj;
         }
-        __syncthreads();
+        wc_sync();
     }
     const int ch = a.chrom_of_row[row];
     const int64_t cs = a.chrom_off[ch], ce = a.chrom_off[ch + 1];
@@ -1686,13 +1686,13 @@ __device__ inline unsigned long long fb_radix_select(int64_t n, int want, V v, U
     unsigned long long prefix = 0ull, mask = 0ull;
     for (int shift = BITS - 8; shift >= 0; shift -= 8) {
         hist[tid] = 0;
-        __syncthreads();
+        wc_sync();
         for (int64_t j = tid; j < n; j += 256) {
             if (!use(j)) continue;
             const unsigned long long key = v(j);
             if ((key & mask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
         }
-        __syncthreads();
+        wc_sync();
         if (tid == 0) {
             int kk = want, d = 0;
             for (; d < 255; ++d) {
@@ -1702,11 +1702,11 @@ __device__ inline unsigned long long fb_radix_select(int64_t n, int want, V v, U
             *s_want = kk;
             *s_pref = prefix | ((unsigned long long)d << shift);
         }
-        __syncthreads();
+        wc_sync();
         want = *s_want;
         prefix = *s_pref;
         mask |= 0xFFull << shift;
-        __syncthreads();
+        wc_sync();
     }
     return prefix;
 }
@@ -1724,17 +1724,17 @@ __device__ inline void fb_select(const FinishArgs &a, int64_t row, const unsigne
     const int64_t orow = row - a.row_begin;
     // how many candidates carry a distance at all
     if (tid < 4) s_int[tid] = 0;
-    __syncthreads();
+    wc_sync();
     {
         int mine = 0;
         for (int64_t j = tid; j < a.B; j += 256) mine += sc[j] != ~0ull;
         for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
         if ((tid & 63) == 0) atomicAdd(&s_int[0], mine);
     }
-    __syncthreads();
+    wc_sync();
     const int n_valid = s_int[0];
     const int take = n_valid < a.k ? n_valid : a.k;        // entries that exist; the rest is padding
-    __syncthreads();
+    wc_sync();
     unsigned long long kth = ~0ull;
     int jth = 0x7FFFFFFF;
     if (take > 0) {
@@ -1742,7 +1742,7 @@ __device__ inline void fb_select(const FinishArgs &a, int64_t row, const unsigne
                                   hist, &s_pref, &s_int[1], tid);
         // entries below the k-th key, and entries equal to it
         if (tid < 4) s_int[tid] = 0;
-        __syncthreads();
+        wc_sync();
         int below = 0, equal = 0;
         for (int64_t j = tid; j < a.B; j += 256) {
             const unsigned long long v = sc[j];
@@ -1751,15 +1751,15 @@ __device__ inline void fb_select(const FinishArgs &a, int64_t row, const unsigne
         }
         for (int o = 32; o > 0; o >>= 1) { below += __shfl_xor(below, o); equal += __shfl_xor(equal, o); }
         if ((tid & 63) == 0) { atomicAdd(&s_int[2], below); atomicAdd(&s_int[3], equal); }
-        __syncthreads();
+        wc_sync();
         const int n_below = s_int[2], n_equal = s_int[3], places = take - n_below;
-        __syncthreads();
+        wc_sync();
         if (n_equal > places)      // more ties than places: the lowest positions win (stable order)
             jth = (int)fb_radix_select<32>(a.B, places - 1, [&](int64_t j) { return (unsigned long long)j; },
                                            [&](int64_t j) { return sc[j] == kth; }, hist, &s_pref, &s_int[1], tid);
     }
     if (tid == 0) s_int[0] = 0;
-    __syncthreads();
+    wc_sync();
     for (int64_t j = tid; j < a.B; j += 256) {
         const unsigned long long v = sc[j];
         if (take > 0 && (v < kth || (v == kth && (int)j <= jth))) {
@@ -1767,7 +1767,7 @@ __device__ inline void fb_select(const FinishArgs &a, int64_t row, const unsigne
             if (at < K_MAX) { selk[at] = v; selj[at] = (int)j; }
         }
     }
-    __syncthreads();
+    wc_sync();
     // order the chosen entries by counting, write the row
     for (int t = tid; t < a.k; t += 256) {
         int32_t oi = -1;
@@ -1786,7 +1786,7 @@ __device__ inline void fb_select(const FinishArgs &a, int64_t row, const unsigne
             a.dist_out[orow * a.k + t] = SENTINEL_DISTANCE;
         }
     }
-    __syncthreads();
+    wc_sync();
 }
 
 // ------------------------------------------------------------ exact path, tiled ----
@@ -1830,7 +1830,7 @@ __global__ __launch_bounds__(256) void k_exact_tile(FinishArgs a, const int *__r
     const int tr = tid >> 4, tc = tid & 15;
     const int64_t j0 = (int64_t)blockIdx.x * EX_T;
     for (int rg = blockIdx.y; rg * EX_T < nf; rg += gridDim.y) {
-        __syncthreads();
+        wc_sync();
         if (tid < EX_T) {
             const int f = rg * EX_T + tid;
             const int row = rows[first + (f < nf ? f : rg * EX_T)];      // slots beyond nf repeat the group's first row
@@ -1839,7 +1839,7 @@ __global__ __launch_bounds__(256) void k_exact_tile(FinishArgs a, const int *__r
             const bool lone = (a.lone_mask >> ch) & 1ull;                // filled by k_exact_select instead
             s_rng[tid] = (f < nf && !lone) ? make_int2((int)a.chrom_off[ch], (int)a.chrom_off[ch + 1]) : make_int2(0, 0x7FFFFFFF);
         }
-        __syncthreads();
+        wc_sync();
         // staging: value e = tid + 256 q of a chunk is sample e & 15 of staged row e >> 4 (targets, then candidates)
         int64_t src[NLD];
 #pragma unroll
@@ -1862,10 +1862,10 @@ __global__ __launch_bounds__(256) void k_exact_tile(FinishArgs a, const int *__r
 #pragma unroll
             for (int q = 0; q < TR; ++q) sum[i][q].init(a);
         for (int64_t c0 = 0; c0 < a.S; c0 += ST_CH) {
-            __syncthreads();                       // the previous chunk's reads are done
+            wc_sync();                       // the previous chunk's reads are done
 #pragma unroll
             for (int q = 0; q < NLD; ++q) buf[(tid & 15) * EX_LD + ((tid + 256 * q) >> 4)] = pre[q];
-            __syncthreads();
+            wc_sync();
             if (c0 + ST_CH < a.S) fetch(c0 + ST_CH);
             if constexpr (SEQ) {
 #pragma unroll
@@ -1946,7 +1946,7 @@ __global__ __launch_bounds__(256) void k_exact_select(FinishArgs a, const int *_
         const int64_t row = rows[first + blockIdx.x];
         unsigned long long *sc = scratch + (int64_t)blockIdx.x * Bpad;
         if ((a.lone_mask >> a.chrom_of_row[row]) & 1ull) fb_fill(a, row, a.X + row * a.S, 0, a.B, sc, tid);
-        __syncthreads();
+        wc_sync();
         fb_select(a, row, sc, rk, rj, hist, tid);
     }
     // targets beyond the cap (only when the host does not know the count: it loops over bands otherwise)
@@ -1955,14 +1955,14 @@ __global__ __launch_bounds__(256) void k_exact_select(FinishArgs a, const int *_
     for (int f = cap + blockIdx.x; f < count; f += gridDim.x) {
         const int64_t row = rows[first + f];
         const double *xi = a.X + row * a.S;
-        __syncthreads();
+        wc_sync();
         if (a.S <= 2048) {
             for (int64_t s = tid; s < a.S; s += 256) xs[s] = xi[s];
             xi = xs;
         }
-        __syncthreads();
+        wc_sync();
         fb_fill(a, row, xi, 0, a.B, own, tid);
-        __syncthreads();
+        wc_sync();
         fb_select(a, row, own, rk, rj, hist, tid);
     }
 }
@@ -1997,13 +1997,13 @@ __global__ __launch_bounds__(64) void k_import_lists(int *__restrict__ cnt, unsi
     const int c = src_cnt[r];
     const int base = cnt[row];
     if (c > src_cap || base > cap) {
-        __syncthreads();
+        wc_sync();
         if (threadIdx.x == 0) cnt[row] = cap + 1;  // lost entries: the row takes the exact path
         return;
     }
     for (int t = threadIdx.x; t < c; t += 64)
         if (base + t < cap) list[row * cap + base + t] = src_list[r * src_cap + t];
-    __syncthreads();
+    wc_sync();
     if (threadIdx.x == 0) cnt[row] = base + c;
 }
 

@@ -21,10 +21,10 @@ __global__ __launch_bounds__(256) void k_prep_totals(const int *__restrict__ cou
     long long s = 0;
     for (int64_t g = threadIdx.x; g < Btot; g += 256) s += row[g];
     sh[threadIdx.x] = s;
-    __syncthreads();
+    wc_sync();
     for (int o = 128; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-        __syncthreads();
+        wc_sync();
     }
     if (threadIdx.x == 0) totals[blockIdx.x] = (double)sh[0];
 }
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void k_prep_norm_centre(const int *__restri
         }
         for (; s < S; s += sstep) tile[i * ld + s] = (double)counts[s * Btot + g] / totals[s];
     }
-    __syncthreads();
+    wc_sync();
     for (int r = 0; r < nb; ++r)
         for (int64_t s = tid; s < S; s += 256) masked[(b0 + r) * S + s] = tile[r * ld + s];
     {
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void k_prep_norm_centre(const int *__restri
             mean[b0 + grp] = m;
         }
     }
-    __syncthreads();
+    wc_sync();
     if (i < nb) {
         const double m = sh_mean[i];
         for (int64_t s = s0; s < S; s += sstep) {
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_prep_syrk(const double *__restrict__ xc
         fetch(b_lo);
         stash(0);
     }
-    __syncthreads();
+    wc_sync();
     int stage = 0;
     for (int64_t b0 = b_lo; b0 < b_hi; b0 += SY_KB, stage ^= 1) {
         const bool more = b0 + SY_KB < b_hi;
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void k_prep_syrk(const double *__restrict__ xc
                     acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[m], fb[n], acc[m][n], 0, 0, 0);
         }
         if (more) stash(stage ^ 1);
-        __syncthreads();
+        wc_sync();
     }
     double *out = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (SY_T * SY_T);
 #pragma unroll
@@ -230,13 +230,13 @@ __global__ __launch_bounds__(1024) void k_prep_components(const double *__restri
     for (int c = 0; c < 8; ++c) {
         if (c >= n_comp) break;
         sh[g][x] = acc[c];
-        __syncthreads();
+        wc_sync();
         if (g == 0 && b < B) {
             double sum = 0.0;
             for (int q = 0; q < 16; ++q) sum += sh[q][x];
             comp[(int64_t)c * B + b] = sum;
         }
-        __syncthreads();
+        wc_sync();
     }
 }
 
@@ -259,13 +259,13 @@ __global__ __launch_bounds__(1024) void k_prep_sign(double *__restrict__ comp, i
         if (ob > best || (ob == best && oa < at)) { best = ob; at = oa; }
     }
     if ((threadIdx.x & 63) == 0) { s_abs[threadIdx.x >> 6] = best; s_idx[threadIdx.x >> 6] = at; }
-    __syncthreads();
+    wc_sync();
     if (threadIdx.x == 0) {
         for (int q = 1; q < 16; ++q)
             if (s_abs[q] > best || (s_abs[q] == best && s_idx[q] < at)) { best = s_abs[q]; at = s_idx[q]; }
         s_flip = row[at] < 0.0;
     }
-    __syncthreads();
+    wc_sync();
     if (s_flip)
         for (int64_t b = threadIdx.x; b < B; b += 1024) row[b] = -row[b];
 }
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(1024) void k_prep_transform(const double *__restric
         for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
         if ((threadIdx.x & 63) == 0) sh[c][threadIdx.x >> 6] = a;
     }
-    __syncthreads();
+    wc_sync();
     if ((int)threadIdx.x < n_comp) {
         double sum = 0.0;
         for (int q = 0; q < 16; ++q) sum += sh[threadIdx.x][q];
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void k_prep_correct_bs(const double *__restric
         }
         tile[j][tx] = v;
     }
-    __syncthreads();
+    wc_sync();
     for (int j = ty; j < 32; j += 8) {
         const int64_t b = b0 + j, s = s0 + tx;
         if (b < B && s < S) corrected_bs[b * S + s] = tile[tx][j];

@@ -71,13 +71,13 @@ __global__ __launch_bounds__(1024) void k_cut_scan(const int *__restrict__ cnt, 
     long long s = 0;
     for (int64_t r = lo; r < hi; ++r) s += cnt[r];
     part[tid] = s;
-    __syncthreads();
+    wc_sync();
     if (tid == 0) {
         long long run = 0;
         for (int t = 0; t < 1024; ++t) { const long long v = part[t]; part[t] = run; run += v; }
         off[rows] = run;
     }
-    __syncthreads();
+    wc_sync();
     long long run = part[tid];
     for (int64_t r = lo; r < hi; ++r) { off[r] = run; run += cnt[r]; }
 }
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void k_sample_totals(const int *__restrict__ c
     }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
-    __syncthreads();
+    wc_sync();
     if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * TOT_SPLIT + blockIdx.y] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
@@ -307,12 +307,12 @@ __global__ __launch_bounds__(256) void k_pca_project(const double *__restrict__ 
     }
 #pragma unroll
     for (int c = 0; c < MAX_COMP; ++c) sh[c][threadIdx.x] = acc[c];
-    __syncthreads();
+    wc_sync();
     for (int o = 128; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o)
 #pragma unroll
             for (int c = 0; c < MAX_COMP; ++c) sh[c][threadIdx.x] += sh[c][threadIdx.x + o];
-        __syncthreads();
+        wc_sync();
     }
     if ((int)threadIdx.x < n_comp)
         proj[((int64_t)blockIdx.x * PROJ_SPLIT + blockIdx.y) * MAX_COMP + threadIdx.x] = sh[threadIdx.x][0];
@@ -368,7 +368,7 @@ __global__ void k_pca_apply_t(const int *__restrict__ counts, int64_t Btot, cons
             for (int q = 0; q < PROJ_SPLIT; ++q) t += proj[(src(i0 + sm) * PROJ_SPLIT + q) * MAX_COMP + c];
         s_t[sm][c] = t;
     }
-    __syncthreads();
+    wc_sync();
     const int64_t b = b0 + tx;
     const double mean_b = b < B ? mean[b] : 0.0;
     const int g = b < B ? m2g[b] : 0;
@@ -387,7 +387,7 @@ __global__ void k_pca_apply_t(const int *__restrict__ counts, int64_t Btot, cons
             tile[j][tx] = raw / rec;
         }
     }
-    __syncthreads();
+    wc_sync();
     for (int j = ty; j < 32; j += 8) {
         const int64_t bb = b0 + j, i = i0 + tx;
         if (bb < B && i < Ns) {
@@ -428,10 +428,10 @@ __global__ __launch_bounds__(256) void k_lat_project(const int *__restrict__ cou
         acc_t = (a0 + a1) + (a2 + a3);
     }
     sh_t[tid] = acc_t;
-    __syncthreads();
+    wc_sync();
     for (int o = 128; o > 0; o >>= 1) {
         if (tid < o) sh_t[tid] += sh_t[tid + o];
-        __syncthreads();
+        wc_sync();
     }
     const double total = (double)sh_t[0];          // integer sums are exact in any order
     if (blockIdx.y == 0 && tid == 0) totals[i] = total;
@@ -470,13 +470,13 @@ __global__ __launch_bounds__(256) void k_lat_project(const int *__restrict__ cou
     }
 #pragma unroll
     for (int c = 0; c < MAX_COMP; ++c) sh[c][tid] = acc[c];
-    __syncthreads();
+    wc_sync();
     for (int o = 128; o > 0; o >>= 1) {
         if (tid < o)
 #pragma unroll
             for (int c = 0; c < MAX_COMP; ++c)
                 if (c < n_comp) sh[c][tid] += sh[c][tid + o];
-        __syncthreads();
+        wc_sync();
     }
     if (tid < n_comp) proj[(i * PROJ_SPLIT + blockIdx.y) * MAX_COMP + tid] = sh[tid][0];
 }
@@ -524,7 +524,7 @@ __global__ void k_transpose(const double *__restrict__ in, int64_t R, int64_t C,
         int64_t r = r0 + j, c = c0 + threadIdx.x;
         if (r < R && c < C) tile[j][threadIdx.x] = in[r * C + c];
     }
-    __syncthreads();
+    wc_sync();
     for (int j = threadIdx.y; j < 32; j += 8) {
         int64_t c = c0 + j, r = r0 + threadIdx.x;
         if (r < R && c < C) {
@@ -1255,7 +1255,7 @@ __global__ __launch_bounds__(1024) void k_lat_repeats(unsigned int *__restrict__
                 flag_wave_vals(t, t < first_n, zv[e], xv[e], thr, Ns, XC, users_off, users, dirty, pairs_a, pair_counts + 1);
         }
         __threadfence_block();
-        __syncthreads();
+        wc_sync();
     }
     for (int it = 1; it < repeats; ++it) {
         unsigned int *cur = (it & 1) ? pairs_a : pairs_b;
@@ -1275,14 +1275,14 @@ __global__ __launch_bounds__(1024) void k_lat_repeats(unsigned int *__restrict__
             }
         }
         __threadfence_block();
-        __syncthreads();
+        wc_sync();
         for (int t0 = 0; t0 < n; t0 += 1024) {
             const int t = t0 + tid;
             flag_wave(t < n ? (int64_t)cur[t] : 0, t < n, zT, thr, Ns, XC, users_off, users, dirty, next,
                       pair_counts + it + 1);
         }
         __threadfence_block();
-        __syncthreads();
+        wc_sync();
     }
 }
 
@@ -1305,7 +1305,7 @@ __global__ __launch_bounds__(256) void k_sd_avg(const double *__restrict__ sdT, 
     const int ss = threadIdx.x % SPB, bq = threadIdx.x / SPB;
     const int64_t i = (int64_t)blockIdx.x * SPB + ss;
     // `only`: per-sample flags of k_sd_fast -- just the samples it could not finish are summed here
-    if (only && !__syncthreads_or(i < Ns && only[i] != 0)) return;
+    if (only && !wc_sync_or(i < Ns && only[i] != 0)) return;
     const bool live = i < Ns && (!only || only[i] != 0);
     // The staging threads do everything that is not the chain: NaN terms (and bins past the
     // end) become +0.0 -- exact for a sum of sds >= +0 -- and are left out of the count, so the
@@ -1325,10 +1325,10 @@ __global__ __launch_bounds__(256) void k_sd_avg(const double *__restrict__ sdT, 
     fetch(0);
     double s = 0.0;
     for (int64_t b0 = 0; b0 < B; b0 += CH) {
-        __syncthreads();
+        wc_sync();
 #pragma unroll
         for (int u = 0; u < 32; ++u) buf[bq + PH * u][ss] = pre[u];
-        __syncthreads();
+        wc_sync();
         if (b0 + CH < B) fetch(b0 + CH);
         if (threadIdx.x < SPB) {
             for (int bb = 0; bb < CH; bb += 16) {
@@ -1341,7 +1341,7 @@ __global__ __launch_bounds__(256) void k_sd_avg(const double *__restrict__ sdT, 
         }
     }
     cnts[bq][ss] = cnt;
-    __syncthreads();
+    wc_sync();
     if (threadIdx.x < SPB && live) {
         long long c = 0;
         for (int q = 0; q < PH; ++q) c += cnts[q][ss];
@@ -1491,13 +1491,13 @@ __device__ inline void sd_fast_block(const int64_t i, SdShared *sm, const double
             if (lane >= o) { incl += up; inc_c += upc; }
         }
         if (lane == 63) { sh_wp[wv] = incl; sh_wc[wv] = inc_c; }
-        __syncthreads();
+        wc_sync();
         double base = 0.0;
         int basec = 0;
         for (int q = 0; q < wv; ++q) { base += sh_wp[q]; basec += sh_wc[q]; }
         sh_p[tid] = base + incl;
         sh_cnt[tid] = basec + inc_c;
-        __syncthreads();
+        wc_sync();
     }
     double before = tid > 0 ? sh_p[tid - 1] : 0.0;
     const int total_cnt = sh_cnt[1023];
@@ -1539,7 +1539,7 @@ __device__ inline void sd_fast_block(const int64_t i, SdShared *sm, const double
     // is a binade boundary nobody recorded (the maps left and right of it assume different units): the serial
     // kernel takes the sample.  (Practically unreachable -- the sum would have to sit within an ulp of 2^k.)
     sm->sh_e[tid] = before > 0.0 ? sd_exponent(before) : -100000;
-    __syncthreads();
+    wc_sync();
     if (tid > 0) {
         const double start = sh_p[tid - 1];
         if ((start > 0.0 ? sd_exponent(start) : -100000) != sm->sh_e[tid - 1]) bad = true;
@@ -1564,7 +1564,7 @@ __device__ inline void sd_fast_block(const int64_t i, SdShared *sm, const double
             }
         }
         if (lane == 63) { sh_wA[wv] = val.A; sh_wH0[wv] = val.H0; sh_wH1[wv] = val.H1; sh_wf[wv] = flag; sh_wn[wv] = nb; }
-        __syncthreads();
+        wc_sync();
         // carry of the earlier waves (their open segment), composed in order
         SdMap carryw; carryw.A = 0; carryw.H0 = 0; carryw.H1 = 0;
         int cf = 0, cn = 0;
@@ -1579,7 +1579,7 @@ __device__ inline void sd_fast_block(const int64_t i, SdShared *sm, const double
         sh_A[tid] = val.A; sh_H0[tid] = val.H0; sh_H1[tid] = val.H1;
         sh_flag[tid] = flag;
         sh_nb[tid] = nb;
-        __syncthreads();
+        wc_sync();
     }
     const int n_total_bound = sh_nb[1023];
     if (n_total_bound > SD_MAX_BOUND) { if (tid == 0) fail[i] = 1; return; }
@@ -1603,7 +1603,7 @@ __device__ inline void sd_fast_block(const int64_t i, SdShared *sm, const double
     }
     // the tail: the open segment through the last thread
     if (tid == 1023) { b_A[n_total_bound] = sh_A[1023]; b_H0[n_total_bound] = sh_H0[1023]; b_H1[n_total_bound] = sh_H1[1023]; }
-    __syncthreads();
+    wc_sync();
     // The fold over the boundaries is a dependent chain of ~n_total_bound steps: the first wave runs it with every
     // lane computing the same values (no divergence), the records of the boundaries in REGISTERS -- lane l holds
     // record l, a step reads it with v_readlane -- instead of five dependent LDS reads per step (records beyond 63
@@ -1744,7 +1744,7 @@ __global__ __launch_bounds__(1024) void k_clean(const double *__restrict__ zT, c
             if (lane == 0) s_cnt[trip][u][w] = __popcll(mask[u]);
             if (tid < 16 && tid >= nwaves) s_cnt[trip][u][tid] = 0;  // waves this workgroup does not have
         }
-        __syncthreads();                     // (the other buffer is written in the next trip: one barrier per trip)
+        wc_sync();                     // (the other buffer is written in the next trip: one barrier per trip)
         int before = count;
 #pragma unroll
         for (int u = 0; u < CL_U; ++u) {
@@ -1971,13 +1971,13 @@ __global__ __launch_bounds__(64) void k_window_valid(const double *__restrict__ 
                 const int t = lo + lane;
                 double val = 0.0;
                 if (t < hi) val = sorted[t];
-                __syncthreads();
+                wc_sync();
                 if (t < hi) sorted[t + 1] = val;
-                __syncthreads();
+                wc_sync();
             }
             if (lane == 0) sorted[pos] = v;
             ++len;
-            __syncthreads();
+            wc_sync();
         }
         double med = NAN;
         if (nans == 0) med = (len & 1) ? sorted[len / 2] : (sorted[len / 2 - 1] + sorted[len / 2]) / 2.0;
@@ -2156,7 +2156,7 @@ __global__ __launch_bounds__(256) void k_block_minmax(const double *__restrict__
         s_mx[tid >> 5] = mx;
     }
     if (!tmin2) return;
-    __syncthreads();
+    wc_sync();
     if (tid < 2 && ((int64_t)blockIdx.x * 2 + tid) * (4 * QB) < total) {
         double a = s_mn[4 * tid], b = s_mx[4 * tid];
         for (int q = 1; q < 4; ++q) { a = fmin(a, s_mn[4 * tid + q]); b = fmax(b, s_mx[4 * tid + q]); }
@@ -2214,7 +2214,7 @@ __device__ inline int quiet_body(const Job job, const Region rg, const double ab
         s_tmn[i] = tmin[k_base + i - tab_k0];
     }
     for (int chunk = first_chunk; chunk * ROWS_HALF < half; chunk += chunk_stride) {
-        __syncthreads();                          // previous chunk's queue and rows are done with
+        wc_sync();                          // previous chunk's queue and rows are done with
         if (s_found) break;
         if (tid == 0) s_nwork = 0;
         if (on) {   // the 64 rows of each side and the 64 prefix entries after them (clipped to the job)
@@ -2232,7 +2232,7 @@ __device__ inline int quiet_body(const Job job, const Region rg, const double ab
             }
             if ((t & 7) == 0) { s_b8x[side][t >> 3] = mx8; s_b8n[side][t >> 3] = mn8; }
         }
-        __syncthreads();
+        wc_sync();
         bool found = false;
         int evals = 0;                            // profiling only: window / bound evaluations of this lane
         for (int side = 0; on && side < 2; ++side) {
@@ -2312,7 +2312,7 @@ __device__ inline int quiet_body(const Job job, const Region rg, const double ab
                 }
             }
         }
-        __syncthreads();
+        wc_sync();
         // queued pairs: 32 ends each, eight pairs per trip
         const int nwork = s_nwork < Q_WORK ? s_nwork : Q_WORK;
         for (int wk = tid >> 5; on && wk < nwork; wk += 8) {
@@ -2331,9 +2331,9 @@ __device__ inline int quiet_body(const Job job, const Region rg, const double ab
             }
         }
     }
-    __syncthreads();
+    wc_sync();
     const int found = s_found;
-    __syncthreads();                              // the shared tables may be reused by the caller's next job
+    wc_sync();                              // the shared tables may be reused by the caller's next job
     return found;
 }
 
@@ -2429,7 +2429,7 @@ __device__ inline void bscan_chunk(const Job &job, const int chunk, const long l
     const long long a_hi = base + L;              // absolute index of the last end
     bool full = !table_ok;
     int evals = 0, wins = 0;                      // profiling only: bounds / windows by value of this thread
-    __syncthreads();                              // the previous chunk's shared state is done with
+    wc_sync();                              // the previous chunk's shared state is done with
     if (tid == 0) {
         s_nwork = 0;
         s_cut[0] = wc::f64_ordered(cut_hi);
@@ -2442,7 +2442,7 @@ __device__ inline void bscan_chunk(const Job &job, const int chunk, const long l
             const long long ai = base + (xr_lo < 0 ? 0 : xr_lo) + t;
             s_pn[side][t] = ai <= a_hi ? prefix[ai] : 0.0;
         }
-        __syncthreads();
+        wc_sync();
         if (tid < 32) {      // 8-entry blocks of the staged stretches: the near windows beyond 8..15 bins go by bound too
             const int side = tid >> 4, b = tid & 15;
             const int xr_lo = side == 0 ? chunk * ROWS_HALF : L - 1 - (chunk * ROWS_HALF + 63);
@@ -2453,7 +2453,7 @@ __device__ inline void bscan_chunk(const Job &job, const int chunk, const long l
             s_b0x[side][b] = mx;
             s_b0n[side][b] = mn;
         }
-        __syncthreads();
+        wc_sync();
         for (int side = 0; side < 2; ++side) {
             int xr = chunk * ROWS_HALF + lane;
             bool live;
@@ -2568,7 +2568,7 @@ __device__ inline void bscan_chunk(const Job &job, const int chunk, const long l
                 if ((++since & 7) == 0) refresh();
             }
         }
-        __syncthreads();
+        wc_sync();
         const int nwork = s_nwork;
         if (nwork > BS_QUEUE) {
             full = true;                          // workgroup-uniform: scan the whole block instead
@@ -2617,7 +2617,7 @@ __device__ inline void bscan_chunk(const Job &job, const int chunk, const long l
         if (MODE == 0) { ubmax = -INFINITY; lbmin = INFINITY; }    // nothing left unevaluated in this block
     }
     if (MODE == 0) {
-        __syncthreads();
+        wc_sync();
         cut_hi = wc::f64_from_ordered(s_cut[0]);                    // (the values seen join it in the caller's reduce)
         cut_lo = -wc::f64_from_ordered(s_cut[1]);
     }
@@ -2642,9 +2642,9 @@ __device__ inline void block_minmax4(double &a_max, double &a_min, double &b_max
         b_max = fmax(b_max, __shfl_xor(b_max, o));
         b_min = fmin(b_min, __shfl_xor(b_min, o));
     }
-    __syncthreads();
+    wc_sync();
     if ((tid & 63) == 0) { red[0][tid >> 6] = a_max; red[1][tid >> 6] = a_min; red[2][tid >> 6] = b_max; red[3][tid >> 6] = b_min; }
-    __syncthreads();
+    wc_sync();
     a_max = fmax(fmax(red[0][0], red[0][1]), fmax(red[0][2], red[0][3]));
     a_min = fmin(fmin(red[1][0], red[1][1]), fmin(red[1][2], red[1][3]));
     b_max = fmax(fmax(red[2][0], red[2][1]), fmax(red[2][2], red[2][3]));
@@ -2695,7 +2695,7 @@ __global__ __launch_bounds__(256) void k_seg_seed(const Job *__restrict__ jobs, 
         const long long base = regions[job.region].off + job.region + job.lo;
         long long k_base, k_last;
         if (stage_block_tables(base, L, tmin, tmax, s_tmx, s_tmn, k_base, k_last, tid)) {
-            __syncthreads();
+            wc_sync();
             // blocks that lie wholly inside the job's prefix slice [base, base + L]
             const int b_first = (int)((base + QB - 1) / QB - k_base);
             const int b_last = (int)((base + L + 1) / QB - 1 - k_base);
@@ -2971,7 +2971,7 @@ __device__ inline void cell_search(CellShared &sh, const CellGeom g, const doubl
     const int L = rhi - rb;
     for (int r0 = (MODE == 0 ? part : 0) * CJ_TRIP; r0 < L; r0 += (MODE == 0 ? parts : 1) * CJ_TRIP) {
         const int a0 = rb + r0;                              // the trip's first row
-        __syncthreads();                                    // the previous trip's rows and queue are done with
+        wc_sync();                                    // the previous trip's rows and queue are done with
 #pragma unroll
         for (int u = 0; u < CJ_LOADS; ++u) {
             const int i = tid + 256 * u;
@@ -2979,7 +2979,7 @@ __device__ inline void cell_search(CellShared &sh, const CellGeom g, const doubl
         }
         if (tid == 0) sh.n_items = 0;
         share_cuts();
-        __syncthreads();
+        wc_sync();
         // maximum / minimum of the staged entries per 8-entry block (entries past the job's end take no part)
         const int k8_0 = a0 >> 3;
         if (tid < CJ_NB8) {
@@ -2993,7 +2993,7 @@ __device__ inline void cell_search(CellShared &sh, const CellGeom g, const doubl
             sh.b8x[tid] = mx;
             sh.b8n[tid] = mn;
         }
-        __syncthreads();
+        wc_sync();
         cuts();
         const int rows_here = L - r0 < CJ_TRIP ? L - r0 : CJ_TRIP;           // rows t = 0 .. rows_here - 1 of this trip
         auto y_near_of = [&](const int ax) {                 // the last end before the row's first 32 x 32 cell
@@ -3054,7 +3054,7 @@ __device__ inline void cell_search(CellShared &sh, const CellGeom g, const doubl
                 if (ub >= chi || lb <= clo) push(t, kb + 1);
             }
         }
-        __syncthreads();
+        wc_sync();
         // queued (row, 8-block) pairs: eight lanes per pair
         const int n_items = sh.n_items < CJ_ITEMQ ? sh.n_items : CJ_ITEMQ;
         for (int i = tid >> 3; i < n_items; i += 32) {
@@ -3064,11 +3064,11 @@ __device__ inline void cell_search(CellShared &sh, const CellGeom g, const doubl
             if (ay > ax && ay <= y_near_of(ax)) see((sh.pn[ay - a0] - sh.pn[t]) * sh.rsn[ay - ax], ax, ay);
         }
     }
-    __syncthreads();
+    wc_sync();
     CJ_CLK(MODE * 4 + 2);
     if (tid == 0) { sh.n_q2 = 0; sh.n_q1 = 0; sh.n_items = 0; }
     share_cuts();
-    __syncthreads();
+    wc_sync();
     cuts();
     // ---- far windows: cells.  What reaches the cut is queued: 128 x 128 cells and the 32 x 32 cells of the band
     // between them and the near windows.  A part of cell_parts(L) owns a few hundred of each at most; ONE workgroup with
@@ -3106,7 +3106,7 @@ __device__ inline void cell_search(CellShared &sh, const CellGeom g, const doubl
                 if (at < CJ_Q1) sh.q1[at] = ((unsigned int)A << 16) | (unsigned int)K;
             }
     }
-    __syncthreads();
+    wc_sync();
     CJ_CLK(MODE * 4 + 3);
     // ---- the loud cells, in bounded steps (a job that is one long aberration ends up evaluating everything, but
     // nothing overflows): sixteen 128 x 128 cells -> their 256 32 x 32 cells, a thread each; 32 x 32 cells 32 at a
@@ -3115,10 +3115,10 @@ __device__ inline void cell_search(CellShared &sh, const CellGeom g, const doubl
     const int hl = tid & 31;
     auto rows_of = [&](const unsigned int *list, const int n) {        // n <= 256 cells of `list` (LDS)
         for (int c0 = 0; c0 < n; c0 += 32) {
-            __syncthreads();                                          // the previous chunk's queue is drained
+            wc_sync();                                          // the previous chunk's queue is drained
             if (tid == 0) sh.n_items = 0;
             share_cuts();
-            __syncthreads();
+            wc_sync();
             cuts();
             const int nc = n - c0 < 32 ? n - c0 : 32;
             for (int i = tid; i < nc * 32; i += 256) {
@@ -3143,7 +3143,7 @@ __device__ inline void cell_search(CellShared &sh, const CellGeom g, const doubl
                     sh.itemq[atomicAdd(&sh.n_items, 1)] = ((unsigned int)ax << 12) | (unsigned int)K;   // (at most 1024)
                 }
             }
-            __syncthreads();
+            wc_sync();
             const int n_items = sh.n_items;
             for (int i = tid >> 5; i < n_items; i += 8) {
                 const unsigned int it = sh.itemq[i];
@@ -3159,9 +3159,9 @@ __device__ inline void cell_search(CellShared &sh, const CellGeom g, const doubl
         if (MODE == 0 && tid == 0 && (sh.n_q2 > CJ_Q2 || sh.n_q1 > CJ_Q1)) sh.lost = 1;     // (read after the next barrier)
         const int n2 = sh.n_q2 < CJ_Q2 ? sh.n_q2 : CJ_Q2, n1 = sh.n_q1 < CJ_Q1 ? sh.n_q1 : CJ_Q1;
         for (int c2 = 0; c2 < n2; c2 += 16) {
-            __syncthreads();
+            wc_sync();
             if (tid == 0) sh.n_l1 = 0;
-            __syncthreads();
+            wc_sync();
             cuts();
             if (c2 + (tid >> 4) < n2) {
                 const unsigned int e = sh.q2[c2 + (tid >> 4)];
@@ -3169,13 +3169,13 @@ __device__ inline void cell_search(CellShared &sh, const CellGeom g, const doubl
                 if (A >= A1f && A <= A1l && K <= K1l && loud1(A, K))
                     sh.l1[atomicAdd(&sh.n_l1, 1)] = ((unsigned int)A << 16) | (unsigned int)K;
             }
-            __syncthreads();
+            wc_sync();
             rows_of(sh.l1, sh.n_l1);
         }
         for (int c1 = 0; c1 < n1; c1 += 256) rows_of(sh.q1 + c1, n1 - c1 < 256 ? n1 - c1 : 256);
     }
 #ifdef WC_CELL_CLOCKS
-    __syncthreads();
+    wc_sync();
     CJ_CLK(MODE * 4 + 4);
     if (tid == 0) { sh.clk[MODE * 4 + 5] += (unsigned long long)sh.n_q2; sh.clk[MODE * 4 + 6] += (unsigned long long)sh.n_q1; }
 #endif
@@ -3200,7 +3200,7 @@ __device__ inline CellGeom cell_setup(CellShared &sh, const Job job, const Regio
     for (int i = tid; i < n2; i += 256) { sh.tmx2[i] = tmax2[k2 + i]; sh.tmn2[i] = tmin2[k2 + i]; }
     if (tid < 64) sh.rsn[tid] = rs[tid];
     if (tid == 0) { sh.n_rec[0] = 0; sh.n_rec[1] = 0; sh.lost = 0; }
-    __syncthreads();
+    wc_sync();
     // The tables are aligned to the concatenated array: the job's first and last block of either level also cover
     // entries of its neighbours (another region's prefix sums: a jump).  Their extremes over the job's own
     // entries, a wave each -- otherwise every cell on the job's edges reaches the cut.
@@ -3220,7 +3220,7 @@ __device__ inline CellGeom cell_setup(CellShared &sh, const Job job, const Regio
             else { sh.tmx[blk] = mx; sh.tmn[blk] = mn; }
         }
     }
-    __syncthreads();
+    wc_sync();
     return g;
 }
 
@@ -3283,11 +3283,11 @@ __global__ __launch_bounds__(256) void k_seg_job(const Job *__restrict__ jobs, i
     if (tid < 32) sh.clk[tid] = 0ull;
     if (tid == 0) sh.t_prev = clock64();
     const unsigned long long t_begin = clock64();
-    __syncthreads();
+    wc_sync();
 #endif
     const CellGeom g = cell_setup(sh, job, rg, job.region, prefix, rs, tmin, tmax, tmin2, tmax2, tid);
     cell_seed(sh, g, T, tid);
-    __syncthreads();
+    wc_sync();
     CJ_CLK(1);
     double vmax = -INFINITY, vmin = INFINITY, d2 = -INFINITY, d3 = INFINITY;
     int wins = 0, evals = 0;
@@ -3314,13 +3314,13 @@ __global__ __launch_bounds__(256) void k_seg_job(const Job *__restrict__ jobs, i
         }
     }
 #ifdef WC_CELL_CLOCKS
-    __syncthreads();
+    wc_sync();
     CJ_CLK(15);
     if (tid == 0) {
         sh.clk[16] = 1ull;
         atomicMax(&g_dbg[48], clock64() - t_begin);          // the longest-lived workgroup
     }
-    __syncthreads();
+    wc_sync();
     if (tid < 32) atomicAdd(&g_dbg[tid], sh.clk[tid]);
 #endif
     if (work) {
@@ -3375,7 +3375,7 @@ __global__ __launch_bounds__(256) void k_seg_merge(const Job *__restrict__ jobs,
     const CellRec *jrec = grec + (int64_t)j * 2 * CJ_GREC;
     int wins = 0, evals = 0;
     if (tid == 0) { sh.n_rec[0] = 0; sh.n_rec[1] = 0; }
-    __syncthreads();
+    wc_sync();
     if (js.overflow || js.n_rec[0] > CJ_GREC || js.n_rec[1] > CJ_GREC) {
         // more near-extreme windows than the records hold (ties): the whole job once more with the final cuts
         const CellGeom g = cell_setup(sh, job, rg, job.region, prefix, rs, tmin, tmax, tmin2, tmax2, tid);
@@ -3391,9 +3391,9 @@ __global__ __launch_bounds__(256) void k_seg_merge(const Job *__restrict__ jobs,
             if (r.v <= lo_cut) { const int at = atomicAdd(&sh.n_rec[1], 1); if (at < CJ_REC) sh.rec[1][at] = r; }
         }
     }
-    __syncthreads();
+    wc_sync();
     if (tid == 0) sh.slot = atomicAdd(&counters[2], 1);
-    __syncthreads();
+    wc_sync();
     const int h = sh.slot;
     if (tid < 2) {
         const int side = tid, n = sh.n_rec[side];
@@ -3549,7 +3549,7 @@ __global__ __launch_bounds__(64 * NW) void k_seg_search(const Job *__restrict__ 
     const double *P = Pg;
     if (PLDS) {
         for (int i = tid; i <= L; i += 64 * NW) pl[i] = Pg[i];
-        __syncthreads();
+        wc_sync();
         P = pl;
     }
     const WindowMask wm{bits, MASKED ? bit_off[job.region] : 0, regions[job.region].n};
@@ -3572,7 +3572,7 @@ __global__ __launch_bounds__(64 * NW) void k_seg_search(const Job *__restrict__ 
         for (int o = 32; o > 0; o >>= 1) n_windows += __shfl_xor(n_windows, o);
         if (lane == 0) atomicAdd(work, (unsigned long long)n_windows);
     }
-    __syncthreads();
+    wc_sync();
     if (tid == 0) {
         Extreme e;
         e.maxv = red_max[0];
@@ -3752,7 +3752,7 @@ __device__ inline void block_best(BestPair &b, int tid) {
     __shared__ double smax[256], smin[256];
     __shared__ int sx[256], sy[256], tx[256], ty[256];
     smax[tid] = b.maxv; smin[tid] = b.minv; sx[tid] = b.mx; sy[tid] = b.my; tx[tid] = b.nx; ty[tid] = b.ny;
-    __syncthreads();
+    wc_sync();
     for (int o = 128; o > 0; o >>= 1) {
         if (tid < o) {
             if (sx[tid + o] >= 0 && better_max(smax[tid + o], sx[tid + o], sy[tid + o], smax[tid], sx[tid], sy[tid])) {
@@ -3762,10 +3762,10 @@ __device__ inline void block_best(BestPair &b, int tid) {
                 smin[tid] = smin[tid + o]; tx[tid] = tx[tid + o]; ty[tid] = ty[tid + o];
             }
         }
-        __syncthreads();
+        wc_sync();
     }
     b.maxv = smax[0]; b.minv = smin[0]; b.mx = sx[0]; b.my = sy[0]; b.nx = tx[0]; b.ny = ty[0];
-    __syncthreads();
+    wc_sync();
 }
 
 __global__ __launch_bounds__(256) void k_seg_decide(const Job *__restrict__ jobs, const int *__restrict__ hot,
@@ -3930,7 +3930,7 @@ __global__ __launch_bounds__(NT) void k_lat_setup(const double *__restrict__ zsr
         if (b < ce) keep = nsrc[i * str_i + b * str_b] >= minref;
         const unsigned long long mask = __ballot(keep);
         if (lane == 0) s_cnt[w] = __popcll(mask);
-        __syncthreads();
+        wc_sync();
         int before = count;
         for (int q = 0; q < w; ++q) before += s_cnt[q];
         if (keep) {
@@ -3942,7 +3942,7 @@ __global__ __launch_bounds__(NT) void k_lat_setup(const double *__restrict__ zsr
             gpos[off + at] = (int)(m2g[b] - goff[c]);
         }
         for (int q = 0; q < NW; ++q) count += s_cnt[q];
-        __syncthreads();
+        wc_sync();
     }
     const int n = count;
     if (tid == 0) {
@@ -3954,7 +3954,7 @@ __global__ __launch_bounds__(NT) void k_lat_setup(const double *__restrict__ zsr
         j.region = (int)r; j.lo = 0; j.hi = n; j.pad = 0;
         jobs[r] = j;
     }
-    __syncthreads();
+    wc_sync();
     WC_STAMP(1);
     // 2. prefix sums, sum |z|, finiteness
     const double *zz = zl;
@@ -3973,19 +3973,19 @@ __global__ __launch_bounds__(NT) void k_lat_setup(const double *__restrict__ zsr
             if (lane >= o) incl += up;
         }
         if (lane == 63) s_sum[w] = incl;
-        __syncthreads();
+        wc_sync();
         double before = run;
         for (int q = 0; q < w; ++q) before += s_sum[q];
         if (t < n) P[t + 1] = before + incl;
         for (int q = 0; q < NW; ++q) run += s_sum[q];
-        __syncthreads();
+        wc_sync();
     }
     for (int o = 32; o > 0; o >>= 1) {
         a += __shfl_xor(a, o);
         finite &= __shfl_xor(finite, o);
     }
     if (lane == 0) { s_abs[w] = a; s_fin[w] = finite; }
-    __syncthreads();
+    wc_sync();
     if (tid == 0) {
         double aa = 0.0;
         int ff = 1;
@@ -4001,7 +4001,7 @@ __global__ __launch_bounds__(NT) void k_lat_setup(const double *__restrict__ zsr
         if (n > 0 && n <= 2048) {        // five halvings of <= 2048 (each half at most n / 2 + 7) end at <= 128 elements
             int next = 0;
             PwBlock<5>::leaves(zz, 0, n, next, tid >> 3, tid & 7, s_leaf);
-            __syncthreads();
+            wc_sync();
             next = 0;
             v = PwBlock<5>::fold(n, next, s_leaf) / sqrt((double)n);
         } else if (n > 0 && w == 0) {
@@ -4069,7 +4069,7 @@ __device__ inline void seg_tree_region(const int region, int *__restrict__ count
     for (int i = tid; i <= rg.n; i += 1024) pl[i] = Pg[i];
     for (int i = tid; i < rg.n; i += 1024) zl[i] = z[rg.off + i];
     if (tid == 0) { s_sp = 1; s_nseg = 0; s_root = 1; s_ext_lo = 0; s_ext_hi = -1; }
-    __syncthreads();
+    wc_sync();
     const double eps = window_eps(rg.n, reg_abs[region]);
     const double *zz = zl;
     const WindowMask wm{nullptr, 0, rg.n};
@@ -4079,27 +4079,27 @@ __device__ inline void seg_tree_region(const int region, int *__restrict__ count
         root.region = region; root.lo = 0; root.hi = rg.n; root.pad = 0;
         stack[0] = root;
     }
-    __syncthreads();
+    wc_sync();
     // which slices of the job whose extremes sit in ext_max / ext_min may hold a call (same test as a whole
     // range's: the larger magnitude + eps against the threshold); bit side * 16 + wave of s_loud[row block]
     auto loud_slices = [&](int nch_job) {
         for (int t = tid; t < nch_job; t += 1024) s_loud[t] = 0u;
-        __syncthreads();
+        wc_sync();
         for (int t = tid; t < nch_job * 32; t += 1024) {
             const double mx = (&ext_max[0][0][0])[t], mn = (&ext_min[0][0][0])[t];
             const bool empty = mx == -INFINITY && mn == INFINITY;       // a slice without a window
             if (!empty && !(fmax(fabs(mx), fabs(mn)) + eps < thr)) atomicOr(&s_loud[t >> 5], 1u << (t & 31));
         }
-        __syncthreads();
+        wc_sync();
     };
     while (true) {
-        __syncthreads();
+        wc_sync();
         if (s_sp == 0) break;
         const Job job = stack[s_sp - 1];
         const bool is_root = s_root != 0;
-        __syncthreads();
+        wc_sync();
         if (tid == 0) { --s_sp; s_nhi = 0; s_nlo = 0; s_root = 0; }
-        __syncthreads();
+        wc_sync();
         ScanCtx c;
         c.P = pl; c.lo = job.lo; c.hi = job.hi; c.L = job.hi - job.lo; c.half = (c.L + 1) / 2; c.chunk = 0;
         c.wm = wm;
@@ -4124,7 +4124,7 @@ __device__ inline void seg_tree_region(const int region, int *__restrict__ count
                 ext_max[ch][side][q] = e2.x;
                 ext_min[ch][side][q] = e2.y;
             }
-            __syncthreads();
+            wc_sync();
             if (fmax(fabs(emax), fabs(emin)) + eps < thr) continue;
             loud_slices(nch);
             if (tid == 0) { s_ext_lo = job.lo; s_ext_hi = job.hi; }
@@ -4141,7 +4141,7 @@ __device__ inline void seg_tree_region(const int region, int *__restrict__ count
                 pc.clip_lo = job.lo; pc.clip_hi = job.hi;
                 const int pnch = (pc.half + ROWS_HALF - 1) / ROWS_HALF;
                 if (tid == 0) s_found = 0;
-                __syncthreads();
+                wc_sync();
                 bool found = false;
                 for (int ch = 0; ch < pnch; ++ch) {
                     const unsigned int loud = s_loud[ch];
@@ -4152,9 +4152,9 @@ __device__ inline void seg_tree_region(const int region, int *__restrict__ count
                     }, ~loud);
                 }
                 if (found) s_found = 1;
-                __syncthreads();
+                wc_sync();
                 const bool quiet = s_found == 0;
-                __syncthreads();
+                wc_sync();
                 if (quiet) continue;
             }
             // value search with the general path's inner loops (four float64 operations per window);
@@ -4175,11 +4175,11 @@ __device__ inline void seg_tree_region(const int region, int *__restrict__ count
                 bmin = fmin(bmin, smin);
             }
             if (lane == 0) { red_max[w] = bmax; red_min[w] = bmin; }
-            __syncthreads();
+            wc_sync();
             emax = red_max[0];
             emin = red_min[0];
             for (int q = 1; q < 16; ++q) { emax = fmax(emax, red_max[q]); emin = fmin(emin, red_min[q]); }
-            __syncthreads();
+            wc_sync();
             if (fmax(fabs(emax), fabs(emin)) + eps < thr) {              // no call in this range (k_seg_classify's test)
                 if (tid == 0) s_ext_hi = -1;                             // the slice extremes at hand are this range's now: drop them
                 continue;
@@ -4195,12 +4195,12 @@ __device__ inline void seg_tree_region(const int region, int *__restrict__ count
         // (every thread walking the 32 extremes of every block itself, with short-circuit tests, was a
         // chain of ~250 dependent LDS reads: 11 us at the root of a 900-bin region)
         for (int t = tid; t < nch; t += 1024) s_reach[t] = 0u;
-        __syncthreads();
+        wc_sync();
         for (int t = tid; t < nch * 32; t += 1024) {
             const bool reach = !((&ext_max[0][0][0])[t] < hi_cut && (&ext_min[0][0][0])[t] > lo_cut);
             if (reach) atomicOr(&s_reach[t >> 5], 1u << (t & 31));      // bit side * 16 + candidate-pass wave
         }
-        __syncthreads();
+        wc_sync();
         for (int ch = 0; ch < nch; ++ch) {
             const unsigned int reach = s_reach[ch];
             if (reach == 0u) continue;
@@ -4217,7 +4217,7 @@ __device__ inline void seg_tree_region(const int region, int *__restrict__ count
                 }
             }, skip);
         }
-        __syncthreads();
+        wc_sync();
         WC_STAMP_AT(is_root ? 10 : 14, region);
         const int n_hi = s_nhi, n_lo = s_nlo;
         if (n_hi > CAND_CAP || n_lo > CAND_CAP) {     // massive ties: the general path evaluates everything exactly
@@ -4242,7 +4242,7 @@ __device__ inline void seg_tree_region(const int region, int *__restrict__ count
             }
             if (lane == 0) s_best[w] = b;
         }
-        __syncthreads();
+        wc_sync();
         WC_STAMP_AT(is_root ? 11 : 15, region);
         if (tid == 0) {
             BestPair b = s_best[0];
@@ -4271,7 +4271,7 @@ __device__ inline void seg_tree_region(const int region, int *__restrict__ count
         }
     }
     // ---- the region's calls, in position order (k_seg_gather + k_call_post of the general path)
-    __syncthreads();
+    wc_sync();
     WC_STAMP_AT(16, region);
     const int nseg = s_nseg;
     if (tid == 0) {
@@ -4284,16 +4284,16 @@ __device__ inline void seg_tree_region(const int region, int *__restrict__ count
         int rank = 0;
         for (int u = 0; u < nseg; ++u) rank += seg_x[u] < x;
         if (rank >= max_calls) continue;                   // k_assemble_calls reports the overflow from out_n
-        __syncthreads();
+        wc_sync();
         if (tid == 0) s_nan = 0;
-        __syncthreads();
+        wc_sync();
         double *sv = pl;                                   // the prefix array is not needed any more
         for (int e = tid; e < L; e += 1024) {
             const double v = rr[x + e];
             sv[e] = v;
             if (v != v) s_nan = 1;
         }
-        __syncthreads();
+        wc_sync();
         const bool has_nan = s_nan != 0;
         if (!has_nan) {
             // every value counts the values below / at-or-below it; the value whose interval covers
@@ -4311,7 +4311,7 @@ __device__ inline void seg_tree_region(const int region, int *__restrict__ count
                 if (lt <= k_hi && k_hi < le) s_mid[1] = xv;
             }
         }
-        __syncthreads();
+        wc_sync();
         if (tid == 0) {
             double med = (L & 1) ? s_mid[0] : (s_mid[0] + s_mid[1]) / 2.0;
             if (has_nan) med = NAN;
@@ -4346,11 +4346,11 @@ __global__ __launch_bounds__(256) void k_seg_gather(const Seg *__restrict__ segs
     if (live) me = segs[s];
     int rank = 0;
     for (int t0 = 0; t0 < n_segs; t0 += 256) {
-        __syncthreads();
+        wc_sync();
         const int t = t0 + threadIdx.x;
         t_region[threadIdx.x] = t < n_segs ? segs[t].region : -2;
         t_x[threadIdx.x] = t < n_segs ? segs[t].x : 0;
-        __syncthreads();
+        wc_sync();
         const int m = n_segs - t0 < 256 ? n_segs - t0 : 256;
         for (int u = 0; u < m; ++u) rank += (t_region[u] == me.region) & (t_x[u] < me.x);
     }
@@ -4377,7 +4377,7 @@ __device__ inline double block_select_of(F at, int L, int k, int tid) {
     unsigned long long prefix = 0ull, mask = 0ull;
     for (int shift = 56; shift >= 0; shift -= 8) {
         if (tid < 256) hist[tid] = 0;
-        __syncthreads();
+        wc_sync();
         for (int e0 = tid; e0 < L; e0 += 4 * NT) {            // four values per trip: their loads are in flight together
             double x4[4];
 #pragma unroll
@@ -4388,7 +4388,7 @@ __device__ inline double block_select_of(F at, int L, int k, int tid) {
                 if (e0 + u * NT < L && (key & mask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
             }
         }
-        __syncthreads();
+        wc_sync();
         unsigned int h = 0, incl = 0;
         const int lane = tid & 63, wv = tid >> 6;
         if (tid < 256) {
@@ -4402,7 +4402,7 @@ __device__ inline double block_select_of(F at, int L, int k, int tid) {
             }
             if (lane == 63) s_wsum[wv] = incl;
         }
-        __syncthreads();
+        wc_sync();
         if (tid < 256) {
             for (int q = 0; q < wv; ++q) incl += s_wsum[q];
             const unsigned int excl = incl - h;
@@ -4411,11 +4411,11 @@ __device__ inline double block_select_of(F at, int L, int k, int tid) {
                 s_prefix = prefix | ((unsigned long long)tid << shift);
             }
         }
-        __syncthreads();
+        wc_sync();
         k = s_k;
         prefix = s_prefix;
         mask |= 0xFFull << shift;
-        __syncthreads();
+        wc_sync();
     }
     return wc::f64_from_ordered(prefix);
 }
@@ -4435,7 +4435,7 @@ __device__ inline void block_select_pair(F at, int L, int k, int k2, int tid, do
     if (k2 == k) return;
     const unsigned long long klo = wc::f64_ordered(lo);
     if (tid == 0) { s_next = ~0ull; s_le = 0; }
-    __syncthreads();
+    wc_sync();
     unsigned long long mine = ~0ull;
     int le = 0;
     for (int e = tid; e < L; e += NT) {
@@ -4449,9 +4449,9 @@ __device__ inline void block_select_pair(F at, int L, int k, int k2, int tid, do
         mine = other < mine ? other : mine;
     }
     if ((tid & 63) == 0) { atomicAdd(&s_le, le); atomicMin(&s_next, mine); }
-    __syncthreads();
+    wc_sync();
     if (s_le <= k2) hi = wc::f64_from_ordered(s_next);     // (ranks 0 .. s_le - 1 hold values <= lo)
-    __syncthreads();
+    wc_sync();
 }
 __global__ __launch_bounds__(CP_THREADS) void k_call_post(const Seg *__restrict__ segs, int n_segs,
                                                    const Region *__restrict__ regions, const double *__restrict__ rc,
@@ -4464,7 +4464,7 @@ __global__ __launch_bounds__(CP_THREADS) void k_call_post(const Seg *__restrict_
     if ((int)blockIdx.x >= n_segs) return;
     const Seg me = segs[blockIdx.x];
     if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
-    __syncthreads();
+    wc_sync();
     int rank = 0;
     for (int t = tid; t < n_segs; t += CP_THREADS) {
         const Seg o = segs[t];
@@ -4476,7 +4476,7 @@ __global__ __launch_bounds__(CP_THREADS) void k_call_post(const Seg *__restrict_
     const double *v = rc + rg.off + x;
     for (int e = tid; e < L; e += CP_THREADS)
         if (v[e] != v[e]) s_flag[1] = 1;
-    __syncthreads();
+    wc_sync();
     rank = s_flag[0];
     const bool has_nan = s_flag[1] != 0;
     if (rank >= max_calls) return;
@@ -4487,7 +4487,7 @@ __global__ __launch_bounds__(CP_THREADS) void k_call_post(const Seg *__restrict_
         __shared__ double sv[SHORT_SEG];
         __shared__ double s_mid[2];
         for (int e = tid; e < L; e += CP_THREADS) sv[e] = v[e];
-        __syncthreads();
+        wc_sync();
         const int k_lo = (L - 1) / 2, k_hi = L / 2;
         for (int e = tid; e < L; e += CP_THREADS) {
             const double xv = sv[e];
@@ -4500,7 +4500,7 @@ __global__ __launch_bounds__(CP_THREADS) void k_call_post(const Seg *__restrict_
             if (lt <= k_lo && k_lo < le) s_mid[0] = xv;      // equal values write the same number
             if (lt <= k_hi && k_hi < le) s_mid[1] = xv;
         }
-        __syncthreads();
+        wc_sync();
         lo = s_mid[0];
         hi = s_mid[1];
     } else if (!has_nan) {
@@ -4556,7 +4556,7 @@ __global__ void k_assemble_calls(const double *__restrict__ reg_calls, const int
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (host_status) {
         assemble_one(reg_calls, out_n, n_sel, max_calls, Ns, calls, n_calls, overflow, i);
-        __syncthreads();
+        wc_sync();
         const int t = threadIdx.x;
         if (t == 0) host_status[16] = overflow[0];
         if (t < 8) host_status[24 + t] = counters[t];
@@ -4717,15 +4717,15 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
         s_sp = 1; s_nseg = 0; s_stop = 0;
     }
     while (true) {
-        __syncthreads();
+        wc_sync();
         if (s_sp == 0 || s_stop) break;
         const Job job = stack[s_sp - 1];
-        __syncthreads();
+        wc_sync();
         if (tid == 0) --s_sp;
         if (job.hi - job.lo <= 0) continue;
         const CellGeom g = cell_setup(sh, job, rg, region, prefix, rs, tmin, tmax, tmin2, tmax2, tid);
         cell_seed(sh, g, T, tid);
-        __syncthreads();
+        wc_sync();
         double vmax = -INFINITY, vmin = INFINITY, d2 = -INFINITY, d3 = INFINITY;
         cell_search<0>(sh, g, rs, eps2, INFINITY, -INFINITY, nullptr, 0, 1, vmax, vmin, wins, evals, tid);
         block_minmax4(vmax, vmin, d2, d3, tid);
@@ -4739,17 +4739,17 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
         const double lo_cut = !(-vmin + eps < thr) ? vmin + eps2 : -INFINITY;
         if (sh.n_rec[0] > CJ_REC || sh.n_rec[1] > CJ_REC) {
             // more near-extreme windows than the record holds (ties): the range once more with the final cuts
-            __syncthreads();
+            wc_sync();
             if (tid == 0) { sh.n_rec[0] = 0; sh.n_rec[1] = 0; }
             double e0 = -INFINITY, e1 = INFINITY;
             cell_search<2>(sh, g, rs, eps2, hi_cut, lo_cut, nullptr, 0, 1, e0, e1, wins, evals, tid);
-            __syncthreads();
+            wc_sync();
             if (sh.n_rec[0] > CJ_REC || sh.n_rec[1] > CJ_REC) {       // massive ties: the general path evaluates everything exactly
                 if (tid == 0) { atomicOr(&counters[6], 4); s_stop = 1; }
                 continue;
             }
         }
-        __syncthreads();                            // the search is done with its staging area: the waves' scratch now
+        wc_sync();                            // the search is done with its staging area: the waves' scratch now
         // exact values of the candidates (numpy pairwise sum / sqrt): waves 0-1 the candidates for the maximum,
         // 2-3 for the minimum (the record also holds windows that were near an earlier cut: the final cuts select)
         {
@@ -4771,7 +4771,7 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
             }
             if (lane == 0) s_best[w] = b;
         }
-        __syncthreads();
+        wc_sync();
         if (tid == 0) {
             BestPair b = s_best[0];
             if (s_best[1].mx >= 0 && better_max(s_best[1].maxv, s_best[1].mx, s_best[1].my, b.maxv, b.mx, b.my)) {
@@ -4801,13 +4801,13 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
     }
     // ---- the region's segments, appended to the batch's list for k_walk_rows (the call rows: position order, genomic
     // bounds, effect size); pad = the segment's number within the region | the region's count << 16
-    __syncthreads();
+    wc_sync();
     const int nseg = s_nseg;
     if (tid == 0) {
         out_n[region] = nseg;
         s_sp = nseg ? atomicAdd(&counters[4], nseg) : 0;     // (the stack pointer's slot: the walk is over)
     }
-    __syncthreads();
+    wc_sync();
     const int base = s_sp;
     for (int sidx = tid; sidx < nseg; sidx += 256) {
         Seg sg;
@@ -4848,9 +4848,9 @@ __global__ __launch_bounds__(256) void k_walk_rows(const Seg *__restrict__ wsegs
     // (workgroup w takes items w, w + gridDim.x, ...: they cost about the same, and a cursor would put one more global
     //  round trip in front of every item)
     for (int item = blockIdx.x; item < total; item += gridDim.x) {
-        __syncthreads();
+        wc_sync();
         if (tid == 0) { s_nan = 0; s_rank = 0; }
-        __syncthreads();
+        wc_sync();
         const Seg me = wsegs[item];
         const int region = me.region, nseg = me.pad >> 16, first = item - (me.pad & 0xFFFF);
         const Region rg = regions[region];
@@ -4870,7 +4870,7 @@ __global__ __launch_bounds__(256) void k_walk_rows(const Seg *__restrict__ wsegs
                 if (t8[u] != t8[u]) s_nan = 1;
             }
         }
-        __syncthreads();
+        wc_sync();
         const int rank = s_rank;
         if (rank >= max_calls) continue;                   // k_assemble_calls reports the overflow from out_n
         const bool has_nan = s_nan != 0;
@@ -4890,7 +4890,7 @@ __global__ __launch_bounds__(256) void k_walk_rows(const Seg *__restrict__ wsegs
                 if (lt <= k_lo && k_lo < le) s_mid[0] = xv;      // equal values write the same number
                 if (lt <= k_hi && k_hi < le) s_mid[1] = xv;
             }
-            __syncthreads();
+            wc_sync();
             lo = s_mid[0];
             hi = s_mid[1];
         } else if (!has_nan) {
@@ -4950,7 +4950,7 @@ __global__ void k_transpose3(const double *__restrict__ in0, const double *__res
         int64_t r = r0 + j, c = c0 + threadIdx.x;
         if (r < R && c < C) tile[j][threadIdx.x] = in[r * C + c];
     }
-    __syncthreads();
+    wc_sync();
     for (int j = threadIdx.y; j < 32; j += 8) {
         int64_t c = c0 + j, r = r0 + threadIdx.x;
         if (r < R && c < C) out[c * R + r] = tile[threadIdx.x][j];
