@@ -61,6 +61,7 @@ struct TestState {
     wc::DevBuf sd_fail;                 // per-sample flags of k_sd_fast (1: the serial kernel takes the sample)
     bool tree_done = false;             // run_stouffer: the tree kernel finished the recursion and wrote the call rows
     bool tree_pending = false;          // ... but its status words are still on their way to pinned memory (deferred check)
+    bool sm_out = false;                // run_repeat: zt / rt / nt / sdt of the last call are sample-major [Ns, B] (tiled first repeat)
     bool no_tree = false;               // repeat of a batch the tree kernel passed on: host-driven rounds only
     int64_t tree_seg_cap = 0;
     bool lat_ride = false;              // latency mode: stdDevAvg rides in k_seg_tree's grid (run_repeat -> run_seg_lat)
@@ -112,7 +113,11 @@ struct wc_ctx {
     }
     int ensure_side_stream() {
         if (side) return WC_OK;
-        WC_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        // lowest priority: what runs here only feeds outputs (stdDevAvg, the inflated arrays, whole-region values) and
+        // must not take CUs from the launch stream's critical path
+        int prio_least = 0, prio_greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_least = 0;
+        WC_HIP(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio_least));
         WC_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         WC_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
         return WC_OK;

@@ -726,13 +726,15 @@ __device__ inline uint32_t umed3(uint32_t x, uint32_t y, uint32_t z) {   // v_me
 
 template <int NV>   // keys per lane (M / 64 rounded up to 16 / 32 / 64), two per 32-bit word
 __global__ __launch_bounds__(256) void k_select_thr(const unsigned int *__restrict__ keys, int64_t ldo, int M,
-                                                    const int *__restrict__ chrom_of_row,
-                                                    const int64_t *__restrict__ chrom_off, int64_t B,
+                                                    const int2 *__restrict__ chrom_range, int64_t B,
                                                     int64_t row_begin, int64_t row_end, int expect, int cap,
                                                     float *__restrict__ thr) {
     const int lane = threadIdx.x & 63;
     int64_t row = row_begin + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= row_end) return;
+    // the rows of this row's chromosome (k_convert wrote them): requested WITH the keys -- chrom_of_row -> chrom_off was
+    // two more dependent round trips at the end of a wave's life
+    const int2 own = chrom_range[row];
     const int words = M / 128;            // 32-bit words per lane
     uint32_t u[NV];
     const uint32_t FIN = 0xFEFFu;         // largest code of a finite key
@@ -757,8 +759,7 @@ __global__ __launch_bounds__(256) void k_select_thr(const unsigned int *__restri
     }
     int mvalid = myvalid;
     for (int o = 32; o > 0; o >>= 1) mvalid += __shfl_xor(mvalid, o);
-    int ch = chrom_of_row[row];
-    int64_t nvalid = B - (chrom_off[ch + 1] - chrom_off[ch]);
+    int64_t nvalid = B - (int64_t)(own.y - own.x);
     float result;
     if (nvalid <= cap / 2) {
         result = WC_ADMIT_ALL;
@@ -1813,23 +1814,22 @@ constexpr int EX_CAP = 1024;     // targets per launch pair when the host knows 
 constexpr int EX_DEV_CAP = 256;  // ... when only the device does (the normal pass: scratch 2 EX_DEV_CAP rows)
 constexpr int EX_LD = 130;       // doubles per staged sample: 128 values + 2 (16-byte aligned rows, spread banks)
 
+constexpr int EXACT_TILE_LDS = ST_CH * EX_LD * 8 + 64 * 4 + 64 * 8;     // buf + s_row + s_rng (64 = the largest EX_T)
+// (bx, by, ny): this workgroup's candidate tile, its first row group and the row groups in flight; nf: rows of this launch
 template <bool SEQ>
-__global__ __launch_bounds__(256) void k_exact_tile(FinishArgs a, const int *__restrict__ rows,
-                                                    const int *__restrict__ n_rows_dev, int n_rows_host, int first,
-                                                    unsigned long long *__restrict__ scratch, int64_t Bpad, int cap) {
+__device__ inline void exact_tile_body(const FinishArgs &a, const int *__restrict__ rows, int nf, int first,
+                                       unsigned long long *__restrict__ scratch, int64_t Bpad, int bx, int by, int ny,
+                                       char *smem) {
     constexpr int TR = SEQ ? 4 : 2;            // pairs per thread: TR targets x TR candidates
     constexpr int EX_T = 16 * TR;              // targets (and candidates) per tile
     constexpr int NLD = 2 * EX_T * ST_CH / 256;   // staged values per thread and chunk
-    __shared__ __attribute__((aligned(16))) double buf[ST_CH * EX_LD];
-    __shared__ int s_row[EX_T];
-    __shared__ int2 s_rng[EX_T];
+    double *buf = reinterpret_cast<double *>(smem);
+    int *s_row = reinterpret_cast<int *>(smem + ST_CH * EX_LD * 8);
+    int2 *s_rng = reinterpret_cast<int2 *>(smem + ST_CH * EX_LD * 8 + 64 * 4);
     const int tid = threadIdx.x;
-    int nf = (n_rows_dev ? *n_rows_dev : n_rows_host) - first;
-    nf = nf > cap ? cap : nf;
-    if (nf <= 0) return;
     const int tr = tid >> 4, tc = tid & 15;
-    const int64_t j0 = (int64_t)blockIdx.x * EX_T;
-    for (int rg = blockIdx.y; rg * EX_T < nf; rg += gridDim.y) {
+    const int64_t j0 = (int64_t)bx * EX_T;
+    for (int rg = by; rg * EX_T < nf; rg += ny) {
         wc_sync();
         if (tid < EX_T) {
             const int f = rg * EX_T + tid;
@@ -1932,27 +1932,40 @@ __global__ __launch_bounds__(256) void k_exact_tile(FinishArgs a, const int *__r
     }
 }
 
-__global__ __launch_bounds__(256) void k_exact_select(FinishArgs a, const int *__restrict__ rows,
-                                                      const int *__restrict__ n_rows_dev, int n_rows_host, int first,
-                                                      unsigned long long *__restrict__ scratch, int64_t Bpad, int cap) {
-    __shared__ unsigned long long rk[K_MAX];
-    __shared__ int rj[K_MAX];
-    __shared__ unsigned int hist[256];
-    __shared__ double xs[2048];
+template <bool SEQ>
+__global__ __launch_bounds__(256) void k_exact_tile(FinishArgs a, const int *__restrict__ rows,
+                                                    const int *__restrict__ n_rows_dev, int n_rows_host, int first,
+                                                    unsigned long long *__restrict__ scratch, int64_t Bpad, int cap) {
+    __shared__ __attribute__((aligned(16))) char smem[EXACT_TILE_LDS];
+    int nf = (n_rows_dev ? *n_rows_dev : n_rows_host) - first;
+    nf = nf > cap ? cap : nf;
+    if (nf <= 0) return;
+    exact_tile_body<SEQ>(a, rows, nf, first, scratch, Bpad, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y, smem);
+}
+
+constexpr int EXACT_SELECT_LDS = K_MAX * 8 + K_MAX * 4 + 256 * 4 + 2048 * 8;    // rk + rj + hist + xs
+// bx of nx select workgroups; count: rows listed (first .. ), of which the first `cap` were filled by the tiles;
+// beyond_cap: also take the rows beyond the cap (the count was only known on the device)
+__device__ inline void exact_select_body(const FinishArgs &a, const int *__restrict__ rows, int count, int first,
+                                         unsigned long long *__restrict__ scratch, int64_t Bpad, int cap, int bx, int nx,
+                                         bool beyond_cap, char *smem) {
+    unsigned long long *rk = reinterpret_cast<unsigned long long *>(smem);
+    int *rj = reinterpret_cast<int *>(smem + K_MAX * 8);
+    unsigned int *hist = reinterpret_cast<unsigned int *>(smem + K_MAX * 12);
+    double *xs = reinterpret_cast<double *>(smem + K_MAX * 12 + 256 * 4);
     const int tid = threadIdx.x;
-    const int count = (n_rows_dev ? *n_rows_dev : n_rows_host) - first;
     const int nf = count > cap ? cap : count;
-    if ((int)blockIdx.x < nf) {
-        const int64_t row = rows[first + blockIdx.x];
-        unsigned long long *sc = scratch + (int64_t)blockIdx.x * Bpad;
+    if (bx < nf) {
+        const int64_t row = rows[first + bx];
+        unsigned long long *sc = scratch + (int64_t)bx * Bpad;
         if ((a.lone_mask >> a.chrom_of_row[row]) & 1ull) fb_fill(a, row, a.X + row * a.S, 0, a.B, sc, tid);
         wc_sync();
         fb_select(a, row, sc, rk, rj, hist, tid);
     }
     // targets beyond the cap (only when the host does not know the count: it loops over bands otherwise)
-    if (!n_rows_dev) return;
-    unsigned long long *own = scratch + ((int64_t)cap + blockIdx.x) * Bpad;
-    for (int f = cap + blockIdx.x; f < count; f += gridDim.x) {
+    if (!beyond_cap) return;
+    unsigned long long *own = scratch + ((int64_t)cap + bx) * Bpad;
+    for (int f = cap + bx; f < count; f += nx) {
         const int64_t row = rows[first + f];
         const double *xi = a.X + row * a.S;
         wc_sync();
@@ -1964,6 +1977,50 @@ __global__ __launch_bounds__(256) void k_exact_select(FinishArgs a, const int *_
         fb_fill(a, row, xi, 0, a.B, own, tid);
         wc_sync();
         fb_select(a, row, own, rk, rj, hist, tid);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_exact_select(FinishArgs a, const int *__restrict__ rows, int n_rows_host, int first,
+                                                      unsigned long long *__restrict__ scratch, int64_t Bpad, int cap) {
+    __shared__ __attribute__((aligned(16))) char smem[EXACT_SELECT_LDS];
+    exact_select_body(a, rows, n_rows_host - first, first, scratch, Bpad, cap, (int)blockIdx.x, (int)gridDim.x, false, smem);
+}
+
+// The normal pass: the number of rows without a certificate is only known on the device (usually NONE), and the two
+// stages were two launches that both found nothing to do -- 9.1 us = 4.6 % of a 100 x 250 kb pass.  ONE launch: the
+// first n_tile workgroups are the tiles (ctiles x row groups), the next n_sel the selections; with no row listed every
+// workgroup leaves at once.  With rows: a tile workgroup publishes its keys (agent-scope fence: the selections run on
+// other XCDs) and counts itself in sync[0]; a selection waits for all n_tile of them.  Workgroups are dispatched in
+// index order and the tiles wait for nobody, so the wait cannot starve them; the last selection to finish clears the two
+// counters for the next launch on the same prepared state.  (The fences make the rare path slower than two launches;
+// launches with a host-known count -- refsize > 256, wc_newref_exact_dev -- keep the two kernels.)
+template <bool SEQ>
+__global__ __launch_bounds__(256) void k_exact_dev(FinishArgs a, const int *__restrict__ rows,
+                                                   const int *__restrict__ n_rows_dev, int *__restrict__ sync,
+                                                   unsigned long long *__restrict__ scratch, int64_t Bpad, int cap,
+                                                   int ctiles, int rgroups, int n_sel) {
+    constexpr int LDS = EXACT_TILE_LDS > EXACT_SELECT_LDS ? EXACT_TILE_LDS : EXACT_SELECT_LDS;
+    __shared__ __attribute__((aligned(16))) char smem[LDS];
+    const int count = *n_rows_dev;
+    if (count <= 0) return;
+    const int tid = threadIdx.x, n_tile = ctiles * rgroups, id = (int)blockIdx.x;
+    if (id < n_tile) {
+        exact_tile_body<SEQ>(a, rows, count > cap ? cap : count, 0, scratch, Bpad, id % ctiles, id / ctiles, rgroups, smem);
+        __threadfence();                               // this workgroup's keys are visible to the other XCDs ...
+        wc_sync();
+        if (tid == 0) atomicAdd(&sync[0], 1);          // ... before it counts itself in
+        return;
+    }
+    if (tid == 0) {
+        while (__hip_atomic_load(&sync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < n_tile) __builtin_amdgcn_s_sleep(8);
+        __threadfence();
+    }
+    wc_sync();
+    exact_select_body(a, rows, count, 0, scratch, Bpad, cap, id - n_tile, n_sel, true, smem);
+    wc_sync();
+    if (tid == 0 && atomicAdd(&sync[1], 1) == n_sel - 1) {
+        atomicExch(&sync[0], 0);
+        atomicExch(&sync[1], 0);
     }
 }
 
@@ -2251,12 +2308,11 @@ int wc_newref_thresholds_dev(wc_ctx *ctx, void *stream_, int64_t row_begin, int6
     unsigned sg = (unsigned)((row_end - row_begin + 3) / 4);
     {
         const unsigned int *kp = st.keys1.as<unsigned int>();
-        const int *cr = st.chrom_of_row.as<int>();
-        const int64_t *co = st.chrom_off_dev.as<int64_t>();
+        const int2 *cr = st.chrom_range.as<int2>();
         const int per_lane = (int)(st.n_sample_cols / 64);
 #define WC_SELECT(NV)                                                                                          \
     hipLaunchKernelGGL(k_select_thr<NV>, dim3(sg), dim3(256), 0, stream, kp, st.n_sample_cols,                \
-                       (int)st.n_sample_cols, cr, co, st.n_bins, row_begin, row_end, (int)st.expect, (int)st.cap, \
+                       (int)st.n_sample_cols, cr, st.n_bins, row_begin, row_end, (int)st.expect, (int)st.cap, \
                        st.thr.as<float>())
         if (per_lane <= 16) WC_SELECT(16);
         else if (per_lane <= 32) WC_SELECT(32);
@@ -2421,18 +2477,25 @@ static int launch_exact(NewrefState &st, hipStream_t stream, const FinishArgs &a
     const unsigned ctiles = (unsigned)((st.n_bins + edge - 1) / edge);
     unsigned long long *scratch = st.fb_scratch.as<unsigned long long>();
     const int *rows = st.fb_rows.as<int>();
-    const int *n_dev = n_host < 0 ? (const int *)st.fb_count.as<int>() : nullptr;
-    const int64_t total = n_host < 0 ? 1 : n_host;
-    for (int64_t first = 0; first < total; first += cap) {
-        const int64_t nf = n_host < 0 ? cap : std::min<int64_t>(cap, n_host - first);
-        // row groups in flight: a few when the count is unknown (surplus workgroups leave at once)
-        const unsigned rgroups = n_host < 0 ? 4u : (unsigned)((nf + edge - 1) / edge);
-        const unsigned nsel = n_host < 0 ? (unsigned)cap : (unsigned)nf;
-        if (seq) hipLaunchKernelGGL((k_exact_tile<true>), dim3(ctiles, rgroups), dim3(256), 0, stream, a, rows, n_dev,
-                                    (int)n_host, (int)first, scratch, st.bins_pad, cap);
-        else hipLaunchKernelGGL((k_exact_tile<false>), dim3(ctiles, rgroups), dim3(256), 0, stream, a, rows, n_dev,
-                                (int)n_host, (int)first, scratch, st.bins_pad, cap);
-        hipLaunchKernelGGL(k_exact_select, dim3(nsel), dim3(256), 0, stream, a, rows, n_dev, (int)n_host, (int)first,
+    if (n_host < 0) {
+        // count on the device: one launch (k_exact_dev); fb_count[1..2] are its two counters (zero between launches)
+        const int rgroups = 4;                         // row groups in flight (surplus workgroups leave at once)
+        int *sync = st.fb_count.as<int>() + 1;
+        const unsigned grid = ctiles * rgroups + (unsigned)cap;
+        if (seq) hipLaunchKernelGGL((k_exact_dev<true>), dim3(grid), dim3(256), 0, stream, a, rows,
+                                    (const int *)st.fb_count.as<int>(), sync, scratch, st.bins_pad, cap, (int)ctiles, rgroups, cap);
+        else hipLaunchKernelGGL((k_exact_dev<false>), dim3(grid), dim3(256), 0, stream, a, rows,
+                                (const int *)st.fb_count.as<int>(), sync, scratch, st.bins_pad, cap, (int)ctiles, rgroups, cap);
+        return WC_OK;
+    }
+    for (int64_t first = 0; first < n_host; first += cap) {
+        const int64_t nf = std::min<int64_t>(cap, n_host - first);
+        const unsigned rgroups = (unsigned)((nf + edge - 1) / edge);
+        if (seq) hipLaunchKernelGGL((k_exact_tile<true>), dim3(ctiles, rgroups), dim3(256), 0, stream, a, rows,
+                                    (const int *)nullptr, (int)n_host, (int)first, scratch, st.bins_pad, cap);
+        else hipLaunchKernelGGL((k_exact_tile<false>), dim3(ctiles, rgroups), dim3(256), 0, stream, a, rows,
+                                (const int *)nullptr, (int)n_host, (int)first, scratch, st.bins_pad, cap);
+        hipLaunchKernelGGL(k_exact_select, dim3((unsigned)nf), dim3(256), 0, stream, a, rows, (int)n_host, (int)first,
                            scratch, st.bins_pad, cap);
     }
     return WC_OK;

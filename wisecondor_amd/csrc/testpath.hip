@@ -583,7 +583,9 @@ __device__ inline void zscore_one(const int64_t b, const int64_t i, const int64_
                                   const double *__restrict__ XT, const double *__restrict__ XC,
                                   const int *__restrict__ gidx, const int *__restrict__ nref, int k, int64_t Ns,
                                   double *__restrict__ zT, double *__restrict__ rT, double *__restrict__ nT,
-                                  double *__restrict__ sdT) {
+                                  double *__restrict__ sdT, const int64_t osm = 0) {
+    // osm: 0 -- the outputs are bin-major like the inputs (index gid); otherwise they are SAMPLE-major with rows of
+    // osm bins (index i * osm + b): what the per-sample consumers read, written by the producer (no transposes)
     const int *lst = gidx + b * k;
     const int n = nref[b];
     StreamSum acc;
@@ -642,10 +644,11 @@ __device__ inline void zscore_one(const int64_t b, const int64_t i, const int64_
     const double var = acc.finish() / (double)m;
     const double sd = sqrt(var);
     const double x = XT[gid];
-    zT[gid] = (x - mean) / sd;
-    rT[gid] = x / mean;
-    nT[gid] = (double)m;
-    sdT[gid] = sd;
+    const int64_t oid = osm ? i * osm + b : gid;
+    zT[oid] = (x - mean) / sd;
+    rT[oid] = x / mean;
+    nT[oid] = (double)m;
+    sdT[oid] = sd;
 }
 
 // The same for a wave that holds ONE bin and 64 samples (b wave-uniform) when every lane keeps
@@ -806,11 +809,17 @@ __device__ inline int row_lane(const int x, const int from) {
     }
 #undef WC_ROW_LANE
 }
-template <int G, int WAVES, int NL>        // NL: 4-slot groups of the list held in registers (list stride k <= 4 NL <= 8 G + 8)
+template <int G, int WAVES, int NL, bool SM>   // NL: 4-slot groups of the list held in registers (list stride k <= 4 NL <= 8 G + 8); SM: sample-major outputs
 __global__ __launch_bounds__(64 * WAVES, 2) void k_zscore_tiled(const double *__restrict__ XT, const double *__restrict__ XC,
                                                          const int *__restrict__ gidx, const int *__restrict__ nref, int k,
                                                          int B, int Ns, double *__restrict__ zT, double *__restrict__ rT,
                                                          double *__restrict__ nT, double *__restrict__ sdT) {
+    const int64_t osm = SM ? B : 0;
+    // SM: the four outputs are written SAMPLE-major [Ns, B] -- the layout k_clean, k_inflate and the
+    // stdDevAvg kernels read -- instead of bin-major: k_transpose3 and k_transpose (0.14 ms of a 125 x 50 kb batch,
+    // 0.9 ms of 1 000 x 50 kb) are gone.  A wave's 4 bins x 16 samples are 16 runs of 32 bytes then; the lanes are
+    // permuted first (lane 4 s + q holds bin q of sample s) so that four neighbouring lanes write one run, and the
+    // four workgroups that complete a 128-byte line are neighbours on the same XCD (their writes merge in its L2).
     // tiles 0 .. 8 F - 1: tile t belongs to XCD t % 8; the R = n_tiles % 8 tiles left over are dealt to all XCDs by
     // (tile, workgroup) items, so that no XCD gets a whole extra tile
     const int n_tiles = Ns >> 4;
@@ -836,7 +845,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_zscore_tiled(const double *__
     const int b = live ? b0 + q2 : B - 1;
     const int64_t i = (int64_t)tile * 16 + sm, gid = (int64_t)b * Ns + i;
     if (k & 3) {
-        if (live) zscore_one(b, i, gid, XT, XC, gidx, nref, k, Ns, zT, rT, nT, sdT);
+        if (live) zscore_one(b, i, gid, XT, XC, gidx, nref, k, Ns, zT, rT, nT, sdT, osm);
         return;
     }
     const int n = nref[b];                         // (not needed before the sums: the list is read whatever its length)
@@ -874,7 +883,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_zscore_tiled(const double *__
             for (int e = 0; e < 8; ++e) top = max(top, (unsigned int)__double2hiint(v[8 * q + e]));
         }
     if (!__all(top < 0x7ff00000u || !live)) {
-        if (live) zscore_one(b, i, gid, XT, XC, gidx, nref, k, Ns, zT, rT, nT, sdT);
+        if (live) zscore_one(b, i, gid, XT, XC, gidx, nref, k, Ns, zT, rT, nT, sdT, osm);
         return;
     }
     // numpy's pairwise sum of m = 8 ng + (kept tail values) numbers: eight strided accumulators over the whole groups,
@@ -928,12 +937,27 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_zscore_tiled(const double *__
             sum = sum + sq;
         }
     const double var = sum / (double)m;
-    if (live) {
-        const double sd = sqrt(var);
-        zT[gid] = (x - mean) / sd;
-        rT[gid] = x / mean;
-        nT[gid] = (double)m;
-        sdT[gid] = sd;
+    const double sd = sqrt(var);
+    if (!SM) {
+        if (live) {
+            zT[gid] = (x - mean) / sd;
+            rT[gid] = x / mean;
+            nT[gid] = (double)m;
+            sdT[gid] = sd;
+        }
+        return;
+    }
+    // sample-major: destination lane d = 4 s + q takes the results of source lane 16 q + s
+    const int src = ((lane & 3) << 4) | (lane >> 2);
+    const double zo = __shfl((x - mean) / sd, src), ro = __shfl(x / mean, src), no = __shfl((double)m, src),
+                 so = __shfl(sd, src);
+    const int ob = b0 + (lane & 3);
+    if (ob < B) {
+        const int64_t oid = ((int64_t)tile * 16 + (lane >> 2)) * osm + ob;
+        zT[oid] = zo;
+        rT[oid] = ro;
+        nT[oid] = no;
+        sdT[oid] = so;
     }
 }
 
@@ -993,7 +1017,7 @@ __device__ inline void zscore_pair8(const unsigned int gid, const int sub, const
                                     const double *__restrict__ XT, const double *__restrict__ XC,
                                     const int *__restrict__ gidx, const int *__restrict__ nref, int k, int64_t Ns,
                                     double *__restrict__ zT, double *__restrict__ rT, double *__restrict__ nT,
-                                    double *__restrict__ sdT) {
+                                    double *__restrict__ sdT, const int64_t osm = 0) {
     const int64_t b = gid / Ns, i = gid - b * Ns;
     const int *lst = gidx + b * k;
     const int n = nref[b];
@@ -1064,10 +1088,11 @@ __device__ inline void zscore_pair8(const unsigned int gid, const int sub, const
     if (sub == 0) {
         const double sd = sqrt(var);
         const double x = XT[gid];
-        zT[gid] = (x - mean) / sd;
-        rT[gid] = x / mean;
-        nT[gid] = (double)m;
-        sdT[gid] = sd;
+        const int64_t oid = osm ? i * osm + b : (int64_t)gid;       // (osm: sample-major outputs, see zscore_one)
+        zT[oid] = (x - mean) / sd;
+        rT[oid] = x / mean;
+        nT[oid] = (double)m;
+        sdT[oid] = sd;
     }
 }
 
@@ -1078,13 +1103,13 @@ __global__ __launch_bounds__(256) void k_zscore_pairs(const unsigned int *__rest
                                                       const int *__restrict__ gidx, const int *__restrict__ nref,
                                                       int k, int64_t Ns, double *__restrict__ zT,
                                                       double *__restrict__ rT, double *__restrict__ nT,
-                                                      double *__restrict__ sdT) {
+                                                      double *__restrict__ sdT, int64_t osm) {
     const int64_t n_pairs = pairs ? (int64_t)*count : n_all;
     const int lane = threadIdx.x & 63, sub = lane & 7, gbase = lane & ~7;
     for (int64_t t = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3; t < n_pairs; t += (int64_t)gridDim.x * 32) {
         const unsigned int gid = pairs ? pairs[t] : (unsigned int)t;
         if (pairs && sub == 0) atomicAnd(&dirty[gid >> 5], ~(1u << (gid & 31)));
-        zscore_pair8(gid, sub, gbase, XT, XC, gidx, nref, k, Ns, zT, rT, nT, sdT);
+        zscore_pair8(gid, sub, gbase, XT, XC, gidx, nref, k, Ns, zT, rT, nT, sdT, osm);
     }
 }
 
@@ -1189,8 +1214,14 @@ __device__ inline void flag_wave_vals(const int64_t gid, const bool valid, const
 __device__ inline void flag_wave(const int64_t gid, const bool valid, const double *__restrict__ zT, double thr,
                                  int64_t Ns, double *__restrict__ XC, const int *__restrict__ users_off,
                                  const int *__restrict__ users, unsigned int *__restrict__ dirty,
-                                 unsigned int *__restrict__ next_pairs, int *__restrict__ next_count) {
-    flag_wave_vals(gid, valid, valid ? zT[gid] : 0.0, valid ? XC[gid] : -1.0, thr, Ns, XC, users_off, users, dirty,
+                                 unsigned int *__restrict__ next_pairs, int *__restrict__ next_count,
+                                 const int64_t osm = 0) {
+    int64_t zid = gid;
+    if (osm) {                                    // sample-major z (see zscore_one)
+        const int64_t b = gid / Ns;
+        zid = (gid - b * Ns) * osm + b;
+    }
+    flag_wave_vals(gid, valid, valid ? zT[zid] : 0.0, valid ? XC[gid] : -1.0, thr, Ns, XC, users_off, users, dirty,
                    next_pairs, next_count);
 }
 
@@ -1201,6 +1232,19 @@ __global__ __launch_bounds__(256) void k_flag(const double *__restrict__ zT, dou
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     flag_wave(gid, gid < n, zT, thr, Ns, XC, users_off, users, dirty, next_pairs, next_count);
 }
+// the same over SAMPLE-major z-scores [Ns, B]: workgroup (x, i) reads 256 consecutive bins of sample i; the working
+// value of a pair (bin-major, a line of its own per lane) is only read where |z| reaches the threshold
+__global__ __launch_bounds__(256) void k_flag_sm(const double *__restrict__ zS, double thr, int64_t B, int64_t Ns,
+                                                 double *__restrict__ XC, const int *__restrict__ users_off,
+                                                 const int *__restrict__ users, unsigned int *__restrict__ dirty,
+                                                 unsigned int *__restrict__ next_pairs, int *__restrict__ next_count) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    const bool valid = b < B;
+    const double zv = valid ? zS[i * B + b] : 0.0;
+    const int64_t gid = valid ? b * Ns + i : 0;
+    const double xcv = (valid && fabs(zv) >= thr) ? XC[gid] : -1.0;
+    flag_wave_vals(gid, valid, zv, xcv, thr, Ns, XC, users_off, users, dirty, next_pairs, next_count);
+}
 
 // the same over the pairs this repeat recomputed (nothing else can have changed)
 __global__ __launch_bounds__(256) void k_flag_pairs(const unsigned int *__restrict__ pairs,
@@ -1209,13 +1253,13 @@ __global__ __launch_bounds__(256) void k_flag_pairs(const unsigned int *__restri
                                                     const int *__restrict__ users_off, const int *__restrict__ users,
                                                     unsigned int *__restrict__ dirty,
                                                     unsigned int *__restrict__ next_pairs,
-                                                    int *__restrict__ next_count) {
+                                                    int *__restrict__ next_count, int64_t osm) {
     const int64_t n = *count;
     const int lane = threadIdx.x & 63;
     for (int64_t t0 = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63); t0 < n; t0 += (int64_t)gridDim.x * 256) {
         const int64_t t = t0 + lane;
         flag_wave(t < n ? (int64_t)pairs[t] : 0, t < n, zT, thr, Ns, XC, users_off, users, dirty, next_pairs,
-                  next_count);
+                  next_count, osm);
     }
 }
 
@@ -1297,7 +1341,8 @@ __global__ __launch_bounds__(1024) void k_lat_repeats(unsigned int *__restrict__
 template <int SPB>
 __global__ __launch_bounds__(256) void k_sd_avg(const double *__restrict__ sdT, int64_t B, int64_t Ns,
                                                 double *__restrict__ out, const int *__restrict__ only,
-                                                double *__restrict__ out2) {
+                                                double *__restrict__ out2, int64_t sb, int64_t si) {
+    // (sb, si): strides per bin and per sample -- (Ns, 1) for the bin-major array, (1, B) for the sample-major one
     constexpr int PH = 256 / SPB;                 // bin phases: thread (ss, bq) stages bins bq, bq + PH, ...
     constexpr int CH = 32 * PH;                   // bins per chunk
     __shared__ double buf[CH][SPB];
@@ -1316,7 +1361,7 @@ __global__ __launch_bounds__(256) void k_sd_avg(const double *__restrict__ sdT, 
 #pragma unroll
         for (int u = 0; u < 32; ++u) {
             const int64_t b = base + bq + PH * u;
-            const double x = (live && b < B) ? sdT[b * Ns + i] : NAN;
+            const double x = (live && b < B) ? sdT[b * sb + i * si] : NAN;
             const bool ok = x == x;
             cnt += ok;
             pre[u] = ok ? x : 0.0;
@@ -2125,44 +2170,38 @@ __device__ inline double window_eps(int n, double abs_sum) {
 constexpr int QB = 32;              // window ends per end block
 constexpr int Q_WORK = 1024;        // undecided (row, end block) pairs a block can queue (10 KB of LDS in all: 8 blocks per CU)
 constexpr int Q_BLOCKS = 256;       // end blocks of one job held in LDS (jobs up to ~8 k bins)
-// One workgroup = 256 consecutive entries = eight blocks: coalesced reads, a half-wave reduces a block.  tmin2 /
-// tmax2 (optional): the second level, minimum and maximum of every 128-entry block (four first-level blocks), for
-// the bound-driven search's long windows.
+// One workgroup = 1 024 consecutive entries: a thread loads four (two 16-byte loads), eight lanes reduce a block of 32,
+// 32 lanes a second-level block of 128 (tmin2 / tmax2: minimum and maximum of every 128-entry block, for the
+// bound-driven search's long windows) -- shuffles only.  (Round 5's form took one entry per thread: 27 000 workgroups
+// for a 125 x 50 kb batch, 48 us for 55 MB.)
+typedef double f64x2_t __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void k_block_minmax(const double *__restrict__ prefix, int64_t total,
                                                       double *__restrict__ tmin, double *__restrict__ tmax,
-                                                      double *__restrict__ tmin2, double *__restrict__ tmax2,
-                                                      double *__restrict__ t8min = nullptr,
-                                                      double *__restrict__ t8max = nullptr) {
-    __shared__ double s_mn[8], s_mx[8];
+                                                      double *__restrict__ tmin2, double *__restrict__ tmax2) {
     const int tid = threadIdx.x;
-    const int64_t at = (int64_t)blockIdx.x * 256 + tid;
+    const int64_t at = ((int64_t)blockIdx.x * 256 + tid) * 4;
     double mn = INFINITY, mx = -INFINITY;
-    if (at < total) mn = mx = prefix[at];
+    if (at + 4 <= total) {
+        const f64x2_t a = *reinterpret_cast<const f64x2_t *>(prefix + at), b = *reinterpret_cast<const f64x2_t *>(prefix + at + 2);
+        mn = fmin(fmin(a.x, a.y), fmin(b.x, b.y));
+        mx = fmax(fmax(a.x, a.y), fmax(b.x, b.y));
+    } else {
+        for (int e = 0; e < 4; ++e)
+            if (at + e < total) { mn = fmin(mn, prefix[at + e]); mx = fmax(mx, prefix[at + e]); }
+    }
     for (int o = 1; o < 8; o <<= 1) {
         mn = fmin(mn, __shfl_xor(mn, o));
         mx = fmax(mx, __shfl_xor(mx, o));
     }
-    // (optional) the level below: minimum and maximum of every 8 entries, for the cell-driven search's near windows
-    if (t8min && (tid & 7) == 0 && at < total) { t8min[at >> 3] = mn; t8max[at >> 3] = mx; }
+    const int64_t k = (int64_t)blockIdx.x * 32 + (tid >> 3);
+    if ((tid & 7) == 0 && k * QB < total) { tmin[k] = mn; tmax[k] = mx; }
+    if (!tmin2) return;
     for (int o = 8; o < 32; o <<= 1) {
         mn = fmin(mn, __shfl_xor(mn, o));
         mx = fmax(mx, __shfl_xor(mx, o));
     }
-    const int64_t k = (int64_t)blockIdx.x * 8 + (tid >> 5);
-    const bool real = k * QB < total;
-    if ((tid & 31) == 0) {
-        if (real) { tmin[k] = mn; tmax[k] = mx; }
-        s_mn[tid >> 5] = mn;
-        s_mx[tid >> 5] = mx;
-    }
-    if (!tmin2) return;
-    wc_sync();
-    if (tid < 2 && ((int64_t)blockIdx.x * 2 + tid) * (4 * QB) < total) {
-        double a = s_mn[4 * tid], b = s_mx[4 * tid];
-        for (int q = 1; q < 4; ++q) { a = fmin(a, s_mn[4 * tid + q]); b = fmax(b, s_mx[4 * tid + q]); }
-        tmin2[(int64_t)blockIdx.x * 2 + tid] = a;
-        tmax2[(int64_t)blockIdx.x * 2 + tid] = b;
-    }
+    const int64_t k2 = (int64_t)blockIdx.x * 8 + (tid >> 5);
+    if ((tid & 31) == 0 && k2 * (4 * QB) < total) { tmin2[k2] = mn; tmax2[k2] = mx; }
 }
 
 // (second level: beyond 512 bins a 128-end block loosens the bound by less than a 32-end block does at 64)
@@ -4845,13 +4884,62 @@ __global__ __launch_bounds__(256) void k_walk_rows(const Seg *__restrict__ wsegs
     __shared__ int s_nan, s_rank;
     const int tid = threadIdx.x;
     const int total = *n_segs_dev < seg_cap ? *n_segs_dev : seg_cap;
+    // ---- segments of at most 64 bins (most calls: a noise spike of a bin or two), a WAVE each, no barriers: a lane per
+    // ratio, the counting median by lane broadcasts (64 x readlane + two compares), the rank among the region's
+    // segments by a ballot.  A workgroup per item spent ~20 us of dependent round trips and barriers on each of them
+    // whatever its length (round 5: 53 us for the 1 283 rows of a 125 x 50 kb batch, 171 us for 9 348 rows).
+    {
+        const int lane = tid & 63;
+        const int n_waves = (int)gridDim.x * 4, wave = (int)blockIdx.x * 4 + (tid >> 6);
+        for (int item = wave; item < total; item += n_waves) {
+            const Seg me = wsegs[item];
+            const int x = me.x, y = me.y, Ls = y - x + 1;
+            if (Ls > 64) continue;                             // (wave-uniform)
+            const int region = me.region, nseg = me.pad >> 16, first = item - (me.pad & 0xFFFF);
+            const Region rg = regions[region];
+            int rank = 0;
+            for (int t0 = 0; t0 < nseg; t0 += 64) {
+                const int t = t0 + lane;
+                rank += __popcll(__ballot(t < nseg && first + t < total && wsegs[first + t].x < x));
+            }
+            if (rank >= max_calls) continue;
+            const double v = lane < Ls ? ratio[rg.off + x + lane] : 0.0;
+            const bool has_nan = __ballot(lane < Ls && v != v) != 0ull;
+            const int k_lo = (Ls - 1) / 2, k_hi = Ls / 2;
+            int lt = 0, le = 0;
+            for (int u = 0; u < Ls; ++u) {
+                const double yv = __shfl(v, u);
+                lt += yv < v;
+                le += yv <= v;
+            }
+            // the lanes whose count interval covers a middle rank hold that order statistic (equal values: any of them)
+            const unsigned long long m_lo = __ballot(lane < Ls && lt <= k_lo && k_lo < le);
+            const unsigned long long m_hi = __ballot(lane < Ls && lt <= k_hi && k_hi < le);
+            const double lo = __shfl(v, m_lo ? __ffsll((long long)m_lo) - 1 : 0);
+            const double hi = __shfl(v, m_hi ? __ffsll((long long)m_hi) - 1 : 0);
+            if (lane == 0) {
+                double med = (Ls & 1) ? lo : (lo + hi) / 2.0;  // np.median: mean of the middle pair
+                if (has_nan) med = NAN;
+                const int start = gpos[rg.off + x];
+                const int end = (y > x) ? gpos[rg.off + y - 1] + 1 : start;
+                double *o = reg_calls + ((int64_t)region * max_calls + rank) * 5;
+                o[0] = (double)(rg.pad + 1);
+                o[1] = (double)start;
+                o[2] = (double)end;
+                o[3] = me.val;
+                o[4] = med - 1.0;
+            }
+        }
+    }
+    // ---- longer segments, a workgroup each
     // (workgroup w takes items w, w + gridDim.x, ...: they cost about the same, and a cursor would put one more global
     //  round trip in front of every item)
     for (int item = blockIdx.x; item < total; item += gridDim.x) {
+        const Seg me = wsegs[item];
+        if (me.y - me.x + 1 <= 64) continue;                   // (done above)
         wc_sync();
         if (tid == 0) { s_nan = 0; s_rank = 0; }
         wc_sync();
-        const Seg me = wsegs[item];
         const int region = me.region, nseg = me.pad >> 16, first = item - (me.pad & 0xFFFF);
         const Region rg = regions[region];
         const int x = me.x, y = me.y, Ls = y - x + 1;
@@ -4975,11 +5063,25 @@ static int reserve_repeat_arrays(TestState &ts, int64_t n, int64_t Ns) {
 // repeatTest on device data [Ns, B]; leaves zt/rt/nt/sdt as [B, Ns] and sd_avg[Ns]
 // lat: latency mode -- k_lat_prepare has already written xt / xc and cleared the counters; the first
 // repeat runs as usual, repeats 2.. in one launch (k_lat_repeats; its overflow flag is pair_counts[repeats + 1])
+// allow_sm: the caller reads z / ratio / counts / sd per SAMPLE and takes them in either layout: when the first repeat
+// runs the tiled kernel they are written sample-major [Ns, B] straight away (ts.sm_out tells which it was)
 int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int64_t Ns, double thr, int repeats,
-               hipStream_t stream, bool lat = false, double *asdef_out = nullptr, bool xt_ready = false) {
+               hipStream_t stream, bool lat = false, double *asdef_out = nullptr, bool xt_ready = false,
+               bool allow_sm = false) {
     TestState &ts = ctx->ts;
     const int64_t n = ref->B * Ns;
     int rc;
+    const char *tiled_env = getenv("WC_ZSCORE_TILED");       // "0": the untiled kernel (a wave = one bin x 64 samples)
+    const char *sm_env = getenv("WC_ZSCORE_SM");             // "0": bin-major outputs + the transposes (round 5's form)
+    // (fewer than eight tiles would leave XCDs idle or without a column of their own: the untiled kernel)
+    const bool tiled = !lat && repeats >= 1 && ref->k <= 128 && Ns >= 128 && (Ns & 15) == 0 &&
+                       (ref->B + 1) * Ns * 8 < ((int64_t)1 << 32) && ref->B < (1 << 24) && Ns * 8 < (1 << 24) &&
+                       !(tiled_env && tiled_env[0] == '0');
+    // (a list stride above 100 -- refsize 101 .. 128 -- needs 104 value slots: with the output permutation that form
+    //  spills six registers, so those references keep the bin-major outputs and the transposes)
+    const bool sm_out = tiled && allow_sm && ref->k <= 100 && !(sm_env && sm_env[0] == '0');
+    const int64_t osm = sm_out ? ref->B : 0;
+    ts.sm_out = sm_out;
     // a caller whose prepare kernel has ALREADY written xt / xc must have sized them with reserve_repeat_arrays: a
     // reserve that grows a buffer frees it (DevBuf keeps no contents) and the z-scores would read fresh memory
     if (lat || xt_ready)
@@ -5041,12 +5143,9 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
                 hipLaunchKernelGGL(k_flag_pairs, dim3((unsigned)std::min<int64_t>(g, 2048)), dim3(256), 0, stream,
                                    (const unsigned int *)cur, (const int *)(pair_counts + it),
                                    (const double *)ts.zt.as<double>(), thr, Ns, ts.xc.as<double>(), uoff, ulst, dirty,
-                                   next, pair_counts + it + 1);
+                                   next, pair_counts + it + 1, (int64_t)0);
         } else if (it == 0) {
-            const char *tiled_env = getenv("WC_ZSCORE_TILED");       // "0": the untiled kernel (a wave = one bin x 64 samples)
-            // (fewer than eight tiles would leave XCDs idle or without a column of their own: the untiled kernel)
-            if (Ns >= 128 && (Ns & 15) == 0 && (ref->B + 1) * Ns * 8 < ((int64_t)1 << 32) && ref->B < (1 << 24) &&
-                Ns * 8 < (1 << 24) && !(tiled_env && tiled_env[0] == '0')) {
+            if (tiled) {
                 constexpr int ZT_G = 12;
                 constexpr int zwaves = 1;                           // (one wave per workgroup: a slot is refilled as soon as it frees; 2 and 4 measured 1-2 % slower)
                 const int64_t zgroups = cdiv(ref->B, 4 * zwaves), ztiles = Ns / 16;
@@ -5054,7 +5153,9 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
                 hipLaunchKernelGGL(k_fill, dim3((unsigned)cdiv(Ns, 256)), dim3(256), 0, stream, ts.xc.as<double>() + ref->B * Ns,
                                    Ns, -1.0);                       // row B of xc: what an index of -1 reads
                 // (a list stride of up to 100 -- refsize 100 -- needs 100 value slots, not the 104 of 8 G + 8)
-                hipLaunchKernelGGL((ref->k <= 100 ? k_zscore_tiled<ZT_G, zwaves, 25> : k_zscore_tiled<ZT_G, zwaves, 26>), dim3((unsigned)n_wg), dim3(64 * zwaves), 0, stream,
+                auto zk = sm_out ? k_zscore_tiled<ZT_G, zwaves, 25, true>
+                                 : (ref->k <= 100 ? k_zscore_tiled<ZT_G, zwaves, 25, false> : k_zscore_tiled<ZT_G, zwaves, 26, false>);
+                hipLaunchKernelGGL(zk, dim3((unsigned)n_wg), dim3(64 * zwaves), 0, stream,
                                    (const double *)ts.xt.as<double>(), (const double *)ts.xc.as<double>(),
                                    (const int *)ref->gidx.as<int>(), (const int *)ref->nref.as<int>(), ref->k,
                                    (int)ref->B, (int)Ns, ts.zt.as<double>(), ts.rt.as<double>(), ts.nt.as<double>(),
@@ -5070,9 +5171,13 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
                                    stream, (const unsigned int *)nullptr, (const int *)nullptr, n, dirty,
                                    (const double *)ts.xt.as<double>(), (const double *)ts.xc.as<double>(),
                                    (const int *)ref->gidx.as<int>(), (const int *)ref->nref.as<int>(), ref->k, Ns,
-                                   ts.zt.as<double>(), ts.rt.as<double>(), ts.nt.as<double>(), ts.sdt.as<double>());
+                                   ts.zt.as<double>(), ts.rt.as<double>(), ts.nt.as<double>(), ts.sdt.as<double>(), (int64_t)0);
             }
-            if (!lat_flag_inside)
+            if (sm_out)
+                hipLaunchKernelGGL(k_flag_sm, dim3((unsigned)cdiv(ref->B, 256), (unsigned)Ns), dim3(256), 0, stream,
+                                   (const double *)ts.zt.as<double>(), thr, ref->B, Ns, ts.xc.as<double>(), uoff, ulst, dirty,
+                                   next, pair_counts + it + 1);
+            else if (!lat_flag_inside)
                 hipLaunchKernelGGL(k_flag, dim3(g), dim3(256), 0, stream, (const double *)ts.zt.as<double>(), thr, n, Ns,
                                    ts.xc.as<double>(), uoff, ulst, dirty, next, pair_counts + it + 1);
         } else {
@@ -5081,10 +5186,10 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
                                (const int *)(pair_counts + it), (int64_t)0, dirty, (const double *)ts.xt.as<double>(),
                                (const double *)ts.xc.as<double>(), (const int *)ref->gidx.as<int>(),
                                (const int *)ref->nref.as<int>(), ref->k, Ns, ts.zt.as<double>(), ts.rt.as<double>(),
-                               ts.nt.as<double>(), ts.sdt.as<double>());
+                               ts.nt.as<double>(), ts.sdt.as<double>(), osm);
             hipLaunchKernelGGL(k_flag_pairs, dim3(gp), dim3(256), 0, stream, (const unsigned int *)cur,
                                (const int *)(pair_counts + it), (const double *)ts.zt.as<double>(), thr, Ns,
-                               ts.xc.as<double>(), uoff, ulst, dirty, next, pair_counts + it + 1);
+                               ts.xc.as<double>(), uoff, ulst, dirty, next, pair_counts + it + 1, osm);
         }
     }
     // stdDevAvg only feeds the asdef output: it runs on the context's side stream under the
@@ -5111,7 +5216,11 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
     double *out2 = lat ? asdef_out : nullptr;
     if (ref->B <= 65536) {
         if ((rc = ts.sd_fail.reserve(sizeof(int) * Ns))) return rc;
-        if (Ns > 8) {
+        if (sm_out) {
+            // the first repeat wrote the standard deviations sample-major already
+            launch_sd_fast(sds, ts.sdt.as<double>(), ref->B, Ns, ts.sd_avg.as<double>(), ts.sd_fail.as<int>(), out2, 1,
+                           ref->B);
+        } else if (Ns > 8) {
             // a batch: the sums run over a sample-major copy (a sample's standard deviations contiguous): in
             // the bin-major array every element of a sample sits in a cache line of its own, and 125
             // workgroups walking 55 337 such lines three times kept the side stream busy for 0.4 ms
@@ -5133,10 +5242,11 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
         // (status word 33) instead of costing every call a launch
     } else if (Ns <= 16)
         hipLaunchKernelGGL(k_sd_avg<16>, dim3((unsigned)cdiv(Ns, 16)), dim3(256), 0, sds,
-                           (const double *)ts.sdt.as<double>(), ref->B, Ns, ts.sd_avg.as<double>(), only, out2);
+                           (const double *)ts.sdt.as<double>(), ref->B, Ns, ts.sd_avg.as<double>(), only, out2, Ns, (int64_t)1);
     else
         hipLaunchKernelGGL(k_sd_avg<64>, dim3((unsigned)cdiv(Ns, 64)), dim3(256), 0, sds,
-                           (const double *)ts.sdt.as<double>(), ref->B, Ns, ts.sd_avg.as<double>(), only, out2);
+                           (const double *)ts.sdt.as<double>(), ref->B, Ns, ts.sd_avg.as<double>(), only, out2,
+                           sm_out ? (int64_t)1 : Ns, sm_out ? ref->B : (int64_t)1);
     WC_HIP(hipEventRecord(ctx->ev_join, ctx->side));
     ctx->side_pending = true;
     WC_HIP(hipGetLastError());
@@ -5320,7 +5430,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
         const int64_t nblk2 = cdiv(nblk, 4);
         if ((rc = ts.tmin2.reserve(sizeof(double) * nblk2))) return rc;
         if ((rc = ts.tmax2.reserve(sizeof(double) * nblk2))) return rc;
-        hipLaunchKernelGGL(k_block_minmax, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream,
+        hipLaunchKernelGGL(k_block_minmax, dim3((unsigned)cdiv(total, 1024)), dim3(256), 0, stream,
                            (const double *)ts.prefix.as<double>(), total, ts.tmin.as<double>(), ts.tmax.as<double>(),
                            ts.tmin2.as<double>(), ts.tmax2.as<double>());
     }
@@ -5940,7 +6050,7 @@ int wc_std_dev_avg(wc_ctx *ctx, const double *sd, int64_t n_samples, int64_t n_b
     }
     hipLaunchKernelGGL(k_sd_avg<64>, dim3((unsigned)cdiv(n_samples, 64)), dim3(256), 0, nullptr,
                        (const double *)ts.sdt.as<double>(), n_bins, n_samples, ts.sd_avg.as<double>(), only,
-                       (double *)nullptr);
+                       (double *)nullptr, n_samples, (int64_t)1);
     WC_HIP(hipDeviceSynchronize());
     WC_HIP(hipMemcpy(out, ts.sd_avg.p, sizeof(double) * n_samples, hipMemcpyDeviceToHost));
     if (serial_samples) {
@@ -6064,7 +6174,7 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
                            ts.misc2.as<int>(), repeats > 0 ? repeats + 2 + n_words : 0);
     }
     ts.mark(1, stream);
-    if ((rc = run_repeat(ctx, ref, ts.data.as<double>(), Np, threshold, repeats, stream, lat, asdef, !lat))) return rc;
+    if ((rc = run_repeat(ctx, ref, ts.data.as<double>(), Np, threshold, repeats, stream, lat, asdef, !lat, !lat))) return rc;
     ts.mark(2, stream);
     struct Joiner {   // asdef is copied out once the side stream's sum is done, on every exit path
         wc_ctx *c; hipStream_t s; double *dst; int64_t n; bool on;
@@ -6081,7 +6191,10 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
     // (latency mode: the few samples are read straight from the bin-major arrays)
     const double *zsrc = ts.zt.as<double>(), *rsrc = ts.rt.as<double>(), *nsrc = ts.nt.as<double>();
     int64_t str_i = 1, str_b = Ns;
-    if (!lat) {
+    if (!lat && ts.sm_out) {
+        // the tiled first repeat (and the later repeats behind it) wrote them sample-major: nothing to transpose
+        str_i = B; str_b = 1;
+    } else if (!lat) {
         for (wc::DevBuf *b : {&ts.zs, &ts.rs2, &ts.ns2})
             if ((rc = b->reserve(sizeof(double) * Np * B))) return rc;
         dim3 g3((unsigned)cdiv(Np, 32), (unsigned)cdiv(B, 32), 3);
