@@ -231,3 +231,21 @@ def test_a_region_that_overflows_the_cell_queues(wt, monkeypatch):
         v = (P[ln:] - P[:-ln]) / np.sqrt(ln)
         best = max(best, float(np.abs(v).max()))
     assert abs(max(abs(v) for v, _ in segs1[0]) - best) < 1e-9
+
+
+@pytest.mark.parametrize("which", ["250kb", "50kb"])
+def test_big_call_repeats_bit_for_bit(wt, case250, case50, monkeypatch, which):
+    """The 1 000-sample call, several times, against ONE run of a second implementation of the segmentation (the
+    host-driven levels, WC_TEST_WALK=0) and of the z-score outputs' layout (WC_ZSCORE_SM=0: bin-major + transposes):
+    every member of every sample's result bit for bit, every time (round 5's defect only showed from run to run)."""
+    case = case250 if which == "250kb" else case50
+    thr = case["threshold"]
+    monkeypatch.setenv("WC_TEST_WALK", "0")
+    monkeypatch.setenv("WC_ZSCORE_SM", "0")
+    want = wt.test_batch(case["reference"], case["tests"], thr)
+    monkeypatch.delenv("WC_TEST_WALK")
+    monkeypatch.delenv("WC_ZSCORE_SM")
+    for _ in range(4):
+        got = wt.test_batch(case["reference"], case["tests"], thr)
+        for i, (a, b) in enumerate(zip(want, got)):
+            assert_same_outputs(a, b, i)

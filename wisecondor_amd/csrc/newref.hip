@@ -1203,23 +1203,37 @@ struct PickArgs {
 
 // Selection for one row by one wave; NE list entries per lane.  Returns the number of pairs, -1
 // when the row has no certificate (exact path).
-template <int NE>
+// LEAN (the lists beyond 512 entries, a few rows at most): only the KEYS stay in registers through the bisection; the
+// candidate numbers and the candidates' slacks are read again where they are needed (the list is L2-hot) -- the full
+// form of sixteen entries per lane took 77 registers and with them the whole kernel's occupancy (six waves per SIMD).
+template <int NE, bool LEAN>
 __device__ inline int pick_row(const PickArgs &p, int64_t row, int lane, int n, bool admit_all, float thr_f,
                                float nhi_f, const unsigned long long (&spec)[8]) {
     const FinishArgs &a = p.f;
     const unsigned long long *lst = a.list + row * a.cap;
-    unsigned long long ent[NE];
-    float nh[NE];
+    unsigned long long ent[LEAN ? 1 : NE];
+    float nh[LEAN ? 1 : NE];
+    uint32_t key[LEAN ? NE : 1];
+    if constexpr (LEAN) {
 #pragma unroll
-    for (int e = 0; e < NE; ++e) {
-        const int t = e * 64 + lane;
-        ent[e] = t < n ? (e < 8 ? spec[e] : lst[t]) : ~0ull;
-    }
+        for (int e = 0; e < NE; ++e) {
+            const int t = e * 64 + lane;
+            key[e] = t < n ? (uint32_t)((e < 8 ? spec[e] : lst[t]) >> 32) : 0xFFFFFFFFu;
+        }
+    } else {
 #pragma unroll
-    for (int e = 0; e < NE; ++e) {
-        const int t = e * 64 + lane;
-        nh[e] = t < n ? a.norm_hi[(int)(uint32_t)ent[e]] : 0.f;
+        for (int e = 0; e < NE; ++e) {
+            const int t = e * 64 + lane;
+            ent[e] = t < n ? (e < 8 ? spec[e] : lst[t]) : ~0ull;
+        }
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int t = e * 64 + lane;
+            nh[e] = t < n ? a.norm_hi[(int)(uint32_t)ent[e]] : 0.f;
+        }
     }
+    auto KU = [&](int e) -> uint32_t { if constexpr (LEAN) return key[e]; else return (uint32_t)(ent[e] >> 32); };
+    auto IDX = [&](int e) -> uint32_t { if constexpr (LEAN) return (uint32_t)lst[e * 64 + lane]; else return (uint32_t)ent[e]; };
     double U = INFINITY;   // admit-all rows with fewer than k candidates re-score everything
     if (n < a.k) {
         if (!admit_all) return -1;
@@ -1233,7 +1247,7 @@ __device__ inline int pick_row(const PickArgs &p, int64_t row, int lane, int n, 
 #pragma unroll
         for (int e = 0; e < NE; ++e)
             if (e * 64 + lane < n) {
-                const uint32_t ku = (uint32_t)(ent[e] >> 32);
+                const uint32_t ku = KU(e);
                 kmin = ku < kmin ? ku : kmin;
                 kmax = ku > kmax ? ku : kmax;
             }
@@ -1250,7 +1264,7 @@ __device__ inline int pick_row(const PickArgs &p, int64_t row, int lane, int n, 
             const uint32_t trial = (uint32_t)(lo + ((hi - lo) >> 1));
             int c = 0;
 #pragma unroll
-            for (int e = 0; e < NE; ++e) c += __popcll(__ballot((uint32_t)(ent[e] >> 32) <= trial));
+            for (int e = 0; e < NE; ++e) c += __popcll(__ballot(KU(e) <= trial));
             // entries beyond n carry ~0 keys: never counted (trial < 2^32 - 1 whenever the loop runs)
             if (c >= a.k) { hi = (long long)trial; res = trial; if (c == a.k) break; }
             else lo = (long long)trial;
@@ -1260,9 +1274,11 @@ __device__ inline int pick_row(const PickArgs &p, int64_t row, int lane, int n, 
         double my = -INFINITY;
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
-            const uint32_t ku = (uint32_t)(ent[e] >> 32);
+            const uint32_t ku = KU(e);
             if (e * 64 + lane < n && ku <= res) {
-                const double ub = (double)wc::f32_from_ordered(ku) + (nhi + (double)nh[e]) + 1e-36;
+                float slack;
+                if constexpr (LEAN) slack = a.norm_hi[(int)IDX(e)]; else slack = nh[e];
+                const double ub = (double)wc::f32_from_ordered(ku) + (nhi + (double)slack) + 1e-36;
                 my = fmax(my, ub);
             }
         }
@@ -1285,16 +1301,16 @@ __device__ inline int pick_row(const PickArgs &p, int64_t row, int lane, int n, 
     int *out = p.pairs + row * RMAX;
 #pragma unroll
     for (int e = 0; e < NE; ++e) {
-        const bool keep = e * 64 + lane < n && (double)wc::f32_from_ordered((uint32_t)(ent[e] >> 32)) <= U;
+        const bool keep = e * 64 + lane < n && (double)wc::f32_from_ordered(KU(e)) <= U;
         const unsigned long long m = __ballot(keep);
         const int at = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (keep && at < RMAX) out[at] = (int)(uint32_t)ent[e];
+        if (keep && at < RMAX) out[at] = (int)IDX(e);
         base += __popcll(m);
     }
     return base;
 }
 
-__global__ __launch_bounds__(256) void k_pick(PickArgs p) {
+__global__ __launch_bounds__(256, 7) void k_pick(PickArgs p) {   // (seven waves per SIMD, 72 registers: the 11 087 rows of cfg2 are 1.55 rounds of the chip instead of 1.8; eight would spill)
     const FinishArgs &a = p.f;
     const int lane = threadIdx.x & 63;
     const int64_t row = a.row_begin + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1311,8 +1327,8 @@ __global__ __launch_bounds__(256) void k_pick(PickArgs p) {
     const bool admit_all = (thr_f == WC_ADMIT_ALL);
     const bool exact = c > a.cap || ((a.lone_mask >> ch) & 1ull);   // lost entries / C-ordered chromData: exact path
     int R = -1;
-    if (!exact) R = c <= 512 ? pick_row<8>(p, row, lane, c, admit_all, thr_f, nhi_f, spec)
-                             : pick_row<LIST_CAP / 64>(p, row, lane, c, admit_all, thr_f, nhi_f, spec);
+    if (!exact) R = c <= 512 ? pick_row<8, false>(p, row, lane, c, admit_all, thr_f, nhi_f, spec)
+                             : pick_row<LIST_CAP / 64, true>(p, row, lane, c, admit_all, thr_f, nhi_f, spec);
     if (lane != 0) return;
     if (R < 0 || R > RMAX) {
         const int at = atomicAdd(a.fb_count, 1);

@@ -579,7 +579,7 @@ struct StreamSum {
 // r & 7: whole groups of eight are added straight into the eight strided accumulators (eight
 // independent loads in flight, no slot selection).  The first dropped value anywhere in the
 // wave ends that: the rest of the list takes the general push().
-__device__ inline void zscore_one(const int64_t b, const int64_t i, const int64_t gid,
+__device__ inline double zscore_one(const int64_t b, const int64_t i, const int64_t gid,
                                   const double *__restrict__ XT, const double *__restrict__ XC,
                                   const int *__restrict__ gidx, const int *__restrict__ nref, int k, int64_t Ns,
                                   double *__restrict__ zT, double *__restrict__ rT, double *__restrict__ nT,
@@ -645,10 +645,12 @@ __device__ inline void zscore_one(const int64_t b, const int64_t i, const int64_
     const double sd = sqrt(var);
     const double x = XT[gid];
     const int64_t oid = osm ? i * osm + b : gid;
-    zT[oid] = (x - mean) / sd;
+    const double zv = (x - mean) / sd;
+    zT[oid] = zv;
     rT[oid] = x / mean;
     nT[oid] = (double)m;
     sdT[oid] = sd;
+    return zv;
 }
 
 // The same for a wave that holds ONE bin and 64 samples (b wave-uniform) when every lane keeps
@@ -813,8 +815,24 @@ template <int G, int WAVES, int NL, bool SM>   // NL: 4-slot groups of the list 
 __global__ __launch_bounds__(64 * WAVES, 2) void k_zscore_tiled(const double *__restrict__ XT, const double *__restrict__ XC,
                                                          const int *__restrict__ gidx, const int *__restrict__ nref, int k,
                                                          int B, int Ns, double *__restrict__ zT, double *__restrict__ rT,
-                                                         double *__restrict__ nT, double *__restrict__ sdT) {
+                                                         double *__restrict__ nT, double *__restrict__ sdT,
+                                                         double thr, unsigned int *__restrict__ hits,
+                                                         int *__restrict__ hit_count) {
     const int64_t osm = SM ? B : 0;
+    // hits (SM only): the pairs whose |z| reaches the threshold are appended to a list -- one in a thousand -- and the
+    // flag pass (k_flag_pairs over that list) no longer reads every z-score of the batch again (k_flag: 39 us of a
+    // 125 x 50 kb batch, 0.18 ms of 1 000 x 50 kb).  The flags themselves cannot be set here: the other waves of this
+    // launch still gather from XC, and the reference applies them after the whole repeat (wisetools.py:446).
+    auto note_hit = [&](const bool on, const unsigned int pair) {
+        if (!SM || !hits) return;
+        const unsigned long long m = __ballot(on);
+        if (!m) return;
+        int base = 0;
+        const int lane_ = threadIdx.x & 63;
+        if (lane_ == (int)__ffsll((long long)m) - 1) base = atomicAdd(hit_count, __popcll(m));
+        base = __shfl(base, __ffsll((long long)m) - 1);
+        if (on) hits[base + __popcll(m & ((1ull << lane_) - 1ull))] = pair;
+    };
     // SM: the four outputs are written SAMPLE-major [Ns, B] -- the layout k_clean, k_inflate and the
     // stdDevAvg kernels read -- instead of bin-major: k_transpose3 and k_transpose (0.14 ms of a 125 x 50 kb batch,
     // 0.9 ms of 1 000 x 50 kb) are gone.  A wave's 4 bins x 16 samples are 16 runs of 32 bytes then; the lanes are
@@ -845,7 +863,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_zscore_tiled(const double *__
     const int b = live ? b0 + q2 : B - 1;
     const int64_t i = (int64_t)tile * 16 + sm, gid = (int64_t)b * Ns + i;
     if (k & 3) {
-        if (live) zscore_one(b, i, gid, XT, XC, gidx, nref, k, Ns, zT, rT, nT, sdT, osm);
+        double zf = 0.0;
+        if (live) zf = zscore_one(b, i, gid, XT, XC, gidx, nref, k, Ns, zT, rT, nT, sdT, osm);
+        note_hit(live && fabs(zf) >= thr, (unsigned int)gid);
         return;
     }
     const int n = nref[b];                         // (not needed before the sums: the list is read whatever its length)
@@ -883,7 +903,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_zscore_tiled(const double *__
             for (int e = 0; e < 8; ++e) top = max(top, (unsigned int)__double2hiint(v[8 * q + e]));
         }
     if (!__all(top < 0x7ff00000u || !live)) {
-        if (live) zscore_one(b, i, gid, XT, XC, gidx, nref, k, Ns, zT, rT, nT, sdT, osm);
+        double zf = 0.0;
+        if (live) zf = zscore_one(b, i, gid, XT, XC, gidx, nref, k, Ns, zT, rT, nT, sdT, osm);
+        note_hit(live && fabs(zf) >= thr, (unsigned int)gid);
         return;
     }
     // numpy's pairwise sum of m = 8 ng + (kept tail values) numbers: eight strided accumulators over the whole groups,
@@ -947,9 +969,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_zscore_tiled(const double *__
         }
         return;
     }
+    const double zmine = (x - mean) / sd;
+    note_hit(live && fabs(zmine) >= thr, (unsigned int)gid);
     // sample-major: destination lane d = 4 s + q takes the results of source lane 16 q + s
     const int src = ((lane & 3) << 4) | (lane >> 2);
-    const double zo = __shfl((x - mean) / sd, src), ro = __shfl(x / mean, src), no = __shfl((double)m, src),
+    const double zo = __shfl(zmine, src), ro = __shfl(x / mean, src), no = __shfl((double)m, src),
                  so = __shfl(sd, src);
     const int ob = b0 + (lane & 3);
     if (ob < B) {
@@ -5159,7 +5183,7 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
                                    (const double *)ts.xt.as<double>(), (const double *)ts.xc.as<double>(),
                                    (const int *)ref->gidx.as<int>(), (const int *)ref->nref.as<int>(), ref->k,
                                    (int)ref->B, (int)Ns, ts.zt.as<double>(), ts.rt.as<double>(), ts.nt.as<double>(),
-                                   ts.sdt.as<double>());
+                                   ts.sdt.as<double>(), thr, sm_out && repeats > 1 ? cur : (unsigned int *)nullptr, pair_counts + 0);
             } else if (Ns >= 32) {
                 const unsigned n_uni = (unsigned)cdiv(ref->B * cdiv(Ns, 64), 4);
                 hipLaunchKernelGGL(k_zscore, dim3(n_uni), dim3(256), 0, stream,
@@ -5173,7 +5197,13 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
                                    (const int *)ref->gidx.as<int>(), (const int *)ref->nref.as<int>(), ref->k, Ns,
                                    ts.zt.as<double>(), ts.rt.as<double>(), ts.nt.as<double>(), ts.sdt.as<double>(), (int64_t)0);
             }
-            if (sm_out)
+            if (sm_out && repeats > 1)
+                // the tiled kernel listed the pairs that reach the threshold (in `cur`, counted in pair_counts[0])
+                hipLaunchKernelGGL(k_flag_pairs, dim3((unsigned)std::min<int64_t>(g, 2048)), dim3(256), 0, stream,
+                                   (const unsigned int *)cur, (const int *)(pair_counts + 0),
+                                   (const double *)ts.zt.as<double>(), thr, Ns, ts.xc.as<double>(), uoff, ulst, dirty, next,
+                                   pair_counts + it + 1, osm);
+            else if (sm_out)
                 hipLaunchKernelGGL(k_flag_sm, dim3((unsigned)cdiv(ref->B, 256), (unsigned)Ns), dim3(256), 0, stream,
                                    (const double *)ts.zt.as<double>(), thr, ref->B, Ns, ts.xc.as<double>(), uoff, ulst, dirty,
                                    next, pair_counts + it + 1);
