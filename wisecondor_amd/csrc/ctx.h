@@ -101,6 +101,8 @@ struct wc_ctx {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool side_pending = false;
+    bool side_fresh = false;               // the side stream was forked from the launch stream and NOTHING has been enqueued on the
+                                           // launch stream since: the next side_begin needs no second event record + wait
     // small pinned host block for count read-backs (a pageable destination costs a staged copy)
     int ensure_pinned(size_t bytes) {
         if (pinned_bytes >= bytes) return WC_OK;

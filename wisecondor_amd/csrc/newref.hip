@@ -2019,20 +2019,28 @@ __global__ __launch_bounds__(256) void k_exact_dev(FinishArgs a, const int *__re
     __shared__ __attribute__((aligned(16))) char smem[LDS];
     const int count = *n_rows_dev;
     if (count <= 0) return;
-    const int tid = threadIdx.x, n_tile = ctiles * rgroups, id = (int)blockIdx.x;
+    // (the grid is small -- EXD_TILE_WGS + EXD_SEL_WGS workgroups that loop over the tiles / rows: an empty launch costs
+    //  what its workgroups cost to dispatch, and this launch is empty in every normal pass)
+    const int tid = threadIdx.x, n_tile = (int)gridDim.x - n_sel, id = (int)blockIdx.x;
     if (id < n_tile) {
-        exact_tile_body<SEQ>(a, rows, count > cap ? cap : count, 0, scratch, Bpad, id % ctiles, id / ctiles, rgroups, smem);
+        for (int t = id; t < ctiles * rgroups; t += n_tile) {
+            wc_sync();
+            exact_tile_body<SEQ>(a, rows, count > cap ? cap : count, 0, scratch, Bpad, t % ctiles, t / ctiles, rgroups, smem);
+        }
         __threadfence();                               // this workgroup's keys are visible to the other XCDs ...
         wc_sync();
         if (tid == 0) atomicAdd(&sync[0], 1);          // ... before it counts itself in
         return;
     }
     if (tid == 0) {
-        while (__hip_atomic_load(&sync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < n_tile) __builtin_amdgcn_s_sleep(8);
-        __threadfence();
+        while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_tile) __builtin_amdgcn_s_sleep(8);
+        __threadfence();                               // (acquire: the tiles' keys)
     }
     wc_sync();
-    exact_select_body(a, rows, count, 0, scratch, Bpad, cap, id - n_tile, n_sel, true, smem);
+    for (int bx = id - n_tile; bx < cap; bx += n_sel) {
+        wc_sync();
+        exact_select_body(a, rows, count, 0, scratch, Bpad, cap, bx, n_sel, bx < n_sel, smem);
+    }
     wc_sync();
     if (tid == 0 && atomicAdd(&sync[1], 1) == n_sel - 1) {
         atomicExch(&sync[0], 0);
@@ -2495,13 +2503,15 @@ static int launch_exact(NewrefState &st, hipStream_t stream, const FinishArgs &a
     const int *rows = st.fb_rows.as<int>();
     if (n_host < 0) {
         // count on the device: one launch (k_exact_dev); fb_count[1..2] are its two counters (zero between launches)
-        const int rgroups = 4;                         // row groups in flight (surplus workgroups leave at once)
+        const int rgroups = 4;                         // row groups in flight per candidate tile
         int *sync = st.fb_count.as<int>() + 1;
-        const unsigned grid = ctiles * rgroups + (unsigned)cap;
+        constexpr int EXD_TILE_WGS = 192, EXD_SEL_WGS = 64;
+        const int n_tile = (int)std::min<int64_t>((int64_t)ctiles * rgroups, EXD_TILE_WGS);
+        const unsigned grid = (unsigned)(n_tile + EXD_SEL_WGS);
         if (seq) hipLaunchKernelGGL((k_exact_dev<true>), dim3(grid), dim3(256), 0, stream, a, rows,
-                                    (const int *)st.fb_count.as<int>(), sync, scratch, st.bins_pad, cap, (int)ctiles, rgroups, cap);
+                                    (const int *)st.fb_count.as<int>(), sync, scratch, st.bins_pad, cap, (int)ctiles, rgroups, EXD_SEL_WGS);
         else hipLaunchKernelGGL((k_exact_dev<false>), dim3(grid), dim3(256), 0, stream, a, rows,
-                                (const int *)st.fb_count.as<int>(), sync, scratch, st.bins_pad, cap, (int)ctiles, rgroups, cap);
+                                (const int *)st.fb_count.as<int>(), sync, scratch, st.bins_pad, cap, (int)ctiles, rgroups, EXD_SEL_WGS);
         return WC_OK;
     }
     for (int64_t first = 0; first < n_host; first += cap) {

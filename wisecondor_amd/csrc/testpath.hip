@@ -396,6 +396,8 @@ __global__ void k_pca_apply_t(const int *__restrict__ counts, int64_t Btot, cons
             xc[bb * Ns + i] = v;
         }
     }
+    // row B of xc = -1.0: what a list index of -1 reads in k_zscore_tiled (was a k_fill launch in front of that kernel)
+    if (blockIdx.x == 0 && ty == 0 && i0 + tx < Ns) xc[B * Ns + i0 + tx] = -1.0;
 }
 
 // Latency mode (a few samples per call): the four preparation launches as two.
@@ -1287,6 +1289,49 @@ __global__ __launch_bounds__(256) void k_flag_pairs(const unsigned int *__restri
     }
 }
 
+// The first repeat's flags from the tiled kernel's hit list: a WAVE per listed pair (k_flag_pairs holds a pair per
+// lane and expands a wave's hits one after the other -- 64 serial expansions per wave when the list is nothing but
+// hits: 40 us for the ~7 000 hits of a 125 x 50 kb batch).
+__global__ __launch_bounds__(256) void k_flag_hits(const unsigned int *__restrict__ hits, const int *__restrict__ count,
+                                                   const double *__restrict__ zT, double thr, int64_t Ns,
+                                                   double *__restrict__ XC, const int *__restrict__ users_off,
+                                                   const int *__restrict__ users, unsigned int *__restrict__ dirty,
+                                                   unsigned int *__restrict__ next_pairs, int *__restrict__ next_count,
+                                                   int64_t osm) {
+    const int n = *count;
+    const int lane = threadIdx.x & 63;
+    const int n_waves = (int)gridDim.x * 4;
+    for (int t = (int)blockIdx.x * 4 + (threadIdx.x >> 6); t < n; t += n_waves) {
+        const int64_t gid = hits[t];
+        const int64_t g = gid / Ns, i = gid - g * Ns;
+        const double zv = zT[osm ? i * osm + g : gid];
+        if (!(fabs(zv) >= thr) || XC[gid] == -1.0) continue;        // (wave-uniform)
+        // every lane has read XC[gid] before any lane writes it: the loads above return before the store is issued
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) XC[gid] = -1.0;
+        if (!next_pairs) continue;                                  // last repeat: nothing follows
+        const int u1 = users_off[g + 1];
+        for (int u0 = users_off[g]; u0 < u1; u0 += 64) {
+            const int u = u0 + lane;
+            unsigned int ug = 0u;
+            bool won = false;        // this lane set the pair's bit: it queues the pair
+            if (u < u1) {
+                ug = (unsigned int)((int64_t)users[u] * Ns + i);
+                const unsigned int bit = 1u << (ug & 31);
+                won = !(atomicOr(&dirty[ug >> 5], bit) & bit);
+            }
+            const unsigned long long winners = __ballot(won);
+            if (winners) {            // one reservation per trip
+                int base = 0;
+                if (lane == 0) base = atomicAdd(next_count, __popcll(winners));
+                base = __shfl(base, 0);
+                if (won) next_pairs[base + __popcll(winners & ((1ull << lane) - 1ull))] = ug;
+            }
+        }
+    }
+}
+
 // Latency mode: repeats 2 .. `repeats` in ONE launch by one workgroup.  After the first repeat a
 // sample usually has a handful of new flags, i.e. some hundred queued pairs, then none: a launch per
 // repeat and step costs more than the work.  Per repeat: recompute the queued pairs (eight lanes
@@ -2084,11 +2129,15 @@ __device__ inline double window_exact(const double *__restrict__ zz, int x, int 
 
 // The same by a whole wave (leaves of numpy's tree summed eight at a time); every lane
 // returns the value.
+// SHORT: the caller's windows never exceed numpy's 8 192-element buffer (one pairwise tree, no loop over pieces)
+template <bool SHORT = false>
 __device__ inline double window_exact_wave(const double *__restrict__ zz, int x, int y, int lane,
                                            const WindowMask &wm, wc::PwWaveScratch &sc) {
     if (!wm.valid(x, y)) return 0.0;
     const double *p = zz + x;
-    double s = wc::pairwise_sum_wave([&](int64_t t) { return p[t]; }, (int64_t)(y - x + 1), lane, sc);
+    double s;
+    if constexpr (SHORT) s = wc::pairwise_tree_wave([&](int64_t t) { return p[t]; }, (int64_t)(y - x + 1), lane, sc);
+    else s = wc::pairwise_sum_wave([&](int64_t t) { return p[t]; }, (int64_t)(y - x + 1), lane, sc);
     return s / sqrt((double)(y - x + 1));
 }
 
@@ -4735,6 +4784,9 @@ __global__ __launch_bounds__(1024) void k_seg_tree(int *__restrict__ counters, c
 // candidates, a recursion deeper than the stack -- sets counters[6] and the caller repeats the call with the
 // host-driven rounds.
 constexpr int WALK_STACK = 64;
+// PROF: the evaluation counters of the profiled run (two registers through the whole kernel otherwise: with them the
+// kernel spilled one register to scratch memory at its 128)
+template <bool PROF>
 __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters, const Region *__restrict__ regions,
                                                   int n_regions, const int *__restrict__ reg_flag,
                                                   const double *__restrict__ prefix, const double *__restrict__ rs,
@@ -4743,7 +4795,8 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
                                                   const double *__restrict__ tmax, const double *__restrict__ tmin2,
                                                   const double *__restrict__ tmax2, Seg *__restrict__ wsegs,
                                                   int seg_cap, int *__restrict__ out_n,
-                                                  unsigned long long *__restrict__ work, int per_sample) {
+                                                  unsigned long long *__restrict__ work, int per_sample,
+                                                  double *__restrict__ whole, double *__restrict__ whole2) {
     __shared__ CellShared sh;
     __shared__ Job stack[WALK_STACK];
     __shared__ int s_sp, s_nseg, s_stop;
@@ -4758,7 +4811,10 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
         region = (int)(blockIdx.x % samples) * per_sample + (int)(blockIdx.x / samples);
     }
     const Region rg = regions[region];
-    if (rg.n <= 0) return;                         // (out_n was zeroed by the set-up kernel)
+    if (rg.n <= 0) {                               // (out_n was zeroed by the set-up kernel)
+        if (whole && tid == 0) { whole[region] = NAN; if (whole2) whole2[region] = NAN; }
+        return;
+    }
     if (rg.n > CJ_MAXLEN || !reg_flag[region]) {
         if (tid == 0) atomicOr(&counters[6], rg.n > CJ_MAXLEN ? 1 : 2);      // (the bits say why: tools/gpu_test_scale.py prints them with WC_TEST_VERBOSE)
         return;
@@ -4778,6 +4834,13 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
         root.region = region; root.lo = 0; root.hi = rg.n; root.pad = 0;
         stack[0] = root;
         s_sp = 1; s_nseg = 0; s_stop = 0;
+    }
+    // the whole-region value getValue(0, n - 1) (wisecondor.py:237; numpy's own sum / sqrt(n)) by the last wave before
+    // the walk starts: k_region_whole -- a launch of one wave per region on the side stream, 0.11 ms beside the walk
+    // and a fork of the launch stream in front of it -- is not needed on this path
+    if (whole && w == 3) {
+        const double v = window_exact_wave<true>(zz, 0, rg.n - 1, lane, wm, sc[3]);
+        if (lane == 0) { whole[region] = v; if (whole2) whole2[region] = v; }
     }
     while (true) {
         wc_sync();
@@ -4877,7 +4940,7 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
         sg.val = seg_val[sidx]; sg.region = region; sg.x = seg_x[sidx]; sg.y = seg_y[sidx]; sg.pad = sidx | (nseg << 16);
         if (base + sidx < seg_cap) wsegs[base + sidx] = sg;   // (beyond: the caller sees counters[4] > seg_cap)
     }
-    if (work) {
+    if constexpr (PROF) {
         for (int o = 32; o > 0; o >>= 1) { evals += __shfl_xor(evals, o); wins += __shfl_xor(wins, o); }
         const int slot = (int)((blockIdx.x * 7u + (unsigned)w) & 63u);
         if (lane == 0) {
@@ -5174,6 +5237,7 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
                 constexpr int zwaves = 1;                           // (one wave per workgroup: a slot is refilled as soon as it frees; 2 and 4 measured 1-2 % slower)
                 const int64_t zgroups = cdiv(ref->B, 4 * zwaves), ztiles = Ns / 16;
                 const int64_t n_wg = 8 * ((ztiles / 8) * zgroups + cdiv((ztiles % 8) * zgroups, 8));
+                if (!xt_ready)                                      // (the batch's prepare kernel, k_pca_apply_t, wrote it)
                 hipLaunchKernelGGL(k_fill, dim3((unsigned)cdiv(Ns, 256)), dim3(256), 0, stream, ts.xc.as<double>() + ref->B * Ns,
                                    Ns, -1.0);                       // row B of xc: what an index of -1 reads
                 // (a list stride of up to 100 -- refsize 100 -- needs 100 value slots, not the 104 of 8 G + 8)
@@ -5199,7 +5263,7 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
             }
             if (sm_out && repeats > 1)
                 // the tiled kernel listed the pairs that reach the threshold (in `cur`, counted in pair_counts[0])
-                hipLaunchKernelGGL(k_flag_pairs, dim3((unsigned)std::min<int64_t>(g, 2048)), dim3(256), 0, stream,
+                hipLaunchKernelGGL(k_flag_hits, dim3(2048), dim3(256), 0, stream,
                                    (const unsigned int *)cur, (const int *)(pair_counts + 0),
                                    (const double *)ts.zt.as<double>(), thr, Ns, ts.xc.as<double>(), uoff, ulst, dirty, next,
                                    pair_counts + it + 1, osm);
@@ -5289,6 +5353,10 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
 static int side_begin(wc_ctx *ctx, hipStream_t stream) {
     int rc;
     if ((rc = ctx->ensure_side_stream())) return rc;
+    if (ctx->side_fresh) {             // forked a moment ago, nothing enqueued on `stream` since: one fork serves both
+        ctx->side_fresh = false;       // (an event record on the launch stream costs it ~10 us: kernel trace, round 6)
+        return WC_OK;
+    }
     WC_HIP(hipEventRecord(ctx->ev_fork, stream));
     WC_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
     return WC_OK;
@@ -5301,6 +5369,7 @@ static int side_end(wc_ctx *ctx) {
 
 // Make `stream` wait for the side-stream work of run_repeat (before sd_avg is consumed).
 int join_side(wc_ctx *ctx, hipStream_t stream) {
+    ctx->side_fresh = false;
     if (ctx->side_pending) {
         WC_HIP(hipStreamWaitEvent(stream, ctx->ev_join, 0));
         ctx->side_pending = false;
@@ -5445,41 +5514,59 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
                            fused->gpos, fused->regions, ts.prefix.as<double>(), ts.reg_abs.as<double>(),
                            ts.reg_flag.as<int>(), ts.whole.as<double>(), fused->whole_copy, ts.jobs_a.as<Job>(), counters,
                            ts.out_n.as<int>(), ts.misc.as<int>(), n_regions);
-    else
-    hipLaunchKernelGGL(k_region_prefix, dim3((unsigned)cdiv(n_regions, 4)), dim3(256), 0, stream, z_dev, regions_dev,
-                       n_regions, ts.prefix.as<double>(), ts.reg_abs.as<double>(), ts.reg_flag.as<int>(), counters,
-                       ts.out_n.as<int>(), ts.misc.as<int>());
-    // The quiet-job certificate (k_seg_quiet) runs before every search round: measured -7 % per
-    // 250 kb batch and -17 % per 50 kb batch on data where 10-40 % of the regions hold a call; jobs
-    // it cannot decide fall through to the full search.
-    const bool certify = true;
-    if (certify) {
-        const int64_t total = total_len + n_regions, nblk = cdiv(total, QB);
-        if ((rc = ts.tmin.reserve(sizeof(double) * nblk))) return rc;
-        if ((rc = ts.tmax.reserve(sizeof(double) * nblk))) return rc;
-        const int64_t nblk2 = cdiv(nblk, 4);
-        if ((rc = ts.tmin2.reserve(sizeof(double) * nblk2))) return rc;
-        if ((rc = ts.tmax2.reserve(sizeof(double) * nblk2))) return rc;
+    // Callers with call rows, regions up to CJ_MAXLEN bins, no -mineffectsize mask: the whole recursion of every region
+    // in ONE launch (k_seg_walk), no host round trip.  WC_TEST_WALK=0: the paths it replaces (tree kernel up to
+    // TREE_MAXLEN, host-driven rounds beyond).
+    const char *walk_env = getenv("WC_TEST_WALK");
+    const bool walk_path = tail && !bits && max_n <= CJ_MAXLEN && !ts.no_tree && !(walk_env && walk_env[0] == '0');
+    const int64_t total = total_len + n_regions, nblk = cdiv(total, QB);
+    if ((rc = ts.tmin.reserve(sizeof(double) * nblk))) return rc;
+    if ((rc = ts.tmax.reserve(sizeof(double) * nblk))) return rc;
+    const int64_t nblk2 = cdiv(nblk, 4);
+    if ((rc = ts.tmin2.reserve(sizeof(double) * nblk2))) return rc;
+    if ((rc = ts.tmax2.reserve(sizeof(double) * nblk2))) return rc;
+    auto block_tables = [&]() {
         hipLaunchKernelGGL(k_block_minmax, dim3((unsigned)cdiv(total, 1024)), dim3(256), 0, stream,
                            (const double *)ts.prefix.as<double>(), total, ts.tmin.as<double>(), ts.tmax.as<double>(),
                            ts.tmin2.as<double>(), ts.tmax2.as<double>());
-    }
-    if (!fused) {
-        // batch path: the whole-region values are an output only -> side stream (one wave per region walks
+    };
+    // (prefix sums AND block tables by one 256-thread workgroup per region -- a thread per 16 consecutive bins, the tables
+    //  from the values it had just written -- measured 125 us against 49 + 42 for these two launches: not kept)
+    if (!fused)
+    hipLaunchKernelGGL(k_region_prefix, dim3((unsigned)cdiv(n_regions, 4)), dim3(256), 0, stream, z_dev, regions_dev,
+                       n_regions, ts.prefix.as<double>(), ts.reg_abs.as<double>(), ts.reg_flag.as<int>(), counters,
+                       ts.out_n.as<int>(), ts.misc.as<int>());
+    // The block tables: the walker's cell search, the quiet-job certificate (k_seg_quiet; measured -7 % per 250 kb batch
+    // and -17 % per 50 kb batch on data where 10-40 % of the regions hold a call) and the bound-driven rounds read them
+    block_tables();
+    const bool certify = true;         // (the certificate runs before every search round of the tree / masked paths)
+    // whole-region values (an output) and the root jobs of the host-driven rounds.  The walker needs no job list:
+    // k_init_jobs stays off its path.  (The whole-region values by the walker's own workgroups -- its last wave before
+    // the walk starts -- were measured: k_seg_walk 265 -> 385 us at 125 x 50 kb, a 4 700-bin pairwise tree walked by
+    // one wave costs ~40 us; they stay a side-stream launch.)
+    auto whole_and_jobs = [&](const bool jobs_too) -> int {
+        // the whole-region values are an output only -> side stream (one wave per region walks
         // the region in numpy's order: 0.1 ms at 50 kb that the search does not have to wait for)
         hipStream_t ws = stream;
         double *wcopy = whole_copy;
+        int rc2;
         if (tail && tail->cwz_out && !bits) {
-            if ((rc = side_begin(ctx, stream))) return rc;
+            // (a second side stream for this launch alone was measured: it then runs beside the walk -- 180 us instead
+            //  of 105, the walk 277 instead of 267, 1 000 x 50 kb 7.69 instead of 7.34 ms; one side stream)
+            if ((rc2 = side_begin(ctx, stream))) return rc2;
             ws = ctx->side;
             wcopy = tail->cwz_out;
         }
         hipLaunchKernelGGL(k_region_whole, dim3((unsigned)cdiv(n_regions, 4)), dim3(256), 0, ws, z_dev, regions_dev,
                            n_regions, bits, bit_off, ts.whole.as<double>(), wcopy);
-        if (ws != stream && (rc = side_end(ctx))) return rc;
-        hipLaunchKernelGGL(k_init_jobs, dim3((unsigned)cdiv(n_regions, 256)), dim3(256), 0, stream, regions_dev, n_regions,
-                           ts.jobs_a.as<Job>(), counters);
-    }
+        if (ws != stream && (rc2 = side_end(ctx))) return rc2;
+        if (jobs_too)
+            hipLaunchKernelGGL(k_init_jobs, dim3((unsigned)cdiv(n_regions, 256)), dim3(256), 0, stream, regions_dev, n_regions,
+                               ts.jobs_a.as<Job>(), counters);
+        return WC_OK;
+    };
+    const bool walker_owns_setup = walk_path && !fused;
+    if (!fused && (rc = whole_and_jobs(!walker_owns_setup))) return rc;
     Job *cur = ts.jobs_a.as<Job>(), *next = ts.jobs_b.as<Job>();
     int64_t n_jobs = n_regions;
     int guard = 0;
@@ -5492,19 +5579,18 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     if ((rc = ctx->ensure_pinned(256))) return rc;
     int *h = (int *)ctx->pinned;          // counter read-backs land in pinned memory
     h[4] = 0;
-    // Callers with call rows, regions up to CJ_MAXLEN bins, no -mineffectsize mask: the whole recursion of every region
-    // in ONE launch (k_seg_walk), no host round trip; k_call_post then takes the segment count from the device.
-    // WC_TEST_WALK=0: the paths it replaces (tree kernel up to TREE_MAXLEN, host-driven rounds beyond).
-    const char *walk_env = getenv("WC_TEST_WALK");
-    if (tail && !bits && max_n <= CJ_MAXLEN && !ts.no_tree && !(walk_env && walk_env[0] == '0')) {
+    if (walk_path) {
         ts.mark(10, stream);
-        hipLaunchKernelGGL(k_seg_walk, dim3((unsigned)n_regions), dim3(256), 0, stream, counters, regions_dev,
+        double *w1 = nullptr, *w2 = nullptr;        // (the walker can write the whole-region values itself: not used, see above)
+        auto walker = work ? k_seg_walk<true> : k_seg_walk<false>;
+        hipLaunchKernelGGL(walker, dim3((unsigned)n_regions), dim3(256), 0, stream, counters, regions_dev,
                            (int)n_regions, (const int *)ts.reg_flag.as<int>(), (const double *)ts.prefix.as<double>(),
                            (const double *)ts.rs.as<double>(), (const double *)ts.reg_abs.as<double>(), z_dev, thr,
                            min_search, (const double *)ts.tmin.as<double>(), (const double *)ts.tmax.as<double>(),
                            (const double *)ts.tmin2.as<double>(), (const double *)ts.tmax2.as<double>(), ts.seg.as<Seg>(),
                            (int)seg_cap, ts.out_n.as<int>(), work,
-                           (tail->per_sample > 1 && n_regions % tail->per_sample == 0) ? tail->per_sample : 0);   // (125 x 50 kb: 287 -> 255 us)
+                           (tail->per_sample > 1 && n_regions % tail->per_sample == 0) ? tail->per_sample : 0,   // (125 x 50 kb: 287 -> 255 us)
+                           w1, w2);
         hipLaunchKernelGGL(k_walk_rows, dim3(768), dim3(256), 0, stream, (const Seg *)ts.seg.as<Seg>(),
                            (const int *)(counters + 4), (int)seg_cap, regions_dev, tail->ratio, tail->gpos,
                            max_calls, tail->reg_calls);
@@ -5536,6 +5622,9 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
         WC_HIP(hipMemsetAsync(counters + 4, 0, sizeof(int), stream));
         WC_HIP(hipMemsetAsync(counters + 6, 0, sizeof(int), stream));
         h[4] = 0;
+        if (walker_owns_setup)             // the root jobs the walker did not need
+            hipLaunchKernelGGL(k_init_jobs, dim3((unsigned)cdiv(n_regions, 256)), dim3(256), 0, stream, regions_dev, n_regions,
+                               ts.jobs_a.as<Job>(), counters);
     }
     const bool tree_ok = tree_ok0 && (walk_env && walk_env[0] == '0');
     const bool bound_path = !bits && !tree_ok;
@@ -6205,6 +6294,9 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
     }
     ts.mark(1, stream);
     if ((rc = run_repeat(ctx, ref, ts.data.as<double>(), Np, threshold, repeats, stream, lat, asdef, !lat, !lat))) return rc;
+    // run_repeat forked the side stream for stdDevAvg at its very end; with sample-major outputs nothing is enqueued on
+    // the launch stream before the inflated outputs go to the side stream too: they ride on the same fork
+    ctx->side_fresh = !lat && ts.sm_out && ctx->side_pending && !ts.profile;
     ts.mark(2, stream);
     struct Joiner {   // asdef is copied out once the side stream's sum is done, on every exit path
         wc_ctx *c; hipStream_t s; double *dst; int64_t n; bool on;
@@ -6250,6 +6342,7 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
                            (const int *)ref->g2m.as<int>(), (double)min_ref_bins, results_z, results_r, str_i, str_b);
         if (is != stream && (rc = side_end(ctx))) return rc;
     }
+    ctx->side_fresh = false;      // (whatever follows on the launch stream is not covered by that fork)
     if (n_sel == 0) {      // nothing to segment: no calls (otherwise k_assemble_calls writes every n_calls)
         if (n_calls) WC_HIP(hipMemsetAsync(n_calls, 0, sizeof(int) * Ns, stream));
         return WC_OK;
