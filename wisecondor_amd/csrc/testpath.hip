@@ -1039,7 +1039,7 @@ struct GroupSum {
 // pairs == nullptr: every pair 0 .. n_all - 1 (first repeat of a small batch, where whole waves
 // per bin would be mostly empty and one thread per pair waits out ~26 dependent gathers).
 // one (bin, sample) pair by an aligned group of eight lanes (sub = lane & 7, gbase = lane & ~7)
-__device__ inline void zscore_pair8(const unsigned int gid, const int sub, const int gbase,
+__device__ __forceinline__ void zscore_pair8(const unsigned int gid, const int sub, const int gbase,
                                     const double *__restrict__ XT, const double *__restrict__ XC,
                                     const int *__restrict__ gidx, const int *__restrict__ nref, int k, int64_t Ns,
                                     double *__restrict__ zT, double *__restrict__ rT, double *__restrict__ nT,
@@ -4784,9 +4784,8 @@ __global__ __launch_bounds__(1024) void k_seg_tree(int *__restrict__ counters, c
 // candidates, a recursion deeper than the stack -- sets counters[6] and the caller repeats the call with the
 // host-driven rounds.
 constexpr int WALK_STACK = 64;
-// PROF: the evaluation counters of the profiled run (two registers through the whole kernel otherwise: with them the
-// kernel spilled one register to scratch memory at its 128)
-template <bool PROF>
+// (Register allocation at the 128-register budget is knife-edge here: the same kernel WITHOUT the two evaluation
+//  counters of the profiled run spills two registers, with them none -- profiles/r06_kernel_resources.txt.)
 __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters, const Region *__restrict__ regions,
                                                   int n_regions, const int *__restrict__ reg_flag,
                                                   const double *__restrict__ prefix, const double *__restrict__ rs,
@@ -4795,8 +4794,7 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
                                                   const double *__restrict__ tmax, const double *__restrict__ tmin2,
                                                   const double *__restrict__ tmax2, Seg *__restrict__ wsegs,
                                                   int seg_cap, int *__restrict__ out_n,
-                                                  unsigned long long *__restrict__ work, int per_sample,
-                                                  double *__restrict__ whole, double *__restrict__ whole2) {
+                                                  unsigned long long *__restrict__ work, int per_sample) {
     __shared__ CellShared sh;
     __shared__ Job stack[WALK_STACK];
     __shared__ int s_sp, s_nseg, s_stop;
@@ -4811,10 +4809,7 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
         region = (int)(blockIdx.x % samples) * per_sample + (int)(blockIdx.x / samples);
     }
     const Region rg = regions[region];
-    if (rg.n <= 0) {                               // (out_n was zeroed by the set-up kernel)
-        if (whole && tid == 0) { whole[region] = NAN; if (whole2) whole2[region] = NAN; }
-        return;
-    }
+    if (rg.n <= 0) return;                         // (out_n was zeroed by the set-up kernel)
     if (rg.n > CJ_MAXLEN || !reg_flag[region]) {
         if (tid == 0) atomicOr(&counters[6], rg.n > CJ_MAXLEN ? 1 : 2);      // (the bits say why: tools/gpu_test_scale.py prints them with WC_TEST_VERBOSE)
         return;
@@ -4834,13 +4829,6 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
         root.region = region; root.lo = 0; root.hi = rg.n; root.pad = 0;
         stack[0] = root;
         s_sp = 1; s_nseg = 0; s_stop = 0;
-    }
-    // the whole-region value getValue(0, n - 1) (wisecondor.py:237; numpy's own sum / sqrt(n)) by the last wave before
-    // the walk starts: k_region_whole -- a launch of one wave per region on the side stream, 0.11 ms beside the walk
-    // and a fork of the launch stream in front of it -- is not needed on this path
-    if (whole && w == 3) {
-        const double v = window_exact_wave<true>(zz, 0, rg.n - 1, lane, wm, sc[3]);
-        if (lane == 0) { whole[region] = v; if (whole2) whole2[region] = v; }
     }
     while (true) {
         wc_sync();
@@ -4940,7 +4928,7 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
         sg.val = seg_val[sidx]; sg.region = region; sg.x = seg_x[sidx]; sg.y = seg_y[sidx]; sg.pad = sidx | (nseg << 16);
         if (base + sidx < seg_cap) wsegs[base + sidx] = sg;   // (beyond: the caller sees counters[4] > seg_cap)
     }
-    if constexpr (PROF) {
+    if (work) {
         for (int o = 32; o > 0; o >>= 1) { evals += __shfl_xor(evals, o); wins += __shfl_xor(wins, o); }
         const int slot = (int)((blockIdx.x * 7u + (unsigned)w) & 63u);
         if (lane == 0) {
@@ -5581,16 +5569,13 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     h[4] = 0;
     if (walk_path) {
         ts.mark(10, stream);
-        double *w1 = nullptr, *w2 = nullptr;        // (the walker can write the whole-region values itself: not used, see above)
-        auto walker = work ? k_seg_walk<true> : k_seg_walk<false>;
-        hipLaunchKernelGGL(walker, dim3((unsigned)n_regions), dim3(256), 0, stream, counters, regions_dev,
+        hipLaunchKernelGGL(k_seg_walk, dim3((unsigned)n_regions), dim3(256), 0, stream, counters, regions_dev,
                            (int)n_regions, (const int *)ts.reg_flag.as<int>(), (const double *)ts.prefix.as<double>(),
                            (const double *)ts.rs.as<double>(), (const double *)ts.reg_abs.as<double>(), z_dev, thr,
                            min_search, (const double *)ts.tmin.as<double>(), (const double *)ts.tmax.as<double>(),
                            (const double *)ts.tmin2.as<double>(), (const double *)ts.tmax2.as<double>(), ts.seg.as<Seg>(),
                            (int)seg_cap, ts.out_n.as<int>(), work,
-                           (tail->per_sample > 1 && n_regions % tail->per_sample == 0) ? tail->per_sample : 0,   // (125 x 50 kb: 287 -> 255 us)
-                           w1, w2);
+                           (tail->per_sample > 1 && n_regions % tail->per_sample == 0) ? tail->per_sample : 0);   // (125 x 50 kb: 287 -> 255 us)
         hipLaunchKernelGGL(k_walk_rows, dim3(768), dim3(256), 0, stream, (const Seg *)ts.seg.as<Seg>(),
                            (const int *)(counters + 4), (int)seg_cap, regions_dev, tail->ratio, tail->gpos,
                            max_calls, tail->reg_calls);
