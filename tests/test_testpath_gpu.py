@@ -425,3 +425,19 @@ def test_long_regions_through_the_host_driven_levels(wt, monkeypatch):
         for s, s2 in zip(segs, segs2):
             assert [(x, y) for _, (x, y) in s] == [(x, y) for _, (x, y) in s2]
             assert same_bits([v for v, _ in s], [v for v, _ in s2])
+
+
+def test_whole_region_values_at_every_tree_shape(wt):
+    """getValue(0, n - 1) = np.sum(z) / np.sqrt(n) (wisecondor.py:237) for region lengths around every change of shape of
+    numpy's pairwise tree: k_region_whole sums regions of 129 .. 8 192 bins with every lane on its own node of the tree
+    (pairwise_tree_lanes, round 6), shorter and longer ones the older ways -- all must carry numpy's bits."""
+    rng = np.random.RandomState(11)
+    lengths = list(range(120, 300)) + [511, 512, 513, 1023, 1024, 1025, 1031, 1032, 1033, 2047, 2048, 2049, 2057, 4095,
+                                       4096, 4097, 4609, 4722, 8185, 8191, 8192, 8193, 8200, 9000] + \
+        [int(v) for v in rng.randint(129, 8193, size=60)]
+    regions = [rng.standard_normal(n) * rng.choice([1.0, 1e-3, 40.0]) for n in lengths]
+    regions[3][:] = -0.0                                  # a sum of negative zeros stays -0.0 ...
+    regions[40][:] = -0.0                                 # ... also when most lanes of the fold hold nothing (160 bins: two nodes)
+    whole, _ = wt.stouffer_segments(regions, np.inf, 3)
+    want = np.array([np.sum(z) / np.sqrt(len(z)) for z in regions])
+    assert same_bits(whole, want), [n for n, a, b in zip(lengths, whole, want) if not same_bits([a], [b])]

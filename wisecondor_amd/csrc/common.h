@@ -183,6 +183,76 @@ template <class F> __device__ inline double pw_leaf_group8(F f, int64_t off, int
     return r;
 }
 
+// numpy's pairwise sum of a node of at most 128 * 2^D elements by ONE thread, the tree unrolled at compile time (no
+// stack: a runtime-indexed private array would live in scratch memory)
+template <int D, class F> __device__ inline double pw_node_serial(F f, int64_t off, int n) {
+    if (n <= WC_PW_BLOCK) return pw_leaf_serial(f, off, n);
+    if constexpr (D == 0) {
+        return NAN;                                  // (not reached: the caller bounds n)
+    } else {
+        int n2 = n / 2;
+        n2 -= n2 % 8;
+        const double l = pw_node_serial<D - 1>(f, off, n2);
+        const double r = pw_node_serial<D - 1>(f, off + n2, n - n2);
+        return l + r;
+    }
+}
+
+// ... and by aligned groups of eight lanes (every lane of the wave calls it with the same n; all return the value)
+template <int D, class F> __device__ inline double pw_node_group8(F f, int64_t off, int n, int sub) {
+    if (n <= WC_PW_BLOCK) return pw_leaf_group8(f, off, n, sub);
+    if constexpr (D == 0) {
+        return NAN;                                  // (not reached: the caller bounds n)
+    } else {
+        int n2 = n / 2;
+        n2 -= n2 % 8;
+        const double l = pw_node_group8<D - 1>(f, off, n2, sub);
+        const double r = pw_node_group8<D - 1>(f, off + n2, n - n2, sub);
+        return l + r;
+    }
+}
+
+// numpy's pairwise sum of f(0 .. n - 1), 128 < n <= 8192, by a wave in which EVERY LANE FINDS ITS OWN NODE: with K the
+// first level of numpy's tree whose largest node (the right-most: n - n2 >= n2) holds at most 128 elements, level
+// K - 1 has 2^(K-1) <= 64 nodes; lane l descends from the root along the bits of l (most significant first), sums the
+// node it arrives at ALONE (at most ~270 elements: a leaf or a split or two, pw_node_serial), and the levels are folded
+// by a butterfly that keeps a subtree's value in the subtree's first lane (left + right, numpy's order).  A node that
+// is a leaf before level K - 1 (the left-most nodes can be 8 per level smaller than the right-most) belongs to the
+// first lane of its subtree; the other lanes of that subtree hold nothing and the fold skips them (adding +0.0 would
+// turn a sum of -0.0 into +0.0).  No LDS, no stack: pairwise_tree_wave walks the tree twice through an LDS stack,
+// 40 us for a 4 700-bin region; this form takes a few microseconds.  Every lane returns the value.
+template <class F> __device__ inline double pairwise_tree_lanes(F f, int n, int lane) {
+    int K = 0;
+    for (int r = n; r > WC_PW_BLOCK; ++K) {          // the right-most path
+        int n2 = r / 2;
+        n2 -= n2 % 8;
+        r -= n2;
+    }
+    const int LV = K - 1, nodes = 1 << LV;            // K >= 1 (n > 128); nodes <= 64 for n <= 8192
+    int off = 0, nn = n;
+    bool valid = lane < nodes;
+    for (int l = 0; l < LV; ++l) {
+        if (nn <= WC_PW_BLOCK) {                      // a leaf above level LV: the subtree's first lane keeps it
+            valid = valid && (lane & ((1 << (LV - l)) - 1)) == 0;
+            break;
+        }
+        int n2 = nn / 2;
+        n2 -= n2 % 8;
+        if ((lane >> (LV - 1 - l)) & 1) { off += n2; nn -= n2; }
+        else nn = n2;
+    }
+    double val = valid ? pw_node_serial<3>(f, (int64_t)off, nn) : 0.0;
+    for (int st = 1; st < nodes; st <<= 1) {          // fold: subtrees of `st` lanes pair up
+        const double right = __shfl(val, (lane + st) & 63);
+        const bool rvalid = __shfl((int)valid, (lane + st) & 63) != 0;
+        if ((lane & (2 * st - 1)) == 0) {
+            if (valid && rvalid) val = val + right;
+            else if (rvalid) { val = right; valid = true; }
+        }
+    }
+    return __shfl(val, 0);
+}
+
 template <bool GROUP8, class F> __device__ inline double pairwise_tree(F f, int64_t n, int sub) {
     if (n <= WC_PW_BLOCK)
         return GROUP8 ? pw_leaf_group8(f, 0, (int)n, sub) : pw_leaf_serial(f, 0, (int)n);

@@ -1177,14 +1177,16 @@ __global__ __launch_bounds__(256) void k_zscore_big(const unsigned int *__restri
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const double mean = wc::pairwise_sum<true>([&](int64_t e) { return buf[e]; }, (int64_t)m, sub) / (double)m;
-        const double var = wc::pairwise_sum<true>(
+        // (m <= BIG_K = 1 024 kept values: numpy's tree is at most four splits deep -- unrolled at compile time; the
+        //  generic walk with its runtime-indexed stack took 498 registers and 304 bytes of scratch per lane here)
+        const double mean = wc::pw_node_group8<4>([&](int64_t e) { return buf[e]; }, 0, m, sub) / (double)m;
+        const double var = wc::pw_node_group8<4>(
                                [&](int64_t e) {
                                    const double dv = buf[e] - mean;
                                    const double sq = dv * dv;
                                    return sq;
                                },
-                               (int64_t)m, sub) / (double)m;
+                               0, m, sub) / (double)m;
         if (lane == 0) {
             const double sd = sqrt(var);
             const double x = XT[gid];
@@ -2151,7 +2153,14 @@ __global__ __launch_bounds__(256) void k_region_whole(const double *__restrict__
     if (r >= n_regions) return;
     const Region rg = regions[r];
     const WindowMask wm{bits, bits ? bit_off[r] : 0, rg.n};
-    const double v = rg.n > 0 ? window_exact_wave(z + rg.off, 0, rg.n - 1, lane, wm, sc[w]) : NAN;
+    double v;
+    if (!bits && rg.n > WC_PW_BLOCK && rg.n <= WC_NPY_BUFSIZE) {
+        // (round 6) every lane sums its own node of numpy's tree: no LDS stack walk (40 us per 4 700-bin region before)
+        const double *p = z + rg.off;
+        v = wc::pairwise_tree_lanes([&](int64_t t) { return p[t]; }, rg.n, lane) / sqrt((double)rg.n);
+    } else {
+        v = rg.n > 0 ? window_exact_wave(z + rg.off, 0, rg.n - 1, lane, wm, sc[w]) : NAN;
+    }
     if (lane == 0) {
         whole[r] = v;
         if (whole2) whole2[r] = v;             // the caller's results_cwz, when it wants no separate copy
