@@ -436,8 +436,8 @@ def test_whole_region_values_at_every_tree_shape(wt):
                                        4096, 4097, 4609, 4722, 8185, 8191, 8192, 8193, 8200, 9000] + \
         [int(v) for v in rng.randint(129, 8193, size=60)]
     regions = [rng.standard_normal(n) * rng.choice([1.0, 1e-3, 40.0]) for n in lengths]
-    regions[3][:] = -0.0                                  # a sum of negative zeros stays -0.0 ...
-    regions[40][:] = -0.0                                 # ... also when most lanes of the fold hold nothing (160 bins: two nodes)
+    regions[3][:] = -0.0                                  # np.sum of nothing but -0.0 is +0.0 (it starts from its identity) ...
+    regions[40][:] = -0.0                                 # ... also where most lanes of the fold hold nothing (160 bins: two nodes)
     whole, _ = wt.stouffer_segments(regions, np.inf, 3)
     want = np.array([np.sum(z) / np.sqrt(len(z)) for z in regions])
     assert same_bits(whole, want), [n for n, a, b in zip(lengths, whole, want) if not same_bits([a], [b])]

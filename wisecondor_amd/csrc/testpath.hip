@@ -2126,6 +2126,7 @@ __device__ inline double window_exact(const double *__restrict__ zz, int x, int 
     if (!wm.valid(x, y)) return 0.0;   // uniform per 8-lane group: all its lanes evaluate the same window
     const double *p = zz + x;
     double s = wc::pairwise_sum<GROUP8>([&](int64_t t) { return p[t]; }, (int64_t)(y - x + 1), sub);
+    s = s + 0.0;        // np.sum starts from its identity +0.0: a sum of nothing but -0.0 comes out as +0.0 (-fno-fast-math keeps this add)
     return s / sqrt((double)(y - x + 1));
 }
 
@@ -2140,6 +2141,7 @@ __device__ inline double window_exact_wave(const double *__restrict__ zz, int x,
     double s;
     if constexpr (SHORT) s = wc::pairwise_tree_wave([&](int64_t t) { return p[t]; }, (int64_t)(y - x + 1), lane, sc);
     else s = wc::pairwise_sum_wave([&](int64_t t) { return p[t]; }, (int64_t)(y - x + 1), lane, sc);
+    s = s + 0.0;        // (np.sum's identity, see window_exact)
     return s / sqrt((double)(y - x + 1));
 }
 
@@ -2157,7 +2159,7 @@ __global__ __launch_bounds__(256) void k_region_whole(const double *__restrict__
     if (!bits && rg.n > WC_PW_BLOCK && rg.n <= WC_NPY_BUFSIZE) {
         // (round 6) every lane sums its own node of numpy's tree: no LDS stack walk (40 us per 4 700-bin region before)
         const double *p = z + rg.off;
-        v = wc::pairwise_tree_lanes([&](int64_t t) { return p[t]; }, rg.n, lane) / sqrt((double)rg.n);
+        v = (wc::pairwise_tree_lanes([&](int64_t t) { return p[t]; }, rg.n, lane) + 0.0) / sqrt((double)rg.n);   // (+ 0.0: np.sum's identity)
     } else {
         v = rg.n > 0 ? window_exact_wave(z + rg.off, 0, rg.n - 1, lane, wm, sc[w]) : NAN;
     }
@@ -4124,7 +4126,7 @@ __global__ __launch_bounds__(NT) void k_lat_setup(const double *__restrict__ zsr
             PwBlock<5>::leaves(zz, 0, n, next, tid >> 3, tid & 7, s_leaf);
             wc_sync();
             next = 0;
-            v = PwBlock<5>::fold(n, next, s_leaf) / sqrt((double)n);
+            v = (PwBlock<5>::fold(n, next, s_leaf) + 0.0) / sqrt((double)n);      // (+ 0.0: np.sum starts from its identity)
         } else if (n > 0 && w == 0) {
             const WindowMask wm{nullptr, 0, n};
             v = window_exact_wave(zz, 0, n - 1, lane, wm, sc);
@@ -5527,8 +5529,13 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
                            (const double *)ts.prefix.as<double>(), total, ts.tmin.as<double>(), ts.tmax.as<double>(),
                            ts.tmin2.as<double>(), ts.tmax2.as<double>());
     };
+    // (measured and not kept: ONE fork of the side stream behind k_clean for stdDevAvg + inflated outputs + whole-region
+    //  values -- k_clean is as long without k_sd_fast beside it, k_block_minmax twice as long with it: 1.15 against 1.115 ms)
     // (prefix sums AND block tables by one 256-thread workgroup per region -- a thread per 16 consecutive bins, the tables
     //  from the values it had just written -- measured 125 us against 49 + 42 for these two launches: not kept)
+    // (a 256-thread workgroup per region -- 1 024 coalesced bins per trip, four wave scans, one barrier -- measured 53 us
+    //  against this kernel's 49 at 125 x 50 kb: what these set-up launches wait for is the half of the chip k_sd_fast's
+    //  1 024-thread workgroups hold on the side stream, not their own parallelism)
     if (!fused)
     hipLaunchKernelGGL(k_region_prefix, dim3((unsigned)cdiv(n_regions, 4)), dim3(256), 0, stream, z_dev, regions_dev,
                        n_regions, ts.prefix.as<double>(), ts.reg_abs.as<double>(), ts.reg_flag.as<int>(), counters,
@@ -6439,6 +6446,17 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
                 WC_CHECK(h[4] <= ts.tree_seg_cap, WC_E_LIMIT, "stouffer: more than max_calls=%d segments per region", max_calls);
             }
             WC_CHECK(!*overflow, WC_E_LIMIT, "test: a sample has more than max_calls=%d calls", max_calls);
+            if (getenv("WC_TEST_VERBOSE") && ts.sd_fail.p && ref->B <= 65536 && ctx->side) {
+                // how many samples the parallel stdDevAvg gave up on (the serial kernel computed them)
+                (void)hipStreamSynchronize(ctx->side);
+                std::vector<int> f((size_t)Ns);
+                if (hipMemcpy(f.data(), ts.sd_fail.p, sizeof(int) * Ns, hipMemcpyDeviceToHost) == hipSuccess) {
+                    int64_t nf = 0;
+                    for (int64_t q = 0; q < Ns; ++q) nf += f[q] != 0;
+                    fprintf(stderr, "wisecondor_amd: stdDevAvg: %lld of %lld samples took the serial kernel\n", (long long)nf,
+                            (long long)Ns);
+                }
+            }
         }
     }
     ts.mark(5, stream);
