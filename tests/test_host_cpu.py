@@ -248,3 +248,27 @@ def test_part_files_go_to_the_rank_that_owns_their_rows():
         assert covered == n_bins
     assert cli.part_owners(3, [1, 2, 3], 11087, 2) is None            # part 2 straddles the two ranks' ranges
     assert cli.part_owners(3, [1, 3], 11087, 2) == {1: 0, 3: 1}       # ... but a resumed run that lacks 1 and 3 only does not
+
+
+def test_bench_compact_line_from_a_full_record():
+    """bench.py's LAST line must stay small (the driver's parser lost round 5's 21 KB line): the compact form of that
+    very record (profiles/r05_bench_cfg2_unprofiled.json is the full round-5 line) is under 6 000 bytes, strict JSON,
+    and carries the contract's keys with `roofline` / `cpu_baseline` as flat objects."""
+    import json
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_cfg2_unprofiled.json")))
+    assert len(json.dumps(full)) > 15000
+    line = json.dumps(bench.compact_line(full), allow_nan=False, separators=(",", ":"))
+    assert len(line) < bench.LINE_LIMIT
+    d = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["value"] == float("%.6g" % full["value"]) and d["ms_per_step"] == float("%.6g" % full["ms_per_step"])
+    assert set(d["config"]) == {"workload", "parallelism", "world_size", "shard_mode"}
+    assert d["roofline"]["kernel"] == "k_rescore" and 0 < d["roofline"]["frac"] <= 1
+    assert all(not isinstance(v, (dict, list)) or k in ("other",) for k, v in d["roofline"].items())
+    assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    # NaN / infinity never reach the line
+    full["value"] = float("nan")
+    assert json.loads(json.dumps(bench.compact_line(full), allow_nan=False))["value"] is None
