@@ -5274,7 +5274,10 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
                 hipLaunchKernelGGL(k_flag, dim3(g), dim3(256), 0, stream, (const double *)ts.zt.as<double>(), thr, n, Ns,
                                    ts.xc.as<double>(), uoff, ulst, dirty, next, pair_counts + it + 1);
         } else {
-            const unsigned gp = (unsigned)std::min<int64_t>(g, 2048);
+            // repeat 2 recomputes the users of the first repeat's flags (10^4 .. 10^5 pairs); repeats 3 .. are a few
+            // hundred pairs at most -- their time is the dispatch of workgroups that find nothing to do: an eighth of the
+            // grid (both kernels stride over their list, so a long list is only walked in more trips)
+            const unsigned gp = (unsigned)std::min<int64_t>(g, it >= 2 ? 256 : 2048);
             hipLaunchKernelGGL(k_zscore_pairs, dim3(gp), dim3(256), 0, stream, (const unsigned int *)cur,
                                (const int *)(pair_counts + it), (int64_t)0, dirty, (const double *)ts.xt.as<double>(),
                                (const double *)ts.xc.as<double>(), (const int *)ref->gidx.as<int>(),
