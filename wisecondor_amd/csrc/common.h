@@ -222,6 +222,8 @@ template <int D, class F> __device__ inline double pw_node_group8(F f, int64_t o
 // turn a sum of -0.0 into +0.0).  No LDS, no stack: pairwise_tree_wave walks the tree twice through an LDS stack,
 // 40 us for a 4 700-bin region; this form takes a few microseconds.  Every lane returns the value.
 template <class F> __device__ inline double pairwise_tree_lanes(F f, int n, int lane) {
+    // (a node of level K - 1 holds at most 256 elements -- its right child, at most 128, is at least half of it -- so two
+    //  more splits always reach leaves: pw_node_serial<2>)
     int K = 0;
     for (int r = n; r > WC_PW_BLOCK; ++K) {          // the right-most path
         int n2 = r / 2;
@@ -241,7 +243,7 @@ template <class F> __device__ inline double pairwise_tree_lanes(F f, int n, int 
         if ((lane >> (LV - 1 - l)) & 1) { off += n2; nn -= n2; }
         else nn = n2;
     }
-    double val = valid ? pw_node_serial<3>(f, (int64_t)off, nn) : 0.0;
+    double val = valid ? pw_node_serial<2>(f, (int64_t)off, nn) : 0.0;
     for (int st = 1; st < nodes; st <<= 1) {          // fold: subtrees of `st` lanes pair up
         const double right = __shfl(val, (lane + st) & 63);
         const bool rvalid = __shfl((int)valid, (lane + st) & 63) != 0;
