@@ -221,7 +221,10 @@ template <int D, class F> __device__ inline double pw_node_group8(F f, int64_t o
 // first lane of its subtree; the other lanes of that subtree hold nothing and the fold skips them (adding +0.0 would
 // turn a sum of -0.0 into +0.0).  No LDS, no stack: pairwise_tree_wave walks the tree twice through an LDS stack,
 // 40 us for a 4 700-bin region; this form takes a few microseconds.  Every lane returns the value.
-template <class F> __device__ inline double pairwise_tree_lanes(F f, int n, int lane) {
+// GROUPS: the nodes are summed by the wave's eight 8-lane groups, eight nodes per round (pw_node_group8: one accumulator
+// and four loads in flight per lane), instead of by their own lanes alone (eight accumulators per lane) -- for callers
+// without the registers; ~3 x the time of the per-lane form, a fifth of the walk through the LDS stack.
+template <bool GROUPS = false, class F> __device__ inline double pairwise_tree_lanes(F f, int n, int lane) {
     // (a node of level K - 1 holds at most 256 elements -- its right child, at most 128, is at least half of it -- so two
     //  more splits always reach leaves: pw_node_serial<2>)
     int K = 0;
@@ -243,7 +246,21 @@ template <class F> __device__ inline double pairwise_tree_lanes(F f, int n, int 
         if ((lane >> (LV - 1 - l)) & 1) { off += n2; nn -= n2; }
         else nn = n2;
     }
-    double val = valid ? pw_node_serial<2>(f, (int64_t)off, nn) : 0.0;
+    double val = 0.0;
+    if constexpr (!GROUPS) {
+        val = valid ? pw_node_serial<2>(f, (int64_t)off, nn) : 0.0;
+    } else {
+        const int sub = lane & 7, grp = lane >> 3;
+        for (int t = 0; 8 * t < nodes; ++t) {         // (nodes is the same in every lane)
+            const int j = 8 * t + grp;                // this group's node of the round: lane j knows where it is
+            const int joff = __shfl(off, j & 63), jn = __shfl(nn, j & 63);
+            const bool jvalid = __shfl((int)valid, j & 63) != 0 && j < nodes;
+            // (the shuffles inside stay within a group: groups may take different branches)
+            const double v = pw_node_group8<2>(f, (int64_t)(jvalid ? joff : 0), jvalid ? jn : 0, sub);
+            const double got = __shfl(v, 8 * (lane & 7));   // the sum of node 8 t + (lane & 7)
+            if ((lane >> 3) == t) val = got;
+        }
+    }
     for (int st = 1; st < nodes; st <<= 1) {          // fold: subtrees of `st` lanes pair up
         const double right = __shfl(val, (lane + st) & 63);
         const bool rvalid = __shfl((int)valid, (lane + st) & 63) != 0;

@@ -44,6 +44,8 @@ struct TestState {
     // Stouffer search
     wc::DevBuf zs, rs2, ns2, sds, sub, tmin, tmax, tmin2, tmax2, cell_state, cell_rec, prefix, reg_abs, reg_flag, rs, jobs_a, jobs_b, job_cnt, partial, cbound, cuts, job_res, hot, cand, cand_cnt;
     wc::DevBuf seg, seg_cnt, out_val, out_x, out_y, out_n, whole, effect, misc, misc2, reduce_tmp, win_bits, bit_off, pairs_a, pairs_b, cut_vals;
+    wc::DevBuf walk_hot;             // k_seg_walk's early starters: [0] count, [16 ..] the list, [16 + 4096 ..] every region's place in it
+    void *walk_hot_clean = nullptr;  // the buffer whose count has been zeroed once (k_walk_rows resets it after every walk)
     int64_t rs_len = 0;
     int64_t last_segs = 0;       // segments of the last segmentation call; negative: -(bound), the count is on the device
     int lat_left = 1;
@@ -135,7 +137,7 @@ struct wc_ctx {
                 &ts.sel, &ts.res_z, &ts.res_r, &ts.cwz, &ts.calls, &ts.n_calls, &ts.zs, &ts.rs2, &ts.ns2, &ts.sds, &ts.sub, &ts.tmin, &ts.tmax, &ts.tmin2, &ts.tmax2, &ts.cell_state, &ts.cell_rec, &ts.prefix, &ts.reg_abs,
                 &ts.reg_flag, &ts.rs, &ts.jobs_a, &ts.jobs_b, &ts.job_cnt, &ts.partial, &ts.cbound, &ts.cuts, &ts.job_res, &ts.hot,
                 &ts.cand, &ts.cand_cnt, &ts.seg, &ts.seg_cnt, &ts.out_val, &ts.out_x, &ts.out_y, &ts.out_n,
-                &ts.whole, &ts.effect, &ts.misc, &ts.misc2, &ts.reduce_tmp, &ts.win_bits, &ts.bit_off, &ts.pairs_a, &ts.pairs_b, &ts.cut_vals, &ts.prof_work, &ts.sd_fail, &prep.eig_ws};
+                &ts.whole, &ts.effect, &ts.misc, &ts.misc2, &ts.reduce_tmp, &ts.win_bits, &ts.bit_off, &ts.pairs_a, &ts.pairs_b, &ts.cut_vals, &ts.prof_work, &ts.sd_fail, &ts.walk_hot, &prep.eig_ws};
     }
 };
 

@@ -1915,13 +1915,24 @@ __global__ void k_fill_rs(double *rs, int64_t n) {
     if (i < n) rs[i] = i > 0 ? 1.0 / sqrt((double)i) : 0.0;
 }
 
+// The regions k_seg_walk should start first (see there): a region whose whole-region value |sum z| / sqrt(n), or one of
+// the 64-bin windows the prefix pass works in, reaches `cut` holds an aberration of some length -- hundreds of loud cells,
+// candidate windows of thousands of bins: up to ten times the mean region's work (a spike of a bin or two costs nothing
+// and is not looked for).  list[0 .. *count - 1]: their numbers; index[region] = its place in the list + 1, or 0.  *count is reset by
+// k_walk_rows (the launch after the walk); a list entry only counts if index[] of THIS batch points back at it.
+struct WalkHot {
+    int *list, *count, *index;
+    int cap;
+    double cut;
+};
 // Prefix sums, sum |z| and a finiteness flag per region; one wave per region (any summation
 // order satisfies window_eps' bound).
 __global__ __launch_bounds__(256) void k_region_prefix(const double *__restrict__ z,
                                                        const Region *__restrict__ regions, int64_t n_regions,
                                                        double *__restrict__ prefix, double *__restrict__ reg_abs,
                                                        int *__restrict__ reg_flag, int *__restrict__ counters,
-                                                       int *__restrict__ out_n, int *__restrict__ misc) {
+                                                       int *__restrict__ out_n, int *__restrict__ misc,
+                                                       const WalkHot hot = WalkHot{nullptr, nullptr, nullptr, 0, 0.0}) {
     const int lane = threadIdx.x & 63;
     int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     // first kernel of a segmentation call: its counters start at zero (no separate memsets)
@@ -1933,7 +1944,7 @@ __global__ __launch_bounds__(256) void k_region_prefix(const double *__restrict_
     const double *zz = z + rg.off;
     double *P = prefix + rg.off + r;
     // 64 consecutive bins per trip (coalesced), inclusive wave scan, running total carried along
-    double a = 0.0, run = 0.0;
+    double a = 0.0, run = 0.0, loud64 = 0.0;
     int finite = 1;
     if (lane == 0) P[0] = 0.0;
     // four trips at a time: their loads and wave scans are independent, only the running total chains them
@@ -1962,7 +1973,9 @@ __global__ __launch_bounds__(256) void k_region_prefix(const double *__restrict_
         for (int u = 0; u < 4; ++u) {
             const int t = t0 + 64 * u + lane;
             if (t < rg.n) P[t + 1] = run + incl[u];
-            run += __shfl(incl[u], 63);
+            const double trip = __shfl(incl[u], 63);
+            loud64 = fmax(loud64, fabs(trip));              // (the trip's 64 bins as one window, see WalkHot)
+            run += trip;
         }
     }
     for (int o = 32; o > 0; o >>= 1) {
@@ -1972,6 +1985,14 @@ __global__ __launch_bounds__(256) void k_region_prefix(const double *__restrict_
     if (lane == 0) {
         reg_abs[r] = a;
         reg_flag[r] = finite;
+        if (hot.index) {
+            int idx = 0;
+            if (finite && rg.n > 0 && (fabs(run) >= hot.cut * sqrt((double)rg.n) || loud64 >= hot.cut * 8.0)) {
+                const int at = atomicAdd(hot.count, 1);
+                if (at < hot.cap) { hot.list[at] = (int)r; idx = at + 1; }
+            }
+            hot.index[r] = idx;
+        }
     }
 }
 
@@ -2138,9 +2159,14 @@ __device__ inline double window_exact_wave(const double *__restrict__ zz, int x,
                                            const WindowMask &wm, wc::PwWaveScratch &sc) {
     if (!wm.valid(x, y)) return 0.0;
     const double *p = zz + x;
+    const int64_t len = (int64_t)(y - x + 1);
     double s;
-    if constexpr (SHORT) s = wc::pairwise_tree_wave([&](int64_t t) { return p[t]; }, (int64_t)(y - x + 1), lane, sc);
-    else s = wc::pairwise_sum_wave([&](int64_t t) { return p[t]; }, (int64_t)(y - x + 1), lane, sc);
+    // (129 .. 8 192 bins: every lane finds its own node of numpy's tree -- the walk through the LDS stack takes ~50 us for
+    //  a 4 700-bin window, and the long windows of an aberrant region were what the slowest workgroups of a batch spent
+    //  their lives on: 110 of 180-245 us)
+    if (len > WC_PW_BLOCK && len <= WC_NPY_BUFSIZE) s = wc::pairwise_tree_lanes<true>([&](int64_t t) { return p[t]; }, (int)len, lane);
+    else if constexpr (SHORT) s = wc::pairwise_tree_wave([&](int64_t t) { return p[t]; }, len, lane, sc);
+    else s = wc::pairwise_sum_wave([&](int64_t t) { return p[t]; }, len, lane, sc);
     s = s + 0.0;        // (np.sum's identity, see window_exact)
     return s / sqrt((double)(y - x + 1));
 }
@@ -3026,11 +3052,44 @@ struct CellGeom {
 
 // MODE 0: extremes with rising cuts, near-extreme windows recorded; MODE 2: windows at or beyond fixed cuts
 // recorded (the whole job by the calling workgroup).  part / parts: this workgroup's share (MODE 0).
+// A near-sweep trip's rows into LDS: thread t < CJ_NB8 owns the t-th 8-entry block that overlaps the trip (aligned to
+// the concatenated array, so the first may start before the trip), loads its eight entries -- trip_load, registers
+// only, so that a caller can have these loads in flight with others -- and leaves them in pn together with the
+// block's extremes over the job's own entries (trip_store; entries past the job's end are staged as 0 and take no
+// part in the extremes).  The queue of the trip is emptied.  A barrier before pn / b8x / b8n / n_items are read.
+struct TripRegs { double v[8]; };
+__device__ inline void trip_load(TripRegs &r, const CellGeom &g, const int a0, const int tid) {
+    const int i0 = (((a0 >> 3) + tid) << 3) - a0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int i = i0 + e;
+        r.v[e] = (tid < CJ_NB8 && i >= 0 && i < CJ_PN && a0 + i <= g.rhi) ? g.P[a0 + i] : 0.0;
+    }
+}
+__device__ inline void trip_store(CellShared &sh, const TripRegs &r, const CellGeom &g, const int a0, const int tid) {
+    if (tid < CJ_NB8) {
+        const int i0 = (((a0 >> 3) + tid) << 3) - a0;
+        double mx = -INFINITY, mn = INFINITY;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int i = i0 + e;
+            if (i >= 0 && i < CJ_PN) {
+                sh.pn[i] = r.v[e];
+                if (a0 + i <= g.rhi) { mx = fmax(mx, r.v[e]); mn = fmin(mn, r.v[e]); }
+            }
+        }
+        sh.b8x[tid] = mx;
+        sh.b8n[tid] = mn;
+    }
+    if (tid == 0) sh.n_items = 0;
+}
+
+// prestaged: the caller's cell_setup has staged this workgroup's first trip already (and a barrier has passed)
 template <int MODE>
 __device__ inline void cell_search(CellShared &sh, const CellGeom g, const double *__restrict__ rs, const double eps2,
                                    const double hi_cut, const double lo_cut, unsigned long long *__restrict__ gcut,
                                    const int part, const int parts, double &vmax, double &vmin, int &wins, int &evals,
-                                   const int tid) {
+                                   const int tid, const bool prestaged = false) {
     const double *__restrict__ P = g.P;
     const int rb = g.rb, rhi = g.rhi;
     const int A1f = rb >> 5, A1l = (rhi - 1) >> 5, K1l = rhi >> 5;
@@ -3092,69 +3151,72 @@ __device__ inline void cell_search(CellShared &sh, const CellGeom g, const doubl
     // more blocks on is ONE bound from the 8-entry block extremes, a row against its own and the next 8-block one
     // bound each; what reaches the cut is queued as (row, 8-block) pairs and evaluated by eight lanes each.
     const int L = rhi - rb;
+    bool staged = MODE == 0 && prestaged;
     for (int r0 = (MODE == 0 ? part : 0) * CJ_TRIP; r0 < L; r0 += (MODE == 0 ? parts : 1) * CJ_TRIP) {
         const int a0 = rb + r0;                              // the trip's first row
-        wc_sync();                                    // the previous trip's rows and queue are done with
-#pragma unroll
-        for (int u = 0; u < CJ_LOADS; ++u) {
-            const int i = tid + 256 * u;
-            if (i < CJ_PN) sh.pn[i] = a0 + i <= rhi ? P[a0 + i] : 0.0;
+        if (!staged) {
+            wc_sync();                                       // the previous trip's rows and queue are done with
+            TripRegs tr;
+            trip_load(tr, g, a0, tid);
+            trip_store(sh, tr, g, a0, tid);
+            share_cuts();
+            wc_sync();
         }
-        if (tid == 0) sh.n_items = 0;
-        share_cuts();
-        wc_sync();
-        // maximum / minimum of the staged entries per 8-entry block (entries past the job's end take no part)
+        staged = false;
+        CJ_CLK(20);
         const int k8_0 = a0 >> 3;
-        if (tid < CJ_NB8) {
-            double mx = -INFINITY, mn = INFINITY;
-            const int i0 = ((k8_0 + tid) << 3) - a0;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int i = i0 + e;
-                if (i >= 0 && i < CJ_PN && a0 + i <= rhi) { mx = fmax(mx, sh.pn[i]); mn = fmin(mn, sh.pn[i]); }
-            }
-            sh.b8x[tid] = mx;
-            sh.b8n[tid] = mn;
-        }
-        wc_sync();
         cuts();
         const int rows_here = L - r0 < CJ_TRIP ? L - r0 : CJ_TRIP;           // rows t = 0 .. rows_here - 1 of this trip
         auto y_near_of = [&](const int ax) {                 // the last end before the row's first 32 x 32 cell
             const int y = (((ax >> 5) + 2) << 5) - 1;
             return y > rhi ? rhi : y;
         };
-        auto push = [&](const int t, const int j8) {        // (row t of the trip, staged 8-block j8)
-            const int at = atomicAdd(&sh.n_items, 1);
-            if (at < CJ_ITEMQ) {
-                sh.itemq[at] = ((unsigned int)t << 8) | (unsigned int)j8;
-            } else {                                         // queue full: the pusher walks the block itself
-                const int ax = a0 + t, y_near = y_near_of(ax);
-                for (int e = 0; e < 8; ++e) {
-                    const int ay = ((k8_0 + j8) << 3) + e;
-                    if (ay > ax && ay <= y_near) see((sh.pn[ay - a0] - sh.pn[t]) * sh.rsn[ay - ax], ax, ay);
+        // rows t_lo .. t_hi of the trip against the staged 8-block j8: ONE reservation for all of them
+        auto push_rows = [&](const int t_lo, const int t_hi, const int j8) {
+            const int at = atomicAdd(&sh.n_items, t_hi - t_lo + 1);
+            for (int t = t_lo; t <= t_hi; ++t) {
+                const int slot = at + (t - t_lo);
+                if (slot < CJ_ITEMQ) {
+                    sh.itemq[slot] = ((unsigned int)t << 8) | (unsigned int)j8;
+                } else {                                     // queue full: the pusher walks the block itself
+                    const int ax = a0 + t, y_near = y_near_of(ax);
+                    for (int e = 0; e < 8; ++e) {
+                        const int ay = ((k8_0 + j8) << 3) + e;
+                        if (ay > ax && ay <= y_near) see((sh.pn[ay - a0] - sh.pn[t]) * sh.rsn[ay - ax], ax, ay);
+                    }
                 }
             }
         };
-        // 8 x 8 cells: a thread per 8-row block of the trip, its end blocks two or more on
-        for (int jb = tid; jb < CJ_NB8; jb += 256) {
-            const int A8 = k8_0 + jb;
-            int t_lo = (A8 << 3) - a0, t_hi = t_lo + 7;       // the block's rows within the trip
+        // The bounds first, every thread's share unrolled (their LDS reads in flight together), as a mask of what
+        // reaches the cut; the pushes -- rare -- afterwards in one loop.
+        // bits 0..3: 8 x 8 cells -- bits 0..2: the 8-row block tid / 2 against its end blocks 2 + 3 (tid & 1) + u blocks
+        // on (two threads share a row block's six), bit 3: the 129th row block of a trip that does not start on a
+        // multiple of eight, its six end blocks by threads 0..5;
+        // bits 4..7: row tid + 256 q against its own 8-block (the entries after it), bits 8..11: against the next one
+        static_assert(CJ_TRIP == 1024 && CJ_RPT <= 4, "the mask of loud bounds: 128 + 1 row blocks, four bits per kind");
+        constexpr int PAIR_TRIPS = 4;
+        auto pair_of = [&](const int u, int &jb, int &j8, int &t_lo, int &t_hi) {
+            jb = u < 3 ? tid >> 1 : 128;
+            j8 = jb + 2 + (u < 3 ? 3 * (tid & 1) + u : tid);
+            t_lo = ((k8_0 + jb) << 3) - a0;
+            t_hi = t_lo + 7;                                  // the block's rows within the trip
             if (t_lo < 0) t_lo = 0;
             if (t_hi >= rows_here) t_hi = rows_here - 1;
-            if (t_lo > t_hi) continue;
-            const int y_near = y_near_of(A8 << 3);            // the same for the eight rows
+            return (u < 3 || tid < 6) && t_lo <= t_hi && ((k8_0 + j8) << 3) <= y_near_of((k8_0 + jb) << 3);   // (the same y_near for the eight rows)
+        };
+        unsigned int loud = 0u;
+#pragma unroll 1                                             // (unrolled: 13 registers of k_seg_walk spilled, and no faster)
+        for (int u = 0; u < PAIR_TRIPS; ++u) {
+            int jb, j8, t_lo, t_hi;
+            if (!pair_of(u, jb, j8, t_lo, t_hi)) continue;
             // (the block's extremes as staged: rows of the neighbouring trip that share it only widen the bound)
-            const double rmx = sh.b8x[jb], rmn = sh.b8n[jb];
-            for (int j8 = jb + 2; ((k8_0 + j8) << 3) <= y_near; ++j8) {
-                const int minlen = ((j8 - jb - 1) << 3) + 1;
-                const double r = rs_above(minlen);
-                const double ub = fmax(sh.b8x[j8] - rmn, 0.0) * r, lb = fmin(sh.b8n[j8] - rmx, 0.0) * r;
-                ++evals;
-                if (ub >= chi || lb <= clo)
-                    for (int t = t_lo; t <= t_hi; ++t) push(t, j8);
-            }
+            const int minlen = ((j8 - jb - 1) << 3) + 1;
+            const double r = rs_above(minlen);
+            const double ub = fmax(sh.b8x[j8] - sh.b8n[jb], 0.0) * r, lb = fmin(sh.b8n[j8] - sh.b8x[jb], 0.0) * r;
+            ++evals;
+            if (ub >= chi || lb <= clo) loud |= 1u << u;
         }
-        // a row against its own 8-block (the entries after it) and the next one
+        __builtin_amdgcn_sched_barrier(0);                   // (both kinds' operands in flight at once cost k_seg_walk its registers)
 #pragma unroll
         for (int q = 0; q < CJ_RPT; ++q) {
             const int t = tid + 256 * q;
@@ -3162,22 +3224,34 @@ __device__ inline void cell_search(CellShared &sh, const CellGeom g, const doubl
             const int ax = a0 + t;
             const double px = sh.pn[t];
             const int kb = (ax >> 3) - k8_0;
-            const int y_near = y_near_of(ax);
             // own block: windows from 1 bin on (the block's extremes include the entries up to the row: a superset)
             {
                 const double ub = fmax(sh.b8x[kb] - px, 0.0), lb = fmin(sh.b8n[kb] - px, 0.0);
                 ++evals;
-                if ((ax & 7) != 7 && (ub >= chi || lb <= clo)) push(t, kb);
+                if ((ax & 7) != 7 && (ub >= chi || lb <= clo)) loud |= 16u << q;
             }
-            if (((k8_0 + kb + 1) << 3) <= y_near) {
+            if (((k8_0 + kb + 1) << 3) <= y_near_of(ax)) {
                 const int minlen = ((k8_0 + kb + 1) << 3) - ax;              // 1..8
                 const double r = sh.rsn[minlen];
                 const double ub = fmax(sh.b8x[kb + 1] - px, 0.0) * r, lb = fmin(sh.b8n[kb + 1] - px, 0.0) * r;
                 ++evals;
-                if (ub >= chi || lb <= clo) push(t, kb + 1);
+                if (ub >= chi || lb <= clo) loud |= 256u << q;
+            }
+        }
+        while (loud) {
+            const int bit = __ffs((int)loud) - 1;
+            loud &= loud - 1u;
+            if (bit < 4) {
+                int jb, j8, t_lo, t_hi;
+                pair_of(bit, jb, j8, t_lo, t_hi);
+                push_rows(t_lo, t_hi, j8);
+            } else {
+                const int t = tid + 256 * (bit & 3);
+                push_rows(t, t, ((a0 + t) >> 3) - k8_0 + (bit >> 3));
             }
         }
         wc_sync();
+        CJ_CLK(22);
         // queued (row, 8-block) pairs: eight lanes per pair
         const int n_items = sh.n_items < CJ_ITEMQ ? sh.n_items : CJ_ITEMQ;
         for (int i = tid >> 3; i < n_items; i += 32) {
@@ -3186,6 +3260,7 @@ __device__ inline void cell_search(CellShared &sh, const CellGeom g, const doubl
             const int ax = a0 + t, ay = ((k8_0 + (int)(it & 255u)) << 3) + (tid & 7);
             if (ay > ax && ay <= y_near_of(ax)) see((sh.pn[ay - a0] - sh.pn[t]) * sh.rsn[ay - ax], ax, ay);
         }
+        CJ_CLK(23);
     }
     wc_sync();
     CJ_CLK(MODE * 4 + 2);
@@ -3305,11 +3380,16 @@ __device__ inline void cell_search(CellShared &sh, const CellGeom g, const doubl
 }
 
 // What both kernels of a job need first: geometry, both table levels of the job in LDS (block 0 = the origin's) with
-// exact edge blocks, the first 64 table factors, empty records.  Ends with a barrier.
+// exact edge blocks, the first 64 table factors, empty records -- and, with stage_r0 >= 0, the near sweep's trip that
+// starts at row stage_r0 (cell_search's `prestaged`).  Every global load of all that is requested before anything is
+// waited for: ONE memory round trip (tables, then edge entries, then the first trip's rows were three).
+// Ends with ONE barrier; the edge blocks are corrected after it, for readers that are at least one more barrier away
+// (the cell sweeps; cell_seed only reads blocks that lie wholly inside the job, which need no correction).
 __device__ inline CellGeom cell_setup(CellShared &sh, const Job job, const Region rg, const int region,
                                       const double *__restrict__ prefix, const double *__restrict__ rs,
                                       const double *__restrict__ tmin, const double *__restrict__ tmax,
-                                      const double *__restrict__ tmin2, const double *__restrict__ tmax2, const int tid) {
+                                      const double *__restrict__ tmin2, const double *__restrict__ tmax2, const int tid,
+                                      const int stage_r0 = -1) {
     const long long base = rg.off + region + job.lo;         // absolute index of the job's first prefix entry
     const long long org = (base >> 7) << 7;
     CellGeom g;
@@ -3319,31 +3399,54 @@ __device__ inline CellGeom cell_setup(CellShared &sh, const Job job, const Regio
     g.job_lo = job.lo;
     const int n1 = (g.rhi >> 5) + 1, n2 = (g.rhi >> 7) + 1;
     const long long k1 = org >> 5, k2 = org >> 7;
-    for (int i = tid; i < n1; i += 256) { sh.tmx[i] = tmax[k1 + i]; sh.tmn[i] = tmin[k1 + i]; }
-    for (int i = tid; i < n2; i += 256) { sh.tmx2[i] = tmax2[k2 + i]; sh.tmn2[i] = tmin2[k2 + i]; }
-    if (tid < 64) sh.rsn[tid] = rs[tid];
-    if (tid == 0) { sh.n_rec[0] = 0; sh.n_rec[1] = 0; sh.lost = 0; }
-    wc_sync();
+    static_assert(CJ_T1 <= 512 && CJ_T2 <= 256, "two and one table entries per thread");
+    // ---- loads
+    double t1x[2], t1n[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + 256 * u;
+        t1x[u] = i < n1 ? tmax[k1 + i] : 0.0;
+        t1n[u] = i < n1 ? tmin[k1 + i] : 0.0;
+    }
+    const double t2x = tid < n2 ? tmax2[k2 + tid] : 0.0, t2n = tid < n2 ? tmin2[k2 + tid] : 0.0;
+    const double rs_mine = tid < 64 ? rs[tid] : 0.0;
     // The tables are aligned to the concatenated array: the job's first and last block of either level also cover
     // entries of its neighbours (another region's prefix sums: a jump).  Their extremes over the job's own
     // entries, a wave each -- otherwise every cell on the job's edges reaches the cut.
-    {
-        const int w = tid >> 6, lane = tid & 63;
-        const int lvl = w >> 1, last = w & 1;                // waves 0 / 1: 32-blocks, 2 / 3: 128-blocks; first / last block
-        const int shift = lvl ? 7 : 5;
-        const int blk = last ? g.rhi >> shift : g.rb >> shift;
-        double mx = -INFINITY, mn = INFINITY;
-        for (int e = lane; e < (1 << shift); e += 64) {
-            const int a = (blk << shift) + e;
-            if (a >= g.rb && a <= g.rhi) { const double v = g.P[a]; mx = fmax(mx, v); mn = fmin(mn, v); }
-        }
-        for (int o = 32; o > 0; o >>= 1) { mx = fmax(mx, __shfl_xor(mx, o)); mn = fmin(mn, __shfl_xor(mn, o)); }
-        if (lane == 0) {
-            if (lvl) { sh.tmx2[blk] = mx; sh.tmn2[blk] = mn; }
-            else { sh.tmx[blk] = mx; sh.tmn[blk] = mn; }
-        }
+    const int w = tid >> 6, lane = tid & 63;
+    const int lvl = w >> 1, last = w & 1;                    // waves 0 / 1: 32-blocks, 2 / 3: 128-blocks; first / last block
+    const int shift = lvl ? 7 : 5;
+    const int blk = last ? g.rhi >> shift : g.rb >> shift;
+    double ev[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = lane + 64 * u, a = (blk << shift) + e;
+        ev[u] = (e < (1 << shift) && a >= g.rb && a <= g.rhi) ? g.P[a] : NAN;
     }
+    TripRegs tr;
+    if (stage_r0 >= 0) trip_load(tr, g, g.rb + stage_r0, tid);
+    // ---- LDS
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + 256 * u;
+        if (i < n1) { sh.tmx[i] = t1x[u]; sh.tmn[i] = t1n[u]; }
+    }
+    if (tid < n2) { sh.tmx2[tid] = t2x; sh.tmn2[tid] = t2n; }
+    if (tid < 64) sh.rsn[tid] = rs_mine;
+    if (tid == 0) { sh.n_rec[0] = 0; sh.n_rec[1] = 0; sh.lost = 0; }
+    if (stage_r0 >= 0) trip_store(sh, tr, g, g.rb + stage_r0, tid);
+    double mx = -INFINITY, mn = INFINITY;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (ev[u] == ev[u]) { mx = fmax(mx, ev[u]); mn = fmin(mn, ev[u]); }
+    for (int o = 32; o > 0; o >>= 1) { mx = fmax(mx, __shfl_xor(mx, o)); mn = fmin(mn, __shfl_xor(mn, o)); }
     wc_sync();
+    // (a block that lies wholly inside the job keeps the table's entry -- the same numbers, and cell_seed may be reading it)
+    const bool partial = last ? ((g.rhi + 1) & ((1 << shift) - 1)) != 0 : (g.rb & ((1 << shift) - 1)) != 0;
+    if (lane == 0 && partial) {
+        if (lvl) { sh.tmx2[blk] = mx; sh.tmn2[blk] = mn; }
+        else { sh.tmx[blk] = mx; sh.tmn[blk] = mn; }
+    }
     return g;
 }
 
@@ -3408,13 +3511,14 @@ __global__ __launch_bounds__(256) void k_seg_job(const Job *__restrict__ jobs, i
     const unsigned long long t_begin = clock64();
     wc_sync();
 #endif
-    const CellGeom g = cell_setup(sh, job, rg, job.region, prefix, rs, tmin, tmax, tmin2, tmax2, tid);
+    const bool pre = part * CJ_TRIP < L;          // this part's first near-sweep trip rides on the set-up's loads
+    const CellGeom g = cell_setup(sh, job, rg, job.region, prefix, rs, tmin, tmax, tmin2, tmax2, tid, pre ? part * CJ_TRIP : -1);
     cell_seed(sh, g, T, tid);
     wc_sync();
     CJ_CLK(1);
     double vmax = -INFINITY, vmin = INFINITY, d2 = -INFINITY, d3 = INFINITY;
     int wins = 0, evals = 0;
-    cell_search<0>(sh, g, rs, eps2, INFINITY, -INFINITY, js->cut, part, parts, vmax, vmin, wins, evals, tid);
+    cell_search<0>(sh, g, rs, eps2, INFINITY, -INFINITY, js->cut, part, parts, vmax, vmin, wins, evals, tid, pre);
     block_minmax4(vmax, vmin, d2, d3, tid);
     // this part's extremes and record into the job's state
     CellRec *jrec = grec + (int64_t)j * 2 * CJ_GREC;
@@ -4805,7 +4909,8 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
                                                   const double *__restrict__ tmax, const double *__restrict__ tmin2,
                                                   const double *__restrict__ tmax2, Seg *__restrict__ wsegs,
                                                   int seg_cap, int *__restrict__ out_n,
-                                                  unsigned long long *__restrict__ work, int per_sample) {
+                                                  unsigned long long *__restrict__ work, int per_sample,
+                                                  const WalkHot hot) {
     __shared__ CellShared sh;
     __shared__ Job stack[WALK_STACK];
     __shared__ int s_sp, s_nseg, s_stop;
@@ -4813,11 +4918,23 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
     __shared__ double seg_val[TREE_SEGS];
     __shared__ int seg_x[TREE_SEGS], seg_y[TREE_SEGS];
     const int tid = threadIdx.x;
-    int region = blockIdx.x;
-    if (region >= n_regions) return;
-    if (per_sample > 1) {                          // workgroup w: chromosome w / samples of sample w % samples
-        const int samples = n_regions / per_sample;
-        region = (int)(blockIdx.x % samples) * per_sample + (int)(blockIdx.x / samples);
+    // The kernel lasts as long as its slowest workgroup, and the slow ones (a region with a long aberration: 150-250 us
+    // against a mean of 44) must not be among the last to start: the first hot.cap workgroups of the grid take the
+    // regions of the hot list (k_region_prefix), the regions' own workgroups then leave them alone.
+    int region;
+    if ((int)blockIdx.x < hot.cap) {
+        if ((int)blockIdx.x >= *hot.count) return;
+        region = hot.list[blockIdx.x];
+        if (region < 0 || region >= n_regions || hot.index[region] != (int)blockIdx.x + 1) return;   // (an entry of an earlier batch)
+    } else {
+        const int wg = (int)blockIdx.x - hot.cap;
+        region = wg;
+        if (region >= n_regions) return;
+        if (per_sample > 1) {                      // workgroup w: chromosome w / samples of sample w % samples
+            const int samples = n_regions / per_sample;
+            region = (wg % samples) * per_sample + wg / samples;
+        }
+        if (hot.cap > 0 && hot.index[region] != 0) return;         // (started early)
     }
     const Region rg = regions[region];
     if (rg.n <= 0) return;                         // (out_n was zeroed by the set-up kernel)
@@ -4848,11 +4965,11 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
         wc_sync();
         if (tid == 0) --s_sp;
         if (job.hi - job.lo <= 0) continue;
-        const CellGeom g = cell_setup(sh, job, rg, region, prefix, rs, tmin, tmax, tmin2, tmax2, tid);
+        const CellGeom g = cell_setup(sh, job, rg, region, prefix, rs, tmin, tmax, tmin2, tmax2, tid, 0);
         cell_seed(sh, g, T, tid);
         wc_sync();
         double vmax = -INFINITY, vmin = INFINITY, d2 = -INFINITY, d3 = INFINITY;
-        cell_search<0>(sh, g, rs, eps2, INFINITY, -INFINITY, nullptr, 0, 1, vmax, vmin, wins, evals, tid);
+        cell_search<0>(sh, g, rs, eps2, INFINITY, -INFINITY, nullptr, 0, 1, vmax, vmin, wins, evals, tid, true);
         block_minmax4(vmax, vmin, d2, d3, tid);
         if (sh.lost) {                              // a cell queue overflowed: the general path (its overflow leads to the exact scan)
             if (tid == 0) { atomicOr(&counters[6], 32); s_stop = 1; }
@@ -4960,7 +5077,8 @@ __global__ __launch_bounds__(256) void k_walk_rows(const Seg *__restrict__ wsegs
                                                    int seg_cap,
                                                    const Region *__restrict__ regions, const double *__restrict__ ratio,
                                                    const int *__restrict__ gpos, int max_calls,
-                                                   double *__restrict__ reg_calls) {
+                                                   double *__restrict__ reg_calls, int *__restrict__ hot_count) {
+    if (hot_count && blockIdx.x == 0 && threadIdx.x == 0) *hot_count = 0;    // (the walk is over: the next batch's list starts empty)
     // ratios staged in LDS up to STAGED values (40 KB: three workgroups per CU); the counting median up to COUNTED (beyond
     // that its L x L / 256 dependent LDS reads per thread lose to the selection's eight passes).  An item costs ~20 us of
     // dependent round trips and barriers whatever its length: 2 304 workgroups with 16 KB each were slower (75 / 38 us)
@@ -5539,10 +5657,25 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     // (a 256-thread workgroup per region -- 1 024 coalesced bins per trip, four wave scans, one barrier -- measured 53 us
     //  against this kernel's 49 at 125 x 50 kb: what these set-up launches wait for is the half of the chip k_sd_fast's
     //  1 024-thread workgroups hold on the side stream, not their own parallelism)
+    // k_seg_walk's early starters (WalkHot): listed by k_region_prefix; WC_TEST_WALK_HOT=0 switches them off
+    WalkHot whot{nullptr, nullptr, nullptr, 0, 0.0};
+    if (walk_path && !fused && !(getenv("WC_TEST_WALK_HOT") && getenv("WC_TEST_WALK_HOT")[0] == '0')) {
+        const int cap = n_regions >= 4096 ? 4096 : 512;
+        if ((rc = ts.walk_hot.reserve(sizeof(int) * (16 + 4096 + n_regions)))) return rc;
+        if (ts.walk_hot.p != ts.walk_hot_clean) {
+            WC_HIP(hipMemsetAsync(ts.walk_hot.p, 0, sizeof(int) * 16, stream));
+            ts.walk_hot_clean = ts.walk_hot.p;
+        }
+        whot.count = ts.walk_hot.as<int>();
+        whot.list = whot.count + 16;
+        whot.index = whot.count + 16 + 4096;
+        whot.cap = cap;
+        whot.cut = 0.75 * thr;
+    }
     if (!fused)
     hipLaunchKernelGGL(k_region_prefix, dim3((unsigned)cdiv(n_regions, 4)), dim3(256), 0, stream, z_dev, regions_dev,
                        n_regions, ts.prefix.as<double>(), ts.reg_abs.as<double>(), ts.reg_flag.as<int>(), counters,
-                       ts.out_n.as<int>(), ts.misc.as<int>());
+                       ts.out_n.as<int>(), ts.misc.as<int>(), whot);
     // The block tables: the walker's cell search, the quiet-job certificate (k_seg_quiet; measured -7 % per 250 kb batch
     // and -17 % per 50 kb batch on data where 10-40 % of the regions hold a call) and the bound-driven rounds read them
     block_tables();
@@ -5588,16 +5721,17 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     h[4] = 0;
     if (walk_path) {
         ts.mark(10, stream);
-        hipLaunchKernelGGL(k_seg_walk, dim3((unsigned)n_regions), dim3(256), 0, stream, counters, regions_dev,
+        hipLaunchKernelGGL(k_seg_walk, dim3((unsigned)(n_regions + whot.cap)), dim3(256), 0, stream, counters, regions_dev,
                            (int)n_regions, (const int *)ts.reg_flag.as<int>(), (const double *)ts.prefix.as<double>(),
                            (const double *)ts.rs.as<double>(), (const double *)ts.reg_abs.as<double>(), z_dev, thr,
                            min_search, (const double *)ts.tmin.as<double>(), (const double *)ts.tmax.as<double>(),
                            (const double *)ts.tmin2.as<double>(), (const double *)ts.tmax2.as<double>(), ts.seg.as<Seg>(),
                            (int)seg_cap, ts.out_n.as<int>(), work,
-                           (tail->per_sample > 1 && n_regions % tail->per_sample == 0) ? tail->per_sample : 0);   // (125 x 50 kb: 287 -> 255 us)
+                           (tail->per_sample > 1 && n_regions % tail->per_sample == 0) ? tail->per_sample : 0,   // (125 x 50 kb: 287 -> 255 us)
+                           whot);
         hipLaunchKernelGGL(k_walk_rows, dim3(768), dim3(256), 0, stream, (const Seg *)ts.seg.as<Seg>(),
                            (const int *)(counters + 4), (int)seg_cap, regions_dev, tail->ratio, tail->gpos,
-                           max_calls, tail->reg_calls);
+                           max_calls, tail->reg_calls, whot.count);
         ts.mark(11, stream);
         const int64_t bound = seg_cap;
         WC_HIP(hipMemcpyAsync(h, counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
