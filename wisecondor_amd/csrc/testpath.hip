@@ -4917,7 +4917,7 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
     __shared__ BestPair s_best[4];
     __shared__ double seg_val[TREE_SEGS];
     __shared__ int seg_x[TREE_SEGS], seg_y[TREE_SEGS];
-    const int tid = threadIdx.x;
+    const int tid0 = threadIdx.x;
     // The kernel lasts as long as its slowest workgroup, and the slow ones (a region with a long aberration: 150-250 us
     // against a mean of 44) must not be among the last to start: the first hot.cap workgroups of the grid take the
     // regions of the hot list (k_region_prefix), the regions' own workgroups then leave them alone.
@@ -4939,7 +4939,7 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
     const Region rg = regions[region];
     if (rg.n <= 0) return;                         // (out_n was zeroed by the set-up kernel)
     if (rg.n > CJ_MAXLEN || !reg_flag[region]) {
-        if (tid == 0) atomicOr(&counters[6], rg.n > CJ_MAXLEN ? 1 : 2);      // (the bits say why: tools/gpu_test_scale.py prints them with WC_TEST_VERBOSE)
+        if (tid0 == 0) atomicOr(&counters[6], rg.n > CJ_MAXLEN ? 1 : 2);      // (the bits say why: tools/gpu_test_scale.py prints them with WC_TEST_VERBOSE)
         return;
     }
     const double eps = window_eps(rg.n, reg_abs[region]);
@@ -4950,15 +4950,20 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
     static_assert(4 * sizeof(wc::PwWaveScratch) <= sizeof(sh.pn) + sizeof(sh.b8x) + sizeof(sh.b8n) + sizeof(sh.q2) +
                                                        sizeof(sh.q1) + sizeof(sh.l1) + sizeof(sh.itemq),
                   "the exact evaluation's scratch does not fit the search's staging area");
-    const int lane = tid & 63, w = tid >> 6;
     int wins = 0, evals = 0;
-    if (tid == 0) {
+    if (tid0 == 0) {
         Job root;
         root.region = region; root.lo = 0; root.hi = rg.n; root.pad = 0;
         stack[0] = root;
         s_sp = 1; s_nseg = 0; s_stop = 0;
     }
     while (true) {
+        // (the thread's number as something the compiler cannot see through: everything derived from it -- dozens of lane
+        //  offsets and LDS addresses -- is otherwise computed once in front of this loop and kept in registers through all
+        //  of it: 18 of them spilled to scratch memory)
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, w = tid >> 6;
         wc_sync();
         if (s_sp == 0 || s_stop) break;
         const Job job = stack[s_sp - 1];
@@ -5044,6 +5049,7 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
     // ---- the region's segments, appended to the batch's list for k_walk_rows (the call rows: position order, genomic
     // bounds, effect size); pad = the segment's number within the region | the region's count << 16
     wc_sync();
+    const int tid = tid0, lane = tid & 63, w = tid >> 6;
     const int nseg = s_nseg;
     if (tid == 0) {
         out_n[region] = nseg;
