@@ -441,3 +441,52 @@ def test_whole_region_values_at_every_tree_shape(wt):
     whole, _ = wt.stouffer_segments(regions, np.inf, 3)
     want = np.array([np.sum(z) / np.sqrt(len(z)) for z in regions])
     assert same_bits(whole, want), [n for n, a, b in zip(lengths, whole, want) if not same_bits([a], [b])]
+
+
+def test_late_repeats_in_one_launch(wt, monkeypatch, capfd):
+    """Batches run repeats 3 .. as ONE launch of one workgroup (k_lat_repeats from repeat 3 on) -- as a rule nothing is
+    queued by then.  Samples with scattered loud bins, where repeats 3 and 4 still have pairs queued: the outputs of that form,
+    of a launch pair per repeat (WC_TEST_TAIL_REPEATS=0) and of the forced overflow (a cap of 0 pairs: the batch is
+    repeated with launch pairs) are the same bits, and the later repeats really had pairs queued."""
+    import re
+    rng = np.random.RandomState(77)
+    sizes = np.array([260, 240, 230, 210, 200, 190, 180, 170, 160, 150, 150, 140, 120, 110, 100, 90, 90, 80, 60, 60, 50, 50], dtype=np.int64)
+    total = int(sizes.sum())
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    mask = np.ones(total, dtype=bool)
+    B, S = total, 30
+    corrected = 1.0 + 0.02 * rng.standard_normal((B, S))
+    idx, dst = wt.getReference(np.asfortranarray(corrected), sizes, np.cumsum(sizes), 40, 1, 1)
+    comps = np.linalg.qr(rng.standard_normal((B, 3)))[0].T
+    mean = np.full(B, 1.0 / B) * (1 + 0.01 * rng.standard_normal(B))
+    reference = wt.Reference(idx, dst, sizes, sizes, mask, mean, comps, binsize=1e6)
+    samples = []
+    r2 = np.random.RandomState(5)
+    for s_ in range(48):
+        lam = np.full(total, 2500.0) * (1 + 0.02 * r2.standard_normal(total)).clip(0.5)
+        lam[r2.rand(total) < 0.1] *= 1.15                       # scattered loud bins: flags in the later repeats, too
+        counts = r2.poisson(lam).astype(np.int32)
+        samples.append({str(c + 1): counts[offs[c]:offs[c + 1]] for c in range(22)})
+    thr = 5.0                                                   # (pairs queued per repeat here: 14 797, 1 016, 96, 0)
+    monkeypatch.setenv("WC_TEST_VERBOSE", "1")
+    capfd.readouterr()
+    got = wt.test_batch(reference, samples, thr)
+    err = capfd.readouterr().err
+    queued = [int(v) for v in re.findall(r"pairs queued per repeat:((?: \d+)+)", err)[-1].split()]
+    assert queued[2] > 0 and queued[3] > 0, queued          # repeats 3 and 4 had work
+    assert "batch repeated with a launch pair" not in err
+    monkeypatch.setenv("WC_TEST_TAIL_REPEATS", "0")
+    want = wt.test_batch(reference, samples, thr)
+    monkeypatch.delenv("WC_TEST_TAIL_REPEATS")
+    monkeypatch.setenv("WC_TEST_TAIL_CAP", "0")
+    capfd.readouterr()
+    again = wt.test_batch(reference, samples, thr)
+    assert "batch repeated with a launch pair" in capfd.readouterr().err
+    for other in (want, again):
+        for a, b in zip(got, other):
+            assert same_bits(np.asarray(a["results_calls"], dtype=np.float64), np.asarray(b["results_calls"], dtype=np.float64))
+            assert same_bits(np.concatenate([np.asarray(v) for v in a["results_z"]]), np.concatenate([np.asarray(v) for v in b["results_z"]]))
+            assert same_bits(np.concatenate([np.asarray(v) for v in a["results_r"]]), np.concatenate([np.asarray(v) for v in b["results_r"]]))
+            assert same_bits(np.asarray(a["results_cwz"], dtype=np.float64), np.asarray(b["results_cwz"], dtype=np.float64))
+            assert same_bits([a["asdef"]], [b["asdef"]])
+    reference.close()

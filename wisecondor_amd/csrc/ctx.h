@@ -46,6 +46,8 @@ struct TestState {
     wc::DevBuf seg, seg_cnt, out_val, out_x, out_y, out_n, whole, effect, misc, misc2, reduce_tmp, win_bits, bit_off, pairs_a, pairs_b, cut_vals;
     wc::DevBuf walk_hot;             // k_seg_walk's early starters: [0] count, [16 ..] the list, [16 + 4096 ..] every region's place in it
     void *walk_hot_clean = nullptr;  // the buffer whose count has been zeroed once (k_walk_rows resets it after every walk)
+    bool tail_used = false, no_tail = false;   // run_repeat: the late repeats ran as ONE workgroup (k_lat_repeats); no_tail: the batch is being repeated without that
+    int *tail_flag = nullptr;                  // ... its overflow word (device)
     int64_t rs_len = 0;
     int64_t last_segs = 0;       // segments of the last segmentation call; negative: -(bound), the count is on the device
     int lat_left = 1;

@@ -1341,6 +1341,7 @@ __global__ __launch_bounds__(256) void k_flag_hits(const unsigned int *__restric
 // users (as k_flag_pairs), barrier.  More queued pairs than LAT_PAIR_CAP in a repeat: *overflow
 // is raised and the caller repeats the call on the general path.
 constexpr int LAT_PAIR_CAP = 1 << 16;
+constexpr int TAIL_PAIR_CAP = 2048;             // batches: pairs a late repeat may hold for the one-workgroup form (16 trips)
 __global__ __launch_bounds__(1024) void k_lat_repeats(unsigned int *__restrict__ pairs_a,
                                                       unsigned int *__restrict__ pairs_b, int *__restrict__ pair_counts,
                                                       int repeats, unsigned int *__restrict__ dirty,
@@ -1350,7 +1351,11 @@ __global__ __launch_bounds__(1024) void k_lat_repeats(unsigned int *__restrict__
                                                       const int *__restrict__ users, double *__restrict__ zT,
                                                       double *__restrict__ rT, double *__restrict__ nT,
                                                       double *__restrict__ sdT, int *__restrict__ overflow,
-                                                      int first_n) {
+                                                      int first_n, int it0 = 1, int64_t osm = 0, int cap = LAT_PAIR_CAP) {
+    // (batches: repeats it0 + 1 .. of a whole batch by this ONE workgroup -- after the second repeat there is as a rule
+    //  nothing queued at all (125 x 50 kb: 12 688 threshold hits, 3 280 pairs for repeat 2, then 0, 0, 0), and two
+    //  launches per empty repeat were 43 us of a 327 us batch; more than `cap` pairs: *overflow, the caller repeats the
+    //  batch with a launch pair per repeat)
     const int tid = threadIdx.x, lane = tid & 63, sub = lane & 7, gbase = lane & ~7;
     if (first_n > 0) {
         // the flag pass of the first repeat (k_flag's job) for up to 16 384 pairs: the z-scores and working
@@ -1372,12 +1377,12 @@ __global__ __launch_bounds__(1024) void k_lat_repeats(unsigned int *__restrict__
         __threadfence_block();
         wc_sync();
     }
-    for (int it = 1; it < repeats; ++it) {
+    for (int it = it0; it < repeats; ++it) {
         unsigned int *cur = (it & 1) ? pairs_a : pairs_b;
         unsigned int *next = it + 1 < repeats ? ((it & 1) ? pairs_b : pairs_a) : nullptr;
         const int n = pair_counts[it];
         if (n == 0) return;                      // nothing queued: every later repeat is identical
-        if (n > LAT_PAIR_CAP) {
+        if (n > cap) {
             if (tid == 0) *overflow = 1;
             return;
         }
@@ -1386,7 +1391,7 @@ __global__ __launch_bounds__(1024) void k_lat_repeats(unsigned int *__restrict__
             if (t < n) {
                 const unsigned int gid = cur[t];
                 if (sub == 0) atomicAnd(&dirty[gid >> 5], ~(1u << (gid & 31)));
-                zscore_pair8(gid, sub, gbase, XT, XC, gidx, nref, k, Ns, zT, rT, nT, sdT);
+                zscore_pair8(gid, sub, gbase, XT, XC, gidx, nref, k, Ns, zT, rT, nT, sdT, osm);
             }
         }
         __threadfence_block();
@@ -1394,7 +1399,7 @@ __global__ __launch_bounds__(1024) void k_lat_repeats(unsigned int *__restrict__
         for (int t0 = 0; t0 < n; t0 += 1024) {
             const int t = t0 + tid;
             flag_wave(t < n ? (int64_t)cur[t] : 0, t < n, zT, thr, Ns, XC, users_off, users, dirty, next,
-                      pair_counts + it + 1);
+                      pair_counts + it + 1, osm);
         }
         __threadfence_block();
         wc_sync();
@@ -1924,6 +1929,7 @@ struct WalkHot {
     int *list, *count, *index;
     int cap;
     double cut;
+    const int *tail_flag;     // (rides along: the late repeats' overflow word, copied to misc[1] for the host)
 };
 // Prefix sums, sum |z| and a finiteness flag per region; one wave per region (any summation
 // order satisfies window_eps' bound).
@@ -1932,12 +1938,12 @@ __global__ __launch_bounds__(256) void k_region_prefix(const double *__restrict_
                                                        double *__restrict__ prefix, double *__restrict__ reg_abs,
                                                        int *__restrict__ reg_flag, int *__restrict__ counters,
                                                        int *__restrict__ out_n, int *__restrict__ misc,
-                                                       const WalkHot hot = WalkHot{nullptr, nullptr, nullptr, 0, 0.0}) {
+                                                       const WalkHot hot = WalkHot{nullptr, nullptr, nullptr, 0, 0.0, nullptr}) {
     const int lane = threadIdx.x & 63;
     int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     // first kernel of a segmentation call: its counters start at zero (no separate memsets)
     if (blockIdx.x == 0 && threadIdx.x < 8) counters[threadIdx.x] = 0;
-    if (blockIdx.x == 0 && threadIdx.x >= 8 && threadIdx.x < 12 && misc) misc[threadIdx.x - 8] = 0;
+    if (blockIdx.x == 0 && threadIdx.x >= 8 && threadIdx.x < 12 && misc) misc[threadIdx.x - 8] = (threadIdx.x == 9 && hot.tail_flag) ? *hot.tail_flag : 0;   // ([1]: the late repeats' overflow word, see run_repeat)
     if (r >= n_regions) return;
     if (lane == 0) out_n[r] = 0;
     const Region rg = regions[r];
@@ -4131,7 +4137,8 @@ __global__ __launch_bounds__(NT) void k_lat_setup(const double *__restrict__ zsr
                                                    int *__restrict__ reg_flag, double *__restrict__ whole,
                                                    double *__restrict__ whole2, Job *__restrict__ jobs,
                                                    int *__restrict__ counters, int *__restrict__ out_n,
-                                                   int *__restrict__ misc, int64_t n_regions) {
+                                                   int *__restrict__ misc, int64_t n_regions,
+                                                   const int *__restrict__ tail_flag = nullptr) {
     extern __shared__ double zl[];                // the region's kept z values (the prefix pass and the exact sum read them here)
     constexpr int NW = NT / 64;
     __shared__ int s_cnt[NW];
@@ -4142,7 +4149,7 @@ __global__ __launch_bounds__(NT) void k_lat_setup(const double *__restrict__ zsr
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t r = blockIdx.x;
     if (r == 0 && tid < 8) counters[tid] = tid == 1 ? (int)n_regions : 0;
-    if (r == 0 && tid >= 8 && tid < 12 && misc) misc[tid - 8] = 0;
+    if (r == 0 && tid >= 8 && tid < 12 && misc) misc[tid - 8] = (tid == 9 && tail_flag) ? *tail_flag : 0;   // ([1]: the late repeats' overflow word, see run_repeat)
     WC_STAMP(0);
     const int64_t i = r / n_sel;
     const int si = (int)(r - i * n_sel);
@@ -5277,7 +5284,7 @@ static int reserve_repeat_arrays(TestState &ts, int64_t n, int64_t Ns) {
 // runs the tiled kernel they are written sample-major [Ns, B] straight away (ts.sm_out tells which it was)
 int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int64_t Ns, double thr, int repeats,
                hipStream_t stream, bool lat = false, double *asdef_out = nullptr, bool xt_ready = false,
-               bool allow_sm = false) {
+               bool allow_sm = false, bool allow_tail = false) {
     TestState &ts = ctx->ts;
     const int64_t n = ref->B * Ns;
     int rc;
@@ -5319,6 +5326,11 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
         WC_HIP(hipMemsetAsync(ts.sdt.p, 0xFF, sizeof(double) * n, stream));
     }
     const int *uoff = ref->users_off.as<int>(), *ulst = ref->users.as<int>();
+    // batches whose caller can repeat them (allow_tail): repeats 3 .. by one workgroup in one launch
+    ts.tail_used = false;
+    ts.tail_flag = nullptr;
+    const bool tail_ok = allow_tail && !lat && !ts.no_tail && repeats > 2 && ref->k <= 128 &&
+                         !(getenv("WC_TEST_TAIL_REPEATS") && getenv("WC_TEST_TAIL_REPEATS")[0] == '0');
     // latency mode, a sample or two: the first repeat's flag pass runs at the head of k_lat_repeats
     const bool lat_flag_inside = lat && repeats > 1 && ref->k <= 128 && n <= 16384;
     for (int it = 0; it < repeats; ++it) {
@@ -5397,8 +5409,20 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
             else if (!lat_flag_inside)
                 hipLaunchKernelGGL(k_flag, dim3(g), dim3(256), 0, stream, (const double *)ts.zt.as<double>(), thr, n, Ns,
                                    ts.xc.as<double>(), uoff, ulst, dirty, next, pair_counts + it + 1);
+        } else if (it == 2 && tail_ok) {
+            // repeats 3 .. in ONE launch of one workgroup (see k_lat_repeats); its overflow word reaches the caller through
+            // the segmentation's set-up kernel (ts.tail_flag -> misc[1])
+            ts.tail_used = true;
+            ts.tail_flag = pair_counts + repeats + 1;
+            hipLaunchKernelGGL(k_lat_repeats, dim3(1), dim3(1024), 0, stream, ts.pairs_a.as<unsigned int>(),
+                               ts.pairs_b.as<unsigned int>(), pair_counts, repeats, dirty,
+                               (const double *)ts.xt.as<double>(), ts.xc.as<double>(), (const int *)ref->gidx.as<int>(),
+                               (const int *)ref->nref.as<int>(), ref->k, Ns, thr, uoff, ulst, ts.zt.as<double>(),
+                               ts.rt.as<double>(), ts.nt.as<double>(), ts.sdt.as<double>(), pair_counts + repeats + 1,
+                               0, 2, osm, getenv("WC_TEST_TAIL_CAP") ? atoi(getenv("WC_TEST_TAIL_CAP")) : TAIL_PAIR_CAP);   // (the test suite forces the overflow with a cap of 0)
+            break;
         } else {
-            // repeat 2 recomputes the users of the first repeat's flags (10^4 .. 10^5 pairs); repeats 3 .. are a few
+            // repeat 2 recomputes the users of the first repeat's flags (10^3 .. 10^5 pairs); repeats 3 .. are a few
             // hundred pairs at most -- their time is the dispatch of workgroups that find nothing to do: an eighth of the
             // grid (both kernels stride over their list, so a long list is only walked in more trips)
             const unsigned gp = (unsigned)std::min<int64_t>(g, it >= 2 ? 256 : 2048);
@@ -5639,7 +5663,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
                            fused->goff, fused->m2g, fused->sel, fused->n_sel, fused->minref, fused->zc, fused->rc,
                            fused->gpos, fused->regions, ts.prefix.as<double>(), ts.reg_abs.as<double>(),
                            ts.reg_flag.as<int>(), ts.whole.as<double>(), fused->whole_copy, ts.jobs_a.as<Job>(), counters,
-                           ts.out_n.as<int>(), ts.misc.as<int>(), n_regions);
+                           ts.out_n.as<int>(), ts.misc.as<int>(), n_regions, ts.tail_used ? (const int *)ts.tail_flag : (const int *)nullptr);
     // Callers with call rows, regions up to CJ_MAXLEN bins, no -mineffectsize mask: the whole recursion of every region
     // in ONE launch (k_seg_walk), no host round trip.  WC_TEST_WALK=0: the paths it replaces (tree kernel up to
     // TREE_MAXLEN, host-driven rounds beyond).
@@ -5664,7 +5688,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     //  against this kernel's 49 at 125 x 50 kb: what these set-up launches wait for is the half of the chip k_sd_fast's
     //  1 024-thread workgroups hold on the side stream, not their own parallelism)
     // k_seg_walk's early starters (WalkHot): listed by k_region_prefix; WC_TEST_WALK_HOT=0 switches them off
-    WalkHot whot{nullptr, nullptr, nullptr, 0, 0.0};
+    WalkHot whot{nullptr, nullptr, nullptr, 0, 0.0, ts.tail_used ? ts.tail_flag : nullptr};
     if (walk_path && !fused && !(getenv("WC_TEST_WALK_HOT") && getenv("WC_TEST_WALK_HOT")[0] == '0')) {
         const int cap = n_regions >= 4096 ? 4096 : 512;
         if ((rc = ts.walk_hot.reserve(sizeof(int) * (16 + 4096 + n_regions)))) return rc;
@@ -6437,7 +6461,9 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
                            ts.misc2.as<int>(), repeats > 0 ? repeats + 2 + n_words : 0);
     }
     ts.mark(1, stream);
-    if ((rc = run_repeat(ctx, ref, ts.data.as<double>(), Np, threshold, repeats, stream, lat, asdef, !lat, !lat))) return rc;
+    if ((rc = run_repeat(ctx, ref, ts.data.as<double>(), Np, threshold, repeats, stream, lat, asdef, !lat, !lat,
+                         !lat && calls && n_calls)))      // (the late repeats as one launch: only where the status check below runs)
+        return rc;
     // run_repeat forked the side stream for stdDevAvg at its very end; with sample-major outputs nothing is enqueued on
     // the launch stream before the inflated outputs go to the side stream too: they ride on the same fork
     ctx->side_fresh = !lat && ts.sm_out && ctx->side_pending && !ts.profile;
@@ -6567,8 +6593,18 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
                            (const int *)ts.sd_fail.as<int>());
         int *overflow = (int *)ctx->pinned + 16;
         if (!lat) {
-            WC_HIP(hipMemcpyAsync(overflow, ts.misc.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+            WC_HIP(hipMemcpyAsync(overflow, ts.misc.p, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
             WC_HIP(hipStreamSynchronize(stream));
+            if (ts.tail_used && overflow[1] != 0) {
+                // a late repeat had more pairs queued than the one-workgroup form takes: the batch again, a launch pair per repeat
+                if (getenv("WC_TEST_VERBOSE")) fprintf(stderr, "wisecondor_amd: batch repeated with a launch pair per late repeat\n");
+                ts.tree_pending = false;
+                ts.no_tail = true;
+                rc = test_batch_body(ctx, stream, ref, counts, Ns, threshold, min_ref_bins, repeats, min_effect, sel,
+                                     max_n, max_calls, results_z, results_r, results_cwz, calls, n_calls, asdef, lat_rounds);
+                ts.no_tail = false;
+                return rc;
+            }
             if (ts.tree_pending) {
                 // the tree kernel's status words arrived with this synchronize (run_stouffer queued the copy)
                 ts.tree_pending = false;
@@ -6589,6 +6625,15 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
                 WC_CHECK(h[4] <= ts.tree_seg_cap, WC_E_LIMIT, "stouffer: more than max_calls=%d segments per region", max_calls);
             }
             WC_CHECK(!*overflow, WC_E_LIMIT, "test: a sample has more than max_calls=%d calls", max_calls);
+            if (getenv("WC_TEST_VERBOSE") && ts.misc2.p && repeats > 0 && repeats < 16) {
+                // the (bin, sample) pairs every repeat had queued: [0] the first repeat's threshold hits (tiled kernel), [it] the pairs repeat it + 1 recomputed
+                int pc[18];
+                if (hipMemcpy(pc, ts.misc2.p, sizeof(int) * (repeats + 2), hipMemcpyDeviceToHost) == hipSuccess) {
+                    fprintf(stderr, "wisecondor_amd: pairs queued per repeat:");
+                    for (int q = 0; q <= repeats; ++q) fprintf(stderr, " %d", pc[q]);
+                    fprintf(stderr, "\n");
+                }
+            }
             if (getenv("WC_TEST_VERBOSE") && ts.sd_fail.p && ref->B <= 65536 && ctx->side) {
                 // how many samples the parallel stdDevAvg gave up on (the serial kernel computed them)
                 (void)hipStreamSynchronize(ctx->side);
