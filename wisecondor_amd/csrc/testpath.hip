@@ -6470,10 +6470,12 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
     ts.mark(2, stream);
     struct Joiner {   // asdef is copied out once the side stream's sum is done, on every exit path
         wc_ctx *c; hipStream_t s; double *dst; int64_t n; bool on;
-        ~Joiner() {
+        void now() {
             if (on && join_side(c, s) == WC_OK && dst)
                 (void)hipMemcpyAsync(dst, c->ts.sd_avg.p, sizeof(double) * n, hipMemcpyDeviceToDevice, s);
+            on = false;
         }
+        ~Joiner() { now(); }
     } joiner{ctx, stream, asdef, Ns, !lat};
     struct LatJoin {   // latency mode: asdef is written by the kernel itself; the side branch still has to rejoin
         wc_ctx *c; hipStream_t s; bool on;
@@ -6593,6 +6595,9 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
                            (const int *)ts.sd_fail.as<int>());
         int *overflow = (int *)ctx->pinned + 16;
         if (!lat) {
+            // the side stream rejoins and asdef is copied out IN FRONT of the synchronize: enqueued behind it (the
+            // destructor's place) they were one more host round trip -- 25 us of idle GPU -- at the end of every batch
+            joiner.now();
             WC_HIP(hipMemcpyAsync(overflow, ts.misc.p, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
             WC_HIP(hipStreamSynchronize(stream));
             if (ts.tail_used && overflow[1] != 0) {
