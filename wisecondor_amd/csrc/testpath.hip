@@ -5591,7 +5591,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     }
     if ((rc = ts.jobs_a.reserve(sizeof(Job) * job_cap))) return rc;
     if ((rc = ts.jobs_b.reserve(sizeof(Job) * job_cap))) return rc;
-    if ((rc = ts.job_cnt.reserve(sizeof(int) * 8))) return rc;
+    if ((rc = ts.job_cnt.reserve(sizeof(int) * 16))) return rc;
     if ((rc = ts.job_res.reserve(sizeof(Extreme) * job_cap))) return rc;
     if ((rc = ts.hot.reserve(sizeof(int) * 2 * job_cap))) return rc;
     if ((rc = ts.seg.reserve(sizeof(Seg) * seg_cap))) return rc;
@@ -5656,14 +5656,14 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     int *counters = ts.job_cnt.as<int>();  // [1] next jobs [2] hot [3] brute [4] segments
     int *hot = ts.hot.as<int>();
     int *brute = hot + job_cap;
-    if ((rc = ts.misc.reserve(sizeof(int) * 4))) return rc;
+    if ((rc = ts.job_cnt.reserve(sizeof(int) * 16))) return rc;
     if (fused)
         hipLaunchKernelGGL(k_lat_setup<256>, dim3((unsigned)n_regions), dim3(256), sizeof(double) * (max_n + 1), stream,
                            fused->zsrc, fused->rsrc, fused->nsrc, fused->str_i, fused->str_b, fused->B, fused->moff,
                            fused->goff, fused->m2g, fused->sel, fused->n_sel, fused->minref, fused->zc, fused->rc,
                            fused->gpos, fused->regions, ts.prefix.as<double>(), ts.reg_abs.as<double>(),
                            ts.reg_flag.as<int>(), ts.whole.as<double>(), fused->whole_copy, ts.jobs_a.as<Job>(), counters,
-                           ts.out_n.as<int>(), ts.misc.as<int>(), n_regions, ts.tail_used ? (const int *)ts.tail_flag : (const int *)nullptr);
+                           ts.out_n.as<int>(), (ts.job_cnt.as<int>() + 8), n_regions, ts.tail_used ? (const int *)ts.tail_flag : (const int *)nullptr);
     // Callers with call rows, regions up to CJ_MAXLEN bins, no -mineffectsize mask: the whole recursion of every region
     // in ONE launch (k_seg_walk), no host round trip.  WC_TEST_WALK=0: the paths it replaces (tree kernel up to
     // TREE_MAXLEN, host-driven rounds beyond).
@@ -5705,7 +5705,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     if (!fused)
     hipLaunchKernelGGL(k_region_prefix, dim3((unsigned)cdiv(n_regions, 4)), dim3(256), 0, stream, z_dev, regions_dev,
                        n_regions, ts.prefix.as<double>(), ts.reg_abs.as<double>(), ts.reg_flag.as<int>(), counters,
-                       ts.out_n.as<int>(), ts.misc.as<int>(), whot);
+                       ts.out_n.as<int>(), (ts.job_cnt.as<int>() + 8), whot);
     // The block tables: the walker's cell search, the quiet-job certificate (k_seg_quiet; measured -7 % per 250 kb batch
     // and -17 % per 50 kb batch on data where 10-40 % of the regions hold a call) and the bound-driven rounds read them
     block_tables();
@@ -5764,8 +5764,9 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
                            max_calls, tail->reg_calls, whot.count);
         ts.mark(11, stream);
         const int64_t bound = seg_cap;
-        WC_HIP(hipMemcpyAsync(h, counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
+        if (!tail->defer_status) WC_HIP(hipMemcpyAsync(h, counters, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
         if (tail->defer_status) {
+            // (the caller's ONE copy at the end of the batch brings the counters and the flag words behind them)
             // the caller looks at the counters after ITS synchronize: h[6] non-zero = the walk gave up on some
             // region, h[4] beyond the bound = more segments than k_call_post's grid covers; it then repeats the
             // batch with the host-driven rounds
@@ -6013,14 +6014,14 @@ int run_seg_lat(wc_ctx *ctx, const wc_reference *ref, const double *zsrc, const 
                            ts.rs_len);
     }
     if ((rc = ts.jobs_a.reserve(sizeof(Job) * (n_regions + 64)))) return rc;
-    if ((rc = ts.job_cnt.reserve(sizeof(int) * 8))) return rc;
+    if ((rc = ts.job_cnt.reserve(sizeof(int) * 16))) return rc;
     if ((rc = ts.seg.reserve(sizeof(Seg) * seg_cap))) return rc;
     if ((rc = ts.out_val.reserve(sizeof(double) * n_regions * max_calls))) return rc;
     if ((rc = ts.out_x.reserve(sizeof(int) * n_regions * max_calls))) return rc;
     if ((rc = ts.out_y.reserve(sizeof(int) * n_regions * max_calls))) return rc;
     if ((rc = ts.out_n.reserve(sizeof(int) * n_regions))) return rc;
     if ((rc = ts.whole.reserve(sizeof(double) * n_regions))) return rc;
-    if ((rc = ts.misc.reserve(sizeof(int) * 4))) return rc;
+    if ((rc = ts.job_cnt.reserve(sizeof(int) * 16))) return rc;
     const int64_t total = total_len + n_regions, nblk = cdiv(total, QB);
     if ((rc = ts.tmin.reserve(sizeof(double) * nblk))) return rc;
     if ((rc = ts.tmax.reserve(sizeof(double) * nblk))) return rc;
@@ -6030,7 +6031,7 @@ int run_seg_lat(wc_ctx *ctx, const wc_reference *ref, const double *zsrc, const 
                        (const int *)ref->m2g.as<int>(), (const int *)ts.sel.as<int>(), n_sel, (double)min_ref_bins,
                        ts.zc.as<double>(), ts.rc.as<double>(), ts.gpos.as<int>(), ts.regions.as<Region>(),
                        ts.prefix.as<double>(), ts.reg_abs.as<double>(), ts.reg_flag.as<int>(), ts.whole.as<double>(),
-                       whole_copy, ts.jobs_a.as<Job>(), counters, ts.out_n.as<int>(), ts.misc.as<int>(), n_regions);
+                       whole_copy, ts.jobs_a.as<Job>(), counters, ts.out_n.as<int>(), (ts.job_cnt.as<int>() + 8), n_regions);
     // the regions' value search with all row blocks in parallel (the general path's kernel, no
     // certificate); the tree kernel starts from its per-block extremes
     const int max_chunks = (int)std::max<int64_t>(1, cdiv((max_n + 1) / 2, ROWS_HALF));
@@ -6526,7 +6527,7 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
     if ((rc = ts.gpos.reserve(sizeof(int) * Ns * B))) return rc;
     if ((rc = ts.regions.reserve(sizeof(Region) * n_regions))) return rc;
     if ((rc = ts.effect.reserve(sizeof(double) * n_regions * max_calls * 5))) return rc;
-    if ((rc = ts.misc.reserve(sizeof(int) * 4))) return rc;
+    if ((rc = ts.job_cnt.reserve(sizeof(int) * 16))) return rc;
     if (lat) {
         if ((rc = ctx->ensure_pinned(256))) return rc;
         InflateRider inf{};
@@ -6577,7 +6578,7 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
         WC_HIP(hipMemcpyAsync(results_cwz, ts.whole.p, sizeof(double) * n_regions, hipMemcpyDeviceToDevice, stream));
     if ((rc = ctx->ensure_pinned(256))) return rc;
     if (calls && n_calls) {
-        // ts.misc (overflow flag) was cleared by k_region_prefix
+        // the overflow flag (counters + 8) was cleared by k_region_prefix
         if (ts.last_segs > 0)
             hipLaunchKernelGGL(k_call_post, dim3((unsigned)ts.last_segs), dim3(CP_THREADS), 0, stream,
                                (const Seg *)ts.seg.as<Seg>(), (int)ts.last_segs,
@@ -6586,19 +6587,21 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
         if (lat && (rc = join_side(ctx, stream))) return rc;      // the status words read k_sd_fast's flags
         if (!lat && n_sel <= 64)
             hipLaunchKernelGGL(k_assemble_batch, dim3((unsigned)Ns), dim3(64), 0, stream, (const double *)ts.effect.as<double>(),
-                               (const int *)ts.out_n.as<int>(), n_sel, max_calls, Ns, calls, n_calls, ts.misc.as<int>());
+                               (const int *)ts.out_n.as<int>(), n_sel, max_calls, Ns, calls, n_calls, (ts.job_cnt.as<int>() + 8));
         else
         hipLaunchKernelGGL(k_assemble_calls, dim3((unsigned)cdiv(Ns, 64)), dim3(64), 0, stream,   // latency mode: Ns <= 8, one workgroup
                            (const double *)ts.effect.as<double>(), (const int *)ts.out_n.as<int>(), n_sel, max_calls, Ns,
-                           calls, n_calls, ts.misc.as<int>(), lat ? (int *)ctx->pinned : (int *)nullptr,
+                           calls, n_calls, (ts.job_cnt.as<int>() + 8), lat ? (int *)ctx->pinned : (int *)nullptr,
                            (const int *)ts.job_cnt.as<int>(), (const int *)(ts.misc2.as<int>() + repeats + 1),
                            (const int *)ts.sd_fail.as<int>());
-        int *overflow = (int *)ctx->pinned + 16;
+        // batches: the segmentation's counters [0..7] and the flag words behind them ([8] a sample with more than max_calls
+        // calls, [9] the late repeats' overflow) come back in ONE copy
+        int *overflow = (int *)ctx->pinned + (lat ? 16 : 8);
         if (!lat) {
             // the side stream rejoins and asdef is copied out IN FRONT of the synchronize: enqueued behind it (the
             // destructor's place) they were one more host round trip -- 25 us of idle GPU -- at the end of every batch
             joiner.now();
-            WC_HIP(hipMemcpyAsync(overflow, ts.misc.p, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+            WC_HIP(hipMemcpyAsync(ctx->pinned, ts.job_cnt.p, 12 * sizeof(int), hipMemcpyDeviceToHost, stream));
             WC_HIP(hipStreamSynchronize(stream));
             if (ts.tail_used && overflow[1] != 0) {
                 // a late repeat had more pairs queued than the one-workgroup form takes: the batch again, a launch pair per repeat
