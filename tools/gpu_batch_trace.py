@@ -8,6 +8,8 @@ def short(n):
 # the last batch: from the last k_sample_totals on
 starts = [i for i, r in enumerate(rows) if "k_sample_totals" in r["Kernel_Name"]]
 seq = rows[starts[-2]:starts[-1]]
+cut = [i for i, r in enumerate(seq) if "at::native" in r["Kernel_Name"]]      # (the harness's own torch kernels behind the call)
+if cut: seq = seq[:cut[0]]
 t0 = int(seq[0]["Start_Timestamp"])
 last_end = {}
 print("batch span %.1f us, %d launches" % ((max(int(r["End_Timestamp"]) for r in seq) - t0) / 1e3, len(seq)))
