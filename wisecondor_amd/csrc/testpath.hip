@@ -5086,6 +5086,10 @@ __global__ __launch_bounds__(256, 4) void k_seg_walk(int *__restrict__ counters,
 // A kernel of its own: as the tail of k_seg_walk the radix selection returned wrong medians for about one row in a
 // thousand, differently from run to run (the selection alone, tools/micro/select_test.hip, is clean), see
 // EXPERIMENTS.md.
+// (2 304 workgroups, three times what is resident: a workgroup whose items are short is gone in a few microseconds and
+//  its slot goes to the next one, so that the long segments -- ~20 us each -- spread over the slots by themselves; with
+//  768 some workgroup always held two of them: 52 -> 38 us at 125 x 50 kb, 256 -> 216 us at 1 000 x 50 kb)
+constexpr int WALK_ROWS_GRID = 2304;
 __global__ __launch_bounds__(256) void k_walk_rows(const Seg *__restrict__ wsegs, const int *__restrict__ n_segs_dev,
                                                    int seg_cap,
                                                    const Region *__restrict__ regions, const double *__restrict__ ratio,
@@ -5759,7 +5763,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
                            (int)seg_cap, ts.out_n.as<int>(), work,
                            (tail->per_sample > 1 && n_regions % tail->per_sample == 0) ? tail->per_sample : 0,   // (125 x 50 kb: 287 -> 255 us)
                            whot);
-        hipLaunchKernelGGL(k_walk_rows, dim3(768), dim3(256), 0, stream, (const Seg *)ts.seg.as<Seg>(),
+        hipLaunchKernelGGL(k_walk_rows, dim3(WALK_ROWS_GRID), dim3(256), 0, stream, (const Seg *)ts.seg.as<Seg>(),
                            (const int *)(counters + 4), (int)seg_cap, regions_dev, tail->ratio, tail->gpos,
                            max_calls, tail->reg_calls, whot.count);
         ts.mark(11, stream);
