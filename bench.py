@@ -837,7 +837,7 @@ def main():
     bins = np.ascontiguousarray(inp["masked_bins"])
     pairs = float(B) * B - float((bins.astype(np.float64) ** 2).sum())   # ordered cross-chromosome pairs
     X = torch.from_numpy(np.ascontiguousarray(corrected)).to(dev)
-    job = distributed.NewrefJob(ctx, X, bins, k, order, rank=rank, world=world, passes=args.steps + args.warmup)
+    job = distributed.NewrefJob(ctx, X, bins, k, order, rank=rank, world=world, passes=2 * args.steps + args.warmup + 1)
     tdev = dev if args.backend == "nccl" else torch.device("cpu")
 
     def sync_all():
@@ -871,22 +871,26 @@ def main():
                  "ms": float(np.mean([r[i]["ms"] for r in runs if i < len(r)]))} for i in range(len(runs[0]))]
 
     # ------------------------------------------------------------ newref ----
-    for _ in range(max(1, args.warmup)):
-        idx, dst = job.run()                          # (the first pass of a multi-rank job also measures the shard mode)
+    idx, dst = job.run()                              # (the first pass of a multi-rank job also measures the shard mode)
     sync_all()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        idx, dst = job.run()                          # the timed region: K plain passes, nothing else
-    sync_all()
-    t_newref = max_over_ranks(time.perf_counter() - t0)
-    # the same K passes again with events between the stages (on the launch stream): kernel times
-    # for the roofline objects; the events cost ~15 % of a 0.2 ms pass, so they stay out of `value`
+    # K passes with events between the stages (on the launch stream): kernel times for the roofline objects; the events
+    # cost ~15 % of a 0.2 ms pass, so they stay out of `value`.  They run FIRST (round 6; behind the timed region
+    # before): the chip's clocks settle over the first ~15 ms of load (consecutive groups of 20
+    # passes read 0.212, 0.208, 0.203, 0.198 ms on a GPU that has just been idle), and this leg is load like any other.
     marks, comms = [], []
     for s in range(args.steps):
         idx, dst = job.run(timing=True)
         marks.append(job.last_marks)
         comms.append(job.last_comm)
     sync_all()
+    for _ in range(max(1, args.warmup)):              # W untimed passes ...
+        idx, dst = job.run()
+    sync_all()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        idx, dst = job.run()                          # ... then the timed region: K plain passes, nothing else
+    sync_all()
+    t_newref = max_over_ranks(time.perf_counter() - t0)
     stages = mean_stages(job, marks)             # every interval booked under the stage that ended it (bands add up)
     collectives = mean_collectives(job, comms)
     gram_ms = stages.get("collected")
@@ -1326,7 +1330,8 @@ def main():
             "dtype_detail": "f16 MFMA (one product per multiply, f32 accumulate, per-row representation error in the "
                             "bounds) distance bounds + f64 exact re-score",
             "timing": "value / ms_per_step: %d plain passes between two synchronizes; stages_ms and the roofline "
-                      "kernel times: %d further passes with events between the stages" % (args.steps, args.steps),
+                      "kernel times: %d passes with events between the stages, run BEFORE the %d warm-up passes and the timed "
+                      "region (they are load like any other: the clocks settle over the first ~15 ms)" % (args.steps, args.steps, args.warmup),
             "data": "synthetic",
             "config": {"workload": "%s: newref %d samples x %d kb bins (%d masked bins, refsize %d), "
                                    "then batched test of %d samples/GPU at the same bin size"
