@@ -198,3 +198,24 @@ def test_the_walker_gives_the_same_calls_on_every_call(wt, case, monkeypatch):
             cb = np.asarray(b["results_calls"], dtype=np.float64).reshape(-1, 5)
             assert ca.shape == cb.shape and same_bits(ca, cb), i
             assert same_bits(a["results_cwz"], b["results_cwz"]), i
+
+
+def test_the_early_start_list_is_per_batch(wt, case, monkeypatch):
+    """k_seg_walk starts the regions k_region_prefix has listed (an aberration of some length) first; the list's count is
+    reset by the launch behind the walk and an entry only counts if THIS batch's index points back at it.  Different
+    batches alternating on one context -- the whole 125 samples, a third of them in another order, the quiet ones
+    alone -- give the calls of the same batches without the list (WC_TEST_WALK_HOT=0), bit for bit, every time."""
+    thr = case["threshold"]
+    tests = case["tests"]
+    batches = [tests, tests[80:40:-1], tests[::5], tests[:33]]
+    monkeypatch.setenv("WC_TEST_WALK_HOT", "0")
+    want = [wt.test_batch(case["reference"], b, thr) for b in batches]
+    monkeypatch.delenv("WC_TEST_WALK_HOT")
+    for rnd in range(3):
+        for q in (0, 1, 2, 3, 1, 0, 3, 2):
+            got = wt.test_batch(case["reference"], batches[q], thr)
+            for i, (a, b) in enumerate(zip(want[q], got)):
+                ca = np.asarray(a["results_calls"], dtype=np.float64).reshape(-1, 5)
+                cb = np.asarray(b["results_calls"], dtype=np.float64).reshape(-1, 5)
+                assert ca.shape == cb.shape and same_bits(ca, cb), (rnd, q, i)
+                assert same_bits(a["results_cwz"], b["results_cwz"]), (rnd, q, i)
