@@ -1542,10 +1542,17 @@ struct SdShared {
     long long sh_wA[16];
     int sh_wH0[16], sh_wH1[16], sh_wf[16], sh_wn[16];
 };
-template <int REG>
+// `stage` (REG == 0, sample-major input): 16 wave-private transposition buffers of 64 x 9 doubles.  A thread's elements
+// are contiguous in memory (55 of them at 50 kb), so a load instruction of the wave used to touch 64 different 128-byte
+// lines for 8 bytes each -- with sixteen waves in flight the 32 KB L1 kept none of them for the next of a thread's
+// eight loads: ~8 000 line requests per wave and walk.  Now the wave's lanes 8 g .. 8 g + 7 fetch the eight consecutive
+// elements of ONE thread (trip i: thread 8 i + g of the wave): eight 64-byte runs per instruction, every byte used,
+// and the values go to their owners through the buffer.
+constexpr int SD_STAGE_DOUBLES = 16 * 64 * 9;
+template <int REG, bool STAGE = false>
 __device__ inline void sd_fast_block(const int64_t i, SdShared *sm, const double *__restrict__ sdT, int64_t B, int64_t Ns,
                                      double *__restrict__ out, int *__restrict__ fail, double *__restrict__ out2,
-                                     int64_t sb, int64_t si) {     // element (bin b, sample i) at sdT[b * sb + i * si]
+                                     int64_t sb, int64_t si, double *stage = nullptr) {     // element (bin b, sample i) at sdT[b * sb + i * si]
     constexpr int PER_MAX = 64;                      // elements per thread (B <= 65536)
     // the workgroup's scratch (caller-provided LDS: static in k_sd_fast, the dynamic region in k_seg_tree)
     double *sh_p = sm->sh_p;
@@ -1566,7 +1573,37 @@ __device__ inline void sd_fast_block(const int64_t i, SdShared *sm, const double
     const int64_t lo = (int64_t)tid * per, hi = lo + per < B ? lo + per : B;
     constexpr int NREG = REG > 0 ? REG : 1;
     double xr[NREG];
-    if (REG > 0) {
+    // STAGE: the thread's elements e0 .. e0 + 7 through the wave's transposition buffer (see SD_STAGE_DOUBLES; sb == 1)
+    auto load8 = [&](const int e0, double (&b8)[8]) {
+        const int lane = tid & 63, g = lane >> 3, u_ = lane & 7;
+        double *buf = stage + (tid >> 6) * (64 * 9);
+        const double *base = sdT + i * si;
+        const int64_t wave_lo = (int64_t)(tid & ~63) * per;          // first element of the wave's first thread
+        double got[8];
+#pragma unroll
+        for (int t8 = 0; t8 < 8; ++t8) {                             // trip t8: the run of the wave's thread 8 t8 + g
+            const int64_t e = wave_lo + (int64_t)(8 * t8 + g) * per + e0 + u_;
+            got[t8] = (e0 + u_ < per && e < B) ? base[e] : 0.0;
+        }
+#pragma unroll
+        for (int t8 = 0; t8 < 8; ++t8) buf[(8 * t8 + g) * 9 + u_] = got[t8];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) b8[u] = buf[lane * 9 + u];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                             // (the buffer is rewritten by the next call)
+    };
+    if constexpr (REG > 0 && STAGE) {
+#pragma unroll
+        for (int r = 0; r < (NREG + 7) / 8; ++r) {
+            double b8[8];
+            load8(8 * r, b8);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (8 * r + u < NREG) xr[8 * r + u] = b8[u];
+        }
+    } else if (REG > 0) {
 #pragma unroll
         for (int e = 0; e < NREG; ++e) xr[e] = lo + e < hi ? sdT[(lo + e) * sb + i * si] : 0.0;
     }
@@ -1579,6 +1616,14 @@ __device__ inline void sd_fast_block(const int64_t i, SdShared *sm, const double
 #pragma unroll
             for (int e = 0; e < NREG; ++e)           // (a predicate, not a break: the loop unrolls, xr[] stays in registers)
                 if (e < n_mine) f(xr[e]);
+        } else if constexpr (STAGE) {
+            for (int e0 = 0; e0 < per; e0 += 8) {                    // (the same trips in every lane; sb == 1: the caller checks)
+                double b8[8];
+                load8(e0, b8);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (e0 + u < n_mine) f(b8[u]);
+            }
         } else {
             for (int e0 = 0; e0 < n_mine; e0 += 8) {
                 double b8[8];
@@ -1786,12 +1831,17 @@ __device__ inline void sd_fast_block(const int64_t i, SdShared *sm, const double
     }
 }
 
-template <int REG>
+template <int REG, bool STAGE = false>
 __global__ __launch_bounds__(1024) void k_sd_fast(const double *__restrict__ sdT, int64_t B, int64_t Ns,
                                                   double *__restrict__ out, int *__restrict__ fail,
                                                   double *__restrict__ out2, int64_t sb, int64_t si) {
     __shared__ SdShared sm;
-    sd_fast_block<REG>(blockIdx.x, &sm, sdT, B, Ns, out, fail, out2, sb, si);
+    if constexpr (STAGE) {
+        __shared__ double stage[SD_STAGE_DOUBLES];
+        sd_fast_block<REG, true>(blockIdx.x, &sm, sdT, B, Ns, out, fail, out2, sb, si, stage);
+    } else {
+        sd_fast_block<REG>(blockIdx.x, &sm, sdT, B, Ns, out, fail, out2, sb, si);
+    }
 }
 
 // what the latency mode appends to another kernel's grid (k_seg_tree): `blocks` workgroups, one per sample
@@ -1807,10 +1857,18 @@ struct SdRider {
 void launch_sd_fast(hipStream_t stream, const double *sdT, int64_t B, int64_t Ns, double *out, int *fail, double *out2,
                     int64_t sb, int64_t si) {
     const int64_t per = (B + 1023) / 1024;
-    if (per <= 12)
+    // (a sample's values contiguous -- every batch: the cooperative loads; WC_TEST_SD_STAGE=0: a lane per run, round 5's form)
+    const bool staged = sb == 1 && !(getenv("WC_TEST_SD_STAGE") && getenv("WC_TEST_SD_STAGE")[0] == '0');
+    if (per <= 12 && staged)
+        hipLaunchKernelGGL((k_sd_fast<12, true>), dim3((unsigned)Ns), dim3(1024), 0, stream, sdT, B, Ns, out, fail, out2, sb, si);
+    else if (per <= 12)
         hipLaunchKernelGGL(k_sd_fast<12>, dim3((unsigned)Ns), dim3(1024), 0, stream, sdT, B, Ns, out, fail, out2, sb, si);
+    else if (per <= 24 && staged)
+        hipLaunchKernelGGL((k_sd_fast<24, true>), dim3((unsigned)Ns), dim3(1024), 0, stream, sdT, B, Ns, out, fail, out2, sb, si);
     else if (per <= 24)
         hipLaunchKernelGGL(k_sd_fast<24>, dim3((unsigned)Ns), dim3(1024), 0, stream, sdT, B, Ns, out, fail, out2, sb, si);
+    else if (staged)
+        hipLaunchKernelGGL((k_sd_fast<0, true>), dim3((unsigned)Ns), dim3(1024), 0, stream, sdT, B, Ns, out, fail, out2, sb, si);
     else
         hipLaunchKernelGGL(k_sd_fast<0>, dim3((unsigned)Ns), dim3(1024), 0, stream, sdT, B, Ns, out, fail, out2, sb, si);
 }
