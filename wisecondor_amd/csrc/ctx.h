@@ -105,6 +105,9 @@ struct wc_ctx {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool side_pending = false;
+    hipStream_t side2 = nullptr;           // big batches: the inflated arrays and the whole-region values beside stdDevAvg, not behind it
+    hipEvent_t ev_join2 = nullptr;
+    bool side2_pending = false;
     bool side_fresh = false;               // the side stream was forked from the launch stream and NOTHING has been enqueued on the
                                            // launch stream since: the next side_begin needs no second event record + wait
     // small pinned host block for count read-backs (a pageable destination costs a staged copy)
@@ -126,6 +129,8 @@ struct wc_ctx {
         WC_HIP(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio_least));
         WC_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         WC_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        WC_HIP(hipStreamCreateWithPriority(&side2, hipStreamNonBlocking, prio_least));
+        WC_HIP(hipEventCreateWithFlags(&ev_join2, hipEventDisableTiming));
         return WC_OK;
     }
 

@@ -52,6 +52,8 @@ void wc_destroy(wc_ctx *ctx) {
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->side2) (void)hipStreamDestroy(ctx->side2);
+    if (ctx->ev_join2) (void)hipEventDestroy(ctx->ev_join2);
     for (hipEvent_t e : ctx->ts.prof_ev) (void)hipEventDestroy(e);
     if (ctx->ts.lat_exec) (void)hipGraphExecDestroy(ctx->ts.lat_exec);
     if (ctx->lat_stream) (void)hipStreamDestroy(ctx->lat_stream);

@@ -5562,18 +5562,32 @@ int run_repeat(wc_ctx *ctx, const wc_reference *ref, const double *data_dev, int
 // Output-only work of a batch (stdDevAvg, the inflated result arrays, the whole-region values) runs on the
 // context's side stream under the segmentation: side_begin makes the side stream wait for what `stream` has
 // enqueued so far, side_end marks the point join_side waits for.
-static int side_begin(wc_ctx *ctx, hipStream_t stream) {
+// second: the SECOND side stream.  In a big batch stdDevAvg (k_sd_fast: a 1 024-thread workgroup per sample) is as long
+// as the whole segmentation -- 1.8 ms of a 1 000 x 50 kb batch -- and the inflated outputs and whole-region values
+// behind it on one stream ended 0.5 ms after the launch stream (kernel trace, round 6): they get a stream of their own.
+static bool side_second(int64_t n_samples) {
+    static const int from = getenv("WC_TEST_SIDE2") ? atoi(getenv("WC_TEST_SIDE2")) : 768;   // (0: never; from 256 on: 256 x 50 kb and 512 x 250 kb are 1 % slower with it)
+    return from > 0 && n_samples >= from;
+}
+static int side_begin(wc_ctx *ctx, hipStream_t stream, bool second = false) {
     int rc;
     if ((rc = ctx->ensure_side_stream())) return rc;
+    hipStream_t s = second ? ctx->side2 : ctx->side;
     if (ctx->side_fresh) {             // forked a moment ago, nothing enqueued on `stream` since: one fork serves both
         ctx->side_fresh = false;       // (an event record on the launch stream costs it ~10 us: kernel trace, round 6)
+        if (second) WC_HIP(hipStreamWaitEvent(s, ctx->ev_fork, 0));
         return WC_OK;
     }
     WC_HIP(hipEventRecord(ctx->ev_fork, stream));
-    WC_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+    WC_HIP(hipStreamWaitEvent(s, ctx->ev_fork, 0));
     return WC_OK;
 }
-static int side_end(wc_ctx *ctx) {
+static int side_end(wc_ctx *ctx, bool second = false) {
+    if (second) {
+        WC_HIP(hipEventRecord(ctx->ev_join2, ctx->side2));
+        ctx->side2_pending = true;
+        return WC_OK;
+    }
     WC_HIP(hipEventRecord(ctx->ev_join, ctx->side));
     ctx->side_pending = true;
     return WC_OK;
@@ -5585,6 +5599,10 @@ int join_side(wc_ctx *ctx, hipStream_t stream) {
     if (ctx->side_pending) {
         WC_HIP(hipStreamWaitEvent(stream, ctx->ev_join, 0));
         ctx->side_pending = false;
+    }
+    if (ctx->side2_pending) {
+        WC_HIP(hipStreamWaitEvent(stream, ctx->ev_join2, 0));
+        ctx->side2_pending = false;
     }
     return WC_OK;
 }
@@ -5776,6 +5794,7 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
     // k_init_jobs stays off its path.  (The whole-region values by the walker's own workgroups -- its last wave before
     // the walk starts -- were measured: k_seg_walk 265 -> 385 us at 125 x 50 kb, a 4 700-bin pairwise tree walked by
     // one wave costs ~40 us; they stay a side-stream launch.)
+    bool whole_second = false;
     auto whole_and_jobs = [&](const bool jobs_too) -> int {
         // the whole-region values are an output only -> side stream (one wave per region walks
         // the region in numpy's order: 0.1 ms at 50 kb that the search does not have to wait for)
@@ -5785,13 +5804,16 @@ int run_stouffer(wc_ctx *ctx, const double *z_dev, const Region *regions_dev, in
         if (tail && tail->cwz_out && !bits) {
             // (a second side stream for this launch alone was measured: it then runs beside the walk -- 180 us instead
             //  of 105, the walk 277 instead of 267, 1 000 x 50 kb 7.69 instead of 7.34 ms; one side stream)
-            if ((rc2 = side_begin(ctx, stream))) return rc2;
-            ws = ctx->side;
+            //  (big batches: the second side stream, see side_second)
+            const bool second = side_second(tail->per_sample > 0 ? n_regions / tail->per_sample : 0);
+            if ((rc2 = side_begin(ctx, stream, second))) return rc2;
+            ws = second ? ctx->side2 : ctx->side;
             wcopy = tail->cwz_out;
+            whole_second = second;
         }
         hipLaunchKernelGGL(k_region_whole, dim3((unsigned)cdiv(n_regions, 4)), dim3(256), 0, ws, z_dev, regions_dev,
                            n_regions, bits, bit_off, ts.whole.as<double>(), wcopy);
-        if (ws != stream && (rc2 = side_end(ctx))) return rc2;
+        if (ws != stream && (rc2 = side_end(ctx, whole_second))) return rc2;
         if (jobs_too)
             hipLaunchKernelGGL(k_init_jobs, dim3((unsigned)cdiv(n_regions, 256)), dim3(256), 0, stream, regions_dev, n_regions,
                                ts.jobs_a.as<Job>(), counters);
@@ -6569,13 +6591,14 @@ static int test_batch_body(wc_ctx *ctx, hipStream_t stream, const wc_reference *
         dim3 g((unsigned)cdiv(ref->Btot, 256), (unsigned)Ns);
         // a batch: the inflated outputs feed nothing downstream -> side stream, under the segmentation
         hipStream_t is = stream;
+        const bool second = side_second(Ns);
         if (!lat && Ns > 8) {
-            if ((rc = side_begin(ctx, stream))) return rc;
-            is = ctx->side;
+            if ((rc = side_begin(ctx, stream, second))) return rc;
+            is = second ? ctx->side2 : ctx->side;
         }
         hipLaunchKernelGGL(k_inflate, g, dim3(256), 0, is, zsrc, rsrc, nsrc, B, ref->Btot,
                            (const int *)ref->g2m.as<int>(), (double)min_ref_bins, results_z, results_r, str_i, str_b);
-        if (is != stream && (rc = side_end(ctx))) return rc;
+        if (is != stream && (rc = side_end(ctx, second))) return rc;
     }
     ctx->side_fresh = false;      // (whatever follows on the launch stream is not covered by that fork)
     if (n_sel == 0) {      // nothing to segment: no calls (otherwise k_assemble_calls writes every n_calls)
