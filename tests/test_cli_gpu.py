@@ -294,7 +294,9 @@ def test_bench_line_is_complete_on_one_gpu(tmp_path):
         one, two = leg["one_batch_in_flight"], leg["pipelined"]
         assert one["ms_per_batch"] > 0 and two["ms_per_batch"] > 0 and two["batches_timed"] >= 8
         assert leg["ms_per_batch"] == one["ms_per_batch"] and leg["value"] == one["value"]
-        assert 0 < leg["roofline"]["algorithmic_fp64_frac"] < 1.0
+        # (EVERY window x 4 operations over the batch time against the float64 peak: above 1 since the 50 kb batch takes
+        #  less than a millisecond -- the search is faster than evaluating all windows at the peak would be)
+        assert 0 < leg["roofline"]["algorithmic_fp64_frac"] < 4.0
     assert test["whole_job_1000_samples"]["samples_per_s"] > test["value"] * 0.8       # the big call amortises the fixed costs
     assert set(line["stages_ms"]) >= {"prepared", "thresholds", "collected", "picked", "rescored", "finished"}
     assert line["multi_rank"] is None
