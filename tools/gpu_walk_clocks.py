@@ -23,6 +23,8 @@ lib, ctx = _lib.load(), _lib.context(0)
 for _ in range(3):
     tb.run()
 a = np.zeros(64, dtype=np.uint64); b = np.zeros(64, dtype=np.uint64)
+before = np.zeros(64 + 8192 + 16384, dtype=np.uint64)
+_lib.check(lib.wc_debug_times(ctx, -7, _lib.ptr(before)))      # (stamps of workgroups that leave at once stay from earlier runs)
 _lib.check(lib.wc_debug_times(ctx, 0, _lib.ptr(a)))
 tb.run()
 torch.cuda.synchronize()
@@ -42,10 +44,10 @@ print("total %.0f ticks per region walk; loud cells per range: 128 x 128 %.1f, 3
 # the workgroups' lives (100 MHz wall clock): how full the 1 024 slots are over the kernel's span
 big = np.zeros(64 + 8192 + 16384, dtype=np.uint64)
 _lib.check(lib.wc_debug_times(ctx, -7, _lib.ptr(big)))
-n_wg = min(int(wgs), 4096)
+n_wg = 4096
 st = big[64:64 + 2 * n_wg:2].astype(np.float64); en = big[65:65 + 2 * n_wg:2].astype(np.float64)
 ok = (st > 0) & (en >= st)
-ok &= st > en.max() - 200000      # (stamps of earlier runs stay where a workgroup left at once)
+ok &= big[64:64 + 2 * n_wg:2] != before[64:64 + 2 * n_wg:2]      # (only the workgroups that ran in THIS call)
 st, en = st[ok], en[ok]
 t0 = st.min(); span = en.max() - t0
 print("workgroups %d: span %.1f us, sum of lives %.0f us (= %.0f slots busy on average), longest life %.1f us, mean %.1f us" % (
